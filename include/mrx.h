@@ -1,0 +1,161 @@
+/*
+ * mrx.h -- C ABI of the MI355X batch regex matcher (libmrx_hip.so).
+ *
+ * Drop-in boundary for the byte-scanning hot path of msaelices/mojo-regex.
+ * The reference has no FFI; the seams this ABI replaces are its two Mojo traits
+ * and the module functions built on them (all paths relative to the reference):
+ *
+ *   Engine        src/regex/engine.mojo:4-37      match_first / match_all
+ *   RegexMatcher  src/regex/matcher.mojo:181-209  match_first / match_all (+ match_next)
+ *   module API    src/regex/matcher.mojo:1325-1415 (search, findall, split, match_first)
+ *                 src/regex/matcher.mojo:1857-1917 (sub)
+ *   CompiledRegex src/regex/matcher.mojo:929-1163  (compile once, match many)
+ *
+ * The reference matches ONE text per call on the CPU.  This library matches a
+ * BATCH of texts per call on the GPU (one wavefront lane per text) and returns,
+ * for every text, exactly what the reference call returns for it: byte offsets,
+ * half-open [start, end), leftmost start / longest end, restart-per-position
+ * search (src/regex/dfa.mojo:1875-2130).
+ *
+ * Conventions (mirroring SURVEY.md 8(b)):
+ *   - Ownership: the caller owns every input and output buffer; the library owns
+ *     the opaque compiled handle until mrx_free().  A handle is immutable after
+ *     mrx_compile(), so concurrent batch calls on one handle are safe.
+ *   - Errors: integer status; mrx_last_error() gives the message of the last
+ *     failing call on this thread.  Pattern syntax errors carry the reference's
+ *     own message text (src/regex/lexer.mojo:150-152, parser.mojo:224-237,340,399).
+ *     Matching never fails on data: "no match" is start = end = -1 / count 0.
+ *   - Text is raw bytes (no UTF-8 awareness), as in the reference (all tables
+ *     are 256 wide, src/regex/dfa.mojo:215-254).
+ *   - Span offsets are int32 and relative to the start of each text (texts up to
+ *     2 GiB - 1); batch offsets are int64.
+ *   - Batch layout: `data` holds the texts back to back, text i occupies
+ *     data[offsets[i] .. offsets[i+1]).  The *_strided entry points take texts
+ *     at a fixed pitch instead: text i starts at data + i*stride and has length
+ *     lens[i] (or `len` for all i when lens == NULL); stride % 16 == 0 and data
+ *     16-byte aligned select the streaming kernel.
+ *   - Pointers named d_* are DEVICE pointers (HBM); everything else is host
+ *     memory.  `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *     The *_dev entry points enqueue work and return without synchronising
+ *     unless they have to report a total (documented per function).
+ *   - No CPU fallback exists: without a usable HIP device every matching entry
+ *     point fails with MRX_E_NO_DEVICE.
+ */
+#ifndef MRX_H
+#define MRX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mrx_handle mrx_handle;
+
+enum {
+  MRX_OK = 0,
+  MRX_E_SYNTAX = 1,       /* the reference's parser raises on this pattern          */
+  MRX_E_UNSUPPORTED = 2,  /* reference routes this pattern/op to an engine outside  */
+                          /* the hot path (backtracking NFA, OnePass): see message  */
+  MRX_E_NO_DEVICE = 3,    /* no HIP device / HIP runtime error                      */
+  MRX_E_CAPACITY = 4,     /* output buffer too small; *total holds the need         */
+  MRX_E_ARGUMENT = 5
+};
+
+/* ---- compile (replaces CompiledRegex(pattern), matcher.mojo:964-978) ---------- */
+int mrx_compile(const char* pattern, size_t pattern_len, mrx_handle** out);
+void mrx_free(mrx_handle* h);
+const char* mrx_last_error(void);
+/* HybridMatcher.get_engine_type(), matcher.mojo:900-918: "DFA", "NFA", "+Prefilter"... */
+const char* mrx_engine_type(const mrx_handle* h);
+/* CompiledRegex.get_stats(), matcher.mojo:1139-1163 */
+const char* mrx_stats(const mrx_handle* h);
+/* Text dump of the compiled tables (states, transitions, flags, kernel plan).
+ * Returns the number of bytes needed (excluding NUL); writes at most cap. */
+size_t mrx_describe(const mrx_handle* h, char* buf, size_t cap);
+/* number of capture groups usable by mrx_captures_* / group references in
+ * mrx_sub_* (fixed-width form, matcher.mojo:1002-1035); 0 if none */
+int mrx_num_groups(const mrx_handle* h);
+
+/* ---- device-resident batches (the measured path) --------------------------- */
+/* regex.match_first(pattern, text), matcher.mojo:1396-1415: anchored at 0.
+ * d_start[i] / d_end[i] = span or -1/-1. */
+int mrx_match_first_dev(const mrx_handle* h, const uint8_t* d_data,
+                        const int64_t* d_offsets, int64_t n,
+                        int32_t* d_start, int32_t* d_end, void* stream);
+/* regex.search(pattern, text), matcher.mojo:1325-1338 (= match_next(text, 0)). */
+int mrx_search_dev(const mrx_handle* h, const uint8_t* d_data,
+                   const int64_t* d_offsets, int64_t n,
+                   int32_t* d_start, int32_t* d_end, void* stream);
+/* CompiledRegex.is_match(text, 0), matcher.mojo:1103-1115 (DFAEngine.is_match
+ * quirk included, dfa.mojo:1815-1849).  d_flag[i] = 0/1. */
+int mrx_is_match_dev(const mrx_handle* h, const uint8_t* d_data,
+                     const int64_t* d_offsets, int64_t n, uint8_t* d_flag,
+                     void* stream);
+/* regex.findall(pattern, text), matcher.mojo:1341-1354.
+ * d_counts_prefix[n+1]: exclusive prefix sum of matches per text (CSR);
+ * d_spans[2*k], d_spans[2*k+1] = start, end of match k (text-relative), in text
+ * order then match order.  span_cap = capacity of d_spans in spans.
+ * Synchronises the stream once to return *total; MRX_E_CAPACITY if
+ * *total > span_cap (nothing written to d_spans beyond capacity). */
+int mrx_findall_dev(const mrx_handle* h, const uint8_t* d_data,
+                    const int64_t* d_offsets, int64_t n,
+                    int64_t* d_counts_prefix, int32_t* d_spans, int64_t span_cap,
+                    int64_t* total, void* stream);
+/* Same, texts at a fixed pitch (see header comment).  d_lens may be NULL. */
+int mrx_findall_strided_dev(const mrx_handle* h, const uint8_t* d_data,
+                            int64_t stride, const int32_t* d_lens, int32_t len,
+                            int64_t n, int64_t* d_counts_prefix, int32_t* d_spans,
+                            int64_t span_cap, int64_t* total, void* stream);
+/* Scan only: matches per text and nothing else (no span output). */
+int mrx_count_dev(const mrx_handle* h, const uint8_t* d_data,
+                  const int64_t* d_offsets, int64_t n, int32_t* d_counts,
+                  void* stream);
+/* search + capture groups, in the order NFAEngine._match_group appends them
+ * (src/regex/nfa.mojo:1057-1103): groups 1..g, then group 0 (whole match).
+ * d_spans[(i*(g+1) + k)*2 + {0,1}]; -1 when text i has no match.
+ * Only the fixed-width (\d{N}) group form is on the hot path. */
+int mrx_captures_dev(const mrx_handle* h, const uint8_t* d_data,
+                     const int64_t* d_offsets, int64_t n, int32_t* d_spans,
+                     void* stream);
+/* regex.sub(pattern, repl, text, count), matcher.mojo:1679-1854.
+ * d_out_offsets[n+1] (CSR of output bytes), d_out_data (capacity out_cap bytes).
+ * Synchronises once to return *total_bytes; MRX_E_CAPACITY if it exceeds out_cap. */
+int mrx_sub_dev(const mrx_handle* h, const char* repl, size_t repl_len, int64_t count,
+                const uint8_t* d_data, const int64_t* d_offsets, int64_t n,
+                int64_t* d_out_offsets, uint8_t* d_out_data, int64_t out_cap,
+                int64_t* total_bytes, void* stream);
+
+/* ---- host-buffer convenience wrappers (copy in, run, copy out) -------------- */
+int mrx_match_first_batch(const mrx_handle* h, const uint8_t* data,
+                          const int64_t* offsets, int64_t n, int32_t* start,
+                          int32_t* end);
+int mrx_search_batch(const mrx_handle* h, const uint8_t* data, const int64_t* offsets,
+                     int64_t n, int32_t* start, int32_t* end);
+int mrx_is_match_batch(const mrx_handle* h, const uint8_t* data, const int64_t* offsets,
+                       int64_t n, uint8_t* flag);
+int mrx_findall_batch(const mrx_handle* h, const uint8_t* data, const int64_t* offsets,
+                      int64_t n, int64_t* counts_prefix, int32_t* spans,
+                      int64_t span_cap, int64_t* total);
+int mrx_captures_batch(const mrx_handle* h, const uint8_t* data, const int64_t* offsets,
+                       int64_t n, int32_t* spans);
+int mrx_sub_batch(const mrx_handle* h, const char* repl, size_t repl_len, int64_t count,
+                  const uint8_t* data, const int64_t* offsets, int64_t n,
+                  int64_t* out_offsets, uint8_t* out_data, int64_t out_cap,
+                  int64_t* total_bytes);
+
+/* ---- measurement hooks -------------------------------------------------------- */
+/* Average duration (ms) of the dominant scan kernel over the launches made by
+ * this thread since the last reset, measured with HIP events on the launch
+ * stream; launches = number of scan-kernel launches measured. */
+void mrx_timing_reset(void);
+void mrx_timing_enable(int on);
+double mrx_timing_scan_ms(int64_t* launches);
+const char* mrx_last_kernel_name(void);
+const char* mrx_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MRX_H */

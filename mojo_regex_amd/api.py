@@ -1,0 +1,401 @@
+"""ctypes binding of include/mrx.h plus the reference-shaped Python interface.
+
+See the package docstring for the mapping to src/regex/matcher.mojo.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_NAME = "libmrx_hip.so"
+_lib = None
+
+MRX_OK, MRX_E_SYNTAX, MRX_E_UNSUPPORTED, MRX_E_NO_DEVICE, MRX_E_CAPACITY, MRX_E_ARGUMENT = range(6)
+
+
+class MrxError(RuntimeError):
+    """Any failure reported by libmrx_hip.so."""
+
+
+class RegexSyntaxError(MrxError):
+    """The reference's lexer/parser raises on this pattern (same message)."""
+
+
+class UnsupportedPattern(MrxError):
+    """The reference routes this pattern/operation to an engine outside the hot
+    path this library implements (backtracking NFA, OnePass)."""
+
+
+def library_path() -> str:
+    return os.path.join(_HERE, _LIB_NAME)
+
+
+def load_library():
+    """Load libmrx_hip.so (built in-tree by __graft_entry__.build()).  Loud
+    failure if it is missing: there is no other implementation to fall back to."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise MrxError(
+            "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % path)
+    lib = C.CDLL(path)
+    H = C.c_void_p
+    u8p, i32p, i64p = C.c_void_p, C.c_void_p, C.c_void_p
+    sigs = {
+        "mrx_compile": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(H)]),
+        "mrx_free": (None, [H]),
+        "mrx_last_error": (C.c_char_p, []),
+        "mrx_engine_type": (C.c_char_p, [H]),
+        "mrx_stats": (C.c_char_p, [H]),
+        "mrx_describe": (C.c_size_t, [H, C.c_char_p, C.c_size_t]),
+        "mrx_num_groups": (C.c_int, [H]),
+        "mrx_match_first_dev": (C.c_int, [H, u8p, i64p, C.c_int64, i32p, i32p, C.c_void_p]),
+        "mrx_search_dev": (C.c_int, [H, u8p, i64p, C.c_int64, i32p, i32p, C.c_void_p]),
+        "mrx_is_match_dev": (C.c_int, [H, u8p, i64p, C.c_int64, u8p, C.c_void_p]),
+        "mrx_findall_dev": (C.c_int, [H, u8p, i64p, C.c_int64, i64p, i32p, C.c_int64,
+                                      C.POINTER(C.c_int64), C.c_void_p]),
+        "mrx_findall_strided_dev": (C.c_int, [H, u8p, C.c_int64, i32p, C.c_int32, C.c_int64, i64p,
+                                              i32p, C.c_int64, C.POINTER(C.c_int64), C.c_void_p]),
+        "mrx_count_dev": (C.c_int, [H, u8p, i64p, C.c_int64, i32p, C.c_void_p]),
+        "mrx_captures_dev": (C.c_int, [H, u8p, i64p, C.c_int64, i32p, C.c_void_p]),
+        "mrx_sub_dev": (C.c_int, [H, C.c_char_p, C.c_size_t, C.c_int64, u8p, i64p, C.c_int64, i64p,
+                                  u8p, C.c_int64, C.POINTER(C.c_int64), C.c_void_p]),
+        "mrx_match_first_batch": (C.c_int, [H, u8p, i64p, C.c_int64, i32p, i32p]),
+        "mrx_search_batch": (C.c_int, [H, u8p, i64p, C.c_int64, i32p, i32p]),
+        "mrx_is_match_batch": (C.c_int, [H, u8p, i64p, C.c_int64, u8p]),
+        "mrx_findall_batch": (C.c_int, [H, u8p, i64p, C.c_int64, i64p, i32p, C.c_int64,
+                                        C.POINTER(C.c_int64)]),
+        "mrx_captures_batch": (C.c_int, [H, u8p, i64p, C.c_int64, i32p]),
+        "mrx_sub_batch": (C.c_int, [H, C.c_char_p, C.c_size_t, C.c_int64, u8p, i64p, C.c_int64, i64p,
+                                    u8p, C.c_int64, C.POINTER(C.c_int64)]),
+        "mrx_timing_reset": (None, []),
+        "mrx_timing_enable": (None, [C.c_int]),
+        "mrx_timing_scan_ms": (C.c_double, [C.POINTER(C.c_int64)]),
+        "mrx_last_kernel_name": (C.c_char_p, []),
+        "mrx_version": (C.c_char_p, []),
+    }
+    for name, (res, args) in sigs.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = [
+    "mrx_compile", "mrx_free", "mrx_last_error", "mrx_engine_type", "mrx_stats", "mrx_describe",
+    "mrx_num_groups", "mrx_match_first_dev", "mrx_search_dev", "mrx_is_match_dev",
+    "mrx_findall_dev", "mrx_findall_strided_dev", "mrx_count_dev", "mrx_captures_dev",
+    "mrx_sub_dev", "mrx_match_first_batch", "mrx_search_batch", "mrx_is_match_batch",
+    "mrx_findall_batch", "mrx_captures_batch", "mrx_sub_batch", "mrx_timing_reset",
+    "mrx_timing_enable", "mrx_timing_scan_ms", "mrx_last_kernel_name", "mrx_version",
+]
+
+
+def _b(x) -> bytes:
+    if isinstance(x, str):
+        return x.encode("utf-8")
+    return bytes(x)
+
+
+def _check(rc: int):
+    if rc == MRX_OK:
+        return
+    msg = load_library().mrx_last_error().decode("utf-8", "replace")
+    if rc == MRX_E_SYNTAX:
+        raise RegexSyntaxError(msg)
+    if rc == MRX_E_UNSUPPORTED:
+        raise UnsupportedPattern(msg)
+    raise MrxError("mrx error %d: %s" % (rc, msg))
+
+
+def pack_texts(texts: Sequence) -> Tuple[np.ndarray, np.ndarray]:
+    """Pack texts back to back: (data uint8[total], offsets int64[n+1])."""
+    bs = [_b(t) for t in texts]
+    offsets = np.zeros(len(bs) + 1, dtype=np.int64)
+    if bs:
+        np.cumsum([len(x) for x in bs], out=offsets[1:])
+    data = np.frombuffer(b"".join(bs), dtype=np.uint8).copy() if offsets[-1] else np.zeros(0, np.uint8)
+    return data, offsets
+
+
+class DeviceBatch:
+    """Texts already resident in HBM (torch tensors on a cuda device).
+
+    CSR form:      DeviceBatch(data_u8, offsets_i64)
+    strided form:  DeviceBatch.strided(data_u8[n*stride], stride, length or lens_i32)
+    """
+
+    def __init__(self, data, offsets=None, *, stride: int = 0, length: int = 0, lens=None, n=None):
+        self.data, self.offsets, self.stride, self.length, self.lens = data, offsets, stride, length, lens
+        if offsets is not None:
+            self.n = int(offsets.numel()) - 1
+        else:
+            self.n = int(n)
+
+    @classmethod
+    def strided(cls, data, stride: int, length: int = 0, lens=None):
+        n = data.numel() // stride
+        return cls(data, None, stride=stride, length=length, lens=lens, n=n)
+
+    @classmethod
+    def from_texts(cls, texts: Sequence, device="cuda"):
+        import torch
+        data, offsets = pack_texts(texts)
+        d = torch.from_numpy(data).to(device) if data.size else torch.zeros(0, dtype=torch.uint8, device=device)
+        return cls(d, torch.from_numpy(offsets).to(device))
+
+    def csr_offsets(self):
+        """CSR offsets for the generic kernels (built on device for strided batches)."""
+        import torch
+        if self.offsets is not None:
+            return self.offsets
+        if self.lens is None and self.length == self.stride:
+            return torch.arange(0, (self.n + 1) * self.stride, self.stride, dtype=torch.int64,
+                                device=self.data.device)
+        raise MrxError("this operation needs a CSR batch (strided batch with padding given)")
+
+
+def _ptr(t) -> int:
+    return 0 if t is None else int(t.data_ptr())
+
+
+class CompiledRegex:
+    """Compile once, match many batches (reference: matcher.mojo:929-1163)."""
+
+    def __init__(self, pattern):
+        self._lib = load_library()
+        self.pattern = _b(pattern)
+        h = C.c_void_p()
+        _check(self._lib.mrx_compile(self.pattern, len(self.pattern), C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._lib.mrx_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # -- introspection (get_engine_type :900-918, get_stats :1139-1163) ------------
+    def get_engine_type(self) -> str:
+        return self._lib.mrx_engine_type(self._h).decode()
+
+    def get_stats(self) -> str:
+        return self._lib.mrx_stats(self._h).decode("utf-8", "replace")
+
+    def describe(self) -> str:
+        need = self._lib.mrx_describe(self._h, None, 0)
+        buf = C.create_string_buffer(need + 1)
+        self._lib.mrx_describe(self._h, buf, need + 1)
+        return buf.value.decode("utf-8", "replace")
+
+    @property
+    def num_groups(self) -> int:
+        return self._lib.mrx_num_groups(self._h)
+
+    # -- host-buffer batches --------------------------------------------------------
+    def _spans_call(self, fn, texts):
+        data, offsets = pack_texts(texts)
+        n = len(offsets) - 1
+        s = np.empty(n, np.int32)
+        e = np.empty(n, np.int32)
+        _check(fn(self._h, data.ctypes.data, offsets.ctypes.data, n, s.ctypes.data, e.ctypes.data))
+        return s, e
+
+    def match_first(self, texts) -> Tuple[np.ndarray, np.ndarray]:
+        """regex.match_first per text: (start[n], end[n]), -1/-1 where none."""
+        if isinstance(texts, DeviceBatch):
+            return self._dev_spans(self._lib.mrx_match_first_dev, texts)
+        return self._spans_call(self._lib.mrx_match_first_batch, texts)
+
+    def match_next(self, texts) -> Tuple[np.ndarray, np.ndarray]:
+        """regex.search per text."""
+        if isinstance(texts, DeviceBatch):
+            return self._dev_spans(self._lib.mrx_search_dev, texts)
+        return self._spans_call(self._lib.mrx_search_batch, texts)
+
+    search = match_next
+
+    def is_match(self, texts) -> np.ndarray:
+        data, offsets = pack_texts(texts)
+        n = len(offsets) - 1
+        f = np.empty(n, np.uint8)
+        _check(self._lib.mrx_is_match_batch(self._h, data.ctypes.data, offsets.ctypes.data, n,
+                                            f.ctypes.data))
+        return f
+
+    def test(self, texts) -> np.ndarray:
+        """CompiledRegex.test (matcher.mojo:1091-1101): does search() match."""
+        s, _ = self.match_next(texts)
+        return (np.asarray(s) >= 0)
+
+    def match_all(self, texts):
+        """regex.findall per text: (counts_prefix int64[n+1], spans int32[total, 2])."""
+        if isinstance(texts, DeviceBatch):
+            return self._dev_findall(texts)
+        data, offsets = pack_texts(texts)
+        n = len(offsets) - 1
+        prefix = np.zeros(n + 1, np.int64)
+        cap = max(64, int(offsets[-1]) // 4 + n)
+        while True:
+            spans = np.empty((cap, 2), np.int32)
+            total = C.c_int64(0)
+            rc = self._lib.mrx_findall_batch(self._h, data.ctypes.data, offsets.ctypes.data, n,
+                                             prefix.ctypes.data, spans.ctypes.data, cap,
+                                             C.byref(total))
+            if rc == MRX_E_CAPACITY:
+                cap = int(total.value)
+                continue
+            _check(rc)
+            return prefix, spans[: total.value]
+
+    findall = match_all
+
+    def findall_lists(self, texts) -> List[List[Tuple[int, int]]]:
+        prefix, spans = self.match_all(texts)
+        out = []
+        for i in range(len(prefix) - 1):
+            out.append([(int(a), int(b)) for a, b in spans[prefix[i]:prefix[i + 1]]])
+        return out
+
+    def captures(self, texts) -> np.ndarray:
+        """search + capture groups, int32[n, g+1, 2] in the order the reference's
+        NFAEngine._match_group appends them: groups 1..g, then group 0."""
+        data, offsets = pack_texts(texts)
+        n = len(offsets) - 1
+        g = self.num_groups
+        out = np.empty((n, g + 1, 2), np.int32)
+        _check(self._lib.mrx_captures_batch(self._h, data.ctypes.data, offsets.ctypes.data, n,
+                                            out.ctypes.data))
+        return out
+
+    def sub(self, repl, texts, count: int = 0) -> List[bytes]:
+        repl = _b(repl)
+        data, offsets = pack_texts(texts)
+        n = len(offsets) - 1
+        out_off = np.zeros(n + 1, np.int64)
+        cap = max(64, int(offsets[-1]) * 2 + 16 * n)
+        while True:
+            out = np.empty(cap, np.uint8)
+            total = C.c_int64(0)
+            rc = self._lib.mrx_sub_batch(self._h, repl, len(repl), count, data.ctypes.data,
+                                         offsets.ctypes.data, n, out_off.ctypes.data,
+                                         out.ctypes.data, cap, C.byref(total))
+            if rc == MRX_E_CAPACITY:
+                cap = int(total.value)
+                continue
+            _check(rc)
+            raw = out[: total.value].tobytes()
+            return [raw[out_off[i]:out_off[i + 1]] for i in range(n)]
+
+    # -- device-resident batches (torch tensors) ------------------------------------
+    def _stream_ptr(self):
+        import torch
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def _dev_spans(self, fn, batch: DeviceBatch):
+        import torch
+        off = batch.csr_offsets()
+        s = torch.empty(batch.n, dtype=torch.int32, device=batch.data.device)
+        e = torch.empty(batch.n, dtype=torch.int32, device=batch.data.device)
+        _check(fn(self._h, _ptr(batch.data), _ptr(off), batch.n, _ptr(s), _ptr(e), self._stream_ptr()))
+        return s, e
+
+    def _dev_findall(self, batch: DeviceBatch, span_cap: Optional[int] = None, out=None):
+        """Returns (counts_prefix int64[n+1], spans int32[cap, 2], total) on device."""
+        import torch
+        dev = batch.data.device
+        if out is None:
+            if span_cap is None:
+                span_cap = max(64, batch.data.numel() // 8 + batch.n)
+            prefix = torch.empty(batch.n + 1, dtype=torch.int64, device=dev)
+            spans = torch.empty((span_cap, 2), dtype=torch.int32, device=dev)
+        else:
+            prefix, spans = out
+            span_cap = spans.shape[0]
+        total = C.c_int64(0)
+        while True:
+            if batch.offsets is not None:
+                rc = self._lib.mrx_findall_dev(self._h, _ptr(batch.data), _ptr(batch.offsets), batch.n,
+                                               _ptr(prefix), _ptr(spans), span_cap, C.byref(total),
+                                               self._stream_ptr())
+            else:
+                rc = self._lib.mrx_findall_strided_dev(self._h, _ptr(batch.data), batch.stride,
+                                                       _ptr(batch.lens), batch.length, batch.n,
+                                                       _ptr(prefix), _ptr(spans), span_cap,
+                                                       C.byref(total), self._stream_ptr())
+            if rc == MRX_E_CAPACITY and out is None:
+                span_cap = int(total.value)
+                spans = torch.empty((span_cap, 2), dtype=torch.int32, device=dev)
+                continue
+            _check(rc)
+            return prefix, spans, int(total.value)
+
+    def count(self, batch: DeviceBatch):
+        import torch
+        counts = torch.empty(batch.n, dtype=torch.int32, device=batch.data.device)
+        _check(self._lib.mrx_count_dev(self._h, _ptr(batch.data), _ptr(batch.csr_offsets()), batch.n,
+                                       _ptr(counts), self._stream_ptr()))
+        return counts
+
+
+# ---------------------------------------------------------------------------------
+# module-level API with the reference's process-wide cache (matcher.mojo:1166-1321)
+# ---------------------------------------------------------------------------------
+_CACHE = {}
+
+
+def compile_regex(pattern) -> CompiledRegex:
+    key = _b(pattern)
+    c = _CACHE.get(key)
+    if c is None:
+        c = CompiledRegex(key)
+        _CACHE[key] = c
+    return c
+
+
+def clear_regex_cache():
+    _CACHE.clear()
+
+
+def match_first(pattern, texts):
+    return compile_regex(pattern).match_first(texts)
+
+
+def search(pattern, texts):
+    return compile_regex(pattern).match_next(texts)
+
+
+def findall(pattern, texts):
+    return compile_regex(pattern).match_all(texts)
+
+
+def sub(pattern, repl, texts, count: int = 0) -> List[bytes]:
+    return compile_regex(pattern).sub(repl, texts, count)
+
+
+def split(pattern, texts, maxsplit: int = 0) -> List[List[bytes]]:
+    """regex.split (matcher.mojo:1357-1393): derived from findall, per text."""
+    bs = [_b(t) for t in texts]
+    lists = compile_regex(pattern).findall_lists(bs)
+    out = []
+    for text, spans in zip(bs, lists):
+        parts, prev, done = [], 0, 0
+        for (s, e) in spans:
+            if maxsplit != 0 and done >= maxsplit:
+                break
+            parts.append(text[prev:s])
+            prev = e
+            done += 1
+        parts.append(text[prev:])
+        out.append(parts)
+    return out

@@ -1,0 +1,395 @@
+// Device-side matching semantics shared by every kernel in mrx_kernels.hip.
+//
+// One wavefront lane owns one text.  The functions below restate, per lane, the
+// reference's matching control flow so that every (pattern, text) pair yields the
+// reference's spans:
+//   walk()              DFAEngine._try_match_at_position table walk  src/regex/dfa.mojo:1979-2024
+//                       LazyDFA._run_lazy                            src/regex/pikevm.mojo:819-867
+//   try_match_at()      DFAEngine._try_match_at_position             dfa.mojo:1906-2026
+//   try_match_simd()    DFAEngine._try_match_simd                    dfa.mojo:2133-2197
+//   engine_match_next() DFAEngine.match_next/_optimized_simd_search  dfa.mojo:1875-1903, 2200-2253
+//                       LazyDFA.match_next                           pikevm.mojo:754-780
+//   hybrid_*()          HybridMatcher.match_first/next/all           matcher.mojo:733-898
+//   for_each_match()    DFAEngine.match_all / LazyDFA.match_all      dfa.mojo:2028-2130, pikevm.mojo:782-817
+//   sub_text()          _sub_impl_with_repl                          matcher.mojo:1679-1854
+// Tables live in LDS (staged once per workgroup from the plan blob).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "mrx_plan.hpp"
+
+namespace mrx {
+
+struct Ctx {
+  DevPlan p;
+  const uint8_t* cls;     // [256] byte -> class
+  const uint8_t* first;   // [256] first-class / first-byte filter
+  const uint16_t* trans;  // [nstates][ncls], 0xFFFF dead, bit15 = target accepts
+  const uint8_t* lit;     // engine / exact literal
+  const uint8_t* pre;     // prefilter literal
+};
+
+struct Text {
+  const uint8_t* ptr;
+  int len;
+  __device__ __forceinline__ int at(int i) const { return ptr[i]; }
+};
+
+__device__ __forceinline__ bool flag(const Ctx& c, uint32_t f) { return (c.p.flags & f) != 0; }
+
+// leftmost occurrence of needle at or after start (simd_search, simd_ops.mojo:963-1024;
+// String.find as used at matcher.mojo:775,835 and prefilter.mojo:420-430)
+__device__ inline int find_literal(const uint8_t* needle, int nlen, const Text& t, int start) {
+  if (nlen == 0) return start;
+  if (start < 0) start = 0;
+  const int last = t.len - nlen;
+  const int n0 = needle[0];
+  for (int pos = start; pos <= last; ++pos) {
+    if (t.at(pos) != n0) continue;
+    int k = 1;
+    while (k < nlen && t.at(pos + k) == needle[k]) ++k;
+    if (k == nlen) return pos;
+  }
+  return -1;
+}
+
+// table walk from `start`; returns the last accepting position or -1
+__device__ inline int walk(const Ctx& c, const Text& t, int start) {
+  int state = 0;
+  int pos = start;
+  int last = flag(c, PF_START_ACCEPTING) ? pos : -1;
+  const int ncls = c.p.ncls;
+  while (pos < t.len) {
+    const uint32_t e = c.trans[state * ncls + c.cls[t.at(pos)]];
+    if (e == 0xFFFFu) break;
+    state = e & 0x7FFF;
+    ++pos;
+    if (e & 0x8000u) last = pos;
+  }
+  return last;
+}
+
+__device__ inline int count_consecutive(const Ctx& c, const Text& t, int start) {
+  int pos = start;
+  while (pos < t.len && c.first[t.at(pos)]) ++pos;
+  return pos - start;
+}
+
+__device__ inline int find_first_class(const Ctx& c, const Text& t, int start) {
+  for (int pos = start; pos < t.len; ++pos)
+    if (c.first[t.at(pos)]) return pos;
+  return -1;
+}
+
+// DFAEngine._try_match_at_position.  On success sets ms/me and returns true.
+__device__ inline bool try_match_at(const Ctx& c, const Text& t, int start_pos, bool exact,
+                                    int& ms, int& me) {
+  if (start_pos > t.len) return false;
+  if (flag(c, PF_PURE_LITERAL)) {
+    const int plen = c.p.lit_len;
+    if (exact) {
+      if (start_pos + plen > t.len) return false;  // verify_match, simd_ops.mojo:937-960
+      for (int k = 0; k < plen; ++k)
+        if (t.at(start_pos + k) != c.lit[k]) return false;
+      ms = start_pos; me = start_pos + plen;
+      return true;
+    }
+    const int pos = find_literal(c.lit, plen, t, start_pos);
+    if (pos < 0) return false;
+    ms = pos; me = pos + plen;
+    return true;
+  }
+  if (flag(c, PF_HAS_MATCHER) && (flag(c, PF_SCAN_ELIGIBLE) || flag(c, PF_START_ACCEPTING))) {
+    // _try_match_simd: the first class's run, or an empty match if the start accepts
+    const int n = count_consecutive(c, t, start_pos);
+    bool valid = false;
+    int end = start_pos + n;
+    if (n == 0) { if (flag(c, PF_START_ACCEPTING)) { valid = true; end = start_pos; } }
+    else valid = true;
+    if (valid && !(flag(c, PF_END_ANCHOR) && end != t.len)) {
+      ms = start_pos; me = end;
+      return true;
+    }
+  }
+  if (start_pos == t.len) {
+    if (flag(c, PF_START_ACCEPTING)) { ms = me = start_pos; return true; }
+    return false;
+  }
+  const int last = walk(c, t, start_pos);
+  if (last < 0) return false;
+  if (flag(c, PF_END_ANCHOR) && last != t.len) return false;
+  ms = start_pos; me = last;
+  return true;
+}
+
+// LazyDFA._run_lazy
+__device__ inline bool lazy_run(const Ctx& c, const Text& t, int start, int& ms, int& me) {
+  if (flag(c, PF_START_DEAD)) return false;
+  if (start > t.len) {  // no byte is read; the start set alone decides (pikevm.mojo:861-866)
+    if (!flag(c, PF_START_ACCEPTING)) return false;
+    ms = me = start;
+    return true;
+  }
+  const int last = walk(c, t, start);
+  if (last < 0) return false;
+  ms = start; me = last;
+  return true;
+}
+
+__device__ inline bool engine_match_first(const Ctx& c, const Text& t, int start, int& ms, int& me) {
+  if (c.p.kind == PLAN_LAZY) return lazy_run(c, t, start, ms, me);
+  if (flag(c, PF_START_ANCHOR) && start > 0) return false;   // dfa.mojo:1866-1867
+  return try_match_at(c, t, start, true, ms, me);
+}
+
+__device__ inline bool engine_match_next(const Ctx& c, const Text& t, int start, int& ms, int& me) {
+  if (c.p.kind == PLAN_LAZY) {
+    if (flag(c, PF_HAS_MATCHER)) {  // first-byte filter
+      int pos = start;
+      while (pos < t.len) {
+        const int cand = find_first_class(c, t, pos);
+        if (cand < 0) break;
+        if (lazy_run(c, t, cand, ms, me)) return true;
+        pos = cand + 1;
+      }
+      return lazy_run(c, t, t.len, ms, me);
+    }
+    for (int p = start; p <= t.len; ++p)
+      if (lazy_run(c, t, p, ms, me)) return true;
+    return false;
+  }
+  if (flag(c, PF_START_ANCHOR)) {
+    if (start == 0) return try_match_at(c, t, 0, false, ms, me);
+    return false;
+  }
+  if (flag(c, PF_HAS_MATCHER) && !flag(c, PF_END_ANCHOR)) {
+    // _optimized_simd_search
+    int pos = start;
+    if (flag(c, PF_SCAN_ELIGIBLE)) {
+      while (pos < t.len) {
+        const int mp = find_first_class(c, t, pos);
+        if (mp < 0) return false;
+        const int ml = count_consecutive(c, t, mp);
+        if (ml > 0) { ms = mp; me = mp + ml; return true; }
+        pos = mp + 1;
+      }
+      return false;
+    }
+    while (pos < t.len) {
+      const int fp = find_first_class(c, t, pos);
+      if (fp < 0) return false;
+      if (try_match_at(c, t, fp, false, ms, me)) return true;
+      pos = fp + 1;
+    }
+    return false;
+  }
+  if (flag(c, PF_PURE_LITERAL)) {
+    // every try_pos runs simd_search from try_pos: the first hit is the answer
+    if (start > t.len) return false;
+    return try_match_at(c, t, start, false, ms, me);
+  }
+  for (int p = start; p <= t.len; ++p)
+    if (try_match_at(c, t, p, false, ms, me)) return true;
+  return false;
+}
+
+// HybridMatcher.match_first, matcher.mojo:733-753
+__device__ inline bool hybrid_match_first(const Ctx& c, const Text& t, int start, int& ms, int& me) {
+  if (c.p.kind == PLAN_ANY) {
+    if (start <= t.len) { ms = start; me = t.len; return true; }
+    return false;
+  }
+  return engine_match_first(c, t, start, ms, me);
+}
+
+// HybridMatcher.match_next, matcher.mojo:755-802
+__device__ inline bool hybrid_match_next(const Ctx& c, const Text& t, int start, int& ms, int& me) {
+  if (c.p.kind == PLAN_ANY) {
+    if (start <= t.len) { ms = start; me = t.len; return true; }
+    return false;
+  }
+  if (flag(c, PF_EXACT_LITERAL)) {
+    if (start >= t.len) return false;
+    const int pos = find_literal(c.lit, c.p.lit_len, t, start);
+    if (pos < 0 || pos + c.p.lit_len > t.len) return false;
+    ms = pos; me = pos + c.p.lit_len;
+    return true;
+  }
+  if (flag(c, PF_PREFILTER)) {
+    if (start >= t.len) return false;
+    const int cand = find_literal(c.pre, c.p.pre_len, t, start);
+    if (cand < 0) return false;
+    return engine_match_next(c, t, cand, ms, me);
+  }
+  return engine_match_next(c, t, start, ms, me);
+}
+
+// DFAEngine.is_match through HybridMatcher.is_match, matcher.mojo:721-731, dfa.mojo:1815-1849
+__device__ inline bool hybrid_is_match(const Ctx& c, const Text& t, int start) {
+  int ms, me;
+  if (c.p.kind == PLAN_ANY) return start <= t.len;
+  if (c.p.kind == PLAN_LAZY) return lazy_run(c, t, start, ms, me);
+  if (flag(c, PF_START_ANCHOR) && start > 0) return false;
+  if (flag(c, PF_HAS_MATCHER) && c.p.nstates > 0) {
+    if (start >= t.len) return flag(c, PF_START_ACCEPTING);
+    if (c.first[t.at(start)]) return true;
+    return flag(c, PF_START_ACCEPTING);
+  }
+  return try_match_at(c, t, start, true, ms, me);
+}
+
+// HybridMatcher.match_all: calls emit(start, end) for every match, in order.
+template <class Emit>
+__device__ inline void for_each_match(const Ctx& c, const Text& t, Emit&& emit) {
+  int ms, me;
+  if (c.p.kind == PLAN_ANY) { emit(0, t.len); return; }
+  if (flag(c, PF_EXACT_LITERAL)) {
+    // matcher.mojo:815-847: start = pos + 1, i.e. overlapping occurrences
+    const int ll = c.p.lit_len;
+    if (ll > t.len) return;
+    const int max_start = t.len - ll;
+    int start = 0;
+    while (start <= max_start) {
+      const int pos = find_literal(c.lit, ll, t, start);
+      if (pos < 0) break;
+      emit(pos, pos + ll);
+      start = pos + 1;
+    }
+    return;
+  }
+  if (c.p.required_byte >= 0) {
+    // _match_all_required_byte, matcher.mojo:864-898
+    int pos = 0;
+    while (pos < t.len) {
+      int hit = -1;
+      for (int k = pos; k < t.len; ++k)
+        if (t.at(k) == c.p.required_byte) { hit = k; break; }
+      if (hit < 0) break;
+      int start = hit;
+      while (start > 0 && c.first[t.at(start - 1)]) --start;
+      if (engine_match_first(c, t, start, ms, me) && me > hit) {
+        emit(ms, me);
+        pos = me;
+        if (pos <= hit) pos = hit + 1;
+      } else {
+        pos = hit + 1;
+      }
+    }
+    return;
+  }
+  if (c.p.kind == PLAN_LAZY) {
+    int pos = 0;
+    if (flag(c, PF_HAS_MATCHER)) {
+      while (pos < t.len) {
+        const int cand = find_first_class(c, t, pos);
+        if (cand < 0) break;
+        pos = cand;
+        if (lazy_run(c, t, pos, ms, me)) { emit(ms, me); pos = (pos + 1 > me) ? pos + 1 : me; }
+        else ++pos;
+      }
+      return;
+    }
+    while (pos <= t.len) {
+      if (lazy_run(c, t, pos, ms, me)) { emit(ms, me); pos = (pos + 1 > me) ? pos + 1 : me; }
+      else ++pos;
+    }
+    return;
+  }
+  // DFAEngine.match_all
+  if (flag(c, PF_START_ANCHOR) || flag(c, PF_END_ANCHOR)) {
+    if (engine_match_next(c, t, 0, ms, me)) emit(ms, me);
+    return;
+  }
+  int pos = 0;
+  if (flag(c, PF_PURE_LITERAL)) {
+    const int plen = c.p.lit_len;
+    while (pos <= t.len - plen) {
+      const int hit = find_literal(c.lit, plen, t, pos);
+      if (hit < 0) break;
+      emit(hit, hit + plen);
+      pos = hit + plen;
+    }
+    return;
+  }
+  if (flag(c, PF_HAS_MATCHER) && c.p.nstates > 0) {
+    if (flag(c, PF_SCAN_ELIGIBLE)) {
+      while (pos < t.len) {
+        const int mp = find_first_class(c, t, pos);
+        if (mp < 0) break;
+        const int ml = count_consecutive(c, t, mp);
+        if (ml > 0) { emit(mp, mp + ml); pos = mp + ml; }
+        else pos = mp + 1;
+      }
+      return;
+    }
+    while (pos < t.len) {
+      const int np = find_first_class(c, t, pos);
+      if (np < 0) break;
+      pos = np;
+      if (try_match_at(c, t, pos, false, ms, me)) {
+        emit(ms, me);
+        pos = (me == ms) ? pos + 1 : me;
+      } else {
+        ++pos;
+      }
+    }
+    return;
+  }
+  while (pos <= t.len) {
+    if (try_match_at(c, t, pos, false, ms, me)) {
+      emit(ms, me);
+      pos = (me == ms) ? pos + 1 : me;
+    } else {
+      ++pos;
+    }
+  }
+}
+
+// _sub_impl_with_repl.  `out` is a sink with bytes(ptr, n); `tpl` the parsed
+// replacement template (only read when use_groups).
+template <class Sink>
+__device__ inline void sub_text(const Ctx& c, const Text& t, const uint8_t* repl, int repl_len,
+                                bool use_groups, const ReplSeg* tpl, int ntpl, long long count,
+                                Sink& out) {
+  if (t.len == 0) return;
+  auto apply_tpl = [&](int match_start) {  // _apply_template_fixed, matcher.mojo:1592-1621
+    for (int k = 0; k < ntpl; ++k) {
+      const ReplSeg s = tpl[k];
+      if (s.group_ref > 0 && s.group_ref <= c.p.fixed_ngroups)
+        out.bytes(t.ptr + match_start + c.p.fixed_off[s.group_ref], c.p.fixed_w[s.group_ref]);
+      else
+        out.bytes(repl + s.start, s.length);
+    }
+  };
+  if (use_groups && c.p.fixed_concat && t.len == c.p.fixed_total) {
+    // matcher.mojo:1726-1744: whole-text fast path, no engine call
+    bool digits = true;
+    for (int i = 0; i < c.p.fixed_total; ++i) {
+      const int b = t.at(i);
+      if (b < '0' || b > '9') { digits = false; break; }
+    }
+    if (digits) apply_tpl(0);
+    else out.bytes(t.ptr, t.len);
+    return;
+  }
+  int pos = 0;
+  long long reps = 0;
+  int ms, me;
+  while (pos <= t.len) {
+    if (!hybrid_match_next(c, t, pos, ms, me)) break;
+    if (ms > pos) out.bytes(t.ptr + pos, ms - pos);
+    if (use_groups) apply_tpl(ms);
+    else out.bytes(repl, repl_len);
+    ++reps;
+    if (me == ms) {
+      if (pos < t.len) out.bytes(t.ptr + pos, 1);  // sic: byte at pos, not at ms (matcher.mojo:1772-1776)
+      pos = me + 1;
+    } else {
+      pos = me;
+    }
+    if (count > 0 && reps >= count) break;
+  }
+  if (pos < t.len) out.bytes(t.ptr + pos, t.len - pos);
+}
+
+}  // namespace mrx

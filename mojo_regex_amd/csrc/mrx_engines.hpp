@@ -1,0 +1,94 @@
+// Host-side engine tables: the DFAEngine-equivalent table set and the PikeVM
+// program with its eagerly determinised LazyDFA.
+//
+// Reference behaviour mirrored:
+//   DFA shape dispatcher + compilers   src/regex/dfa.mojo:308-1803, 2385-3589
+//   byte-class matcher metadata         src/regex/simd_ops.mojo:63-134, 261-420
+//   PikeVM bytecode                     src/regex/pikevm.mojo:39-333
+//   first-byte filter / LazyDFA         src/regex/pikevm.mojo:367-416, 664-987
+// The LazyDFA of the reference memoises PikeVM state sets on demand; here the
+// reachable sets are enumerated once at compile time (same sets, same
+// leftmost-start / longest-end results; see DESIGN.md "LazyDFA").
+#pragma once
+#include <array>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "mrx_ast.hpp"
+
+namespace mrx {
+
+struct DfaCompileError : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+
+struct ClassMatcher {
+  std::array<uint8_t, 256> lookup{};  // 0/1
+  int num_ranges = 0;                  // 0 => reference uses the nibble-table scan
+  std::array<uint8_t, 16> lo_tbl{}, hi_tbl{};
+  void build(const std::string& char_class);
+  void finish();  // detect ranges + nibble tables from lookup
+  bool nibble_hit(int c) const { return (lo_tbl[c & 15] & hi_tbl[(c >> 4) & 15]) != 0; }
+};
+
+struct DfaEngine {
+  std::vector<std::array<int16_t, 256>> trans;  // -1 = no transition
+  std::vector<uint8_t> accepting;
+  bool has_start_anchor = false, has_end_anchor = false;
+  bool is_pure_literal = false;
+  bool has_matcher = false, scan_eligible = false;
+  ClassMatcher matcher;
+  std::string literal;
+  std::string shape;  // which dispatcher branch fired
+
+  int nstates() const { return (int)trans.size(); }
+  int add_state(bool acc = false) {
+    std::array<int16_t, 256> row;
+    row.fill(-1);
+    trans.push_back(row);
+    accepting.push_back(acc ? 1 : 0);
+    return (int)trans.size() - 1;
+  }
+};
+
+// throws DfaCompileError where the reference's compile_dfa_pattern raises
+void compile_dfa_pattern(const Ast& a, DfaEngine& out);
+
+// ---- PikeVM ------------------------------------------------------------------
+enum Op : uint8_t {
+  OP_BYTE, OP_RANGE, OP_CLASS, OP_ANY, OP_SPLIT, OP_JUMP, OP_MATCH, OP_START_ANCHOR,
+  OP_END_ANCHOR
+};
+struct Inst {
+  Op op;
+  int a0, a1;
+};
+struct Program {
+  std::vector<Inst> insts;
+  std::vector<std::array<uint8_t, 256>> classes;
+  bool has_end_anchor() const {
+    for (const auto& i : insts)
+      if (i.op == OP_END_ANCHOR) return true;
+    return false;
+  }
+};
+constexpr int kPikeMaxStates = 512;  // pikevm.mojo:342
+
+void compile_program(const Ast& a, Program& p);
+
+struct LazyTables {
+  bool supported = false;       // program <= 512 instructions
+  bool has_filter = false;      // first-byte filter usable (pikevm.mojo:416)
+  std::array<uint8_t, 256> first_byte{};
+  std::array<uint8_t, 16> lo_tbl{}, hi_tbl{};
+  bool start_dead = false;      // start closure empty (LAZY_DFA_DEAD)
+  // determinised automaton: state 0 = start set
+  std::vector<std::array<int32_t, 256>> trans;  // -1 dead
+  std::vector<uint8_t> is_match;
+  bool too_large = false;       // determinisation exceeded the state budget
+};
+void build_lazy(const Program& p, LazyTables& out, int max_dfa_states);
+
+}  // namespace mrx

@@ -1,0 +1,872 @@
+// HIP kernels (gfx950 / CDNA4) and the C ABI of libmrx_hip.so.
+//
+// Kernels
+//   k_match<OP>        one lane per text: match_first / search / is_match / captures
+//   k_findall<MODE>    one lane per text: count, or emit spans at a CSR offset
+//   k_stream_findall   the streaming scan: texts at a fixed pitch, a wavefront
+//                      stages 64 texts x CHUNK bytes through LDS with coalesced
+//                      16-byte loads, each lane then walks its own text in lockstep
+//                      through a register-indexed search automaton (no per-byte
+//                      dependent memory access); spans go to per-text slots
+//   k_compact          slots -> CSR spans
+//   k_sub<MODE>        output sizes / output bytes of sub()
+//   k_scan_*           exclusive prefix sums (counts -> CSR offsets)
+// All tables are staged from the plan blob into LDS once per workgroup.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/mrx.h"
+#include "mrx_device.hpp"
+
+using namespace mrx;
+
+// ============================================================================
+// device side
+// ============================================================================
+namespace {
+
+constexpr int kBlock = 256;  // 4 wavefronts
+
+struct Layout {  // where text i lives
+  const uint8_t* data;
+  const int64_t* offsets;  // CSR layout when non-null
+  int64_t stride;          // fixed pitch otherwise
+  const int32_t* lens;     // optional per-text length (fixed pitch)
+  int32_t len;             // common length when lens == nullptr
+  __device__ __forceinline__ Text text(int64_t i) const {
+    if (offsets) {
+      const int64_t a = offsets[i], b = offsets[i + 1];
+      return Text{data + a, (int)(b - a)};
+    }
+    return Text{data + i * stride, lens ? lens[i] : len};
+  }
+};
+
+__device__ __forceinline__ Ctx stage_tables(const DevPlan& p, const uint8_t* __restrict__ blob,
+                                            uint8_t* lds) {
+  // cooperative 4-byte copy of the plan blob into LDS
+  const uint32_t* src = (const uint32_t*)blob;
+  uint32_t* dst = (uint32_t*)lds;
+  const int words = p.blob_bytes >> 2;
+  for (int i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
+  __syncthreads();
+  Ctx c;
+  c.p = p;
+  c.cls = lds + p.off_cls;
+  c.first = lds + p.off_first;
+  c.trans = (const uint16_t*)(lds + p.off_trans);
+  c.lit = lds + p.off_lit;
+  c.pre = lds + p.off_pre;
+  return c;
+}
+
+enum { OP_MATCH_FIRST = 0, OP_SEARCH = 1, OP_IS_MATCH = 2, OP_CAPTURES = 3 };
+
+template <int OP>
+__global__ __launch_bounds__(kBlock) void k_match(DevPlan p, const uint8_t* __restrict__ blob,
+                                                  Layout lay, int64_t n, int32_t* __restrict__ out_s,
+                                                  int32_t* __restrict__ out_e,
+                                                  uint8_t* __restrict__ out_flag) {
+  extern __shared__ __align__(16) uint8_t lds[];
+  const Ctx c = stage_tables(p, blob, lds);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const Text t = lay.text(i);
+    int ms = -1, me = -1;
+    if (OP == OP_MATCH_FIRST) {
+      // regex.match_first, matcher.mojo:1396-1415: keep only matches starting at 0
+      if (!(hybrid_match_first(c, t, 0, ms, me) && ms == 0)) ms = me = -1;
+      out_s[i] = ms; out_e[i] = me;
+    } else if (OP == OP_SEARCH) {
+      if (!hybrid_match_next(c, t, 0, ms, me)) ms = me = -1;
+      out_s[i] = ms; out_e[i] = me;
+    } else if (OP == OP_IS_MATCH) {
+      out_flag[i] = hybrid_is_match(c, t, 0) ? 1 : 0;
+    } else {
+      // search + fixed-width groups in NFAEngine._match_group order (nfa.mojo:1057-1103)
+      const int g = p.fixed_ngroups;
+      int32_t* o = out_s + i * (int64_t)(g + 1) * 2;
+      if (hybrid_match_next(c, t, 0, ms, me)) {
+        for (int k = 1; k <= g; ++k) {
+          o[(k - 1) * 2] = ms + p.fixed_off[k];
+          o[(k - 1) * 2 + 1] = ms + p.fixed_off[k] + p.fixed_w[k];
+        }
+        o[g * 2] = ms; o[g * 2 + 1] = me;
+      } else {
+        for (int k = 0; k < (g + 1) * 2; ++k) o[k] = -1;
+      }
+    }
+  }
+}
+
+enum { FA_COUNT = 0, FA_EMIT = 1 };
+
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_findall(DevPlan p, const uint8_t* __restrict__ blob,
+                                                    Layout lay, int64_t n,
+                                                    int32_t* __restrict__ counts,
+                                                    const int64_t* __restrict__ prefix,
+                                                    int32_t* __restrict__ spans, int64_t span_cap) {
+  extern __shared__ __align__(16) uint8_t lds[];
+  const Ctx c = stage_tables(p, blob, lds);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const Text t = lay.text(i);
+    if (MODE == FA_COUNT) {
+      int k = 0;
+      for_each_match(c, t, [&](int, int) { ++k; });
+      counts[i] = k;
+    } else {
+      int64_t w = prefix[i];
+      for_each_match(c, t, [&](int s, int e) {
+        if (w < span_cap) { spans[2 * w] = s; spans[2 * w + 1] = e; }
+        ++w;
+      });
+    }
+  }
+}
+
+// ---- streaming findall ----------------------------------------------------------
+// Each wavefront owns 64 consecutive texts (fixed pitch).  Per CHUNK of 64 bytes:
+//   1. 4 coalesced wave loads (16 B per lane; lane l reads text 16*j + l/4, segment
+//      l%4) bring 64 texts x 64 B into registers and then LDS, row pitch 80 B so
+//      that the per-lane 16-byte read-back is bank-conflict free;
+//   2. every lane reads its own 64 bytes back (4 x ds_read_b128) and steps the
+//      4-state search automaton once per byte.  The transition for byte b is
+//      (col[b] >> 4*state) & 15 where col[] is a 256-entry u16 table in LDS: the
+//      table lookup depends only on the byte, never on the state, so the serial
+//      state chain is two register ops per byte.
+// Entry bits: next<<2 | EMIT<<1 | NEWSTART (built by build_stream_cols()).
+constexpr int kChunk = 64;
+constexpr int kRowPitch = 80;                    // bytes; 80/4 = 20 dwords -> conflict-free b128
+constexpr int kTileBytes = 64 * kRowPitch;       // one wavefront's tile
+constexpr int kStreamWaves = 4;
+
+struct SlotOut {
+  int32_t* slot;     // this text's span slots
+  int cap;           // spans per slot
+  int cnt;
+  __device__ __forceinline__ void emit(int s, int e) {
+    if (cnt < cap) { slot[2 * cnt] = s; slot[2 * cnt + 1] = e; }
+    ++cnt;
+  }
+};
+
+template <bool COUNT_ONLY>
+__global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
+    DevPlan p, const uint8_t* __restrict__ blob, const uint8_t* __restrict__ data, int64_t stride,
+    const int32_t* __restrict__ lens, int32_t common_len, int64_t n, int32_t* __restrict__ counts,
+    int32_t* __restrict__ slots, int slot_cap) {
+  __shared__ __align__(16) uint8_t tiles[kStreamWaves][kTileBytes];
+  __shared__ __align__(16) uint16_t col_lds[256];
+  {
+    const uint16_t* src = (const uint16_t*)(blob + p.off_stcol);
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) col_lds[i] = src[i];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  uint8_t* tile = tiles[wave];
+  const int64_t nwaves_total = (n + 63) >> 6;
+  const uint32_t accmask = p.st_accept_mask;
+
+  for (int64_t w = (int64_t)blockIdx.x * kStreamWaves + wave; w < nwaves_total;
+       w += (int64_t)gridDim.x * kStreamWaves) {
+    const int64_t base_text = w << 6;
+    const int64_t my_text = base_text + lane;
+    const bool live = my_text < n;
+    const int my_len = live ? (lens ? lens[my_text] : common_len) : 0;
+    // longest text in this wavefront decides the trip count
+    int max_len = my_len;
+    for (int off = 32; off > 0; off >>= 1) max_len = max(max_len, __shfl_xor(max_len, off));
+
+    uint32_t q4 = 0;       // 4 * state
+    int start = 0;
+    int cnt = 0;
+    int32_t* slot = slots ? slots + my_text * (int64_t)slot_cap * 2 : nullptr;
+
+    for (int cbase = 0; cbase < max_len; cbase += kChunk) {
+      // ---- stage 64 texts x 64 bytes -------------------------------------------
+      uint4 v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = 16 * j + (lane >> 2);
+        const int seg = lane & 3;
+        int64_t tr = base_text + row;
+        if (tr >= n) tr = n - 1;  // stay in bounds; the lane that owns it is not live
+        // the pitch is a multiple of 16 and rows are padded up to it, so a 16-byte
+        // load that starts inside the row never leaves it
+        const int64_t boff = (int64_t)cbase + seg * 16;
+        const uint8_t* src = data + tr * stride + (boff < stride ? boff : 0);
+        v[j] = *(const uint4*)src;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = 16 * j + (lane >> 2);
+        const int seg = lane & 3;
+        *(uint4*)(tile + row * kRowPitch + seg * 16) = v[j];
+      }
+      // the tile is private to this wavefront: a wave-level fence is enough
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+      // ---- walk my 64 bytes -------------------------------------------------------
+      const int lim = my_len - cbase;  // bytes of mine in this chunk (may be <= 0 or > 64)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const uint4 wv = *(const uint4*)(tile + lane * kRowPitch + g * 16);
+        const uint32_t words[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          const int rel = g * 16 + k;
+          const uint32_t b = (words[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
+          const uint32_t col = col_lds[b];
+          uint32_t e = (col >> q4) & 0xFu;
+          const bool valid = rel < lim;
+          if (valid) {
+            const int pos = cbase + rel;
+            if (e & 2u) {  // EMIT: the walk that started at `start` ended here
+              if (!COUNT_ONLY) {
+                if (cnt < slot_cap) { slot[2 * cnt] = start; slot[2 * cnt + 1] = pos; }
+              }
+              ++cnt;
+            }
+            if (e & 1u) start = pos;  // NEWSTART
+            q4 = e & 0xCu;
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    // end of text: a walk that is in an accepting state ends at len
+    if (live) {
+      if ((accmask >> (q4 >> 2)) & 1u) {
+        if (!COUNT_ONLY) {
+          if (cnt < slot_cap) { slot[2 * cnt] = start; slot[2 * cnt + 1] = my_len; }
+        }
+        ++cnt;
+      }
+      counts[my_text] = cnt;
+    }
+  }
+}
+
+// slots -> CSR.  Texts whose count exceeds the slot capacity are re-walked with
+// the generic loop (rare by construction of the capacity).
+__global__ __launch_bounds__(kBlock) void k_compact(DevPlan p, const uint8_t* __restrict__ blob,
+                                                    Layout lay, int64_t n,
+                                                    const int32_t* __restrict__ counts,
+                                                    const int64_t* __restrict__ prefix,
+                                                    const int32_t* __restrict__ slots, int slot_cap,
+                                                    int32_t* __restrict__ spans, int64_t span_cap) {
+  extern __shared__ __align__(16) uint8_t lds[];
+  const Ctx c = stage_tables(p, blob, lds);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int k = counts[i];
+    int64_t w = prefix[i];
+    if (k <= slot_cap) {
+      const int32_t* s = slots + i * (int64_t)slot_cap * 2;
+      for (int j = 0; j < k; ++j, ++w)
+        if (w < span_cap) { spans[2 * w] = s[2 * j]; spans[2 * w + 1] = s[2 * j + 1]; }
+    } else {
+      const Text t = lay.text(i);
+      for_each_match(c, t, [&](int s, int e) {
+        if (w < span_cap) { spans[2 * w] = s; spans[2 * w + 1] = e; }
+        ++w;
+      });
+    }
+  }
+}
+
+// ---- sub() -------------------------------------------------------------------------
+struct SizeSink {
+  int64_t n = 0;
+  __device__ __forceinline__ void bytes(const uint8_t*, int k) { n += k; }
+};
+struct WriteSink {
+  uint8_t* out;
+  int64_t pos, cap;
+  __device__ __forceinline__ void bytes(const uint8_t* src, int k) {
+    for (int j = 0; j < k; ++j)
+      if (pos + j < cap) out[pos + j] = src[j];
+    pos += k;
+  }
+};
+
+enum { SUB_SIZE = 0, SUB_EMIT = 1 };
+
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_sub(DevPlan p, const uint8_t* __restrict__ blob,
+                                                Layout lay, int64_t n,
+                                                const uint8_t* __restrict__ repl, int repl_len,
+                                                int use_groups, const ReplSeg* __restrict__ tpl,
+                                                int ntpl, long long count,
+                                                int64_t* __restrict__ sizes,
+                                                const int64_t* __restrict__ out_off,
+                                                uint8_t* __restrict__ out, int64_t out_cap) {
+  extern __shared__ __align__(16) uint8_t lds[];
+  const Ctx c = stage_tables(p, blob, lds);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const Text t = lay.text(i);
+    if (MODE == SUB_SIZE) {
+      SizeSink s;
+      sub_text(c, t, repl, repl_len, use_groups != 0, tpl, ntpl, count, s);
+      sizes[i] = s.n;
+    } else {
+      WriteSink s{out, out_off[i], out_cap};
+      sub_text(c, t, repl, repl_len, use_groups != 0, tpl, ntpl, count, s);
+    }
+  }
+}
+
+// ---- exclusive scan (counts -> CSR offsets) ---------------------------------------
+constexpr int kScanBlock = 256;
+constexpr int kScanItems = 8;  // per thread
+constexpr int kScanTile = kScanBlock * kScanItems;
+
+template <class T>
+__global__ __launch_bounds__(kScanBlock) void k_scan_local(const T* __restrict__ in, int64_t n,
+                                                           int64_t* __restrict__ out,
+                                                           int64_t* __restrict__ block_sums) {
+  __shared__ int64_t wsum[kScanBlock / 64];
+  const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+  int64_t v[kScanItems];
+  int64_t local = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    const int64_t idx = base + k;
+    const int64_t x = idx < n ? (int64_t)in[idx] : 0;
+    v[k] = local;
+    local += x;
+  }
+  // wave inclusive scan of `local`
+  int64_t inc = local;
+  const int lane = threadIdx.x & 63;
+  for (int off = 1; off < 64; off <<= 1) {
+    const int64_t y = __shfl_up(inc, off);
+    if (lane >= off) inc += y;
+  }
+  const int wave = threadIdx.x >> 6;
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  int64_t wave_off = 0;
+  for (int w2 = 0; w2 < wave; ++w2) wave_off += wsum[w2];
+  const int64_t excl = wave_off + inc - local;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    const int64_t idx = base + k;
+    if (idx < n) out[idx] = excl + v[k];
+  }
+  if (threadIdx.x == kScanBlock - 1) block_sums[blockIdx.x] = wave_off + inc;
+}
+
+__global__ void k_scan_blocks(int64_t* __restrict__ block_sums, int64_t nblocks,
+                              int64_t* __restrict__ total) {
+  // single workgroup, sequential over tiles of 256: nblocks <= n/2048
+  __shared__ int64_t carry;
+  __shared__ int64_t wsum[4];
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int64_t base = 0; base < nblocks; base += blockDim.x) {
+    const int64_t idx = base + threadIdx.x;
+    const int64_t x = idx < nblocks ? block_sums[idx] : 0;
+    int64_t inc = x;
+    const int lane = threadIdx.x & 63;
+    for (int off = 1; off < 64; off <<= 1) {
+      const int64_t y = __shfl_up(inc, off);
+      if (lane >= off) inc += y;
+    }
+    const int wave = threadIdx.x >> 6;
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int64_t wave_off = carry;
+    for (int w2 = 0; w2 < wave; ++w2) wave_off += wsum[w2];
+    if (idx < nblocks) block_sums[idx] = wave_off + inc - x;
+    __syncthreads();
+    if (threadIdx.x == blockDim.x - 1) carry = wave_off + inc;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total = carry;
+}
+
+__global__ __launch_bounds__(kScanBlock) void k_scan_add(int64_t* __restrict__ out, int64_t n,
+                                                         const int64_t* __restrict__ block_sums,
+                                                         const int64_t* __restrict__ total) {
+  const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+  const int64_t add = block_sums[blockIdx.x];
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    const int64_t idx = base + k;
+    if (idx < n) out[idx] += add;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = *total;
+}
+
+}  // namespace
+
+// ============================================================================
+// host side
+// ============================================================================
+struct mrx_handle {
+  HostPlan hp;
+  uint8_t* d_blob = nullptr;
+  int device = -1;
+  std::string describe_cache;
+};
+
+namespace {
+
+thread_local std::string g_err;
+thread_local bool g_timing = false;
+thread_local double g_scan_ms = 0.0;
+thread_local int64_t g_scan_launches = 0;
+thread_local const char* g_last_kernel = "";
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                  \
+  do {                                                                                 \
+    hipError_t e_ = (expr);                                                            \
+    if (e_ != hipSuccess)                                                              \
+      return fail(MRX_E_NO_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+int ensure_device(const mrx_handle* hc) {
+  mrx_handle* h = const_cast<mrx_handle*>(hc);
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lk(mu);
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  if (h->d_blob && h->device == dev) return MRX_OK;
+  if (h->d_blob) { (void)hipFree(h->d_blob); h->d_blob = nullptr; }
+  HIP_TRY(hipMalloc((void**)&h->d_blob, h->hp.blob.size()));
+  HIP_TRY(hipMemcpy(h->d_blob, h->hp.blob.data(), h->hp.blob.size(), hipMemcpyHostToDevice));
+  h->device = dev;
+  return MRX_OK;
+}
+
+int grid_for(int64_t n, int block) {
+  int64_t g = (n + block - 1) / block;
+  if (g < 1) g = 1;
+  const int64_t cap = 256 * 8;  // 256 CUs x 8 workgroups
+  return (int)(g < cap ? g : cap);
+}
+
+struct ScanTimer {  // HIP events around the dominant scan kernel, on its own stream
+  hipEvent_t a = nullptr, b = nullptr;
+  hipStream_t s;
+  bool on;
+  explicit ScanTimer(hipStream_t st) : s(st), on(g_timing) {
+    if (on) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, s); }
+  }
+  void stop() {
+    if (!on) return;
+    (void)hipEventRecord(b, s);
+    (void)hipEventSynchronize(b);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, a, b);
+    g_scan_ms += ms;
+    g_scan_launches += 1;
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    on = false;
+  }
+};
+
+int check_search_supported(const mrx_handle* h) {
+  if (!h->hp.why_no_search.empty()) return fail(MRX_E_UNSUPPORTED, h->hp.why_no_search);
+  return MRX_OK;
+}
+
+// exclusive scan of n counts into prefix[n+1]; *d_total receives the sum
+template <class T>
+int device_scan(const T* d_in, int64_t n, int64_t* d_prefix, int64_t* d_total, hipStream_t s) {
+  const int64_t nblocks = n > 0 ? (n + kScanTile - 1) / kScanTile : 1;
+  int64_t* d_bs = nullptr;
+  HIP_TRY(hipMallocAsync((void**)&d_bs, sizeof(int64_t) * nblocks, s));
+  hipLaunchKernelGGL(k_scan_local<T>, dim3((unsigned)nblocks), dim3(kScanBlock), 0, s, d_in, n,
+                     d_prefix, d_bs);
+  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, s, d_bs, nblocks, d_total);
+  hipLaunchKernelGGL(k_scan_add, dim3((unsigned)nblocks), dim3(kScanBlock), 0, s, d_prefix, n,
+                     d_bs, d_total);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipFreeAsync(d_bs, s));
+  return MRX_OK;
+}
+
+size_t lds_for(const mrx_handle* h) { return (size_t)h->hp.dev.blob_bytes; }
+
+int check_lds(const mrx_handle* h) {
+  if (h->hp.dev.blob_bytes > 60 * 1024)
+    return fail(MRX_E_UNSUPPORTED, "compiled tables exceed the 60 KiB LDS staging budget");
+  return MRX_OK;
+}
+
+template <int OP>
+int run_match(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d_s, int32_t* d_e,
+              uint8_t* d_flag, void* stream) {
+  if (!h) return fail(MRX_E_ARGUMENT, "null handle");
+  if (n < 0) return fail(MRX_E_ARGUMENT, "negative batch size");
+  if (OP == OP_MATCH_FIRST || OP == OP_IS_MATCH) {
+    if (!h->hp.why_no_match_first.empty()) return fail(MRX_E_UNSUPPORTED, h->hp.why_no_match_first);
+  } else {
+    if (int rc = check_search_supported(h)) return rc;
+  }
+  if (OP == OP_CAPTURES && h->hp.fixed_total < 0)
+    return fail(MRX_E_UNSUPPORTED,
+                "capture groups outside the fixed-width (\\d{N}) form need the reference's "
+                "backtracking NFA (nfa.mojo:500-574)");
+  if (int rc = check_lds(h)) return rc;
+  if (int rc = ensure_device(h)) return rc;
+  if (n == 0) return MRX_OK;
+  hipStream_t s = (hipStream_t)stream;
+  ScanTimer tm(s);
+  hipLaunchKernelGGL(k_match<OP>, dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s, h->hp.dev,
+                     h->d_blob, lay, n, d_s, d_e, d_flag);
+  g_last_kernel = "k_match";
+  HIP_TRY(hipGetLastError());
+  tm.stop();
+  return MRX_OK;
+}
+
+int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_prefix,
+                int32_t* d_spans, int64_t span_cap, int64_t* total, void* stream) {
+  if (!h) return fail(MRX_E_ARGUMENT, "null handle");
+  if (n < 0 || span_cap < 0) return fail(MRX_E_ARGUMENT, "negative size");
+  if (int rc = check_search_supported(h)) return rc;
+  if (int rc = check_lds(h)) return rc;
+  if (int rc = ensure_device(h)) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  int32_t* d_counts = nullptr;
+  int64_t* d_total = nullptr;
+  HIP_TRY(hipMallocAsync((void**)&d_counts, sizeof(int32_t) * (n > 0 ? n : 1), s));
+  HIP_TRY(hipMallocAsync((void**)&d_total, sizeof(int64_t), s));
+  const DevPlan& p = h->hp.dev;
+  const bool stream_ok = (p.flags & PF_STREAMABLE) && !lay.offsets && (lay.stride % 16 == 0) &&
+                         (((uintptr_t)lay.data) % 16 == 0) && n > 0;
+  int32_t* d_slots = nullptr;
+  int slot_cap = 0;
+  if (n > 0) {
+    if (stream_ok) {
+      // slot capacity: a match needs >= 1 byte and two matches cannot touch unless the
+      // second starts where the first ends; cap the slot at 64 spans and let the
+      // compaction kernel re-walk the (rare) texts that overflow
+      const int64_t max_len = lay.lens ? lay.stride : lay.len;
+      slot_cap = (int)(max_len < 64 ? (max_len > 0 ? max_len : 1) : 64);
+      HIP_TRY(hipMallocAsync((void**)&d_slots, sizeof(int32_t) * 2 * (size_t)slot_cap * n, s));
+      const int64_t nw = (n + 63) / 64;
+      int64_t g = (nw + kStreamWaves - 1) / kStreamWaves;
+      if (g > 256 * 8) g = 256 * 8;
+      ScanTimer tm(s);
+      hipLaunchKernelGGL(k_stream_findall<false>, dim3((unsigned)g), dim3(64 * kStreamWaves), 0, s, p,
+                         h->d_blob, lay.data, lay.stride, lay.lens, lay.len, n, d_counts, d_slots,
+                         slot_cap);
+      g_last_kernel = "k_stream_findall";
+      HIP_TRY(hipGetLastError());
+      tm.stop();
+    } else {
+      ScanTimer tm(s);
+      hipLaunchKernelGGL(k_findall<FA_COUNT>, dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s,
+                         p, h->d_blob, lay, n, d_counts, (const int64_t*)nullptr, (int32_t*)nullptr,
+                         (int64_t)0);
+      g_last_kernel = "k_findall_count";
+      HIP_TRY(hipGetLastError());
+      tm.stop();
+    }
+  }
+  if (int rc = device_scan<int32_t>(d_counts, n, d_prefix, d_total, s)) return rc;
+  int64_t tot = 0;
+  HIP_TRY(hipMemcpyAsync(&tot, d_total, sizeof tot, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (total) *total = tot;
+  int rc = MRX_OK;
+  if (tot > span_cap) {
+    rc = fail(MRX_E_CAPACITY, "span buffer too small: need " + std::to_string(tot));
+  } else if (n > 0 && tot > 0) {
+    if (stream_ok) {
+      hipLaunchKernelGGL(k_compact, dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s, p,
+                         h->d_blob, lay, n, d_counts, d_prefix, d_slots, slot_cap, d_spans, span_cap);
+    } else {
+      hipLaunchKernelGGL(k_findall<FA_EMIT>, dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s, p,
+                         h->d_blob, lay, n, (int32_t*)nullptr, d_prefix, d_spans, span_cap);
+    }
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(hipFreeAsync(d_counts, s));
+  HIP_TRY(hipFreeAsync(d_total, s));
+  if (d_slots) HIP_TRY(hipFreeAsync(d_slots, s));
+  return rc;
+}
+
+}  // namespace
+
+namespace {
+struct DevBatch {
+  uint8_t* data = nullptr;
+  int64_t* offsets = nullptr;
+  int64_t nbytes = 0;
+  ~DevBatch() { if (data) (void)hipFree(data); if (offsets) (void)hipFree(offsets); }
+  int upload(const uint8_t* h_data, const int64_t* h_off, int64_t n) {
+    if (n < 0 || !h_off) return fail(MRX_E_ARGUMENT, "bad batch");
+    nbytes = h_off[n];
+    HIP_TRY(hipMalloc((void**)&data, (size_t)nbytes + 64));
+    HIP_TRY(hipMalloc((void**)&offsets, sizeof(int64_t) * (n + 1)));
+    if (nbytes) HIP_TRY(hipMemcpy(data, h_data + h_off[0], (size_t)(nbytes - h_off[0]), hipMemcpyHostToDevice));
+    std::vector<int64_t> rel(n + 1);
+    for (int64_t i = 0; i <= n; ++i) rel[i] = h_off[i] - h_off[0];
+    HIP_TRY(hipMemcpy(offsets, rel.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice));
+    return MRX_OK;
+  }
+};
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  int alloc(size_t count) { HIP_TRY(hipMalloc((void**)&p, sizeof(T) * (count ? count : 1))); return MRX_OK; }
+};
+}  // namespace
+
+extern "C" {
+
+int mrx_compile(const char* pattern, size_t pattern_len, mrx_handle** out) {
+  if (!out || (!pattern && pattern_len)) return fail(MRX_E_ARGUMENT, "null argument");
+  *out = nullptr;
+  mrx_handle* h = new mrx_handle();
+  try {
+    build_plan(std::string(pattern, pattern_len), h->hp);
+  } catch (const SyntaxError& e) {
+    delete h;
+    return fail(MRX_E_SYNTAX, e.what());
+  } catch (const std::exception& e) {
+    delete h;
+    return fail(MRX_E_UNSUPPORTED, e.what());
+  }
+  *out = h;
+  return MRX_OK;
+}
+
+void mrx_free(mrx_handle* h) {
+  if (!h) return;
+  if (h->d_blob) (void)hipFree(h->d_blob);
+  delete h;
+}
+
+const char* mrx_last_error(void) { return g_err.c_str(); }
+const char* mrx_engine_type(const mrx_handle* h) { return h ? h->hp.engine_type.c_str() : ""; }
+const char* mrx_stats(const mrx_handle* h) { return h ? h->hp.stats.c_str() : ""; }
+int mrx_num_groups(const mrx_handle* h) { return (h && h->hp.fixed_total >= 0) ? h->hp.fixed_ngroups : 0; }
+const char* mrx_version(void) { return "mrx-hip 0.1 (gfx950)"; }
+
+size_t mrx_describe(const mrx_handle* h, char* buf, size_t cap) {
+  if (!h) return 0;
+  const std::string s = describe_plan(h->hp);
+  if (buf && cap) {
+    const size_t k = s.size() < cap - 1 ? s.size() : cap - 1;
+    std::memcpy(buf, s.data(), k);
+    buf[k] = 0;
+  }
+  return s.size();
+}
+
+int mrx_match_first_dev(const mrx_handle* h, const uint8_t* d, const int64_t* off, int64_t n,
+                        int32_t* s, int32_t* e, void* st) {
+  return run_match<OP_MATCH_FIRST>(h, Layout{d, off, 0, nullptr, 0}, n, s, e, nullptr, st);
+}
+int mrx_search_dev(const mrx_handle* h, const uint8_t* d, const int64_t* off, int64_t n, int32_t* s,
+                   int32_t* e, void* st) {
+  return run_match<OP_SEARCH>(h, Layout{d, off, 0, nullptr, 0}, n, s, e, nullptr, st);
+}
+int mrx_is_match_dev(const mrx_handle* h, const uint8_t* d, const int64_t* off, int64_t n,
+                     uint8_t* f, void* st) {
+  return run_match<OP_IS_MATCH>(h, Layout{d, off, 0, nullptr, 0}, n, nullptr, nullptr, f, st);
+}
+int mrx_captures_dev(const mrx_handle* h, const uint8_t* d, const int64_t* off, int64_t n,
+                     int32_t* spans, void* st) {
+  return run_match<OP_CAPTURES>(h, Layout{d, off, 0, nullptr, 0}, n, spans, nullptr, nullptr, st);
+}
+int mrx_findall_dev(const mrx_handle* h, const uint8_t* d, const int64_t* off, int64_t n,
+                    int64_t* prefix, int32_t* spans, int64_t cap, int64_t* total, void* st) {
+  return run_findall(h, Layout{d, off, 0, nullptr, 0}, n, prefix, spans, cap, total, st);
+}
+int mrx_findall_strided_dev(const mrx_handle* h, const uint8_t* d, int64_t stride,
+                            const int32_t* lens, int32_t len, int64_t n, int64_t* prefix,
+                            int32_t* spans, int64_t cap, int64_t* total, void* st) {
+  if (stride <= 0) return fail(MRX_E_ARGUMENT, "stride must be positive");
+  if (!lens && (len < 0 || len > stride)) return fail(MRX_E_ARGUMENT, "len must be in [0, stride]");
+  return run_findall(h, Layout{d, nullptr, stride, lens, len}, n, prefix, spans, cap, total, st);
+}
+
+int mrx_count_dev(const mrx_handle* h, const uint8_t* d, const int64_t* off, int64_t n,
+                  int32_t* counts, void* st) {
+  if (!h) return fail(MRX_E_ARGUMENT, "null handle");
+  if (int rc = check_search_supported(h)) return rc;
+  if (int rc = check_lds(h)) return rc;
+  if (int rc = ensure_device(h)) return rc;
+  if (n <= 0) return MRX_OK;
+  hipStream_t s = (hipStream_t)st;
+  ScanTimer tm(s);
+  hipLaunchKernelGGL(k_findall<FA_COUNT>, dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s,
+                     h->hp.dev, h->d_blob, Layout{d, off, 0, nullptr, 0}, n, counts,
+                     (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0);
+  g_last_kernel = "k_findall_count";
+  HIP_TRY(hipGetLastError());
+  tm.stop();
+  return MRX_OK;
+}
+
+int mrx_sub_dev(const mrx_handle* h, const char* repl, size_t repl_len, int64_t count,
+                const uint8_t* d, const int64_t* off, int64_t n, int64_t* out_off, uint8_t* out,
+                int64_t out_cap, int64_t* total_bytes, void* st) {
+  if (!h) return fail(MRX_E_ARGUMENT, "null handle");
+  if (n < 0) return fail(MRX_E_ARGUMENT, "negative batch size");
+  if (int rc = check_search_supported(h)) return rc;
+  const std::string r(repl ? repl : "", repl_len);
+  const bool groups = repl_has_group_refs(r);
+  std::vector<ReplSeg> tpl;
+  if (groups) {
+    if (h->hp.fixed_total < 0)
+      return fail(MRX_E_UNSUPPORTED,
+                  "sub() with \\1..\\9 on a pattern outside the fixed-width (\\d{N}) group form "
+                  "uses NFAEngine.match_next_with_groups (backtracking NFA, nfa.mojo:500-574)");
+    tpl = parse_repl_template(r);
+  }
+  if (int rc = check_lds(h)) return rc;
+  if (int rc = ensure_device(h)) return rc;
+  hipStream_t s = (hipStream_t)st;
+  uint8_t* d_repl = nullptr;
+  ReplSeg* d_tpl = nullptr;
+  int64_t *d_sizes = nullptr, *d_total = nullptr;
+  HIP_TRY(hipMallocAsync((void**)&d_repl, r.size() + 16, s));
+  HIP_TRY(hipMallocAsync((void**)&d_tpl, sizeof(ReplSeg) * (tpl.size() + 1), s));
+  HIP_TRY(hipMallocAsync((void**)&d_sizes, sizeof(int64_t) * (n > 0 ? n : 1), s));
+  HIP_TRY(hipMallocAsync((void**)&d_total, sizeof(int64_t), s));
+  if (!r.empty()) HIP_TRY(hipMemcpyAsync(d_repl, r.data(), r.size(), hipMemcpyHostToDevice, s));
+  if (!tpl.empty())
+    HIP_TRY(hipMemcpyAsync(d_tpl, tpl.data(), sizeof(ReplSeg) * tpl.size(), hipMemcpyHostToDevice, s));
+  const Layout lay{d, off, 0, nullptr, 0};
+  if (n > 0) {
+    ScanTimer tm(s);
+    hipLaunchKernelGGL(k_sub<SUB_SIZE>, dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s,
+                       h->hp.dev, h->d_blob, lay, n, d_repl, (int)r.size(), groups ? 1 : 0, d_tpl,
+                       (int)tpl.size(), (long long)count, d_sizes, (const int64_t*)nullptr,
+                       (uint8_t*)nullptr, (int64_t)0);
+    g_last_kernel = "k_sub_size";
+    HIP_TRY(hipGetLastError());
+    tm.stop();
+  }
+  if (int rc = device_scan<int64_t>(d_sizes, n, out_off, d_total, s)) return rc;
+  int64_t tot = 0;
+  HIP_TRY(hipMemcpyAsync(&tot, d_total, sizeof tot, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (total_bytes) *total_bytes = tot;
+  int rc = MRX_OK;
+  if (tot > out_cap) {
+    rc = fail(MRX_E_CAPACITY, "output buffer too small: need " + std::to_string(tot));
+  } else if (n > 0 && tot > 0) {
+    hipLaunchKernelGGL(k_sub<SUB_EMIT>, dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s,
+                       h->hp.dev, h->d_blob, lay, n, d_repl, (int)r.size(), groups ? 1 : 0, d_tpl,
+                       (int)tpl.size(), (long long)count, (int64_t*)nullptr, out_off, out, out_cap);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s));
+  }
+  HIP_TRY(hipFreeAsync(d_repl, s));
+  HIP_TRY(hipFreeAsync(d_tpl, s));
+  HIP_TRY(hipFreeAsync(d_sizes, s));
+  HIP_TRY(hipFreeAsync(d_total, s));
+  return rc;
+}
+
+// ---- host-buffer wrappers -----------------------------------------------------------
+
+int mrx_match_first_batch(const mrx_handle* h, const uint8_t* data, const int64_t* off, int64_t n,
+                          int32_t* start, int32_t* end) {
+  DevBatch b; DevBuf<int32_t> s, e;
+  if (int rc = b.upload(data, off, n)) return rc;
+  if (int rc = s.alloc(n)) return rc;
+  if (int rc = e.alloc(n)) return rc;
+  if (int rc = mrx_match_first_dev(h, b.data, b.offsets, n, s.p, e.p, nullptr)) return rc;
+  HIP_TRY(hipMemcpy(start, s.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(end, e.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+  return MRX_OK;
+}
+int mrx_search_batch(const mrx_handle* h, const uint8_t* data, const int64_t* off, int64_t n,
+                     int32_t* start, int32_t* end) {
+  DevBatch b; DevBuf<int32_t> s, e;
+  if (int rc = b.upload(data, off, n)) return rc;
+  if (int rc = s.alloc(n)) return rc;
+  if (int rc = e.alloc(n)) return rc;
+  if (int rc = mrx_search_dev(h, b.data, b.offsets, n, s.p, e.p, nullptr)) return rc;
+  HIP_TRY(hipMemcpy(start, s.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(end, e.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+  return MRX_OK;
+}
+int mrx_is_match_batch(const mrx_handle* h, const uint8_t* data, const int64_t* off, int64_t n,
+                       uint8_t* flag) {
+  DevBatch b; DevBuf<uint8_t> f;
+  if (int rc = b.upload(data, off, n)) return rc;
+  if (int rc = f.alloc(n)) return rc;
+  if (int rc = mrx_is_match_dev(h, b.data, b.offsets, n, f.p, nullptr)) return rc;
+  HIP_TRY(hipMemcpy(flag, f.p, n, hipMemcpyDeviceToHost));
+  return MRX_OK;
+}
+int mrx_findall_batch(const mrx_handle* h, const uint8_t* data, const int64_t* off, int64_t n,
+                      int64_t* counts_prefix, int32_t* spans, int64_t span_cap, int64_t* total) {
+  DevBatch b; DevBuf<int64_t> pre; DevBuf<int32_t> sp;
+  if (int rc = b.upload(data, off, n)) return rc;
+  if (int rc = pre.alloc(n + 1)) return rc;
+  if (int rc = sp.alloc(2 * (size_t)span_cap)) return rc;
+  int64_t tot = 0;
+  const int rc = mrx_findall_dev(h, b.data, b.offsets, n, pre.p, sp.p, span_cap, &tot, nullptr);
+  if (total) *total = tot;
+  if (rc != MRX_OK && rc != MRX_E_CAPACITY) return rc;
+  HIP_TRY(hipMemcpy(counts_prefix, pre.p, sizeof(int64_t) * (n + 1), hipMemcpyDeviceToHost));
+  if (rc == MRX_OK && tot > 0)
+    HIP_TRY(hipMemcpy(spans, sp.p, sizeof(int32_t) * 2 * tot, hipMemcpyDeviceToHost));
+  return rc;
+}
+int mrx_captures_batch(const mrx_handle* h, const uint8_t* data, const int64_t* off, int64_t n,
+                       int32_t* spans) {
+  DevBatch b; DevBuf<int32_t> sp;
+  if (int rc = b.upload(data, off, n)) return rc;
+  const size_t per = (size_t)(mrx_num_groups(h) + 1) * 2;
+  if (int rc = sp.alloc(per * n)) return rc;
+  if (int rc = mrx_captures_dev(h, b.data, b.offsets, n, sp.p, nullptr)) return rc;
+  HIP_TRY(hipMemcpy(spans, sp.p, sizeof(int32_t) * per * n, hipMemcpyDeviceToHost));
+  return MRX_OK;
+}
+int mrx_sub_batch(const mrx_handle* h, const char* repl, size_t repl_len, int64_t count,
+                  const uint8_t* data, const int64_t* off, int64_t n, int64_t* out_offsets,
+                  uint8_t* out_data, int64_t out_cap, int64_t* total_bytes) {
+  DevBatch b; DevBuf<int64_t> oo; DevBuf<uint8_t> od;
+  if (int rc = b.upload(data, off, n)) return rc;
+  if (int rc = oo.alloc(n + 1)) return rc;
+  if (int rc = od.alloc((size_t)out_cap)) return rc;
+  int64_t tot = 0;
+  const int rc = mrx_sub_dev(h, repl, repl_len, count, b.data, b.offsets, n, oo.p, od.p, out_cap,
+                             &tot, nullptr);
+  if (total_bytes) *total_bytes = tot;
+  if (rc != MRX_OK && rc != MRX_E_CAPACITY) return rc;
+  HIP_TRY(hipMemcpy(out_offsets, oo.p, sizeof(int64_t) * (n + 1), hipMemcpyDeviceToHost));
+  if (rc == MRX_OK && tot > 0) HIP_TRY(hipMemcpy(out_data, od.p, (size_t)tot, hipMemcpyDeviceToHost));
+  return rc;
+}
+
+void mrx_timing_reset(void) { g_scan_ms = 0; g_scan_launches = 0; }
+void mrx_timing_enable(int on) { g_timing = on != 0; }
+double mrx_timing_scan_ms(int64_t* launches) {
+  if (launches) *launches = g_scan_launches;
+  return g_scan_launches ? g_scan_ms / (double)g_scan_launches : 0.0;
+}
+const char* mrx_last_kernel_name(void) { return g_last_kernel; }
+
+}  // extern "C"

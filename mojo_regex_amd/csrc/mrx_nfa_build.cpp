@@ -1,0 +1,267 @@
+// PikeVM bytecode (src/regex/pikevm.mojo:124-333), first-byte filter
+// (:367-416) and eager determinisation of the LazyDFA (:664-987).
+#include <map>
+
+#include "mrx_engines.hpp"
+
+namespace mrx {
+namespace {
+
+struct Emitter {
+  const Ast& a;
+  Program& p;
+
+  int emit(Op op, int a0 = 0, int a1 = 0) {
+    p.insts.push_back({op, a0, a1});
+    return (int)p.insts.size() - 1;
+  }
+  int len() const { return (int)p.insts.size(); }
+
+  int class_index(const std::array<uint8_t, 256>& t) {  // pikevm.mojo:101-109
+    for (size_t i = 0; i < p.classes.size(); ++i)
+      if (p.classes[i] == t) return (int)i;
+    p.classes.push_back(t);
+    return (int)p.classes.size() - 1;
+  }
+
+  void node(const Node& n) {  // pikevm.mojo:142-164
+    switch (n.type) {
+      case N_GROUP:
+        for (int i = 0; i < a.nkids(n); ++i) quantified(a.child(n, i));
+        break;
+      case N_OR: alt(n); break;
+      case N_ELEMENT:
+        if (a.has_value(n)) emit(OP_BYTE, (unsigned char)a.value(n)[0]);
+        break;
+      case N_DIGIT: case N_WORD: case N_SPACE: case N_RANGE: char_class(n); break;
+      case N_WILDCARD: emit(OP_ANY); break;
+      case N_START: emit(OP_START_ANCHOR); break;
+      case N_END: emit(OP_END_ANCHOR); break;
+      default: break;
+    }
+  }
+
+  void quantified(const Node& n) {  // pikevm.mojo:174-229
+    const int mn = n.min, mx = n.max;
+    if (mn == 1 && mx == 1) { node(n); return; }
+    if (mn == 0 && mx == 1) {
+      const int sp = emit(OP_SPLIT);
+      const int body = len();
+      node(n);
+      p.insts[sp].a0 = body; p.insts[sp].a1 = len();
+      return;
+    }
+    if (mn == mx && mn > 1) { for (int i = 0; i < mn; ++i) node(n); return; }
+    if (mx > 0) {
+      for (int i = 0; i < mn; ++i) node(n);
+      std::vector<int> splits;
+      for (int i = 0; i < mx - mn; ++i) { splits.push_back(emit(OP_SPLIT)); node(n); }
+      const int after = len();
+      for (int s : splits) { p.insts[s].a0 = s + 1; p.insts[s].a1 = after; }
+      return;
+    }
+    if (mx == -1) {
+      for (int i = 0; i < mn; ++i) node(n);
+      const int sp = emit(OP_SPLIT);
+      const int body = len();
+      node(n);
+      emit(OP_JUMP, sp);
+      p.insts[sp].a0 = body; p.insts[sp].a1 = len();
+      return;
+    }
+  }
+
+  void alt(const Node& n) {  // pikevm.mojo:232-254
+    const int k = a.nkids(n);
+    if (k == 0) return;
+    if (k == 1) { node(a.child(n, 0)); return; }
+    const int sp = emit(OP_SPLIT);
+    const int l = len();
+    node(a.child(n, 0));
+    const int jp = emit(OP_JUMP);
+    const int r = len();
+    node(a.child(n, 1));
+    p.insts[sp].a0 = l; p.insts[sp].a1 = r;
+    p.insts[jp].a0 = len();
+  }
+
+  void char_class(const Node& n) {  // pikevm.mojo:271-333
+    std::array<uint8_t, 256> t{};
+    auto range = [&](int lo, int hi) { for (int c = lo; c <= hi && c < 256; ++c) t[c] = 1; };
+    if (n.type == N_DIGIT) range('0', '9');
+    else if (n.type == N_WORD) { range('a', 'z'); range('A', 'Z'); range('0', '9'); t['_'] = 1; }
+    else if (n.type == N_SPACE) { for (unsigned char c : std::string(" \t\n\r\f")) t[c] = 1; }
+    else if (n.type == N_RANGE && a.has_value(n)) {
+      std::string_view in = a.value(n);
+      if (in.size() >= 2 && in.front() == '[' && in.back() == ']') in = in.substr(1, in.size() - 2);
+      const size_t m = in.size();
+      for (size_t j = 0; j < m;) {
+        const int c0 = (unsigned char)in[j];
+        if (j + 1 < m && c0 == '\\') {
+          const int nc = (unsigned char)in[j + 1];
+          if (nc == 's') { for (unsigned char c : std::string(" \t\n\r\f")) t[c] = 1; }
+          else if (nc == 'd') range('0', '9');
+          else if (nc == 'w') { range('a', 'z'); range('A', 'Z'); range('0', '9'); t['_'] = 1; }
+          else t[nc] = 1;
+          j += 2;
+        } else if (j + 2 < m && in[j + 1] == '-') {
+          range(c0, (unsigned char)in[j + 2]);
+          j += 3;
+        } else {
+          t[c0] = 1;
+          ++j;
+        }
+      }
+    }
+    if (!n.positive)
+      for (auto& x : t) x = 1 - x;
+    emit(OP_CLASS, class_index(t));
+  }
+};
+
+struct Closure {
+  const Program& p;
+  // _add_state, pikevm.mojo:604-648.  at_text_start / at_text_end decide ^ / $.
+  void add(std::vector<uint8_t>& seen, int& leaves, int pc, bool at_start, bool at_end) const {
+    if (pc >= (int)p.insts.size() || seen[pc]) return;
+    const Inst& in = p.insts[pc];
+    switch (in.op) {
+      case OP_SPLIT:
+        seen[pc] = 1;
+        add(seen, leaves, in.a0, at_start, at_end);
+        add(seen, leaves, in.a1, at_start, at_end);
+        break;
+      case OP_JUMP:
+        seen[pc] = 1;
+        add(seen, leaves, in.a0, at_start, at_end);
+        break;
+      case OP_START_ANCHOR:
+        if (at_start) { seen[pc] = 1; add(seen, leaves, pc + 1, at_start, at_end); }
+        break;
+      case OP_END_ANCHOR:
+        if (at_end) { seen[pc] = 1; add(seen, leaves, pc + 1, at_start, at_end); }
+        break;
+      default:
+        seen[pc] = 1;
+        ++leaves;
+        break;
+    }
+  }
+  bool has_match(const std::vector<uint8_t>& set) const {
+    for (size_t pc = 0; pc < p.insts.size(); ++pc)
+      if (set[pc] && p.insts[pc].op == OP_MATCH) return true;
+    return false;
+  }
+  bool steps(int pc, int ch) const {
+    const Inst& in = p.insts[pc];
+    switch (in.op) {
+      case OP_BYTE: return ch == in.a0;
+      case OP_CLASS: return p.classes[in.a0][ch] != 0;
+      case OP_ANY: return ch != 10;
+      case OP_RANGE: return ch >= in.a0 && ch <= in.a1;
+      default: return false;
+    }
+  }
+};
+
+}  // namespace
+
+void compile_program(const Ast& a, Program& p) {  // pikevm.mojo:124-139
+  p = Program();
+  Emitter e{a, p};
+  if (a.root.type == N_RE && a.nkids(a.root) > 0) e.node(a.child(a.root, 0));
+  e.emit(OP_MATCH);
+}
+
+void build_lazy(const Program& p, LazyTables& out, int max_dfa_states) {
+  out = LazyTables();
+  const int n = (int)p.insts.size();
+  out.supported = n <= kPikeMaxStates;  // PikeVMEngine.is_supported, pikevm.mojo:363-365
+  if (!out.supported || n == 0) return;
+
+  // first-byte filter, pikevm.mojo:367-416 (matching_bytes counts duplicates)
+  {
+    std::vector<uint8_t> seen(n, 0);
+    std::vector<int> st{0};
+    int matching = 0;
+    bool abandoned = false;
+    while (!st.empty() && !abandoned) {
+      const int pc = st.back(); st.pop_back();
+      if (pc >= n || seen[pc]) continue;
+      seen[pc] = 1;
+      const Inst& in = p.insts[pc];
+      switch (in.op) {
+        case OP_BYTE: out.first_byte[in.a0] = 1; ++matching; break;
+        case OP_CLASS:
+          for (int c = 0; c < 256; ++c)
+            if (p.classes[in.a0][c]) { out.first_byte[c] = 1; ++matching; }
+          break;
+        case OP_RANGE:
+          for (int c = in.a0; c <= in.a1; ++c) { out.first_byte[c] = 1; ++matching; }
+          break;
+        case OP_ANY: case OP_MATCH: abandoned = true; break;
+        case OP_SPLIT: st.push_back(in.a0); st.push_back(in.a1); break;
+        case OP_JUMP: st.push_back(in.a0); break;
+        case OP_START_ANCHOR: case OP_END_ANCHOR: st.push_back(pc + 1); break;
+      }
+    }
+    out.has_filter = !abandoned && matching < 128;
+    if (out.has_filter) {
+      int bucket = 0;
+      for (int c = 0; c < 256; ++c)
+        if (out.first_byte[c]) {
+          const uint8_t bit = (uint8_t)(1u << (bucket & 7));
+          out.lo_tbl[c & 15] |= bit; out.hi_tbl[(c >> 4) & 15] |= bit;
+          ++bucket;
+        }
+    }
+  }
+
+  // Eager version of LazyDFA._get_or_create_state_for_pos / _compute_transition
+  // (pikevm.mojo:869-978).  The start closure is built as upstream with pos = 0
+  // and text_len = 0, so '^' (and '$') are satisfied there at every start
+  // position; afterwards pos+1 is never 0, and '$' programs are refused by the
+  // router, so closures after a byte are position independent.
+  Closure cl{p};
+  std::map<std::vector<uint8_t>, int> ids;
+  std::vector<std::vector<uint8_t>> sets;
+  {
+    std::vector<uint8_t> seen(n, 0);
+    int leaves = 0;
+    cl.add(seen, leaves, 0, /*at_start=*/true, /*at_end=*/true);
+    if (leaves == 0 && !cl.has_match(seen)) { out.start_dead = true; return; }
+    ids[seen] = 0;
+    sets.push_back(seen);
+  }
+  for (size_t s = 0; s < sets.size(); ++s) {
+    out.trans.emplace_back();
+    out.trans.back().fill(-1);
+    out.is_match.push_back(cl.has_match(sets[s]) ? 1 : 0);
+  }
+  for (size_t s = 0; s < sets.size(); ++s) {
+    for (int ch = 0; ch < 256; ++ch) {
+      std::vector<uint8_t> nxt(n, 0);
+      int leaves = 0;
+      const std::vector<uint8_t> cur = sets[s];
+      for (int pc = 0; pc < n; ++pc)
+        if (cur[pc] && cl.steps(pc, ch)) cl.add(nxt, leaves, pc + 1, false, false);
+      if (leaves == 0) continue;  // LAZY_DFA_DEAD
+      auto it = ids.find(nxt);
+      int id;
+      if (it == ids.end()) {
+        id = (int)sets.size();
+        if (id >= max_dfa_states) { out.too_large = true; return; }
+        ids[nxt] = id;
+        sets.push_back(nxt);
+        out.trans.emplace_back();
+        out.trans.back().fill(-1);
+        out.is_match.push_back(cl.has_match(nxt) ? 1 : 0);
+      } else {
+        id = it->second;
+      }
+      out.trans[s][ch] = id;
+    }
+  }
+}
+
+}  // namespace mrx

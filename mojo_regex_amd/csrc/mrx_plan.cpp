@@ -1,0 +1,585 @@
+// Routing + device payload construction.  See mrx_plan.hpp.
+#include "mrx_plan.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <set>
+#include <sstream>
+
+namespace mrx {
+namespace {
+
+// _is_simple_pattern_skip_prefilter, matcher.mojo:447-532
+bool skip_prefilter(const std::string& p) {
+  const int n = (int)p.size();
+  if (n <= 4) return true;
+  bool q = false, alt = false, anch = false, wild = false;
+  for (int i = 0; i < n; ++i) {
+    const char c = p[i];
+    if (c == '*' || c == '+' || c == '?') q = true;
+    else if (c == '|') alt = true;
+    else if (c == '^' && i == 0) anch = true;
+    else if (c == '$' && i == n - 1) anch = true;
+    else if (c == '.') wild = true;
+  }
+  if (q && !alt && !wild) return true;
+  if (alt && n <= 10 && !wild) {
+    const int bars = (int)std::count(p.begin(), p.end(), '|');
+    if (bars >= n / 3) return true;
+  }
+  if (anch && n <= 10) return true;
+  if (wild && n >= 8) return false;
+  if (alt && n >= 12) return false;
+  if (n >= 15) return false;
+  return true;
+}
+
+bool ast_has_anchors(const Ast& a, const Node& n) {  // matcher.mojo:168-178
+  if (n.type == N_START || n.type == N_END) return true;
+  if (n.type == N_GROUP || n.type == N_RE)
+    for (int i = 0; i < a.nkids(n); ++i)
+      if (ast_has_anchors(a, a.child(n, i))) return true;
+  return false;
+}
+
+int rare_required_byte(const Ast& a, const std::array<uint8_t, 256>& lookup) {
+  // matcher.mojo:122-165
+  const Node* n = &a.root;
+  if (n->type == N_RE && a.nkids(*n) == 1) n = &a.child(*n, 0);
+  if (n->type != N_GROUP) return -1;
+  for (int i = 0; i < a.nkids(*n); ++i) {
+    const Node& c = a.child(*n, i);
+    if (c.type != N_ELEMENT || c.min < 1) continue;
+    auto v = a.value(c);
+    if (v.size() != 1) continue;
+    const int b = (unsigned char)v[0];
+    if (lookup[b] == 0) return b;
+  }
+  return -1;
+}
+
+// _detect_fixed_width_groups, matcher.mojo:1485-1586
+bool detect_fixed_width(const std::string& p, std::vector<int>& segs) {
+  const int n = (int)p.size();
+  int i = 0, lit = 0;
+  segs.clear();
+  while (i < n) {
+    if (p[i] == '(') {
+      if (lit > 0) { segs.push_back(-lit); lit = 0; }
+      if (i + 1 < n && p[i + 1] == '?') return false;
+      ++i;
+      if (i + 1 >= n || p[i] != '\\' || p[i + 1] != 'd') return false;
+      i += 2;
+      if (i < n && p[i] == '{') {
+        ++i;
+        const int ns = i;
+        while (i < n && p[i] >= '0' && p[i] <= '9') ++i;
+        if (i == ns || i >= n || p[i] != '}') return false;
+        long w = 0;
+        for (int j = ns; j < i; ++j) w = w * 10 + (p[j] - '0');
+        ++i;
+        segs.push_back((int)w);
+      } else if (i < n && p[i] == ')') {
+        segs.push_back(1);
+      } else {
+        return false;
+      }
+      if (i >= n || p[i] != ')') return false;
+      ++i;
+    } else if (p[i] == '|' || p[i] == '[') {
+      return false;
+    } else {
+      if (p[i] == '\\' && i + 1 < n) { ++lit; i += 2; }
+      else { ++lit; ++i; }
+    }
+  }
+  for (int s : segs)
+    if (s > 0) return true;
+  return false;
+}
+
+// ---- single-pass ("streaming") search automaton --------------------------------
+// findall's restart-per-position loop (dfa.mojo:2074-2128) visits candidate starts
+// in increasing order.  The streaming kernel replaces it by ONE left-to-right pass
+// that, when a walk dies at byte q, restarts at q itself.  That is equivalent to
+// the reference loop iff (a) a successful walk always dies right at its last
+// accepting position and (b) when a walk started at p fails at q, every walk
+// started in (p, q) fails too.  Both are decided here on the actual table by
+// exploring pairs (state of the earlier walk, state of a later walk).
+struct SearchAutomaton {
+  int n = 0;                                  // states, 0 = idle/start
+  std::vector<std::array<int, 256>> next;     // -1 dead
+  std::vector<uint8_t> acc;
+  std::array<uint8_t, 256> allowed{};         // bytes a walk may start on
+};
+
+bool check_streamable(const SearchAutomaton& s, std::string& why) {
+  if (s.acc[0]) { why = "start state accepts (empty matches)"; return false; }
+  for (int q = 0; q < s.n; ++q)
+    for (int c = 0; c < 256; ++c)
+      if (s.next[q][c] == 0) { why = "transition back into the start state"; return false; }
+  // (a) accept-closed
+  for (int q = 0; q < s.n; ++q)
+    if (s.acc[q])
+      for (int c = 0; c < 256; ++c) {
+        const int t = s.next[q][c];
+        if (t >= 0 && !s.acc[t]) { why = "accepting state continues into a non-accepting one"; return false; }
+      }
+  // reachable states
+  std::vector<uint8_t> reach(s.n, 0);
+  std::vector<int> st;
+  for (int c = 0; c < 256; ++c)
+    if (s.allowed[c] && s.next[0][c] > 0 && !reach[s.next[0][c]]) {
+      reach[s.next[0][c]] = 1; st.push_back(s.next[0][c]);
+    }
+  while (!st.empty()) {
+    const int q = st.back(); st.pop_back();
+    for (int c = 0; c < 256; ++c) {
+      const int t = s.next[q][c];
+      if (t > 0 && !reach[t]) { reach[t] = 1; st.push_back(t); }
+    }
+  }
+  // (b) pair exploration: x = earlier (still failing) walk, y = later walk
+  // y == -2: the later walk starts on the next byte ("fresh")
+  std::set<std::pair<int, int>> seen;
+  std::vector<std::pair<int, int>> work;
+  for (int x = 1; x < s.n; ++x)
+    if (reach[x] && !s.acc[x]) work.push_back({x, -2});
+  while (!work.empty()) {
+    auto [x, y] = work.back(); work.pop_back();
+    if (!seen.insert({x, y}).second) continue;
+    for (int c = 0; c < 256; ++c) {
+      const int xn = s.next[x][c];
+      const bool fresh = (y == -2);
+      const int yn = fresh ? (s.allowed[c] ? s.next[0][c] : -1) : s.next[y][c];
+      if (xn >= 0 && s.acc[xn]) continue;  // earlier walk succeeds: not a failed walk
+      if (yn < 0) continue;                // later walk dies here
+      if (xn < 0) {
+        if (fresh) continue;               // later walk starts at the death byte: that IS the restart
+        why = "a later start survives the byte that kills the earlier walk";
+        return false;
+      }
+      if (xn == yn) continue;              // merged
+      if (s.acc[yn]) { why = "a later start accepts while the earlier walk is still undecided"; return false; }
+      work.push_back({xn, yn});
+    }
+  }
+  return true;
+}
+
+// Build the byte-column table for the 4-state streaming kernel:
+// col[byte] = 4 entries x 4 bit, entry(q) = next<<2 | EMIT<<1 | NEWSTART
+bool build_stream_cols(const SearchAutomaton& s, const std::vector<int>& remap, int nlive,
+                       std::vector<uint16_t>& cols) {
+  if (nlive > 4) return false;
+  cols.assign(256, 0);
+  for (int c = 0; c < 256; ++c) {
+    uint16_t col = 0;
+    for (int q = 0; q < s.n; ++q) {
+      if (remap[q] < 0) continue;
+      int t = (q == 0) ? (s.allowed[c] ? s.next[0][c] : -1) : s.next[q][c];
+      bool emit = false, newstart = false;
+      if (q == 0) {
+        newstart = t > 0;
+      } else if (t < 0) {  // walk dies: emit if it had accepted, then restart on this byte
+        emit = s.acc[q] != 0;
+        t = s.allowed[c] ? s.next[0][c] : -1;
+        newstart = t > 0;
+      }
+      const int tn = t > 0 ? remap[t] : 0;
+      col |= (uint16_t)(((tn << 2) | (emit ? 2 : 0) | (newstart ? 1 : 0)) << (4 * remap[q]));
+    }
+    cols[c] = col;
+  }
+  return true;
+}
+
+void put(std::vector<uint8_t>& blob, const void* p, size_t n) {
+  const uint8_t* b = (const uint8_t*)p;
+  blob.insert(blob.end(), b, b + n);
+}
+void align(std::vector<uint8_t>& blob, size_t a) {
+  while (blob.size() % a) blob.push_back(0);
+}
+
+}  // namespace
+
+bool repl_has_group_refs(const std::string& r) {  // matcher.mojo:1472-1482
+  for (size_t i = 0; i + 1 < r.size(); ++i)
+    if (r[i] == '\\' && r[i + 1] >= '1' && r[i + 1] <= '9') return true;
+  return false;
+}
+
+std::vector<ReplSeg> parse_repl_template(const std::string& r) {  // matcher.mojo:1436-1469
+  std::vector<ReplSeg> segs;
+  const int n = (int)r.size();
+  int i = 0, lit_start = 0;
+  while (i < n) {
+    if (r[i] == '\\' && i + 1 < n) {
+      const char nc = r[i + 1];
+      if (nc >= '1' && nc <= '9') {
+        if (i > lit_start) segs.push_back({0, lit_start, i - lit_start});
+        segs.push_back({nc - '0', 0, 0});
+        i += 2;
+        lit_start = i;
+        continue;
+      }
+    }
+    ++i;
+  }
+  if (lit_start < n) segs.push_back({0, lit_start, n - lit_start});
+  return segs;
+}
+
+void build_plan(const std::string& pattern, HostPlan& hp) {
+  hp = HostPlan();
+  hp.pattern = pattern;
+  hp.wildcard_any = (pattern == ".*");  // matcher.mojo:435-444, 573-591
+
+  // fixed-width capture groups, CompiledRegex._try_precompute_fixed_sub (:1002-1035)
+  {
+    std::vector<int> segs;
+    if (detect_fixed_width(pattern, segs)) {
+      int ng = 0, total = 0;
+      bool lits = false, ok = true;
+      int off[10] = {0}, w[10] = {0};
+      for (int s : segs) {
+        if (s > 0) {
+          if (++ng > 9) { ok = false; break; }
+          off[ng] = total; w[ng] = s; total += s;
+        } else { lits = true; total += -s; }
+      }
+      if (ok && ng > 0) {
+        hp.fixed_total = total; hp.fixed_ngroups = ng; hp.fixed_concat = !lits;
+        std::memcpy(hp.fixed_off, off, sizeof off);
+        std::memcpy(hp.fixed_w, w, sizeof w);
+      }
+    }
+  }
+
+  Ast ast;
+  if (!hp.wildcard_any) {
+    parse(pattern, ast);  // may throw SyntaxError
+    hp.complexity = classify(ast);
+    hp.use_pure_dfa = should_use_pure_dfa(ast);
+    const bool analyze = !skip_prefilter(pattern) && !hp.use_pure_dfa;
+    if (analyze) {  // matcher.mojo:609-654
+      LiteralSet ls = extract_literals(ast);
+      const bool anchors = ast_has_anchors(ast, ast.root);
+      const LiteralInfo* best = ls.best_literal();
+      bool exact = false;
+      if (best && !best->literal.empty()) {
+        hp.best_literal = best->literal;
+        const bool ops = pattern.find_first_of("*+?.|([{") != std::string::npos;
+        exact = best->is_required && has_literal_prefix(ast) && !anchors && !ops;
+      }
+      hp.literal_has_anchors = anchors;
+      hp.exact_literal = exact;
+      if (pattern.find('|') == std::string::npos && hp.best_literal.size() >= 2) {
+        hp.has_prefilter = true;  // create_optimized_prefilter, matcher.mojo:99-108
+        hp.prefilter_literal = hp.best_literal;
+      }
+    }
+    // NFAMatcher (always built), matcher.mojo:301-322 + NFAEngine flags, nfa.mojo:86-143
+    {
+      LiteralSet ls = extract_literals(ast);
+      if (const LiteralInfo* b = ls.best_literal()) {
+        if (b->is_prefix && b->is_required && b->literal.size() >= 1) hp.nfa_has_literal_opt = true;
+        else if (b->is_required && b->literal.size() >= 3) hp.nfa_has_literal_opt = true;
+      }
+      auto ends = [&](const char* s) {
+        const size_t k = std::strlen(s);
+        return pattern.size() >= k && pattern.compare(pattern.size() - k, k, s) == 0;
+      };
+      hp.nfa_ends_dotstar = ends(".*") && !ends("\\.*");
+      if (pattern.compare(0, 2, ".*") == 0) {
+        hp.nfa_starts_dotstar = true;
+        if (pattern.size() > 2 && (pattern[2] == '?' || pattern[2] == '*' || pattern[2] == '+'))
+          hp.nfa_starts_dotstar = false;
+      }
+      compile_program(ast, hp.program);
+      build_lazy(hp.program, hp.lazy, /*max_dfa_states=*/4096);
+    }
+    if (hp.complexity == CX_SIMPLE) {  // matcher.mojo:664-675
+      try {
+        compile_dfa_pattern(ast, hp.dfa);
+        hp.use_dfa = true;
+      } catch (const DfaCompileError&) {
+        hp.use_dfa = false;
+      }
+    }
+    if (hp.use_dfa && !hp.literal_has_anchors && hp.dfa.has_matcher)
+      hp.required_byte = rare_required_byte(ast, hp.dfa.matcher.lookup);
+  }
+
+  // get_engine_type / get_stats, matcher.mojo:900-918, 1139-1163
+  hp.engine_type = hp.use_dfa ? "DFA" : "NFA";
+  if (hp.exact_literal && !hp.literal_has_anchors) hp.engine_type += "+ExactLiteral";
+  else if (hp.has_prefilter && !hp.literal_has_anchors) hp.engine_type += "+Prefilter";
+  static const char* cxn[] = {"SIMPLE", "MEDIUM", "COMPLEX"};
+  hp.stats = "Pattern: '" + pattern + "', Engine: " + hp.engine_type +
+             ", Complexity: " + cxn[hp.complexity];
+
+  // ---- which operations stay on the hot path ----------------------------------
+  const bool lazy_ok = hp.lazy.supported && !hp.lazy.too_large;
+  const bool nfa_end = hp.program.has_end_anchor();
+  if (!hp.wildcard_any && !hp.use_dfa) {
+    // NFAMatcher.match_first, matcher.mojo:361-380
+    if (!(lazy_ok && !nfa_end))
+      hp.why_no_match_first = hp.lazy.too_large
+          ? "LazyDFA determinisation exceeds the state budget"
+          : "reference routes match_first to OnePass / the backtracking NFA ('$' in an NFA-routed pattern)";
+    // NFAMatcher.match_next / match_all, matcher.mojo:383-431
+    const bool fast_absent = !hp.nfa_has_literal_opt && !hp.nfa_starts_dotstar && !hp.nfa_ends_dotstar;
+    if (!(hp.lazy.supported && fast_absent))
+      hp.why_no_search = "reference routes search/findall to the backtracking NFA "
+                         "(literal prefilter or leading/trailing .* fast path)";
+    else if (nfa_end)
+      hp.why_no_search = "LazyDFA search with '$' depends on the transition cache history "
+                         "(pikevm.mojo:697-700); not reproducible";
+    else if (hp.lazy.too_large)
+      hp.why_no_search = "LazyDFA determinisation exceeds the state budget";
+  }
+  if (hp.use_dfa && hp.dfa.has_matcher && hp.dfa.matcher.num_ranges == 0 && !hp.dfa.scan_eligible) {
+    // nibble-table false positives (simd_ops.mojo:63-134) are SIMD-width dependent
+    // upstream; they are result-neutral unless a false-positive byte can start a
+    // walk or the start state accepts.
+    const ClassMatcher& m = hp.dfa.matcher;
+    for (int x = 0; x < 256; ++x)
+      if (!m.lookup[x] && m.nibble_hit(x) && (hp.dfa.accepting[0] || hp.dfa.trans[0][x] != -1)) {
+        hp.why_no_search = "first-class nibble-table false positives change results "
+                           "(depends on the reference build's SIMD width)";
+        break;
+      }
+  }
+
+  // ---- device payload ------------------------------------------------------------
+  DevPlan& d = hp.dev;
+  d = DevPlan();
+  d.required_byte = -1;
+  d.fixed_total = hp.fixed_total; d.fixed_ngroups = hp.fixed_ngroups;
+  d.fixed_concat = hp.fixed_concat ? 1 : 0;
+  std::memcpy(d.fixed_off, hp.fixed_off, sizeof d.fixed_off);
+  std::memcpy(d.fixed_w, hp.fixed_w, sizeof d.fixed_w);
+  std::vector<std::array<int, 256>> T;  // transition rows (int, -1 dead)
+  std::vector<uint8_t> acc;
+  std::array<uint8_t, 256> first{};
+  std::string lit, exact_lit, pre;  // engine literal, exact-literal bypass, prefilter literal
+  if (hp.wildcard_any) {
+    d.kind = PLAN_ANY;
+  } else if (hp.use_dfa) {
+    d.kind = PLAN_DFA;
+    const DfaEngine& e = hp.dfa;
+    for (int s = 0; s < e.nstates(); ++s) {
+      std::array<int, 256> row;
+      for (int c = 0; c < 256; ++c) row[c] = e.trans[s][c];
+      T.push_back(row);
+      acc.push_back(e.accepting[s]);
+    }
+    if (e.has_start_anchor) d.flags |= PF_START_ANCHOR;
+    if (e.has_end_anchor) d.flags |= PF_END_ANCHOR;
+    if (e.is_pure_literal) { d.flags |= PF_PURE_LITERAL; lit = e.literal; }
+    if (e.has_matcher) { d.flags |= PF_HAS_MATCHER; first = e.matcher.lookup; }
+    if (e.scan_eligible) d.flags |= PF_SCAN_ELIGIBLE;
+    if (!acc.empty() && acc[0]) d.flags |= PF_START_ACCEPTING;
+    if (hp.exact_literal && !hp.literal_has_anchors) { d.flags |= PF_EXACT_LITERAL; exact_lit = hp.best_literal; }
+    else if (hp.has_prefilter && !hp.literal_has_anchors) { d.flags |= PF_PREFILTER; pre = hp.prefilter_literal; }
+    d.required_byte = hp.required_byte;
+  } else {
+    d.kind = PLAN_LAZY;
+    const LazyTables& z = hp.lazy;
+    if (z.start_dead || !lazy_ok) d.flags |= PF_START_DEAD;
+    for (size_t s = 0; s < z.trans.size(); ++s) {
+      std::array<int, 256> row;
+      for (int c = 0; c < 256; ++c) row[c] = z.trans[s][c];
+      T.push_back(row);
+      acc.push_back(z.is_match[s]);
+    }
+    if (T.empty()) { std::array<int, 256> row; row.fill(-1); T.push_back(row); acc.push_back(0); }
+    if (z.has_filter) { d.flags |= PF_HAS_MATCHER; first = z.first_byte; }
+    if (acc[0]) d.flags |= PF_START_ACCEPTING;
+    if (hp.exact_literal && !hp.literal_has_anchors) { d.flags |= PF_EXACT_LITERAL; exact_lit = hp.best_literal; }
+    else if (hp.has_prefilter && !hp.literal_has_anchors) { d.flags |= PF_PREFILTER; pre = hp.prefilter_literal; }
+  }
+  if (T.empty()) { std::array<int, 256> row; row.fill(-1); T.push_back(row); acc.push_back(0); }
+
+  // byte classes: bytes with identical columns share a class
+  std::array<uint8_t, 256> cls{};
+  int ncls = 0;
+  {
+    std::map<std::vector<int>, int> seen;
+    for (int c = 0; c < 256; ++c) {
+      std::vector<int> col(T.size());
+      for (size_t s = 0; s < T.size(); ++s) col[s] = T[s][c];
+      auto it = seen.find(col);
+      if (it == seen.end()) it = seen.emplace(col, ncls++).first;
+      cls[c] = (uint8_t)it->second;
+    }
+  }
+  d.nstates = (int)T.size();
+  d.ncls = ncls;
+  // the exact-literal bypass (matcher.mojo:768-781, 815-847) replaces the engine
+  // entirely, so its literal can share the slot of the engine literal
+  if (d.flags & PF_EXACT_LITERAL) lit = exact_lit;
+  d.lit_len = (int)lit.size();
+  d.pre_len = (int)pre.size();
+  hp.blob.clear();
+  d.off_cls = 0; put(hp.blob, cls.data(), 256);
+  d.off_first = 256; put(hp.blob, first.data(), 256);
+  d.off_trans = (int)hp.blob.size();
+  {
+    // u16 entries: bit 15 = target accepts, low 15 bits = target, 0xFFFF = dead
+    std::vector<uint16_t> tr((size_t)d.nstates * ncls, 0xFFFF);
+    for (int c = 0; c < 256; ++c)
+      for (int s = 0; s < d.nstates; ++s) {
+        const int t = T[s][c];
+        if (t >= 0) tr[(size_t)s * ncls + cls[c]] = (uint16_t)(t | (acc[t] ? 0x8000 : 0));
+      }
+    put(hp.blob, tr.data(), tr.size() * 2);
+  }
+  d.off_lit = (int)hp.blob.size();
+  put(hp.blob, lit.data(), lit.size());
+  d.off_pre = (int)hp.blob.size();
+  put(hp.blob, pre.data(), pre.size());
+  align(hp.blob, 4);
+  if (d.nstates >= 0x7FFF) {
+    hp.why_no_match_first = hp.why_no_search = "more than 32766 DFA states";
+  }
+
+  // ---- streaming automaton (findall only) -----------------------------------------
+  d.off_stcol = -1;
+  hp.streamable_why_not.clear();
+  if (d.kind != PLAN_DFA) hp.streamable_why_not = "not a DFAEngine plan";
+  else if (d.flags & (PF_START_ANCHOR | PF_END_ANCHOR)) hp.streamable_why_not = "anchored";
+  else if (d.flags & (PF_PURE_LITERAL | PF_EXACT_LITERAL | PF_PREFILTER)) hp.streamable_why_not = "literal path";
+  else if (d.required_byte >= 0) hp.streamable_why_not = "required-byte findall path";
+  else if (!hp.why_no_search.empty()) hp.streamable_why_not = hp.why_no_search;
+  else {
+    SearchAutomaton sa;
+    if (d.flags & PF_SCAN_ELIGIBLE) {
+      // dfa.mojo:2075-2094: maximal runs of first-class bytes, whatever the table says
+      sa.n = 2;
+      sa.next.assign(2, {});
+      for (auto& r : sa.next) r.fill(-1);
+      sa.acc = {0, 1};
+      for (int c = 0; c < 256; ++c)
+        if (first[c]) { sa.next[0][c] = 1; sa.next[1][c] = 1; }
+      sa.allowed = first;
+    } else {
+      sa.n = d.nstates;
+      sa.next = T;
+      sa.acc = acc;
+      if (d.flags & PF_HAS_MATCHER) sa.allowed = first;
+      else sa.allowed.fill(1);
+    }
+    std::string why;
+    if (!check_streamable(sa, why)) {
+      hp.streamable_why_not = why;
+    } else {
+      // number the states actually reachable
+      std::vector<int> remap(sa.n, -1);
+      int nlive = 0;
+      remap[0] = nlive++;
+      std::vector<int> st{0};
+      while (!st.empty()) {
+        const int q = st.back(); st.pop_back();
+        for (int c = 0; c < 256; ++c) {
+          const int t = (q == 0) ? (sa.allowed[c] ? sa.next[0][c] : -1) : sa.next[q][c];
+          if (t > 0 && remap[t] < 0) { remap[t] = nlive++; st.push_back(t); }
+        }
+      }
+      std::vector<uint16_t> cols;
+      if (!build_stream_cols(sa, remap, nlive, cols)) {
+        hp.streamable_why_not = "more than 4 live states in the search automaton";
+      } else {
+        d.flags |= PF_STREAMABLE;
+        d.st_nstates = nlive;
+        d.st_accept_mask = 0;
+        for (int q = 0; q < sa.n; ++q)
+          if (remap[q] >= 0 && sa.acc[q]) d.st_accept_mask |= 1u << remap[q];
+        align(hp.blob, 4);
+        d.off_stcol = (int)hp.blob.size();
+        put(hp.blob, cols.data(), 512);
+      }
+    }
+  }
+  align(hp.blob, 16);
+  d.blob_bytes = (int)hp.blob.size();
+}
+
+std::string describe_plan(const HostPlan& hp) {
+  std::ostringstream o;
+  const DevPlan& d = hp.dev;
+  o << "pattern=" << hp.pattern << "\n";
+  o << "engine_type=" << hp.engine_type << "\n";
+  static const char* cxn[] = {"SIMPLE", "MEDIUM", "COMPLEX"};
+  o << "complexity=" << cxn[hp.complexity] << "\n";
+  o << "use_dfa=" << hp.use_dfa << " wildcard_any=" << hp.wildcard_any
+    << " use_pure_dfa=" << hp.use_pure_dfa << "\n";
+  o << "exact_literal=" << hp.exact_literal << " literal_has_anchors=" << hp.literal_has_anchors
+    << " prefilter=" << hp.has_prefilter << " required_byte=" << hp.required_byte << "\n";
+  auto hex = [&](const std::string& s) {
+    static const char* dg = "0123456789abcdef";
+    std::string h;
+    for (unsigned char c : s) { h.push_back(dg[c >> 4]); h.push_back(dg[c & 15]); }
+    return h;
+  };
+  o << "best_literal=" << hex(hp.best_literal) << "\n";
+  if (hp.use_dfa) {
+    const DfaEngine& e = hp.dfa;
+    o << "dfa.shape=" << e.shape << "\n";
+    o << "dfa.nstates=" << e.nstates() << "\n";
+    o << "dfa.flags start_anchor=" << e.has_start_anchor << " end_anchor=" << e.has_end_anchor
+      << " pure_literal=" << e.is_pure_literal << " has_matcher=" << e.has_matcher
+      << " scan_eligible=" << e.scan_eligible << "\n";
+    o << "dfa.literal=" << hex(e.literal) << "\n";
+    o << "dfa.accepting=";
+    for (int s = 0; s < e.nstates(); ++s) o << (int)e.accepting[s];
+    o << "\n";
+    if (e.has_matcher) {
+      o << "dfa.matcher.num_ranges=" << e.matcher.num_ranges << "\n";
+      o << "dfa.matcher.lookup=";
+      for (int c = 0; c < 256; ++c) o << (int)e.matcher.lookup[c];
+      o << "\n";
+    }
+    for (int s = 0; s < e.nstates(); ++s) {
+      o << "dfa.row" << s << "=";
+      // run-length form: c0-c1:target
+      int c = 0;
+      bool firstr = true;
+      while (c < 256) {
+        const int t = e.trans[s][c];
+        int c2 = c;
+        while (c2 + 1 < 256 && e.trans[s][c2 + 1] == t) ++c2;
+        if (t != -1) {
+          if (!firstr) o << ",";
+          o << c << "-" << c2 << ":" << t;
+          firstr = false;
+        }
+        c = c2 + 1;
+      }
+      o << "\n";
+    }
+  } else if (!hp.wildcard_any) {
+    o << "nfa.program_len=" << hp.program.insts.size() << "\n";
+    o << "nfa.program=";
+    for (const Inst& in : hp.program.insts) o << (int)in.op << ":" << in.a0 << ":" << in.a1 << ";";
+    o << "\n";
+    o << "nfa.has_filter=" << hp.lazy.has_filter << " lazy_states=" << hp.lazy.trans.size()
+      << " start_dead=" << hp.lazy.start_dead << " too_large=" << hp.lazy.too_large << "\n";
+    o << "nfa.literal_opt=" << hp.nfa_has_literal_opt << " starts_dotstar=" << hp.nfa_starts_dotstar
+      << " ends_dotstar=" << hp.nfa_ends_dotstar << "\n";
+  }
+  o << "fixed_groups=" << hp.fixed_ngroups << " fixed_total=" << hp.fixed_total
+    << " fixed_concat=" << hp.fixed_concat << "\n";
+  o << "support.match_first=" << (hp.why_no_match_first.empty() ? "yes" : hp.why_no_match_first) << "\n";
+  o << "support.search=" << (hp.why_no_search.empty() ? "yes" : hp.why_no_search) << "\n";
+  o << "device.kind=" << d.kind << " nstates=" << d.nstates << " ncls=" << d.ncls
+    << " flags=0x" << std::hex << d.flags << std::dec << " blob_bytes=" << d.blob_bytes << "\n";
+  o << "device.streamable=" << ((d.flags & PF_STREAMABLE) ? "yes" : ("no: " + hp.streamable_why_not))
+    << " st_nstates=" << d.st_nstates << "\n";
+  return o.str();
+}
+
+}  // namespace mrx

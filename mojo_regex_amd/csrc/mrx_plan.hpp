@@ -1,0 +1,96 @@
+// HostPlan: everything mrx_compile() derives from a pattern -- the reference's
+// routing decision (HybridMatcher.__init__, src/regex/matcher.mojo:566-693;
+// NFAMatcher, :273-431; NFAEngine flags, src/regex/nfa.mojo:86-143;
+// CompiledRegex fixed-width groups, matcher.mojo:1002-1035) plus the flat,
+// byte-class-compressed table blob the kernels stage into LDS.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "mrx_analysis.hpp"
+#include "mrx_engines.hpp"
+
+namespace mrx {
+
+// ---- device-visible plan (POD, passed to kernels by value) --------------------
+enum PlanKind : int32_t {
+  PLAN_DFA = 0,   // DFAEngine semantics (src/regex/dfa.mojo:1815-2253)
+  PLAN_LAZY = 1,  // LazyDFA semantics   (src/regex/pikevm.mojo:754-867)
+  PLAN_ANY = 2    // pattern ".*"        (matcher.mojo:740-745, 762-766, 809-813)
+};
+
+enum PlanFlags : uint32_t {
+  PF_START_ANCHOR = 1u << 0,
+  PF_END_ANCHOR = 1u << 1,
+  PF_PURE_LITERAL = 1u << 2,    // DFAEngine.is_pure_literal
+  PF_HAS_MATCHER = 1u << 3,     // DFAEngine._has_simd_matcher / LazyDFA has_filter
+  PF_SCAN_ELIGIBLE = 1u << 4,   // DFAEngine._simd_scan_eligible
+  PF_START_ACCEPTING = 1u << 5,
+  PF_EXACT_LITERAL = 1u << 6,   // HybridMatcher.is_exact_literal && !has_anchors
+  PF_PREFILTER = 1u << 7,       // HybridMatcher.prefilter && !has_anchors
+  PF_START_DEAD = 1u << 8,      // LazyDFA start state is LAZY_DFA_DEAD
+  PF_STREAMABLE = 1u << 9       // findall can run on the single-pass streaming kernel
+};
+
+constexpr int kMaxTemplateSegs = 32;
+
+struct DevPlan {
+  int32_t kind;
+  uint32_t flags;
+  int32_t nstates, ncls;
+  int32_t lit_len;        // engine literal (pure literal) or exact literal length
+  int32_t pre_len;        // MemchrPrefilter literal length (PF_PREFILTER)
+  int32_t required_byte;  // -1 if none (matcher.mojo:684-693)
+  // byte offsets into the table blob
+  int32_t off_cls, off_first, off_trans, off_lit, off_pre, blob_bytes;
+  // fixed-width capture groups (matcher.mojo:1002-1035)
+  int32_t fixed_total, fixed_ngroups, fixed_concat;
+  int32_t fixed_off[10], fixed_w[10];
+  // streaming (single-pass search automaton), see mrx_kernels.hip
+  int32_t st_nstates;
+  int32_t off_stcol;      // u32 column table [256] in the blob (8 states x 4 bit)
+  uint32_t st_accept_mask;
+};
+
+struct HostPlan {
+  std::string pattern;
+  // routing facts (for mrx_engine_type / mrx_stats / mrx_describe)
+  Complexity complexity = CX_SIMPLE;
+  bool wildcard_any = false;
+  bool use_dfa = false;
+  bool use_pure_dfa = false;
+  bool exact_literal = false, literal_has_anchors = false;
+  std::string best_literal;
+  bool has_prefilter = false;
+  std::string prefilter_literal;
+  int required_byte = -1;
+  std::string engine_type, stats;
+  DfaEngine dfa;
+  Program program;
+  LazyTables lazy;
+  bool nfa_has_literal_opt = false, nfa_starts_dotstar = false, nfa_ends_dotstar = false;
+  // per-operation support: empty string = supported, else the reason
+  std::string why_no_match_first, why_no_search;
+  // fixed-width group form
+  int fixed_total = -1, fixed_ngroups = 0;
+  bool fixed_concat = false;
+  int fixed_off[10] = {0}, fixed_w[10] = {0};
+  // device payload
+  DevPlan dev{};
+  std::vector<uint8_t> blob;
+  std::string streamable_why_not;
+};
+
+// Throws SyntaxError for patterns the reference's parser raises on.
+void build_plan(const std::string& pattern, HostPlan& out);
+std::string describe_plan(const HostPlan& p);
+
+// replacement template (matcher.mojo:1436-1482)
+struct ReplSeg {
+  int32_t group_ref, start, length;
+};
+bool repl_has_group_refs(const std::string& repl);
+std::vector<ReplSeg> parse_repl_template(const std::string& repl);
+
+}  // namespace mrx

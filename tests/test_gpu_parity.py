@@ -1,0 +1,338 @@
+"""GPU parity: the HIP path (through the C ABI) against the oracle.
+
+Bit-exact is the bar: every start/end offset, every count, every replaced byte.
+  * the reference's own known-answer vectors (tests/golden) through the GPU;
+  * seeded random batches (ragged, empty, high bytes) for a pattern set that
+    covers every kernel plan, compared with the oracle text by text;
+  * the streaming kernel against the generic kernel and the oracle, with pitches
+    and lengths that are not multiples of the chunk size;
+  * at BASELINE.json's full size (1M x 1KiB) through size-independent properties.
+"""
+import collections
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+import mojo_regex_amd as M  # noqa: E402
+from mrx_ref import hybrid as O  # noqa: E402  (oracle: checker only)
+from mrx_ref import UnsupportedByOracle  # noqa: E402
+from vector_eval import load_vectors, evaluate, Unsupported  # noqa: E402
+from mojo_regex_amd.workloads import make_c2_batch  # noqa: E402
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test run without a GPU: the HIP path has no fallback")
+
+
+class ProductBackend:
+    """tests/vector_eval.py backend that answers from the GPU, one text per call."""
+    name = "hip"
+
+    def _rx(self, p):
+        return M.compile_regex(p)
+
+    def _one(self, pair):
+        s, e = int(pair[0][0]), int(pair[1][0])
+        return None if s < 0 else (s, e)
+
+    def match_first(self, p, t):
+        return self._one(self._rx(p).match_first([t]))
+
+    def search(self, p, t):
+        return self._one(self._rx(p).match_next([t]))
+
+    def findall(self, p, t):
+        return self._rx(p).findall_lists([t])[0]
+
+    def sub(self, p, r, t, count=0):
+        return self._rx(p).sub(r, [t], count)[0]
+
+    def split(self, p, t, maxsplit=0):
+        return M.split(p, [t], maxsplit)[0]
+
+    def obj_match_first(self, p, t, start=0):
+        if start != 0:
+            raise Unsupported("start offset is not part of the batch ABI")
+        return self._one(self._rx(p).match_first([t]))  # same as engine match_first at 0
+
+    def obj_match_next(self, p, t, start=0):
+        if start != 0:
+            raise Unsupported("start offset is not part of the batch ABI")
+        return self.search(p, t)
+
+    def obj_test(self, p, t):
+        return bool(self._rx(p).test([t])[0])
+
+    def obj_is_match(self, p, t, start=0):
+        if start != 0:
+            raise Unsupported("start offset is not part of the batch ABI")
+        return bool(self._rx(p).is_match([t])[0])
+
+    def engine_type(self, p):
+        return self._rx(p).get_engine_type()
+
+    def stats(self, p):
+        return self._rx(p).get_stats()
+
+    # comptime API == runtime API whenever the runtime route is the DFA
+    def _ct_ok(self, p):
+        if "use_dfa=1" not in self._rx(p).describe():
+            raise Unsupported("comptime route differs from the runtime route")
+
+    def ct_search(self, p, t):
+        self._ct_ok(p)
+        return self.search(p, t)
+
+    def ct_match_first(self, p, t):
+        self._ct_ok(p)
+        return self.match_first(p, t)
+
+    def ct_findall(self, p, t):
+        self._ct_ok(p)
+        return self.findall(p, t)
+
+    def _dfa_pat(self, build):
+        if build["kind"] != "pattern":
+            raise Unsupported("direct DFAEngine construction is not an ABI entry point")
+        p = build["pattern"].encode()
+        self._ct_ok(p)
+        return p
+
+    def dfa_match_first(self, build, t, start=0):
+        if start != 0:
+            raise Unsupported("start offset")
+        s, e = self._rx(self._dfa_pat(build)).match_first([t])
+        # DFAEngine.match_first does not filter on start == 0, but with start=0 it cannot differ
+        return self._one((s, e))
+
+    def dfa_match_next(self, build, t, start=0):
+        if start != 0:
+            raise Unsupported("start offset")
+        return self.search(self._dfa_pat(build), t)
+
+    def dfa_match_all(self, build, t):
+        return self.findall(self._dfa_pat(build), t)
+
+
+def test_reference_vectors_through_the_gpu():
+    _need_gpu()
+    be = ProductBackend()
+    failures, skipped, passed = [], collections.Counter(), 0
+    for v in load_vectors():
+        try:
+            f = evaluate(be, v)
+        except (M.UnsupportedPattern, Unsupported) as e:
+            skipped[str(e)[:60]] += 1
+            continue
+        if f:
+            failures.extend(f)
+        else:
+            passed += 1
+    assert not failures, "\n".join(failures[:25])
+    assert passed >= 400, (passed, skipped)
+
+
+PATTERNS = [
+    b"hello", b"a", b"aa", b"[a-z]+\\d+", b"[a-z]+[0-9]+", b"\\d+", b"[0-9]+", b"[a-z]+", b"[0-9]*",
+    b"[a-z]{3}", b"[0-9]{2,4}", b"[a-z]{2,}", b"[^0-9]+", b"[^abc]+", b"(\\d{3})(\\d{3})(\\d{4})",
+    b"(x|y|foo|bar)+", b"(x|y|foo|bar)+z", b"a|b|c", b"(a|b)", b"(a|b)x", b"a+b", b"a+b*", b"(abc)+",
+    b"(abc)*", b"(ab)?", b"[A-Z][a-z]+[0-9]+", b"[a-z]*[0-9]+", b"[0-9]+\\.?[0-9]*", b"\\w+@\\w+\\.com",
+    b"[a-zA-Z0-9._%+-]+@[a-zA-Z0-9.-]+\\.[a-z]{2,}", b"\\d{3}-\\d{4}", b".*", b".+", b".", b"^a", b"a$",
+    b"^abc$", b"", b"^", b"(hello|help|helicopter)", b"(cat|dog)+", b"3[02]|40|[68]9",
+    b"(?:00|33|44)\\d{3}", b"hello world this is long", b"x[0-9]{2,4}y", b"\\s*\\d+", b"[a-c]+[x-z]?",
+    b"((a|b)|(c|d))", b"a**", b"[a|b]", b"\\d+\\s\\w+",
+]
+
+ALPHABETS = {
+    "words": b"abcxyzfor 0189-.@helpcatdog\n",
+    "digits": b"0123456789 ab",
+    "printable": bytes(range(32, 127)),
+    "bytes": bytes(range(256)),
+}
+
+
+def _random_texts(rng, n, max_len, alphabet):
+    al = np.frombuffer(alphabet, dtype=np.uint8)
+    lens = rng.integers(0, max_len + 1, size=n)
+    lens[: min(n, 3)] = [0, 1, max_len][: min(n, 3)]
+    return [bytes(rng.choice(al, size=int(k)).tolist()) for k in lens]
+
+
+@pytest.mark.parametrize("pat", PATTERNS)
+def test_random_batches_match_oracle(pat):
+    _need_gpu()
+    rng = np.random.default_rng(zlib.crc32(pat))
+    texts = []
+    for name, al in ALPHABETS.items():
+        texts += _random_texts(rng, 60, 96, al)
+    texts += [b"hello123 world456 test789", b"xyfoo", b"6502530000 and 4155551234", b"abcabcabc",
+              b"user@example.com, other@test.org", b"x123y x1y x12345y"]
+    try:
+        rx = M.compile_regex(pat)
+        got_all = rx.findall_lists(texts)
+        s, e = rx.match_next(texts)
+    except M.UnsupportedPattern:
+        # must be out of scope for the oracle too (same routing)
+        with pytest.raises(UnsupportedByOracle):
+            O.findall(pat, b"abc")
+        return
+    for i, t in enumerate(texts):
+        assert got_all[i] == O.findall(pat, t), (pat, t)
+        w = O.search(pat, t)
+        assert (int(s[i]), int(e[i])) == (w if w else (-1, -1)), (pat, t)
+    try:
+        fs, fe = rx.match_first(texts)
+        fl = rx.is_match(texts)
+    except M.UnsupportedPattern:
+        with pytest.raises(UnsupportedByOracle):
+            O.match_first(pat, b"abc")
+        return
+    c = O.compile_regex(pat)
+    for i, t in enumerate(texts):
+        w = O.match_first(pat, t)
+        assert (int(fs[i]), int(fe[i])) == (w if w else (-1, -1)), (pat, t)
+        assert bool(fl[i]) == c.is_match(t, 0), (pat, t)
+
+
+SUB_CASES = [
+    (b"(\\d{3})(\\d{3})(\\d{4})", b"\\1-\\2-\\3"), (b"(\\d{3})(\\d{4})", b"\\1-\\2"),
+    (b"(\\d{2})(\\d{2})", b"\\2\\1"), (b"(\\d{4})-(\\d{2})-(\\d{2})", b"\\2/\\3/\\1"),
+    (b"[0-9]+", b"NUM"), (b"hello", b"\\0hi"), (b"a*", b"-"), (b"\\d+", b"<\\1>"), (b"[a-z]+\\d+", b""),
+    (b".*", b"X"), (b"(x|y|foo|bar)+", b"_"),
+]
+
+
+@pytest.mark.parametrize("pat,repl", SUB_CASES)
+@pytest.mark.parametrize("count", [0, 1, 2])
+def test_sub_matches_oracle(pat, repl, count):
+    _need_gpu()
+    rng = np.random.default_rng(7)
+    texts = _random_texts(rng, 80, 64, b"0123456789 -ab") + [
+        b"6502530000", b"6502530000 and 4155551234", b"5551234 and 9876543", b"1234",
+        b"Date: 2026-04-12 is today", b"hello world", b"", b"abc123def456", b"xyfoo bar"]
+    try:
+        got = M.compile_regex(pat).sub(repl, texts, count)
+    except M.UnsupportedPattern:
+        with pytest.raises(UnsupportedByOracle):
+            O.sub(pat, repl, b"abc 123", count)
+        return
+    for t, g in zip(texts, got):
+        assert g == O.sub(pat, repl, t, count), (pat, repl, t, count)
+
+
+def test_captures_fixed_width_groups():
+    _need_gpu()
+    pat = b"(\\d{3})(\\d{3})(\\d{4})"
+    texts = [b"Call 6502530000 or 4155551234 today.", b"no digits", b"123456789", b"x12345678901234"]
+    rx = M.compile_regex(pat)
+    assert rx.num_groups == 3
+    got = rx.captures(texts)
+    c = O.compile_regex(pat)
+    for i, t in enumerate(texts):
+        w = c.captures_fixed(t)
+        if w is None:
+            assert (got[i] == -1).all()
+        else:
+            # a18 order: groups 1..g, then the whole match
+            assert [tuple(int(x) for x in r) for r in got[i]] == [(s, e) for (_, s, e) in w]
+    with pytest.raises(M.UnsupportedPattern):
+        M.compile_regex(b"(\\w+) (\\w+)").captures([b"hello world"])
+
+
+STREAM_PATTERNS = [b"[a-z]+\\d+", b"\\d+", b"[a-z]+", b"[a-z]{2,}", b"[^0-9]+", b"[a-z]+[0-9]+"]
+
+
+@pytest.mark.parametrize("pat", STREAM_PATTERNS)
+@pytest.mark.parametrize("n,pitch,var", [(1, 16, False), (63, 48, True), (64, 64, False),
+                                         (65, 80, True), (777, 208, True), (1000, 256, False),
+                                         (130, 1024, True)])
+def test_streaming_kernel_equals_generic_and_oracle(pat, n, pitch, var):
+    _need_gpu()
+    rng = np.random.default_rng(n * 131 + pitch)
+    al = np.frombuffer(b"abcdxyz0123456789 -", dtype=np.uint8)
+    arr = rng.choice(al, size=(n, pitch)).astype(np.uint8)
+    # long runs that span chunk boundaries
+    for i in range(0, n, 5):
+        k = int(rng.integers(0, pitch))
+        arr[i, :k] = ord("q")
+    lens = rng.integers(0, pitch + 1, size=n).astype(np.int32) if var else None
+    rx = M.compile_regex(pat)
+    assert "device.streamable=yes" in rx.describe()
+    d = torch.from_numpy(arr).cuda().reshape(-1)
+    dl = torch.from_numpy(lens).cuda() if var else None
+    batch = M.DeviceBatch.strided(d, pitch, length=pitch, lens=dl)
+    prefix, spans, total = rx._dev_findall(batch)
+    assert M.load_library().mrx_last_kernel_name() in (b"k_stream_findall",)
+    prefix, spans = prefix.cpu().numpy(), spans.cpu().numpy()
+    texts = [arr[i, : (lens[i] if var else pitch)].tobytes() for i in range(n)]
+    generic = rx.findall_lists(texts)          # CSR batch -> generic kernel
+    assert int(prefix[-1]) == total == sum(len(x) for x in generic)
+    for i, t in enumerate(texts):
+        have = [tuple(int(x) for x in r) for r in spans[prefix[i]:prefix[i + 1]]]
+        assert have == generic[i], (pat, i)
+        if i % 7 == 0:
+            assert have == O.findall(pat, t), (pat, i)
+
+
+def test_streaming_slot_overflow_is_rewalked():
+    _need_gpu()
+    # 128 matches in one text: more than the 64-span slot
+    t = (b"a1 " * 128)
+    arr = np.frombuffer(t, dtype=np.uint8).reshape(1, -1).repeat(70, axis=0).copy()
+    arr[3, :] = ord(" ")
+    d = torch.from_numpy(arr).cuda().reshape(-1)
+    rx = M.compile_regex(b"[a-z]+\\d+")
+    prefix, spans, total = rx._dev_findall(M.DeviceBatch.strided(d, arr.shape[1], length=arr.shape[1]))
+    prefix, spans = prefix.cpu().numpy(), spans.cpu().numpy()
+    want = O.findall(b"[a-z]+\\d+", t)
+    assert len(want) == 128 and total == 128 * 69
+    assert [tuple(int(x) for x in r) for r in spans[prefix[0]:prefix[1]]] == want
+    assert prefix[4] - prefix[3] == 0
+
+
+def test_full_size_c2_properties():
+    """BASELINE.json config 2 at full size: 2^20 texts x 1 KiB."""
+    _need_gpu()
+    n, L = 1 << 20, 1024
+    d = make_c2_batch(n, L, seed=20260102, device="cuda")
+    rx = M.compile_regex(b"[a-z]+\\d+")
+    batch = M.DeviceBatch.strided(d.reshape(-1), L, length=L)
+    prefix, spans, total = rx._dev_findall(batch)
+    assert total > n  # the token texts alone carry dozens of matches each
+    sp = spans[:total].to(torch.int64)
+    counts = prefix[1:] - prefix[:-1]
+    owner = torch.repeat_interleave(torch.arange(n, device="cuda"), counts)
+    # spans lie inside their text, are non-empty, ordered and non-overlapping per text
+    assert bool((sp[:, 0] >= 0).all()) and bool((sp[:, 1] <= L).all())
+    assert bool((sp[:, 1] > sp[:, 0]).all())
+    same = owner[1:] == owner[:-1]
+    assert bool((sp[1:, 0][same] >= sp[:-1, 1][same]).all())
+    # every match is [a-z]+ followed by [0-9]+ and is maximal on both sides
+    flat = d.reshape(-1).to(torch.int64)
+    base = owner * L
+    first = flat[base + sp[:, 0]]
+    last = flat[base + sp[:, 1] - 1]
+    assert bool(((first >= 97) & (first <= 122)).all())
+    assert bool(((last >= 48) & (last <= 57)).all())
+    has_prev = sp[:, 0] > 0
+    prev = flat[(base + sp[:, 0] - 1).clamp(min=0)]
+    assert not bool((has_prev & (prev >= 97) & (prev <= 122)).any())
+    has_next = sp[:, 1] < L
+    nxt = flat[(base + sp[:, 1]).clamp(max=flat.numel() - 1)]
+    assert not bool((has_next & (nxt >= 48) & (nxt <= 57)).any())
+    # the generic kernel (count only) agrees text by text
+    counts2 = rx.count(batch)
+    assert bool((counts2.to(torch.int64) == counts).all())
+    # and the oracle agrees on a sample of every text kind
+    host = d[:: n // 256].cpu().numpy()
+    pre = prefix.cpu().numpy()
+    sph = spans[:total].cpu().numpy()
+    for j, i in enumerate(range(0, n, n // 256)):
+        have = [tuple(int(x) for x in r) for r in sph[pre[i]:pre[i + 1]]]
+        assert have == O.findall(b"[a-z]+\\d+", host[j].tobytes()), i

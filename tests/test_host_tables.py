@@ -1,0 +1,105 @@
+"""CPU: the product's C++ pattern compiler against the oracle's Python one.
+
+Two independent implementations of the reference's front end, classifier,
+router and table builders must produce the same routing decision and the same
+tables (states, transitions, accept flags, matcher set, PikeVM program) for
+every pattern the reference's own tests use plus a set of shape-covering extras.
+Also checks that libmrx_hip.so loads and exports every symbol of include/mrx.h
+(no compute calls: this runs without a GPU).
+"""
+import os
+import re
+
+import pytest
+
+import mojo_regex_amd as M
+from mojo_regex_amd import api
+from mrx_ref import RegexSyntaxError as OracleSyntaxError
+from mrx_ref.describe import describe
+from vector_eval import load_vectors
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+EXTRA = [
+    "(x|y|foo|bar)+z", "[a-z]{2,}", "[a-z]{0,3}", "[^abc]+\\d", "\\s*\\d+", "\\w+@\\w+\\.com",
+    "[a-zA-Z0-9._%+-]+@[a-zA-Z0-9.-]+\\.[a-z]{2,}", "(?:00|33|44)\\d{3}", "a{3}b",
+    "ab{3}cdefghijklmnopq", "hello world this is long", "a\\.bcdefghijklmnopq", "(abc)+", "(abc)*",
+    "(abc)?", "(a|b)*", "(cat|dog)+", "(hello|help|helicopter)", ".+", ".?", ".", "^", "$", "^$", "",
+    "[", "(", ")", "a{x}", "a|", "|", "\\t", "[a-Z]", "x[0-9]{2,4}y", "\\d{3}-\\d{4}",
+    "([A-Z]{3}[0-9]{4})-([A-Z]{3}[0-9]{3})", "3[02]|40|[68]9", "(a|b)x", "h[ae]llo", "hello.world",
+    "^[a-z]+$", "(\\d+)", "[+]*\\d+[-]*\\d+[-]*\\d+[-]*\\d+", "[0-9]+\\.?[0-9]*", "a*", "test+",
+    "[a-c]+[x-z]?", "(?:a|b)+", "((a|b)|(c|d))", "a|b|c|d|e|f|g|h|i", "[a-z]+\\d+", "\\d+", "hello",
+    "(\\d{3})(\\d{3})(\\d{4})", "(x|y|foo|bar)+", ".*", "a**", "a^b", "[(]", "[a|b]", "x{2,}", "x{,3}",
+]
+
+
+def _patterns():
+    pats = sorted({v["pattern"] for v in load_vectors() if v.get("pattern") is not None})
+    return pats + [p for p in EXTRA if p not in pats]
+
+
+def _product_describe(p: bytes) -> str:
+    try:
+        return M.CompiledRegex(p).describe()
+    except M.RegexSyntaxError as e:
+        return "SYNTAX:" + str(e)
+
+
+def _oracle_describe(p: bytes) -> str:
+    try:
+        return describe(p)
+    except OracleSyntaxError as e:
+        return "SYNTAX:" + str(e)
+
+
+@pytest.mark.parametrize("pattern", _patterns())
+def test_tables_match_oracle(pattern):
+    pb = pattern.encode("utf-8")
+    od, pd = _oracle_describe(pb), _product_describe(pb)
+    if od.startswith("SYNTAX") or pd.startswith("SYNTAX"):
+        assert od == pd
+        return
+    ol = od.strip().split("\n")
+    pl = [l for l in pd.strip().split("\n")
+          if not l.startswith(("support.", "device.", "nfa.has_filter"))]
+    assert ol == pl
+
+
+def test_library_exports_every_header_symbol():
+    lib = M.load_library()
+    hdr = open(os.path.join(ROOT, "include", "mrx.h")).read()
+    declared = sorted(set(re.findall(r"\b(mrx_[a-z_]+)\s*\(", hdr)))
+    assert len(declared) >= 24
+    assert sorted(api.EXPORTED_SYMBOLS) == declared
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert b"gfx950" in lib.mrx_version()
+
+
+def test_config_plans():
+    """Routing + kernel plan of the five BASELINE.json configs."""
+    want = {
+        "hello": ("literal", "streamable=no"),
+        "[a-z]+\\d+": ("multi_class_sequence", "streamable=yes"),
+        "\\d+": ("single_class", "streamable=yes"),
+        "(\\d{3})(\\d{3})(\\d{4})": ("multi_class_sequence", "streamable=no"),
+        "(x|y|foo|bar)+": ("alternation", "streamable=no"),
+    }
+    for pat, (shape, st) in want.items():
+        d = M.CompiledRegex(pat).describe()
+        assert "engine_type=DFA\n" in d and ("dfa.shape=%s\n" % shape) in d, d
+        assert ("device." + st) in d, d
+        assert "support.search=yes" in d and "support.match_first=yes" in d
+
+
+def test_out_of_scope_patterns_fail_loudly_without_a_gpu():
+    # routed by the reference to OnePass / the backtracking NFA: refused, never guessed
+    rx = M.CompiledRegex("^[a-z]+[0-9]+$")
+    d = rx.describe()
+    assert "support.match_first=reference routes" in d
+    rx = M.CompiledRegex("hello.world")
+    assert "support.search=reference routes" in rx.describe()
+    with pytest.raises(M.RegexSyntaxError, match=r"Missing closing '\]'"):
+        M.CompiledRegex("[abc")
+    with pytest.raises(M.RegexSyntaxError, match="Unescaped closing parenthesis"):
+        M.CompiledRegex("a)")
