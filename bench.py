@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's headline metric on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Workload (BASELINE.json configs[1]): findall of `[a-z]+\\d+` over 2^20 synthetic
+1 KiB ASCII texts PER GPU (SURVEY.md 8(d) mix: 40 % full / 30 % tokens / 20 % noise
+/ 10 % adversarial), already resident in HBM.  One step = one pass of the hot path
+over the batch through the C ABI (mrx_findall_strided_dev): streaming scan kernel
++ CSR prefix sum + span compaction.  Texts are independent, so N GPUs each scan
+their own batch (weak scaling, no data-path collective).
+
+Prints ONE JSON line (rank 0) with the contract fields plus
+  roofline     dominant kernel (k_stream_findall): algorithmic bytes per launch /
+               its mean duration from HIP events on the launch stream; peak 8 TB/s
+  cpu_baseline the oracle's C port (scalar, 1 thread) on a bounded sample of the
+               same batch, timed on this box's host cores (rank 0, N == 1 only)
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PATTERN = b"[a-z]+\\d+"
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def cpu_baseline(host_rows, pattern: bytes):
+    """Oracle C port on a bounded sample (checker code, used here only as the
+    reported CPU baseline -- never on the measured GPU path)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    from mrx_ref.cfast import CDfa
+    n, L = host_rows.shape
+    cd = CDfa(pattern)
+    offsets = np.arange(0, (n + 1) * L, L, dtype=np.int64)
+    data = host_rows.reshape(-1)
+    t0 = time.perf_counter()
+    counts, _, total = cd.findall_batch(data, offsets, want_spans=False)
+    dt = time.perf_counter() - t0
+    return {
+        "value": round(n * L / dt / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
+        "sample": "first %d texts (%d MiB) of the same batch, findall, oracle/c/mrx_oracle.c, "
+                  "%.1f s, %d matches" % (n, n * L >> 20, dt, total),
+        "matches_per_s": round(total / dt, 1),
+    }, counts
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--texts", type=int, default=1 << 20, help="texts per GPU")
+    ap.add_argument("--length", type=int, default=1024)
+    ap.add_argument("--cpu-sample", type=int, default=1 << 16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import mojo_regex_amd as M
+    from mojo_regex_amd import dist as D
+    from mojo_regex_amd.workloads import make_c2_batch
+
+    rank, local_rank, world = D.env_world()
+    if world != args.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = "cuda:%d" % local_rank
+    if world > 1:
+        D.init("nccl")
+
+    n, L = args.texts, args.length
+    batch_t = make_c2_batch(n, L, seed=20260102 + rank, device=dev)
+    batch = M.DeviceBatch.strided(batch_t.reshape(-1), L, length=L)
+    rx = M.compile_regex(PATTERN)
+    lib = M.load_library()
+
+    # preallocated outputs: no allocation of result buffers inside the timed region
+    prefix = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    spans = torch.empty((n * 24, 2), dtype=torch.int32, device=dev)
+    out = (prefix, spans)
+
+    def step():
+        return rx._dev_findall(batch, out=out)[2]
+
+    total = 0
+    for _ in range(args.warmup):
+        total = step()
+    torch.cuda.synchronize()
+    D.barrier(world, dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        total = step()
+    torch.cuda.synchronize()
+    D.barrier(world, dev)
+    elapsed = time.perf_counter() - t0
+
+    agg = D.combine(world, elapsed, {"bytes": float(n) * L * args.steps,
+                                     "matches": float(total) * args.steps}, device=dev)
+
+    # ---- roofline of the dominant kernel: HIP events on its own launch stream -------
+    lib.mrx_timing_enable(1)
+    lib.mrx_timing_reset()
+    for _ in range(max(5, min(args.steps, 20))):
+        step()
+    torch.cuda.synchronize()
+    launches = ctypes.c_int64(0)
+    scan_ms = lib.mrx_timing_scan_ms(ctypes.byref(launches))
+    lib.mrx_timing_enable(0)
+    kernel = lib.mrx_last_kernel_name().decode()
+    # algorithmic bytes per launch (DESIGN.md "Measurement"): every input byte once,
+    # + 8 B per span written to its slot + 4 B per text for the count
+    alg_bytes = float(n) * L + 8.0 * total + 4.0 * n
+    achieved = alg_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+
+    if rank == 0:
+        value = agg["bytes"] / agg["elapsed_s"] / 1e9
+        line = {
+            "metric": "GB/s input scanned + matches/sec, 1M x 1KiB batch, [a-z]+\\d+ DFA",
+            "value": round(value, 3), "unit": "GB/s",
+            "matches_per_s": round(agg["matches"] / agg["elapsed_s"], 1),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(agg["elapsed_s"] / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "findall [a-z]+\\d+ over %d x %d B ASCII texts per GPU "
+                                   "(40/30/20/10 full/tokens/noise/adversarial)" % (n, L),
+                       "texts_per_gpu": n, "text_bytes": L, "pattern": PATTERN.decode(),
+                       "op": "findall", "matches_per_batch": int(total),
+                       "parallelism": "texts sharded, %d rank(s), no data-path collective" % world},
+            "hbm_frac_of_peak_whole_step": round(value / world / HBM_PEAK_GBS, 4),
+            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel_ms": round(scan_ms, 4), "launches_timed": int(launches.value),
+                         "algorithmic_bytes_per_launch": int(alg_bytes)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            m = min(args.cpu_sample, n)
+            host = batch_t[:m].cpu().numpy()
+            cb, counts = cpu_baseline(host, PATTERN)
+            # the sample doubles as a parity spot check of the measured path
+            gpu_counts = (prefix[1:m + 1] - prefix[:m]).cpu().numpy()
+            cb["parity_on_sample"] = bool((gpu_counts == counts).all())
+            line["cpu_baseline"] = cb
+        print(json.dumps(line), flush=True)
+
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -45,6 +45,13 @@ def load_library():
         raise MrxError(
             "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback." % path)
+    try:
+        # PyTorch wheels bundle their own HIP runtime.  Load it first so that the
+        # process holds ONE libamdhip64 (ours resolves to the copy already mapped);
+        # two runtimes in one process do not share the device.
+        import torch  # noqa: F401
+    except Exception:
+        pass
     lib = C.CDLL(path)
     H = C.c_void_p
     u8p, i32p, i64p = C.c_void_p, C.c_void_p, C.c_void_p

@@ -354,6 +354,10 @@ void build_plan(const std::string& pattern, HostPlan& hp) {
       }
   }
 
+  // the exact-literal bypass answers search/findall/sub before any engine is consulted
+  // (matcher.mojo:768-781, 815-847)
+  if (hp.exact_literal && !hp.literal_has_anchors) hp.why_no_search.clear();
+
   // ---- device payload ------------------------------------------------------------
   DevPlan& d = hp.dev;
   d = DevPlan();

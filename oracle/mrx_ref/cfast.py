@@ -1,0 +1,120 @@
+"""ORACLE (test infrastructure) -- ctypes bridge to oracle/c/mrx_oracle.c.
+
+Runs the C restatement of the DFAEngine loops over whole batches, with tables
+taken from the Python oracle.  Only plain DFAEngine routes are handled here
+(which is what the BASELINE.json configs use); anything else stays in Python.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import SIMD_WIDTH
+from .hybrid import CompiledRegex, UnsupportedByOracle
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ORACLE_DIR = os.path.dirname(_HERE)
+_SO = os.path.join(_ORACLE_DIR, "_build", "libmrx_oracle.so")
+_lib = None
+
+
+class _Dfa(C.Structure):
+    _fields_ = [
+        ("nstates", C.c_int32), ("trans", C.c_void_p), ("accepting", C.c_void_p),
+        ("has_start_anchor", C.c_int32), ("has_end_anchor", C.c_int32),
+        ("is_pure_literal", C.c_int32), ("has_simd_matcher", C.c_int32),
+        ("simd_scan_eligible", C.c_int32), ("lookup", C.c_void_p), ("num_ranges", C.c_int32),
+        ("lo_tbl", C.c_void_p), ("hi_tbl", C.c_void_p), ("literal", C.c_void_p),
+        ("literal_len", C.c_int32), ("simd_width", C.c_int32),
+    ]
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            subprocess.run(["make", "-s", "-C", _ORACLE_DIR], check=True)
+        lib = C.CDLL(_SO)
+        P = C.POINTER(_Dfa)
+        lib.mrx_oracle_findall_batch.restype = C.c_int64
+        lib.mrx_oracle_findall_batch.argtypes = [P, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                                 C.c_void_p, C.c_int64]
+        lib.mrx_oracle_span_batch.restype = None
+        lib.mrx_oracle_span_batch.argtypes = [P, C.c_int, C.c_void_p, C.c_void_p, C.c_int64,
+                                              C.c_void_p, C.c_void_p]
+        lib.mrx_oracle_match_first_bytes.restype = C.c_int64
+        lib.mrx_oracle_match_first_bytes.argtypes = [P, C.c_void_p, C.c_void_p, C.c_int64]
+        _lib = lib
+    return _lib
+
+
+class CDfa:
+    """A DFAEngine of the Python oracle, frozen into C-readable arrays."""
+
+    def __init__(self, pattern: bytes):
+        c = CompiledRegex(pattern)
+        m = c.matcher
+        if (m.is_wildcard_match_any or not m.use_dfa or m.is_exact_literal
+                or m.prefilter_literal is not None or m.required_byte >= 0):
+            raise UnsupportedByOracle("C oracle covers plain DFAEngine routes only")
+        e = m.dfa
+        self.pattern = pattern
+        self._trans = np.array([s.transitions for s in e.states], dtype=np.int32).reshape(-1, 256)
+        self._acc = np.array([1 if s.is_accepting else 0 for s in e.states], dtype=np.uint8)
+        self._lookup = np.array(e.matcher.lookup, dtype=np.uint8)
+        self._lo = np.array(e.matcher.lo_tbl, dtype=np.uint8)
+        self._hi = np.array(e.matcher.hi_tbl, dtype=np.uint8)
+        self._lit = np.frombuffer(e.literal_pattern + b"\0", dtype=np.uint8).copy()
+        d = _Dfa()
+        d.nstates = len(e.states)
+        d.trans = self._trans.ctypes.data
+        d.accepting = self._acc.ctypes.data
+        d.has_start_anchor = int(e.has_start_anchor)
+        d.has_end_anchor = int(e.has_end_anchor)
+        d.is_pure_literal = int(e.is_pure_literal)
+        d.has_simd_matcher = int(e.has_simd_matcher)
+        d.simd_scan_eligible = int(e.simd_scan_eligible)
+        d.lookup = self._lookup.ctypes.data
+        d.num_ranges = e.matcher.num_ranges
+        d.lo_tbl = self._lo.ctypes.data
+        d.hi_tbl = self._hi.ctypes.data
+        d.literal = self._lit.ctypes.data
+        d.literal_len = len(e.literal_pattern)
+        d.simd_width = SIMD_WIDTH
+        self._d = d
+        self._lib = load()
+
+    def findall_batch(self, data: np.ndarray, offsets: np.ndarray, want_spans: bool = True):
+        """(counts int32[n], spans int32[total,2] or None, total)."""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        n = len(offsets) - 1
+        counts = np.zeros(n, np.int32)
+        total = self._lib.mrx_oracle_findall_batch(C.byref(self._d), data.ctypes.data,
+                                                   offsets.ctypes.data, n, counts.ctypes.data, None, 0)
+        if not want_spans:
+            return counts, None, int(total)
+        spans = np.empty((max(int(total), 1), 2), np.int32)
+        self._lib.mrx_oracle_findall_batch(C.byref(self._d), data.ctypes.data, offsets.ctypes.data, n,
+                                           counts.ctypes.data, spans.ctypes.data, int(total))
+        return counts, spans[: int(total)], int(total)
+
+    def span_batch(self, which: str, data: np.ndarray, offsets: np.ndarray):
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        n = len(offsets) - 1
+        s = np.empty(n, np.int32)
+        e = np.empty(n, np.int32)
+        self._lib.mrx_oracle_span_batch(C.byref(self._d), 0 if which == "match_first" else 1,
+                                        data.ctypes.data, offsets.ctypes.data, n, s.ctypes.data,
+                                        e.ctypes.data)
+        return s, e
+
+    def match_first_bytes(self, data: np.ndarray, offsets: np.ndarray) -> int:
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        return int(self._lib.mrx_oracle_match_first_bytes(C.byref(self._d), data.ctypes.data,
+                                                          offsets.ctypes.data, len(offsets) - 1))
