@@ -157,11 +157,20 @@ struct SlotOut {
   }
 };
 
-template <bool COUNT_ONLY>
+enum { ST_SLOTS = 0, ST_COUNT = 1, ST_OVERFLOW = 2 };
+
+// MODE ST_SLOTS:    spans of text i go to slots[i*slot_cap ...] (first slot_cap of them), counts[i] = #matches
+// MODE ST_COUNT:    counts only
+// MODE ST_OVERFLOW: second launch for the texts whose count exceeded the slot capacity: they are
+//                   streamed again and write straight to their CSR position (prefix known by then);
+//                   wavefronts without such a text return after reading 64 counts
+template <int MODE>
 __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
     DevPlan p, const uint8_t* __restrict__ blob, const uint8_t* __restrict__ data, int64_t stride,
     const int32_t* __restrict__ lens, int32_t common_len, int64_t n, int32_t* __restrict__ counts,
-    int32_t* __restrict__ slots, int slot_cap) {
+    int32_t* __restrict__ slots, int slot_cap_arg, const int64_t* __restrict__ prefix,
+    int32_t* __restrict__ spans, int64_t span_cap) {
+  constexpr bool COUNT_ONLY = MODE == ST_COUNT;
   __shared__ __align__(16) uint8_t tiles[kStreamWaves][kTileBytes];
   __shared__ __align__(16) uint16_t col_lds[256];
   {
@@ -179,7 +188,22 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
        w += (int64_t)gridDim.x * kStreamWaves) {
     const int64_t base_text = w << 6;
     const int64_t my_text = base_text + lane;
-    const bool live = my_text < n;
+    bool live = my_text < n;
+    int slot_cap = slot_cap_arg;
+    int32_t* slot = nullptr;
+    if (MODE == ST_OVERFLOW) {
+      const int k_prev = live ? counts[my_text] : 0;
+      live = live && k_prev > slot_cap_arg;
+      if (!__any(live)) continue;
+      if (live) {
+        const int64_t pre = prefix[my_text];
+        const int64_t room = span_cap - pre;
+        slot = spans + 2 * pre;
+        slot_cap = (int)(room < k_prev ? (room > 0 ? room : 0) : k_prev);
+      }
+    } else if (MODE == ST_SLOTS) {
+      slot = slots + my_text * (int64_t)slot_cap * 2;
+    }
     const int my_len = live ? (lens ? lens[my_text] : common_len) : 0;
     // longest text in this wavefront decides the trip count
     int max_len = my_len;
@@ -188,7 +212,6 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
     uint32_t q4 = 0;       // 4 * state
     int start = 0;
     int cnt = 0;
-    int32_t* slot = slots ? slots + my_text * (int64_t)slot_cap * 2 : nullptr;
 
     for (int cbase = 0; cbase < max_len; cbase += kChunk) {
       // ---- stage 64 texts x 64 bytes -------------------------------------------
@@ -218,27 +241,65 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
 
       // ---- walk my 64 bytes -------------------------------------------------------
       const int lim = my_len - cbase;  // bytes of mine in this chunk (may be <= 0 or > 64)
+      if (__all(lim >= kChunk)) {
+        // Fast path, no per-byte branch.  Per 16-byte group: 16 independent column
+        // lookups (LDS, addressed by the byte only), then the serial state chain in
+        // registers; the two event bits of every byte are packed into F (bit 2k =
+        // NEWSTART, bit 2k+1 = EMIT of byte k) and turned into spans afterwards.
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const uint4 wv = *(const uint4*)(tile + lane * kRowPitch + g * 16);
-        const uint32_t words[4] = {wv.x, wv.y, wv.z, wv.w};
+        for (int g = 0; g < 4; ++g) {
+          const uint4 wv = *(const uint4*)(tile + lane * kRowPitch + g * 16);
+          const uint32_t words[4] = {wv.x, wv.y, wv.z, wv.w};
+          uint32_t cv[16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-          const int rel = g * 16 + k;
-          const uint32_t b = (words[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
-          const uint32_t col = col_lds[b];
-          uint32_t e = (col >> q4) & 0xFu;
-          const bool valid = rel < lim;
-          if (valid) {
-            const int pos = cbase + rel;
-            if (e & 2u) {  // EMIT: the walk that started at `start` ended here
+          for (int k = 0; k < 16; ++k)
+            cv[k] = col_lds[(words[k >> 2] >> ((k & 3) * 8)) & 0xFFu];
+          uint32_t F = 0;
+#pragma unroll
+          for (int k = 0; k < 16; ++k) {
+            const uint32_t e = cv[k] >> q4;
+            q4 = e & 0xCu;
+            F |= (e & 3u) << (2 * k);
+          }
+          const int gbase = cbase + g * 16;
+          uint32_t em = F & 0xAAAAAAAAu;
+          const uint32_t ns = F & 0x55555555u;
+          while (__any(em != 0)) {
+            if (em != 0) {
+              const int kk = __builtin_ctz(em) >> 1;                // byte of the first pending EMIT
+              const uint32_t nsb = ns & ((1u << (2 * kk)) - 1u);     // NEWSTARTs strictly before it
+              const int st = nsb ? gbase + ((31 - __builtin_clz(nsb)) >> 1) : start;
               if (!COUNT_ONLY) {
-                if (cnt < slot_cap) { slot[2 * cnt] = start; slot[2 * cnt + 1] = pos; }
+                if (cnt < slot_cap) { slot[2 * cnt] = st; slot[2 * cnt + 1] = gbase + kk; }
               }
               ++cnt;
+              em &= em - 1;
             }
-            if (e & 1u) start = pos;  // NEWSTART
-            q4 = e & 0xCu;
+          }
+          if (ns) start = gbase + ((31 - __builtin_clz(ns)) >> 1);
+        }
+      } else {
+        // a text of this wavefront ends inside the chunk: per-byte validity
+#pragma unroll 1
+        for (int g = 0; g < 4; ++g) {
+          const uint4 wv = *(const uint4*)(tile + lane * kRowPitch + g * 16);
+          const uint32_t words[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+          for (int k = 0; k < 16; ++k) {
+            const int rel = g * 16 + k;
+            const uint32_t b = (words[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
+            const uint32_t e = (col_lds[b] >> q4) & 0xFu;
+            if (rel < lim) {
+              const int pos = cbase + rel;
+              if (e & 2u) {  // EMIT: the walk that started at `start` ended here
+                if (!COUNT_ONLY) {
+                  if (cnt < slot_cap) { slot[2 * cnt] = start; slot[2 * cnt + 1] = pos; }
+                }
+                ++cnt;
+              }
+              if (e & 1u) start = pos;  // NEWSTART
+              q4 = e & 0xCu;
+            }
           }
         }
       }
@@ -252,35 +313,56 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
         }
         ++cnt;
       }
-      counts[my_text] = cnt;
+      if (MODE != ST_OVERFLOW) counts[my_text] = cnt;
     }
   }
 }
 
-// slots -> CSR.  Texts whose count exceeds the slot capacity are re-walked with
-// the generic loop (rare by construction of the capacity).
+// slots -> CSR, one wavefront per 64 consecutive texts.  The wavefront's output
+// range [prefix[first], prefix[last+1]) is contiguous, so lane l copies output span
+// w = j + l for j = 0, 64, ...: it finds the owning text by a 6-step search over the
+// wavefront's 64 local offsets (registers, __shfl) and reads that text's slot.
+// Writes are fully coalesced, reads are contiguous per text.  Texts whose count
+// exceeds the slot capacity are skipped here (k_stream_findall<ST_OVERFLOW> writes them).
 __global__ __launch_bounds__(kBlock) void k_compact(DevPlan p, const uint8_t* __restrict__ blob,
                                                     Layout lay, int64_t n,
                                                     const int32_t* __restrict__ counts,
                                                     const int64_t* __restrict__ prefix,
                                                     const int32_t* __restrict__ slots, int slot_cap,
                                                     int32_t* __restrict__ spans, int64_t span_cap) {
-  extern __shared__ __align__(16) uint8_t lds[];
-  const Ctx c = stage_tables(p, blob, lds);
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    const int k = counts[i];
-    int64_t w = prefix[i];
-    if (k <= slot_cap) {
-      const int32_t* s = slots + i * (int64_t)slot_cap * 2;
-      for (int j = 0; j < k; ++j, ++w)
-        if (w < span_cap) { spans[2 * w] = s[2 * j]; spans[2 * w + 1] = s[2 * j + 1]; }
-    } else {
-      const Text t = lay.text(i);
-      for_each_match(c, t, [&](int s, int e) {
-        if (w < span_cap) { spans[2 * w] = s; spans[2 * w + 1] = e; }
-        ++w;
-      });
+  const int lane = threadIdx.x & 63;
+  const int64_t nw = (n + 63) >> 6;
+  const int waves_per_block = blockDim.x >> 6;
+  for (int64_t w = (int64_t)blockIdx.x * waves_per_block + (threadIdx.x >> 6); w < nw;
+       w += (int64_t)gridDim.x * waves_per_block) {
+    const int64_t i = (w << 6) + lane;
+    const bool live = i < n;
+    const int k = live ? counts[i] : 0;
+    const int64_t my_pre = live ? prefix[i] : 0;
+    const int64_t base = __shfl(my_pre, 0);
+    const int my_off = (int)(my_pre - base);  // < 64 * 2^31 in theory; counts are bounded by text length
+    const int last_live = (int)(((n - (w << 6)) < 64 ? (n - (w << 6)) : 64) - 1);
+    const int total = __shfl(my_off + k, last_live);
+    for (int j = 0; j < total; j += 64) {
+      const int o = j + lane;
+      // largest t in [0, last_live] with off[t] <= o
+      int lo = 0;
+#pragma unroll
+      for (int step = 32; step > 0; step >>= 1) {
+        const int cand = lo + step;
+        const int off_c = __shfl(my_off, cand > 63 ? 63 : cand);
+        if (cand <= last_live && off_c <= o) lo = cand;
+      }
+      const int off_t = __shfl(my_off, lo);
+      const int cnt_t = __shfl(k, lo);
+      if (o < total && cnt_t <= slot_cap) {
+        const int64_t src = (((w << 6) + lo) * (int64_t)slot_cap + (o - off_t)) * 2;
+        const int64_t dst = base + o;
+        if (dst < span_cap) {
+          const int2 v = *(const int2*)(slots + src);
+          *(int2*)(spans + 2 * dst) = v;
+        }
+      }
     }
   }
 }
@@ -568,9 +650,9 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
       int64_t g = (nw + kStreamWaves - 1) / kStreamWaves;
       if (g > 256 * 8) g = 256 * 8;
       ScanTimer tm(s);
-      hipLaunchKernelGGL(k_stream_findall<false>, dim3((unsigned)g), dim3(64 * kStreamWaves), 0, s, p,
-                         h->d_blob, lay.data, lay.stride, lay.lens, lay.len, n, d_counts, d_slots,
-                         slot_cap);
+      hipLaunchKernelGGL(k_stream_findall<ST_SLOTS>, dim3((unsigned)g), dim3(64 * kStreamWaves), 0, s,
+                         p, h->d_blob, lay.data, lay.stride, lay.lens, lay.len, n, d_counts, d_slots,
+                         slot_cap, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0);
       g_last_kernel = "k_stream_findall";
       HIP_TRY(hipGetLastError());
       tm.stop();
@@ -596,6 +678,12 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
     if (stream_ok) {
       hipLaunchKernelGGL(k_compact, dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s, p,
                          h->d_blob, lay, n, d_counts, d_prefix, d_slots, slot_cap, d_spans, span_cap);
+      const int64_t nw2 = (n + 63) / 64;
+      int64_t g2 = (nw2 + kStreamWaves - 1) / kStreamWaves;
+      if (g2 > 256 * 8) g2 = 256 * 8;
+      hipLaunchKernelGGL(k_stream_findall<ST_OVERFLOW>, dim3((unsigned)g2), dim3(64 * kStreamWaves), 0,
+                         s, p, h->d_blob, lay.data, lay.stride, lay.lens, lay.len, n, d_counts,
+                         (int32_t*)nullptr, slot_cap, d_prefix, d_spans, span_cap);
     } else {
       hipLaunchKernelGGL(k_findall<FA_EMIT>, dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s, p,
                          h->d_blob, lay, n, (int32_t*)nullptr, d_prefix, d_spans, span_cap);
