@@ -7,8 +7,8 @@
 //                      stages 64 texts x CHUNK bytes through LDS with coalesced
 //                      16-byte loads, each lane then walks its own text in lockstep
 //                      through a register-indexed search automaton (no per-byte
-//                      dependent memory access); spans go to per-text slots
-//   k_compact          slots -> CSR spans
+//                      dependent memory access); match events go to per-text records
+//   k_decode           event records -> CSR spans
 //   k_sub<MODE>        output sizes / output bytes of sub()
 //   k_scan_*           exclusive prefix sums (counts -> CSR offsets)
 // All tables are staged from the plan blob into LDS once per workgroup.
@@ -134,43 +134,51 @@ __global__ __launch_bounds__(kBlock) void k_findall(DevPlan p, const uint8_t* __
 // ---- streaming findall ----------------------------------------------------------
 // Each wavefront owns 64 consecutive texts (fixed pitch).  Per CHUNK of 64 bytes:
 //   1. 4 coalesced wave loads (16 B per lane; lane l reads text 16*j + l/4, segment
-//      l%4) bring 64 texts x 64 B into registers and then LDS, row pitch 80 B so
-//      that the per-lane 16-byte read-back is bank-conflict free;
+//      l%4) bring 64 texts x 64 B into registers (issued one chunk ahead, so their
+//      latency hides behind the walk of the previous chunk) and then into an LDS
+//      tile with an 80-byte row pitch: the per-lane 16-byte read-back is bank
+//      conflict free;
 //   2. every lane reads its own 64 bytes back (4 x ds_read_b128) and steps the
-//      4-state search automaton once per byte.  The transition for byte b is
-//      (col[b] >> 4*state) & 15 where col[] is a 256-entry u16 table in LDS: the
-//      table lookup depends only on the byte, never on the state, so the serial
-//      state chain is two register ops per byte.
+//      <=4-state search automaton once per byte.  The transition for byte b is
+//      (stcol[b] >> 4*state) & 15 with stcol[] a 256-entry u16 table in LDS: the
+//      lookup depends only on the byte, never on the state, so the serial chain is
+//      two register ops per byte and the lookups of a group issue back to back.
 // Entry bits: next<<2 | EMIT<<1 | NEWSTART (built by build_stream_cols()).
+// Events are not turned into spans here.  Per 16-byte group the two event bits of
+// every byte are packed into one word F (bit 2k = NEWSTART, bit 2k+1 = EMIT of byte
+// k); a group that holds an EMIT produces ONE 16-byte record {F, start carried into
+// the group, byte position of the group, #matches of the text before it | lane}.
+// The records of a wavefront go to ONE dense stream per wavefront: the lanes that
+// have a record in a group are ranked with ballot/mbcnt and write consecutive
+// 16-byte slots, so the stores are coalesced (per-lane scattered 16-byte stores
+// were measured to cost 3x the whole rest of the kernel, tools/stream_ablate.hip).
+// At most one record per text and group, so a stream of 64 * (len/16 + 2) slots
+// cannot overflow.  k_decode turns records into CSR spans; records carry their
+// text (lane) and rank, so their order in the stream does not matter.  This keeps
+// the hot loop free of per-match work whose trip count would otherwise be the
+// maximum over the 64 lanes.
 constexpr int kChunk = 64;
 constexpr int kRowPitch = 80;                    // bytes; 80/4 = 20 dwords -> conflict-free b128
 constexpr int kTileBytes = 64 * kRowPitch;       // one wavefront's tile
 constexpr int kStreamWaves = 4;
 
-struct SlotOut {
-  int32_t* slot;     // this text's span slots
-  int cap;           // spans per slot
-  int cnt;
-  __device__ __forceinline__ void emit(int s, int e) {
-    if (cnt < cap) { slot[2 * cnt] = s; slot[2 * cnt + 1] = e; }
-    ++cnt;
-  }
+struct EvRec {   // 16 bytes
+  uint32_t F;
+  int32_t start;     // start of the walk that is alive when the group begins
+  int32_t pos_base;  // text position of the group's first byte
+  uint32_t meta;     // (lane << 26) | matches of this text before this group
 };
+constexpr uint32_t kRecBeforeMask = (1u << 26) - 1u;
 
-enum { ST_SLOTS = 0, ST_COUNT = 1, ST_OVERFLOW = 2 };
+__host__ __device__ inline int64_t rec_row_len(int64_t max_len) { return max_len / 16 + 2; }
 
-// MODE ST_SLOTS:    spans of text i go to slots[i*slot_cap ...] (first slot_cap of them), counts[i] = #matches
-// MODE ST_COUNT:    counts only
-// MODE ST_OVERFLOW: second launch for the texts whose count exceeded the slot capacity: they are
-//                   streamed again and write straight to their CSR position (prefix known by then);
-//                   wavefronts without such a text return after reading 64 counts
+enum { ST_RECORDS = 0, ST_COUNT = 1 };
+
 template <int MODE>
 __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
     DevPlan p, const uint8_t* __restrict__ blob, const uint8_t* __restrict__ data, int64_t stride,
     const int32_t* __restrict__ lens, int32_t common_len, int64_t n, int32_t* __restrict__ counts,
-    int32_t* __restrict__ slots, int slot_cap_arg, const int64_t* __restrict__ prefix,
-    int32_t* __restrict__ spans, int64_t span_cap) {
-  constexpr bool COUNT_ONLY = MODE == ST_COUNT;
+    int32_t* __restrict__ wave_nrecs, EvRec* __restrict__ recs, int64_t rec_row) {
   __shared__ __align__(16) uint8_t tiles[kStreamWaves][kTileBytes];
   __shared__ __align__(16) uint16_t col_lds[256];
   {
@@ -183,185 +191,164 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
   uint8_t* tile = tiles[wave];
   const int64_t nwaves_total = (n + 63) >> 6;
   const uint32_t accmask = p.st_accept_mask;
+  const int seg = lane & 3;
 
   for (int64_t w = (int64_t)blockIdx.x * kStreamWaves + wave; w < nwaves_total;
        w += (int64_t)gridDim.x * kStreamWaves) {
     const int64_t base_text = w << 6;
     const int64_t my_text = base_text + lane;
-    bool live = my_text < n;
-    int slot_cap = slot_cap_arg;
-    int32_t* slot = nullptr;
-    if (MODE == ST_OVERFLOW) {
-      const int k_prev = live ? counts[my_text] : 0;
-      live = live && k_prev > slot_cap_arg;
-      if (!__any(live)) continue;
-      if (live) {
-        const int64_t pre = prefix[my_text];
-        const int64_t room = span_cap - pre;
-        slot = spans + 2 * pre;
-        slot_cap = (int)(room < k_prev ? (room > 0 ? room : 0) : k_prev);
-      }
-    } else if (MODE == ST_SLOTS) {
-      slot = slots + my_text * (int64_t)slot_cap * 2;
-    }
+    const bool live = my_text < n;
     const int my_len = live ? (lens ? lens[my_text] : common_len) : 0;
-    // longest text in this wavefront decides the trip count
-    int max_len = my_len;
+    int max_len = my_len;  // longest text in this wavefront decides the trip count
     for (int off = 32; off > 0; off >>= 1) max_len = max(max_len, __shfl_xor(max_len, off));
 
-    uint32_t q4 = 0;       // 4 * state
+    // rows this lane stages: texts 16*j + lane/4 of the wavefront (clamped in range)
+    const int64_t last_text = n - 1;
+    const int64_t t0 = base_text + (lane >> 2);
+    const uint8_t* row0 = data + (t0 < last_text ? t0 : last_text) * stride;
+    const uint8_t* row1 = data + (t0 + 16 < last_text ? t0 + 16 : last_text) * stride;
+    const uint8_t* row2 = data + (t0 + 32 < last_text ? t0 + 32 : last_text) * stride;
+    const uint8_t* row3 = data + (t0 + 48 < last_text ? t0 + 48 : last_text) * stride;
+    // The pitch is a multiple of 16, so a 16-byte load that starts inside a row stays
+    // inside it; past the row end the first bytes are read instead (and ignored).
+#define MRX_LOAD_CHUNK(CB)                                         \
+    do {                                                           \
+      int64_t boff_ = (int64_t)(CB) + seg * 16;                    \
+      if (boff_ >= stride) boff_ = 0;                              \
+      v0 = *(const uint4*)(row0 + boff_);                          \
+      v1 = *(const uint4*)(row1 + boff_);                          \
+      v2 = *(const uint4*)(row2 + boff_);                          \
+      v3 = *(const uint4*)(row3 + boff_);                          \
+    } while (0)
+
+    uint32_t q4 = 0;  // 4 * state
     int start = 0;
     int cnt = 0;
+    int wrec = 0;  // records written by this wavefront so far (wave uniform)
+    EvRec* wave_recs = (MODE == ST_RECORDS) ? recs + base_text * rec_row : nullptr;
 
+    uint4 v0, v1, v2, v3;
+    v0 = v1 = v2 = v3 = make_uint4(0, 0, 0, 0);
+    if (max_len > 0) MRX_LOAD_CHUNK(0);
+    uint8_t* wr = tile + (lane >> 2) * kRowPitch + seg * 16;
     for (int cbase = 0; cbase < max_len; cbase += kChunk) {
-      // ---- stage 64 texts x 64 bytes -------------------------------------------
-      uint4 v[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int row = 16 * j + (lane >> 2);
-        const int seg = lane & 3;
-        int64_t tr = base_text + row;
-        if (tr >= n) tr = n - 1;  // stay in bounds; the lane that owns it is not live
-        // the pitch is a multiple of 16 and rows are padded up to it, so a 16-byte
-        // load that starts inside the row never leaves it
-        const int64_t boff = (int64_t)cbase + seg * 16;
-        const uint8_t* src = data + tr * stride + (boff < stride ? boff : 0);
-        v[j] = *(const uint4*)src;
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int row = 16 * j + (lane >> 2);
-        const int seg = lane & 3;
-        *(uint4*)(tile + row * kRowPitch + seg * 16) = v[j];
-      }
-      // the tile is private to this wavefront: a wave-level fence is enough
+      *(uint4*)(wr) = v0;
+      *(uint4*)(wr + 16 * kRowPitch) = v1;
+      *(uint4*)(wr + 32 * kRowPitch) = v2;
+      *(uint4*)(wr + 48 * kRowPitch) = v3;
+      // the tile is private to this wavefront: wave-level ordering is enough
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (cbase + kChunk < max_len) MRX_LOAD_CHUNK(cbase + kChunk);  // prefetch next chunk
 
-      // ---- walk my 64 bytes -------------------------------------------------------
       const int lim = my_len - cbase;  // bytes of mine in this chunk (may be <= 0 or > 64)
-      if (__all(lim >= kChunk)) {
-        // Fast path, no per-byte branch.  Per 16-byte group: 16 independent column
-        // lookups (LDS, addressed by the byte only), then the serial state chain in
-        // registers; the two event bits of every byte are packed into F (bit 2k =
-        // NEWSTART, bit 2k+1 = EMIT of byte k) and turned into spans afterwards.
+      const bool full = __all(lim >= kChunk);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const uint4 wv = *(const uint4*)(tile + lane * kRowPitch + g * 16);
-          const uint32_t words[4] = {wv.x, wv.y, wv.z, wv.w};
+      for (int g = 0; g < 4; ++g) {
+        const uint4 wv = *(const uint4*)(tile + lane * kRowPitch + g * 16);
+        const uint32_t words[4] = {wv.x, wv.y, wv.z, wv.w};
+        uint32_t F = 0;
+        if (full) {
           uint32_t cv[16];
 #pragma unroll
           for (int k = 0; k < 16; ++k)
             cv[k] = col_lds[(words[k >> 2] >> ((k & 3) * 8)) & 0xFFu];
-          uint32_t F = 0;
 #pragma unroll
           for (int k = 0; k < 16; ++k) {
             const uint32_t e = cv[k] >> q4;
             q4 = e & 0xCu;
-            F |= (e & 3u) << (2 * k);
+            F = __builtin_amdgcn_alignbit(e, F, 2);  // F = (F >> 2) | (e << 30)
           }
-          const int gbase = cbase + g * 16;
-          uint32_t em = F & 0xAAAAAAAAu;
-          const uint32_t ns = F & 0x55555555u;
-          while (__any(em != 0)) {
-            if (em != 0) {
-              const int kk = __builtin_ctz(em) >> 1;                // byte of the first pending EMIT
-              const uint32_t nsb = ns & ((1u << (2 * kk)) - 1u);     // NEWSTARTs strictly before it
-              const int st = nsb ? gbase + ((31 - __builtin_clz(nsb)) >> 1) : start;
-              if (!COUNT_ONLY) {
-                if (cnt < slot_cap) { slot[2 * cnt] = st; slot[2 * cnt + 1] = gbase + kk; }
-              }
-              ++cnt;
-              em &= em - 1;
-            }
-          }
-          if (ns) start = gbase + ((31 - __builtin_clz(ns)) >> 1);
-        }
-      } else {
-        // a text of this wavefront ends inside the chunk: per-byte validity
-#pragma unroll 1
-        for (int g = 0; g < 4; ++g) {
-          const uint4 wv = *(const uint4*)(tile + lane * kRowPitch + g * 16);
-          const uint32_t words[4] = {wv.x, wv.y, wv.z, wv.w};
+        } else {
+          // a text of this wavefront ends inside the chunk: bytes past the end are no-ops
 #pragma unroll
           for (int k = 0; k < 16; ++k) {
-            const int rel = g * 16 + k;
             const uint32_t b = (words[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
-            const uint32_t e = (col_lds[b] >> q4) & 0xFu;
-            if (rel < lim) {
-              const int pos = cbase + rel;
-              if (e & 2u) {  // EMIT: the walk that started at `start` ended here
-                if (!COUNT_ONLY) {
-                  if (cnt < slot_cap) { slot[2 * cnt] = start; slot[2 * cnt + 1] = pos; }
-                }
-                ++cnt;
-              }
-              if (e & 1u) start = pos;  // NEWSTART
-              q4 = e & 0xCu;
-            }
+            uint32_t e = col_lds[b] >> q4;
+            if (g * 16 + k >= lim) e = q4;  // keep the state, no event bits
+            q4 = e & 0xCu;
+            F = __builtin_amdgcn_alignbit(e, F, 2);
           }
         }
+        const uint32_t em = F & 0xAAAAAAAAu;
+        const uint32_t ns = F & 0x55555555u;
+        const int gbase = cbase + g * 16;
+        if (MODE == ST_RECORDS) {
+          const uint64_t has = __ballot(em != 0);
+          if (has) {  // wave uniform
+            if (em) {
+              const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(has >> 32),
+                                                         __builtin_amdgcn_mbcnt_lo((uint32_t)has, 0));
+              EvRec r;
+              r.F = F; r.start = start; r.pos_base = gbase;
+              r.meta = ((uint32_t)lane << 26) | ((uint32_t)cnt & kRecBeforeMask);
+              wave_recs[wrec + rank] = r;
+            }
+            wrec += __builtin_popcountll(has);
+          }
+        }
+        cnt += __builtin_popcount(em);
+        if (ns) start = gbase + ((31 - __builtin_clz(ns)) >> 1);
       }
       __builtin_amdgcn_wave_barrier();
     }
     // end of text: a walk that is in an accepting state ends at len
-    if (live) {
-      if ((accmask >> (q4 >> 2)) & 1u) {
-        if (!COUNT_ONLY) {
-          if (cnt < slot_cap) { slot[2 * cnt] = start; slot[2 * cnt + 1] = my_len; }
+    {
+      const bool tail = live && ((accmask >> (q4 >> 2)) & 1u);
+      if (MODE == ST_RECORDS) {
+        const uint64_t has = __ballot(tail);
+        if (tail) {
+          const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(has >> 32),
+                                                     __builtin_amdgcn_mbcnt_lo((uint32_t)has, 0));
+          EvRec r;
+          r.F = 2u; r.start = start; r.pos_base = my_len;  // EMIT at byte 0 of a group placed at len
+          r.meta = ((uint32_t)lane << 26) | ((uint32_t)cnt & kRecBeforeMask);
+          wave_recs[wrec + rank] = r;
         }
-        ++cnt;
+        wrec += __builtin_popcountll(has);
+        if (lane == 0) wave_nrecs[w] = wrec;
       }
-      if (MODE != ST_OVERFLOW) counts[my_text] = cnt;
+      if (tail) ++cnt;
+      if (live) counts[my_text] = cnt;
     }
   }
+#undef MRX_LOAD_CHUNK
 }
 
-// slots -> CSR, one wavefront per 64 consecutive texts.  The wavefront's output
-// range [prefix[first], prefix[last+1]) is contiguous, so lane l copies output span
-// w = j + l for j = 0, 64, ...: it finds the owning text by a 6-step search over the
-// wavefront's 64 local offsets (registers, __shfl) and reads that text's slot.
-// Writes are fully coalesced, reads are contiguous per text.  Texts whose count
-// exceeds the slot capacity are skipped here (k_stream_findall<ST_OVERFLOW> writes them).
-__global__ __launch_bounds__(kBlock) void k_compact(DevPlan p, const uint8_t* __restrict__ blob,
-                                                    Layout lay, int64_t n,
-                                                    const int32_t* __restrict__ counts,
-                                                    const int64_t* __restrict__ prefix,
-                                                    const int32_t* __restrict__ slots, int slot_cap,
-                                                    int32_t* __restrict__ spans, int64_t span_cap) {
+// records -> CSR spans.  One wavefront per 64 consecutive texts (the wavefront that
+// produced the stream): lane l takes record j + l (j = 0, 64, ...) of the stream,
+// gets the CSR offset of the record's text from the lane that holds it (__shfl) and
+// expands the record's EMIT bits into spans at prefix[text] + before + i.
+__global__ __launch_bounds__(kBlock) void k_decode(int64_t n, const int32_t* __restrict__ wave_nrecs,
+                                                   const EvRec* __restrict__ recs, int64_t rec_row,
+                                                   const int64_t* __restrict__ prefix,
+                                                   int32_t* __restrict__ spans, int64_t span_cap) {
   const int lane = threadIdx.x & 63;
   const int64_t nw = (n + 63) >> 6;
   const int waves_per_block = blockDim.x >> 6;
   for (int64_t w = (int64_t)blockIdx.x * waves_per_block + (threadIdx.x >> 6); w < nw;
        w += (int64_t)gridDim.x * waves_per_block) {
     const int64_t i = (w << 6) + lane;
-    const bool live = i < n;
-    const int k = live ? counts[i] : 0;
-    const int64_t my_pre = live ? prefix[i] : 0;
-    const int64_t base = __shfl(my_pre, 0);
-    const int my_off = (int)(my_pre - base);  // < 64 * 2^31 in theory; counts are bounded by text length
-    const int last_live = (int)(((n - (w << 6)) < 64 ? (n - (w << 6)) : 64) - 1);
-    const int total = __shfl(my_off + k, last_live);
+    const int64_t my_pre = i < n ? prefix[i] : 0;
+    const int total = wave_nrecs[w];
+    const EvRec* wave_recs = recs + (w << 6) * rec_row;
     for (int j = 0; j < total; j += 64) {
       const int o = j + lane;
-      // largest t in [0, last_live] with off[t] <= o
-      int lo = 0;
-#pragma unroll
-      for (int step = 32; step > 0; step >>= 1) {
-        const int cand = lo + step;
-        const int off_c = __shfl(my_off, cand > 63 ? 63 : cand);
-        if (cand <= last_live && off_c <= o) lo = cand;
-      }
-      const int off_t = __shfl(my_off, lo);
-      const int cnt_t = __shfl(k, lo);
-      if (o < total && cnt_t <= slot_cap) {
-        const int64_t src = (((w << 6) + lo) * (int64_t)slot_cap + (o - off_t)) * 2;
-        const int64_t dst = base + o;
-        if (dst < span_cap) {
-          const int2 v = *(const int2*)(slots + src);
-          *(int2*)(spans + 2 * dst) = v;
-        }
+      EvRec r;
+      r.F = 0; r.start = 0; r.pos_base = 0; r.meta = 0;
+      if (o < total) r = wave_recs[o];
+      const int64_t pre_t = __shfl(my_pre, (int)(r.meta >> 26));
+      uint32_t em = r.F & 0xAAAAAAAAu;
+      const uint32_t ns = r.F & 0x55555555u;
+      int64_t dst = pre_t + (r.meta & kRecBeforeMask);
+      while (em) {
+        const int kk = __builtin_ctz(em) >> 1;              // byte of this EMIT
+        const uint32_t nsb = ns & ((1u << (2 * kk)) - 1u);   // NEWSTARTs strictly before it
+        const int st = nsb ? r.pos_base + ((31 - __builtin_clz(nsb)) >> 1) : r.start;
+        if (dst < span_cap) { spans[2 * dst] = st; spans[2 * dst + 1] = r.pos_base + kk; }
+        ++dst;
+        em &= em - 1;
       }
     }
   }
@@ -636,23 +623,22 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
   const DevPlan& p = h->hp.dev;
   const bool stream_ok = (p.flags & PF_STREAMABLE) && !lay.offsets && (lay.stride % 16 == 0) &&
                          (((uintptr_t)lay.data) % 16 == 0) && n > 0;
-  int32_t* d_slots = nullptr;
-  int slot_cap = 0;
+  EvRec* d_recs = nullptr;
+  int32_t* d_nrecs = nullptr;
+  int64_t rec_row = 0;
   if (n > 0) {
     if (stream_ok) {
-      // slot capacity: a match needs >= 1 byte and two matches cannot touch unless the
-      // second starts where the first ends; cap the slot at 64 spans and let the
-      // compaction kernel re-walk the (rare) texts that overflow
-      const int64_t max_len = lay.lens ? lay.stride : lay.len;
-      slot_cap = (int)(max_len < 64 ? (max_len > 0 ? max_len : 1) : 64);
-      HIP_TRY(hipMallocAsync((void**)&d_slots, sizeof(int32_t) * 2 * (size_t)slot_cap * n, s));
+      // one 16-byte record per 16-byte group at most (+1 for the match that ends at len)
+      rec_row = rec_row_len(lay.lens ? lay.stride : lay.len);
+      HIP_TRY(hipMallocAsync((void**)&d_recs, sizeof(EvRec) * (size_t)rec_row * n, s));
+      HIP_TRY(hipMallocAsync((void**)&d_nrecs, sizeof(int32_t) * ((n + 63) / 64), s));
       const int64_t nw = (n + 63) / 64;
       int64_t g = (nw + kStreamWaves - 1) / kStreamWaves;
       if (g > 256 * 8) g = 256 * 8;
       ScanTimer tm(s);
-      hipLaunchKernelGGL(k_stream_findall<ST_SLOTS>, dim3((unsigned)g), dim3(64 * kStreamWaves), 0, s,
-                         p, h->d_blob, lay.data, lay.stride, lay.lens, lay.len, n, d_counts, d_slots,
-                         slot_cap, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0);
+      hipLaunchKernelGGL(k_stream_findall<ST_RECORDS>, dim3((unsigned)g), dim3(64 * kStreamWaves), 0,
+                         s, p, h->d_blob, lay.data, lay.stride, lay.lens, lay.len, n, d_counts,
+                         d_nrecs, d_recs, rec_row);
       g_last_kernel = "k_stream_findall";
       HIP_TRY(hipGetLastError());
       tm.stop();
@@ -676,14 +662,8 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
     rc = fail(MRX_E_CAPACITY, "span buffer too small: need " + std::to_string(tot));
   } else if (n > 0 && tot > 0) {
     if (stream_ok) {
-      hipLaunchKernelGGL(k_compact, dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s, p,
-                         h->d_blob, lay, n, d_counts, d_prefix, d_slots, slot_cap, d_spans, span_cap);
-      const int64_t nw2 = (n + 63) / 64;
-      int64_t g2 = (nw2 + kStreamWaves - 1) / kStreamWaves;
-      if (g2 > 256 * 8) g2 = 256 * 8;
-      hipLaunchKernelGGL(k_stream_findall<ST_OVERFLOW>, dim3((unsigned)g2), dim3(64 * kStreamWaves), 0,
-                         s, p, h->d_blob, lay.data, lay.stride, lay.lens, lay.len, n, d_counts,
-                         (int32_t*)nullptr, slot_cap, d_prefix, d_spans, span_cap);
+      hipLaunchKernelGGL(k_decode, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, n, d_nrecs, d_recs,
+                         rec_row, d_prefix, d_spans, span_cap);
     } else {
       hipLaunchKernelGGL(k_findall<FA_EMIT>, dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s, p,
                          h->d_blob, lay, n, (int32_t*)nullptr, d_prefix, d_spans, span_cap);
@@ -692,7 +672,8 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
   }
   HIP_TRY(hipFreeAsync(d_counts, s));
   HIP_TRY(hipFreeAsync(d_total, s));
-  if (d_slots) HIP_TRY(hipFreeAsync(d_slots, s));
+  if (d_recs) HIP_TRY(hipFreeAsync(d_recs, s));
+  if (d_nrecs) HIP_TRY(hipFreeAsync(d_nrecs, s));
   return rc;
 }
 
