@@ -317,39 +317,60 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
 }
 
 // records -> CSR spans.  One wavefront per 64 consecutive texts (the wavefront that
-// produced the stream): lane l takes record j + l (j = 0, 64, ...) of the stream,
-// gets the CSR offset of the record's text from the lane that holds it (__shfl) and
-// expands the record's EMIT bits into spans at prefix[text] + before + i.
+// produced the stream).  The wavefront's output range [prefix[first], prefix[last+1])
+// is contiguous but the stream is ordered by (group, lane), so spans are first
+// scattered into an LDS tile at their final relative position and the tile is then
+// written out with fully coalesced 8-byte stores.  Per tile the stream is read once
+// (coalesced 16-byte loads; re-reads for further tiles come from L2).
+constexpr int kDecodeTile = 1024;  // spans per LDS tile and wavefront (8 KiB)
+
 __global__ __launch_bounds__(kBlock) void k_decode(int64_t n, const int32_t* __restrict__ wave_nrecs,
                                                    const EvRec* __restrict__ recs, int64_t rec_row,
                                                    const int64_t* __restrict__ prefix,
                                                    int32_t* __restrict__ spans, int64_t span_cap) {
+  __shared__ int2 tile_all[kBlock / 64][kDecodeTile];
   const int lane = threadIdx.x & 63;
+  int2* tile = tile_all[threadIdx.x >> 6];
   const int64_t nw = (n + 63) >> 6;
   const int waves_per_block = blockDim.x >> 6;
   for (int64_t w = (int64_t)blockIdx.x * waves_per_block + (threadIdx.x >> 6); w < nw;
        w += (int64_t)gridDim.x * waves_per_block) {
-    const int64_t i = (w << 6) + lane;
-    const int64_t my_pre = i < n ? prefix[i] : 0;
-    const int total = wave_nrecs[w];
-    const EvRec* wave_recs = recs + (w << 6) * rec_row;
-    for (int j = 0; j < total; j += 64) {
-      const int o = j + lane;
-      EvRec r;
-      r.F = 0; r.start = 0; r.pos_base = 0; r.meta = 0;
-      if (o < total) r = wave_recs[o];
-      const int64_t pre_t = __shfl(my_pre, (int)(r.meta >> 26));
-      uint32_t em = r.F & 0xAAAAAAAAu;
-      const uint32_t ns = r.F & 0x55555555u;
-      int64_t dst = pre_t + (r.meta & kRecBeforeMask);
-      while (em) {
-        const int kk = __builtin_ctz(em) >> 1;              // byte of this EMIT
-        const uint32_t nsb = ns & ((1u << (2 * kk)) - 1u);   // NEWSTARTs strictly before it
-        const int st = nsb ? r.pos_base + ((31 - __builtin_clz(nsb)) >> 1) : r.start;
-        if (dst < span_cap) { spans[2 * dst] = st; spans[2 * dst + 1] = r.pos_base + kk; }
-        ++dst;
-        em &= em - 1;
+    const int64_t first = w << 6;
+    const int64_t i = first + lane;
+    const int64_t pre0 = prefix[first];
+    const int my_rel = (int)((i < n ? prefix[i] : 0) - pre0);   // start of my text's spans in the range
+    const int64_t last1 = first + 64 < n ? first + 64 : n;
+    const int total_spans = (int)(prefix[last1] - pre0);
+    const int total_recs = wave_nrecs[w];
+    const EvRec* wave_recs = recs + first * rec_row;
+    for (int tb = 0; tb < total_spans; tb += kDecodeTile) {
+      for (int j = 0; j < total_recs; j += 64) {
+        const int o = j + lane;
+        EvRec r;
+        r.F = 0; r.start = 0; r.pos_base = 0; r.meta = 0;
+        if (o < total_recs) r = wave_recs[o];
+        const int rel_t = __shfl(my_rel, (int)(r.meta >> 26));
+        uint32_t em = r.F & 0xAAAAAAAAu;
+        const uint32_t ns = r.F & 0x55555555u;
+        int dst = rel_t + (int)(r.meta & kRecBeforeMask) - tb;
+        while (em) {
+          const int kk = __builtin_ctz(em) >> 1;              // byte of this EMIT
+          const uint32_t nsb = ns & ((1u << (2 * kk)) - 1u);   // NEWSTARTs strictly before it
+          const int st = nsb ? r.pos_base + ((31 - __builtin_clz(nsb)) >> 1) : r.start;
+          if (dst >= 0 && dst < kDecodeTile) tile[dst] = make_int2(st, r.pos_base + kk);
+          ++dst;
+          em &= em - 1;
+        }
       }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int cnt = total_spans - tb < kDecodeTile ? total_spans - tb : kDecodeTile;
+      for (int k = lane; k < cnt; k += 64) {
+        const int64_t dst = pre0 + tb + k;
+        if (dst < span_cap) *(int2*)(spans + 2 * dst) = tile[k];
+      }
+      __builtin_amdgcn_wave_barrier();
     }
   }
 }
@@ -653,14 +674,10 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
     }
   }
   if (int rc = device_scan<int32_t>(d_counts, n, d_prefix, d_total, s)) return rc;
-  int64_t tot = 0;
-  HIP_TRY(hipMemcpyAsync(&tot, d_total, sizeof tot, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
-  if (total) *total = tot;
-  int rc = MRX_OK;
-  if (tot > span_cap) {
-    rc = fail(MRX_E_CAPACITY, "span buffer too small: need " + std::to_string(tot));
-  } else if (n > 0 && tot > 0) {
+  // Second stage is enqueued before the total is known on the host: both kernels clip
+  // at span_cap, so a too-small buffer is reported (MRX_E_CAPACITY) without overrun and
+  // the whole call needs a single stream synchronisation.
+  if (n > 0 && span_cap > 0) {
     if (stream_ok) {
       hipLaunchKernelGGL(k_decode, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, n, d_nrecs, d_recs,
                          rec_row, d_prefix, d_spans, span_cap);
@@ -670,6 +687,12 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
     }
     HIP_TRY(hipGetLastError());
   }
+  int64_t tot = 0;
+  HIP_TRY(hipMemcpyAsync(&tot, d_total, sizeof tot, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (total) *total = tot;
+  int rc = MRX_OK;
+  if (tot > span_cap) rc = fail(MRX_E_CAPACITY, "span buffer too small: need " + std::to_string(tot));
   HIP_TRY(hipFreeAsync(d_counts, s));
   HIP_TRY(hipFreeAsync(d_total, s));
   if (d_recs) HIP_TRY(hipFreeAsync(d_recs, s));
