@@ -132,13 +132,14 @@ __global__ __launch_bounds__(kBlock) void k_findall(DevPlan p, const uint8_t* __
 }
 
 // ---- streaming findall ----------------------------------------------------------
-// Each wavefront owns 64 consecutive texts (fixed pitch).  Per CHUNK of 64 bytes:
-//   1. 4 coalesced wave loads (16 B per lane; lane l reads text 16*j + l/4, segment
-//      l%4) bring 64 texts x 64 B into registers (issued one chunk ahead, so their
+// Each wavefront owns 64 consecutive texts (fixed pitch).  Per CHUNK (128 bytes of
+// every text, i.e. one cache line per text):
+//   1. CHUNK/16 coalesced wave loads (16 B per lane; 8 lanes cover one text's line,
+//      8 texts per instruction) bring 64 texts x CHUNK bytes into registers (issued one chunk ahead, so their
 //      latency hides behind the walk of the previous chunk) and then into an LDS
-//      tile with an 80-byte row pitch: the per-lane 16-byte read-back is bank
-//      conflict free;
-//   2. every lane reads its own 64 bytes back (4 x ds_read_b128) and steps the
+//      tile with a (CHUNK+16)-byte row pitch: the per-lane 16-byte read-back is
+//      bank conflict free;
+//   2. every lane reads its own CHUNK bytes back (ds_read_b128) and steps the
 //      <=4-state search automaton once per byte.  The transition for byte b is
 //      (stcol[b] >> 4*state) & 15 with stcol[] a 256-entry u16 table in LDS: the
 //      lookup depends only on the byte, never on the state, so the serial chain is
@@ -157,10 +158,13 @@ __global__ __launch_bounds__(kBlock) void k_findall(DevPlan p, const uint8_t* __
 // text (lane) and rank, so their order in the stream does not matter.  This keeps
 // the hot loop free of per-match work whose trip count would otherwise be the
 // maximum over the 64 lanes.
-constexpr int kChunk = 64;
-constexpr int kRowPitch = 80;                    // bytes; 80/4 = 20 dwords -> conflict-free b128
-constexpr int kTileBytes = 64 * kRowPitch;       // one wavefront's tile
 constexpr int kStreamWaves = 4;
+// Bytes of every text staged per step.  128 = one full cache line per text and step:
+// with 64 the two halves of a line are requested a chunk-time apart and part of the
+// lines are fetched from HBM twice (rocprof FETCH_SIZE).
+#ifndef MRX_STREAM_CHUNK
+#define MRX_STREAM_CHUNK 128
+#endif
 
 struct EvRec {   // 16 bytes
   uint32_t F;
@@ -174,12 +178,17 @@ __host__ __device__ inline int64_t rec_row_len(int64_t max_len) { return max_len
 
 enum { ST_RECORDS = 0, ST_COUNT = 1 };
 
-template <int MODE>
+template <int MODE, int CH>
 __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
     DevPlan p, const uint8_t* __restrict__ blob, const uint8_t* __restrict__ data, int64_t stride,
     const int32_t* __restrict__ lens, int32_t common_len, int64_t n, int32_t* __restrict__ counts,
     int32_t* __restrict__ wave_nrecs, EvRec* __restrict__ recs, int64_t rec_row) {
-  __shared__ __align__(16) uint8_t tiles[kStreamWaves][kTileBytes];
+  constexpr int kChunk = CH;
+  constexpr int kRowPitch = CH + 16;      // +16: the per-lane 16-byte read-back is bank-conflict free
+  constexpr int LPR = CH / 16;            // lanes that cover one text row in a load instruction
+  constexpr int RPI = 64 / LPR;           // text rows per load instruction
+  constexpr int NL = 64 / RPI;            // load instructions per chunk (= CH / 16)
+  __shared__ __align__(16) uint8_t tiles[kStreamWaves][64 * kRowPitch];
   __shared__ __align__(16) uint16_t col_lds[256];
   {
     const uint16_t* src = (const uint16_t*)(blob + p.off_stcol);
@@ -191,7 +200,8 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
   uint8_t* tile = tiles[wave];
   const int64_t nwaves_total = (n + 63) >> 6;
   const uint32_t accmask = p.st_accept_mask;
-  const int seg = lane & 3;
+  const int seg = lane % LPR;
+  const int rsub = lane / LPR;
 
   for (int64_t w = (int64_t)blockIdx.x * kStreamWaves + wave; w < nwaves_total;
        w += (int64_t)gridDim.x * kStreamWaves) {
@@ -202,23 +212,25 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
     int max_len = my_len;  // longest text in this wavefront decides the trip count
     for (int off = 32; off > 0; off >>= 1) max_len = max(max_len, __shfl_xor(max_len, off));
 
-    // rows this lane stages: texts 16*j + lane/4 of the wavefront (clamped in range)
-    const int64_t last_text = n - 1;
-    const int64_t t0 = base_text + (lane >> 2);
-    const uint8_t* row0 = data + (t0 < last_text ? t0 : last_text) * stride;
-    const uint8_t* row1 = data + (t0 + 16 < last_text ? t0 + 16 : last_text) * stride;
-    const uint8_t* row2 = data + (t0 + 32 < last_text ? t0 + 32 : last_text) * stride;
-    const uint8_t* row3 = data + (t0 + 48 < last_text ? t0 + 48 : last_text) * stride;
+    // rows this lane stages: texts RPI*j + lane/LPR of the wavefront.  Addresses are a
+    // wave-uniform base plus a 32-bit lane offset (rows past the batch end are clamped).
+    const uint8_t* wbase = data + base_text * stride;
+    const int64_t rows_here = n - base_text < 64 ? n - base_text : 64;
+    uint32_t roff[NL];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      int r = RPI * j + rsub;
+      if (r >= rows_here) r = (int)rows_here - 1;
+      roff[j] = (uint32_t)(r * stride) + seg * 16;
+    }
     // The pitch is a multiple of 16, so a 16-byte load that starts inside a row stays
     // inside it; past the row end the first bytes are read instead (and ignored).
-#define MRX_LOAD_CHUNK(CB)                                         \
-    do {                                                           \
-      int64_t boff_ = (int64_t)(CB) + seg * 16;                    \
-      if (boff_ >= stride) boff_ = 0;                              \
-      v0 = *(const uint4*)(row0 + boff_);                          \
-      v1 = *(const uint4*)(row1 + boff_);                          \
-      v2 = *(const uint4*)(row2 + boff_);                          \
-      v3 = *(const uint4*)(row3 + boff_);                          \
+#define MRX_LOAD_CHUNK(CB)                                                       \
+    do {                                                                         \
+      uint32_t cb_ = (uint32_t)(CB);                                             \
+      if ((int64_t)cb_ + seg * 16 >= stride) cb_ = (uint32_t)0 - (uint32_t)(seg * 16); \
+      _Pragma("unroll") for (int j_ = 0; j_ < NL; ++j_)                          \
+        v[j_] = *(const uint4*)(wbase + (roff[j_] + cb_));                       \
     } while (0)
 
     uint32_t q4 = 0;  // 4 * state
@@ -227,15 +239,14 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
     int wrec = 0;  // records written by this wavefront so far (wave uniform)
     EvRec* wave_recs = (MODE == ST_RECORDS) ? recs + base_text * rec_row : nullptr;
 
-    uint4 v0, v1, v2, v3;
-    v0 = v1 = v2 = v3 = make_uint4(0, 0, 0, 0);
+    uint4 v[NL];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) v[j] = make_uint4(0, 0, 0, 0);
     if (max_len > 0) MRX_LOAD_CHUNK(0);
-    uint8_t* wr = tile + (lane >> 2) * kRowPitch + seg * 16;
+    uint8_t* wr = tile + rsub * kRowPitch + seg * 16;
     for (int cbase = 0; cbase < max_len; cbase += kChunk) {
-      *(uint4*)(wr) = v0;
-      *(uint4*)(wr + 16 * kRowPitch) = v1;
-      *(uint4*)(wr + 32 * kRowPitch) = v2;
-      *(uint4*)(wr + 48 * kRowPitch) = v3;
+#pragma unroll
+      for (int j = 0; j < NL; ++j) *(uint4*)(wr + j * RPI * kRowPitch) = v[j];
       // the tile is private to this wavefront: wave-level ordering is enough
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -245,7 +256,7 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
       const int lim = my_len - cbase;  // bytes of mine in this chunk (may be <= 0 or > 64)
       const bool full = __all(lim >= kChunk);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
+      for (int g = 0; g < kChunk / 16; ++g) {
         const uint4 wv = *(const uint4*)(tile + lane * kRowPitch + g * 16);
         const uint32_t words[4] = {wv.x, wv.y, wv.z, wv.w};
         uint32_t F = 0;
@@ -344,22 +355,30 @@ __global__ __launch_bounds__(kBlock) void k_decode(int64_t n, const int32_t* __r
     const int total_recs = wave_nrecs[w];
     const EvRec* wave_recs = recs + first * rec_row;
     for (int tb = 0; tb < total_spans; tb += kDecodeTile) {
-      for (int j = 0; j < total_recs; j += 64) {
-        const int o = j + lane;
-        EvRec r;
-        r.F = 0; r.start = 0; r.pos_base = 0; r.meta = 0;
-        if (o < total_recs) r = wave_recs[o];
-        const int rel_t = __shfl(my_rel, (int)(r.meta >> 26));
-        uint32_t em = r.F & 0xAAAAAAAAu;
-        const uint32_t ns = r.F & 0x55555555u;
-        int dst = rel_t + (int)(r.meta & kRecBeforeMask) - tb;
-        while (em) {
-          const int kk = __builtin_ctz(em) >> 1;              // byte of this EMIT
-          const uint32_t nsb = ns & ((1u << (2 * kk)) - 1u);   // NEWSTARTs strictly before it
-          const int st = nsb ? r.pos_base + ((31 - __builtin_clz(nsb)) >> 1) : r.start;
-          if (dst >= 0 && dst < kDecodeTile) tile[dst] = make_int2(st, r.pos_base + kk);
-          ++dst;
-          em &= em - 1;
+      for (int j = 0; j < total_recs; j += 256) {
+        // four independent 16-byte loads in flight per lane before any is consumed
+        EvRec rr[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int o = j + u * 64 + lane;
+          rr[u].F = 0; rr[u].start = 0; rr[u].pos_base = 0; rr[u].meta = 0;
+          if (o < total_recs) rr[u] = wave_recs[o];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const EvRec r = rr[u];
+          const int rel_t = __shfl(my_rel, (int)(r.meta >> 26));
+          uint32_t em = r.F & 0xAAAAAAAAu;
+          const uint32_t ns = r.F & 0x55555555u;
+          int dst = rel_t + (int)(r.meta & kRecBeforeMask) - tb;
+          while (em) {
+            const int kk = __builtin_ctz(em) >> 1;              // byte of this EMIT
+            const uint32_t nsb = ns & ((1u << (2 * kk)) - 1u);   // NEWSTARTs strictly before it
+            const int st = nsb ? r.pos_base + ((31 - __builtin_clz(nsb)) >> 1) : r.start;
+            if (dst >= 0 && dst < kDecodeTile) tile[dst] = make_int2(st, r.pos_base + kk);
+            ++dst;
+            em &= em - 1;
+          }
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -643,7 +662,8 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
   HIP_TRY(hipMallocAsync((void**)&d_total, sizeof(int64_t), s));
   const DevPlan& p = h->hp.dev;
   const bool stream_ok = (p.flags & PF_STREAMABLE) && !lay.offsets && (lay.stride % 16 == 0) &&
-                         (((uintptr_t)lay.data) % 16 == 0) && n > 0;
+                         (((uintptr_t)lay.data) % 16 == 0) && n > 0 &&
+                         lay.stride * 64 < (int64_t(1) << 31);
   EvRec* d_recs = nullptr;
   int32_t* d_nrecs = nullptr;
   int64_t rec_row = 0;
@@ -657,7 +677,7 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
       int64_t g = (nw + kStreamWaves - 1) / kStreamWaves;
       if (g > 256 * 8) g = 256 * 8;
       ScanTimer tm(s);
-      hipLaunchKernelGGL(k_stream_findall<ST_RECORDS>, dim3((unsigned)g), dim3(64 * kStreamWaves), 0,
+      hipLaunchKernelGGL((k_stream_findall<ST_RECORDS, MRX_STREAM_CHUNK>), dim3((unsigned)g), dim3(64 * kStreamWaves), 0,
                          s, p, h->d_blob, lay.data, lay.stride, lay.lens, lay.len, n, d_counts,
                          d_nrecs, d_recs, rec_row);
       g_last_kernel = "k_stream_findall";

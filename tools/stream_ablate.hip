@@ -11,13 +11,14 @@
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
 constexpr int kChunk = 64, kRowPitch = 80, kTileBytes = 64 * kRowPitch, kWaves = 4;
-struct EvRec { uint32_t F; int32_t start, pos_base, before; };
+struct EvRec { uint32_t F; int32_t start, pos_base; uint32_t meta; };
 
 // VAR bits: 1 = no column lookup (cv from the byte itself), 2 = no record store,
 // 4 = no global loads after the first chunk (reuse registers), 8 = no LDS tile (walk v0 directly),
-// 16 = no event handling at all
-template <int VAR>
-__global__ __launch_bounds__(64 * kWaves) void k(const uint16_t* __restrict__ cols,
+// 16 = no event handling at all, 32 = old per-lane scattered record rows
+// LB = waves per SIMD requested through __launch_bounds__
+template <int VAR, int LB>
+__global__ __launch_bounds__(64 * kWaves, LB) void k(const uint16_t* __restrict__ cols,
                                                    const uint8_t* __restrict__ data, int64_t stride,
                                                    int32_t len, int64_t n, int32_t* __restrict__ counts,
                                                    EvRec* __restrict__ recs, int64_t rec_row) {
@@ -35,8 +36,9 @@ __global__ __launch_bounds__(64 * kWaves) void k(const uint16_t* __restrict__ co
     const uint8_t* row1 = data + (t0 + 16) * stride;
     const uint8_t* row2 = data + (t0 + 32) * stride;
     const uint8_t* row3 = data + (t0 + 48) * stride;
-    uint32_t q4 = 0; int start = 0, cnt = 0, nrec = 0;
+    uint32_t q4 = 0; int start = 0, cnt = 0, nrec = 0, wrec = 0;
     EvRec* myrec = recs + my_text * rec_row;
+    EvRec* wave_recs = recs + base_text * rec_row;
     uint4 v0, v1, v2, v3;
 #define LOADC(CB) do { int64_t b_ = (CB) + seg * 16; v0 = *(const uint4*)(row0 + b_); v1 = *(const uint4*)(row1 + b_); \
                        v2 = *(const uint4*)(row2 + b_); v3 = *(const uint4*)(row3 + b_); } while (0)
@@ -73,16 +75,28 @@ __global__ __launch_bounds__(64 * kWaves) void k(const uint16_t* __restrict__ co
         if (VAR & 16) { cnt += F; continue; }
         const uint32_t em = F & 0xAAAAAAAAu, ns = F & 0x55555555u;
         const int gbase = cbase + g * 16;
-        if (em) {
-          if (!(VAR & 2)) { EvRec r; r.F = F; r.start = start; r.pos_base = gbase; r.before = cnt; myrec[nrec] = r; }
-          ++nrec;
-          cnt += __builtin_popcount(em);
+        if (VAR & 32) {
+          if (em) {
+            if (!(VAR & 2)) { EvRec r; r.F = F; r.start = start; r.pos_base = gbase; r.meta = cnt; myrec[nrec] = r; }
+            ++nrec;
+          }
+        } else {
+          const uint64_t has = __ballot(em != 0);
+          if (has) {
+            if (em && !(VAR & 2)) {
+              const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(has >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)has, 0));
+              EvRec r; r.F = F; r.start = start; r.pos_base = gbase; r.meta = ((uint32_t)lane << 26) | cnt;
+              wave_recs[wrec + rank] = r;
+            }
+            wrec += __builtin_popcountll(has);
+          }
         }
+        cnt += __builtin_popcount(em);
         if (ns) start = gbase + ((31 - __builtin_clz(ns)) >> 1);
       }
       __builtin_amdgcn_wave_barrier();
     }
-    counts[my_text] = cnt + nrec + start;
+    counts[my_text] = cnt + nrec + start + wrec;
   }
 }
 
@@ -92,6 +106,11 @@ int main() {
   uint32_t x = 12345;
   for (size_t i = 0; i < h.size(); ++i) { x = x * 1664525u + 1013904223u; uint32_t r = x >> 24;
     h[i] = r < 150 ? 'a' + r % 26 : r < 200 ? '0' + r % 10 : ' '; }
+  // make the first 40% of texts 'full' ([a-z]{k}[0-9]{len-k}) and 10% adversarial like the bench mix
+  for (int64_t t = 0; t < n; ++t) { const int kind = (int)(t % 10); uint8_t* row = &h[(size_t)t * len];
+    if (kind < 4) { const int ksplit = 1 + (int)((t * 2654435761u) % (len - 1)); for (int j = 0; j < len; ++j) row[j] = j < ksplit ? 'a' + (j * 7 + t) % 26 : '0' + (j + t) % 10; }
+    else if (kind == 4) { for (int j = 0; j < len; ++j) row[j] = 'a' + (j * 11 + t) % 26; row[len - 1] = '!'; }
+    else if (kind < 7) { x = (uint32_t)t * 747796405u + 1; for (int j = 0; j < len; ++j) { x = x * 1664525u + 1013904223u; row[j] = 32 + (x >> 24) % 95; } } }
   // [a-z]+\d+ search automaton columns: states 0 idle, 1 letters, 2 digits(acc)
   std::vector<uint16_t> cols(256);
   for (int c = 0; c < 256; ++c) {
@@ -111,11 +130,17 @@ int main() {
   CK(hipMemcpy(dc, cols.data(), 512, hipMemcpyHostToDevice));
   const int grid = 2048;
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-#define RUN(V, NAME) do { for (int it = 0; it < 3; ++it) hipLaunchKernelGGL(k<V>, dim3(grid), dim3(256), 0, 0, dc, d, stride, len, n, dcount, drec, rec_row); \
-    CK(hipEventRecord(a)); for (int it = 0; it < 10; ++it) hipLaunchKernelGGL(k<V>, dim3(grid), dim3(256), 0, 0, dc, d, stride, len, n, dcount, drec, rec_row); \
+#define RUN2(V, LB, NAME) do { for (int it = 0; it < 3; ++it) hipLaunchKernelGGL((k<V, LB>), dim3(grid), dim3(256), 0, 0, dc, d, stride, len, n, dcount, drec, rec_row); \
+    CK(hipEventRecord(a)); for (int it = 0; it < 10; ++it) hipLaunchKernelGGL((k<V, LB>), dim3(grid), dim3(256), 0, 0, dc, d, stride, len, n, dcount, drec, rec_row); \
     CK(hipEventRecord(b)); CK(hipEventSynchronize(b)); float ms; CK(hipEventElapsedTime(&ms, a, b)); ms /= 10; \
     printf("%-34s %.4f ms  %.0f GB/s\n", NAME, ms, (double)n * len / ms / 1e6); } while (0)
-  RUN(0, "full");
+#define RUN(V, NAME) RUN2(V, 1, NAME)
+  RUN2(0, 1, "full (dense records) lb1");
+  RUN2(0, 5, "full lb5");
+  RUN2(0, 6, "full lb6");
+  RUN2(0, 7, "full lb7");
+  RUN2(0, 8, "full lb8");
+  RUN(32, "old scattered record rows");
   RUN(1, "no col lookup");
   RUN(2, "no record store");
   RUN(3, "no col lookup, no store");
