@@ -98,7 +98,10 @@ int mrx_is_match_dev(const mrx_handle* h, const uint8_t* d_data,
  * d_spans[2*k], d_spans[2*k+1] = start, end of match k (text-relative), in text
  * order then match order.  span_cap = capacity of d_spans in spans.
  * Synchronises the stream once to return *total; MRX_E_CAPACITY if
- * *total > span_cap (nothing written to d_spans beyond capacity). */
+ * *total > span_cap (nothing is ever written to d_spans beyond capacity).
+ * total == NULL: nothing is read back and the call returns without synchronising;
+ * d_counts_prefix[n] holds the total once the stream has drained (compare it with
+ * span_cap before using the spans). */
 int mrx_findall_dev(const mrx_handle* h, const uint8_t* d_data,
                     const int64_t* d_offsets, int64_t n,
                     int64_t* d_counts_prefix, int32_t* d_spans, int64_t span_cap,

@@ -317,6 +317,22 @@ class CompiledRegex:
         _check(fn(self._h, _ptr(batch.data), _ptr(off), batch.n, _ptr(s), _ptr(e), self._stream_ptr()))
         return s, e
 
+    def findall_async(self, batch: DeviceBatch, out):
+        """Enqueue findall on the current stream without reading anything back.
+        out = (counts_prefix int64[n+1], spans int32[cap, 2]) device tensors; the total
+        is counts_prefix[n] once the stream has drained (check it against cap)."""
+        prefix, spans = out
+        if batch.offsets is not None:
+            rc = self._lib.mrx_findall_dev(self._h, _ptr(batch.data), _ptr(batch.offsets), batch.n,
+                                           _ptr(prefix), _ptr(spans), spans.shape[0], None,
+                                           self._stream_ptr())
+        else:
+            rc = self._lib.mrx_findall_strided_dev(self._h, _ptr(batch.data), batch.stride,
+                                                   _ptr(batch.lens), batch.length, batch.n,
+                                                   _ptr(prefix), _ptr(spans), spans.shape[0], None,
+                                                   self._stream_ptr())
+        _check(rc)
+
     def _dev_findall(self, batch: DeviceBatch, span_cap: Optional[int] = None, out=None):
         """Returns (counts_prefix int64[n+1], spans int32[cap, 2], total) on device."""
         import torch

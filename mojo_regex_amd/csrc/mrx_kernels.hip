@@ -333,7 +333,8 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
 // scattered into an LDS tile at their final relative position and the tile is then
 // written out with fully coalesced 8-byte stores.  Per tile the stream is read once
 // (coalesced 16-byte loads; re-reads for further tiles come from L2).
-constexpr int kDecodeTile = 1024;  // spans per LDS tile and wavefront (8 KiB)
+constexpr int kDecodeTile = 2048;  // spans per LDS tile and wavefront (16 KiB): one pass for typical wavefronts
+constexpr int kDecodeBatch = 8;    // independent 16-byte record loads in flight per lane
 
 __global__ __launch_bounds__(kBlock) void k_decode(int64_t n, const int32_t* __restrict__ wave_nrecs,
                                                    const EvRec* __restrict__ recs, int64_t rec_row,
@@ -355,17 +356,17 @@ __global__ __launch_bounds__(kBlock) void k_decode(int64_t n, const int32_t* __r
     const int total_recs = wave_nrecs[w];
     const EvRec* wave_recs = recs + first * rec_row;
     for (int tb = 0; tb < total_spans; tb += kDecodeTile) {
-      for (int j = 0; j < total_recs; j += 256) {
-        // four independent 16-byte loads in flight per lane before any is consumed
-        EvRec rr[4];
+      for (int j = 0; j < total_recs; j += 64 * kDecodeBatch) {
+        // several independent 16-byte loads in flight per lane before any is consumed
+        EvRec rr[kDecodeBatch];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < kDecodeBatch; ++u) {
           const int o = j + u * 64 + lane;
           rr[u].F = 0; rr[u].start = 0; rr[u].pos_base = 0; rr[u].meta = 0;
           if (o < total_recs) rr[u] = wave_recs[o];
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < kDecodeBatch; ++u) {
           const EvRec r = rr[u];
           const int rel_t = __shfl(my_rel, (int)(r.meta >> 26));
           uint32_t em = r.F & 0xAAAAAAAAu;
@@ -707,12 +708,14 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
     }
     HIP_TRY(hipGetLastError());
   }
-  int64_t tot = 0;
-  HIP_TRY(hipMemcpyAsync(&tot, d_total, sizeof tot, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
-  if (total) *total = tot;
   int rc = MRX_OK;
-  if (tot > span_cap) rc = fail(MRX_E_CAPACITY, "span buffer too small: need " + std::to_string(tot));
+  if (total) {
+    int64_t tot = 0;
+    HIP_TRY(hipMemcpyAsync(&tot, d_total, sizeof tot, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    *total = tot;
+    if (tot > span_cap) rc = fail(MRX_E_CAPACITY, "span buffer too small: need " + std::to_string(tot));
+  }  // total == NULL: fully asynchronous; d_counts_prefix[n] holds the total when the stream drains
   HIP_TRY(hipFreeAsync(d_counts, s));
   HIP_TRY(hipFreeAsync(d_total, s));
   if (d_recs) HIP_TRY(hipFreeAsync(d_recs, s));
