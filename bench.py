@@ -54,6 +54,23 @@ def cpu_baseline(host_rows, pattern: bytes):
     }, counts
 
 
+def measured_traffic(n: int, L: int):
+    """HBM bytes per launch of the scan kernel from the committed PMC passes
+    (profiles/rNN_traffic.json, produced by tools/pmc_pass.sh + tools/summarize_profiles.py:
+    separate rocprofv3 --pmc runs, FETCH_SIZE x2 + WRITE_SIZE as the MI355X guide prescribes).
+    None unless a profile of exactly this workload exists."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json"))):
+        try:
+            t = json.load(open(f))
+        except Exception:
+            continue
+        if t.get("config") == {"texts_per_gpu": n, "text_bytes": L}:
+            best = (int(t["traffic_bytes_per_launch"]), os.path.basename(f))
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -147,7 +164,9 @@ def main():
             "hbm_frac_of_peak_whole_step": round(value / world / HBM_PEAK_GBS, 4),
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": (measured_traffic(n, L) or (None, None))[0],
+                         "traffic_source": (measured_traffic(n, L) or (None, None))[1],
                          "kernel_ms": round(scan_ms, 4), "launches_timed": int(launches.value),
                          "algorithmic_bytes_per_launch": int(alg_bytes)},
         }
