@@ -29,10 +29,27 @@ struct Ctx {
   const uint8_t* pre;     // prefilter literal
 };
 
+// One lane's text.  Reads go through an 8-byte register window: the generic kernels
+// walk a text mostly forwards, so one aligned 8-byte global load serves 8 bytes
+// instead of one dependent byte load per step.  The window is aligned on the
+// ADDRESS, so it may cover up to 7 bytes before/after the text inside the same
+// aligned word (never another page); those bytes are loaded but never returned.
 struct Text {
   const uint8_t* ptr;
   int len;
-  __device__ __forceinline__ int at(int i) const { return ptr[i]; }
+  mutable uint64_t win = 0;
+  mutable int win_lo = 0x40000000;  // index of the window's first byte; invalid at start
+  __device__ __forceinline__ Text(const uint8_t* p, int n) : ptr(p), len(n) {}
+  __device__ __forceinline__ int at(int i) const {
+    unsigned d = (unsigned)(i - win_lo);
+    if (d >= 8u) {
+      const uintptr_t a = (uintptr_t)(ptr + i);
+      win = *(const uint64_t*)(a & ~(uintptr_t)7);
+      d = (unsigned)(a & 7);
+      win_lo = i - (int)d;
+    }
+    return (int)((win >> (8 * d)) & 0xFFu);
+  }
 };
 
 __device__ __forceinline__ bool flag(const Ctx& c, uint32_t f) { return (c.p.flags & f) != 0; }

@@ -41,9 +41,9 @@ struct Layout {  // where text i lives
   __device__ __forceinline__ Text text(int64_t i) const {
     if (offsets) {
       const int64_t a = offsets[i], b = offsets[i + 1];
-      return Text{data + a, (int)(b - a)};
+      return Text(data + a, (int)(b - a));
     }
-    return Text{data + i * stride, lens ? lens[i] : len};
+    return Text(data + i * stride, lens ? lens[i] : len);
   }
 };
 

@@ -73,22 +73,28 @@ def make_c2_batch(n: int, L: int = 1024, seed: int = 20260102, device="cuda") ->
 
 
 def make_digits_batch(n: int, L: int = 256, seed: int = 20260103, device="cuda") -> torch.Tensor:
-    """Config 3 (\\d+ findall): bytes with P(digit)=0.08 in runs (run length ~ Geom(0.4))."""
+    """Config 3 (\\d+ findall): bytes with P(digit) ~ 0.08 in runs (a run continues with
+    probability 0.6, i.e. run length ~ Geom(0.4)), about 4 digit runs per 256-byte text."""
     g = _gen(seed, device)
-    # two-state Markov chain approximated per byte: start a run w.p. p_on, stay w.p. 0.6
-    r = torch.rand((n, L), generator=g, device=device)
-    on = torch.zeros((n, L), dtype=torch.bool, device=device)
-    p_stay, p_on = 0.6, 0.035
-    prev = torch.zeros(n, dtype=torch.bool, device=device)
-    for j in range(L):
-        cur = torch.where(prev, r[:, j] < p_stay, r[:, j] < p_on)
-        on[:, j] = cur
-        prev = cur
-    digits = (torch.randint(0, 10, (n, L), generator=g, device=device) + _DIGIT0).to(torch.uint8)
-    other = (torch.randint(0, 26, (n, L), generator=g, device=device) + _LOWER0).to(torch.uint8)
-    sp = torch.rand((n, L), generator=g, device=device) < 0.15
-    other = torch.where(sp, torch.full_like(other, 32), other)
-    return torch.where(on, digits, other)
+    out = torch.empty((n, L), dtype=torch.uint8, device=device)
+    step = max(1, min(n, (128 << 20) // max(L, 1)))
+    p_stay, p_on = 0.6, 0.017
+    for a in range(0, n, step):
+        b = min(n, a + step)
+        m = b - a
+        r = torch.rand((m, L), generator=g, device=device)
+        on = torch.zeros((m, L), dtype=torch.bool, device=device)
+        prev = torch.zeros(m, dtype=torch.bool, device=device)
+        for j in range(L):
+            cur = torch.where(prev, r[:, j] < p_stay, r[:, j] < p_on)
+            on[:, j] = cur
+            prev = cur
+        digits = (torch.randint(0, 10, (m, L), generator=g, device=device) + _DIGIT0).to(torch.uint8)
+        other = (torch.randint(0, 26, (m, L), generator=g, device=device) + _LOWER0).to(torch.uint8)
+        sp = torch.rand((m, L), generator=g, device=device) < 0.15
+        other = torch.where(sp, torch.full_like(other, 32), other)
+        out[a:b] = torch.where(on, digits, other)
+    return out
 
 
 def make_phone_batch(n: int, L: int = 1024, seed: int = 20260104, device="cuda") -> torch.Tensor:
@@ -98,18 +104,22 @@ def make_phone_batch(n: int, L: int = 1024, seed: int = 20260104, device="cuda")
     g = _gen(seed, device)
     tmpl = torch.tensor(list(b"Call DDDDDDDDDD or DDDDDDDDDD today. "), dtype=torch.uint8, device=device)
     reps = (L + tmpl.numel() - 1) // tmpl.numel()
-    base = tmpl.repeat(reps)[:L].unsqueeze(0).expand(n, L).clone()
-    digits = (torch.randint(0, 10, (n, L), generator=g, device=device) + _DIGIT0).to(torch.uint8)
-    is_d = base == ord("D")
-    kind = torch.rand(n, generator=g, device=device)
-    # near misses: turn the 10th digit of every number into a letter
+    row = tmpl.repeat(reps)[:L]
+    is_d = (row == ord("D"))[None, :]
     tpos = torch.arange(L, device=device) % tmpl.numel()
-    tenth = (tpos == 14) | (tpos == 28)
-    near = (kind < 0.25)[:, None] & tenth[None, :]
-    # long runs: also make the separators digits on a stretch
-    longr = ((kind >= 0.25) & (kind < 0.30))[:, None] & ((tpos >= 15) & (tpos <= 18))[None, :]
-    out = torch.where(is_d | longr, digits, base)
-    out = torch.where(near, torch.full_like(out, ord("x")), out)
+    tenth = ((tpos == 14) | (tpos == 28))[None, :]        # 10th digit of each number
+    sep = ((tpos >= 15) & (tpos <= 18))[None, :]           # " or " between the two numbers
+    out = torch.empty((n, L), dtype=torch.uint8, device=device)
+    step = max(1, min(n, (64 << 20) // max(L, 1)))
+    for a in range(0, n, step):
+        b = min(n, a + step)
+        m = b - a
+        digits = (torch.randint(0, 10, (m, L), generator=g, device=device) + _DIGIT0).to(torch.uint8)
+        kind = torch.rand(m, generator=g, device=device)
+        near = (kind < 0.25)[:, None] & tenth                 # near misses: 9-digit runs only
+        longr = ((kind >= 0.25) & (kind < 0.30))[:, None] & sep  # 24-digit runs
+        blk = torch.where(is_d | longr, digits, row[None, :].expand(m, L))
+        out[a:b] = torch.where(near, torch.full_like(blk, ord("x")), blk)
     return out
 
 
@@ -119,5 +129,12 @@ def make_alt_batch(n: int, L: int = 4096, seed: int = 20260105, device="cuda") -
     g = _gen(seed, device)
     sym = torch.tensor(list(b"xyfobar "), dtype=torch.uint8, device=device)
     w = torch.tensor([0.08, 0.08, 0.14, 0.26, 0.12, 0.12, 0.12, 0.08], device=device)
-    idx = torch.multinomial(w, n * L, replacement=True, generator=g)
-    return sym[idx].reshape(n, L)
+    cdf = torch.cumsum(w, 0)
+    out = torch.empty((n, L), dtype=torch.uint8, device=device)
+    step = max(1, min(n, (256 << 20) // max(L, 1)))  # bound temporaries to ~1 GiB of floats
+    for a in range(0, n, step):
+        b = min(n, a + step)
+        r = torch.rand((b - a, L), generator=g, device=device)
+        idx = torch.bucketize(r, cdf[:-1], right=True)
+        out[a:b] = sym[idx]
+    return out
