@@ -88,6 +88,14 @@ int mrx_match_first_dev(const mrx_handle* h, const uint8_t* d_data,
 int mrx_search_dev(const mrx_handle* h, const uint8_t* d_data,
                    const int64_t* d_offsets, int64_t n,
                    int32_t* d_start, int32_t* d_end, void* stream);
+/* Same two operations for texts at a fixed pitch (see header comment); search uses
+ * the streaming kernel when the plan allows it. */
+int mrx_match_first_strided_dev(const mrx_handle* h, const uint8_t* d_data, int64_t stride,
+                                const int32_t* d_lens, int32_t len, int64_t n,
+                                int32_t* d_start, int32_t* d_end, void* stream);
+int mrx_search_strided_dev(const mrx_handle* h, const uint8_t* d_data, int64_t stride,
+                           const int32_t* d_lens, int32_t len, int64_t n,
+                           int32_t* d_start, int32_t* d_end, void* stream);
 /* CompiledRegex.is_match(text, 0), matcher.mojo:1103-1115 (DFAEngine.is_match
  * quirk included, dfa.mojo:1815-1849).  d_flag[i] = 0/1. */
 int mrx_is_match_dev(const mrx_handle* h, const uint8_t* d_data,

@@ -65,6 +65,10 @@ def load_library():
         "mrx_num_groups": (C.c_int, [H]),
         "mrx_match_first_dev": (C.c_int, [H, u8p, i64p, C.c_int64, i32p, i32p, C.c_void_p]),
         "mrx_search_dev": (C.c_int, [H, u8p, i64p, C.c_int64, i32p, i32p, C.c_void_p]),
+        "mrx_match_first_strided_dev": (C.c_int, [H, u8p, C.c_int64, i32p, C.c_int32, C.c_int64, i32p,
+                                                  i32p, C.c_void_p]),
+        "mrx_search_strided_dev": (C.c_int, [H, u8p, C.c_int64, i32p, C.c_int32, C.c_int64, i32p, i32p,
+                                             C.c_void_p]),
         "mrx_is_match_dev": (C.c_int, [H, u8p, i64p, C.c_int64, u8p, C.c_void_p]),
         "mrx_findall_dev": (C.c_int, [H, u8p, i64p, C.c_int64, i64p, i32p, C.c_int64,
                                       C.POINTER(C.c_int64), C.c_void_p]),
@@ -98,7 +102,8 @@ def load_library():
 
 EXPORTED_SYMBOLS = [
     "mrx_compile", "mrx_free", "mrx_last_error", "mrx_engine_type", "mrx_stats", "mrx_describe",
-    "mrx_num_groups", "mrx_match_first_dev", "mrx_search_dev", "mrx_is_match_dev",
+    "mrx_num_groups", "mrx_match_first_dev", "mrx_search_dev", "mrx_match_first_strided_dev",
+    "mrx_search_strided_dev", "mrx_is_match_dev",
     "mrx_findall_dev", "mrx_findall_strided_dev", "mrx_count_dev", "mrx_captures_dev",
     "mrx_sub_dev", "mrx_match_first_batch", "mrx_search_batch", "mrx_is_match_batch",
     "mrx_findall_batch", "mrx_captures_batch", "mrx_sub_batch", "mrx_timing_reset",
@@ -221,13 +226,14 @@ class CompiledRegex:
     def match_first(self, texts) -> Tuple[np.ndarray, np.ndarray]:
         """regex.match_first per text: (start[n], end[n]), -1/-1 where none."""
         if isinstance(texts, DeviceBatch):
-            return self._dev_spans(self._lib.mrx_match_first_dev, texts)
+            return self._dev_spans(self._lib.mrx_match_first_dev, self._lib.mrx_match_first_strided_dev,
+                                   texts)
         return self._spans_call(self._lib.mrx_match_first_batch, texts)
 
     def match_next(self, texts) -> Tuple[np.ndarray, np.ndarray]:
         """regex.search per text."""
         if isinstance(texts, DeviceBatch):
-            return self._dev_spans(self._lib.mrx_search_dev, texts)
+            return self._dev_spans(self._lib.mrx_search_dev, self._lib.mrx_search_strided_dev, texts)
         return self._spans_call(self._lib.mrx_search_batch, texts)
 
     search = match_next
@@ -309,12 +315,16 @@ class CompiledRegex:
         import torch
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
-    def _dev_spans(self, fn, batch: DeviceBatch):
+    def _dev_spans(self, fn_csr, fn_strided, batch: DeviceBatch):
         import torch
-        off = batch.csr_offsets()
         s = torch.empty(batch.n, dtype=torch.int32, device=batch.data.device)
         e = torch.empty(batch.n, dtype=torch.int32, device=batch.data.device)
-        _check(fn(self._h, _ptr(batch.data), _ptr(off), batch.n, _ptr(s), _ptr(e), self._stream_ptr()))
+        if batch.offsets is not None:
+            _check(fn_csr(self._h, _ptr(batch.data), _ptr(batch.offsets), batch.n, _ptr(s), _ptr(e),
+                          self._stream_ptr()))
+        else:
+            _check(fn_strided(self._h, _ptr(batch.data), batch.stride, _ptr(batch.lens), batch.length,
+                              batch.n, _ptr(s), _ptr(e), self._stream_ptr()))
         return s, e
 
     def findall_async(self, batch: DeviceBatch, out):

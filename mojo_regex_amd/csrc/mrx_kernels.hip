@@ -176,13 +176,14 @@ constexpr uint32_t kRecBeforeMask = (1u << 26) - 1u;
 
 __host__ __device__ inline int64_t rec_row_len(int64_t max_len) { return max_len / 16 + 2; }
 
-enum { ST_RECORDS = 0, ST_COUNT = 1 };
+enum { ST_RECORDS = 0, ST_COUNT = 1, ST_SEARCH = 2 };  // ST_SEARCH: first match only (regex.search)
 
 template <int MODE, int CH>
 __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
     DevPlan p, const uint8_t* __restrict__ blob, const uint8_t* __restrict__ data, int64_t stride,
     const int32_t* __restrict__ lens, int32_t common_len, int64_t n, int32_t* __restrict__ counts,
-    int32_t* __restrict__ wave_nrecs, EvRec* __restrict__ recs, int64_t rec_row) {
+    int32_t* __restrict__ wave_nrecs, EvRec* __restrict__ recs, int64_t rec_row,
+    int32_t* __restrict__ out_s, int32_t* __restrict__ out_e) {
   constexpr int kChunk = CH;
   constexpr int kRowPitch = CH + 16;      // +16: the per-lane 16-byte read-back is bank-conflict free
   constexpr int LPR = CH / 16;            // lanes that cover one text row in a load instruction
@@ -237,6 +238,8 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
     int start = 0;
     int cnt = 0;
     int wrec = 0;  // records written by this wavefront so far (wave uniform)
+    bool done = !live;          // ST_SEARCH: this lane has its answer
+    int res_s = -1, res_e = -1;
     EvRec* wave_recs = (MODE == ST_RECORDS) ? recs + base_text * rec_row : nullptr;
 
     uint4 v[NL];
@@ -251,6 +254,7 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (MODE == ST_SEARCH) { if (__all(done)) break; }
       if (cbase + kChunk < max_len) MRX_LOAD_CHUNK(cbase + kChunk);  // prefetch next chunk
 
       const int lim = my_len - cbase;  // bytes of mine in this chunk (may be <= 0 or > 64)
@@ -299,6 +303,15 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
             wrec += __builtin_popcountll(has);
           }
         }
+        if (MODE == ST_SEARCH) {
+          if (!done && em) {  // leftmost match = first EMIT of the text
+            const int kk = __builtin_ctz(em) >> 1;
+            const uint32_t nsb = ns & ((1u << (2 * kk)) - 1u);
+            res_s = nsb ? gbase + ((31 - __builtin_clz(nsb)) >> 1) : start;
+            res_e = gbase + kk;
+            done = true;
+          }
+        }
         cnt += __builtin_popcount(em);
         if (ns) start = gbase + ((31 - __builtin_clz(ns)) >> 1);
       }
@@ -321,7 +334,15 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
         if (lane == 0) wave_nrecs[w] = wrec;
       }
       if (tail) ++cnt;
-      if (live) counts[my_text] = cnt;
+      if (MODE == ST_SEARCH) {
+        if (live) {
+          if (!done && tail) { res_s = start; res_e = my_len; }
+          out_s[my_text] = res_s;
+          out_e[my_text] = res_e;
+        }
+      } else {
+        if (live) counts[my_text] = cnt;
+      }
     }
   }
 #undef MRX_LOAD_CHUNK
@@ -680,7 +701,7 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
       ScanTimer tm(s);
       hipLaunchKernelGGL((k_stream_findall<ST_RECORDS, MRX_STREAM_CHUNK>), dim3((unsigned)g), dim3(64 * kStreamWaves), 0,
                          s, p, h->d_blob, lay.data, lay.stride, lay.lens, lay.len, n, d_counts,
-                         d_nrecs, d_recs, rec_row);
+                         d_nrecs, d_recs, rec_row, (int32_t*)nullptr, (int32_t*)nullptr);
       g_last_kernel = "k_stream_findall";
       HIP_TRY(hipGetLastError());
       tm.stop();
@@ -800,6 +821,38 @@ int mrx_match_first_dev(const mrx_handle* h, const uint8_t* d, const int64_t* of
 int mrx_search_dev(const mrx_handle* h, const uint8_t* d, const int64_t* off, int64_t n, int32_t* s,
                    int32_t* e, void* st) {
   return run_match<OP_SEARCH>(h, Layout{d, off, 0, nullptr, 0}, n, s, e, nullptr, st);
+}
+int mrx_search_strided_dev(const mrx_handle* h, const uint8_t* d, int64_t stride, const int32_t* lens,
+                           int32_t len, int64_t n, int32_t* ds, int32_t* de, void* st) {
+  if (!h) return fail(MRX_E_ARGUMENT, "null handle");
+  if (stride <= 0) return fail(MRX_E_ARGUMENT, "stride must be positive");
+  if (!lens && (len < 0 || len > stride)) return fail(MRX_E_ARGUMENT, "len must be in [0, stride]");
+  const Layout lay{d, nullptr, stride, lens, len};
+  const DevPlan& p = h->hp.dev;
+  const bool stream_ok = (p.flags & PF_STREAMABLE) && (stride % 16 == 0) && (((uintptr_t)d) % 16 == 0) &&
+                         n > 0 && stride * 64 < (int64_t(1) << 31);
+  if (!stream_ok) return run_match<OP_SEARCH>(h, lay, n, ds, de, nullptr, st);
+  if (int rc = check_search_supported(h)) return rc;
+  if (int rc = ensure_device(h)) return rc;
+  hipStream_t s = (hipStream_t)st;
+  const int64_t nw = (n + 63) / 64;
+  int64_t g = (nw + kStreamWaves - 1) / kStreamWaves;
+  if (g > 256 * 8) g = 256 * 8;
+  ScanTimer tm(s);
+  hipLaunchKernelGGL((k_stream_findall<ST_SEARCH, MRX_STREAM_CHUNK>), dim3((unsigned)g),
+                     dim3(64 * kStreamWaves), 0, s, p, h->d_blob, d, stride, lens, len, n,
+                     (int32_t*)nullptr, (int32_t*)nullptr, (EvRec*)nullptr, (int64_t)0, ds, de);
+  g_last_kernel = "k_stream_search";
+  HIP_TRY(hipGetLastError());
+  tm.stop();
+  return MRX_OK;
+}
+int mrx_match_first_strided_dev(const mrx_handle* h, const uint8_t* d, int64_t stride,
+                                const int32_t* lens, int32_t len, int64_t n, int32_t* ds,
+                                int32_t* de, void* st) {
+  if (stride <= 0) return fail(MRX_E_ARGUMENT, "stride must be positive");
+  if (!lens && (len < 0 || len > stride)) return fail(MRX_E_ARGUMENT, "len must be in [0, stride]");
+  return run_match<OP_MATCH_FIRST>(h, Layout{d, nullptr, stride, lens, len}, n, ds, de, nullptr, st);
 }
 int mrx_is_match_dev(const mrx_handle* h, const uint8_t* d, const int64_t* off, int64_t n,
                      uint8_t* f, void* st) {

@@ -281,11 +281,20 @@ def test_streaming_kernel_equals_generic_and_oracle(pat, n, pitch, var):
     texts = [arr[i, : (lens[i] if var else pitch)].tobytes() for i in range(n)]
     generic = rx.findall_lists(texts)          # CSR batch -> generic kernel
     assert int(prefix[-1]) == total == sum(len(x) for x in generic)
+    # search on the same strided batch runs the streaming kernel in first-match mode
+    ss, se = rx.match_next(batch)
+    assert M.load_library().mrx_last_kernel_name() == b"k_stream_search"
+    ss, se = ss.cpu().numpy(), se.cpu().numpy()
+    fs, fe = rx.match_first(batch)
+    fs, fe = fs.cpu().numpy(), fe.cpu().numpy()
     for i, t in enumerate(texts):
         have = [tuple(int(x) for x in r) for r in spans[prefix[i]:prefix[i + 1]]]
         assert have == generic[i], (pat, i)
+        assert (int(ss[i]), int(se[i])) == (have[0] if have else (-1, -1)), (pat, i)
         if i % 7 == 0:
             assert have == O.findall(pat, t), (pat, i)
+            w = O.match_first(pat, t)
+            assert (int(fs[i]), int(fe[i])) == (w if w else (-1, -1)), (pat, i)
 
 
 def test_streaming_slot_overflow_is_rewalked():

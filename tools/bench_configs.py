@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Throughput of every BASELINE.json config on one GPU (documentation numbers, not the
+bench.py contract line).  GB/s = input bytes of the batch / wall time of the whole
+call (device-resident inputs, outputs stay on device)."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+import mojo_regex_amd as M  # noqa: E402
+from mojo_regex_amd import workloads as W  # noqa: E402
+
+
+def timeit(fn, reps=5):
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def main():
+    out = []
+    lib = M.load_library()
+    cases = [
+        ("c2 [a-z]+\\d+", b"[a-z]+\\d+", lambda: W.make_c2_batch(1 << 20, 1024), 32),
+        ("c3 \\d+", b"\\d+", lambda: W.make_digits_batch(1 << 23, 256), 8),
+        ("c4 (\\d{3})(\\d{3})(\\d{4})", b"(\\d{3})(\\d{3})(\\d{4})", lambda: W.make_phone_batch(1 << 20, 1024), 56),
+        ("c5 (x|y|foo|bar)+", b"(x|y|foo|bar)+", lambda: W.make_alt_batch(1 << 20, 4096), 900),
+        ("c1 hello", b"hello", lambda: W.make_c2_batch(1 << 20, 1024, seed=5), 4),
+    ]
+    for name, pat, gen, per_text in cases:
+        d = gen()
+        n, L = d.shape
+        rx = M.compile_regex(pat)
+        batch = M.DeviceBatch.strided(d.reshape(-1), L, length=L)
+        prefix = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+        spans = torch.empty((n * per_text, 2), dtype=torch.int32, device="cuda")
+        nbytes = n * L
+        t_find = timeit(lambda: rx.findall_async(batch, (prefix, spans)))
+        kernel = lib.mrx_last_kernel_name().decode()
+        total = int(prefix[n].item())
+        assert total <= spans.shape[0]
+        t_search = timeit(lambda: rx.match_next(batch))
+        t_first = timeit(lambda: rx.match_first(batch))
+        row = {"config": name, "texts": n, "bytes_per_text": L, "matches": total,
+               "findall_kernel": kernel,
+               "findall_GBps": round(nbytes / t_find / 1e9, 1), "findall_ms": round(t_find * 1e3, 3),
+               "search_GBps": round(nbytes / t_search / 1e9, 1),
+               "match_first_ms": round(t_first * 1e3, 3)}
+        out.append(row)
+        print(json.dumps(row), flush=True)
+        del d, batch, prefix, spans
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()
