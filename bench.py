@@ -92,10 +92,15 @@ def main():
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = "cuda:%d" % local_rank
+    # MRX_BENCH_BACKEND=gloo + MRX_BENCH_SHARE_GPU=1: rehearsal of the N>1 flow on a box with
+    # fewer GPUs than ranks (ranks share cuda:0, rendezvous over gloo).  The driver's real
+    # runs use one GPU per rank and nccl (= RCCL).
+    backend = os.environ.get("MRX_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count() if os.environ.get("MRX_BENCH_SHARE_GPU") else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = "cuda:%d" % dev_index
     if world > 1:
-        D.init("nccl")
+        D.init(backend)
 
     n, L = args.texts, args.length
     batch_t = make_c2_batch(n, L, seed=20260102 + rank, device=dev)
@@ -117,19 +122,20 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    D.barrier(world, dev)
+    D.barrier(world, dev if backend == "nccl" else None)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    D.barrier(world, dev)
+    D.barrier(world, dev if backend == "nccl" else None)
     elapsed = time.perf_counter() - t0
     total = int(prefix[n].item())
     if total > span_cap:
         raise SystemExit("span buffer too small (%d > %d): result incomplete, run invalid" % (total, span_cap))
 
     agg = D.combine(world, elapsed, {"bytes": float(n) * L * args.steps,
-                                     "matches": float(total) * args.steps}, device=dev)
+                                     "matches": float(total) * args.steps},
+                    device=dev if backend == "nccl" else "cpu")
 
     # ---- roofline of the dominant kernel: HIP events on its own launch stream -------
     lib.mrx_timing_enable(1)
