@@ -178,7 +178,11 @@ __host__ __device__ inline int64_t rec_row_len(int64_t max_len) { return max_len
 
 enum { ST_RECORDS = 0, ST_COUNT = 1, ST_SEARCH = 2 };  // ST_SEARCH: first match only (regex.search)
 
-template <int MODE, int CH>
+// AUTO = 1: byte-column automaton (<= 4 states, described above).
+// AUTO = 2: class-table automaton for any streamable plan: cls[byte] (u8, LDS) is looked
+//           up ahead for the whole group, then trans[state_row + cls] (u16, LDS) is a
+//           dependent lookup per byte -- latency bound, hidden by the other wavefronts.
+template <int MODE, int CH, int AUTO>
 __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
     DevPlan p, const uint8_t* __restrict__ blob, const uint8_t* __restrict__ data, int64_t stride,
     const int32_t* __restrict__ lens, int32_t common_len, int64_t n, int32_t* __restrict__ counts,
@@ -191,11 +195,19 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
   constexpr int NL = 64 / RPI;            // load instructions per chunk (= CH / 16)
   __shared__ __align__(16) uint8_t tiles[kStreamWaves][64 * kRowPitch];
   __shared__ __align__(16) uint16_t col_lds[256];
-  {
+  extern __shared__ __align__(16) uint8_t stg_lds[];  // AUTO == 2: cls | trans | accept
+  if (AUTO == 1) {
     const uint16_t* src = (const uint16_t*)(blob + p.off_stcol);
     for (int i = threadIdx.x; i < 256; i += blockDim.x) col_lds[i] = src[i];
+  } else {
+    const uint32_t* src = (const uint32_t*)(blob + p.off_stg_cls);
+    uint32_t* dst = (uint32_t*)stg_lds;
+    for (int i = threadIdx.x; i < (p.stg_bytes >> 2); i += blockDim.x) dst[i] = src[i];
   }
   __syncthreads();
+  const uint8_t* cls_lds = stg_lds;
+  const uint16_t* tr_lds = (const uint16_t*)(stg_lds + (p.off_stg_trans - p.off_stg_cls));
+  const uint8_t* acc_lds = stg_lds + (p.off_stg_acc - p.off_stg_cls);
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   uint8_t* tile = tiles[wave];
@@ -264,7 +276,19 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
         const uint4 wv = *(const uint4*)(tile + lane * kRowPitch + g * 16);
         const uint32_t words[4] = {wv.x, wv.y, wv.z, wv.w};
         uint32_t F = 0;
-        if (full) {
+        if (AUTO == 2) {
+          uint32_t cc[16];
+#pragma unroll
+          for (int k = 0; k < 16; ++k)
+            cc[k] = cls_lds[(words[k >> 2] >> ((k & 3) * 8)) & 0xFFu];
+#pragma unroll
+          for (int k = 0; k < 16; ++k) {
+            uint32_t e = tr_lds[q4 + cc[k]];                    // q4 = row offset of the state
+            if (!full) { if (g * 16 + k >= lim) e = q4 << 2; }   // past the end: no-op
+            q4 = e >> 2;
+            F = __builtin_amdgcn_alignbit(e, F, 2);
+          }
+        } else if (full) {
           uint32_t cv[16];
 #pragma unroll
           for (int k = 0; k < 16; ++k)
@@ -319,7 +343,8 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
     }
     // end of text: a walk that is in an accepting state ends at len
     {
-      const bool tail = live && ((accmask >> (q4 >> 2)) & 1u);
+      const bool tail = live && (AUTO == 2 ? acc_lds[q4 >> p.st_cshift] != 0
+                                          : ((accmask >> (q4 >> 2)) & 1u) != 0);
       if (MODE == ST_RECORDS) {
         const uint64_t has = __ballot(tail);
         if (tail) {
@@ -355,6 +380,7 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
 // written out with fully coalesced 8-byte stores.  Per tile the stream is read once
 // (coalesced 16-byte loads; re-reads for further tiles come from L2).
 constexpr int kDecodeTile = 2048;  // spans per LDS tile and wavefront (16 KiB): one pass for typical wavefronts
+constexpr int kDecodeDirect = 3 * kDecodeTile;  // above this many spans per wavefront: one direct pass
 constexpr int kDecodeBatch = 8;    // independent 16-byte record loads in flight per lane
 
 __global__ __launch_bounds__(kBlock) void k_decode(int64_t n, const int32_t* __restrict__ wave_nrecs,
@@ -376,6 +402,37 @@ __global__ __launch_bounds__(kBlock) void k_decode(int64_t n, const int32_t* __r
     const int total_spans = (int)(prefix[last1] - pre0);
     const int total_recs = wave_nrecs[w];
     const EvRec* wave_recs = recs + first * rec_row;
+    if (total_spans > kDecodeDirect) {
+      // dense matches: the tile passes would re-read the stream total_spans / kDecodeTile
+      // times.  One pass with direct 8-byte stores instead; every text's spans are written
+      // in increasing order, so L2 merges them into full lines.
+      for (int j = 0; j < total_recs; j += 64 * kDecodeBatch) {
+        EvRec rr[kDecodeBatch];
+#pragma unroll
+        for (int u = 0; u < kDecodeBatch; ++u) {
+          const int o = j + u * 64 + lane;
+          rr[u].F = 0; rr[u].start = 0; rr[u].pos_base = 0; rr[u].meta = 0;
+          if (o < total_recs) rr[u] = wave_recs[o];
+        }
+#pragma unroll
+        for (int u = 0; u < kDecodeBatch; ++u) {
+          const EvRec r = rr[u];
+          const int rel_t = __shfl(my_rel, (int)(r.meta >> 26));
+          uint32_t em = r.F & 0xAAAAAAAAu;
+          const uint32_t ns = r.F & 0x55555555u;
+          int64_t dst = pre0 + rel_t + (int)(r.meta & kRecBeforeMask);
+          while (em) {
+            const int kk = __builtin_ctz(em) >> 1;
+            const uint32_t nsb = ns & ((1u << (2 * kk)) - 1u);
+            const int st = nsb ? r.pos_base + ((31 - __builtin_clz(nsb)) >> 1) : r.start;
+            if (dst < span_cap) *(int2*)(spans + 2 * dst) = make_int2(st, r.pos_base + kk);
+            ++dst;
+            em &= em - 1;
+          }
+        }
+      }
+      continue;
+    }
     for (int tb = 0; tb < total_spans; tb += kDecodeTile) {
       for (int j = 0; j < total_recs; j += 64 * kDecodeBatch) {
         // several independent 16-byte loads in flight per lane before any is consumed
@@ -699,9 +756,16 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
       int64_t g = (nw + kStreamWaves - 1) / kStreamWaves;
       if (g > 256 * 8) g = 256 * 8;
       ScanTimer tm(s);
-      hipLaunchKernelGGL((k_stream_findall<ST_RECORDS, MRX_STREAM_CHUNK>), dim3((unsigned)g), dim3(64 * kStreamWaves), 0,
-                         s, p, h->d_blob, lay.data, lay.stride, lay.lens, lay.len, n, d_counts,
-                         d_nrecs, d_recs, rec_row, (int32_t*)nullptr, (int32_t*)nullptr);
+      if (p.st_kind == 1)
+        hipLaunchKernelGGL((k_stream_findall<ST_RECORDS, MRX_STREAM_CHUNK, 1>), dim3((unsigned)g),
+                           dim3(64 * kStreamWaves), 0, s, p, h->d_blob, lay.data, lay.stride, lay.lens,
+                           lay.len, n, d_counts, d_nrecs, d_recs, rec_row, (int32_t*)nullptr,
+                           (int32_t*)nullptr);
+      else
+        hipLaunchKernelGGL((k_stream_findall<ST_RECORDS, MRX_STREAM_CHUNK, 2>), dim3((unsigned)g),
+                           dim3(64 * kStreamWaves), (size_t)p.stg_bytes, s, p, h->d_blob, lay.data,
+                           lay.stride, lay.lens, lay.len, n, d_counts, d_nrecs, d_recs, rec_row,
+                           (int32_t*)nullptr, (int32_t*)nullptr);
       g_last_kernel = "k_stream_findall";
       HIP_TRY(hipGetLastError());
       tm.stop();
@@ -839,9 +903,14 @@ int mrx_search_strided_dev(const mrx_handle* h, const uint8_t* d, int64_t stride
   int64_t g = (nw + kStreamWaves - 1) / kStreamWaves;
   if (g > 256 * 8) g = 256 * 8;
   ScanTimer tm(s);
-  hipLaunchKernelGGL((k_stream_findall<ST_SEARCH, MRX_STREAM_CHUNK>), dim3((unsigned)g),
-                     dim3(64 * kStreamWaves), 0, s, p, h->d_blob, d, stride, lens, len, n,
-                     (int32_t*)nullptr, (int32_t*)nullptr, (EvRec*)nullptr, (int64_t)0, ds, de);
+  if (p.st_kind == 1)
+    hipLaunchKernelGGL((k_stream_findall<ST_SEARCH, MRX_STREAM_CHUNK, 1>), dim3((unsigned)g),
+                       dim3(64 * kStreamWaves), 0, s, p, h->d_blob, d, stride, lens, len, n,
+                       (int32_t*)nullptr, (int32_t*)nullptr, (EvRec*)nullptr, (int64_t)0, ds, de);
+  else
+    hipLaunchKernelGGL((k_stream_findall<ST_SEARCH, MRX_STREAM_CHUNK, 2>), dim3((unsigned)g),
+                       dim3(64 * kStreamWaves), (size_t)p.stg_bytes, s, p, h->d_blob, d, stride, lens,
+                       len, n, (int32_t*)nullptr, (int32_t*)nullptr, (EvRec*)nullptr, (int64_t)0, ds, de);
   g_last_kernel = "k_stream_search";
   HIP_TRY(hipGetLastError());
   tm.stop();

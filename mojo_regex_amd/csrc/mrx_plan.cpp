@@ -195,6 +195,29 @@ bool build_stream_cols(const SearchAutomaton& s, const std::vector<int>& remap, 
   return true;
 }
 
+// Entry matrix of the search automaton over live states: next<<2 | EMIT<<1 | NEWSTART
+std::vector<std::array<uint16_t, 256>> stream_entries(const SearchAutomaton& s,
+                                                      const std::vector<int>& remap, int nlive) {
+  std::vector<std::array<uint16_t, 256>> E(nlive);
+  for (int q = 0; q < s.n; ++q) {
+    if (remap[q] < 0) continue;
+    for (int c = 0; c < 256; ++c) {
+      int t = (q == 0) ? (s.allowed[c] ? s.next[0][c] : -1) : s.next[q][c];
+      bool emit = false, newstart = false;
+      if (q == 0) {
+        newstart = t > 0;
+      } else if (t < 0) {  // the walk dies: emit if it had accepted, restart on this byte
+        emit = s.acc[q] != 0;
+        t = s.allowed[c] ? s.next[0][c] : -1;
+        newstart = t > 0;
+      }
+      const int tn = t > 0 ? remap[t] : 0;
+      E[remap[q]][c] = (uint16_t)((tn << 2) | (emit ? 2 : 0) | (newstart ? 1 : 0));
+    }
+  }
+  return E;
+}
+
 void put(std::vector<uint8_t>& blob, const void* p, size_t n) {
   const uint8_t* b = (const uint8_t*)p;
   blob.insert(blob.end(), b, b + n);
@@ -454,9 +477,11 @@ void build_plan(const std::string& pattern, HostPlan& hp) {
   // ---- streaming automaton (findall only) -----------------------------------------
   d.off_stcol = -1;
   hp.streamable_why_not.clear();
-  if (d.kind != PLAN_DFA) hp.streamable_why_not = "not a DFAEngine plan";
+  d.st_kind = 0;
+  if (d.kind == PLAN_ANY) hp.streamable_why_not = "'.*' shortcut";
+  else if (d.flags & PF_START_DEAD) hp.streamable_why_not = "dead start state";
   else if (d.flags & (PF_START_ANCHOR | PF_END_ANCHOR)) hp.streamable_why_not = "anchored";
-  else if (d.flags & (PF_PURE_LITERAL | PF_EXACT_LITERAL | PF_PREFILTER)) hp.streamable_why_not = "literal path";
+  else if (d.flags & (PF_EXACT_LITERAL | PF_PREFILTER)) hp.streamable_why_not = "exact-literal / prefilter path";
   else if (d.required_byte >= 0) hp.streamable_why_not = "required-byte findall path";
   else if (!hp.why_no_search.empty()) hp.streamable_why_not = hp.why_no_search;
   else {
@@ -471,6 +496,9 @@ void build_plan(const std::string& pattern, HostPlan& hp) {
         if (first[c]) { sa.next[0][c] = 1; sa.next[1][c] = 1; }
       sa.allowed = first;
     } else {
+      // DFAEngine table walk (also the chain of a pure literal: simd_search == leftmost
+      // start whose walk reaches the end) or LazyDFA walk; candidate starts are limited
+      // by the first-class / first-byte filter when the engine has one
       sa.n = d.nstates;
       sa.next = T;
       sa.acc = acc;
@@ -493,18 +521,61 @@ void build_plan(const std::string& pattern, HostPlan& hp) {
           if (t > 0 && remap[t] < 0) { remap[t] = nlive++; st.push_back(t); }
         }
       }
+      d.st_nstates = nlive;
+      d.st_accept_mask = 0;
       std::vector<uint16_t> cols;
-      if (!build_stream_cols(sa, remap, nlive, cols)) {
-        hp.streamable_why_not = "more than 4 live states in the search automaton";
-      } else {
+      if (build_stream_cols(sa, remap, nlive, cols)) {
         d.flags |= PF_STREAMABLE;
-        d.st_nstates = nlive;
-        d.st_accept_mask = 0;
+        d.st_kind = 1;
         for (int q = 0; q < sa.n; ++q)
           if (remap[q] >= 0 && sa.acc[q]) d.st_accept_mask |= 1u << remap[q];
         align(hp.blob, 4);
         d.off_stcol = (int)hp.blob.size();
         put(hp.blob, cols.data(), 512);
+      } else {
+        // class-table form: any number of live states that fits u16 entries and LDS
+        auto E = stream_entries(sa, remap, nlive);
+        std::array<uint8_t, 256> scls{};
+        int sncls = 0;
+        {
+          std::map<std::vector<uint16_t>, int> seen;
+          for (int c = 0; c < 256; ++c) {
+            std::vector<uint16_t> col(nlive);
+            for (int q = 0; q < nlive; ++q) col[q] = E[q][c];
+            auto it = seen.find(col);
+            if (it == seen.end()) it = seen.emplace(col, sncls++).first;
+            scls[c] = (uint8_t)it->second;
+          }
+        }
+        int cshift = 0;
+        while ((1 << cshift) < sncls) ++cshift;
+        const int ncp = 1 << cshift;
+        if ((int64_t)nlive * ncp > 8192) {
+          hp.streamable_why_not = "search automaton too large for the streaming kernel's LDS table";
+        } else {
+          std::vector<uint16_t> tr((size_t)nlive * ncp, 0);
+          for (int c = 0; c < 256; ++c)
+            for (int q = 0; q < nlive; ++q) {
+              const uint16_t e = E[q][c];
+              tr[(size_t)q * ncp + scls[c]] = (uint16_t)((((e >> 2) << cshift) << 2) | (e & 3));
+            }
+          std::vector<uint8_t> sacc(nlive, 0);
+          for (int q = 0; q < sa.n; ++q)
+            if (remap[q] >= 0) sacc[remap[q]] = sa.acc[q];
+          d.flags |= PF_STREAMABLE;
+          d.st_kind = 2;
+          d.st_cshift = cshift;
+          align(hp.blob, 16);
+          const int begin = (int)hp.blob.size();
+          d.off_stg_cls = begin;
+          put(hp.blob, scls.data(), 256);
+          d.off_stg_trans = (int)hp.blob.size();
+          put(hp.blob, tr.data(), tr.size() * 2);
+          d.off_stg_acc = (int)hp.blob.size();
+          put(hp.blob, sacc.data(), sacc.size());
+          align(hp.blob, 16);
+          d.stg_bytes = (int)hp.blob.size() - begin;
+        }
       }
     }
   }
@@ -582,7 +653,7 @@ std::string describe_plan(const HostPlan& hp) {
   o << "device.kind=" << d.kind << " nstates=" << d.nstates << " ncls=" << d.ncls
     << " flags=0x" << std::hex << d.flags << std::dec << " blob_bytes=" << d.blob_bytes << "\n";
   o << "device.streamable=" << ((d.flags & PF_STREAMABLE) ? "yes" : ("no: " + hp.streamable_why_not))
-    << " st_nstates=" << d.st_nstates << "\n";
+    << " st_nstates=" << d.st_nstates << " st_kind=" << d.st_kind << "\n";
   return o.str();
 }
 

@@ -48,9 +48,13 @@ struct DevPlan {
   int32_t fixed_total, fixed_ngroups, fixed_concat;
   int32_t fixed_off[10], fixed_w[10];
   // streaming (single-pass search automaton), see mrx_kernels.hip
-  int32_t st_nstates;
-  int32_t off_stcol;      // u32 column table [256] in the blob (8 states x 4 bit)
+  int32_t st_nstates;     // live states of the search automaton (0 = idle)
+  int32_t st_kind;        // 0 none, 1 = byte-column form (<= 4 states), 2 = class-table form
+  int32_t off_stcol;      // kind 1: u16 column table [256] (4 states x 4 bit)
   uint32_t st_accept_mask;
+  // kind 2: cls[256] u8, trans[st_nstates][1 << st_cshift] u16 = (next << st_cshift) << 2 | EMIT << 1 | NEWSTART,
+  // accept[st_nstates] u8
+  int32_t off_stg_cls, off_stg_trans, off_stg_acc, st_cshift, stg_bytes;
 };
 
 struct HostPlan {

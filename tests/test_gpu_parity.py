@@ -253,7 +253,11 @@ def test_captures_fixed_width_groups():
 
 
 STREAM_PATTERNS = [b"[a-z]+\\d+", b"\\d+", b"[a-z]+", b"\\w+\\s+", b"[^0-9]+", b"[a-z][0-9]", b"[a-z]{1,}",
-                   b"[a-z]+[0-9]+x", b"ab|bc"]
+                   b"[a-z]+[0-9]+x", b"ab|bc",
+                   # class-table automata (more than 4 live states), literals, LazyDFA plans
+                   b"hello", b"(\\d{3})(\\d{3})(\\d{4})", b"(x|y|foo|bar)+", b"(x|y|foo|bar)+z", b"(abc)+",
+                   b"(a|b)x", b"a+b", b"[a-c]+[0-9]+[x-z]+[0-9]+", b"\\d{4}", b"[a-z]+[0-9]+[a-z]+[0-9]+[a-z]+",
+                   b"(cat|dog)", b"(ab)+c", b"(foo|bar|baz)+"]
 
 
 @pytest.mark.parametrize("pat", STREAM_PATTERNS)
@@ -263,7 +267,8 @@ STREAM_PATTERNS = [b"[a-z]+\\d+", b"\\d+", b"[a-z]+", b"\\w+\\s+", b"[^0-9]+", b
 def test_streaming_kernel_equals_generic_and_oracle(pat, n, pitch, var):
     _need_gpu()
     rng = np.random.default_rng(n * 131 + pitch)
-    al = np.frombuffer(b"abcdxyz0123456789 -bcab", dtype=np.uint8)
+    al = np.frombuffer(b"abcdxyz0123456789 -bcab" + bytes(c for c in pat if chr(c).isalnum()) * 2,
+                       dtype=np.uint8)
     arr = rng.choice(al, size=(n, pitch)).astype(np.uint8)
     # long runs that span chunk boundaries
     for i in range(0, n, 5):
@@ -311,6 +316,28 @@ def test_streaming_slot_overflow_is_rewalked():
     assert len(want) == 128 and total == 128 * 69
     assert [tuple(int(x) for x in r) for r in spans[prefix[0]:prefix[1]]] == want
     assert prefix[4] - prefix[3] == 0
+
+
+@pytest.mark.parametrize("reps", [20, 50, 96, 340])
+def test_streaming_dense_matches_all_decode_paths(reps):
+    """Matches per wavefront below one decode tile, across several tiles, and above the
+    direct-store threshold."""
+    _need_gpu()
+    rng = np.random.default_rng(reps)
+    pitch = 1024
+    arr = np.full((130, pitch), ord(" "), dtype=np.uint8)
+    for i in range(130):
+        k = int(rng.integers(0, reps + 1))
+        body = b"".join(rng.choice([b"a1 ", b"xy22 ", b"q7"]) for _ in range(k))[:pitch]
+        arr[i, :len(body)] = np.frombuffer(body, dtype=np.uint8)
+    d = torch.from_numpy(arr).cuda().reshape(-1)
+    pat = b"[a-z]+\\d+"
+    rx = M.compile_regex(pat)
+    prefix, spans, total = rx._dev_findall(M.DeviceBatch.strided(d, pitch, length=pitch))
+    prefix, spans = prefix.cpu().numpy(), spans.cpu().numpy()
+    for i in range(130):
+        have = [tuple(int(x) for x in r) for r in spans[prefix[i]:prefix[i + 1]]]
+        assert have == O.findall(pat, arr[i].tobytes()), i
 
 
 def test_full_size_c2_properties():
