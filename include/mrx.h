@@ -65,6 +65,14 @@ enum {
 
 /* ---- compile (replaces CompiledRegex(pattern), matcher.mojo:964-978) ---------- */
 int mrx_compile(const char* pattern, size_t pattern_len, mrx_handle** out);
+/* Options.  MRX_COMPILE_LAZYDFA_SEMANTICS routes the pattern as the reference does when
+ * DFAEngine compilation fails (matcher.mojo:666-672): NFAMatcher / LazyDFA, leftmost-longest
+ * over the PikeVM program (pikevm.mojo:754-867).  It is NOT what the reference returns for
+ * SIMPLE patterns -- e.g. it honours the `+` of (x|y|foo|bar)+ that the DFA alternation
+ * compiler drops (dfa.mojo:873-928) -- and exists so that config-5 numbers can be reported
+ * under both readings.  mrx_describe() shows the option. */
+enum { MRX_COMPILE_LAZYDFA_SEMANTICS = 1 };
+int mrx_compile_ex(const char* pattern, size_t pattern_len, uint32_t options, mrx_handle** out);
 void mrx_free(mrx_handle* h);
 const char* mrx_last_error(void);
 /* HybridMatcher.get_engine_type(), matcher.mojo:900-918: "DFA", "NFA", "+Prefilter"... */

@@ -57,6 +57,7 @@ def load_library():
     u8p, i32p, i64p = C.c_void_p, C.c_void_p, C.c_void_p
     sigs = {
         "mrx_compile": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(H)]),
+        "mrx_compile_ex": (C.c_int, [C.c_char_p, C.c_size_t, C.c_uint32, C.POINTER(H)]),
         "mrx_free": (None, [H]),
         "mrx_last_error": (C.c_char_p, []),
         "mrx_engine_type": (C.c_char_p, [H]),
@@ -101,7 +102,7 @@ def load_library():
 
 
 EXPORTED_SYMBOLS = [
-    "mrx_compile", "mrx_free", "mrx_last_error", "mrx_engine_type", "mrx_stats", "mrx_describe",
+    "mrx_compile", "mrx_compile_ex", "mrx_free", "mrx_last_error", "mrx_engine_type", "mrx_stats", "mrx_describe",
     "mrx_num_groups", "mrx_match_first_dev", "mrx_search_dev", "mrx_match_first_strided_dev",
     "mrx_search_strided_dev", "mrx_is_match_dev",
     "mrx_findall_dev", "mrx_findall_strided_dev", "mrx_count_dev", "mrx_captures_dev",
@@ -182,11 +183,15 @@ def _ptr(t) -> int:
 class CompiledRegex:
     """Compile once, match many batches (reference: matcher.mojo:929-1163)."""
 
-    def __init__(self, pattern):
+    def __init__(self, pattern, lazydfa_semantics: bool = False):
+        """lazydfa_semantics: MRX_COMPILE_LAZYDFA_SEMANTICS (include/mrx.h) -- NOT the
+        reference's result for SIMPLE patterns; off by default."""
         self._lib = load_library()
         self.pattern = _b(pattern)
+        self.lazydfa_semantics = bool(lazydfa_semantics)
         h = C.c_void_p()
-        _check(self._lib.mrx_compile(self.pattern, len(self.pattern), C.byref(h)))
+        _check(self._lib.mrx_compile_ex(self.pattern, len(self.pattern), 1 if lazydfa_semantics else 0,
+                                        C.byref(h)))
         self._h = h
 
     def __del__(self):
@@ -387,11 +392,11 @@ class CompiledRegex:
 _CACHE = {}
 
 
-def compile_regex(pattern) -> CompiledRegex:
-    key = _b(pattern)
+def compile_regex(pattern, lazydfa_semantics: bool = False) -> CompiledRegex:
+    key = (_b(pattern), bool(lazydfa_semantics))
     c = _CACHE.get(key)
     if c is None:
-        c = CompiledRegex(key)
+        c = CompiledRegex(key[0], lazydfa_semantics)
         _CACHE[key] = c
     return c
 

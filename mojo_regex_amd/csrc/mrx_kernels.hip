@@ -839,11 +839,16 @@ struct DevBuf {
 extern "C" {
 
 int mrx_compile(const char* pattern, size_t pattern_len, mrx_handle** out) {
+  return mrx_compile_ex(pattern, pattern_len, 0u, out);
+}
+
+int mrx_compile_ex(const char* pattern, size_t pattern_len, uint32_t options, mrx_handle** out) {
   if (!out || (!pattern && pattern_len)) return fail(MRX_E_ARGUMENT, "null argument");
+  if (options & ~(uint32_t)MRX_COMPILE_LAZYDFA_SEMANTICS) return fail(MRX_E_ARGUMENT, "unknown compile option");
   *out = nullptr;
   mrx_handle* h = new mrx_handle();
   try {
-    build_plan(std::string(pattern, pattern_len), h->hp);
+    build_plan(std::string(pattern, pattern_len), h->hp, (options & MRX_COMPILE_LAZYDFA_SEMANTICS) != 0);
   } catch (const SyntaxError& e) {
     delete h;
     return fail(MRX_E_SYNTAX, e.what());

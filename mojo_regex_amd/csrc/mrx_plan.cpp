@@ -255,8 +255,9 @@ std::vector<ReplSeg> parse_repl_template(const std::string& r) {  // matcher.moj
   return segs;
 }
 
-void build_plan(const std::string& pattern, HostPlan& hp) {
+void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa) {
   hp = HostPlan();
+  hp.force_nfa = force_nfa;
   hp.pattern = pattern;
   hp.wildcard_any = (pattern == ".*");  // matcher.mojo:435-444, 573-591
 
@@ -324,7 +325,7 @@ void build_plan(const std::string& pattern, HostPlan& hp) {
       compile_program(ast, hp.program);
       build_lazy(hp.program, hp.lazy, /*max_dfa_states=*/4096);
     }
-    if (hp.complexity == CX_SIMPLE) {  // matcher.mojo:664-675
+    if (hp.complexity == CX_SIMPLE && !force_nfa) {  // matcher.mojo:664-675
       try {
         compile_dfa_pattern(ast, hp.dfa);
         hp.use_dfa = true;
@@ -590,6 +591,7 @@ std::string describe_plan(const HostPlan& hp) {
   o << "engine_type=" << hp.engine_type << "\n";
   static const char* cxn[] = {"SIMPLE", "MEDIUM", "COMPLEX"};
   o << "complexity=" << cxn[hp.complexity] << "\n";
+  if (hp.force_nfa) o << "option.lazydfa_semantics=1\n";
   o << "use_dfa=" << hp.use_dfa << " wildcard_any=" << hp.wildcard_any
     << " use_pure_dfa=" << hp.use_pure_dfa << "\n";
   o << "exact_literal=" << hp.exact_literal << " literal_has_anchors=" << hp.literal_has_anchors

@@ -64,6 +64,7 @@ struct HostPlan {
   bool wildcard_any = false;
   bool use_dfa = false;
   bool use_pure_dfa = false;
+  bool force_nfa = false;  // MRX_COMPILE_LAZYDFA_SEMANTICS
   bool exact_literal = false, literal_has_anchors = false;
   std::string best_literal;
   bool has_prefilter = false;
@@ -87,7 +88,9 @@ struct HostPlan {
 };
 
 // Throws SyntaxError for patterns the reference's parser raises on.
-void build_plan(const std::string& pattern, HostPlan& out);
+// force_nfa: route as if DFAEngine compilation had failed (matcher.mojo:666-672), i.e. the
+// NFAMatcher / LazyDFA path -- the "LazyDFA semantics" switch of SURVEY.md 8(c).
+void build_plan(const std::string& pattern, HostPlan& out, bool force_nfa = false);
 std::string describe_plan(const HostPlan& p);
 
 // replacement template (matcher.mojo:1436-1482)

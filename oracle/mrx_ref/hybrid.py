@@ -170,7 +170,9 @@ class NFAMatcher:
 class HybridMatcher:
     """matcher.mojo:535-926."""
 
-    def __init__(self, pattern: bytes):
+    def __init__(self, pattern: bytes, force_nfa: bool = False):
+        # force_nfa: behave as if DFAEngine compilation had failed (matcher.mojo:666-672);
+        # the "LazyDFA semantics" switch of SURVEY.md 8(c), never the default.
         self.pattern = pattern
         self.is_wildcard_match_any = pattern == b".*"
         self.best_literal: Optional[bytes] = None
@@ -208,7 +210,7 @@ class HybridMatcher:
                 if self.best_literal is not None and len(self.best_literal) >= 2:
                     self.prefilter_literal = self.best_literal
         self.nfa_matcher = NFAMatcher(ast, pattern)
-        if self.complexity == SIMPLE:
+        if self.complexity == SIMPLE and not force_nfa:
             try:
                 self.dfa = compile_dfa_pattern(ast)
                 self.use_dfa = True
@@ -410,11 +412,11 @@ def detect_fixed_width_groups(p: bytes) -> Optional[List[int]]:
 class CompiledRegex:
     """matcher.mojo:929-1163."""
 
-    def __init__(self, pattern: bytes):
+    def __init__(self, pattern: bytes, force_nfa: bool = False):
         if isinstance(pattern, str):
             pattern = pattern.encode("latin-1")
         self.pattern = pattern
-        self.matcher = HybridMatcher(pattern)
+        self.matcher = HybridMatcher(pattern, force_nfa)
         self.fixed_total_width = -1
         self.fixed_num_groups = 0
         self.fixed_offsets = [0] * 10

@@ -31,7 +31,7 @@ def main():
         ("c2 [a-z]+\\d+", b"[a-z]+\\d+", lambda: W.make_c2_batch(1 << 20, 1024), 32),
         ("c3 \\d+", b"\\d+", lambda: W.make_digits_batch(1 << 23, 256), 8),
         ("c4 (\\d{3})(\\d{3})(\\d{4})", b"(\\d{3})(\\d{3})(\\d{4})", lambda: W.make_phone_batch(1 << 20, 1024), 56),
-        ("c5 (x|y|foo|bar)+", b"(x|y|foo|bar)+", lambda: W.make_alt_batch(1 << 20, 4096), 900),
+        ("c5 (x|y|foo|bar)+", b"(x|y|foo|bar)+", lambda: W.make_alt_batch(1 << 22, 4096), 720),
         ("c1 hello", b"hello", lambda: W.make_c2_batch(1 << 20, 1024, seed=5), 4),
     ]
     for name, pat, gen, per_text in cases:
