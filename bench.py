@@ -80,6 +80,9 @@ def main():
     ap.add_argument("--length", type=int, default=1024)
     ap.add_argument("--cpu-sample", type=int, default=1 << 16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gather", action="store_true",
+                    help="N > 1: also time scan + results exchange (SURVEY.md 8(e): all-gatherv of the "
+                         "spans to every rank); reported as an extra object, never as `value`")
     args = ap.parse_args()
 
     import torch
@@ -137,6 +140,33 @@ def main():
                                      "matches": float(total) * args.steps},
                     device=dev if backend == "nccl" else "cpu")
 
+    # ---- optional: scan + results exchange (results stay sharded in the headline) -----
+    gather_info = None
+    if args.gather and world > 1:
+        try:
+            gsteps = max(3, min(args.steps, 10))
+            gdev = dev if backend == "nccl" else None
+            def gstep():
+                rx.findall_async(batch, out)
+                tot = int(prefix[n].item())          # the exchange needs the per-rank totals
+                return D.gather_spans(world, prefix, spans, tot)
+            gp, gs = gstep()
+            torch.cuda.synchronize()
+            D.barrier(world, gdev)
+            g0 = time.perf_counter()
+            for _ in range(gsteps):
+                gp, gs = gstep()
+            torch.cuda.synchronize()
+            D.barrier(world, gdev)
+            gel = time.perf_counter() - g0
+            gagg = D.combine(world, gel, {"bytes": float(n) * L * gsteps}, device=dev if backend == "nccl" else "cpu")
+            gather_info = {"ms_per_step": round(gagg["elapsed_s"] / gsteps * 1e3, 4),
+                           "GBps_scan_plus_gather": round(gagg["bytes"] / gagg["elapsed_s"] / 1e9, 3),
+                           "gathered_span_bytes_per_rank": int(gs.shape[0]) * 8,
+                           "global_texts": int(gp.shape[0]) - 1, "steps": gsteps}
+        except Exception as e:  # the headline line must survive a failing exchange
+            gather_info = {"error": "%s: %s" % (type(e).__name__, e)}
+
     # ---- roofline of the dominant kernel: HIP events on its own launch stream -------
     lib.mrx_timing_enable(1)
     lib.mrx_timing_reset()
@@ -176,6 +206,8 @@ def main():
                          "kernel_ms": round(scan_ms, 4), "launches_timed": int(launches.value),
                          "algorithmic_bytes_per_launch": int(alg_bytes)},
         }
+        if gather_info is not None:
+            line["scan_plus_gather"] = gather_info
         if world == 1 and not args.no_cpu_baseline:
             m = min(args.cpu_sample, n)
             host = batch_t[:m].cpu().numpy()
