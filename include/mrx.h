@@ -70,8 +70,13 @@ int mrx_compile(const char* pattern, size_t pattern_len, mrx_handle** out);
  * over the PikeVM program (pikevm.mojo:754-867).  It is NOT what the reference returns for
  * SIMPLE patterns -- e.g. it honours the `+` of (x|y|foo|bar)+ that the DFA alternation
  * compiler drops (dfa.mojo:873-928) -- and exists so that config-5 numbers can be reported
- * under both readings.  mrx_describe() shows the option. */
-enum { MRX_COMPILE_LAZYDFA_SEMANTICS = 1 };
+ * under both readings.  mrx_describe() shows the option.
+ *
+ * MRX_COMPILE_BITSET_NFA: patterns the reference routes to LazyDFA (pikevm.mojo:664-987)
+ * normally run on its eagerly determinised table; with this option -- and always when that
+ * table would exceed 4096 states -- the walk runs on the bitset NFA instead (state = bit
+ * mask of live PikeVM positions, up to 256).  Results are identical; only the kernel differs. */
+enum { MRX_COMPILE_LAZYDFA_SEMANTICS = 1, MRX_COMPILE_BITSET_NFA = 2 };
 int mrx_compile_ex(const char* pattern, size_t pattern_len, uint32_t options, mrx_handle** out);
 void mrx_free(mrx_handle* h);
 const char* mrx_last_error(void);

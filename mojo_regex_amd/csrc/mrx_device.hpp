@@ -27,6 +27,10 @@ struct Ctx {
   const uint16_t* trans;  // [nstates][ncls], 0xFFFF dead, bit15 = target accepts
   const uint8_t* lit;     // engine / exact literal
   const uint8_t* pre;     // prefilter literal
+  // bitset NFA (PF_BITSET)
+  const uint8_t* bs_cls;       // [256] byte -> mask row
+  const uint64_t* bs_mask;     // [bs_ncls][bs_nw] positions that consume a byte of the class
+  const uint64_t* bs_follow;   // [bs_npos][bs_nw] closure after position i
 };
 
 // One lane's text.  Reads go through an 8-byte register window: the generic kernels
@@ -139,6 +143,51 @@ __device__ inline bool try_match_at(const Ctx& c, const Text& t, int start_pos, 
   return true;
 }
 
+// The same walk on the bitset NFA: the state is the set of live PikeVM positions
+// (pikevm.mojo:497-602 thread list, as a bit mask) instead of the id of its determinised
+// LazyDFA state; transitions are computed, not looked up:
+//     next = OR_{i in set & mask[byte]} follow[i],  dead iff next is empty.
+// One lane still owns one text; the per-byte cost grows with the number of live positions.
+template <int NW>
+__device__ __noinline__ int walk_bitset(const Ctx& c, const Text& t, int start) {
+  uint64_t S[NW];
+#pragma unroll
+  for (int w = 0; w < NW; ++w) S[w] = c.p.bs_start[w];
+  int pos = start;
+  int last = flag(c, PF_START_ACCEPTING) ? pos : -1;
+  while (pos < t.len) {
+    const uint64_t* m = c.bs_mask + (int)c.bs_cls[t.at(pos)] * NW;
+    uint64_t N[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) N[w] = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      uint64_t hit = S[w] & m[w];
+      while (hit) {
+        const int i = w * 64 + __builtin_ctzll(hit);
+        hit &= hit - 1;
+        const uint64_t* f = c.bs_follow + i * NW;
+#pragma unroll
+        for (int v = 0; v < NW; ++v) N[v] |= f[v];
+      }
+    }
+    uint64_t any = 0, acc = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { any |= N[w]; acc |= N[w] & c.p.bs_match[w]; S[w] = N[w]; }
+    if (!any) break;  // LAZY_DFA_DEAD
+    ++pos;
+    if (acc) last = pos;
+  }
+  return last;
+}
+
+__device__ inline int lazy_walk(const Ctx& c, const Text& t, int start) {
+  if (!flag(c, PF_BITSET)) return walk(c, t, start);
+  if (c.p.bs_nw == 1) return walk_bitset<1>(c, t, start);
+  if (c.p.bs_nw == 2) return walk_bitset<2>(c, t, start);
+  return walk_bitset<4>(c, t, start);
+}
+
 // LazyDFA._run_lazy
 __device__ inline bool lazy_run(const Ctx& c, const Text& t, int start, int& ms, int& me) {
   if (flag(c, PF_START_DEAD)) return false;
@@ -147,7 +196,7 @@ __device__ inline bool lazy_run(const Ctx& c, const Text& t, int start, int& ms,
     ms = me = start;
     return true;
   }
-  const int last = walk(c, t, start);
+  const int last = lazy_walk(c, t, start);
   if (last < 0) return false;
   ms = start; me = last;
   return true;

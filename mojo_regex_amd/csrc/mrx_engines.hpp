@@ -91,4 +91,22 @@ struct LazyTables {
 };
 void build_lazy(const Program& p, LazyTables& out, int max_dfa_states);
 
+// Bit-parallel form of the same PikeVM program (the "bitset NFA"): one bit per
+// non-epsilon instruction ("position": BYTE / CLASS / ANY / RANGE / MATCH).  A state set
+// is kBitsetWords x 64 bits; one byte step is
+//     next = OR over positions i in (set & byte_mask[byte]) of follow[i]
+// with follow[i] = epsilon closure of pc_i + 1 (pikevm.mojo:604-648, not at text start).
+// It yields exactly the sets LazyDFA._compute_transition determinises (pikevm.mojo:870-942),
+// without enumerating them -- so it also serves programs whose DFA exceeds any budget.
+constexpr int kBitsetWords = 4;  // up to 256 positions
+struct BitsetNfa {
+  bool ok = false;  // program fits (<= 256 positions) and has no '$'
+  int npos = 0, nw = 0;
+  std::vector<int> pos_pc;
+  std::array<uint64_t, kBitsetWords> start{}, match{};
+  std::vector<std::array<uint64_t, kBitsetWords>> follow;     // [npos]
+  std::array<std::array<uint64_t, kBitsetWords>, 256> byte_mask{};
+};
+void build_bitset(const Program& p, BitsetNfa& out);
+
 }  // namespace mrx

@@ -62,6 +62,9 @@ __device__ __forceinline__ Ctx stage_tables(const DevPlan& p, const uint8_t* __r
   c.trans = (const uint16_t*)(lds + p.off_trans);
   c.lit = lds + p.off_lit;
   c.pre = lds + p.off_pre;
+  c.bs_cls = lds + p.off_bs_cls;
+  c.bs_mask = (const uint64_t*)(lds + p.off_bs_mask);
+  c.bs_follow = (const uint64_t*)(lds + p.off_bs_follow);
   return c;
 }
 
@@ -844,11 +847,13 @@ int mrx_compile(const char* pattern, size_t pattern_len, mrx_handle** out) {
 
 int mrx_compile_ex(const char* pattern, size_t pattern_len, uint32_t options, mrx_handle** out) {
   if (!out || (!pattern && pattern_len)) return fail(MRX_E_ARGUMENT, "null argument");
-  if (options & ~(uint32_t)MRX_COMPILE_LAZYDFA_SEMANTICS) return fail(MRX_E_ARGUMENT, "unknown compile option");
+  if (options & ~(uint32_t)(MRX_COMPILE_LAZYDFA_SEMANTICS | MRX_COMPILE_BITSET_NFA))
+    return fail(MRX_E_ARGUMENT, "unknown compile option");
   *out = nullptr;
   mrx_handle* h = new mrx_handle();
   try {
-    build_plan(std::string(pattern, pattern_len), h->hp, (options & MRX_COMPILE_LAZYDFA_SEMANTICS) != 0);
+    build_plan(std::string(pattern, pattern_len), h->hp, (options & MRX_COMPILE_LAZYDFA_SEMANTICS) != 0,
+               (options & MRX_COMPILE_BITSET_NFA) != 0);
   } catch (const SyntaxError& e) {
     delete h;
     return fail(MRX_E_SYNTAX, e.what());

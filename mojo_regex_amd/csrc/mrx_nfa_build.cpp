@@ -264,4 +264,50 @@ void build_lazy(const Program& p, LazyTables& out, int max_dfa_states) {
   }
 }
 
+void build_bitset(const Program& p, BitsetNfa& out) {
+  out = BitsetNfa();
+  const int n = (int)p.insts.size();
+  if (n == 0 || n > kPikeMaxStates || p.has_end_anchor()) return;
+  std::vector<int> pos_of(n, -1);
+  for (int pc = 0; pc < n; ++pc) {
+    const Op op = p.insts[pc].op;
+    if (op == OP_BYTE || op == OP_CLASS || op == OP_ANY || op == OP_RANGE || op == OP_MATCH) {
+      pos_of[pc] = (int)out.pos_pc.size();
+      out.pos_pc.push_back(pc);
+    }
+  }
+  out.npos = (int)out.pos_pc.size();
+  if (out.npos == 0 || out.npos > 64 * kBitsetWords) return;
+  out.nw = out.npos <= 64 ? 1 : out.npos <= 128 ? 2 : 4;
+  Closure cl{p};
+  auto to_bits = [&](const std::vector<uint8_t>& seen, std::array<uint64_t, kBitsetWords>& bits) {
+    bits.fill(0);
+    for (int pc = 0; pc < n; ++pc)
+      if (seen[pc] && pos_of[pc] >= 0) bits[pos_of[pc] >> 6] |= 1ull << (pos_of[pc] & 63);
+  };
+  {
+    // start closure as LazyDFA builds it: pos = 0, so '^' passes at every start position
+    std::vector<uint8_t> seen(n, 0);
+    int leaves = 0;
+    cl.add(seen, leaves, 0, /*at_start=*/true, /*at_end=*/true);
+    to_bits(seen, out.start);
+  }
+  out.follow.resize(out.npos);
+  for (int i = 0; i < out.npos; ++i) {
+    const int pc = out.pos_pc[i];
+    if (p.insts[pc].op == OP_MATCH) {
+      out.match[i >> 6] |= 1ull << (i & 63);
+      out.follow[i].fill(0);
+      continue;
+    }
+    std::vector<uint8_t> seen(n, 0);
+    int leaves = 0;
+    cl.add(seen, leaves, pc + 1, false, false);
+    to_bits(seen, out.follow[i]);
+    for (int ch = 0; ch < 256; ++ch)
+      if (cl.steps(pc, ch)) out.byte_mask[ch][i >> 6] |= 1ull << (i & 63);
+  }
+  out.ok = true;
+}
+
 }  // namespace mrx

@@ -255,9 +255,10 @@ std::vector<ReplSeg> parse_repl_template(const std::string& r) {  // matcher.moj
   return segs;
 }
 
-void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa) {
+void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool force_bitset) {
   hp = HostPlan();
   hp.force_nfa = force_nfa;
+  hp.force_bitset = force_bitset;
   hp.pattern = pattern;
   hp.wildcard_any = (pattern == ".*");  // matcher.mojo:435-444, 573-591
 
@@ -324,6 +325,7 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa) {
       }
       compile_program(ast, hp.program);
       build_lazy(hp.program, hp.lazy, /*max_dfa_states=*/4096);
+      build_bitset(hp.program, hp.bitset);
     }
     if (hp.complexity == CX_SIMPLE && !force_nfa) {  // matcher.mojo:664-675
       try {
@@ -346,12 +348,16 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa) {
              ", Complexity: " + cxn[hp.complexity];
 
   // ---- which operations stay on the hot path ----------------------------------
-  const bool lazy_ok = hp.lazy.supported && !hp.lazy.too_large;
+  // a LazyDFA whose determinisation exceeds the budget still runs, on the bitset NFA
+  const bool use_bitset = hp.lazy.supported && !hp.lazy.start_dead && hp.bitset.ok &&
+                          (hp.lazy.too_large || hp.force_bitset);
+  const bool too_large = hp.lazy.too_large && !use_bitset;
+  const bool lazy_ok = hp.lazy.supported && !too_large;
   const bool nfa_end = hp.program.has_end_anchor();
   if (!hp.wildcard_any && !hp.use_dfa) {
     // NFAMatcher.match_first, matcher.mojo:361-380
     if (!(lazy_ok && !nfa_end))
-      hp.why_no_match_first = hp.lazy.too_large
+      hp.why_no_match_first = too_large
           ? "LazyDFA determinisation exceeds the state budget"
           : "reference routes match_first to OnePass / the backtracking NFA ('$' in an NFA-routed pattern)";
     // NFAMatcher.match_next / match_all, matcher.mojo:383-431
@@ -362,8 +368,9 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa) {
     else if (nfa_end)
       hp.why_no_search = "LazyDFA search with '$' depends on the transition cache history "
                          "(pikevm.mojo:697-700); not reproducible";
-    else if (hp.lazy.too_large)
-      hp.why_no_search = "LazyDFA determinisation exceeds the state budget";
+    else if (too_large)
+      hp.why_no_search = "LazyDFA determinisation exceeds the state budget and the program has more "
+                         "than 256 positions";
   }
   if (hp.use_dfa && hp.dfa.has_matcher && hp.dfa.matcher.num_ranges == 0 && !hp.dfa.scan_eligible) {
     // nibble-table false positives (simd_ops.mojo:63-134) are SIMD-width dependent
@@ -418,11 +425,16 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa) {
     d.kind = PLAN_LAZY;
     const LazyTables& z = hp.lazy;
     if (z.start_dead || !lazy_ok) d.flags |= PF_START_DEAD;
-    for (size_t s = 0; s < z.trans.size(); ++s) {
+    if (use_bitset) d.flags |= PF_BITSET;
+    for (size_t s = 0; s < z.trans.size() && !use_bitset; ++s) {
       std::array<int, 256> row;
       for (int c = 0; c < 256; ++c) row[c] = z.trans[s][c];
       T.push_back(row);
       acc.push_back(z.is_match[s]);
+    }
+    if (use_bitset) {  // the table is not used; only "does the start set accept" survives
+      std::array<int, 256> row; row.fill(-1); T.push_back(row);
+      acc.push_back(!z.is_match.empty() && z.is_match[0]);
     }
     if (T.empty()) { std::array<int, 256> row; row.fill(-1); T.push_back(row); acc.push_back(0); }
     if (z.has_filter) { d.flags |= PF_HAS_MATCHER; first = z.first_byte; }
@@ -470,7 +482,26 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa) {
   put(hp.blob, lit.data(), lit.size());
   d.off_pre = (int)hp.blob.size();
   put(hp.blob, pre.data(), pre.size());
-  align(hp.blob, 4);
+  align(hp.blob, 8);
+  if (d.flags & PF_BITSET) {
+    const BitsetNfa& b = hp.bitset;
+    d.bs_nw = b.nw; d.bs_npos = b.npos;
+    for (int w = 0; w < kBitsetWords; ++w) { d.bs_start[w] = b.start[w]; d.bs_match[w] = b.match[w]; }
+    std::array<uint8_t, 256> bcls{};
+    std::vector<std::array<uint64_t, kBitsetWords>> masks;
+    for (int c = 0; c < 256; ++c) {
+      size_t k = 0;
+      while (k < masks.size() && masks[k] != b.byte_mask[c]) ++k;
+      if (k == masks.size()) masks.push_back(b.byte_mask[c]);
+      bcls[c] = (uint8_t)k;   // at most 256 distinct columns
+    }
+    d.bs_ncls = (int)masks.size();
+    d.off_bs_cls = (int)hp.blob.size(); put(hp.blob, bcls.data(), 256);
+    d.off_bs_mask = (int)hp.blob.size();
+    for (const auto& m : masks) put(hp.blob, m.data(), 8 * b.nw);
+    d.off_bs_follow = (int)hp.blob.size();
+    for (const auto& f : b.follow) put(hp.blob, f.data(), 8 * b.nw);
+  }
   if (d.nstates >= 0x7FFF) {
     hp.why_no_match_first = hp.why_no_search = "more than 32766 DFA states";
   }
@@ -481,6 +512,7 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa) {
   d.st_kind = 0;
   if (d.kind == PLAN_ANY) hp.streamable_why_not = "'.*' shortcut";
   else if (d.flags & PF_START_DEAD) hp.streamable_why_not = "dead start state";
+  else if (d.flags & PF_BITSET) hp.streamable_why_not = "bitset NFA walk (no determinised table)";
   else if (d.flags & (PF_START_ANCHOR | PF_END_ANCHOR)) hp.streamable_why_not = "anchored";
   else if (d.flags & (PF_EXACT_LITERAL | PF_PREFILTER)) hp.streamable_why_not = "exact-literal / prefilter path";
   else if (d.required_byte >= 0) hp.streamable_why_not = "required-byte findall path";
@@ -592,6 +624,7 @@ std::string describe_plan(const HostPlan& hp) {
   static const char* cxn[] = {"SIMPLE", "MEDIUM", "COMPLEX"};
   o << "complexity=" << cxn[hp.complexity] << "\n";
   if (hp.force_nfa) o << "option.lazydfa_semantics=1\n";
+  if (hp.force_bitset) o << "option.bitset_nfa=1\n";
   o << "use_dfa=" << hp.use_dfa << " wildcard_any=" << hp.wildcard_any
     << " use_pure_dfa=" << hp.use_pure_dfa << "\n";
   o << "exact_literal=" << hp.exact_literal << " literal_has_anchors=" << hp.literal_has_anchors
@@ -656,6 +689,8 @@ std::string describe_plan(const HostPlan& hp) {
     << " flags=0x" << std::hex << d.flags << std::dec << " blob_bytes=" << d.blob_bytes << "\n";
   o << "device.streamable=" << ((d.flags & PF_STREAMABLE) ? "yes" : ("no: " + hp.streamable_why_not))
     << " st_nstates=" << d.st_nstates << " st_kind=" << d.st_kind << "\n";
+  if (d.flags & PF_BITSET)
+    o << "device.bitset=yes positions=" << d.bs_npos << " words=" << d.bs_nw << " byte_classes=" << d.bs_ncls << "\n";
   return o.str();
 }
 

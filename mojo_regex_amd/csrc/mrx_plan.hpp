@@ -30,7 +30,8 @@ enum PlanFlags : uint32_t {
   PF_EXACT_LITERAL = 1u << 6,   // HybridMatcher.is_exact_literal && !has_anchors
   PF_PREFILTER = 1u << 7,       // HybridMatcher.prefilter && !has_anchors
   PF_START_DEAD = 1u << 8,      // LazyDFA start state is LAZY_DFA_DEAD
-  PF_STREAMABLE = 1u << 9       // findall can run on the single-pass streaming kernel
+  PF_STREAMABLE = 1u << 9,      // findall can run on the single-pass streaming kernel
+  PF_BITSET = 1u << 10          // PLAN_LAZY walks run on the bitset NFA instead of the DFA table
 };
 
 constexpr int kMaxTemplateSegs = 32;
@@ -55,6 +56,9 @@ struct DevPlan {
   // kind 2: cls[256] u8, trans[st_nstates][1 << st_cshift] u16 = (next << st_cshift) << 2 | EMIT << 1 | NEWSTART,
   // accept[st_nstates] u8
   int32_t off_stg_cls, off_stg_trans, off_stg_acc, st_cshift, stg_bytes;
+  // bitset NFA (PF_BITSET): cls[256] u8, byte masks u64[bs_ncls][bs_nw], follow u64[bs_npos][bs_nw]
+  int32_t bs_nw, bs_npos, bs_ncls, off_bs_cls, off_bs_mask, off_bs_follow;
+  uint64_t bs_start[4], bs_match[4];
 };
 
 struct HostPlan {
@@ -74,6 +78,8 @@ struct HostPlan {
   DfaEngine dfa;
   Program program;
   LazyTables lazy;
+  BitsetNfa bitset;
+  bool force_bitset = false;  // MRX_COMPILE_BITSET_NFA
   bool nfa_has_literal_opt = false, nfa_starts_dotstar = false, nfa_ends_dotstar = false;
   // per-operation support: empty string = supported, else the reason
   std::string why_no_match_first, why_no_search;
@@ -90,7 +96,9 @@ struct HostPlan {
 // Throws SyntaxError for patterns the reference's parser raises on.
 // force_nfa: route as if DFAEngine compilation had failed (matcher.mojo:666-672), i.e. the
 // NFAMatcher / LazyDFA path -- the "LazyDFA semantics" switch of SURVEY.md 8(c).
-void build_plan(const std::string& pattern, HostPlan& out, bool force_nfa = false);
+// force_bitset: LazyDFA-routed patterns walk the bitset NFA even when the determinised table fits.
+void build_plan(const std::string& pattern, HostPlan& out, bool force_nfa = false,
+                bool force_bitset = false);
 std::string describe_plan(const HostPlan& p);
 
 // replacement template (matcher.mojo:1436-1482)

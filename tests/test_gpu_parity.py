@@ -380,3 +380,52 @@ def test_full_size_c2_properties():
     for j, i in enumerate(range(0, n, n // 256)):
         have = [tuple(int(x) for x in r) for r in sph[pre[i]:pre[i + 1]]]
         assert have == O.findall(b"[a-z]+\\d+", host[j].tobytes()), i
+
+
+# ---- bitset NFA (the PikeVM / LazyDFA path without a table) -----
+BITSET_CASES = [
+    # (pattern, lazydfa_semantics, forced, alphabet)
+    (b"(a|b)*a(a|b){12}", False, False, b"ab"),               # 2^13 DFA states: table refused, bitset runs
+    (b"(a|b)*a(a|b){12}", False, False, b"abc"),
+    (b"(a|b)*a[ab]{13}c", False, False, b"abbc"),
+    (b"(a|b)*a(a|b){40}c", False, False, b"aabbc"),           # 85 positions: two words
+    (b"(a|b)*a(a|b){70}", False, False, b"ab", 8),            # 144 positions: four words (slow in the oracle)
+    (b"(a|b)x", False, True, b"abx "),                        # fits the table; forced onto the bitset walk
+    (b"(ab)+c", False, True, b"abc"),
+    (b"(foo|bar)+baz?", False, True, b"fobarz "),
+    (b"x*y?z+(ab|cd)*", False, True, b"xyzabcd "),            # start set accepts? (no: z+ required)
+    (b"(a|b)*", True, True, b"abc"),                          # start set accepts: empty matches
+    (b"^(a|b)+c", False, True, b"abc"),                       # '^' passes at every start (pikevm.mojo:714)
+    (b"(x|y|foo|bar)+", True, True, b"xyfobar "),             # config 5, LazyDFA reading
+    (b"(\\d{3})(\\d{3})(\\d{4})", True, True, b"0123456789 -"),  # config 4 program on the NFA kernel
+    (b"[a-z]+\\d+", True, True, b"abz019 -"),
+]
+
+
+@pytest.mark.parametrize("case", BITSET_CASES, ids=lambda c: c[0].decode() + "/" + c[3].decode())
+def test_bitset_nfa_matches_oracle(case):
+    _need_gpu()
+    from mrx_ref.hybrid import CompiledRegex as OracleRegex
+    pat, lazy, forced, al = case[:4]
+    fewer = case[4] if len(case) > 4 else 1
+    rng = np.random.default_rng(zlib.crc32(pat + al))
+    texts = _random_texts(rng, 300 // fewer, 120, al) + _random_texts(rng, 40 // fewer, 600, al)
+    rx = M.compile_regex(pat, lazydfa_semantics=lazy, bitset_nfa=forced)
+    d = rx.describe()
+    assert "device.bitset=yes" in d, d
+    o = OracleRegex(pat, force_nfa=lazy)
+    got_all = rx.findall_lists(texts)
+    s, e = rx.match_next(texts)
+    fs, fe = rx.match_first(texts)
+    for i, t in enumerate(texts):
+        assert got_all[i] == o.match_all(t), (pat, i, t)
+        w = o.match_next(t, 0)
+        assert (int(s[i]), int(e[i])) == (w if w else (-1, -1)), (pat, i, t)
+        w = o.match_first(t, 0)
+        w = w if (w and w[0] == 0) else None
+        assert (int(fs[i]), int(fe[i])) == (w if w else (-1, -1)), (pat, i, t)
+    if forced:
+        # the table walk and the bitset walk are the same function of the text
+        tab = M.compile_regex(pat, lazydfa_semantics=lazy)
+        assert "device.bitset" not in tab.describe()
+        assert tab.findall_lists(texts) == got_all

@@ -33,11 +33,23 @@ def main():
         ("c4 (\\d{3})(\\d{3})(\\d{4})", b"(\\d{3})(\\d{3})(\\d{4})", lambda: W.make_phone_batch(1 << 20, 1024), 56),
         ("c5 (x|y|foo|bar)+", b"(x|y|foo|bar)+", lambda: W.make_alt_batch(1 << 22, 4096), 720),
         ("c1 hello", b"hello", lambda: W.make_c2_batch(1 << 20, 1024, seed=5), 4),
+        # the PikeVM program of configs 4 / 5 (MRX_COMPILE_LAZYDFA_SEMANTICS): determinised
+        # table walk vs. bitset-NFA walk, generic lane-per-text kernels
+        ("c4 LazyDFA table", b"(\\d{3})(\\d{3})(\\d{4})", lambda: W.make_phone_batch(1 << 20, 1024), 56,
+         dict(lazydfa_semantics=True)),
+        ("c4 bitset NFA", b"(\\d{3})(\\d{3})(\\d{4})", lambda: W.make_phone_batch(1 << 20, 1024), 56,
+         dict(lazydfa_semantics=True, bitset_nfa=True)),
+        ("c5 LazyDFA table ('+' honoured)", b"(x|y|foo|bar)+", lambda: W.make_alt_batch(1 << 20, 4096), 720,
+         dict(lazydfa_semantics=True)),
+        ("c5 bitset NFA ('+' honoured)", b"(x|y|foo|bar)+", lambda: W.make_alt_batch(1 << 20, 4096), 720,
+         dict(lazydfa_semantics=True, bitset_nfa=True)),
     ]
-    for name, pat, gen, per_text in cases:
+    for case in cases:
+        name, pat, gen, per_text = case[:4]
+        opts = case[4] if len(case) > 4 else {}
         d = gen()
         n, L = d.shape
-        rx = M.compile_regex(pat)
+        rx = M.compile_regex(pat, **opts)
         batch = M.DeviceBatch.strided(d.reshape(-1), L, length=L)
         prefix = torch.empty(n + 1, dtype=torch.int64, device="cuda")
         spans = torch.empty((n * per_text, 2), dtype=torch.int32, device="cuda")
