@@ -179,7 +179,10 @@ constexpr uint32_t kRecBeforeMask = (1u << 26) - 1u;
 
 __host__ __device__ inline int64_t rec_row_len(int64_t max_len) { return max_len / 16 + 2; }
 
-enum { ST_RECORDS = 0, ST_COUNT = 1, ST_SEARCH = 2 };  // ST_SEARCH: first match only (regex.search)
+// ST_SEARCH: first match only (regex.search).  ST_FIRST: regex.match_first -- the plan's anchored
+// automaton (DevPlan::off_fa_*) run from byte 0, EMIT bit = "the state entered accepts"; a lane is
+// finished when it enters the dead state, finished rows are no longer fetched.
+enum { ST_RECORDS = 0, ST_COUNT = 1, ST_SEARCH = 2, ST_FIRST = 3 };
 
 // AUTO = 1: byte-column automaton (<= 4 states, described above).
 // AUTO = 2: class-table automaton for any streamable plan: cls[byte] (u8, LDS) is looked
@@ -203,14 +206,17 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
     const uint16_t* src = (const uint16_t*)(blob + p.off_stcol);
     for (int i = threadIdx.x; i < 256; i += blockDim.x) col_lds[i] = src[i];
   } else {
-    const uint32_t* src = (const uint32_t*)(blob + p.off_stg_cls);
+    const uint32_t* src = (const uint32_t*)(blob + (MODE == ST_FIRST ? p.off_fa_cls : p.off_stg_cls));
     uint32_t* dst = (uint32_t*)stg_lds;
-    for (int i = threadIdx.x; i < (p.stg_bytes >> 2); i += blockDim.x) dst[i] = src[i];
+    const int words = (MODE == ST_FIRST ? p.fa_bytes : p.stg_bytes) >> 2;
+    for (int i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
   }
   __syncthreads();
   const uint8_t* cls_lds = stg_lds;
-  const uint16_t* tr_lds = (const uint16_t*)(stg_lds + (p.off_stg_trans - p.off_stg_cls));
+  const uint16_t* tr_lds = (const uint16_t*)(stg_lds + (MODE == ST_FIRST ? p.off_fa_trans - p.off_fa_cls
+                                                                        : p.off_stg_trans - p.off_stg_cls));
   const uint8_t* acc_lds = stg_lds + (p.off_stg_acc - p.off_stg_cls);
+  const uint32_t fa_dead = (uint32_t)p.fa_nstates << p.fa_cshift;  // row offset of the dead state
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   uint8_t* tile = tiles[wave];
@@ -246,17 +252,44 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
       uint32_t cb_ = (uint32_t)(CB);                                             \
       if ((int64_t)cb_ + seg * 16 >= stride) cb_ = (uint32_t)0 - (uint32_t)(seg * 16); \
       _Pragma("unroll") for (int j_ = 0; j_ < NL; ++j_)                          \
-        v[j_] = *(const uint4*)(wbase + (roff[j_] + cb_));                       \
+        if (MODE != ST_FIRST || !((skip_rows >> (RPI * j_ + rsub)) & 1ull))       \
+          v[j_] = *(const uint4*)(wbase + (roff[j_] + cb_));                     \
     } while (0)
+    uint64_t skip_rows = 0;  // ST_FIRST: rows (= lanes) whose walk has ended
 
     uint32_t q4 = 0;  // 4 * state
     int start = 0;
     int cnt = 0;
     int wrec = 0;  // records written by this wavefront so far (wave uniform)
-    bool done = !live;          // ST_SEARCH: this lane has its answer
-    int res_s = -1, res_e = -1;
+    bool done = !live;          // ST_SEARCH / ST_FIRST: this lane has its answer
+    int res_s = -1, res_e = (MODE == ST_FIRST && live && p.fa_start_acc) ? 0 : -1;
     EvRec* wave_recs = (MODE == ST_RECORDS) ? recs + base_text * rec_row : nullptr;
 
+    if (MODE == ST_FIRST) {
+      // Probe: most anchored walks end within a few bytes.  Every lane reads the first 16 bytes
+      // of its own text (one load instruction per wavefront instead of a full 128-byte chunk per
+      // text); when that settles all 64 texts the wavefront is done.
+      uint4 pv = make_uint4(0, 0, 0, 0);
+      if (live && my_len > 0) pv = *(const uint4*)(data + my_text * stride);
+      const uint32_t pw[4] = {pv.x, pv.y, pv.z, pv.w};
+      uint32_t pq = 0, pF = 0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        uint32_t e = tr_lds[pq + cls_lds[(pw[k >> 2] >> ((k & 3) * 8)) & 0xFFu]];
+        if (k >= my_len) e = pq << 2;
+        pq = e >> 2;
+        pF = __builtin_amdgcn_alignbit(e, pF, 2);
+      }
+      const uint32_t pem = pF & 0xAAAAAAAAu;
+      if (__all(!live || pq == fa_dead || my_len <= 16)) {
+        if (live) {
+          const int e_ = pem ? ((31 - __builtin_clz(pem)) >> 1) + 1 : (p.fa_start_acc ? 0 : -1);
+          out_s[my_text] = e_ >= 0 ? 0 : -1;
+          out_e[my_text] = e_;
+        }
+        continue;
+      }
+    }
     uint4 v[NL];
 #pragma unroll
     for (int j = 0; j < NL; ++j) v[j] = make_uint4(0, 0, 0, 0);
@@ -270,6 +303,10 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       if (MODE == ST_SEARCH) { if (__all(done)) break; }
+      if (MODE == ST_FIRST) {
+        skip_rows = __ballot(done || cbase + kChunk >= my_len);
+        if (__all(done)) break;
+      }
       if (cbase + kChunk < max_len) MRX_LOAD_CHUNK(cbase + kChunk);  // prefetch next chunk
 
       const int lim = my_len - cbase;  // bytes of mine in this chunk (may be <= 0 or > 64)
@@ -330,6 +367,10 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
             wrec += __builtin_popcountll(has);
           }
         }
+        if (MODE == ST_FIRST) {
+          if (em) res_e = gbase + ((31 - __builtin_clz(em)) >> 1) + 1;  // last accepting position so far
+          if (q4 == fa_dead) done = true;
+        }
         if (MODE == ST_SEARCH) {
           if (!done && em) {  // leftmost match = first EMIT of the text
             const int kk = __builtin_ctz(em) >> 1;
@@ -346,8 +387,8 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
     }
     // end of text: a walk that is in an accepting state ends at len
     {
-      const bool tail = live && (AUTO == 2 ? acc_lds[q4 >> p.st_cshift] != 0
-                                          : ((accmask >> (q4 >> 2)) & 1u) != 0);
+      const bool tail = MODE != ST_FIRST && live &&
+                        (AUTO == 2 ? acc_lds[q4 >> p.st_cshift] != 0 : ((accmask >> (q4 >> 2)) & 1u) != 0);
       if (MODE == ST_RECORDS) {
         const uint64_t has = __ballot(tail);
         if (tail) {
@@ -362,7 +403,12 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
         if (lane == 0) wave_nrecs[w] = wrec;
       }
       if (tail) ++cnt;
-      if (MODE == ST_SEARCH) {
+      if (MODE == ST_FIRST) {
+        if (live) {
+          out_s[my_text] = res_e >= 0 ? 0 : -1;
+          out_e[my_text] = res_e;
+        }
+      } else if (MODE == ST_SEARCH) {
         if (live) {
           if (!done && tail) { res_s = start; res_e = my_len; }
           out_s[my_text] = res_s;
@@ -929,9 +975,28 @@ int mrx_search_strided_dev(const mrx_handle* h, const uint8_t* d, int64_t stride
 int mrx_match_first_strided_dev(const mrx_handle* h, const uint8_t* d, int64_t stride,
                                 const int32_t* lens, int32_t len, int64_t n, int32_t* ds,
                                 int32_t* de, void* st) {
+  if (!h) return fail(MRX_E_ARGUMENT, "null handle");
   if (stride <= 0) return fail(MRX_E_ARGUMENT, "stride must be positive");
   if (!lens && (len < 0 || len > stride)) return fail(MRX_E_ARGUMENT, "len must be in [0, stride]");
-  return run_match<OP_MATCH_FIRST>(h, Layout{d, nullptr, stride, lens, len}, n, ds, de, nullptr, st);
+  const Layout lay{d, nullptr, stride, lens, len};
+  const DevPlan& p = h->hp.dev;
+  const bool stream_ok = p.fa_bytes > 0 && (stride % 16 == 0) && (((uintptr_t)d) % 16 == 0) && n > 0 &&
+                         stride * 64 < (int64_t(1) << 31);
+  if (!stream_ok) return run_match<OP_MATCH_FIRST>(h, lay, n, ds, de, nullptr, st);
+  if (!h->hp.why_no_match_first.empty()) return fail(MRX_E_UNSUPPORTED, h->hp.why_no_match_first);
+  if (int rc = ensure_device(h)) return rc;
+  hipStream_t s = (hipStream_t)st;
+  const int64_t nw = (n + 63) / 64;
+  int64_t g = (nw + kStreamWaves - 1) / kStreamWaves;
+  if (g > 256 * 8) g = 256 * 8;
+  ScanTimer tm(s);
+  hipLaunchKernelGGL((k_stream_findall<ST_FIRST, MRX_STREAM_CHUNK, 2>), dim3((unsigned)g),
+                     dim3(64 * kStreamWaves), (size_t)p.fa_bytes, s, p, h->d_blob, d, stride, lens, len, n,
+                     (int32_t*)nullptr, (int32_t*)nullptr, (EvRec*)nullptr, (int64_t)0, ds, de);
+  g_last_kernel = "k_stream_first";
+  HIP_TRY(hipGetLastError());
+  tm.stop();
+  return MRX_OK;
 }
 int mrx_is_match_dev(const mrx_handle* h, const uint8_t* d, const int64_t* off, int64_t n,
                      uint8_t* f, void* st) {

@@ -612,6 +612,85 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
       }
     }
   }
+  // ---- anchored automaton: regex.match_first as one forward pass ----------------------
+  // match_first(text) = engine_match_first(text, 0) keeps no restart loop, so it is a plain
+  // automaton run from byte 0 that remembers the last accepting position:
+  //   pure literal       verify_match at 0 (simd_ops.mojo:937-960): the literal's chain
+  //   _try_match_simd    (dfa.mojo:2133-2197) first-class run; falls through to the table walk
+  //                      when the run is empty and the start state does not accept
+  //   otherwise          the table walk (dfa.mojo:1979-2024 / pikevm.mojo:819-867)
+  d.fa_bytes = 0; d.fa_nstates = 0; d.fa_start_acc = 0; d.off_fa_cls = d.off_fa_trans = -1; d.fa_cshift = 0;
+  hp.first_stream_why_not.clear();
+  if (d.kind == PLAN_ANY) hp.first_stream_why_not = "'.*' shortcut";
+  else if (!hp.why_no_match_first.empty()) hp.first_stream_why_not = hp.why_no_match_first;
+  else if (d.flags & PF_START_DEAD) hp.first_stream_why_not = "dead start state";
+  else if (d.flags & PF_BITSET) hp.first_stream_why_not = "bitset NFA walk (no determinised table)";
+  else if (d.flags & PF_END_ANCHOR) hp.first_stream_why_not = "'$' needs the end-of-text check of both paths";
+  else {
+    std::vector<std::array<int, 256>> N;  // -1 = dead
+    std::vector<uint8_t> A;
+    auto add = [&](bool a) { std::array<int, 256> r; r.fill(-1); N.push_back(r); A.push_back(a ? 1 : 0); return (int)N.size() - 1; };
+    if (d.flags & PF_PURE_LITERAL) {
+      const std::string& L = hp.dfa.literal;
+      add(L.empty());
+      for (size_t k = 0; k < L.size(); ++k) { const int t = add(k + 1 == L.size()); N[t - 1][(unsigned char)L[k]] = t; }
+    } else {
+      const bool quirk = d.kind == PLAN_DFA && (d.flags & PF_HAS_MATCHER) &&
+                         (d.flags & (PF_SCAN_ELIGIBLE | PF_START_ACCEPTING));
+      const int base = quirk ? 2 : 0;   // quirk: 0 = start, 1 = inside the first-class run
+      if (quirk) { add((d.flags & PF_START_ACCEPTING) != 0); add(true); }
+      for (size_t q = 0; q < T.size(); ++q) {
+        const int id = add(acc[q] != 0);
+        for (int c = 0; c < 256; ++c) N[id][c] = T[q][c] < 0 ? -1 : T[q][c] + base;
+      }
+      if (quirk)
+        for (int c = 0; c < 256; ++c) {
+          if (first[c]) { N[0][c] = 1; N[1][c] = 1; }
+          else if (!(d.flags & PF_START_ACCEPTING)) N[0][c] = N[base][c];  // empty run: table walk from 0
+        }
+    }
+    // reachable states only, then the dead state
+    std::vector<int> remap(N.size(), -1), order;
+    remap[0] = 0; order.push_back(0);
+    for (size_t k = 0; k < order.size(); ++k)
+      for (int c = 0; c < 256; ++c) {
+        const int t = N[order[k]][c];
+        if (t >= 0 && remap[t] < 0) { remap[t] = (int)order.size(); order.push_back(t); }
+      }
+    const int nl = (int)order.size();      // live states; dead = nl
+    std::array<uint8_t, 256> fcls{};
+    int fn = 0;
+    {
+      std::map<std::vector<int>, int> seen;
+      for (int c = 0; c < 256; ++c) {
+        std::vector<int> col(nl);
+        for (int q = 0; q < nl; ++q) { const int t = N[order[q]][c]; col[q] = t < 0 ? -1 : remap[t]; }
+        auto it = seen.find(col);
+        if (it == seen.end()) it = seen.emplace(col, fn++).first;
+        fcls[c] = (uint8_t)it->second;
+      }
+    }
+    int cshift = 0;
+    while ((1 << cshift) < fn) ++cshift;
+    const int ncp = 1 << cshift;
+    if ((int64_t)(nl + 1) * ncp > 8192) {
+      hp.first_stream_why_not = "anchored automaton too large for the streaming kernel's LDS table";
+    } else {
+      std::vector<uint16_t> tr((size_t)(nl + 1) * ncp, (uint16_t)(((nl << cshift) << 2)));  // default: dead
+      for (int c = 0; c < 256; ++c)
+        for (int q = 0; q < nl; ++q) {
+          const int t = N[order[q]][c];
+          if (t >= 0) tr[(size_t)q * ncp + fcls[c]] = (uint16_t)((((remap[t]) << cshift) << 2) | (A[t] ? 2 : 0));
+        }
+      align(hp.blob, 16);
+      const int begin = (int)hp.blob.size();
+      d.off_fa_cls = begin; put(hp.blob, fcls.data(), 256);
+      d.off_fa_trans = (int)hp.blob.size(); put(hp.blob, tr.data(), tr.size() * 2);
+      align(hp.blob, 16);
+      d.fa_bytes = (int)hp.blob.size() - begin;
+      d.fa_cshift = cshift; d.fa_nstates = nl; d.fa_start_acc = A[0];
+    }
+  }
   align(hp.blob, 16);
   d.blob_bytes = (int)hp.blob.size();
 }
@@ -689,6 +768,8 @@ std::string describe_plan(const HostPlan& hp) {
     << " flags=0x" << std::hex << d.flags << std::dec << " blob_bytes=" << d.blob_bytes << "\n";
   o << "device.streamable=" << ((d.flags & PF_STREAMABLE) ? "yes" : ("no: " + hp.streamable_why_not))
     << " st_nstates=" << d.st_nstates << " st_kind=" << d.st_kind << "\n";
+  o << "device.first_stream=" << (d.fa_bytes ? "yes" : ("no: " + hp.first_stream_why_not))
+    << " fa_nstates=" << d.fa_nstates << "\n";
   if (d.flags & PF_BITSET)
     o << "device.bitset=yes positions=" << d.bs_npos << " words=" << d.bs_nw << " byte_classes=" << d.bs_ncls << "\n";
   return o.str();

@@ -56,6 +56,9 @@ struct DevPlan {
   // kind 2: cls[256] u8, trans[st_nstates][1 << st_cshift] u16 = (next << st_cshift) << 2 | EMIT << 1 | NEWSTART,
   // accept[st_nstates] u8
   int32_t off_stg_cls, off_stg_trans, off_stg_acc, st_cshift, stg_bytes;
+  // anchored automaton for match_first on the streaming kernel (fa_bytes == 0: none); same layout
+  // as kind 2 but entry = (next << fa_cshift) << 2 | ACCEPT(next) << 1, last row = dead state
+  int32_t off_fa_cls, off_fa_trans, fa_cshift, fa_bytes, fa_nstates, fa_start_acc;
   // bitset NFA (PF_BITSET): cls[256] u8, byte masks u64[bs_ncls][bs_nw], follow u64[bs_npos][bs_nw]
   int32_t bs_nw, bs_npos, bs_ncls, off_bs_cls, off_bs_mask, off_bs_follow;
   uint64_t bs_start[4], bs_match[4];
@@ -91,6 +94,7 @@ struct HostPlan {
   DevPlan dev{};
   std::vector<uint8_t> blob;
   std::string streamable_why_not;
+  std::string first_stream_why_not;
 };
 
 // Throws SyntaxError for patterns the reference's parser raises on.

@@ -429,3 +429,44 @@ def test_bitset_nfa_matches_oracle(case):
         tab = M.compile_regex(pat, lazydfa_semantics=lazy)
         assert "device.bitset" not in tab.describe()
         assert tab.findall_lists(texts) == got_all
+
+
+FIRST_PATTERNS = STREAM_PATTERNS + [b"[a-z]*[0-9]*", b"^abc", b"a*", b"\\w+@\\w+\\.com", b"[a-c]+x[0-9]+y",
+                                    b"\\d{3}-\\d{4}", b"hello world this is long", b"^[a-z]+\\d*", b"x?y?z?",
+                                    b"[a-z]+\\s+[a-z]+\\s+[0-9]+"]
+
+
+@pytest.mark.parametrize("pat", FIRST_PATTERNS)
+@pytest.mark.parametrize("n,pitch,var", [(1, 16, False), (65, 80, True), (777, 208, True), (130, 1024, False)])
+def test_streaming_match_first_equals_generic_and_oracle(pat, n, pitch, var):
+    """regex.match_first on a fixed-pitch batch runs the anchored automaton on the streaming
+    kernel; it must agree with the generic lane-per-text kernel on every text and with the
+    oracle on a sample."""
+    _need_gpu()
+    rng = np.random.default_rng(n * 977 + pitch + zlib.crc32(pat))
+    al = np.frombuffer(b"abcdxyz0123456789 -bcab" + bytes(c for c in pat if chr(c).isalnum() or c in b" @.-") * 2,
+                       dtype=np.uint8)
+    arr = rng.choice(al, size=(n, pitch)).astype(np.uint8)
+    for i in range(0, n, 3):   # texts that begin like a match: long letter runs, then digits
+        k = int(rng.integers(0, pitch))
+        arr[i, :k] = ord("q")
+        arr[i, k:k + int(rng.integers(0, 40))] = ord("7")
+    for i in range(1, n, 11):  # texts that begin with the pattern's own literal bytes
+        lit = bytes(c for c in pat if chr(c).isalnum() or c in b" ")[:pitch]
+        arr[i, :len(lit)] = np.frombuffer(lit, dtype=np.uint8)
+    lens = rng.integers(0, pitch + 1, size=n).astype(np.int32) if var else None
+    rx = M.compile_regex(pat)
+    assert "device.first_stream=yes" in rx.describe()
+    d = torch.from_numpy(arr).cuda().reshape(-1)
+    dl = torch.from_numpy(lens).cuda() if var else None
+    batch = M.DeviceBatch.strided(d, pitch, length=pitch, lens=dl)
+    fs, fe = rx.match_first(batch)
+    assert M.load_library().mrx_last_kernel_name() == b"k_stream_first"
+    fs, fe = fs.cpu().numpy(), fe.cpu().numpy()
+    texts = [arr[i, : (lens[i] if var else pitch)].tobytes() for i in range(n)]
+    gs, ge = rx.match_first(texts)   # CSR batch -> generic kernel
+    assert M.load_library().mrx_last_kernel_name() == b"k_match"
+    assert np.array_equal(fs, gs) and np.array_equal(fe, ge), pat
+    for i in range(0, n, 5):
+        w = O.match_first(pat, texts[i])
+        assert (int(fs[i]), int(fe[i])) == (w if w else (-1, -1)), (pat, i)
