@@ -31,7 +31,8 @@ class UnsupportedPattern(MrxError):
 
 
 def library_path() -> str:
-    return os.path.join(_HERE, _LIB_NAME)
+    # MRX_LIB: measurement hook (tools/ablate.sh loads instrumented builds of the same library)
+    return os.environ.get("MRX_LIB") or os.path.join(_HERE, _LIB_NAME)
 
 
 def load_library():

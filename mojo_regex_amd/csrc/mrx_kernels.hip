@@ -168,6 +168,13 @@ constexpr int kStreamWaves = 4;
 #ifndef MRX_STREAM_CHUNK
 #define MRX_STREAM_CHUNK 128
 #endif
+// Measurement only (tools/ablate.sh): switch pieces of the streaming loop off to see what
+// bounds it.  Results are WRONG for any value but 0; never set in a product build.
+//   1 no record stores   2 no global loads after a wavefront's first chunk
+//   4 no column lookup   16 no event handling
+#ifndef MRX_ABLATE
+#define MRX_ABLATE 0
+#endif
 
 struct EvRec {   // 16 bytes
   uint32_t F;
@@ -307,6 +314,7 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
         skip_rows = __ballot(done || cbase + kChunk >= my_len);
         if (__all(done)) break;
       }
+      if (!(MRX_ABLATE & 2))
       if (cbase + kChunk < max_len) MRX_LOAD_CHUNK(cbase + kChunk);  // prefetch next chunk
 
       const int lim = my_len - cbase;  // bytes of mine in this chunk (may be <= 0 or > 64)
@@ -332,7 +340,8 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
           uint32_t cv[16];
 #pragma unroll
           for (int k = 0; k < 16; ++k)
-            cv[k] = col_lds[(words[k >> 2] >> ((k & 3) * 8)) & 0xFFu];
+            cv[k] = (MRX_ABLATE & 4) ? ((words[k >> 2] >> ((k & 3) * 8)) & 0xFFu) * 0x0101u
+                                     : col_lds[(words[k >> 2] >> ((k & 3) * 8)) & 0xFFu];
 #pragma unroll
           for (int k = 0; k < 16; ++k) {
             const uint32_t e = cv[k] >> q4;
@@ -353,6 +362,7 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
         const uint32_t em = F & 0xAAAAAAAAu;
         const uint32_t ns = F & 0x55555555u;
         const int gbase = cbase + g * 16;
+        if (MRX_ABLATE & 16) { cnt += (F == 0x12345u); continue; }
         if (MODE == ST_RECORDS) {
           const uint64_t has = __ballot(em != 0);
           if (has) {  // wave uniform
@@ -362,7 +372,8 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
               EvRec r;
               r.F = F; r.start = start; r.pos_base = gbase;
               r.meta = ((uint32_t)lane << 26) | ((uint32_t)cnt & kRecBeforeMask);
-              wave_recs[wrec + rank] = r;
+              if (!(MRX_ABLATE & 1)) wave_recs[wrec + rank] = r;
+              else if (r.F == 0x12345u && r.start == -77) wave_recs[0] = r;  // keep r alive
             }
             wrec += __builtin_popcountll(has);
           }
