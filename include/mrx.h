@@ -177,6 +177,9 @@ void mrx_timing_reset(void);
 void mrx_timing_enable(int on);
 double mrx_timing_scan_ms(int64_t* launches);
 const char* mrx_last_kernel_name(void);
+/* Testing aid: route every call to the generic lane-per-text kernels (the streaming kernel is
+ * then never used) so that the two implementations can be compared on the same batch. */
+void mrx_debug_force_generic(int on);
 const char* mrx_version(void);
 
 #ifdef __cplusplus

@@ -185,6 +185,13 @@ struct EvRec {   // 16 bytes
 constexpr uint32_t kRecBeforeMask = (1u << 26) - 1u;
 
 __host__ __device__ inline int64_t rec_row_len(int64_t max_len) { return max_len / 16 + 2; }
+// CSR batches: wavefront w's record region.  A text yields at most len/16 + 3 records (its frame
+// has at most len/16 + 2 groups, plus the match that ends at len), so 64 texts starting at byte
+// offset `first_off` need at most span/16 + 192 slots; regions floor(off/16) + 256 w apart cannot
+// overlap.  Whole buffer: total_bytes/16 + 256 * waves + 256 slots.
+__host__ __device__ inline int64_t rec_region_start(int64_t first_off, int64_t w) {
+  return (first_off >> 4) + 256 * w;
+}
 
 // ST_SEARCH: first match only (regex.search).  ST_FIRST: regex.match_first -- the plan's anchored
 // automaton (DevPlan::off_fa_*) run from byte 0, EMIT bit = "the state entered accepts"; a lane is
@@ -195,10 +202,16 @@ enum { ST_RECORDS = 0, ST_COUNT = 1, ST_SEARCH = 2, ST_FIRST = 3 };
 // AUTO = 2: class-table automaton for any streamable plan: cls[byte] (u8, LDS) is looked
 //           up ahead for the whole group, then trans[state_row + cls] (u16, LDS) is a
 //           dependent lookup per byte -- latency bound, hidden by the other wavefronts.
-template <int MODE, int CH, int AUTO>
+// CSR = 1: ragged batch (texts back to back, int64 offsets[n+1]) instead of a fixed pitch.  A text
+//           is then walked in the frame of the 16-byte blocks that hold it: it starts `a` bytes
+//           into its first block (a = address & 15); frame bytes before the text and after its
+//           end are no-ops exactly like the bytes past the end of a short text.  Row base, a and
+//           frame length of every text live in the 16 pad bytes behind its tile row.
+template <int MODE, int CH, int AUTO, int CSR>
 __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
     DevPlan p, const uint8_t* __restrict__ blob, const uint8_t* __restrict__ data, int64_t stride,
-    const int32_t* __restrict__ lens, int32_t common_len, int64_t n, int32_t* __restrict__ counts,
+    const int32_t* __restrict__ lens, int32_t common_len, const int64_t* __restrict__ offsets,
+    int64_t n, int32_t* __restrict__ counts,
     int32_t* __restrict__ wave_nrecs, EvRec* __restrict__ recs, int64_t rec_row,
     int32_t* __restrict__ out_s, int32_t* __restrict__ out_e) {
   constexpr int kChunk = CH;
@@ -237,8 +250,24 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
     const int64_t base_text = w << 6;
     const int64_t my_text = base_text + lane;
     const bool live = my_text < n;
-    const int my_len = live ? (lens ? lens[my_text] : common_len) : 0;
-    int max_len = my_len;  // longest text in this wavefront decides the trip count
+    int my_len, mis = 0;   // mis: bytes of my first 16-byte block that precede the text (CSR)
+    if (CSR) {
+      const int64_t o0 = live ? offsets[my_text] : 0, o1 = live ? offsets[my_text + 1] : 0;
+      my_len = (int)(o1 - o0);
+      // an empty text owns no block: park its row on the offsets array (valid memory, never read as text)
+      const uintptr_t addr = my_len > 0 ? (uintptr_t)(data + o0) : (uintptr_t)offsets;
+      mis = my_len > 0 ? (int)(addr & 15) : 0;
+      const uintptr_t rb = addr & ~(uintptr_t)15;
+      *(uint4*)(tile + lane * kRowPitch + CH) =
+          make_uint4((uint32_t)rb, (uint32_t)((uint64_t)rb >> 32), (uint32_t)(mis + my_len), 0u);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+      my_len = live ? (lens ? lens[my_text] : common_len) : 0;
+    }
+    const int flen = mis + my_len;  // length of my text's frame
+    int max_len = flen;  // longest frame in this wavefront decides the trip count
     for (int off = 32; off > 0; off >>= 1) max_len = max(max_len, __shfl_xor(max_len, off));
 
     // rows this lane stages: texts RPI*j + lane/LPR of the wavefront.  Addresses are a
@@ -257,10 +286,18 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
 #define MRX_LOAD_CHUNK(CB)                                                       \
     do {                                                                         \
       uint32_t cb_ = (uint32_t)(CB);                                             \
-      if ((int64_t)cb_ + seg * 16 >= stride) cb_ = (uint32_t)0 - (uint32_t)(seg * 16); \
+      if (!CSR && (int64_t)cb_ + seg * 16 >= stride) cb_ = (uint32_t)0 - (uint32_t)(seg * 16); \
       _Pragma("unroll") for (int j_ = 0; j_ < NL; ++j_)                          \
-        if (MODE != ST_FIRST || !((skip_rows >> (RPI * j_ + rsub)) & 1ull))       \
-          v[j_] = *(const uint4*)(wbase + (roff[j_] + cb_));                     \
+        if (MODE != ST_FIRST || !((skip_rows >> (RPI * j_ + rsub)) & 1ull)) {     \
+          if (CSR) {                                                             \
+            const uint4 rs_ = *(const uint4*)(tile + (RPI * j_ + rsub) * kRowPitch + CH); \
+            uint32_t fo_ = cb_ + seg * 16;                                       \
+            if (fo_ >= rs_.z) fo_ = 0;  /* past the frame: re-read its first block */ \
+            v[j_] = *(const uint4*)((const uint8_t*)(((uint64_t)rs_.y << 32) | rs_.x) + fo_); \
+          } else {                                                               \
+            v[j_] = *(const uint4*)(wbase + (roff[j_] + cb_));                   \
+          }                                                                      \
+        }                                                                        \
     } while (0)
     uint64_t skip_rows = 0;  // ST_FIRST: rows (= lanes) whose walk has ended
 
@@ -270,27 +307,31 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
     int wrec = 0;  // records written by this wavefront so far (wave uniform)
     bool done = !live;          // ST_SEARCH / ST_FIRST: this lane has its answer
     int res_s = -1, res_e = (MODE == ST_FIRST && live && p.fa_start_acc) ? 0 : -1;
-    EvRec* wave_recs = (MODE == ST_RECORDS) ? recs + base_text * rec_row : nullptr;
+    EvRec* wave_recs = (MODE == ST_RECORDS)
+        ? recs + (CSR ? rec_region_start(offsets[base_text], w) : base_text * rec_row) : nullptr;
 
     if (MODE == ST_FIRST) {
       // Probe: most anchored walks end within a few bytes.  Every lane reads the first 16 bytes
       // of its own text (one load instruction per wavefront instead of a full 128-byte chunk per
       // text); when that settles all 64 texts the wavefront is done.
       uint4 pv = make_uint4(0, 0, 0, 0);
-      if (live && my_len > 0) pv = *(const uint4*)(data + my_text * stride);
+      if (live && my_len > 0) {
+        if (CSR) pv = *(const uint4*)(((uintptr_t)(data + offsets[my_text])) & ~(uintptr_t)15);
+        else pv = *(const uint4*)(data + my_text * stride);
+      }
       const uint32_t pw[4] = {pv.x, pv.y, pv.z, pv.w};
       uint32_t pq = 0, pF = 0;
 #pragma unroll
       for (int k = 0; k < 16; ++k) {
         uint32_t e = tr_lds[pq + cls_lds[(pw[k >> 2] >> ((k & 3) * 8)) & 0xFFu]];
-        if (k >= my_len) e = pq << 2;
+        if (k < mis || k >= flen) e = pq << 2;
         pq = e >> 2;
         pF = __builtin_amdgcn_alignbit(e, pF, 2);
       }
       const uint32_t pem = pF & 0xAAAAAAAAu;
-      if (__all(!live || pq == fa_dead || my_len <= 16)) {
+      if (__all(!live || pq == fa_dead || flen <= 16)) {
         if (live) {
-          const int e_ = pem ? ((31 - __builtin_clz(pem)) >> 1) + 1 : (p.fa_start_acc ? 0 : -1);
+          const int e_ = pem ? ((31 - __builtin_clz(pem)) >> 1) + 1 - mis : (p.fa_start_acc ? 0 : -1);
           out_s[my_text] = e_ >= 0 ? 0 : -1;
           out_e[my_text] = e_;
         }
@@ -311,14 +352,15 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       if (MODE == ST_SEARCH) { if (__all(done)) break; }
       if (MODE == ST_FIRST) {
-        skip_rows = __ballot(done || cbase + kChunk >= my_len);
+        skip_rows = __ballot(done || cbase + kChunk >= flen);
         if (__all(done)) break;
       }
       if (!(MRX_ABLATE & 2))
       if (cbase + kChunk < max_len) MRX_LOAD_CHUNK(cbase + kChunk);  // prefetch next chunk
 
-      const int lim = my_len - cbase;  // bytes of mine in this chunk (may be <= 0 or > 64)
-      const bool full = __all(lim >= kChunk);
+      const int lim = flen - cbase;    // frame bytes [lo, lim) of this chunk are text (lim may be <= 0 or > CH)
+      const int lo = mis - cbase;      // > 0 only in a misaligned text's first chunk (CSR)
+      const bool full = __all(lim >= kChunk && lo <= 0);
 #pragma unroll
       for (int g = 0; g < kChunk / 16; ++g) {
         const uint4 wv = *(const uint4*)(tile + lane * kRowPitch + g * 16);
@@ -332,7 +374,7 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
 #pragma unroll
           for (int k = 0; k < 16; ++k) {
             uint32_t e = tr_lds[q4 + cc[k]];                    // q4 = row offset of the state
-            if (!full) { if (g * 16 + k >= lim) e = q4 << 2; }   // past the end: no-op
+            if (!full) { if (g * 16 + k >= lim || g * 16 + k < lo) e = q4 << 2; }   // outside the text: no-op
             q4 = e >> 2;
             F = __builtin_amdgcn_alignbit(e, F, 2);
           }
@@ -354,14 +396,14 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
           for (int k = 0; k < 16; ++k) {
             const uint32_t b = (words[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
             uint32_t e = col_lds[b] >> q4;
-            if (g * 16 + k >= lim) e = q4;  // keep the state, no event bits
+            if (g * 16 + k >= lim || g * 16 + k < lo) e = q4;  // keep the state, no event bits
             q4 = e & 0xCu;
             F = __builtin_amdgcn_alignbit(e, F, 2);
           }
         }
         const uint32_t em = F & 0xAAAAAAAAu;
         const uint32_t ns = F & 0x55555555u;
-        const int gbase = cbase + g * 16;
+        const int gbase = cbase + g * 16 - mis;  // text position of the group's first byte
         if (MRX_ABLATE & 16) { cnt += (F == 0x12345u); continue; }
         if (MODE == ST_RECORDS) {
           const uint64_t has = __ballot(em != 0);
@@ -445,6 +487,7 @@ constexpr int kDecodeBatch = 8;    // independent 16-byte record loads in flight
 
 __global__ __launch_bounds__(kBlock) void k_decode(int64_t n, const int32_t* __restrict__ wave_nrecs,
                                                    const EvRec* __restrict__ recs, int64_t rec_row,
+                                                   const int64_t* __restrict__ offsets,
                                                    const int64_t* __restrict__ prefix,
                                                    int32_t* __restrict__ spans, int64_t span_cap) {
   __shared__ int2 tile_all[kBlock / 64][kDecodeTile];
@@ -461,7 +504,7 @@ __global__ __launch_bounds__(kBlock) void k_decode(int64_t n, const int32_t* __r
     const int64_t last1 = first + 64 < n ? first + 64 : n;
     const int total_spans = (int)(prefix[last1] - pre0);
     const int total_recs = wave_nrecs[w];
-    const EvRec* wave_recs = recs + first * rec_row;
+    const EvRec* wave_recs = recs + (offsets ? rec_region_start(offsets[first], w) : first * rec_row);
     if (total_spans > kDecodeDirect) {
       // dense matches: the tile passes would re-read the stream total_spans / kDecodeTile
       // times.  One pass with direct 8-byte stores instead; every text's spans are written
@@ -677,6 +720,9 @@ thread_local bool g_timing = false;
 thread_local double g_scan_ms = 0.0;
 thread_local int64_t g_scan_launches = 0;
 thread_local const char* g_last_kernel = "";
+// mrx_debug_force_generic(): route every call to the generic lane-per-text kernels (tests compare
+// the two implementations; never set in production)
+int g_force_generic = 0;
 
 int fail(int code, const std::string& msg) {
   g_err = msg;
@@ -787,6 +833,37 @@ int run_match(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d_s, i
   return MRX_OK;
 }
 
+// can this batch layout go through the streaming kernel?
+bool stream_layout_ok(const Layout& lay, int64_t n) {
+  if (n <= 0) return false;
+  if (lay.offsets) return true;   // CSR: any alignment, any lengths
+  return (lay.stride % 16 == 0) && (((uintptr_t)lay.data) % 16 == 0) && lay.stride * 64 < (int64_t(1) << 31);
+}
+
+template <int MODE>
+void launch_stream(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d_counts, int32_t* d_nrecs,
+                   EvRec* d_recs, int64_t rec_row, int32_t* d_s, int32_t* d_e, hipStream_t s) {
+  const DevPlan& p = h->hp.dev;
+  const int64_t nw = (n + 63) / 64;
+  int64_t g = (nw + kStreamWaves - 1) / kStreamWaves;
+  if (g > 256 * 8) g = 256 * 8;
+  const dim3 grid((unsigned)g), block(64 * kStreamWaves);
+  const bool table = MODE == ST_FIRST || p.st_kind == 2;
+  const size_t lds = !table ? 0 : (size_t)(MODE == ST_FIRST ? p.fa_bytes : p.stg_bytes);
+#define MRX_LAUNCH(AUTO, CSR)                                                                     \
+  hipLaunchKernelGGL((k_stream_findall<MODE, MRX_STREAM_CHUNK, AUTO, CSR>), grid, block, lds, s, p, \
+                     h->d_blob, lay.data, lay.stride, lay.lens, lay.len, lay.offsets, n, d_counts, \
+                     d_nrecs, d_recs, rec_row, d_s, d_e)
+  if (lay.offsets) {
+    if (table) MRX_LAUNCH(2, 1);
+    else if (MODE != ST_FIRST) MRX_LAUNCH(1, 1);
+  } else {
+    if (table) MRX_LAUNCH(2, 0);
+    else if (MODE != ST_FIRST) MRX_LAUNCH(1, 0);
+  }
+#undef MRX_LAUNCH
+}
+
 int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_prefix,
                 int32_t* d_spans, int64_t span_cap, int64_t* total, void* stream) {
   if (!h) return fail(MRX_E_ARGUMENT, "null handle");
@@ -800,32 +877,31 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
   HIP_TRY(hipMallocAsync((void**)&d_counts, sizeof(int32_t) * (n > 0 ? n : 1), s));
   HIP_TRY(hipMallocAsync((void**)&d_total, sizeof(int64_t), s));
   const DevPlan& p = h->hp.dev;
-  const bool stream_ok = (p.flags & PF_STREAMABLE) && !lay.offsets && (lay.stride % 16 == 0) &&
-                         (((uintptr_t)lay.data) % 16 == 0) && n > 0 &&
-                         lay.stride * 64 < (int64_t(1) << 31);
+  const bool stream_ok = !g_force_generic && (p.flags & PF_STREAMABLE) && stream_layout_ok(lay, n);
   EvRec* d_recs = nullptr;
   int32_t* d_nrecs = nullptr;
   int64_t rec_row = 0;
   if (n > 0) {
     if (stream_ok) {
-      // one 16-byte record per 16-byte group at most (+1 for the match that ends at len)
-      rec_row = rec_row_len(lay.lens ? lay.stride : lay.len);
-      HIP_TRY(hipMallocAsync((void**)&d_recs, sizeof(EvRec) * (size_t)rec_row * n, s));
-      HIP_TRY(hipMallocAsync((void**)&d_nrecs, sizeof(int32_t) * ((n + 63) / 64), s));
       const int64_t nw = (n + 63) / 64;
-      int64_t g = (nw + kStreamWaves - 1) / kStreamWaves;
-      if (g > 256 * 8) g = 256 * 8;
+      size_t nrec;
+      if (lay.offsets) {
+        // the record buffer is sized by the batch's byte count, which only the device knows:
+        // one 8-byte read-back (the only host synchronisation the CSR path adds)
+        int64_t total_bytes = 0;
+        HIP_TRY(hipMemcpyAsync(&total_bytes, lay.offsets + n, sizeof total_bytes, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (total_bytes < 0) return fail(MRX_E_ARGUMENT, "offsets[n] is negative");
+        nrec = (size_t)(total_bytes / 16 + 256 * nw + 256);
+      } else {
+        // one 16-byte record per 16-byte group at most (+1 for the match that ends at len)
+        rec_row = rec_row_len(lay.lens ? lay.stride : lay.len);
+        nrec = (size_t)rec_row * n;
+      }
+      HIP_TRY(hipMallocAsync((void**)&d_recs, sizeof(EvRec) * nrec, s));
+      HIP_TRY(hipMallocAsync((void**)&d_nrecs, sizeof(int32_t) * nw, s));
       ScanTimer tm(s);
-      if (p.st_kind == 1)
-        hipLaunchKernelGGL((k_stream_findall<ST_RECORDS, MRX_STREAM_CHUNK, 1>), dim3((unsigned)g),
-                           dim3(64 * kStreamWaves), 0, s, p, h->d_blob, lay.data, lay.stride, lay.lens,
-                           lay.len, n, d_counts, d_nrecs, d_recs, rec_row, (int32_t*)nullptr,
-                           (int32_t*)nullptr);
-      else
-        hipLaunchKernelGGL((k_stream_findall<ST_RECORDS, MRX_STREAM_CHUNK, 2>), dim3((unsigned)g),
-                           dim3(64 * kStreamWaves), (size_t)p.stg_bytes, s, p, h->d_blob, lay.data,
-                           lay.stride, lay.lens, lay.len, n, d_counts, d_nrecs, d_recs, rec_row,
-                           (int32_t*)nullptr, (int32_t*)nullptr);
+      launch_stream<ST_RECORDS>(h, lay, n, d_counts, d_nrecs, d_recs, rec_row, nullptr, nullptr, s);
       g_last_kernel = "k_stream_findall";
       HIP_TRY(hipGetLastError());
       tm.stop();
@@ -846,7 +922,7 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
   if (n > 0 && span_cap > 0) {
     if (stream_ok) {
       hipLaunchKernelGGL(k_decode, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, n, d_nrecs, d_recs,
-                         rec_row, d_prefix, d_spans, span_cap);
+                         rec_row, lay.offsets, d_prefix, d_spans, span_cap);
     } else {
       hipLaunchKernelGGL(k_findall<FA_EMIT>, dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s, p,
                          h->d_blob, lay, n, (int32_t*)nullptr, d_prefix, d_spans, span_cap);
@@ -945,69 +1021,63 @@ size_t mrx_describe(const mrx_handle* h, char* buf, size_t cap) {
   return s.size();
 }
 
-int mrx_match_first_dev(const mrx_handle* h, const uint8_t* d, const int64_t* off, int64_t n,
-                        int32_t* s, int32_t* e, void* st) {
-  return run_match<OP_MATCH_FIRST>(h, Layout{d, off, 0, nullptr, 0}, n, s, e, nullptr, st);
-}
-int mrx_search_dev(const mrx_handle* h, const uint8_t* d, const int64_t* off, int64_t n, int32_t* s,
-                   int32_t* e, void* st) {
-  return run_match<OP_SEARCH>(h, Layout{d, off, 0, nullptr, 0}, n, s, e, nullptr, st);
-}
-int mrx_search_strided_dev(const mrx_handle* h, const uint8_t* d, int64_t stride, const int32_t* lens,
-                           int32_t len, int64_t n, int32_t* ds, int32_t* de, void* st) {
+// regex.search / regex.match_first for any layout: the streaming kernel when the plan and the
+// layout allow it, the generic lane-per-text kernel otherwise
+static int run_search_any(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* ds, int32_t* de,
+                          void* st) {
   if (!h) return fail(MRX_E_ARGUMENT, "null handle");
-  if (stride <= 0) return fail(MRX_E_ARGUMENT, "stride must be positive");
-  if (!lens && (len < 0 || len > stride)) return fail(MRX_E_ARGUMENT, "len must be in [0, stride]");
-  const Layout lay{d, nullptr, stride, lens, len};
   const DevPlan& p = h->hp.dev;
-  const bool stream_ok = (p.flags & PF_STREAMABLE) && (stride % 16 == 0) && (((uintptr_t)d) % 16 == 0) &&
-                         n > 0 && stride * 64 < (int64_t(1) << 31);
-  if (!stream_ok) return run_match<OP_SEARCH>(h, lay, n, ds, de, nullptr, st);
+  if (g_force_generic || !(p.flags & PF_STREAMABLE) || !stream_layout_ok(lay, n))
+    return run_match<OP_SEARCH>(h, lay, n, ds, de, nullptr, st);
   if (int rc = check_search_supported(h)) return rc;
   if (int rc = ensure_device(h)) return rc;
   hipStream_t s = (hipStream_t)st;
-  const int64_t nw = (n + 63) / 64;
-  int64_t g = (nw + kStreamWaves - 1) / kStreamWaves;
-  if (g > 256 * 8) g = 256 * 8;
   ScanTimer tm(s);
-  if (p.st_kind == 1)
-    hipLaunchKernelGGL((k_stream_findall<ST_SEARCH, MRX_STREAM_CHUNK, 1>), dim3((unsigned)g),
-                       dim3(64 * kStreamWaves), 0, s, p, h->d_blob, d, stride, lens, len, n,
-                       (int32_t*)nullptr, (int32_t*)nullptr, (EvRec*)nullptr, (int64_t)0, ds, de);
-  else
-    hipLaunchKernelGGL((k_stream_findall<ST_SEARCH, MRX_STREAM_CHUNK, 2>), dim3((unsigned)g),
-                       dim3(64 * kStreamWaves), (size_t)p.stg_bytes, s, p, h->d_blob, d, stride, lens,
-                       len, n, (int32_t*)nullptr, (int32_t*)nullptr, (EvRec*)nullptr, (int64_t)0, ds, de);
+  launch_stream<ST_SEARCH>(h, lay, n, nullptr, nullptr, nullptr, 0, ds, de, s);
   g_last_kernel = "k_stream_search";
   HIP_TRY(hipGetLastError());
   tm.stop();
   return MRX_OK;
 }
-int mrx_match_first_strided_dev(const mrx_handle* h, const uint8_t* d, int64_t stride,
-                                const int32_t* lens, int32_t len, int64_t n, int32_t* ds,
-                                int32_t* de, void* st) {
+static int run_first_any(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* ds, int32_t* de,
+                         void* st) {
   if (!h) return fail(MRX_E_ARGUMENT, "null handle");
-  if (stride <= 0) return fail(MRX_E_ARGUMENT, "stride must be positive");
-  if (!lens && (len < 0 || len > stride)) return fail(MRX_E_ARGUMENT, "len must be in [0, stride]");
-  const Layout lay{d, nullptr, stride, lens, len};
   const DevPlan& p = h->hp.dev;
-  const bool stream_ok = p.fa_bytes > 0 && (stride % 16 == 0) && (((uintptr_t)d) % 16 == 0) && n > 0 &&
-                         stride * 64 < (int64_t(1) << 31);
-  if (!stream_ok) return run_match<OP_MATCH_FIRST>(h, lay, n, ds, de, nullptr, st);
+  if (g_force_generic || p.fa_bytes <= 0 || !stream_layout_ok(lay, n))
+    return run_match<OP_MATCH_FIRST>(h, lay, n, ds, de, nullptr, st);
   if (!h->hp.why_no_match_first.empty()) return fail(MRX_E_UNSUPPORTED, h->hp.why_no_match_first);
   if (int rc = ensure_device(h)) return rc;
   hipStream_t s = (hipStream_t)st;
-  const int64_t nw = (n + 63) / 64;
-  int64_t g = (nw + kStreamWaves - 1) / kStreamWaves;
-  if (g > 256 * 8) g = 256 * 8;
   ScanTimer tm(s);
-  hipLaunchKernelGGL((k_stream_findall<ST_FIRST, MRX_STREAM_CHUNK, 2>), dim3((unsigned)g),
-                     dim3(64 * kStreamWaves), (size_t)p.fa_bytes, s, p, h->d_blob, d, stride, lens, len, n,
-                     (int32_t*)nullptr, (int32_t*)nullptr, (EvRec*)nullptr, (int64_t)0, ds, de);
+  launch_stream<ST_FIRST>(h, lay, n, nullptr, nullptr, nullptr, 0, ds, de, s);
   g_last_kernel = "k_stream_first";
   HIP_TRY(hipGetLastError());
   tm.stop();
   return MRX_OK;
+}
+
+int mrx_match_first_dev(const mrx_handle* h, const uint8_t* d, const int64_t* off, int64_t n,
+                        int32_t* s, int32_t* e, void* st) {
+  if (!off) return fail(MRX_E_ARGUMENT, "null offsets");
+  return run_first_any(h, Layout{d, off, 0, nullptr, 0}, n, s, e, st);
+}
+int mrx_search_dev(const mrx_handle* h, const uint8_t* d, const int64_t* off, int64_t n, int32_t* s,
+                   int32_t* e, void* st) {
+  if (!off) return fail(MRX_E_ARGUMENT, "null offsets");
+  return run_search_any(h, Layout{d, off, 0, nullptr, 0}, n, s, e, st);
+}
+int mrx_search_strided_dev(const mrx_handle* h, const uint8_t* d, int64_t stride, const int32_t* lens,
+                           int32_t len, int64_t n, int32_t* ds, int32_t* de, void* st) {
+  if (stride <= 0) return fail(MRX_E_ARGUMENT, "stride must be positive");
+  if (!lens && (len < 0 || len > stride)) return fail(MRX_E_ARGUMENT, "len must be in [0, stride]");
+  return run_search_any(h, Layout{d, nullptr, stride, lens, len}, n, ds, de, st);
+}
+int mrx_match_first_strided_dev(const mrx_handle* h, const uint8_t* d, int64_t stride,
+                                const int32_t* lens, int32_t len, int64_t n, int32_t* ds,
+                                int32_t* de, void* st) {
+  if (stride <= 0) return fail(MRX_E_ARGUMENT, "stride must be positive");
+  if (!lens && (len < 0 || len > stride)) return fail(MRX_E_ARGUMENT, "len must be in [0, stride]");
+  return run_first_any(h, Layout{d, nullptr, stride, lens, len}, n, ds, de, st);
 }
 int mrx_is_match_dev(const mrx_handle* h, const uint8_t* d, const int64_t* off, int64_t n,
                      uint8_t* f, void* st) {
@@ -1191,5 +1261,6 @@ double mrx_timing_scan_ms(int64_t* launches) {
   return g_scan_launches ? g_scan_ms / (double)g_scan_launches : 0.0;
 }
 const char* mrx_last_kernel_name(void) { return g_last_kernel; }
+void mrx_debug_force_generic(int on) { g_force_generic = on ? 1 : 0; }
 
 }  // extern "C"

@@ -138,3 +138,21 @@ def make_alt_batch(n: int, L: int = 4096, seed: int = 20260105, device="cuda") -
         idx = torch.bucketize(r, cdf[:-1], right=True)
         out[a:b] = sym[idx]
     return out
+
+
+def to_ragged(batch: torch.Tensor, min_len: int = 0, seed: int = 20260110):
+    """CSR form of a fixed-pitch batch: row i is cut to a length drawn uniformly from
+    [min_len, L] and the rows are packed back to back.  Returns (data u8[total], offsets i64[n+1])."""
+    n, L = batch.shape
+    g = _gen(seed, batch.device)
+    lens = torch.randint(min_len, L + 1, (n,), generator=g, device=batch.device)
+    offsets = torch.zeros(n + 1, dtype=torch.int64, device=batch.device)
+    offsets[1:] = torch.cumsum(lens, 0)
+    data = torch.empty(int(offsets[-1].item()), dtype=torch.uint8, device=batch.device)
+    col = torch.arange(L, device=batch.device)
+    step = max(1, (256 << 20) // max(L, 1))
+    for a in range(0, n, step):
+        b = min(n, a + step)
+        keep = col[None, :] < lens[a:b, None]
+        data[int(offsets[a].item()):int(offsets[b].item())] = batch[a:b][keep]
+    return data, offsets

@@ -157,6 +157,21 @@ ALPHABETS = {
 }
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def generic_kernels():
+    """Route calls to the generic lane-per-text kernels (the second implementation the
+    streaming kernel is compared with)."""
+    lib = M.load_library()
+    lib.mrx_debug_force_generic(1)
+    try:
+        yield
+    finally:
+        lib.mrx_debug_force_generic(0)
+
+
 def _random_texts(rng, n, max_len, alphabet):
     al = np.frombuffer(alphabet, dtype=np.uint8)
     lens = rng.integers(0, max_len + 1, size=n)
@@ -284,7 +299,11 @@ def test_streaming_kernel_equals_generic_and_oracle(pat, n, pitch, var):
     assert M.load_library().mrx_last_kernel_name() in (b"k_stream_findall",)
     prefix, spans = prefix.cpu().numpy(), spans.cpu().numpy()
     texts = [arr[i, : (lens[i] if var else pitch)].tobytes() for i in range(n)]
-    generic = rx.findall_lists(texts)          # CSR batch -> generic kernel
+    with generic_kernels():
+        generic = rx.findall_lists(texts)
+        assert M.load_library().mrx_last_kernel_name() == b"k_findall_count"
+    assert rx.findall_lists(texts) == generic   # CSR batch -> streaming kernel, ragged frame
+    assert M.load_library().mrx_last_kernel_name() == b"k_stream_findall"
     assert int(prefix[-1]) == total == sum(len(x) for x in generic)
     # search on the same strided batch runs the streaming kernel in first-match mode
     ss, se = rx.match_next(batch)
@@ -464,9 +483,57 @@ def test_streaming_match_first_equals_generic_and_oracle(pat, n, pitch, var):
     assert M.load_library().mrx_last_kernel_name() == b"k_stream_first"
     fs, fe = fs.cpu().numpy(), fe.cpu().numpy()
     texts = [arr[i, : (lens[i] if var else pitch)].tobytes() for i in range(n)]
-    gs, ge = rx.match_first(texts)   # CSR batch -> generic kernel
-    assert M.load_library().mrx_last_kernel_name() == b"k_match"
+    with generic_kernels():
+        gs, ge = rx.match_first(texts)
+        assert M.load_library().mrx_last_kernel_name() == b"k_match"
     assert np.array_equal(fs, gs) and np.array_equal(fe, ge), pat
+    cs, ce = rx.match_first(texts)   # CSR batch -> streaming kernel, ragged frame
+    assert M.load_library().mrx_last_kernel_name() == b"k_stream_first"
+    assert np.array_equal(cs, gs) and np.array_equal(ce, ge), pat
     for i in range(0, n, 5):
         w = O.match_first(pat, texts[i])
         assert (int(fs[i]), int(fe[i])) == (w if w else (-1, -1)), (pat, i)
+
+
+@pytest.mark.parametrize("pat", [b"[a-z]+\\d+", b"\\d+", b"hello", b"(\\d{3})(\\d{3})(\\d{4})", b"(x|y|foo|bar)+",
+                                 b"(a|b)x", b"[a-z]+[0-9]+x"])
+@pytest.mark.parametrize("shift", [0, 1, 7, 15])
+def test_streaming_csr_ragged_unaligned(pat, shift):
+    """CSR batches on the streaming kernel: arbitrary text lengths (0 .. 3000 bytes, several
+    chunks), arbitrary alignment of every text and of the data pointer itself; findall, search
+    and match_first against the generic kernels on every text and the oracle on a sample."""
+    _need_gpu()
+    rng = np.random.default_rng(zlib.crc32(pat) + shift)
+    al = b"abcdxyz0123456789 -bcab" + bytes(c for c in pat if chr(c).isalnum()) * 2
+    lens = np.concatenate([rng.integers(0, 40, size=150), rng.integers(0, 400, size=100),
+                           rng.integers(1000, 3000, size=12), [0, 0, 1, 15, 16, 17, 127, 128, 129, 0]])
+    rng.shuffle(lens)
+    texts = [bytes(rng.choice(np.frombuffer(al, dtype=np.uint8), size=int(k)).tolist()) for k in lens]
+    for i in range(0, len(texts), 9):      # long letter runs that cross chunk boundaries
+        k = len(texts[i])
+        texts[i] = (b"q" * (k // 2) + b"7" * (k // 6) + texts[i])[:k]
+    data, offsets = M.api.pack_texts(texts)
+    buf = torch.zeros(data.size + 64, dtype=torch.uint8, device="cuda")
+    buf[shift:shift + data.size] = torch.from_numpy(data).cuda()
+    batch = M.DeviceBatch(buf[shift:shift + data.size], torch.from_numpy(offsets).cuda())
+    assert batch.data.data_ptr() % 16 == shift
+    rx = M.compile_regex(pat)
+    lib = M.load_library()
+    prefix, spans, total = rx._dev_findall(batch)
+    assert lib.mrx_last_kernel_name() == b"k_stream_findall"
+    ss, se = rx.match_next(batch)
+    assert lib.mrx_last_kernel_name() == b"k_stream_search"
+    fs, fe = rx.match_first(batch)
+    assert lib.mrx_last_kernel_name() == b"k_stream_first"
+    with generic_kernels():
+        gp, gsp, gtotal = rx._dev_findall(batch)
+        assert lib.mrx_last_kernel_name() == b"k_findall_count"
+        gss, gse = rx.match_next(batch)
+        gfs, gfe = rx.match_first(batch)
+    assert total == gtotal and torch.equal(prefix, gp) and torch.equal(spans[:total], gsp[:total])
+    assert torch.equal(ss, gss) and torch.equal(se, gse)
+    assert torch.equal(fs, gfs) and torch.equal(fe, gfe)
+    pre, sp = prefix.cpu().numpy(), spans.cpu().numpy()
+    for i in range(0, len(texts), 6):
+        have = [tuple(int(x) for x in r) for r in sp[pre[i]:pre[i + 1]]]
+        assert have == O.findall(pat, texts[i]), (pat, i)

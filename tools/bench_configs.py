@@ -71,5 +71,35 @@ def main():
         torch.cuda.empty_cache()
 
 
+def ragged():
+    """Config 2 as a ragged CSR batch (the C ABI's primary layout): rows cut to U[64, 1024] bytes and
+    packed back to back, so almost every text starts unaligned."""
+    lib = M.load_library()
+    d = W.make_c2_batch(1 << 20, 1024)
+    data, offsets = W.to_ragged(d, 64)
+    del d
+    batch = M.DeviceBatch(data, offsets)
+    n, nbytes = batch.n, int(data.numel())
+    for pat in (b"[a-z]+\\d+", b"(\\d{3})(\\d{3})(\\d{4})"):
+        rx = M.compile_regex(pat)
+        prefix = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+        spans = torch.empty((n * 32, 2), dtype=torch.int32, device="cuda")
+        row = {"config": "c2 texts, CSR ragged", "pattern": pat.decode(), "texts": n, "bytes": nbytes}
+        for name, force in (("stream", 0), ("generic", 1)):
+            lib.mrx_debug_force_generic(force)
+            t_find = timeit(lambda: rx._dev_findall(batch, out=(prefix, spans)))
+            row["findall_kernel_" + name] = lib.mrx_last_kernel_name().decode()
+            t_search = timeit(lambda: rx.match_next(batch))
+            t_first = timeit(lambda: rx.match_first(batch))
+            row.update({"findall_GBps_" + name: round(nbytes / t_find / 1e9, 1),
+                        "search_GBps_" + name: round(nbytes / t_search / 1e9, 1),
+                        "match_first_ms_" + name: round(t_first * 1e3, 3)})
+        lib.mrx_debug_force_generic(0)
+        print(json.dumps(row), flush=True)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "ragged":
+        ragged()
+        sys.exit(0)
     main()
