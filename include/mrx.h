@@ -136,6 +136,9 @@ int mrx_findall_strided_dev(const mrx_handle* h, const uint8_t* d_data,
 int mrx_count_dev(const mrx_handle* h, const uint8_t* d_data,
                   const int64_t* d_offsets, int64_t n, int32_t* d_counts,
                   void* stream);
+int mrx_count_strided_dev(const mrx_handle* h, const uint8_t* d_data, int64_t stride,
+                          const int32_t* d_lens, int32_t len, int64_t n, int32_t* d_counts,
+                          void* stream);
 /* search + capture groups, in the order NFAEngine._match_group appends them
  * (src/regex/nfa.mojo:1057-1103): groups 1..g, then group 0 (whole match).
  * d_spans[(i*(g+1) + k)*2 + {0,1}]; -1 when text i has no match.

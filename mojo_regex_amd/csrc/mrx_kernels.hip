@@ -1099,8 +1099,7 @@ int mrx_findall_strided_dev(const mrx_handle* h, const uint8_t* d, int64_t strid
   return run_findall(h, Layout{d, nullptr, stride, lens, len}, n, prefix, spans, cap, total, st);
 }
 
-int mrx_count_dev(const mrx_handle* h, const uint8_t* d, const int64_t* off, int64_t n,
-                  int32_t* counts, void* st) {
+static int run_count_any(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* counts, void* st) {
   if (!h) return fail(MRX_E_ARGUMENT, "null handle");
   if (int rc = check_search_supported(h)) return rc;
   if (int rc = check_lds(h)) return rc;
@@ -1108,13 +1107,29 @@ int mrx_count_dev(const mrx_handle* h, const uint8_t* d, const int64_t* off, int
   if (n <= 0) return MRX_OK;
   hipStream_t s = (hipStream_t)st;
   ScanTimer tm(s);
-  hipLaunchKernelGGL(k_findall<FA_COUNT>, dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s,
-                     h->hp.dev, h->d_blob, Layout{d, off, 0, nullptr, 0}, n, counts,
-                     (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0);
-  g_last_kernel = "k_findall_count";
+  if (!g_force_generic && (h->hp.dev.flags & PF_STREAMABLE) && stream_layout_ok(lay, n)) {
+    launch_stream<ST_COUNT>(h, lay, n, counts, nullptr, nullptr, 0, nullptr, nullptr, s);
+    g_last_kernel = "k_stream_count";
+  } else {
+    hipLaunchKernelGGL(k_findall<FA_COUNT>, dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s,
+                       h->hp.dev, h->d_blob, lay, n, counts, (const int64_t*)nullptr, (int32_t*)nullptr,
+                       (int64_t)0);
+    g_last_kernel = "k_findall_count";
+  }
   HIP_TRY(hipGetLastError());
   tm.stop();
   return MRX_OK;
+}
+int mrx_count_dev(const mrx_handle* h, const uint8_t* d, const int64_t* off, int64_t n,
+                  int32_t* counts, void* st) {
+  if (!off) return fail(MRX_E_ARGUMENT, "null offsets");
+  return run_count_any(h, Layout{d, off, 0, nullptr, 0}, n, counts, st);
+}
+int mrx_count_strided_dev(const mrx_handle* h, const uint8_t* d, int64_t stride, const int32_t* lens,
+                          int32_t len, int64_t n, int32_t* counts, void* st) {
+  if (stride <= 0) return fail(MRX_E_ARGUMENT, "stride must be positive");
+  if (!lens && (len < 0 || len > stride)) return fail(MRX_E_ARGUMENT, "len must be in [0, stride]");
+  return run_count_any(h, Layout{d, nullptr, stride, lens, len}, n, counts, st);
 }
 
 int mrx_sub_dev(const mrx_handle* h, const char* repl, size_t repl_len, int64_t count,

@@ -390,8 +390,13 @@ def test_full_size_c2_properties():
     nxt = flat[(base + sp[:, 1]).clamp(max=flat.numel() - 1)]
     assert not bool((has_next & (nxt >= 48) & (nxt <= 57)).any())
     # the generic kernel (count only) agrees text by text
-    counts2 = rx.count(batch)
+    with generic_kernels():
+        counts2 = rx.count(batch)
+        assert M.load_library().mrx_last_kernel_name() == b"k_findall_count"
     assert bool((counts2.to(torch.int64) == counts).all())
+    counts3 = rx.count(batch)   # count-only mode of the streaming kernel (no records, no decode)
+    assert M.load_library().mrx_last_kernel_name() == b"k_stream_count"
+    assert bool((counts3.to(torch.int64) == counts).all())
     # and the oracle agrees on a sample of every text kind
     host = d[:: n // 256].cpu().numpy()
     pre = prefix.cpu().numpy()

@@ -60,10 +60,12 @@ def main():
         assert total <= spans.shape[0]
         t_search = timeit(lambda: rx.match_next(batch))
         t_first = timeit(lambda: rx.match_first(batch))
+        t_count = timeit(lambda: rx.count(batch))
         row = {"config": name, "texts": n, "bytes_per_text": L, "matches": total,
                "findall_kernel": kernel,
                "findall_GBps": round(nbytes / t_find / 1e9, 1), "findall_ms": round(t_find * 1e3, 3),
                "search_GBps": round(nbytes / t_search / 1e9, 1),
+               "count_GBps": round(nbytes / t_count / 1e9, 1),
                "match_first_ms": round(t_first * 1e3, 3)}
         out.append(row)
         print(json.dumps(row), flush=True)
