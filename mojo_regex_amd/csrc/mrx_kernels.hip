@@ -225,6 +225,10 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
   if (AUTO == 1) {
     const uint16_t* src = (const uint16_t*)(blob + p.off_stcol);
     for (int i = threadIdx.x; i < 256; i += blockDim.x) col_lds[i] = src[i];
+  } else if (AUTO == 3) {
+    const uint32_t* src = (const uint32_t*)(blob + p.off_stcol);
+    uint32_t* dst = (uint32_t*)stg_lds;
+    for (int i = threadIdx.x; i < 512; i += blockDim.x) dst[i] = src[i];
   } else {
     const uint32_t* src = (const uint32_t*)(blob + (MODE == ST_FIRST ? p.off_fa_cls : p.off_stg_cls));
     uint32_t* dst = (uint32_t*)stg_lds;
@@ -232,6 +236,7 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
     for (int i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
   }
   __syncthreads();
+  const uint64_t* col64_lds = (const uint64_t*)stg_lds;   // AUTO == 3
   const uint8_t* cls_lds = stg_lds;
   const uint16_t* tr_lds = (const uint16_t*)(stg_lds + (MODE == ST_FIRST ? p.off_fa_trans - p.off_fa_cls
                                                                         : p.off_stg_trans - p.off_stg_cls));
@@ -378,6 +383,22 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
             q4 = e >> 2;
             F = __builtin_amdgcn_alignbit(e, F, 2);
           }
+        } else if (AUTO == 3) {
+          // wide byte columns: q4 is the bit offset of the state's 8-bit field
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            uint64_t cw[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+              cw[k] = col64_lds[(words[(8 * h + k) >> 2] >> ((k & 3) * 8)) & 0xFFu];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              uint32_t e = (uint32_t)(cw[k] >> q4);
+              if (!full) { if (g * 16 + 8 * h + k >= lim || g * 16 + 8 * h + k < lo) e = q4; }
+              q4 = e & 0x38u;
+              F = __builtin_amdgcn_alignbit(e, F, 2);
+            }
+          }
         } else if (full) {
           uint32_t cv[16];
 #pragma unroll
@@ -441,7 +462,8 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
     // end of text: a walk that is in an accepting state ends at len
     {
       const bool tail = MODE != ST_FIRST && live &&
-                        (AUTO == 2 ? acc_lds[q4 >> p.st_cshift] != 0 : ((accmask >> (q4 >> 2)) & 1u) != 0);
+                        (AUTO == 2 ? acc_lds[q4 >> p.st_cshift] != 0
+                                   : ((accmask >> (q4 >> (AUTO == 3 ? 3 : 2))) & 1u) != 0);
       if (MODE == ST_RECORDS) {
         const uint64_t has = __ballot(tail);
         if (tail) {
@@ -849,16 +871,19 @@ void launch_stream(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d
   if (g > 256 * 8) g = 256 * 8;
   const dim3 grid((unsigned)g), block(64 * kStreamWaves);
   const bool table = MODE == ST_FIRST || p.st_kind == 2;
-  const size_t lds = !table ? 0 : (size_t)(MODE == ST_FIRST ? p.fa_bytes : p.stg_bytes);
+  const bool wide = !table && p.st_kind == 3;
+  const size_t lds = wide ? 2048 : !table ? 0 : (size_t)(MODE == ST_FIRST ? p.fa_bytes : p.stg_bytes);
 #define MRX_LAUNCH(AUTO, CSR)                                                                     \
   hipLaunchKernelGGL((k_stream_findall<MODE, MRX_STREAM_CHUNK, AUTO, CSR>), grid, block, lds, s, p, \
                      h->d_blob, lay.data, lay.stride, lay.lens, lay.len, lay.offsets, n, d_counts, \
                      d_nrecs, d_recs, rec_row, d_s, d_e)
   if (lay.offsets) {
     if (table) MRX_LAUNCH(2, 1);
+    else if (MODE != ST_FIRST && wide) MRX_LAUNCH(3, 1);
     else if (MODE != ST_FIRST) MRX_LAUNCH(1, 1);
   } else {
     if (table) MRX_LAUNCH(2, 0);
+    else if (MODE != ST_FIRST && wide) MRX_LAUNCH(3, 0);
     else if (MODE != ST_FIRST) MRX_LAUNCH(1, 0);
   }
 #undef MRX_LAUNCH

@@ -565,6 +565,21 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
         align(hp.blob, 4);
         d.off_stcol = (int)hp.blob.size();
         put(hp.blob, cols.data(), 512);
+      } else if (nlive <= 8) {
+        // wide byte-column form: 8 states x 8-bit fields in a u64 column,
+        // field(q) = next << 3 | EMIT << 1 | NEWSTART, so "field & 0x38" is the next shift amount
+        auto E = stream_entries(sa, remap, nlive);
+        std::vector<uint64_t> cols64(256, 0);
+        for (int c = 0; c < 256; ++c)
+          for (int q = 0; q < nlive; ++q)
+            cols64[c] |= (uint64_t)((((E[q][c] >> 2) << 3) | (E[q][c] & 3)) & 0xFF) << (8 * q);
+        d.flags |= PF_STREAMABLE;
+        d.st_kind = 3;
+        for (int q = 0; q < sa.n; ++q)
+          if (remap[q] >= 0 && sa.acc[q]) d.st_accept_mask |= 1u << remap[q];
+        align(hp.blob, 16);
+        d.off_stcol = (int)hp.blob.size();
+        put(hp.blob, cols64.data(), 2048);
       } else {
         // class-table form: any number of live states that fits u16 entries and LDS
         auto E = stream_entries(sa, remap, nlive);

@@ -79,11 +79,11 @@ def test_library_exports_every_header_symbol():
 def test_config_plans():
     """Routing + kernel plan of the five BASELINE.json configs."""
     want = {
-        "hello": ("literal", "streamable=yes st_nstates=6 st_kind=2"),
+        "hello": ("literal", "streamable=yes st_nstates=6 st_kind=3"),
         "[a-z]+\\d+": ("multi_class_sequence", "streamable=yes st_nstates=3 st_kind=1"),
         "\\d+": ("single_class", "streamable=yes st_nstates=2 st_kind=1"),
         "(\\d{3})(\\d{3})(\\d{4})": ("multi_class_sequence", "streamable=yes st_nstates=11 st_kind=2"),
-        "(x|y|foo|bar)+": ("alternation", "streamable=yes st_nstates=6 st_kind=2"),
+        "(x|y|foo|bar)+": ("alternation", "streamable=yes st_nstates=6 st_kind=3"),
     }
     for pat, (shape, st) in want.items():
         d = M.CompiledRegex(pat).describe()
