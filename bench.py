@@ -46,12 +46,25 @@ def cpu_baseline(host_rows, pattern: bytes):
     t0 = time.perf_counter()
     counts, _, total = cd.findall_batch(data, offsets, want_spans=False)
     dt = time.perf_counter() - t0
-    return {
+    out = {
         "value": round(n * L / dt / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
         "sample": "first %d texts (%d MiB) of the same batch, findall, oracle/c/mrx_oracle.c, "
                   "%.1f s, %d matches" % (n, n * L >> 20, dt, total),
         "matches_per_s": round(total / dt, 1),
-    }, counts
+    }
+    # second leg: the same scan with the texts split over all host cores this
+    # process may use; the reference itself is single threaded, so `value` stays the 1-thread figure
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    if cores > 1:
+        t0 = time.perf_counter()
+        counts_mt, total_mt = cd.count_batch_mt(data, offsets, cores)
+        dt = time.perf_counter() - t0
+        out["all_cores"] = {"value": round(n * L / dt / 1e9, 4), "unit": "GB/s", "cores": cores,
+                            "seconds": round(dt, 2), "same_counts": bool((counts_mt == counts).all())}
+    return out, counts
 
 
 def measured_traffic(n: int, L: int):

@@ -274,6 +274,21 @@ int64_t mrx_oracle_findall_batch(const mrx_dfa* d, const uint8_t* data, const in
   return total;
 }
 
+/* Same scan, texts split over `threads` host threads (counts only; the reference itself is
+ * single threaded -- this is the "all host cores" leg of SURVEY.md 8(d)).  dynamic schedule:
+ * the adversarial texts cost ~1000x the others under restart-per-position search. */
+int64_t mrx_oracle_count_batch_mt(const mrx_dfa* d, const uint8_t* data, const int64_t* offsets,
+                                  int64_t n, int32_t* counts, int threads) {
+  int64_t total = 0;
+#pragma omp parallel for schedule(dynamic, 64) num_threads(threads) reduction(+ : total)
+  for (int64_t i = 0; i < n; ++i) {
+    const int64_t k = mrx_oracle_match_all(d, data + offsets[i], offsets[i + 1] - offsets[i], (int32_t*)0, 0);
+    if (counts) counts[i] = (int32_t)k;
+    total += k;
+  }
+  return total;
+}
+
 /* which: 0 = match_first (kept only if it starts at 0, matcher.mojo:1411-1415), 1 = search */
 void mrx_oracle_span_batch(const mrx_dfa* d, int which, const uint8_t* data, const int64_t* offsets,
                            int64_t n, int32_t* start, int32_t* end) {

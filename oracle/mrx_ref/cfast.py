@@ -42,6 +42,8 @@ def load():
         lib.mrx_oracle_findall_batch.restype = C.c_int64
         lib.mrx_oracle_findall_batch.argtypes = [P, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                                  C.c_void_p, C.c_int64]
+        lib.mrx_oracle_count_batch_mt.restype = C.c_int64
+        lib.mrx_oracle_count_batch_mt.argtypes = [P, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]
         lib.mrx_oracle_span_batch.restype = None
         lib.mrx_oracle_span_batch.argtypes = [P, C.c_int, C.c_void_p, C.c_void_p, C.c_int64,
                                               C.c_void_p, C.c_void_p]
@@ -101,6 +103,16 @@ class CDfa:
         self._lib.mrx_oracle_findall_batch(C.byref(self._d), data.ctypes.data, offsets.ctypes.data, n,
                                            counts.ctypes.data, spans.ctypes.data, int(total))
         return counts, spans[: int(total)], int(total)
+
+    def count_batch_mt(self, data: np.ndarray, offsets: np.ndarray, threads: int):
+        """findall counts with the texts split over `threads` host threads: (counts, total)."""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        n = len(offsets) - 1
+        counts = np.zeros(n, np.int32)
+        total = self._lib.mrx_oracle_count_batch_mt(C.byref(self._d), data.ctypes.data, offsets.ctypes.data,
+                                                    n, counts.ctypes.data, int(threads))
+        return counts, int(total)
 
     def span_batch(self, which: str, data: np.ndarray, offsets: np.ndarray):
         data = np.ascontiguousarray(data, dtype=np.uint8)
