@@ -91,6 +91,17 @@ struct LazyTables {
 };
 void build_lazy(const Program& p, LazyTables& out, int max_dfa_states);
 
+// OnePass NFA (src/regex/onepass.mojo:180-355): subset construction that rejects programs in
+// which one byte can fire two positions with different follow-up closures.  The reference
+// consults it only for NFAMatcher.match_first on '$' programs (matcher.mojo:310-313, 378-379).
+struct OnePassTables {
+  bool ok = false;                              // compiled (one-pass, <= 512 states)
+  bool has_start_anchor = false, has_end_anchor = false;
+  std::vector<std::array<int16_t, 256>> trans;  // -1 dead
+  std::vector<uint8_t> is_match, is_end_match;
+};
+void build_onepass(const Program& p, OnePassTables& out);
+
 // Bit-parallel form of the same PikeVM program (the "bitset NFA"): one bit per
 // non-epsilon instruction ("position": BYTE / CLASS / ANY / RANGE / MATCH).  A state set
 // is kBitsetWords x 64 bits; one byte step is

@@ -107,6 +107,11 @@ __global__ __launch_bounds__(kBlock) void k_match(DevPlan p, const uint8_t* __re
   }
 }
 
+__global__ void k_span_to_flag(int64_t n, const int32_t* __restrict__ start, uint8_t* __restrict__ flag) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    flag[i] = start[i] >= 0 ? 1 : 0;
+}
+
 enum { FA_COUNT = 0, FA_EMIT = 1 };
 
 template <int MODE>
@@ -257,10 +262,18 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
     const bool live = my_text < n;
     int my_len, mis = 0;   // mis: bytes of my first 16-byte block that precede the text (CSR)
     if (CSR) {
-      const int64_t o0 = live ? offsets[my_text] : 0, o1 = live ? offsets[my_text + 1] : 0;
-      my_len = (int)(o1 - o0);
-      // an empty text owns no block: park its row on the offsets array (valid memory, never read as text)
-      const uintptr_t addr = my_len > 0 ? (uintptr_t)(data + o0) : (uintptr_t)offsets;
+      // offsets == nullptr: fixed pitch that is not 16-byte aligned (or too wide for 32-bit row
+      // offsets) -- same frame treatment, text i at data + i * stride
+      int64_t o0;
+      if (offsets) {
+        o0 = live ? offsets[my_text] : 0;
+        my_len = live ? (int)(offsets[my_text + 1] - o0) : 0;
+      } else {
+        o0 = my_text * stride;
+        my_len = live ? (lens ? lens[my_text] : common_len) : 0;
+      }
+      // an empty text owns no block: park its row on the plan blob (valid memory, never read as text)
+      const uintptr_t addr = my_len > 0 ? (uintptr_t)(data + o0) : (uintptr_t)blob;
       mis = my_len > 0 ? (int)(addr & 15) : 0;
       const uintptr_t rb = addr & ~(uintptr_t)15;
       *(uint4*)(tile + lane * kRowPitch + CH) =
@@ -313,7 +326,7 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
     bool done = !live;          // ST_SEARCH / ST_FIRST: this lane has its answer
     int res_s = -1, res_e = (MODE == ST_FIRST && live && p.fa_start_acc) ? 0 : -1;
     EvRec* wave_recs = (MODE == ST_RECORDS)
-        ? recs + (CSR ? rec_region_start(offsets[base_text], w) : base_text * rec_row) : nullptr;
+        ? recs + ((CSR && offsets) ? rec_region_start(offsets[base_text], w) : base_text * rec_row) : nullptr;
 
     if (MODE == ST_FIRST) {
       // Probe: most anchored walks end within a few bytes.  Every lane reads the first 16 bytes
@@ -321,7 +334,7 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
       // text); when that settles all 64 texts the wavefront is done.
       uint4 pv = make_uint4(0, 0, 0, 0);
       if (live && my_len > 0) {
-        if (CSR) pv = *(const uint4*)(((uintptr_t)(data + offsets[my_text])) & ~(uintptr_t)15);
+        if (CSR) pv = *(const uint4*)(((uintptr_t)(data + (offsets ? offsets[my_text] : my_text * stride))) & ~(uintptr_t)15);
         else pv = *(const uint4*)(data + my_text * stride);
       }
       const uint32_t pw[4] = {pv.x, pv.y, pv.z, pv.w};
@@ -336,7 +349,8 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
       const uint32_t pem = pF & 0xAAAAAAAAu;
       if (__all(!live || pq == fa_dead || flen <= 16)) {
         if (live) {
-          const int e_ = pem ? ((31 - __builtin_clz(pem)) >> 1) + 1 - mis : (p.fa_start_acc ? 0 : -1);
+          int e_ = pem ? ((31 - __builtin_clz(pem)) >> 1) + 1 - mis : (p.fa_start_acc ? 0 : -1);
+          if (p.off_fa_end >= 0 && stg_lds[(p.off_fa_end - p.off_fa_cls) + (pq >> p.fa_cshift)]) e_ = my_len;
           out_s[my_text] = e_ >= 0 ? 0 : -1;
           out_e[my_text] = e_;
         }
@@ -480,6 +494,8 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
       if (tail) ++cnt;
       if (MODE == ST_FIRST) {
         if (live) {
+          // OnePass '$' fixup: the walk reached the end of the text alive in an end-accepting state
+          if (p.off_fa_end >= 0 && stg_lds[(p.off_fa_end - p.off_fa_cls) + (q4 >> p.fa_cshift)]) res_e = my_len;
           out_s[my_text] = res_e >= 0 ? 0 : -1;
           out_e[my_text] = res_e;
         }
@@ -835,6 +851,8 @@ int run_match(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d_s, i
   if (n < 0) return fail(MRX_E_ARGUMENT, "negative batch size");
   if (OP == OP_MATCH_FIRST || OP == OP_IS_MATCH) {
     if (!h->hp.why_no_match_first.empty()) return fail(MRX_E_UNSUPPORTED, h->hp.why_no_match_first);
+    if (h->hp.first_onepass)  // only the streaming kernel carries the OnePass tables
+      return fail(MRX_E_UNSUPPORTED, "internal: OnePass plans have no generic kernel");
   } else {
     if (int rc = check_search_supported(h)) return rc;
   }
@@ -856,10 +874,12 @@ int run_match(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d_s, i
 }
 
 // can this batch layout go through the streaming kernel?
-bool stream_layout_ok(const Layout& lay, int64_t n) {
-  if (n <= 0) return false;
-  if (lay.offsets) return true;   // CSR: any alignment, any lengths
-  return (lay.stride % 16 == 0) && (((uintptr_t)lay.data) % 16 == 0) && lay.stride * 64 < (int64_t(1) << 31);
+bool stream_layout_ok(const Layout&, int64_t n) { return n > 0; }  // every layout has a streaming form
+// fixed pitch, 16-byte aligned, 64 rows within 32-bit offsets: the fast strided form; otherwise the
+// frame form (CSR, or a fixed pitch at arbitrary alignment)
+bool strided_fast(const Layout& lay) {
+  return !lay.offsets && (lay.stride % 16 == 0) && (((uintptr_t)lay.data) % 16 == 0) &&
+         lay.stride * 64 < (int64_t(1) << 31);
 }
 
 template <int MODE>
@@ -877,7 +897,7 @@ void launch_stream(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d
   hipLaunchKernelGGL((k_stream_findall<MODE, MRX_STREAM_CHUNK, AUTO, CSR>), grid, block, lds, s, p, \
                      h->d_blob, lay.data, lay.stride, lay.lens, lay.len, lay.offsets, n, d_counts, \
                      d_nrecs, d_recs, rec_row, d_s, d_e)
-  if (lay.offsets) {
+  if (!strided_fast(lay)) {
     if (table) MRX_LAUNCH(2, 1);
     else if (MODE != ST_FIRST && wide) MRX_LAUNCH(3, 1);
     else if (MODE != ST_FIRST) MRX_LAUNCH(1, 1);
@@ -920,7 +940,7 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
         nrec = (size_t)(total_bytes / 16 + 256 * nw + 256);
       } else {
         // one 16-byte record per 16-byte group at most (+1 for the match that ends at len)
-        rec_row = rec_row_len(lay.lens ? lay.stride : lay.len);
+        rec_row = rec_row_len(lay.lens ? lay.stride : lay.len) + (strided_fast(lay) ? 0 : 1);  // frame: one more group
         nrec = (size_t)rec_row * n;
       }
       HIP_TRY(hipMallocAsync((void**)&d_recs, sizeof(EvRec) * nrec, s));
@@ -1068,7 +1088,8 @@ static int run_first_any(const mrx_handle* h, const Layout& lay, int64_t n, int3
                          void* st) {
   if (!h) return fail(MRX_E_ARGUMENT, "null handle");
   const DevPlan& p = h->hp.dev;
-  if (g_force_generic || p.fa_bytes <= 0 || !stream_layout_ok(lay, n))
+  if (n == 0 && h->hp.why_no_match_first.empty()) return MRX_OK;
+  if ((g_force_generic && !h->hp.first_onepass) || p.fa_bytes <= 0 || !stream_layout_ok(lay, n))
     return run_match<OP_MATCH_FIRST>(h, lay, n, ds, de, nullptr, st);
   if (!h->hp.why_no_match_first.empty()) return fail(MRX_E_UNSUPPORTED, h->hp.why_no_match_first);
   if (int rc = ensure_device(h)) return rc;
@@ -1106,6 +1127,19 @@ int mrx_match_first_strided_dev(const mrx_handle* h, const uint8_t* d, int64_t s
 }
 int mrx_is_match_dev(const mrx_handle* h, const uint8_t* d, const int64_t* off, int64_t n,
                      uint8_t* f, void* st) {
+  if (h && h->hp.first_onepass && n > 0) {
+    // NFA-routed: is_match = match_first(text, 0) is not None (matcher.mojo:721-731)
+    hipStream_t s = (hipStream_t)st;
+    int32_t* tmp = nullptr;
+    HIP_TRY(hipMallocAsync((void**)&tmp, sizeof(int32_t) * 2 * n, s));
+    int rc = run_first_any(h, Layout{d, off, 0, nullptr, 0}, n, tmp, tmp + n, st);
+    if (rc == MRX_OK) {
+      hipLaunchKernelGGL(k_span_to_flag, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, n, tmp, f);
+      HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipFreeAsync(tmp, s));
+    return rc;
+  }
   return run_match<OP_IS_MATCH>(h, Layout{d, off, 0, nullptr, 0}, n, nullptr, nullptr, f, st);
 }
 int mrx_captures_dev(const mrx_handle* h, const uint8_t* d, const int64_t* off, int64_t n,

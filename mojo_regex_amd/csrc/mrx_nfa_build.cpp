@@ -264,6 +264,86 @@ void build_lazy(const Program& p, LazyTables& out, int max_dfa_states) {
   }
 }
 
+namespace {
+// _epsilon_close, onepass.mojo:64-110: every visited pc is marked; byte ops and MATCH are kept
+std::vector<uint8_t> onepass_close(const Program& p, const std::vector<int>& start, bool at_start,
+                                   bool at_end) {
+  const int n = (int)p.insts.size();
+  std::vector<uint8_t> r(n, 0);
+  std::vector<int> st(start);
+  while (!st.empty()) {
+    const int pc = st.back(); st.pop_back();
+    if (pc < 0 || pc >= n || r[pc]) continue;
+    r[pc] = 1;
+    const Inst& in = p.insts[pc];
+    if (in.op == OP_SPLIT) { st.push_back(in.a0); st.push_back(in.a1); }
+    else if (in.op == OP_JUMP) st.push_back(in.a0);
+    else if (in.op == OP_START_ANCHOR) { if (at_start) st.push_back(pc + 1); }
+    else if (in.op == OP_END_ANCHOR) { if (at_end) st.push_back(pc + 1); }
+  }
+  return r;
+}
+}  // namespace
+
+void build_onepass(const Program& p, OnePassTables& out) {  // compile_onepass, onepass.mojo:180-355
+  out = OnePassTables();
+  const int n = (int)p.insts.size();
+  if (n == 0 || n > kPikeMaxStates) return;
+  for (const Inst& in : p.insts) {
+    if (in.op == OP_START_ANCHOR) out.has_start_anchor = true;
+    if (in.op == OP_END_ANCHOR) out.has_end_anchor = true;
+  }
+  Closure cl{p};
+  std::vector<std::vector<uint8_t>> sets;
+  std::map<std::vector<uint8_t>, int> index;
+  sets.push_back(onepass_close(p, {0}, true, false));
+  index[sets[0]] = 0;
+  out.trans.emplace_back(); out.trans.back().fill(-1);
+  std::vector<int> work{0};
+  constexpr int kMax = 512;  // ONEPASS_MAX_STATES
+  while (!work.empty()) {
+    const int sid = work.back(); work.pop_back();
+    const std::vector<uint8_t> cur = sets[sid];
+    std::vector<int> active;
+    for (int pc = 0; pc < n; ++pc) {
+      const Op op = p.insts[pc].op;
+      if (cur[pc] && (op == OP_BYTE || op == OP_CLASS || op == OP_ANY || op == OP_RANGE)) active.push_back(pc);
+    }
+    for (int b = 0; b < 256; ++b) {
+      std::vector<int> nxt;
+      for (int pc : active)
+        if (cl.steps(pc, b)) nxt.push_back(pc + 1);
+      if (nxt.empty()) continue;
+      const std::vector<uint8_t> first = onepass_close(p, {nxt[0]}, false, false);
+      for (size_t i = 1; i < nxt.size(); ++i)
+        if (onepass_close(p, {nxt[i]}, false, false) != first) { out = OnePassTables(); return; }
+      auto it = index.find(first);
+      int idx;
+      if (it != index.end()) idx = it->second;
+      else {
+        if ((int)sets.size() >= kMax) { out = OnePassTables(); return; }
+        idx = (int)sets.size();
+        sets.push_back(first);
+        index[first] = idx;
+        out.trans.emplace_back(); out.trans.back().fill(-1);
+        work.push_back(idx);
+      }
+      out.trans[sid][b] = (int16_t)idx;
+    }
+  }
+  for (const auto& s : sets) {
+    out.is_match.push_back(cl.has_match(s) ? 1 : 0);
+    uint8_t e = 0;
+    if (out.has_end_anchor) {  // _closure_reaches_match_with_end_anchor, onepass.mojo:122-140
+      std::vector<int> pcs;
+      for (int pc = 0; pc < n; ++pc) if (s[pc]) pcs.push_back(pc);
+      e = cl.has_match(onepass_close(p, pcs, false, true)) ? 1 : 0;
+    }
+    out.is_end_match.push_back(e);
+  }
+  out.ok = true;
+}
+
 void build_bitset(const Program& p, BitsetNfa& out) {
   out = BitsetNfa();
   const int n = (int)p.insts.size();

@@ -326,6 +326,8 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
       compile_program(ast, hp.program);
       build_lazy(hp.program, hp.lazy, /*max_dfa_states=*/4096);
       build_bitset(hp.program, hp.bitset);
+      // NFAMatcher.__init__, matcher.mojo:310-313: OnePass only for programs with '$'
+      if (hp.lazy.supported && hp.program.has_end_anchor()) build_onepass(hp.program, hp.onepass);
     }
     if (hp.complexity == CX_SIMPLE && !force_nfa) {  // matcher.mojo:664-675
       try {
@@ -356,10 +358,13 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
   const bool nfa_end = hp.program.has_end_anchor();
   if (!hp.wildcard_any && !hp.use_dfa) {
     // NFAMatcher.match_first, matcher.mojo:361-380
-    if (!(lazy_ok && !nfa_end))
+    if (lazy_ok && nfa_end && hp.onepass.ok)
+      hp.first_onepass = true;  // matcher.mojo:378-379
+    else if (!(lazy_ok && !nfa_end))
       hp.why_no_match_first = too_large
           ? "LazyDFA determinisation exceeds the state budget"
-          : "reference routes match_first to OnePass / the backtracking NFA ('$' in an NFA-routed pattern)";
+          : "reference routes match_first to the backtracking NFA ('$' in an NFA-routed pattern that is "
+            "not one-pass)";
     // NFAMatcher.match_next / match_all, matcher.mojo:383-431
     const bool fast_absent = !hp.nfa_has_literal_opt && !hp.nfa_starts_dotstar && !hp.nfa_ends_dotstar;
     if (!(hp.lazy.supported && fast_absent))
@@ -635,17 +640,26 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
   //                      when the run is empty and the start state does not accept
   //   otherwise          the table walk (dfa.mojo:1979-2024 / pikevm.mojo:819-867)
   d.fa_bytes = 0; d.fa_nstates = 0; d.fa_start_acc = 0; d.off_fa_cls = d.off_fa_trans = -1; d.fa_cshift = 0;
+  d.off_fa_end = -1;
   hp.first_stream_why_not.clear();
   if (d.kind == PLAN_ANY) hp.first_stream_why_not = "'.*' shortcut";
   else if (!hp.why_no_match_first.empty()) hp.first_stream_why_not = hp.why_no_match_first;
-  else if (d.flags & PF_START_DEAD) hp.first_stream_why_not = "dead start state";
-  else if (d.flags & PF_BITSET) hp.first_stream_why_not = "bitset NFA walk (no determinised table)";
+  else if (!hp.first_onepass && (d.flags & PF_START_DEAD)) hp.first_stream_why_not = "dead start state";
+  else if (!hp.first_onepass && (d.flags & PF_BITSET)) hp.first_stream_why_not = "bitset NFA walk (no determinised table)";
   else if (d.flags & PF_END_ANCHOR) hp.first_stream_why_not = "'$' needs the end-of-text check of both paths";
   else {
     std::vector<std::array<int, 256>> N;  // -1 = dead
-    std::vector<uint8_t> A;
+    std::vector<uint8_t> A, E;            // E: OnePass end-of-text flags (empty otherwise)
     auto add = [&](bool a) { std::array<int, 256> r; r.fill(-1); N.push_back(r); A.push_back(a ? 1 : 0); return (int)N.size() - 1; };
-    if (d.flags & PF_PURE_LITERAL) {
+    if (hp.first_onepass) {
+      // OnePassNFA.match_first from 0 (onepass.mojo:440-488); '^' is vacuous at start == 0
+      const OnePassTables& op = hp.onepass;
+      for (size_t q = 0; q < op.trans.size(); ++q) {
+        const int id = add(op.is_match[q] != 0);
+        for (int c = 0; c < 256; ++c) N[id][c] = op.trans[q][c];
+        E.push_back(op.is_end_match[q]);
+      }
+    } else if (d.flags & PF_PURE_LITERAL) {
       const std::string& L = hp.dfa.literal;
       add(L.empty());
       for (size_t k = 0; k < L.size(); ++k) { const int t = add(k + 1 == L.size()); N[t - 1][(unsigned char)L[k]] = t; }
@@ -701,11 +715,18 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
       const int begin = (int)hp.blob.size();
       d.off_fa_cls = begin; put(hp.blob, fcls.data(), 256);
       d.off_fa_trans = (int)hp.blob.size(); put(hp.blob, tr.data(), tr.size() * 2);
+      if (!E.empty()) {
+        std::vector<uint8_t> ends(nl + 1, 0);
+        for (int q = 0; q < nl; ++q) ends[q] = E[order[q]];
+        d.off_fa_end = (int)hp.blob.size(); put(hp.blob, ends.data(), ends.size());
+      }
       align(hp.blob, 16);
       d.fa_bytes = (int)hp.blob.size() - begin;
       d.fa_cshift = cshift; d.fa_nstates = nl; d.fa_start_acc = A[0];
     }
   }
+  if (hp.first_onepass && d.fa_bytes == 0)  // no generic kernel walks the OnePass tables
+    hp.why_no_match_first = "OnePass table too large for the streaming kernel's LDS table";
   align(hp.blob, 16);
   d.blob_bytes = (int)hp.blob.size();
 }
@@ -784,7 +805,7 @@ std::string describe_plan(const HostPlan& hp) {
   o << "device.streamable=" << ((d.flags & PF_STREAMABLE) ? "yes" : ("no: " + hp.streamable_why_not))
     << " st_nstates=" << d.st_nstates << " st_kind=" << d.st_kind << "\n";
   o << "device.first_stream=" << (d.fa_bytes ? "yes" : ("no: " + hp.first_stream_why_not))
-    << " fa_nstates=" << d.fa_nstates << "\n";
+    << " fa_nstates=" << d.fa_nstates << (hp.first_onepass ? " onepass=yes" : "") << "\n";
   if (d.flags & PF_BITSET)
     o << "device.bitset=yes positions=" << d.bs_npos << " words=" << d.bs_nw << " byte_classes=" << d.bs_ncls << "\n";
   return o.str();

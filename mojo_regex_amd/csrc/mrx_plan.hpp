@@ -60,6 +60,9 @@ struct DevPlan {
   // anchored automaton for match_first on the streaming kernel (fa_bytes == 0: none); same layout
   // as kind 2 but entry = (next << fa_cshift) << 2 | ACCEPT(next) << 1, last row = dead state
   int32_t off_fa_cls, off_fa_trans, fa_cshift, fa_bytes, fa_nstates, fa_start_acc;
+  // OnePass '$' fixup (onepass.mojo:480-484): u8 per state (dead row included), consulted when the
+  // walk reaches the end of the text alive; -1 = the automaton has no such flags
+  int32_t off_fa_end;
   // bitset NFA (PF_BITSET): cls[256] u8, byte masks u64[bs_ncls][bs_nw], follow u64[bs_npos][bs_nw]
   int32_t bs_nw, bs_npos, bs_ncls, off_bs_cls, off_bs_mask, off_bs_follow;
   uint64_t bs_start[4], bs_match[4];
@@ -83,6 +86,8 @@ struct HostPlan {
   Program program;
   LazyTables lazy;
   BitsetNfa bitset;
+  OnePassTables onepass;
+  bool first_onepass = false;  // match_first runs the OnePass tables (NFA-routed '$' pattern)
   bool force_bitset = false;  // MRX_COMPILE_BITSET_NFA
   bool nfa_has_literal_opt = false, nfa_starts_dotstar = false, nfa_ends_dotstar = false;
   // per-operation support: empty string = supported, else the reason

@@ -20,6 +20,7 @@ from .analysis import (classify, should_use_pure_dfa, extract_literals,
                        has_literal_prefix, SIMPLE, COMPLEXITY_NAMES)
 from .dfa_engine import compile_dfa_pattern, DFACompileError, DFAEngine
 from .pikevm import compile_ast, PikeVMEngine, LazyDFA, OP_END_ANCHOR
+from .onepass import compile_onepass
 
 Span = Tuple[int, int]
 
@@ -129,11 +130,11 @@ class NFAMatcher:
         self.engine = NFAEngineFlags(pattern)
         vm = PikeVMEngine(compile_ast(ast))
         self.program = vm.program
-        self.onepass = False
+        self.onepass = None   # OnePassNFA, only for '$' programs that compile one-pass (:310-313)
         self.lazy: Optional[LazyDFA] = None
         if vm.is_supported():
             if any(ins[0] == OP_END_ANCHOR for ins in vm.program.instructions):
-                self.onepass = True  # compile_onepass may still reject; see below
+                self.onepass = compile_onepass(vm.program)
             self.lazy = LazyDFA(vm)
 
     def _nfa_fast_paths_absent(self) -> bool:
@@ -147,7 +148,9 @@ class NFAMatcher:
     def match_first(self, text: bytes, start: int = 0):
         if self.lazy is not None and not self.lazy.has_end_anchor:
             return self.lazy.match_first(text, start)
-        raise UnsupportedByOracle("match_first routed to OnePass/backtracking NFA")
+        if self.onepass is not None:
+            return self.onepass.match_first(text, start)
+        raise UnsupportedByOracle("match_first routed to the backtracking NFA")
 
     def match_next(self, text: bytes, start: int = 0):
         if self._use_lazy_dfa_for_search():

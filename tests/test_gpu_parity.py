@@ -278,7 +278,9 @@ STREAM_PATTERNS = [b"[a-z]+\\d+", b"\\d+", b"[a-z]+", b"\\w+\\s+", b"[^0-9]+", b
 @pytest.mark.parametrize("pat", STREAM_PATTERNS)
 @pytest.mark.parametrize("n,pitch,var", [(1, 16, False), (63, 48, True), (64, 64, False),
                                          (65, 80, True), (777, 208, True), (1000, 256, False),
-                                         (130, 1024, True)])
+                                         (130, 1024, True),
+                                         # pitch not a multiple of 16: frame form of the kernel
+                                         (200, 50, True), (70, 1001, False), (129, 7, True)])
 def test_streaming_kernel_equals_generic_and_oracle(pat, n, pitch, var):
     _need_gpu()
     rng = np.random.default_rng(n * 131 + pitch)
@@ -542,3 +544,46 @@ def test_streaming_csr_ragged_unaligned(pat, shift):
     for i in range(0, len(texts), 6):
         have = [tuple(int(x) for x in r) for r in sp[pre[i]:pre[i + 1]]]
         assert have == O.findall(pat, texts[i]), (pat, i)
+
+
+ONEPASS_PATTERNS = [b"^[a-z]+[0-9]+$", b"^a|b$", b"^\\d+$", b"[a-z]+$", b"^\\w+$", b"^\\s$", b"^xa|yb$",
+                    b"^\\+?1?[\\s.-]?\\(?([2-9]\\d{2})\\)?[\\s.-]?([2-9]\\d{2})[\\s.-]?(\\d{4})$"]
+
+
+@pytest.mark.parametrize("pat", ONEPASS_PATTERNS)
+def test_onepass_match_first_matches_oracle(pat):
+    """NFA-routed '$' patterns that compile one-pass (matcher.mojo:378-379,
+    onepass.mojo:440-488): match_first / is_match on the OnePass tables, CSR and fixed pitch."""
+    _need_gpu()
+    rng = np.random.default_rng(zlib.crc32(pat))
+    rx = M.compile_regex(pat)
+    assert "onepass=yes" in rx.describe()
+    texts = _random_texts(rng, 150, 40, b"ab019 nz") + _random_texts(rng, 50, 300, b"abcxyz0123456789") + [
+        b"", b"a", b"b", b"ab", b"na", b"nb", b"abc123", b"abc123x", b"12345", b" ", b"\t", b"hello_world1",
+        b"6502530000", b"+1 (650) 253-0000", b"1-650-253-0000", b"650.253.0000", b"(650)253-0000",
+        b"650 253 0000x", b"+1 (150) 253-0000", b"q" * 700, b"q" * 700 + b"1", b"7" * 513]
+    fs, fe = rx.match_first(texts)
+    assert M.load_library().mrx_last_kernel_name() == b"k_stream_first"
+    flags = rx.is_match(texts)
+    for i, t in enumerate(texts):
+        w = O.match_first(pat, t)
+        assert (int(fs[i]), int(fe[i])) == (w if w else (-1, -1)), (pat, t)
+        assert bool(flags[i]) == (w is not None), (pat, t)
+    # fixed pitch, aligned and not
+    for pitch in (64, 50):
+        arr = np.full((len(texts), pitch), ord("!"), dtype=np.uint8)
+        lens = np.zeros(len(texts), np.int32)
+        for i, t in enumerate(texts):
+            k = min(len(t), pitch)
+            arr[i, :k] = np.frombuffer(t[:k], dtype=np.uint8)
+            lens[i] = k
+        batch = M.DeviceBatch.strided(torch.from_numpy(arr).cuda().reshape(-1), pitch,
+                                      lens=torch.from_numpy(lens).cuda())
+        s2, e2 = rx.match_first(batch)
+        s2, e2 = s2.cpu().numpy(), e2.cpu().numpy()
+        for i, t in enumerate(texts):
+            w = O.match_first(pat, t[:pitch])
+            assert (int(s2[i]), int(e2[i])) == (w if w else (-1, -1)), (pat, pitch, t)
+    # search / findall stay refused for these patterns (LazyDFA with '$' is history dependent)
+    with pytest.raises(M.UnsupportedPattern):
+        rx.match_next([b"abc"])

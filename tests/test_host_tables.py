@@ -94,9 +94,12 @@ def test_config_plans():
 
 def test_out_of_scope_patterns_fail_loudly_without_a_gpu():
     # routed by the reference to OnePass / the backtracking NFA: refused, never guessed
-    rx = M.CompiledRegex("^[a-z]+[0-9]+$")
+    rx = M.CompiledRegex("^aaaa.*a$")   # '$' program that is not one-pass: backtracker
     d = rx.describe()
     assert "support.match_first=reference routes" in d
+    d = M.CompiledRegex("^[a-z]+[0-9]+$").describe()   # one-pass: match_first on the OnePass tables
+    assert "support.match_first=yes" in d and "onepass=yes" in d
+    assert "support.search=LazyDFA search with '$'" in d
     rx = M.CompiledRegex("hello.world")
     assert "support.search=reference routes" in rx.describe()
     with pytest.raises(M.RegexSyntaxError, match=r"Missing closing '\]'"):

@@ -98,3 +98,38 @@ def test_sub_pins(oracle_backend):
     assert be.sub(b"(\\d{4})-(\\d{2})-(\\d{2})", b"\\2/\\3/\\1",
                   b"Date: 2026-04-12 is today") == b"Date: 04/12/2026 is today"
     assert be.sub(b"hello", b"\\0hi", b"hello world") == b"\\0hi world"
+
+
+def test_onepass_engine_vectors():
+    """The reference's own OnePass tests (tests/test_onepass.mojo), engine-level API."""
+    import json
+    import os
+    from mrx_ref.frontend import parse
+    from mrx_ref.pikevm import compile_ast
+    from mrx_ref.onepass import compile_onepass
+    path = os.path.join(os.path.dirname(__file__), "golden", "onepass_vectors.json")
+    for v in json.load(open(path))["vectors"]:
+        op = compile_onepass(compile_ast(parse(v["pattern"].encode())))
+        if v["op"] == "compiles":
+            assert (op is not None) == v["want"], v
+            continue
+        got = getattr(op, v["op"])(v["text"].encode(), 0)
+        if "want_end" in v:
+            assert got is not None and got[1] == v["want_end"], v
+        else:
+            assert got == (tuple(v["want"]) if v["want"] is not None else None), v
+
+
+def test_onepass_routing_and_rejections():
+    """NFAMatcher.match_first (matcher.mojo:361-380): '$' programs go to OnePass when they
+    compile one-pass, otherwise to the backtracker (out of scope)."""
+    from mrx_ref import hybrid as H
+    assert H.match_first(b"^[a-z]+[0-9]+$", b"abc123") == (0, 6)
+    assert H.match_first(b"^[a-z]+[0-9]+$", b"abc123x") is None
+    assert H.match_first(b"^a|b$", b"a") == (0, 1)        # '^a' branch accepts mid-text (onepass.mojo:449-453)
+    assert H.match_first(b"^a|b$", b"ab") == (0, 1)
+    assert H.match_first(b"^\\d+$", b"12345") == (0, 5)
+    with pytest.raises(UnsupportedByOracle):               # `.` and `a` both fire: not one-pass
+        H.match_first(b"^aaaa.*a$", b"aaaaa")
+    with pytest.raises(UnsupportedByOracle):               # search with '$' stays LazyDFA (history dependent)
+        H.search(b"^[a-z]+$", b"abc")
