@@ -320,6 +320,25 @@ class CompiledRegex:
             raw = out[: total.value].tobytes()
             return [raw[out_off[i]:out_off[i + 1]] for i in range(n)]
 
+    def sub_dev(self, repl, batch: "DeviceBatch", count: int = 0, out_cap: Optional[int] = None):
+        """regex.sub on a device-resident CSR batch: (out_offsets int64[n+1], out_data uint8[total])."""
+        import torch
+        repl = _b(repl)
+        dev = batch.data.device
+        off = batch.csr_offsets()
+        cap = int(out_cap) if out_cap else int(batch.data.numel()) * 2 + 16 * batch.n + 64
+        out_off = torch.empty(batch.n + 1, dtype=torch.int64, device=dev)
+        while True:
+            out = torch.empty(cap, dtype=torch.uint8, device=dev)
+            total = C.c_int64(0)
+            rc = self._lib.mrx_sub_dev(self._h, repl, len(repl), count, _ptr(batch.data), _ptr(off), batch.n,
+                                       _ptr(out_off), _ptr(out), cap, C.byref(total), self._stream_ptr())
+            if rc == MRX_E_CAPACITY:
+                cap = int(total.value)
+                continue
+            _check(rc)
+            return out_off, out[: total.value]
+
     # -- device-resident batches (torch tensors) ------------------------------------
     def _stream_ptr(self):
         import torch

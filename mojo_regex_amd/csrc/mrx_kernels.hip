@@ -629,6 +629,101 @@ struct WriteSink {
   }
 };
 
+// ---- sub() from findall spans (streamable plans) -----------------------------------------
+// For plans whose findall runs on the streaming kernel, regex.sub is assembled from the CSR spans:
+// the first `count` matches of a text (all when count == 0) are replaced, matches are never empty,
+// and the replacement has a fixed length R (literal, or template over fixed-width groups), so
+//   out position of replacement m:  rstart(m) = s_m - cum_m + m * R     (cum_m = matched bytes before m)
+// k_subs_sizes: one lane per text -> output length and cum_m per span.
+__global__ __launch_bounds__(kBlock) void k_subs_sizes(int64_t n, const int64_t* __restrict__ offsets,
+                                                       const int64_t* __restrict__ prefix,
+                                                       const int32_t* __restrict__ spans, long long count,
+                                                       int R, int64_t* __restrict__ sizes,
+                                                       int32_t* __restrict__ cum) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t a = prefix[i];
+    int64_t k = prefix[i + 1] - a;
+    if (count > 0 && k > count) k = count;
+    int c = 0;
+    for (int64_t m = 0; m < k; ++m) {
+      cum[a + m] = c;
+      const int2 sp = *(const int2*)(spans + 2 * (a + m));
+      c += sp.y - sp.x;
+    }
+    sizes[i] = (offsets[i + 1] - offsets[i]) - c + k * (int64_t)R;
+  }
+}
+
+// k_subs_emit: one wavefront per text, output centric.  Each lane produces one 16-byte block of
+// the output (aligned on the output ADDRESS, so full blocks are single coalesced 16-byte stores),
+// finds by binary search which replacement precedes its first byte and then walks: replacement
+// bytes come from rmap (literal byte, or 0x8000 | offset into the match for a group byte), kept
+// bytes from the input through an 8-byte register window.
+__global__ __launch_bounds__(kBlock) void k_subs_emit(int64_t n, const uint8_t* __restrict__ data,
+                                                      const int64_t* __restrict__ offsets,
+                                                      const int64_t* __restrict__ prefix,
+                                                      const int32_t* __restrict__ spans,
+                                                      const int32_t* __restrict__ cum, long long count,
+                                                      int R, const uint16_t* __restrict__ rmap,
+                                                      const int64_t* __restrict__ out_off,
+                                                      uint8_t* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  for (int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); i < n; i += nwaves) {
+    const int64_t ibase = offsets[i];
+    const Text t(data + ibase, (int)(offsets[i + 1] - ibase));
+    const int64_t a = prefix[i];
+    int64_t k64 = prefix[i + 1] - a;
+    if (count > 0 && k64 > count) k64 = count;
+    const int k = (int)k64;
+    const int64_t obase = out_off[i];
+    const int olen = (int)(out_off[i + 1] - obase);
+    if (olen <= 0) continue;
+    const int32_t* sp = spans + 2 * a;
+    const int32_t* cm = cum + a;
+    auto rstart = [&](int m) { return sp[2 * m] - cm[m] + m * R; };
+    const int head = (int)((uintptr_t)(out + obase) & 15);  // output starts `head` bytes into its first 16-byte block
+    for (int blk = 0; blk * 16 < head + olen; blk += 64) {
+      const int p_lo = (blk + lane) * 16 - head;   // first output position of my block (may be < 0)
+      int p = p_lo < 0 ? 0 : p_lo;
+      const int p_hi = p_lo + 16 < olen ? p_lo + 16 : olen;
+      if (p >= p_hi) continue;
+      // j = last replacement with rstart(j) <= p, or -1
+      int lo = -1, hi = k;
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (rstart(mid) <= p) lo = mid; else hi = mid;
+      }
+      int j = lo;
+      int rs = j >= 0 ? rstart(j) : 0, ms = j >= 0 ? sp[2 * j] : 0, me = j >= 0 ? sp[2 * j + 1] : 0;
+      int nxt = j + 1 < k ? rstart(j + 1) : 0x7FFFFFFF;
+      uint32_t w[4] = {0, 0, 0, 0};
+      for (; p < p_hi; ++p) {
+        while (p == nxt) {   // several replacements can start here when R == 0 and matches touch
+          ++j;
+          rs = nxt; ms = sp[2 * j]; me = sp[2 * j + 1];
+          nxt = j + 1 < k ? rstart(j + 1) : 0x7FFFFFFF;
+        }
+        int b;
+        if (j >= 0 && p < rs + R) {
+          const uint32_t r = rmap[p - rs];
+          b = (r & 0x8000u) ? t.at(ms + (int)(r & 0x7FFFu)) : (int)r;
+        } else {
+          b = t.at(j >= 0 ? p - (rs + R) + me : p);
+        }
+        const int q = p - p_lo;
+        w[q >> 2] |= (uint32_t)b << ((q & 3) * 8);
+      }
+      uint8_t* dst = out + (obase + p_lo);
+      if (p_lo >= 0 && p_lo + 16 <= olen) {
+        *(uint4*)dst = make_uint4(w[0], w[1], w[2], w[3]);
+      } else {  // block shared with a neighbouring text: byte stores only
+        for (int q = (p_lo < 0 ? -p_lo : 0); q < p_hi - p_lo; ++q) dst[q] = (uint8_t)(w[q >> 2] >> ((q & 3) * 8));
+      }
+    }
+  }
+}
+
 enum { SUB_SIZE = 0, SUB_EMIT = 1 };
 
 template <int MODE>
@@ -992,6 +1087,67 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
 }  // namespace
 
 namespace {
+// regex.sub for streamable plans: streaming findall -> sizes -> prefix sums -> emit (see k_subs_*)
+int sub_from_spans(const mrx_handle* h, const Layout& lay, int64_t n, const std::vector<uint16_t>& rmap,
+                   int64_t count, int64_t* out_off, uint8_t* out, int64_t out_cap, int64_t* total_bytes,
+                   hipStream_t s) {
+  int64_t in_bytes = 0;
+  HIP_TRY(hipMemcpyAsync(&in_bytes, lay.offsets + n, sizeof in_bytes, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  int64_t* d_prefix = nullptr;
+  int32_t* d_spans = nullptr;
+  HIP_TRY(hipMallocAsync((void**)&d_prefix, sizeof(int64_t) * (n + 1), s));
+  int64_t cap = in_bytes / 8 + n + 64, nm = 0;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    HIP_TRY(hipMallocAsync((void**)&d_spans, sizeof(int32_t) * 2 * (size_t)cap, s));
+    const int rc = run_findall(h, lay, n, d_prefix, d_spans, cap, &nm, s);
+    if (rc == MRX_OK) break;
+    HIP_TRY(hipFreeAsync(d_spans, s));
+    d_spans = nullptr;
+    if (rc != MRX_E_CAPACITY || attempt == 1) { (void)hipFreeAsync(d_prefix, s); return rc; }
+    cap = nm;
+  }
+  const int R = (int)rmap.size();
+  uint16_t* d_rmap = nullptr;
+  int32_t* d_cum = nullptr;
+  int64_t *d_sizes = nullptr, *d_total = nullptr;
+  HIP_TRY(hipMallocAsync((void**)&d_rmap, sizeof(uint16_t) * (R + 8), s));
+  HIP_TRY(hipMallocAsync((void**)&d_cum, sizeof(int32_t) * (size_t)(nm + 1), s));
+  HIP_TRY(hipMallocAsync((void**)&d_sizes, sizeof(int64_t) * n, s));
+  HIP_TRY(hipMallocAsync((void**)&d_total, sizeof(int64_t), s));
+  if (R) HIP_TRY(hipMemcpyAsync(d_rmap, rmap.data(), sizeof(uint16_t) * R, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_subs_sizes, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, n, lay.offsets, d_prefix,
+                     d_spans, (long long)count, R, d_sizes, d_cum);
+  HIP_TRY(hipGetLastError());
+  int rc = device_scan<int64_t>(d_sizes, n, out_off, d_total, s);
+  int64_t tot = 0;
+  if (rc == MRX_OK) {
+    HIP_TRY(hipMemcpyAsync(&tot, d_total, sizeof tot, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (total_bytes) *total_bytes = tot;
+    if (tot > out_cap) {
+      rc = fail(MRX_E_CAPACITY, "output buffer too small: need " + std::to_string(tot));
+    } else if (tot > 0) {
+      const int64_t blocks = (n + (kBlock / 64) - 1) / (kBlock / 64);
+      hipLaunchKernelGGL(k_subs_emit, dim3((unsigned)(blocks < 65536 * 4 ? blocks : 65536 * 4)), dim3(kBlock), 0,
+                         s, n, lay.data, lay.offsets, d_prefix, d_spans, d_cum, (long long)count, R, d_rmap,
+                         out_off, out);
+      g_last_kernel = "k_subs_emit";
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipStreamSynchronize(s));
+    }
+  }
+  HIP_TRY(hipFreeAsync(d_prefix, s));
+  HIP_TRY(hipFreeAsync(d_spans, s));
+  HIP_TRY(hipFreeAsync(d_rmap, s));
+  HIP_TRY(hipFreeAsync(d_cum, s));
+  HIP_TRY(hipFreeAsync(d_sizes, s));
+  HIP_TRY(hipFreeAsync(d_total, s));
+  return rc;
+}
+}  // namespace
+
+namespace {
 struct DevBatch {
   uint8_t* data = nullptr;
   int64_t* offsets = nullptr;
@@ -1210,6 +1366,24 @@ int mrx_sub_dev(const mrx_handle* h, const char* repl, size_t repl_len, int64_t 
   if (int rc = check_lds(h)) return rc;
   if (int rc = ensure_device(h)) return rc;
   hipStream_t s = (hipStream_t)st;
+  if (!g_force_generic && (h->hp.dev.flags & PF_STREAMABLE) && n > 0 && off) {
+    // replacement as a fixed-length byte map
+    std::vector<uint16_t> rmap;
+    if (groups) {
+      for (const ReplSeg& sg : tpl) {
+        if (sg.group_ref > 0 && sg.group_ref <= h->hp.fixed_ngroups)
+          for (int j = 0; j < h->hp.fixed_w[sg.group_ref]; ++j)
+            rmap.push_back((uint16_t)(0x8000 | (h->hp.fixed_off[sg.group_ref] + j)));
+        else
+          for (int j = 0; j < sg.length; ++j) rmap.push_back((uint8_t)r[sg.start + j]);
+      }
+    } else {
+      for (unsigned char ch : r) rmap.push_back(ch);
+    }
+    if (rmap.size() <= 4096 && h->hp.fixed_total < 0x7FFF)
+      return sub_from_spans(h, Layout{d, off, 0, nullptr, 0}, n, rmap, count, out_off, out, out_cap,
+                            total_bytes, s);
+  }
   uint8_t* d_repl = nullptr;
   ReplSeg* d_tpl = nullptr;
   int64_t *d_sizes = nullptr, *d_total = nullptr;

@@ -587,3 +587,27 @@ def test_onepass_match_first_matches_oracle(pat):
     # search / findall stay refused for these patterns (LazyDFA with '$' is history dependent)
     with pytest.raises(M.UnsupportedPattern):
         rx.match_next([b"abc"])
+
+
+@pytest.mark.parametrize("pat,repl", [(b"[a-z]+\\d+", b"#"), (b"[a-z]+\\d+", b""), (b"\\d", b""), (b"\\d+", b"<NUM>"),
+                                      (b"(\\d{3})(\\d{3})(\\d{4})", b"\\1-\\2-\\3"),
+                                      (b"(\\d{3})(\\d{3})(\\d{4})", b"(\\1) \\2-\\3 ext \\7"),
+                                      (b"(x|y|foo|bar)+", b"_"), (b"hello", b"HELLO WORLD")])
+@pytest.mark.parametrize("count", [0, 1, 3])
+def test_sub_from_spans_equals_generic_and_oracle(pat, repl, count):
+    """regex.sub assembled from streaming findall spans (k_subs_*) vs the generic lane-per-text
+    sub kernel on every text and vs the oracle's _sub_impl on a sample."""
+    _need_gpu()
+    rng = np.random.default_rng(zlib.crc32(pat + repl) + count)
+    al = b"abcxyz0123456789 -" + bytes(c for c in pat if chr(c).isalnum()) * 2
+    texts = _random_texts(rng, 300, 90, al) + _random_texts(rng, 40, 1500, al) + [
+        b"", b"6502530000", b"Call 6502530000 or 4155551234 today.", b"123", b"1", b"a1b2c3", b"hellohello",
+        b"q" * 600 + b"1", b"9" * 333]
+    rx = M.compile_regex(pat)
+    got = rx.sub(repl, texts, count)
+    assert M.load_library().mrx_last_kernel_name() == b"k_subs_emit"
+    with generic_kernels():
+        want = rx.sub(repl, texts, count)
+    assert got == want
+    for i in range(0, len(texts), 7):
+        assert got[i] == O.sub(pat, repl, texts[i], count), (pat, repl, texts[i], count)

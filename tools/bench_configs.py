@@ -73,6 +73,26 @@ def main():
         torch.cuda.empty_cache()
 
 
+def sub_bench():
+    """regex.sub on config 4 (`\\1-\\2-\\3`) and config 2, device resident."""
+    for name, pat, repl, gen in (
+            ("c4 sub", b"(\\d{3})(\\d{3})(\\d{4})", b"\\1-\\2-\\3", lambda: W.make_phone_batch(1 << 20, 1024)),
+            ("c4 sub literal", b"(\\d{3})(\\d{3})(\\d{4})", b"<phone>", lambda: W.make_phone_batch(1 << 20, 1024)),
+            ("c2 sub", b"[a-z]+\\d+", b"#", lambda: W.make_c2_batch(1 << 20, 1024))):
+        d = gen()
+        n, L = d.shape
+        rx = M.compile_regex(pat)
+        batch = M.DeviceBatch.strided(d.reshape(-1), L, length=L)
+        cap = n * L * 2
+        t = timeit(lambda: rx.sub_dev(repl, batch, 0, out_cap=cap), reps=3)
+        off, out = rx.sub_dev(repl, batch, 0, out_cap=cap)
+        print(json.dumps({"config": name, "texts": n, "in_bytes": n * L, "out_bytes": int(out.numel()),
+                          "sub_ms": round(t * 1e3, 3), "sub_GBps": round(n * L / t / 1e9, 1),
+                          "kernel": M.load_library().mrx_last_kernel_name().decode()}), flush=True)
+        del d, batch, off, out
+        torch.cuda.empty_cache()
+
+
 def ragged():
     """Config 2 as a ragged CSR batch (the C ABI's primary layout): rows cut to U[64, 1024] bytes and
     packed back to back, so almost every text starts unaligned."""
@@ -103,5 +123,8 @@ def ragged():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "ragged":
         ragged()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "sub":
+        sub_bench()
         sys.exit(0)
     main()
