@@ -640,17 +640,31 @@ __global__ __launch_bounds__(kBlock) void k_subs_sizes(int64_t n, const int64_t*
                                                        const int32_t* __restrict__ spans, long long count,
                                                        int R, int64_t* __restrict__ sizes,
                                                        int32_t* __restrict__ cum) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+  // one wavefront per text: coalesced span loads, wave prefix sum of the match lengths
+  const int lane = threadIdx.x & 63;
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  for (int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); i < n; i += nwaves) {
     const int64_t a = prefix[i];
     int64_t k = prefix[i + 1] - a;
     if (count > 0 && k > count) k = count;
-    int c = 0;
-    for (int64_t m = 0; m < k; ++m) {
-      cum[a + m] = c;
-      const int2 sp = *(const int2*)(spans + 2 * (a + m));
-      c += sp.y - sp.x;
+    int carry = 0;
+    for (int64_t m0 = 0; m0 < k; m0 += 64) {
+      const int64_t m = m0 + lane;
+      int len = 0;
+      if (m < k) {
+        const int2 sp = *(const int2*)(spans + 2 * (a + m));
+        len = sp.y - sp.x;
+      }
+      int incl = len;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int v = __shfl_up(incl, d);
+        if (lane >= d) incl += v;
+      }
+      if (m < k) cum[a + m] = carry + incl - len;
+      carry += __shfl(incl, 63);
     }
-    sizes[i] = (offsets[i + 1] - offsets[i]) - c + k * (int64_t)R;
+    if (lane == 0) sizes[i] = (offsets[i + 1] - offsets[i]) - carry + k * (int64_t)R;
   }
 }
 
@@ -659,6 +673,20 @@ __global__ __launch_bounds__(kBlock) void k_subs_sizes(int64_t n, const int64_t*
 // finds by binary search which replacement precedes its first byte and then walks: replacement
 // bytes come from rmap (literal byte, or 0x8000 | offset into the match for a group byte), kept
 // bytes from the input through an 8-byte register window.
+constexpr int kSubsStage = 256;  // replacements per text staged in LDS (more: read from global)
+
+// bytes src .. src+15 of a text as two little-endian u64 (bytes past the text are unspecified but
+// never fetched from beyond the aligned word that holds the text's last byte)
+__device__ __forceinline__ void load16(const uint8_t* base, int len, int src, uint64_t& lo, uint64_t& hi) {
+  const uintptr_t addr = (uintptr_t)(base + src);
+  const uint64_t* w = (const uint64_t*)(addr & ~(uintptr_t)7);
+  const uint64_t* last = (const uint64_t*)(((uintptr_t)(base + len - 1)) & ~(uintptr_t)7);  // len > 0
+  const uint64_t w0 = w <= last ? w[0] : 0, w1 = w + 1 <= last ? w[1] : 0, w2 = w + 2 <= last ? w[2] : 0;
+  const int sh = (int)(addr & 7) * 8;
+  if (sh == 0) { lo = w0; hi = w1; }
+  else { lo = (w0 >> sh) | (w1 << (64 - sh)); hi = (w1 >> sh) | (w2 << (64 - sh)); }
+}
+
 __global__ __launch_bounds__(kBlock) void k_subs_emit(int64_t n, const uint8_t* __restrict__ data,
                                                       const int64_t* __restrict__ offsets,
                                                       const int64_t* __restrict__ prefix,
@@ -667,11 +695,18 @@ __global__ __launch_bounds__(kBlock) void k_subs_emit(int64_t n, const uint8_t* 
                                                       int R, const uint16_t* __restrict__ rmap,
                                                       const int64_t* __restrict__ out_off,
                                                       uint8_t* __restrict__ out) {
+  __shared__ int3 stage_all[kBlock / 64][kSubsStage];  // {rstart, match start, match end}
+  extern __shared__ __align__(16) uint8_t subs_dyn[];   // the replacement map (R u16 entries)
+  uint16_t* rmap_lds = (uint16_t*)subs_dyn;
+  for (int r = threadIdx.x; r < R; r += blockDim.x) rmap_lds[r] = rmap[r];
+  __syncthreads();
   const int lane = threadIdx.x & 63;
+  int3* stage = stage_all[threadIdx.x >> 6];
   const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
   for (int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); i < n; i += nwaves) {
     const int64_t ibase = offsets[i];
-    const Text t(data + ibase, (int)(offsets[i + 1] - ibase));
+    const uint8_t* tptr = data + ibase;
+    const int tlen = (int)(offsets[i + 1] - ibase);
     const int64_t a = prefix[i];
     int64_t k64 = prefix[i + 1] - a;
     if (count > 0 && k64 > count) k64 = count;
@@ -681,7 +716,22 @@ __global__ __launch_bounds__(kBlock) void k_subs_emit(int64_t n, const uint8_t* 
     if (olen <= 0) continue;
     const int32_t* sp = spans + 2 * a;
     const int32_t* cm = cum + a;
-    auto rstart = [&](int m) { return sp[2 * m] - cm[m] + m * R; };
+    const bool staged = k <= kSubsStage;
+    __builtin_amdgcn_wave_barrier();
+    if (staged) {
+      for (int m = lane; m < k; m += 64) {
+        const int2 se = *(const int2*)(sp + 2 * m);
+        stage[m] = make_int3(se.x - cm[m] + m * R, se.x, se.y);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    auto repl_at = [&](int m) {  // {rstart, match start, match end} of replacement m
+      if (staged) return stage[m];
+      const int2 se = *(const int2*)(sp + 2 * m);
+      return make_int3(se.x - cm[m] + m * R, se.x, se.y);
+    };
     const int head = (int)((uintptr_t)(out + obase) & 15);  // output starts `head` bytes into its first 16-byte block
     for (int blk = 0; blk * 16 < head + olen; blk += 64) {
       const int p_lo = (blk + lane) * 16 - head;   // first output position of my block (may be < 0)
@@ -692,35 +742,59 @@ __global__ __launch_bounds__(kBlock) void k_subs_emit(int64_t n, const uint8_t* 
       int lo = -1, hi = k;
       while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
-        if (rstart(mid) <= p) lo = mid; else hi = mid;
+        if (repl_at(mid).x <= p) lo = mid; else hi = mid;
       }
       int j = lo;
-      int rs = j >= 0 ? rstart(j) : 0, ms = j >= 0 ? sp[2 * j] : 0, me = j >= 0 ? sp[2 * j + 1] : 0;
-      int nxt = j + 1 < k ? rstart(j + 1) : 0x7FFFFFFF;
-      uint32_t w[4] = {0, 0, 0, 0};
-      for (; p < p_hi; ++p) {
+      int3 cur = j >= 0 ? repl_at(j) : make_int3(0, 0, 0);
+      int nxt = j + 1 < k ? repl_at(j + 1).x : 0x7FFFFFFF;
+      uint64_t wlo = 0, whi = 0;   // the 16 output bytes
+      // OR `cnt` (1..16) bytes of (vlo, vhi) into the block at byte offset q
+      auto put = [&](uint64_t vlo, uint64_t vhi, int q, int cnt) {
+        if (cnt < 8) { vlo &= (1ull << (cnt * 8)) - 1; vhi = 0; }
+        else if (cnt < 16) { vhi &= (cnt == 8) ? 0ull : ((1ull << ((cnt - 8) * 8)) - 1); }
+        if (q == 0) { wlo |= vlo; whi |= vhi; }
+        else if (q < 8) { wlo |= vlo << (q * 8); whi |= (vhi << (q * 8)) | (vlo >> (64 - q * 8)); }
+        else if (q == 8) { whi |= vlo; }
+        else { whi |= vlo << ((q - 8) * 8); }
+      };
+      while (p < p_hi) {
         while (p == nxt) {   // several replacements can start here when R == 0 and matches touch
           ++j;
-          rs = nxt; ms = sp[2 * j]; me = sp[2 * j + 1];
-          nxt = j + 1 < k ? rstart(j + 1) : 0x7FFFFFFF;
+          cur = repl_at(j);
+          nxt = j + 1 < k ? repl_at(j + 1).x : 0x7FFFFFFF;
         }
-        int b;
-        if (j >= 0 && p < rs + R) {
-          const uint32_t r = rmap[p - rs];
-          b = (r & 0x8000u) ? t.at(ms + (int)(r & 0x7FFFu)) : (int)r;
-        } else {
-          b = t.at(j >= 0 ? p - (rs + R) + me : p);
+        if (j >= 0 && p < cur.x + R) {   // replacement bytes: literal, or group bytes of the match
+          int stop = cur.x + R < p_hi ? cur.x + R : p_hi;
+          if (nxt < stop) stop = nxt;
+          uint64_t mlo, mhi;
+          load16(tptr, tlen, cur.y, mlo, mhi);   // the first 16 bytes of the match
+          for (; p < stop; ++p) {
+            const uint32_t r = rmap_lds[p - cur.x];
+            int b = (int)r;
+            if (r & 0x8000u) {
+              const int o = (int)(r & 0x7FFFu);
+              b = o < 16 ? (int)(((o < 8 ? mlo : mhi) >> ((o & 7) * 8)) & 0xFFu) : (int)tptr[cur.y + o];
+            }
+            put((uint64_t)(uint32_t)b, 0, p - p_lo, 1);
+          }
+        } else {                          // kept input bytes up to the next replacement: one 16-byte fetch
+          const int src = j >= 0 ? p - (cur.x + R) + cur.z : p;
+          const int stop = nxt < p_hi ? nxt : p_hi;
+          uint64_t vlo, vhi;
+          load16(tptr, tlen, src, vlo, vhi);
+          put(vlo, vhi, p - p_lo, stop - p);
+          p = stop;
         }
-        const int q = p - p_lo;
-        w[q >> 2] |= (uint32_t)b << ((q & 3) * 8);
       }
       uint8_t* dst = out + (obase + p_lo);
       if (p_lo >= 0 && p_lo + 16 <= olen) {
-        *(uint4*)dst = make_uint4(w[0], w[1], w[2], w[3]);
+        *(uint4*)dst = make_uint4((uint32_t)wlo, (uint32_t)(wlo >> 32), (uint32_t)whi, (uint32_t)(whi >> 32));
       } else {  // block shared with a neighbouring text: byte stores only
-        for (int q = (p_lo < 0 ? -p_lo : 0); q < p_hi - p_lo; ++q) dst[q] = (uint8_t)(w[q >> 2] >> ((q & 3) * 8));
+        for (int q = (p_lo < 0 ? -p_lo : 0); q < p_hi - p_lo; ++q)
+          dst[q] = (uint8_t)((q < 8 ? wlo : whi) >> ((q & 7) * 8));
       }
     }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -1116,8 +1190,11 @@ int sub_from_spans(const mrx_handle* h, const Layout& lay, int64_t n, const std:
   HIP_TRY(hipMallocAsync((void**)&d_sizes, sizeof(int64_t) * n, s));
   HIP_TRY(hipMallocAsync((void**)&d_total, sizeof(int64_t), s));
   if (R) HIP_TRY(hipMemcpyAsync(d_rmap, rmap.data(), sizeof(uint16_t) * R, hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(k_subs_sizes, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, n, lay.offsets, d_prefix,
-                     d_spans, (long long)count, R, d_sizes, d_cum);
+  {
+    const int64_t blocks = (n + (kBlock / 64) - 1) / (kBlock / 64);
+    hipLaunchKernelGGL(k_subs_sizes, dim3((unsigned)(blocks < 65536 * 4 ? blocks : 65536 * 4)), dim3(kBlock), 0, s,
+                       n, lay.offsets, d_prefix, d_spans, (long long)count, R, d_sizes, d_cum);
+  }
   HIP_TRY(hipGetLastError());
   int rc = device_scan<int64_t>(d_sizes, n, out_off, d_total, s);
   int64_t tot = 0;
@@ -1129,8 +1206,8 @@ int sub_from_spans(const mrx_handle* h, const Layout& lay, int64_t n, const std:
       rc = fail(MRX_E_CAPACITY, "output buffer too small: need " + std::to_string(tot));
     } else if (tot > 0) {
       const int64_t blocks = (n + (kBlock / 64) - 1) / (kBlock / 64);
-      hipLaunchKernelGGL(k_subs_emit, dim3((unsigned)(blocks < 65536 * 4 ? blocks : 65536 * 4)), dim3(kBlock), 0,
-                         s, n, lay.data, lay.offsets, d_prefix, d_spans, d_cum, (long long)count, R, d_rmap,
+      hipLaunchKernelGGL(k_subs_emit, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(kBlock),
+                         (size_t)(2 * R + 16), s, n, lay.data, lay.offsets, d_prefix, d_spans, d_cum, (long long)count, R, d_rmap,
                          out_off, out);
       g_last_kernel = "k_subs_emit";
       HIP_TRY(hipGetLastError());

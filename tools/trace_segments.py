@@ -27,7 +27,7 @@ def main(root):
     if cur:
         segs.append(cur)
     for i, s in enumerate(segs):
-        if sum(len(v) for v in s.values()) < 4:
+        if sum(len(v) for v in s.values()) < 1:
             continue
         print("segment %d" % i)
         for k, v in s.items():
