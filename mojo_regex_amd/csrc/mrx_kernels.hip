@@ -1068,12 +1068,10 @@ void launch_stream(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d
                      d_nrecs, d_recs, rec_row, d_s, d_e)
   if (!strided_fast(lay)) {
     if (table) MRX_LAUNCH(2, 1);
-    else if (MODE != ST_FIRST && wide) MRX_LAUNCH(3, 1);
-    else if (MODE != ST_FIRST) MRX_LAUNCH(1, 1);
+    else if constexpr (MODE != ST_FIRST) { if (wide) MRX_LAUNCH(3, 1); else MRX_LAUNCH(1, 1); }
   } else {
     if (table) MRX_LAUNCH(2, 0);
-    else if (MODE != ST_FIRST && wide) MRX_LAUNCH(3, 0);
-    else if (MODE != ST_FIRST) MRX_LAUNCH(1, 0);
+    else if constexpr (MODE != ST_FIRST) { if (wide) MRX_LAUNCH(3, 0); else MRX_LAUNCH(1, 0); }
   }
 #undef MRX_LAUNCH
 }
