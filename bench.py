@@ -93,6 +93,9 @@ def main():
     ap.add_argument("--length", type=int, default=1024)
     ap.add_argument("--cpu-sample", type=int, default=1 << 16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="HIP streams the K steps are issued on round-robin (each with its own output "
+                         "buffers); 1 = strictly serial steps")
     ap.add_argument("--gather", action="store_true",
                     help="N > 1: also time scan + results exchange (SURVEY.md 8(e): all-gatherv of the "
                          "spans to every rank); reported as an extra object, never as `value`")
@@ -124,21 +127,33 @@ def main():
     rx = M.compile_regex(PATTERN)
     lib = M.load_library()
 
-    # preallocated outputs: no allocation of result buffers inside the timed region
-    prefix = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    # preallocated outputs: no allocation of result buffers inside the timed region.  Every step is
+    # a complete findall pass into its stream's own (prefix, spans) buffers; with --streams 2 the
+    # record decode of one step overlaps the scan of the next (two batches in flight, as a caller
+    # feeding batches continuously would run it).
     span_cap = n * 32
-    spans = torch.empty((span_cap, 2), dtype=torch.int32, device=dev)
-    out = (prefix, spans)
+    nstreams = max(1, args.streams)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
+    outs = [(torch.empty(n + 1, dtype=torch.int64, device=dev),
+             torch.empty((span_cap, 2), dtype=torch.int32, device=dev)) for _ in range(nstreams)]
+    prefix, spans = outs[0]
+    out = outs[0]
+    issued = [0]
 
     def step():
         # enqueue one full findall pass (scan kernel + prefix sums + decode); results and
         # the total stay on the device, nothing is read back inside the timed region
-        rx.findall_async(batch, out)
+        k = issued[0] % nstreams
+        issued[0] += 1
+        with torch.cuda.stream(streams[k]):
+            rx.findall_async(batch, outs[k])
 
+    torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
     D.barrier(world, dev if backend == "nccl" else None)
+    issued[0] = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -209,7 +224,8 @@ def main():
                                    "(40/30/20/10 full/tokens/noise/adversarial)" % (n, L),
                        "texts_per_gpu": n, "text_bytes": L, "pattern": PATTERN.decode(),
                        "op": "findall", "matches_per_batch": int(total),
-                       "parallelism": "texts sharded, %d rank(s), no data-path collective" % world},
+                       "parallelism": "texts sharded, %d rank(s), no data-path collective" % world,
+                       "streams": nstreams},
             "hbm_frac_of_peak_whole_step": round(value / world / HBM_PEAK_GBS, 4),
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",

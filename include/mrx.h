@@ -172,6 +172,11 @@ int mrx_sub_batch(const mrx_handle* h, const char* repl, size_t repl_len, int64_
                   int64_t* out_offsets, uint8_t* out_data, int64_t out_cap,
                   int64_t* total_bytes);
 
+/* Per-call scratch (counts, event records, block sums) is kept in a grow-only arena per calling
+ * thread and stream and reused by the next call on that stream.  mrx_release_scratch() frees the
+ * calling thread's arenas (it synchronises their streams first). */
+void mrx_release_scratch(void);
+
 /* ---- measurement hooks -------------------------------------------------------- */
 /* Average duration (ms) of the dominant scan kernel over the launches made by
  * this thread since the last reset, measured with HIP events on the launch

@@ -13,6 +13,8 @@
 //   k_scan_*           exclusive prefix sums (counts -> CSR offsets)
 // All tables are staged from the plan blob into LDS once per workgroup.
 #include <hip/hip_runtime.h>
+#include <unordered_map>
+#include <chrono>
 
 #include <cstdio>
 #include <cstring>
@@ -519,8 +521,14 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
 // scattered into an LDS tile at their final relative position and the tile is then
 // written out with fully coalesced 8-byte stores.  Per tile the stream is read once
 // (coalesced 16-byte loads; re-reads for further tiles come from L2).
-constexpr int kDecodeTile = 2048;  // spans per LDS tile and wavefront (16 KiB): one pass for typical wavefronts
-constexpr int kDecodeDirect = 3 * kDecodeTile;  // above this many spans per wavefront: one direct pass
+#ifndef MRX_DECODE_TILE
+#define MRX_DECODE_TILE 2048
+#endif
+constexpr int kDecodeTile = MRX_DECODE_TILE;  // spans per LDS tile and wavefront (16 KiB): one pass for typical wavefronts
+#ifndef MRX_DECODE_DIRECT
+#define MRX_DECODE_DIRECT (3 * kDecodeTile)
+#endif
+constexpr int kDecodeDirect = MRX_DECODE_DIRECT;  // above this many spans per wavefront: one direct pass
 constexpr int kDecodeBatch = 8;    // independent 16-byte record loads in flight per lane
 
 __global__ __launch_bounds__(kBlock) void k_decode(int64_t n, const int32_t* __restrict__ wave_nrecs,
@@ -943,6 +951,66 @@ int fail(int code, const std::string& msg) {
       return fail(MRX_E_NO_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
   } while (0)
 
+// ---- per-call scratch ------------------------------------------------------------------
+// Counts, records, block sums ... live only for one API call.  hipFreeAsync was measured to block
+// the host until the stream reaches it (296 us behind the scan kernel), which serialises host and
+// GPU; so scratch comes from a grow-only arena per (host thread, stream) instead.  Calls on one
+// stream run in order, so the next call may reuse the bytes; the arena is rewound when the last
+// allocation of a call is released and is only ever freed after synchronising its stream.
+struct ScratchArena {
+  struct Chunk { uint8_t* base; size_t cap, used; };
+  std::vector<Chunk> chunks;
+  int live = 0;
+};
+thread_local std::unordered_map<hipStream_t, ScratchArena> g_scratch;
+
+hipError_t scratch_alloc(void** out, size_t bytes, hipStream_t s) {
+  ScratchArena& a = g_scratch[s];
+  bytes = (bytes + 255) & ~(size_t)255;
+  if (bytes == 0) bytes = 256;
+  if (a.live == 0 && a.chunks.size() > 1) {  // grew during the previous call: one chunk from now on
+    size_t total = 0;
+    hipError_t e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return e;
+    for (auto& c : a.chunks) { total += c.cap; (void)hipFree(c.base); }
+    a.chunks.clear();
+    uint8_t* p = nullptr;
+    e = hipMalloc((void**)&p, total);
+    if (e != hipSuccess) return e;
+    a.chunks.push_back({p, total, 0});
+  }
+  for (auto& c : a.chunks)
+    if (c.cap - c.used >= bytes) {
+      *out = c.base + c.used;
+      c.used += bytes;
+      ++a.live;
+      return hipSuccess;
+    }
+  size_t cap = bytes;
+  if (!a.chunks.empty() && a.chunks.back().cap / 2 > cap) cap = a.chunks.back().cap / 2;
+  uint8_t* p = nullptr;
+  const hipError_t e = hipMalloc((void**)&p, cap);
+  if (e != hipSuccess) return e;
+  a.chunks.push_back({p, cap, bytes});
+  *out = p;
+  ++a.live;
+  return hipSuccess;
+}
+hipError_t scratch_free(void* p, hipStream_t s) {
+  if (!p) return hipSuccess;
+  ScratchArena& a = g_scratch[s];
+  if (a.live > 0 && --a.live == 0)
+    for (auto& c : a.chunks) c.used = 0;
+  return hipSuccess;
+}
+void scratch_release_all() {
+  for (auto& kv : g_scratch) {
+    (void)hipStreamSynchronize(kv.first);
+    for (auto& c : kv.second.chunks) (void)hipFree(c.base);
+  }
+  g_scratch.clear();
+}
+
 int ensure_device(const mrx_handle* hc) {
   mrx_handle* h = const_cast<mrx_handle*>(hc);
   static std::mutex mu;
@@ -994,14 +1062,14 @@ template <class T>
 int device_scan(const T* d_in, int64_t n, int64_t* d_prefix, int64_t* d_total, hipStream_t s) {
   const int64_t nblocks = n > 0 ? (n + kScanTile - 1) / kScanTile : 1;
   int64_t* d_bs = nullptr;
-  HIP_TRY(hipMallocAsync((void**)&d_bs, sizeof(int64_t) * nblocks, s));
+  HIP_TRY(scratch_alloc((void**)&d_bs, sizeof(int64_t) * nblocks, s));
   hipLaunchKernelGGL(k_scan_local<T>, dim3((unsigned)nblocks), dim3(kScanBlock), 0, s, d_in, n,
                      d_prefix, d_bs);
   hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, s, d_bs, nblocks, d_total);
   hipLaunchKernelGGL(k_scan_add, dim3((unsigned)nblocks), dim3(kScanBlock), 0, s, d_prefix, n,
                      d_bs, d_total);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipFreeAsync(d_bs, s));
+  HIP_TRY(scratch_free(d_bs, s));
   return MRX_OK;
 }
 
@@ -1086,8 +1154,8 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
   hipStream_t s = (hipStream_t)stream;
   int32_t* d_counts = nullptr;
   int64_t* d_total = nullptr;
-  HIP_TRY(hipMallocAsync((void**)&d_counts, sizeof(int32_t) * (n > 0 ? n : 1), s));
-  HIP_TRY(hipMallocAsync((void**)&d_total, sizeof(int64_t), s));
+  HIP_TRY(scratch_alloc((void**)&d_counts, sizeof(int32_t) * (n > 0 ? n : 1), s));
+  HIP_TRY(scratch_alloc((void**)&d_total, sizeof(int64_t), s));
   const DevPlan& p = h->hp.dev;
   const bool stream_ok = !g_force_generic && (p.flags & PF_STREAMABLE) && stream_layout_ok(lay, n);
   EvRec* d_recs = nullptr;
@@ -1110,8 +1178,8 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
         rec_row = rec_row_len(lay.lens ? lay.stride : lay.len) + (strided_fast(lay) ? 0 : 1);  // frame: one more group
         nrec = (size_t)rec_row * n;
       }
-      HIP_TRY(hipMallocAsync((void**)&d_recs, sizeof(EvRec) * nrec, s));
-      HIP_TRY(hipMallocAsync((void**)&d_nrecs, sizeof(int32_t) * nw, s));
+      HIP_TRY(scratch_alloc((void**)&d_recs, sizeof(EvRec) * nrec, s));
+      HIP_TRY(scratch_alloc((void**)&d_nrecs, sizeof(int32_t) * nw, s));
       ScanTimer tm(s);
       launch_stream<ST_RECORDS>(h, lay, n, d_counts, d_nrecs, d_recs, rec_row, nullptr, nullptr, s);
       g_last_kernel = "k_stream_findall";
@@ -1149,10 +1217,10 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
     *total = tot;
     if (tot > span_cap) rc = fail(MRX_E_CAPACITY, "span buffer too small: need " + std::to_string(tot));
   }  // total == NULL: fully asynchronous; d_counts_prefix[n] holds the total when the stream drains
-  HIP_TRY(hipFreeAsync(d_counts, s));
-  HIP_TRY(hipFreeAsync(d_total, s));
-  if (d_recs) HIP_TRY(hipFreeAsync(d_recs, s));
-  if (d_nrecs) HIP_TRY(hipFreeAsync(d_nrecs, s));
+  HIP_TRY(scratch_free(d_counts, s));
+  HIP_TRY(scratch_free(d_total, s));
+  if (d_recs) HIP_TRY(scratch_free(d_recs, s));
+  if (d_nrecs) HIP_TRY(scratch_free(d_nrecs, s));
   return rc;
 }
 
@@ -1168,25 +1236,25 @@ int sub_from_spans(const mrx_handle* h, const Layout& lay, int64_t n, const std:
   HIP_TRY(hipStreamSynchronize(s));
   int64_t* d_prefix = nullptr;
   int32_t* d_spans = nullptr;
-  HIP_TRY(hipMallocAsync((void**)&d_prefix, sizeof(int64_t) * (n + 1), s));
+  HIP_TRY(scratch_alloc((void**)&d_prefix, sizeof(int64_t) * (n + 1), s));
   int64_t cap = in_bytes / 8 + n + 64, nm = 0;
   for (int attempt = 0; attempt < 2; ++attempt) {
-    HIP_TRY(hipMallocAsync((void**)&d_spans, sizeof(int32_t) * 2 * (size_t)cap, s));
+    HIP_TRY(scratch_alloc((void**)&d_spans, sizeof(int32_t) * 2 * (size_t)cap, s));
     const int rc = run_findall(h, lay, n, d_prefix, d_spans, cap, &nm, s);
     if (rc == MRX_OK) break;
-    HIP_TRY(hipFreeAsync(d_spans, s));
+    HIP_TRY(scratch_free(d_spans, s));
     d_spans = nullptr;
-    if (rc != MRX_E_CAPACITY || attempt == 1) { (void)hipFreeAsync(d_prefix, s); return rc; }
+    if (rc != MRX_E_CAPACITY || attempt == 1) { (void)scratch_free(d_prefix, s); return rc; }
     cap = nm;
   }
   const int R = (int)rmap.size();
   uint16_t* d_rmap = nullptr;
   int32_t* d_cum = nullptr;
   int64_t *d_sizes = nullptr, *d_total = nullptr;
-  HIP_TRY(hipMallocAsync((void**)&d_rmap, sizeof(uint16_t) * (R + 8), s));
-  HIP_TRY(hipMallocAsync((void**)&d_cum, sizeof(int32_t) * (size_t)(nm + 1), s));
-  HIP_TRY(hipMallocAsync((void**)&d_sizes, sizeof(int64_t) * n, s));
-  HIP_TRY(hipMallocAsync((void**)&d_total, sizeof(int64_t), s));
+  HIP_TRY(scratch_alloc((void**)&d_rmap, sizeof(uint16_t) * (R + 8), s));
+  HIP_TRY(scratch_alloc((void**)&d_cum, sizeof(int32_t) * (size_t)(nm + 1), s));
+  HIP_TRY(scratch_alloc((void**)&d_sizes, sizeof(int64_t) * n, s));
+  HIP_TRY(scratch_alloc((void**)&d_total, sizeof(int64_t), s));
   if (R) HIP_TRY(hipMemcpyAsync(d_rmap, rmap.data(), sizeof(uint16_t) * R, hipMemcpyHostToDevice, s));
   {
     const int64_t blocks = (n + (kBlock / 64) - 1) / (kBlock / 64);
@@ -1212,12 +1280,12 @@ int sub_from_spans(const mrx_handle* h, const Layout& lay, int64_t n, const std:
       HIP_TRY(hipStreamSynchronize(s));
     }
   }
-  HIP_TRY(hipFreeAsync(d_prefix, s));
-  HIP_TRY(hipFreeAsync(d_spans, s));
-  HIP_TRY(hipFreeAsync(d_rmap, s));
-  HIP_TRY(hipFreeAsync(d_cum, s));
-  HIP_TRY(hipFreeAsync(d_sizes, s));
-  HIP_TRY(hipFreeAsync(d_total, s));
+  HIP_TRY(scratch_free(d_prefix, s));
+  HIP_TRY(scratch_free(d_spans, s));
+  HIP_TRY(scratch_free(d_rmap, s));
+  HIP_TRY(scratch_free(d_cum, s));
+  HIP_TRY(scratch_free(d_sizes, s));
+  HIP_TRY(scratch_free(d_total, s));
   return rc;
 }
 }  // namespace
@@ -1362,13 +1430,13 @@ int mrx_is_match_dev(const mrx_handle* h, const uint8_t* d, const int64_t* off, 
     // NFA-routed: is_match = match_first(text, 0) is not None (matcher.mojo:721-731)
     hipStream_t s = (hipStream_t)st;
     int32_t* tmp = nullptr;
-    HIP_TRY(hipMallocAsync((void**)&tmp, sizeof(int32_t) * 2 * n, s));
+    HIP_TRY(scratch_alloc((void**)&tmp, sizeof(int32_t) * 2 * n, s));
     int rc = run_first_any(h, Layout{d, off, 0, nullptr, 0}, n, tmp, tmp + n, st);
     if (rc == MRX_OK) {
       hipLaunchKernelGGL(k_span_to_flag, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, n, tmp, f);
       HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipFreeAsync(tmp, s));
+    HIP_TRY(scratch_free(tmp, s));
     return rc;
   }
   return run_match<OP_IS_MATCH>(h, Layout{d, off, 0, nullptr, 0}, n, nullptr, nullptr, f, st);
@@ -1462,10 +1530,10 @@ int mrx_sub_dev(const mrx_handle* h, const char* repl, size_t repl_len, int64_t 
   uint8_t* d_repl = nullptr;
   ReplSeg* d_tpl = nullptr;
   int64_t *d_sizes = nullptr, *d_total = nullptr;
-  HIP_TRY(hipMallocAsync((void**)&d_repl, r.size() + 16, s));
-  HIP_TRY(hipMallocAsync((void**)&d_tpl, sizeof(ReplSeg) * (tpl.size() + 1), s));
-  HIP_TRY(hipMallocAsync((void**)&d_sizes, sizeof(int64_t) * (n > 0 ? n : 1), s));
-  HIP_TRY(hipMallocAsync((void**)&d_total, sizeof(int64_t), s));
+  HIP_TRY(scratch_alloc((void**)&d_repl, r.size() + 16, s));
+  HIP_TRY(scratch_alloc((void**)&d_tpl, sizeof(ReplSeg) * (tpl.size() + 1), s));
+  HIP_TRY(scratch_alloc((void**)&d_sizes, sizeof(int64_t) * (n > 0 ? n : 1), s));
+  HIP_TRY(scratch_alloc((void**)&d_total, sizeof(int64_t), s));
   if (!r.empty()) HIP_TRY(hipMemcpyAsync(d_repl, r.data(), r.size(), hipMemcpyHostToDevice, s));
   if (!tpl.empty())
     HIP_TRY(hipMemcpyAsync(d_tpl, tpl.data(), sizeof(ReplSeg) * tpl.size(), hipMemcpyHostToDevice, s));
@@ -1495,10 +1563,10 @@ int mrx_sub_dev(const mrx_handle* h, const char* repl, size_t repl_len, int64_t 
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s));
   }
-  HIP_TRY(hipFreeAsync(d_repl, s));
-  HIP_TRY(hipFreeAsync(d_tpl, s));
-  HIP_TRY(hipFreeAsync(d_sizes, s));
-  HIP_TRY(hipFreeAsync(d_total, s));
+  HIP_TRY(scratch_free(d_repl, s));
+  HIP_TRY(scratch_free(d_tpl, s));
+  HIP_TRY(scratch_free(d_sizes, s));
+  HIP_TRY(scratch_free(d_total, s));
   return rc;
 }
 
@@ -1585,5 +1653,6 @@ double mrx_timing_scan_ms(int64_t* launches) {
 }
 const char* mrx_last_kernel_name(void) { return g_last_kernel; }
 void mrx_debug_force_generic(int on) { g_force_generic = on ? 1 : 0; }
+void mrx_release_scratch(void) { scratch_release_all(); }
 
 }  // extern "C"
