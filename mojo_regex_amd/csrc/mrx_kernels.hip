@@ -494,6 +494,12 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
         if (lane == 0) wave_nrecs[w] = wrec;
       }
       if (tail) ++cnt;
+      if (MODE == ST_RECORDS) {
+        // matches of the whole wavefront: the CSR offsets are built from these 1/64th as many sums
+        int wt = live ? cnt : 0;
+        for (int off = 32; off > 0; off >>= 1) wt += __shfl_xor(wt, off);
+        if (lane == 0) wave_nrecs[nwaves_total + w] = wt;
+      }
       if (MODE == ST_FIRST) {
         if (live) {
           // OnePass '$' fixup: the walk reached the end of the text alive in an end-accepting state
@@ -534,7 +540,9 @@ constexpr int kDecodeBatch = 8;    // independent 16-byte record loads in flight
 __global__ __launch_bounds__(kBlock) void k_decode(int64_t n, const int32_t* __restrict__ wave_nrecs,
                                                    const EvRec* __restrict__ recs, int64_t rec_row,
                                                    const int64_t* __restrict__ offsets,
-                                                   const int64_t* __restrict__ prefix,
+                                                   const int32_t* __restrict__ counts,
+                                                   const int64_t* __restrict__ wave_base,
+                                                   int64_t* __restrict__ prefix,
                                                    int32_t* __restrict__ spans, int64_t span_cap) {
   __shared__ int2 tile_all[kBlock / 64][kDecodeTile];
   const int lane = threadIdx.x & 63;
@@ -545,10 +553,19 @@ __global__ __launch_bounds__(kBlock) void k_decode(int64_t n, const int32_t* __r
        w += (int64_t)gridDim.x * waves_per_block) {
     const int64_t first = w << 6;
     const int64_t i = first + lane;
-    const int64_t pre0 = prefix[first];
-    const int my_rel = (int)((i < n ? prefix[i] : 0) - pre0);   // start of my text's spans in the range
-    const int64_t last1 = first + 64 < n ? first + 64 : n;
-    const int total_spans = (int)(prefix[last1] - pre0);
+    // CSR offsets of my 64 texts: exclusive scan of their counts on top of the wavefront's base
+    const int64_t pre0 = wave_base[w];
+    const int my_cnt = i < n ? counts[i] : 0;
+    int incl = my_cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int v = __shfl_up(incl, d);
+      if (lane >= d) incl += v;
+    }
+    const int my_rel = incl - my_cnt;   // start of my text's spans in the wavefront's range
+    const int total_spans = __shfl(incl, 63);
+    if (i < n) prefix[i] = pre0 + my_rel;
+    if (i == n - 1) prefix[n] = pre0 + incl;
     const int total_recs = wave_nrecs[w];
     const EvRec* wave_recs = recs + (offsets ? rec_region_start(offsets[first], w) : first * rec_row);
     if (total_spans > kDecodeDirect) {
@@ -1160,6 +1177,7 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
   const bool stream_ok = !g_force_generic && (p.flags & PF_STREAMABLE) && stream_layout_ok(lay, n);
   EvRec* d_recs = nullptr;
   int32_t* d_nrecs = nullptr;
+  int64_t* d_wbase = nullptr;
   int64_t rec_row = 0;
   if (n > 0) {
     if (stream_ok) {
@@ -1179,7 +1197,8 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
         nrec = (size_t)rec_row * n;
       }
       HIP_TRY(scratch_alloc((void**)&d_recs, sizeof(EvRec) * nrec, s));
-      HIP_TRY(scratch_alloc((void**)&d_nrecs, sizeof(int32_t) * nw, s));
+      HIP_TRY(scratch_alloc((void**)&d_nrecs, sizeof(int32_t) * 2 * nw, s));  // records | matches per wavefront
+      HIP_TRY(scratch_alloc((void**)&d_wbase, sizeof(int64_t) * (nw + 1), s));
       ScanTimer tm(s);
       launch_stream<ST_RECORDS>(h, lay, n, d_counts, d_nrecs, d_recs, rec_row, nullptr, nullptr, s);
       g_last_kernel = "k_stream_findall";
@@ -1195,14 +1214,21 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
       tm.stop();
     }
   }
-  if (int rc = device_scan<int32_t>(d_counts, n, d_prefix, d_total, s)) return rc;
+  if (stream_ok) {
+    // prefix sums over the wavefronts' totals only (n/64 values); k_decode derives the per-text
+    // offsets from its 64 counts and writes them along with the spans
+    const int64_t nw = (n + 63) / 64;
+    if (int rc = device_scan<int32_t>(d_nrecs + nw, nw, d_wbase, d_total, s)) return rc;
+    hipLaunchKernelGGL(k_decode, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, n, d_nrecs, d_recs, rec_row,
+                       lay.offsets, d_counts, d_wbase, d_prefix, d_spans, span_cap);
+    HIP_TRY(hipGetLastError());
+  } else if (int rc = device_scan<int32_t>(d_counts, n, d_prefix, d_total, s)) return rc;
   // Second stage is enqueued before the total is known on the host: both kernels clip
   // at span_cap, so a too-small buffer is reported (MRX_E_CAPACITY) without overrun and
   // the whole call needs a single stream synchronisation.
   if (n > 0 && span_cap > 0) {
     if (stream_ok) {
-      hipLaunchKernelGGL(k_decode, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, n, d_nrecs, d_recs,
-                         rec_row, lay.offsets, d_prefix, d_spans, span_cap);
+      // spans were written by k_decode above
     } else {
       hipLaunchKernelGGL(k_findall<FA_EMIT>, dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s, p,
                          h->d_blob, lay, n, (int32_t*)nullptr, d_prefix, d_spans, span_cap);
@@ -1221,6 +1247,7 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
   HIP_TRY(scratch_free(d_total, s));
   if (d_recs) HIP_TRY(scratch_free(d_recs, s));
   if (d_nrecs) HIP_TRY(scratch_free(d_nrecs, s));
+  if (d_wbase) HIP_TRY(scratch_free(d_wbase, s));
   return rc;
 }
 
