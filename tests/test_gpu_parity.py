@@ -611,3 +611,51 @@ def test_sub_from_spans_equals_generic_and_oracle(pat, repl, count):
     assert got == want
     for i in range(0, len(texts), 7):
         assert got[i] == O.sub(pat, repl, texts[i], count), (pat, repl, texts[i], count)
+
+
+@pytest.mark.parametrize("seed", [20260503, 20260504, 20260505, 20260506])
+def test_generated_patterns_results_match_oracle(seed):
+    """4 x 300 generated patterns (tests/pattern_gen.py) x 60 random texts: every operation the
+    product accepts must return the oracle's result; refusals must coincide with the oracle's."""
+    _need_gpu()
+    from pattern_gen import patterns
+    rng = np.random.default_rng(seed + 1)
+    texts = (_random_texts(rng, 25, 48, b"abcxyz019 -@.") + _random_texts(rng, 15, 160, b"abcfoobarhellocatdog0123456789 xyz@.-")
+             + _random_texts(rng, 10, 40, b"ab01") + [b"", b"a", b"foo", b"hello", b"abc123", b"foobar baz", b"cat dog",
+                                                      b"http://id.no", b"aaa", b"xyz 999", b"q" * 200 + b"1"])
+    checked = {"findall": 0, "search": 0, "match_first": 0, "refused": 0}
+    for p in patterns(seed, 300):
+        pb = p.encode()
+        try:
+            rx = M.compile_regex(pb)
+        except M.RegexSyntaxError:
+            with pytest.raises(Exception):
+                O.compile_regex(pb)
+            continue
+        for op in ("findall", "search", "match_first"):
+            try:
+                if op == "findall":
+                    got = rx.findall_lists(texts)
+                elif op == "search":
+                    s, e = rx.match_next(texts)
+                    got = [(int(a), int(b)) if a >= 0 else None for a, b in zip(s, e)]
+                else:
+                    s, e = rx.match_first(texts)
+                    got = [(int(a), int(b)) if a >= 0 else None for a, b in zip(s, e)]
+            except M.UnsupportedPattern as exc:
+                checked["refused"] += 1
+                try:
+                    for t in texts:
+                        getattr(O, op)(pb, t)
+                except UnsupportedByOracle:
+                    continue
+                # The oracle got through every text: only the two documented conservative refusals
+                # may do that -- the product refuses per pattern, the oracle per text (a literal
+                # prefilter that finds nothing never reaches the backtracker), and nibble-table
+                # false positives are modelled by the oracle for one SIMD width only.
+                assert ("literal prefilter" in str(exc)) or ("nibble-table" in str(exc)), (p, op, str(exc))
+                continue
+            for t, g in zip(texts, got):
+                assert g == getattr(O, op)(pb, t), (p, op, t)
+            checked[op] += 1
+    assert checked["findall"] > 100 and checked["match_first"] > 150, checked
