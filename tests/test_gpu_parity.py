@@ -659,3 +659,59 @@ def test_generated_patterns_results_match_oracle(seed):
                 assert g == getattr(O, op)(pb, t), (p, op, t)
             checked[op] += 1
     assert checked["findall"] > 100 and checked["match_first"] > 150, checked
+
+
+@pytest.mark.parametrize("seed", [20260601, 20260602, 20260603])
+def test_generated_patterns_streaming_equals_generic(seed):
+    """The streamability proof under fire: for every generated pattern that the plan marks
+    streamable, the single-pass kernel (findall, search, match_first, count) must equal the
+    generic restart-per-position kernels on texts built from the pattern's own alphabet."""
+    _need_gpu()
+    from pattern_gen import patterns
+    lib = M.load_library()
+    rng = np.random.default_rng(seed)
+    n, pitch = 192, 272
+    base = np.frombuffer(b"abcxyz019 -@.fobrhelcatdg", dtype=np.uint8)
+    nstream = nfirst = 0
+    for p in patterns(seed, 400):
+        pb = p.encode()
+        try:
+            rx = M.compile_regex(pb)
+        except M.RegexSyntaxError:
+            continue
+        d = rx.describe()
+        streamable = "device.streamable=yes" in d
+        first_stream = "device.first_stream=yes" in d
+        if not (streamable or first_stream):
+            continue
+        lit = np.frombuffer(bytes(c for c in pb if chr(c).isalnum() or c in b" -@."), dtype=np.uint8)
+        al = np.concatenate([base, lit, lit]) if lit.size else base
+        arr = rng.choice(al, size=(n, pitch)).astype(np.uint8)
+        for i in range(0, n, 4):     # long single-byte runs: worst case for restart-per-position
+            arr[i, : int(rng.integers(0, pitch))] = al[int(rng.integers(0, al.size))]
+        lens = rng.integers(0, pitch + 1, size=n).astype(np.int32)
+        batch = M.DeviceBatch.strided(torch.from_numpy(arr).cuda().reshape(-1), pitch,
+                                      lens=torch.from_numpy(lens).cuda())
+        if streamable:
+            nstream += 1
+            pre, sp, tot = rx._dev_findall(batch)
+            assert lib.mrx_last_kernel_name() == b"k_stream_findall"
+            ss, se = rx.match_next(batch)
+            cnt = rx.count(batch)
+        if first_stream:
+            nfirst += 1
+            fs, fe = rx.match_first(batch)
+            assert lib.mrx_last_kernel_name() == b"k_stream_first"
+        with generic_kernels():
+            if streamable:
+                gpre, gsp, gtot = rx._dev_findall(batch)
+                gss, gse = rx.match_next(batch)
+            if first_stream and "onepass=yes" not in d:
+                gfs, gfe = rx.match_first(batch)
+        if streamable:
+            assert tot == gtot and torch.equal(pre, gpre) and torch.equal(sp[:tot], gsp[:tot]), p
+            assert torch.equal(ss, gss) and torch.equal(se, gse), p
+            assert torch.equal(cnt.to(torch.int64), pre[1:] - pre[:-1]), p
+        if first_stream and "onepass=yes" not in d:
+            assert torch.equal(fs, gfs) and torch.equal(fe, gfe), p
+    assert nstream > 40 and nfirst > 150, (nstream, nfirst)
