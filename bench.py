@@ -93,6 +93,9 @@ def main():
     ap.add_argument("--length", type=int, default=1024)
     ap.add_argument("--cpu-sample", type=int, default=1 << 16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: --texts is the WHOLE job, split over the ranks by contiguous "
+                         "index ranges (dist.shard_range); default is weak scaling (--texts per GPU)")
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams the K steps are issued on round-robin (each with its own output "
                          "buffers); 1 = strictly serial steps")
@@ -122,6 +125,9 @@ def main():
         D.init(backend)
 
     n, L = args.texts, args.length
+    if args.strong:
+        lo, hi = D.shard_range(args.texts, rank, world)
+        n = hi - lo
     batch_t = make_c2_batch(n, L, seed=20260102 + rank, device=dev)
     batch = M.DeviceBatch.strided(batch_t.reshape(-1), L, length=L)
     rx = M.compile_regex(PATTERN)
@@ -218,7 +224,7 @@ def main():
             "matches_per_s": round(agg["matches"] / agg["elapsed_s"], 1),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(agg["elapsed_s"] / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": "findall [a-z]+\\d+ over %d x %d B ASCII texts per GPU "
                                    "(40/30/20/10 full/tokens/noise/adversarial)" % (n, L),
