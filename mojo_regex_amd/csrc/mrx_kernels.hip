@@ -13,6 +13,7 @@
 //   k_scan_*           exclusive prefix sums (counts -> CSR offsets)
 // All tables are staged from the plan blob into LDS once per workgroup.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <unordered_map>
 #include <chrono>
 
@@ -537,6 +538,10 @@ constexpr int kDecodeTile = MRX_DECODE_TILE;  // spans per LDS tile and wavefron
 constexpr int kDecodeDirect = MRX_DECODE_DIRECT;  // above this many spans per wavefront: one direct pass
 constexpr int kDecodeBatch = 8;    // independent 16-byte record loads in flight per lane
 
+// PACK16: every position of the batch fits 16 bits (texts of at most 65535 bytes), so a span takes
+// 4 bytes in the LDS tile instead of 8 -- half the LDS per wavefront, twice the resident
+// wavefronts for this latency-bound kernel.
+template <bool PACK16>
 __global__ __launch_bounds__(kBlock) void k_decode(int64_t n, const int32_t* __restrict__ wave_nrecs,
                                                    const EvRec* __restrict__ recs, int64_t rec_row,
                                                    const int64_t* __restrict__ offsets,
@@ -544,9 +549,10 @@ __global__ __launch_bounds__(kBlock) void k_decode(int64_t n, const int32_t* __r
                                                    const int64_t* __restrict__ wave_base,
                                                    int64_t* __restrict__ prefix,
                                                    int32_t* __restrict__ spans, int64_t span_cap) {
-  __shared__ int2 tile_all[kBlock / 64][kDecodeTile];
+  using Slot = typename std::conditional<PACK16, uint32_t, int2>::type;
+  __shared__ Slot tile_all[kBlock / 64][kDecodeTile];
   const int lane = threadIdx.x & 63;
-  int2* tile = tile_all[threadIdx.x >> 6];
+  Slot* tile = tile_all[threadIdx.x >> 6];
   const int64_t nw = (n + 63) >> 6;
   const int waves_per_block = blockDim.x >> 6;
   for (int64_t w = (int64_t)blockIdx.x * waves_per_block + (threadIdx.x >> 6); w < nw;
@@ -620,7 +626,10 @@ __global__ __launch_bounds__(kBlock) void k_decode(int64_t n, const int32_t* __r
             const int kk = __builtin_ctz(em) >> 1;              // byte of this EMIT
             const uint32_t nsb = ns & ((1u << (2 * kk)) - 1u);   // NEWSTARTs strictly before it
             const int st = nsb ? r.pos_base + ((31 - __builtin_clz(nsb)) >> 1) : r.start;
-            if (dst >= 0 && dst < kDecodeTile) tile[dst] = make_int2(st, r.pos_base + kk);
+            if (dst >= 0 && dst < kDecodeTile) {
+              if constexpr (PACK16) tile[dst] = ((uint32_t)st << 16) | (uint32_t)(r.pos_base + kk);
+              else tile[dst] = make_int2(st, r.pos_base + kk);
+            }
             ++dst;
             em &= em - 1;
           }
@@ -632,7 +641,10 @@ __global__ __launch_bounds__(kBlock) void k_decode(int64_t n, const int32_t* __r
       const int cnt = total_spans - tb < kDecodeTile ? total_spans - tb : kDecodeTile;
       for (int k = lane; k < cnt; k += 64) {
         const int64_t dst = pre0 + tb + k;
-        if (dst < span_cap) *(int2*)(spans + 2 * dst) = tile[k];
+        if (dst < span_cap) {
+          if constexpr (PACK16) { const uint32_t v = tile[k]; *(int2*)(spans + 2 * dst) = make_int2((int)(v >> 16), (int)(v & 0xFFFFu)); }
+          else *(int2*)(spans + 2 * dst) = tile[k];
+        }
       }
       __builtin_amdgcn_wave_barrier();
     }
@@ -1219,8 +1231,13 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
     // offsets from its 64 counts and writes them along with the spans
     const int64_t nw = (n + 63) / 64;
     if (int rc = device_scan<int32_t>(d_nrecs + nw, nw, d_wbase, d_total, s)) return rc;
-    hipLaunchKernelGGL(k_decode, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, n, d_nrecs, d_recs, rec_row,
-                       lay.offsets, d_counts, d_wbase, d_prefix, d_spans, span_cap);
+    const bool pack16 = !lay.offsets && (lay.lens ? lay.stride : (int64_t)lay.len) <= 65535;
+    if (pack16)
+      hipLaunchKernelGGL(k_decode<true>, dim3(grid_for(n, kBlock) * 2), dim3(kBlock), 0, s, n, d_nrecs, d_recs,
+                         rec_row, lay.offsets, d_counts, d_wbase, d_prefix, d_spans, span_cap);
+    else
+      hipLaunchKernelGGL(k_decode<false>, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, n, d_nrecs, d_recs,
+                         rec_row, lay.offsets, d_counts, d_wbase, d_prefix, d_spans, span_cap);
     HIP_TRY(hipGetLastError());
   } else if (int rc = device_scan<int32_t>(d_counts, n, d_prefix, d_total, s)) return rc;
   // Second stage is enqueued before the total is known on the host: both kernels clip
