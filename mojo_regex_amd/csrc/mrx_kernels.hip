@@ -13,6 +13,7 @@
 //   k_scan_*           exclusive prefix sums (counts -> CSR offsets)
 // All tables are staged from the plan blob into LDS once per workgroup.
 #include <hip/hip_runtime.h>
+#include <map>
 #include <type_traits>
 #include <unordered_map>
 #include <chrono>
@@ -183,6 +184,31 @@ constexpr int kStreamWaves = 4;
 #ifndef MRX_ABLATE
 #define MRX_ABLATE 0
 #endif
+// The text stream is read exactly once: non-temporal loads keep it from displacing the event
+// records (written here, read back by k_decode) in L2 / Infinity Cache.  -DMRX_NT_LOADS=0 to compare.
+#ifndef MRX_NT_LOADS
+#define MRX_NT_LOADS 1
+#endif
+typedef unsigned int mrx_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 mrx_ldg(const uint4* p) {
+#if MRX_NT_LOADS
+  const mrx_u32x4 v = __builtin_nontemporal_load((const mrx_u32x4*)p);
+  return make_uint4(v.x, v.y, v.z, v.w);
+#else
+  return *p;
+#endif
+}
+#define MRX_LDG(P) mrx_ldg(P)
+typedef int mrx_i32x2 __attribute__((ext_vector_type(2)));
+// result spans are written once and not read again by this library
+__device__ __forceinline__ void mrx_stg_span(int32_t* p, int a, int b) {
+#if MRX_NT_LOADS
+  mrx_i32x2 v; v.x = a; v.y = b;
+  __builtin_nontemporal_store(v, (mrx_i32x2*)p);
+#else
+  *(int2*)p = make_int2(a, b);
+#endif
+}
 
 struct EvRec {   // 16 bytes
   uint32_t F;
@@ -314,9 +340,9 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
             const uint4 rs_ = *(const uint4*)(tile + (RPI * j_ + rsub) * kRowPitch + CH); \
             uint32_t fo_ = cb_ + seg * 16;                                       \
             if (fo_ >= rs_.z) fo_ = 0;  /* past the frame: re-read its first block */ \
-            v[j_] = *(const uint4*)((const uint8_t*)(((uint64_t)rs_.y << 32) | rs_.x) + fo_); \
+            v[j_] = MRX_LDG((const uint4*)((const uint8_t*)(((uint64_t)rs_.y << 32) | rs_.x) + fo_)); \
           } else {                                                               \
-            v[j_] = *(const uint4*)(wbase + (roff[j_] + cb_));                   \
+            v[j_] = MRX_LDG((const uint4*)(wbase + (roff[j_] + cb_)));                   \
           }                                                                      \
         }                                                                        \
     } while (0)
@@ -642,8 +668,8 @@ __global__ __launch_bounds__(kBlock) void k_decode(int64_t n, const int32_t* __r
       for (int k = lane; k < cnt; k += 64) {
         const int64_t dst = pre0 + tb + k;
         if (dst < span_cap) {
-          if constexpr (PACK16) { const uint32_t v = tile[k]; *(int2*)(spans + 2 * dst) = make_int2((int)(v >> 16), (int)(v & 0xFFFFu)); }
-          else *(int2*)(spans + 2 * dst) = tile[k];
+          if constexpr (PACK16) { const uint32_t v = tile[k]; mrx_stg_span(spans + 2 * dst, (int)(v >> 16), (int)(v & 0xFFFFu)); }
+          else { const int2 v = tile[k]; mrx_stg_span(spans + 2 * dst, v.x, v.y); }
         }
       }
       __builtin_amdgcn_wave_barrier();
@@ -991,10 +1017,16 @@ struct ScratchArena {
   std::vector<Chunk> chunks;
   int live = 0;
 };
-thread_local std::unordered_map<hipStream_t, ScratchArena> g_scratch;
+// keyed by (device, stream): the null stream of two devices must not share an arena
+thread_local std::map<std::pair<int, hipStream_t>, ScratchArena> g_scratch;
+static ScratchArena& scratch_arena(hipStream_t s) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  return g_scratch[std::make_pair(dev, s)];
+}
 
 hipError_t scratch_alloc(void** out, size_t bytes, hipStream_t s) {
-  ScratchArena& a = g_scratch[s];
+  ScratchArena& a = scratch_arena(s);
   bytes = (bytes + 255) & ~(size_t)255;
   if (bytes == 0) bytes = 256;
   if (a.live == 0 && a.chunks.size() > 1) {  // grew during the previous call: one chunk from now on
@@ -1027,16 +1059,20 @@ hipError_t scratch_alloc(void** out, size_t bytes, hipStream_t s) {
 }
 hipError_t scratch_free(void* p, hipStream_t s) {
   if (!p) return hipSuccess;
-  ScratchArena& a = g_scratch[s];
+  ScratchArena& a = scratch_arena(s);
   if (a.live > 0 && --a.live == 0)
     for (auto& c : a.chunks) c.used = 0;
   return hipSuccess;
 }
 void scratch_release_all() {
+  int cur = 0;
+  (void)hipGetDevice(&cur);
   for (auto& kv : g_scratch) {
-    (void)hipStreamSynchronize(kv.first);
+    (void)hipSetDevice(kv.first.first);
+    (void)hipStreamSynchronize(kv.first.second);
     for (auto& c : kv.second.chunks) (void)hipFree(c.base);
   }
+  (void)hipSetDevice(cur);
   g_scratch.clear();
 }
 
