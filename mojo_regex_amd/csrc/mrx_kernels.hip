@@ -610,7 +610,10 @@ __global__ __launch_bounds__(kBlock) void k_decode(int64_t n, const int32_t* __r
         for (int u = 0; u < kDecodeBatch; ++u) {
           const int o = j + u * 64 + lane;
           rr[u].F = 0; rr[u].start = 0; rr[u].pos_base = 0; rr[u].meta = 0;
-          if (o < total_recs) rr[u] = wave_recs[o];
+          if (o < total_recs) {   // last use of the record: non-temporal
+            const uint4 q_ = mrx_ldg((const uint4*)(wave_recs + o));
+            rr[u].F = q_.x; rr[u].start = (int32_t)q_.y; rr[u].pos_base = (int32_t)q_.z; rr[u].meta = q_.w;
+          }
         }
 #pragma unroll
         for (int u = 0; u < kDecodeBatch; ++u) {
@@ -639,7 +642,10 @@ __global__ __launch_bounds__(kBlock) void k_decode(int64_t n, const int32_t* __r
         for (int u = 0; u < kDecodeBatch; ++u) {
           const int o = j + u * 64 + lane;
           rr[u].F = 0; rr[u].start = 0; rr[u].pos_base = 0; rr[u].meta = 0;
-          if (o < total_recs) rr[u] = wave_recs[o];
+          if (o < total_recs) {   // last use of the record: non-temporal
+            const uint4 q_ = mrx_ldg((const uint4*)(wave_recs + o));
+            rr[u].F = q_.x; rr[u].start = (int32_t)q_.y; rr[u].pos_base = (int32_t)q_.z; rr[u].meta = q_.w;
+          }
         }
 #pragma unroll
         for (int u = 0; u < kDecodeBatch; ++u) {
