@@ -146,6 +146,9 @@ int mrx_count_strided_dev(const mrx_handle* h, const uint8_t* d_data, int64_t st
 int mrx_captures_dev(const mrx_handle* h, const uint8_t* d_data,
                      const int64_t* d_offsets, int64_t n, int32_t* d_spans,
                      void* stream);
+int mrx_captures_strided_dev(const mrx_handle* h, const uint8_t* d_data, int64_t stride,
+                             const int32_t* d_lens, int32_t len, int64_t n, int32_t* d_spans,
+                             void* stream);
 /* regex.sub(pattern, repl, text, count), matcher.mojo:1679-1854.
  * d_out_offsets[n+1] (CSR of output bytes), d_out_data (capacity out_cap bytes).
  * Synchronises once to return *total_bytes; MRX_E_CAPACITY if it exceeds out_cap. */

@@ -78,6 +78,7 @@ def load_library():
                                               i32p, C.c_int64, C.POINTER(C.c_int64), C.c_void_p]),
         "mrx_count_dev": (C.c_int, [H, u8p, i64p, C.c_int64, i32p, C.c_void_p]),
         "mrx_count_strided_dev": (C.c_int, [H, u8p, C.c_int64, i32p, C.c_int32, C.c_int64, i32p, C.c_void_p]),
+        "mrx_captures_strided_dev": (C.c_int, [H, u8p, C.c_int64, i32p, C.c_int32, C.c_int64, i32p, C.c_void_p]),
         "mrx_captures_dev": (C.c_int, [H, u8p, i64p, C.c_int64, i32p, C.c_void_p]),
         "mrx_sub_dev": (C.c_int, [H, C.c_char_p, C.c_size_t, C.c_int64, u8p, i64p, C.c_int64, i64p,
                                   u8p, C.c_int64, C.POINTER(C.c_int64), C.c_void_p]),
@@ -109,7 +110,8 @@ EXPORTED_SYMBOLS = [
     "mrx_compile", "mrx_compile_ex", "mrx_free", "mrx_last_error", "mrx_engine_type", "mrx_stats", "mrx_describe",
     "mrx_num_groups", "mrx_match_first_dev", "mrx_search_dev", "mrx_match_first_strided_dev",
     "mrx_search_strided_dev", "mrx_is_match_dev",
-    "mrx_findall_dev", "mrx_findall_strided_dev", "mrx_count_dev", "mrx_count_strided_dev", "mrx_captures_dev",
+    "mrx_findall_dev", "mrx_findall_strided_dev", "mrx_count_dev", "mrx_count_strided_dev",
+    "mrx_captures_strided_dev", "mrx_captures_dev",
     "mrx_sub_dev", "mrx_match_first_batch", "mrx_search_batch", "mrx_is_match_batch",
     "mrx_findall_batch", "mrx_captures_batch", "mrx_sub_batch", "mrx_timing_reset",
     "mrx_timing_enable", "mrx_timing_scan_ms", "mrx_last_kernel_name", "mrx_version", "mrx_debug_force_generic", "mrx_release_scratch",
@@ -320,6 +322,19 @@ class CompiledRegex:
             _check(rc)
             raw = out[: total.value].tobytes()
             return [raw[out_off[i]:out_off[i + 1]] for i in range(n)]
+
+    def captures_dev(self, batch: "DeviceBatch"):
+        """search + capture groups on a device-resident batch: int32[n, g+1, 2] (device tensor)."""
+        import torch
+        g = self.num_groups
+        out = torch.empty((batch.n, g + 1, 2), dtype=torch.int32, device=batch.data.device)
+        if batch.offsets is not None:
+            _check(self._lib.mrx_captures_dev(self._h, _ptr(batch.data), _ptr(batch.offsets), batch.n, _ptr(out),
+                                              self._stream_ptr()))
+        else:
+            _check(self._lib.mrx_captures_strided_dev(self._h, _ptr(batch.data), batch.stride, _ptr(batch.lens),
+                                                      batch.length, batch.n, _ptr(out), self._stream_ptr()))
+        return out
 
     def sub_dev(self, repl, batch: "DeviceBatch", count: int = 0, out_cap: Optional[int] = None):
         """regex.sub on a device-resident CSR batch: (out_offsets int64[n+1], out_data uint8[total])."""

@@ -111,6 +111,26 @@ __global__ __launch_bounds__(kBlock) void k_match(DevPlan p, const uint8_t* __re
   }
 }
 
+// captures from a search result: groups 1..g at their fixed offsets, then the whole match
+// (NFAEngine._match_group order, nfa.mojo:1057-1103), -1 everywhere when the text has no match
+__global__ void k_expand_captures(DevPlan p, int64_t n, const int32_t* __restrict__ start,
+                                  const int32_t* __restrict__ end, int32_t* __restrict__ out) {
+  const int g = p.fixed_ngroups;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    int32_t* o = out + i * (int64_t)(g + 1) * 2;
+    const int ms = start[i], me = end[i];
+    if (ms >= 0) {
+      for (int k = 1; k <= g; ++k) {
+        o[(k - 1) * 2] = ms + p.fixed_off[k];
+        o[(k - 1) * 2 + 1] = ms + p.fixed_off[k] + p.fixed_w[k];
+      }
+      o[g * 2] = ms; o[g * 2 + 1] = me;
+    } else {
+      for (int k = 0; k < (g + 1) * 2; ++k) o[k] = -1;
+    }
+  }
+}
+
 __global__ void k_span_to_flag(int64_t n, const int32_t* __restrict__ start, uint8_t* __restrict__ flag) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     flag[i] = start[i] >= 0 ? 1 : 0;
@@ -1527,9 +1547,33 @@ int mrx_is_match_dev(const mrx_handle* h, const uint8_t* d, const int64_t* off, 
   }
   return run_match<OP_IS_MATCH>(h, Layout{d, off, 0, nullptr, 0}, n, nullptr, nullptr, f, st);
 }
+static int run_captures_any(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* spans, void* st) {
+  if (!h) return fail(MRX_E_ARGUMENT, "null handle");
+  if (g_force_generic || !(h->hp.dev.flags & PF_STREAMABLE) || h->hp.fixed_total < 0 || n <= 0)
+    return run_match<OP_CAPTURES>(h, lay, n, spans, nullptr, nullptr, st);
+  // streamable plan: search on the streaming kernel, then the groups at their fixed offsets
+  hipStream_t s = (hipStream_t)st;
+  int32_t* tmp = nullptr;
+  HIP_TRY(scratch_alloc((void**)&tmp, sizeof(int32_t) * 2 * n, s));
+  int rc = run_search_any(h, lay, n, tmp, tmp + n, st);
+  if (rc == MRX_OK) {
+    hipLaunchKernelGGL(k_expand_captures, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, h->hp.dev, n, tmp,
+                       tmp + n, spans);
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(scratch_free(tmp, s));
+  return rc;
+}
 int mrx_captures_dev(const mrx_handle* h, const uint8_t* d, const int64_t* off, int64_t n,
                      int32_t* spans, void* st) {
-  return run_match<OP_CAPTURES>(h, Layout{d, off, 0, nullptr, 0}, n, spans, nullptr, nullptr, st);
+  if (!off) return fail(MRX_E_ARGUMENT, "null offsets");
+  return run_captures_any(h, Layout{d, off, 0, nullptr, 0}, n, spans, st);
+}
+int mrx_captures_strided_dev(const mrx_handle* h, const uint8_t* d, int64_t stride, const int32_t* lens,
+                             int32_t len, int64_t n, int32_t* spans, void* st) {
+  if (stride <= 0) return fail(MRX_E_ARGUMENT, "stride must be positive");
+  if (!lens && (len < 0 || len > stride)) return fail(MRX_E_ARGUMENT, "len must be in [0, stride]");
+  return run_captures_any(h, Layout{d, nullptr, stride, lens, len}, n, spans, st);
 }
 int mrx_findall_dev(const mrx_handle* h, const uint8_t* d, const int64_t* off, int64_t n,
                     int64_t* prefix, int32_t* spans, int64_t cap, int64_t* total, void* st) {

@@ -95,6 +95,13 @@ def test_config4_phone_groups_at_full_size():
     has = counts > 0
     first[has] = spans[prefix[:-1][has], 0]
     assert bool((s == first).all())
+    # captures of the whole batch on the device (streaming search + fixed offsets)
+    cd_ = rx.captures_dev(batch)
+    ok = s >= 0
+    assert bool((cd_[:, 3, 0] == s).all()) and bool((cd_[:, 3, 1] == e).all())
+    assert bool((cd_[ok][:, 0, 0] == s[ok]).all()) and bool((cd_[ok][:, 0, 1] == s[ok] + 3).all())
+    assert bool((cd_[ok][:, 1, 1] == s[ok] + 6).all()) and bool((cd_[ok][:, 2, 1] == s[ok] + 10).all())
+    assert bool((cd_[~ok] == -1).all())
     sub = d[:4096].cpu().numpy()
     caps = rx.captures([r.tobytes() for r in sub])
     s_h = s[:4096].cpu().numpy()
