@@ -171,6 +171,32 @@ class DeviceBatch:
         d = torch.from_numpy(data).to(device) if data.size else torch.zeros(0, dtype=torch.uint8, device=device)
         return cls(d, torch.from_numpy(offsets).to(device))
 
+    @classmethod
+    def from_arrow(cls, arr, device="cuda"):
+        """Batch from a pyarrow LargeBinary / LargeString array: the array's
+        two buffers ARE the packed form of the C ABI -- text bytes back to back and int64
+        offsets[n+1] -- so they are uploaded as they stand (a sliced array keeps its offsets; the
+        data buffer is cut to the referenced range).  Nulls are treated as empty texts."""
+        import numpy as np
+        import pyarrow as pa
+        import torch
+        if isinstance(arr, pa.ChunkedArray):
+            arr = arr.combine_chunks()
+        if pa.types.is_binary(arr.type) or pa.types.is_string(arr.type):
+            arr = arr.cast(pa.large_binary())
+        if not (pa.types.is_large_binary(arr.type) or pa.types.is_large_string(arr.type)):
+            raise MrxError("from_arrow needs a (large_)binary or (large_)string array")
+        if arr.null_count:
+            arr = arr.fill_null(b"")
+        bufs = arr.buffers()   # [validity, offsets, data]
+        n = len(arr)
+        offs = np.frombuffer(bufs[1], dtype=np.int64, count=n + 1, offset=arr.offset * 8).copy()
+        lo, hi = int(offs[0]), int(offs[-1])
+        data = np.frombuffer(bufs[2], dtype=np.uint8, count=hi - lo, offset=lo) if hi > lo else np.zeros(0, np.uint8)
+        offs -= lo
+        d = torch.from_numpy(data.copy()).to(device) if data.size else torch.zeros(0, dtype=torch.uint8, device=device)
+        return cls(d, torch.from_numpy(offs).to(device))
+
     def csr_offsets(self):
         """CSR offsets for the generic kernels (built on device for strided batches)."""
         import torch

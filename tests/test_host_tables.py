@@ -106,3 +106,21 @@ def test_out_of_scope_patterns_fail_loudly_without_a_gpu():
         M.CompiledRegex("[abc")
     with pytest.raises(M.RegexSyntaxError, match="Unescaped closing parenthesis"):
         M.CompiledRegex("a)")
+
+
+def test_arrow_large_binary_is_the_packed_batch_form():
+    """an Arrow LargeBinary array's (offsets, data) buffers are the C ABI's
+    packed batch form; slices and nulls included (CPU tensors here, no GPU needed)."""
+    import numpy as np
+    import pyarrow as pa
+    texts = [b"hello123", b"", b"world456 test789", None, b"x"]
+    arr = pa.array(texts, type=pa.large_binary())
+    b = M.DeviceBatch.from_arrow(arr, device="cpu")
+    want = [t or b"" for t in texts]
+    data, offsets = api.pack_texts(want)
+    assert b.n == 5 and np.array_equal(b.offsets.numpy(), offsets) and np.array_equal(b.data.numpy(), data)
+    sl = M.DeviceBatch.from_arrow(arr.slice(2, 3), device="cpu")
+    d2, o2 = api.pack_texts(want[2:5])
+    assert np.array_equal(sl.offsets.numpy(), o2) and np.array_equal(sl.data.numpy(), d2)
+    st = M.DeviceBatch.from_arrow(pa.array(["ab12", "cd"]), device="cpu")   # plain string array
+    assert st.offsets.tolist() == [0, 4, 6] and bytes(st.data.numpy().tobytes()) == b"ab12cd"
