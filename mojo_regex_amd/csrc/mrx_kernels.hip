@@ -1477,7 +1477,7 @@ static int run_search_any(const mrx_handle* h, const Layout& lay, int64_t n, int
                           void* st) {
   if (!h) return fail(MRX_E_ARGUMENT, "null handle");
   const DevPlan& p = h->hp.dev;
-  if (g_force_generic || !(p.flags & PF_STREAMABLE) || !stream_layout_ok(lay, n))
+  if (g_force_generic || !(p.flags & PF_STREAM_SEARCH) || !stream_layout_ok(lay, n))
     return run_match<OP_SEARCH>(h, lay, n, ds, de, nullptr, st);
   if (int rc = check_search_supported(h)) return rc;
   if (int rc = ensure_device(h)) return rc;
@@ -1549,7 +1549,7 @@ int mrx_is_match_dev(const mrx_handle* h, const uint8_t* d, const int64_t* off, 
 }
 static int run_captures_any(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* spans, void* st) {
   if (!h) return fail(MRX_E_ARGUMENT, "null handle");
-  if (g_force_generic || !(h->hp.dev.flags & PF_STREAMABLE) || h->hp.fixed_total < 0 || n <= 0)
+  if (g_force_generic || !(h->hp.dev.flags & PF_STREAM_SEARCH) || h->hp.fixed_total < 0 || n <= 0)
     return run_match<OP_CAPTURES>(h, lay, n, spans, nullptr, nullptr, st);
   // streamable plan: search on the streaming kernel, then the groups at their fixed offsets
   hipStream_t s = (hipStream_t)st;
@@ -1639,7 +1639,7 @@ int mrx_sub_dev(const mrx_handle* h, const char* repl, size_t repl_len, int64_t 
   if (int rc = check_lds(h)) return rc;
   if (int rc = ensure_device(h)) return rc;
   hipStream_t s = (hipStream_t)st;
-  if (!g_force_generic && (h->hp.dev.flags & PF_STREAMABLE) && n > 0 && off) {
+  if (!g_force_generic && (h->hp.dev.flags & PF_STREAM_SEARCH) && n > 0 && off) {
     // replacement as a fixed-length byte map
     std::vector<uint16_t> rmap;
     if (groups) {

@@ -519,7 +519,7 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
   else if (d.flags & PF_START_DEAD) hp.streamable_why_not = "dead start state";
   else if (d.flags & PF_BITSET) hp.streamable_why_not = "bitset NFA walk (no determinised table)";
   else if (d.flags & (PF_START_ANCHOR | PF_END_ANCHOR)) hp.streamable_why_not = "anchored";
-  else if (d.flags & (PF_EXACT_LITERAL | PF_PREFILTER)) hp.streamable_why_not = "exact-literal / prefilter path";
+  else if (d.flags & PF_EXACT_LITERAL) hp.streamable_why_not = "exact-literal path";
   else if (d.required_byte >= 0) hp.streamable_why_not = "required-byte findall path";
   else if (!hp.why_no_search.empty()) hp.streamable_why_not = hp.why_no_search;
   else {
@@ -563,7 +563,7 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
       d.st_accept_mask = 0;
       std::vector<uint16_t> cols;
       if (build_stream_cols(sa, remap, nlive, cols)) {
-        d.flags |= PF_STREAMABLE;
+        d.flags |= PF_STREAMABLE | ((d.flags & PF_PREFILTER) ? 0u : (uint32_t)PF_STREAM_SEARCH);
         d.st_kind = 1;
         for (int q = 0; q < sa.n; ++q)
           if (remap[q] >= 0 && sa.acc[q]) d.st_accept_mask |= 1u << remap[q];
@@ -578,7 +578,7 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
         for (int c = 0; c < 256; ++c)
           for (int q = 0; q < nlive; ++q)
             cols64[c] |= (uint64_t)((((E[q][c] >> 2) << 3) | (E[q][c] & 3)) & 0xFF) << (8 * q);
-        d.flags |= PF_STREAMABLE;
+        d.flags |= PF_STREAMABLE | ((d.flags & PF_PREFILTER) ? 0u : (uint32_t)PF_STREAM_SEARCH);
         d.st_kind = 3;
         for (int q = 0; q < sa.n; ++q)
           if (remap[q] >= 0 && sa.acc[q]) d.st_accept_mask |= 1u << remap[q];
@@ -615,7 +615,7 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
           std::vector<uint8_t> sacc(nlive, 0);
           for (int q = 0; q < sa.n; ++q)
             if (remap[q] >= 0) sacc[remap[q]] = sa.acc[q];
-          d.flags |= PF_STREAMABLE;
+          d.flags |= PF_STREAMABLE | ((d.flags & PF_PREFILTER) ? 0u : (uint32_t)PF_STREAM_SEARCH);
           d.st_kind = 2;
           d.st_cshift = cshift;
           align(hp.blob, 16);
@@ -803,7 +803,8 @@ std::string describe_plan(const HostPlan& hp) {
   o << "device.kind=" << d.kind << " nstates=" << d.nstates << " ncls=" << d.ncls
     << " flags=0x" << std::hex << d.flags << std::dec << " blob_bytes=" << d.blob_bytes << "\n";
   o << "device.streamable=" << ((d.flags & PF_STREAMABLE) ? "yes" : ("no: " + hp.streamable_why_not))
-    << " st_nstates=" << d.st_nstates << " st_kind=" << d.st_kind << "\n";
+    << " st_nstates=" << d.st_nstates << " st_kind=" << d.st_kind
+    << (((d.flags & PF_STREAMABLE) && !(d.flags & PF_STREAM_SEARCH)) ? " findall_only=1" : "") << "\n";
   o << "device.first_stream=" << (d.fa_bytes ? "yes" : ("no: " + hp.first_stream_why_not))
     << " fa_nstates=" << d.fa_nstates << (hp.first_onepass ? " onepass=yes" : "") << "\n";
   if (d.flags & PF_BITSET)

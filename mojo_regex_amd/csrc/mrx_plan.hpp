@@ -31,7 +31,10 @@ enum PlanFlags : uint32_t {
   PF_PREFILTER = 1u << 7,       // HybridMatcher.prefilter && !has_anchors
   PF_START_DEAD = 1u << 8,      // LazyDFA start state is LAZY_DFA_DEAD
   PF_STREAMABLE = 1u << 9,      // findall can run on the single-pass streaming kernel
-  PF_BITSET = 1u << 10          // PLAN_LAZY walks run on the bitset NFA instead of the DFA table
+  PF_BITSET = 1u << 10,         // PLAN_LAZY walks run on the bitset NFA instead of the DFA table
+  PF_STREAM_SEARCH = 1u << 11   // search / sub / captures may use the streaming kernel too (findall and
+                                // count may whenever PF_STREAMABLE is set): not with a memchr prefilter,
+                                // which only match_next consults (matcher.mojo:784-796)
 };
 
 constexpr int kMaxTemplateSegs = 32;
