@@ -514,6 +514,7 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
             const uint32_t nsb = ns & ((1u << (2 * kk)) - 1u);
             res_s = nsb ? gbase + ((31 - __builtin_clz(nsb)) >> 1) : start;
             res_e = gbase + kk;
+            if (p.st_fixed_len > 0) res_s = res_e - p.st_fixed_len;   // exact-literal automaton
             done = true;
           }
         }
@@ -556,7 +557,7 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
         }
       } else if (MODE == ST_SEARCH) {
         if (live) {
-          if (!done && tail) { res_s = start; res_e = my_len; }
+          if (!done && tail) { res_s = p.st_fixed_len > 0 ? my_len - p.st_fixed_len : start; res_e = my_len; }
           out_s[my_text] = res_s;
           out_e[my_text] = res_e;
         }
@@ -594,7 +595,8 @@ __global__ __launch_bounds__(kBlock) void k_decode(int64_t n, const int32_t* __r
                                                    const int32_t* __restrict__ counts,
                                                    const int64_t* __restrict__ wave_base,
                                                    int64_t* __restrict__ prefix,
-                                                   int32_t* __restrict__ spans, int64_t span_cap) {
+                                                   int32_t* __restrict__ spans, int64_t span_cap,
+                                                   int fixed_len) {
   using Slot = typename std::conditional<PACK16, uint32_t, int2>::type;
   __shared__ Slot tile_all[kBlock / 64][kDecodeTile];
   const int lane = threadIdx.x & 63;
@@ -645,7 +647,8 @@ __global__ __launch_bounds__(kBlock) void k_decode(int64_t n, const int32_t* __r
           while (em) {
             const int kk = __builtin_ctz(em) >> 1;
             const uint32_t nsb = ns & ((1u << (2 * kk)) - 1u);
-            const int st = nsb ? r.pos_base + ((31 - __builtin_clz(nsb)) >> 1) : r.start;
+            int st = nsb ? r.pos_base + ((31 - __builtin_clz(nsb)) >> 1) : r.start;
+            if (fixed_len > 0) st = r.pos_base + kk - fixed_len;
             if (dst < span_cap) *(int2*)(spans + 2 * dst) = make_int2(st, r.pos_base + kk);
             ++dst;
             em &= em - 1;
@@ -677,7 +680,8 @@ __global__ __launch_bounds__(kBlock) void k_decode(int64_t n, const int32_t* __r
           while (em) {
             const int kk = __builtin_ctz(em) >> 1;              // byte of this EMIT
             const uint32_t nsb = ns & ((1u << (2 * kk)) - 1u);   // NEWSTARTs strictly before it
-            const int st = nsb ? r.pos_base + ((31 - __builtin_clz(nsb)) >> 1) : r.start;
+            int st = nsb ? r.pos_base + ((31 - __builtin_clz(nsb)) >> 1) : r.start;
+            if (fixed_len > 0) st = r.pos_base + kk - fixed_len;
             if (dst >= 0 && dst < kDecodeTile) {
               if constexpr (PACK16) tile[dst] = ((uint32_t)st << 16) | (uint32_t)(r.pos_base + kk);
               else tile[dst] = make_int2(st, r.pos_base + kk);
@@ -1296,10 +1300,10 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
     const bool pack16 = !lay.offsets && (lay.lens ? lay.stride : (int64_t)lay.len) <= 65535;
     if (pack16)
       hipLaunchKernelGGL(k_decode<true>, dim3(grid_for(n, kBlock) * 2), dim3(kBlock), 0, s, n, d_nrecs, d_recs,
-                         rec_row, lay.offsets, d_counts, d_wbase, d_prefix, d_spans, span_cap);
+                         rec_row, lay.offsets, d_counts, d_wbase, d_prefix, d_spans, span_cap, p.st_fixed_len);
     else
       hipLaunchKernelGGL(k_decode<false>, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, n, d_nrecs, d_recs,
-                         rec_row, lay.offsets, d_counts, d_wbase, d_prefix, d_spans, span_cap);
+                         rec_row, lay.offsets, d_counts, d_wbase, d_prefix, d_spans, span_cap, p.st_fixed_len);
     HIP_TRY(hipGetLastError());
   } else if (int rc = device_scan<int32_t>(d_counts, n, d_prefix, d_total, s)) return rc;
   // Second stage is enqueued before the total is known on the host: both kernels clip
@@ -1639,7 +1643,8 @@ int mrx_sub_dev(const mrx_handle* h, const char* repl, size_t repl_len, int64_t 
   if (int rc = check_lds(h)) return rc;
   if (int rc = ensure_device(h)) return rc;
   hipStream_t s = (hipStream_t)st;
-  if (!g_force_generic && (h->hp.dev.flags & PF_STREAM_SEARCH) && n > 0 && off) {
+  if (!g_force_generic && (h->hp.dev.flags & PF_STREAM_SEARCH) && !(h->hp.dev.flags & PF_EXACT_LITERAL) && n > 0 &&
+      off) {   // (exact literals: findall spans overlap, sub's own search loop does not)
     // replacement as a fixed-length byte map
     std::vector<uint16_t> rmap;
     if (groups) {

@@ -168,33 +168,6 @@ bool check_streamable(const SearchAutomaton& s, std::string& why) {
   return true;
 }
 
-// Build the byte-column table for the 4-state streaming kernel:
-// col[byte] = 4 entries x 4 bit, entry(q) = next<<2 | EMIT<<1 | NEWSTART
-bool build_stream_cols(const SearchAutomaton& s, const std::vector<int>& remap, int nlive,
-                       std::vector<uint16_t>& cols) {
-  if (nlive > 4) return false;
-  cols.assign(256, 0);
-  for (int c = 0; c < 256; ++c) {
-    uint16_t col = 0;
-    for (int q = 0; q < s.n; ++q) {
-      if (remap[q] < 0) continue;
-      int t = (q == 0) ? (s.allowed[c] ? s.next[0][c] : -1) : s.next[q][c];
-      bool emit = false, newstart = false;
-      if (q == 0) {
-        newstart = t > 0;
-      } else if (t < 0) {  // walk dies: emit if it had accepted, then restart on this byte
-        emit = s.acc[q] != 0;
-        t = s.allowed[c] ? s.next[0][c] : -1;
-        newstart = t > 0;
-      }
-      const int tn = t > 0 ? remap[t] : 0;
-      col |= (uint16_t)(((tn << 2) | (emit ? 2 : 0) | (newstart ? 1 : 0)) << (4 * remap[q]));
-    }
-    cols[c] = col;
-  }
-  return true;
-}
-
 // Entry matrix of the search automaton over live states: next<<2 | EMIT<<1 | NEWSTART
 std::vector<std::array<uint16_t, 256>> stream_entries(const SearchAutomaton& s,
                                                       const std::vector<int>& remap, int nlive) {
@@ -515,11 +488,114 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
   d.off_stcol = -1;
   hp.streamable_why_not.clear();
   d.st_kind = 0;
+  d.st_fixed_len = 0;
+  // Tables of a search automaton given as an entry matrix over its live states
+  // (E[q][byte] = next << 2 | EMIT << 1 | NEWSTART) and their accept flags; picks the form.
+  auto emit_stream_tables = [&](const std::vector<std::array<uint16_t, 256>>& E,
+                                const std::vector<uint8_t>& live_acc) {
+    const int nlive = (int)E.size();
+    const uint32_t fl = PF_STREAMABLE | ((d.flags & PF_PREFILTER) ? 0u : (uint32_t)PF_STREAM_SEARCH);
+    d.st_nstates = nlive;
+    d.st_accept_mask = 0;
+    for (int q = 0; q < nlive && q < 32; ++q)
+      if (live_acc[q]) d.st_accept_mask |= 1u << q;
+    if (nlive <= 4) {
+      // byte-column form: col[byte] = 4 entries x 4 bit
+      std::vector<uint16_t> cols(256, 0);
+      for (int c = 0; c < 256; ++c)
+        for (int q = 0; q < nlive; ++q) cols[c] |= (uint16_t)((E[q][c] & 0xF) << (4 * q));
+      d.flags |= fl;
+      d.st_kind = 1;
+      align(hp.blob, 4);
+      d.off_stcol = (int)hp.blob.size();
+      put(hp.blob, cols.data(), 512);
+    } else if (nlive <= 8) {
+      // wide byte-column form: 8 states x 8-bit fields in a u64 column,
+      // field(q) = next << 3 | EMIT << 1 | NEWSTART, so "field & 0x38" is the next shift amount
+      std::vector<uint64_t> cols64(256, 0);
+      for (int c = 0; c < 256; ++c)
+        for (int q = 0; q < nlive; ++q)
+          cols64[c] |= (uint64_t)((((E[q][c] >> 2) << 3) | (E[q][c] & 3)) & 0xFF) << (8 * q);
+      d.flags |= fl;
+      d.st_kind = 3;
+      align(hp.blob, 16);
+      d.off_stcol = (int)hp.blob.size();
+      put(hp.blob, cols64.data(), 2048);
+    } else {
+      // class-table form: any number of live states that fits u16 entries and LDS
+      std::array<uint8_t, 256> scls{};
+      int sncls = 0;
+      {
+        std::map<std::vector<uint16_t>, int> seen;
+        for (int c = 0; c < 256; ++c) {
+          std::vector<uint16_t> col(nlive);
+          for (int q = 0; q < nlive; ++q) col[q] = E[q][c];
+          auto it = seen.find(col);
+          if (it == seen.end()) it = seen.emplace(col, sncls++).first;
+          scls[c] = (uint8_t)it->second;
+        }
+      }
+      int cshift = 0;
+      while ((1 << cshift) < sncls) ++cshift;
+      const int ncp = 1 << cshift;
+      if ((int64_t)nlive * ncp > 8192) {
+        hp.streamable_why_not = "search automaton too large for the streaming kernel's LDS table";
+        return;
+      }
+      std::vector<uint16_t> tr((size_t)nlive * ncp, 0);
+      for (int c = 0; c < 256; ++c)
+        for (int q = 0; q < nlive; ++q) {
+          const uint16_t e = E[q][c];
+          tr[(size_t)q * ncp + scls[c]] = (uint16_t)((((e >> 2) << cshift) << 2) | (e & 3));
+        }
+      d.flags |= fl;
+      d.st_kind = 2;
+      d.st_cshift = cshift;
+      align(hp.blob, 16);
+      const int begin = (int)hp.blob.size();
+      d.off_stg_cls = begin;
+      put(hp.blob, scls.data(), 256);
+      d.off_stg_trans = (int)hp.blob.size();
+      put(hp.blob, tr.data(), tr.size() * 2);
+      d.off_stg_acc = (int)hp.blob.size();
+      put(hp.blob, live_acc.data(), live_acc.size());
+      align(hp.blob, 16);
+      d.stg_bytes = (int)hp.blob.size() - begin;
+    }
+  };
   if (d.kind == PLAN_ANY) hp.streamable_why_not = "'.*' shortcut";
+  else if (d.flags & PF_EXACT_LITERAL) {
+    // HybridMatcher's exact-literal bypass (matcher.mojo:768-781, 815-847): search = first
+    // occurrence, findall = EVERY occurrence, overlapping ones included (start = pos + 1).  That
+    // is the KMP automaton of the literal: state = length of the matched prefix, the full state L
+    // emits on the byte that follows it (or at the end of the text) and continues through its
+    // failure link; a match is [end - L, end), so no start tracking is needed.
+    const std::string& lit_ = exact_lit;
+    const int Ln = (int)lit_.size();
+    if (Ln == 0 || Ln > 4000) hp.streamable_why_not = "exact literal too long for the streaming tables";
+    else {
+      std::vector<std::array<int, 256>> delta(Ln + 1);
+      std::vector<int> fail(Ln + 1, 0);
+      for (int c = 0; c < 256; ++c) delta[0][c] = ((unsigned char)lit_[0] == c) ? 1 : 0;
+      for (int q = 1; q <= Ln; ++q) {
+        // fail[q] = state reached by the text lit[1..q) ; standard KMP automaton construction
+        fail[q] = (q == 1) ? 0 : delta[fail[q - 1]][(unsigned char)lit_[q - 1]];
+        for (int c = 0; c < 256; ++c)
+          delta[q][c] = (q < Ln && (unsigned char)lit_[q] == c) ? q + 1 : delta[fail[q]][c];
+      }
+      std::vector<std::array<uint16_t, 256>> E(Ln + 1);
+      std::vector<uint8_t> live_acc(Ln + 1, 0);
+      live_acc[Ln] = 1;
+      for (int q = 0; q <= Ln; ++q)
+        for (int c = 0; c < 256; ++c) E[q][c] = (uint16_t)((delta[q][c] << 2) | (q == Ln ? 2 : 0));
+      d.st_fixed_len = Ln;
+      emit_stream_tables(E, live_acc);
+      if (!(d.flags & PF_STREAMABLE)) d.st_fixed_len = 0;
+    }
+  }
   else if (d.flags & PF_START_DEAD) hp.streamable_why_not = "dead start state";
   else if (d.flags & PF_BITSET) hp.streamable_why_not = "bitset NFA walk (no determinised table)";
   else if (d.flags & (PF_START_ANCHOR | PF_END_ANCHOR)) hp.streamable_why_not = "anchored";
-  else if (d.flags & PF_EXACT_LITERAL) hp.streamable_why_not = "exact-literal path";
   else if (d.required_byte >= 0) hp.streamable_why_not = "required-byte findall path";
   else if (!hp.why_no_search.empty()) hp.streamable_why_not = hp.why_no_search;
   else {
@@ -559,77 +635,10 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
           if (t > 0 && remap[t] < 0) { remap[t] = nlive++; st.push_back(t); }
         }
       }
-      d.st_nstates = nlive;
-      d.st_accept_mask = 0;
-      std::vector<uint16_t> cols;
-      if (build_stream_cols(sa, remap, nlive, cols)) {
-        d.flags |= PF_STREAMABLE | ((d.flags & PF_PREFILTER) ? 0u : (uint32_t)PF_STREAM_SEARCH);
-        d.st_kind = 1;
-        for (int q = 0; q < sa.n; ++q)
-          if (remap[q] >= 0 && sa.acc[q]) d.st_accept_mask |= 1u << remap[q];
-        align(hp.blob, 4);
-        d.off_stcol = (int)hp.blob.size();
-        put(hp.blob, cols.data(), 512);
-      } else if (nlive <= 8) {
-        // wide byte-column form: 8 states x 8-bit fields in a u64 column,
-        // field(q) = next << 3 | EMIT << 1 | NEWSTART, so "field & 0x38" is the next shift amount
-        auto E = stream_entries(sa, remap, nlive);
-        std::vector<uint64_t> cols64(256, 0);
-        for (int c = 0; c < 256; ++c)
-          for (int q = 0; q < nlive; ++q)
-            cols64[c] |= (uint64_t)((((E[q][c] >> 2) << 3) | (E[q][c] & 3)) & 0xFF) << (8 * q);
-        d.flags |= PF_STREAMABLE | ((d.flags & PF_PREFILTER) ? 0u : (uint32_t)PF_STREAM_SEARCH);
-        d.st_kind = 3;
-        for (int q = 0; q < sa.n; ++q)
-          if (remap[q] >= 0 && sa.acc[q]) d.st_accept_mask |= 1u << remap[q];
-        align(hp.blob, 16);
-        d.off_stcol = (int)hp.blob.size();
-        put(hp.blob, cols64.data(), 2048);
-      } else {
-        // class-table form: any number of live states that fits u16 entries and LDS
-        auto E = stream_entries(sa, remap, nlive);
-        std::array<uint8_t, 256> scls{};
-        int sncls = 0;
-        {
-          std::map<std::vector<uint16_t>, int> seen;
-          for (int c = 0; c < 256; ++c) {
-            std::vector<uint16_t> col(nlive);
-            for (int q = 0; q < nlive; ++q) col[q] = E[q][c];
-            auto it = seen.find(col);
-            if (it == seen.end()) it = seen.emplace(col, sncls++).first;
-            scls[c] = (uint8_t)it->second;
-          }
-        }
-        int cshift = 0;
-        while ((1 << cshift) < sncls) ++cshift;
-        const int ncp = 1 << cshift;
-        if ((int64_t)nlive * ncp > 8192) {
-          hp.streamable_why_not = "search automaton too large for the streaming kernel's LDS table";
-        } else {
-          std::vector<uint16_t> tr((size_t)nlive * ncp, 0);
-          for (int c = 0; c < 256; ++c)
-            for (int q = 0; q < nlive; ++q) {
-              const uint16_t e = E[q][c];
-              tr[(size_t)q * ncp + scls[c]] = (uint16_t)((((e >> 2) << cshift) << 2) | (e & 3));
-            }
-          std::vector<uint8_t> sacc(nlive, 0);
-          for (int q = 0; q < sa.n; ++q)
-            if (remap[q] >= 0) sacc[remap[q]] = sa.acc[q];
-          d.flags |= PF_STREAMABLE | ((d.flags & PF_PREFILTER) ? 0u : (uint32_t)PF_STREAM_SEARCH);
-          d.st_kind = 2;
-          d.st_cshift = cshift;
-          align(hp.blob, 16);
-          const int begin = (int)hp.blob.size();
-          d.off_stg_cls = begin;
-          put(hp.blob, scls.data(), 256);
-          d.off_stg_trans = (int)hp.blob.size();
-          put(hp.blob, tr.data(), tr.size() * 2);
-          d.off_stg_acc = (int)hp.blob.size();
-          put(hp.blob, sacc.data(), sacc.size());
-          align(hp.blob, 16);
-          d.stg_bytes = (int)hp.blob.size() - begin;
-        }
-      }
+      std::vector<uint8_t> live_acc(nlive, 0);
+      for (int q = 0; q < sa.n; ++q)
+        if (remap[q] >= 0) live_acc[remap[q]] = sa.acc[q];
+      emit_stream_tables(stream_entries(sa, remap, nlive), live_acc);
     }
   }
   // ---- anchored automaton: regex.match_first as one forward pass ----------------------

@@ -55,6 +55,7 @@ struct DevPlan {
   int32_t st_nstates;     // live states of the search automaton (0 = idle)
   int32_t st_kind;        // 0 none, 1 = byte-column form (<= 4 states), 2 = class-table form,
                           // 3 = wide byte-column form (<= 8 states)
+  int32_t st_fixed_len;   // > 0: every match is [end - st_fixed_len, end) (exact-literal KMP automaton)
   int32_t off_stcol;      // kind 1: u16 column table [256] (4 states x 4 bit); kind 3: u64 [256] (8 x 8 bit)
   uint32_t st_accept_mask;
   // kind 2: cls[256] u8, trans[st_nstates][1 << st_cshift] u16 = (next << st_cshift) << 2 | EMIT << 1 | NEWSTART,

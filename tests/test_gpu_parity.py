@@ -715,3 +715,52 @@ def test_generated_patterns_streaming_equals_generic(seed):
         if first_stream and "onepass=yes" not in d:
             assert torch.equal(fs, gfs) and torch.equal(fe, gfe), p
     assert nstream > 40 and nfirst > 150, (nstream, nfirst)
+
+
+EXACT_LITERALS = [b"hello world this is long", b"abcabcabcabcabcabcabcabc", b"aaaaaaaaaaaaaaaaaaaaaa",
+                  b"aaaaaaaaaaaaaaaaaaaab", b"xyxyxyxyxyxyxyxyxyxyxyxyxy"]
+
+
+@pytest.mark.parametrize("pat", EXACT_LITERALS)
+def test_exact_literal_kmp_streaming(pat):
+    """HybridMatcher's exact-literal bypass (matcher.mojo:768-781, 815-847) on the streaming kernel:
+    KMP automaton of the literal, findall returns EVERY occurrence (overlapping ones too), search
+    the first; against the generic kernels on every text and the oracle on a sample."""
+    _need_gpu()
+    rx = M.compile_regex(pat)
+    d = rx.describe()
+    assert "ExactLiteral" in rx.get_engine_type() and "device.streamable=yes" in d
+    lib = M.load_library()
+    rng = np.random.default_rng(zlib.crc32(pat))
+    al = bytes(set(pat)) + b" z"
+    texts = []
+    for _ in range(200):
+        parts = []
+        for _ in range(int(rng.integers(0, 6))):
+            k = rng.random()
+            if k < 0.45:
+                parts.append(pat)
+            elif k < 0.7:   # a run of the literal's own period: overlapping occurrences
+                parts.append(pat[: max(1, len(pat) // 8)] * int(rng.integers(1, 40)))
+            else:
+                parts.append(bytes(rng.choice(np.frombuffer(al, dtype=np.uint8), size=int(rng.integers(0, 50))).tolist()))
+        texts.append(b"".join(parts))
+    texts += [b"", pat, pat[:-1], pat + pat, pat[1:] + pat]
+    got = rx.findall_lists(texts)
+    assert lib.mrx_last_kernel_name() == b"k_stream_findall"
+    s, e = rx.match_next(texts)
+    assert lib.mrx_last_kernel_name() == b"k_stream_search"
+    cnt_total = sum(len(g) for g in got)
+    with generic_kernels():
+        want = rx.findall_lists(texts)
+        gs, ge = rx.match_next(texts)
+    assert got == want and cnt_total > 100
+    assert np.array_equal(s, gs) and np.array_equal(e, ge)
+    for i in range(0, len(texts), 5):
+        assert got[i] == O.findall(pat, texts[i]), (pat, texts[i])
+        w = O.search(pat, texts[i])
+        assert (int(s[i]), int(e[i])) == (w if w else (-1, -1))
+    # sub keeps its own non-overlapping search loop (generic kernel)
+    out = rx.sub(b"#", texts[:40])
+    for i in range(40):
+        assert out[i] == O.sub(pat, b"#", texts[i]), (pat, texts[i])
