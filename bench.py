@@ -216,6 +216,24 @@ def main():
     alg_bytes = float(n) * L + 8.0 * total + 4.0 * n
     achieved = alg_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
 
+    # ---- the other operations of the path on the same batch (rank 0's view; extra fields) -------
+    def _time(fn, reps=10):
+        fn()
+        torch.cuda.synchronize()
+        a = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - a) / reps
+
+    other = None
+    if rank == 0:
+        nb = float(n) * L
+        other = {"count_GBps": round(nb / _time(lambda: rx.count(batch)) / 1e9, 1),
+                 "search_GBps": round(nb / _time(lambda: rx.match_next(batch)) / 1e9, 1),
+                 "match_first_GBps_whole_batch": round(nb / _time(lambda: rx.match_first(batch)) / 1e9, 1),
+                 "note": "same batch, device resident, per rank; count = scan without records/decode"}
+
     if rank == 0:
         value = agg["bytes"] / agg["elapsed_s"] / 1e9
         line = {
@@ -241,6 +259,8 @@ def main():
                          "kernel_ms": round(scan_ms, 4), "launches_timed": int(launches.value),
                          "algorithmic_bytes_per_launch": int(alg_bytes)},
         }
+        if other is not None:
+            line["other_ops"] = other
         if gather_info is not None:
             line["scan_plus_gather"] = gather_info
         if world == 1 and not args.no_cpu_baseline:
