@@ -72,6 +72,33 @@ __device__ __forceinline__ Ctx stage_tables(const DevPlan& p, const uint8_t* __r
   return c;
 }
 
+// The text stream is read exactly once: non-temporal loads keep it from displacing the event
+// records (written here, read back by k_decode) in L2 / Infinity Cache.  -DMRX_NT_LOADS=0 to compare.
+#ifndef MRX_NT_LOADS
+#define MRX_NT_LOADS 1
+#endif
+typedef unsigned int mrx_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 mrx_ldg(const uint4* p) {
+#if MRX_NT_LOADS
+  const mrx_u32x4 v = __builtin_nontemporal_load((const mrx_u32x4*)p);
+  return make_uint4(v.x, v.y, v.z, v.w);
+#else
+  return *p;
+#endif
+}
+#define MRX_LDG(P) mrx_ldg(P)
+typedef int mrx_i32x2 __attribute__((ext_vector_type(2)));
+// result spans are written once and not read again by this library
+__device__ __forceinline__ void mrx_stg_span(int32_t* p, int a, int b) {
+#if MRX_NT_LOADS
+  mrx_i32x2 v; v.x = a; v.y = b;
+  __builtin_nontemporal_store(v, (mrx_i32x2*)p);
+#else
+  *(int2*)p = make_int2(a, b);
+#endif
+}
+
+
 enum { OP_MATCH_FIRST = 0, OP_SEARCH = 1, OP_IS_MATCH = 2, OP_CAPTURES = 3 };
 
 template <int OP>
@@ -137,6 +164,150 @@ __global__ void k_span_to_flag(int64_t n, const int32_t* __restrict__ start, uin
 }
 
 enum { FA_COUNT = 0, FA_EMIT = 1 };
+enum { STEP_COUNT = 0, STEP_EMIT = 1, STEP_SEARCH = 2 };
+
+// Windowed stepper for PF_STEPPABLE plans.  Same results as for_each_match() / hybrid_match_next()
+// on those plans, but (1) ONE loop whose every iteration looks at one byte of every lane's text --
+// skipping to a candidate start and walking the table are two short arms of the same iteration
+// instead of two inner loops that make the lanes of a wavefront take turns -- and (2) the text
+// bytes come from an LDS tile that the wavefront fills with coalesced 128-byte rows (one per text,
+// frame form as in the streaming kernel), one window after the other.  A lane whose restart
+// position falls behind the window reads those few bytes from global memory; a lane that has run
+// past the window waits for the next one.  The per-step cost drops from ~160 instructions
+// (register window, 64-bit addressing and bounds logic of the generic Text; rocprof: 92 VALU + 67
+// SALU instructions per byte step on config 4) to ~30.
+constexpr int kWsWaves = 4;
+constexpr uint32_t kWsDead = 0xFFFFu, kWsAcc = 0x8000u, kWsStart = 0x4000u;
+__host__ __device__ inline size_t wstep_table_bytes(int nstates) { return (size_t)(nstates + 1) * 512; }
+
+template <int MODE>
+__global__ __launch_bounds__(64 * kWsWaves) void k_wstep(DevPlan p, const uint8_t* __restrict__ blob, Layout lay,
+                                                         int64_t n, int32_t* __restrict__ counts,
+                                                         const int64_t* __restrict__ prefix,
+                                                         int32_t* __restrict__ spans, int64_t span_cap,
+                                                         int32_t* __restrict__ out_s, int32_t* __restrict__ out_e) {
+  constexpr int CH = 128, kRowPitch = CH + 16, LPR = CH / 16, RPI = 64 / LPR, NL = 64 / RPI;
+  __shared__ __align__(16) uint8_t tiles[kWsWaves][64 * kRowPitch];
+  extern __shared__ __align__(16) uint8_t lds[];
+  // One byte-indexed table for the whole step: row q < nstates is DFA state q, row nstates is
+  // "looking for a start".  Entry = next | ACC | START, or DEAD.  (Built from the plan's class
+  // tables, so a step costs one dependent LDS read instead of three.)
+  uint16_t* tab = (uint16_t*)lds;
+  const int ns = p.nstates, idle = ns;
+  {
+    const uint8_t* g_cls = blob + p.off_cls;
+    const uint8_t* g_first = blob + p.off_first;
+    const uint16_t* g_tr = (const uint16_t*)(blob + p.off_trans);
+    const bool filt = (p.flags & PF_HAS_MATCHER) != 0;
+    for (int e = threadIdx.x; e < (ns + 1) * 256; e += blockDim.x) {
+      const int q = e >> 8, b = e & 255;
+      uint32_t v;
+      if (q < ns) {
+        const uint32_t t = g_tr[q * p.ncls + g_cls[b]];
+        v = t == 0xFFFFu ? kWsDead : ((t & 0x7FFFu) | ((t & 0x8000u) ? kWsAcc : 0u));
+      } else {   // find_first_class + the first step of the walk it starts
+        const uint32_t t = g_tr[0 * p.ncls + g_cls[b]];
+        v = ((filt && !g_first[b]) || t == 0xFFFFu) ? (uint32_t)idle
+                                                    : ((t & 0x7FFFu) | ((t & 0x8000u) ? kWsAcc : 0u) | kWsStart);
+      }
+      tab[e] = (uint16_t)v;
+    }
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint8_t* tile = tiles[wave];
+  const int seg = lane % LPR, rsub = lane / LPR;
+  const int64_t nw = (n + 63) >> 6;
+  for (int64_t w = (int64_t)blockIdx.x * kWsWaves + wave; w < nw; w += (int64_t)gridDim.x * kWsWaves) {
+    const int64_t i = (w << 6) + lane;
+    const bool live = i < n;
+    const Text t = live ? lay.text(i) : Text(blob, 0);
+    const uintptr_t addr = t.len > 0 ? (uintptr_t)t.ptr : (uintptr_t)blob;   // empty rows park on the blob
+    const int mis = t.len > 0 ? (int)(addr & 15) : 0;
+    const uintptr_t rb = addr & ~(uintptr_t)15;
+    const int end = mis + t.len;   // frame coordinates: the text is [mis, end)
+    __builtin_amdgcn_wave_barrier();
+    *(uint4*)(tile + lane * kRowPitch + CH) = make_uint4((uint32_t)rb, (uint32_t)((uint64_t)rb >> 32), (uint32_t)end, 0u);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    int max_end = end;
+    for (int off = 32; off > 0; off >>= 1) max_end = max(max_end, __shfl_xor(max_end, off));
+
+    int pos = mis, start = mis, last = -1, k = 0, rs = -1, re = -1;
+    int state = idle;
+    bool fin = !live || t.len == 0;
+    int64_t wo = (MODE == STEP_EMIT && live) ? prefix[i] : 0;
+    const uint8_t* myrow = tile + lane * kRowPitch;
+    const uint8_t* frame = (const uint8_t*)rb;   // frame position f is frame[f] in global memory
+    uint32_t cword = 0;
+    int cpos = -4;   // frame position of cword's first byte (multiple of 4); -4 = none
+    uint4 v[NL];
+#define MRX_WS_LOAD(CB)                                                                   \
+    do {                                                                                  \
+      _Pragma("unroll") for (int j_ = 0; j_ < NL; ++j_) {                                  \
+        const uint4 rs_ = *(const uint4*)(tile + (RPI * j_ + rsub) * kRowPitch + CH);      \
+        uint32_t fo_ = (uint32_t)(CB) + seg * 16;                                          \
+        if (fo_ >= rs_.z) fo_ = 0;                                                         \
+        v[j_] = mrx_ldg((const uint4*)((const uint8_t*)(((uint64_t)rs_.y << 32) | rs_.x) + fo_)); \
+      }                                                                                    \
+    } while (0)
+    if (max_end > 0) MRX_WS_LOAD(0);
+    for (int wb = 0; wb < max_end; wb += CH) {
+#pragma unroll
+      for (int j = 0; j < NL; ++j) *(uint4*)(tile + (RPI * j + rsub) * kRowPitch + seg * 16) = v[j];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (wb + CH < max_end) MRX_WS_LOAD(wb + CH);   // next window, in flight while this one is stepped
+      const int wend = wb + CH;
+      cpos = -4;   // the tile changed under the cached word
+      while (true) {
+        const bool active = !fin && (pos < wend || pos >= end);
+        if (!__any(active)) break;
+        if (active) {
+          const bool inside = pos < end;
+          if (inside && (pos & ~3) != cpos) {   // 4 text bytes per fetch
+            cpos = pos & ~3;
+            if (cpos >= wb) cword = *(const uint32_t*)(myrow + (cpos - wb));   // from the tile (LDS)
+            else cword = *(const uint32_t*)(frame + cpos);                     // behind the window: memory
+          }
+          // past the end of the text the walk (if any) ends: DEAD
+          const uint32_t e = inside ? (uint32_t)tab[(state << 8) + ((cword >> ((pos & 3) * 8)) & 0xFFu)] : kWsDead;
+          // branch-free update: every lane executes the same few selects
+          const bool alive = e != kWsDead;
+          const bool begins = alive && (e & kWsStart);
+          const bool ends = !alive && state != idle;        // a walk stops here
+          const bool matched = ends && last >= 0;           // matches are never empty on these plans
+          if (MODE == STEP_EMIT) {
+            if (matched) {
+              if (wo < span_cap) { spans[2 * wo] = start - mis; spans[2 * wo + 1] = last - mis; }
+              ++wo;
+            }
+          }
+          if (MODE == STEP_SEARCH) { if (matched) { rs = start - mis; re = last - mis; } }
+          fin = fin || (!alive && state == idle) || (MODE == STEP_SEARCH && matched);
+          k += matched ? 1 : 0;
+          const int after = ends ? (matched ? last : start + 1) : pos;   // where the search resumes
+          start = begins ? pos : start;
+          last = begins ? -1 : last;
+          const int nxt = pos + 1;
+          last = (alive && (e & kWsAcc)) ? nxt : last;
+          pos = alive ? nxt : after;
+          state = alive ? (int)(e & 0x3FFFu) : idle;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (__all(fin)) break;
+    }
+#undef MRX_WS_LOAD
+    if (live) {
+      if (MODE == STEP_COUNT) counts[i] = k;
+      if (MODE == STEP_SEARCH) { out_s[i] = rs; out_e[i] = re; }
+    }
+  }
+}
+
 
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void k_findall(DevPlan p, const uint8_t* __restrict__ blob,
@@ -204,32 +375,6 @@ constexpr int kStreamWaves = 4;
 #ifndef MRX_ABLATE
 #define MRX_ABLATE 0
 #endif
-// The text stream is read exactly once: non-temporal loads keep it from displacing the event
-// records (written here, read back by k_decode) in L2 / Infinity Cache.  -DMRX_NT_LOADS=0 to compare.
-#ifndef MRX_NT_LOADS
-#define MRX_NT_LOADS 1
-#endif
-typedef unsigned int mrx_u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ uint4 mrx_ldg(const uint4* p) {
-#if MRX_NT_LOADS
-  const mrx_u32x4 v = __builtin_nontemporal_load((const mrx_u32x4*)p);
-  return make_uint4(v.x, v.y, v.z, v.w);
-#else
-  return *p;
-#endif
-}
-#define MRX_LDG(P) mrx_ldg(P)
-typedef int mrx_i32x2 __attribute__((ext_vector_type(2)));
-// result spans are written once and not read again by this library
-__device__ __forceinline__ void mrx_stg_span(int32_t* p, int a, int b) {
-#if MRX_NT_LOADS
-  mrx_i32x2 v; v.x = a; v.y = b;
-  __builtin_nontemporal_store(v, (mrx_i32x2*)p);
-#else
-  *(int2*)p = make_int2(a, b);
-#endif
-}
-
 struct EvRec {   // 16 bytes
   uint32_t F;
   int32_t start;     // start of the walk that is alive when the group begins
@@ -1022,7 +1167,7 @@ thread_local int64_t g_scan_launches = 0;
 thread_local const char* g_last_kernel = "";
 // mrx_debug_force_generic(): route every call to the generic lane-per-text kernels (tests compare
 // the two implementations; never set in production)
-int g_force_generic = 0;
+int g_force_generic = 0;   // 0 best kernel, 1 no streaming kernel, 2 literal restatement (mrx_device.hpp) only
 
 int fail(int code, const std::string& msg) {
   g_err = msg;
@@ -1127,6 +1272,13 @@ int grid_for(int64_t n, int block) {
   return (int)(g < cap ? g : cap);
 }
 
+int wstep_grid(int64_t n) {
+  const int64_t nw = (n + 63) / 64;
+  int64_t g = (nw + kWsWaves - 1) / kWsWaves;
+  if (g < 1) g = 1;
+  return (int)(g < 256 * 8 ? g : 256 * 8);
+}
+
 struct ScanTimer {  // HIP events around the dominant scan kernel, on its own stream
   hipEvent_t a = nullptr, b = nullptr;
   hipStream_t s;
@@ -1197,9 +1349,17 @@ int run_match(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d_s, i
   if (n == 0) return MRX_OK;
   hipStream_t s = (hipStream_t)stream;
   ScanTimer tm(s);
-  hipLaunchKernelGGL(k_match<OP>, dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s, h->hp.dev,
-                     h->d_blob, lay, n, d_s, d_e, d_flag);
-  g_last_kernel = "k_match";
+  if (OP == OP_SEARCH && g_force_generic < 2 && (h->hp.dev.flags & PF_STEPPABLE) &&
+      !(h->hp.dev.flags & PF_PREFILTER)) {   // (the memchr prefilter changes match_next, matcher.mojo:784-796)
+    hipLaunchKernelGGL(k_wstep<STEP_SEARCH>, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_table_bytes(h->hp.dev.nstates), s, h->hp.dev,
+                       h->d_blob, lay, n, (int32_t*)nullptr, (const int64_t*)nullptr, (int32_t*)nullptr,
+                       (int64_t)0, d_s, d_e);
+    g_last_kernel = "k_step_search";
+  } else {
+    hipLaunchKernelGGL(k_match<OP>, dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s, h->hp.dev,
+                       h->d_blob, lay, n, d_s, d_e, d_flag);
+    g_last_kernel = "k_match";
+  }
   HIP_TRY(hipGetLastError());
   tm.stop();
   return MRX_OK;
@@ -1253,6 +1413,7 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
   HIP_TRY(scratch_alloc((void**)&d_total, sizeof(int64_t), s));
   const DevPlan& p = h->hp.dev;
   const bool stream_ok = !g_force_generic && (p.flags & PF_STREAMABLE) && stream_layout_ok(lay, n);
+  const bool step_ok = g_force_generic < 2 && (p.flags & PF_STEPPABLE);
   EvRec* d_recs = nullptr;
   int32_t* d_nrecs = nullptr;
   int64_t* d_wbase = nullptr;
@@ -1284,10 +1445,15 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
       tm.stop();
     } else {
       ScanTimer tm(s);
-      hipLaunchKernelGGL(k_findall<FA_COUNT>, dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s,
-                         p, h->d_blob, lay, n, d_counts, (const int64_t*)nullptr, (int32_t*)nullptr,
-                         (int64_t)0);
-      g_last_kernel = "k_findall_count";
+      if (step_ok)
+        hipLaunchKernelGGL(k_wstep<STEP_COUNT>, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_table_bytes(h->hp.dev.nstates), s, p,
+                           h->d_blob, lay, n, d_counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0,
+                           (int32_t*)nullptr, (int32_t*)nullptr);
+      else
+        hipLaunchKernelGGL(k_findall<FA_COUNT>, dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s,
+                           p, h->d_blob, lay, n, d_counts, (const int64_t*)nullptr, (int32_t*)nullptr,
+                           (int64_t)0);
+      g_last_kernel = step_ok ? "k_step_count" : "k_findall_count";
       HIP_TRY(hipGetLastError());
       tm.stop();
     }
@@ -1313,8 +1479,13 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
     if (stream_ok) {
       // spans were written by k_decode above
     } else {
-      hipLaunchKernelGGL(k_findall<FA_EMIT>, dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s, p,
-                         h->d_blob, lay, n, (int32_t*)nullptr, d_prefix, d_spans, span_cap);
+      if (step_ok)
+        hipLaunchKernelGGL(k_wstep<STEP_EMIT>, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_table_bytes(h->hp.dev.nstates), s, p, h->d_blob,
+                           lay, n, (int32_t*)nullptr, d_prefix, d_spans, span_cap, (int32_t*)nullptr,
+                           (int32_t*)nullptr);
+      else
+        hipLaunchKernelGGL(k_findall<FA_EMIT>, dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s, p,
+                           h->d_blob, lay, n, (int32_t*)nullptr, d_prefix, d_spans, span_cap);
     }
     HIP_TRY(hipGetLastError());
   }
@@ -1603,10 +1774,17 @@ static int run_count_any(const mrx_handle* h, const Layout& lay, int64_t n, int3
     launch_stream<ST_COUNT>(h, lay, n, counts, nullptr, nullptr, 0, nullptr, nullptr, s);
     g_last_kernel = "k_stream_count";
   } else {
-    hipLaunchKernelGGL(k_findall<FA_COUNT>, dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s,
-                       h->hp.dev, h->d_blob, lay, n, counts, (const int64_t*)nullptr, (int32_t*)nullptr,
-                       (int64_t)0);
-    g_last_kernel = "k_findall_count";
+    if (g_force_generic < 2 && (h->hp.dev.flags & PF_STEPPABLE)) {
+      hipLaunchKernelGGL(k_wstep<STEP_COUNT>, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_table_bytes(h->hp.dev.nstates), s, h->hp.dev,
+                         h->d_blob, lay, n, counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0,
+                         (int32_t*)nullptr, (int32_t*)nullptr);
+      g_last_kernel = "k_step_count";
+    } else {
+      hipLaunchKernelGGL(k_findall<FA_COUNT>, dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s,
+                         h->hp.dev, h->d_blob, lay, n, counts, (const int64_t*)nullptr, (int32_t*)nullptr,
+                         (int64_t)0);
+      g_last_kernel = "k_findall_count";
+    }
   }
   HIP_TRY(hipGetLastError());
   tm.stop();
@@ -1787,7 +1965,7 @@ double mrx_timing_scan_ms(int64_t* launches) {
   return g_scan_launches ? g_scan_ms / (double)g_scan_launches : 0.0;
 }
 const char* mrx_last_kernel_name(void) { return g_last_kernel; }
-void mrx_debug_force_generic(int on) { g_force_generic = on ? 1 : 0; }
+void mrx_debug_force_generic(int on) { g_force_generic = on < 0 ? 0 : on > 2 ? 2 : on; }
 void mrx_release_scratch(void) { scratch_release_all(); }
 
 }  // extern "C"

@@ -641,6 +641,17 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
       emit_stream_tables(stream_entries(sa, remap, nlive), live_acc);
     }
   }
+  // ---- flattened generic kernel (k_step_*) -------------------------------------------------
+  // The plain route of DFAEngine.match_all / match_next (dfa.mojo:2096-2130, 2200-2253) and of
+  // LazyDFA (pikevm.mojo:754-817): optional skip to a first-class / first-byte candidate, table
+  // walk, emit (start, last accept) and continue at the match end, or retry at start + 1.
+  // Everything that takes another branch upstream keeps the literal restatement in mrx_device.hpp.
+  if ((d.kind == PLAN_DFA || d.kind == PLAN_LAZY) && hp.why_no_search.empty() &&
+      !(d.flags & (PF_START_ANCHOR | PF_END_ANCHOR | PF_PURE_LITERAL | PF_EXACT_LITERAL | PF_START_ACCEPTING |
+                   PF_START_DEAD | PF_BITSET | PF_SCAN_ELIGIBLE)) &&
+      d.required_byte < 0 && d.nstates <= 96)   // (nstates + 1) x 512 B byte-indexed table in LDS
+    d.flags |= PF_STEPPABLE;
+
   // ---- anchored automaton: regex.match_first as one forward pass ----------------------
   // match_first(text) = engine_match_first(text, 0) keeps no restart loop, so it is a plain
   // automaton run from byte 0 that remembers the last accepting position:
@@ -814,6 +825,7 @@ std::string describe_plan(const HostPlan& hp) {
   o << "device.streamable=" << ((d.flags & PF_STREAMABLE) ? "yes" : ("no: " + hp.streamable_why_not))
     << " st_nstates=" << d.st_nstates << " st_kind=" << d.st_kind
     << (((d.flags & PF_STREAMABLE) && !(d.flags & PF_STREAM_SEARCH)) ? " findall_only=1" : "") << "\n";
+  o << "device.steppable=" << ((d.flags & PF_STEPPABLE) ? "yes" : "no") << "\n";
   o << "device.first_stream=" << (d.fa_bytes ? "yes" : ("no: " + hp.first_stream_why_not))
     << " fa_nstates=" << d.fa_nstates << (hp.first_onepass ? " onepass=yes" : "") << "\n";
   if (d.flags & PF_BITSET)

@@ -165,6 +165,17 @@ def generic_kernels():
     """Route calls to the generic lane-per-text kernels (the second implementation the
     streaming kernel is compared with)."""
     lib = M.load_library()
+    lib.mrx_debug_force_generic(2)   # 2 = the literal restatement of the reference's loops only
+    try:
+        yield
+    finally:
+        lib.mrx_debug_force_generic(0)
+
+
+@contextlib.contextmanager
+def no_streaming_kernels():
+    """Level 1: everything but the streaming kernel (the flattened k_step_* kernels stay on)."""
+    lib = M.load_library()
     lib.mrx_debug_force_generic(1)
     try:
         yield
@@ -764,3 +775,46 @@ def test_exact_literal_kmp_streaming(pat):
     out = rx.sub(b"#", texts[:40])
     for i in range(40):
         assert out[i] == O.sub(pat, b"#", texts[i]), (pat, texts[i])
+
+
+@pytest.mark.parametrize("seed", [20260701, 20260702, 20260703])
+def test_generated_patterns_stepper_equals_literal_restatement(seed):
+    """k_step_* (one flattened loop) against the literal restatement of the reference's nested loops
+    on every generated PF_STEPPABLE pattern: findall, count and search, ragged texts built from the
+    pattern's own alphabet; plus the oracle on a sample."""
+    _need_gpu()
+    from pattern_gen import patterns
+    lib = M.load_library()
+    rng = np.random.default_rng(seed)
+    base = b"abcxyz019 -@.fobrhelcatdg"
+    nstep = 0
+    for p in patterns(seed, 400):
+        pb = p.encode()
+        try:
+            rx = M.compile_regex(pb)
+        except M.RegexSyntaxError:
+            continue
+        if "device.steppable=yes" not in rx.describe():
+            continue
+        nstep += 1
+        al = base + bytes(c for c in pb if chr(c).isalnum() or c in b" -@.") * 2
+        texts = _random_texts(rng, 90, 70, al) + _random_texts(rng, 12, 400, al)
+        for j in range(0, len(texts), 6):
+            k = len(texts[j])
+            texts[j] = (bytes([al[int(rng.integers(0, len(al)))]]) * (k // 2) + texts[j])[:k]
+        try:
+            with no_streaming_kernels():
+                got = rx.findall_lists(texts)
+                assert lib.mrx_last_kernel_name() == b"k_step_count"
+                gs, ge = rx.match_next(texts)
+        except M.UnsupportedPattern:   # tables beyond the LDS staging budget
+            continue
+        with generic_kernels():
+            want = rx.findall_lists(texts)
+            assert lib.mrx_last_kernel_name() == b"k_findall_count"
+            ws, we = rx.match_next(texts)
+        assert got == want, p
+        assert np.array_equal(gs, ws) and np.array_equal(ge, we), p
+        for j in range(0, len(texts), 17):
+            assert got[j] == O.findall(pb, texts[j]), (p, texts[j])
+    assert nstep > 150, nstep
