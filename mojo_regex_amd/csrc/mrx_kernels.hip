@@ -240,8 +240,6 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_wstep(DevPlan p, const uint8_
     int64_t wo = (MODE == STEP_EMIT && live) ? prefix[i] : 0;
     const uint8_t* myrow = tile + lane * kRowPitch;
     const uint8_t* frame = (const uint8_t*)rb;   // frame position f is frame[f] in global memory
-    uint32_t cword = 0;
-    int cpos = -4;   // frame position of cword's first byte (multiple of 4); -4 = none
     uint4 v[NL];
 #define MRX_WS_LOAD(CB)                                                                   \
     do {                                                                                  \
@@ -260,42 +258,48 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_wstep(DevPlan p, const uint8_
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       if (wb + CH < max_end) MRX_WS_LOAD(wb + CH);   // next window, in flight while this one is stepped
-      const int wend = wb + CH;
-      cpos = -4;   // the tile changed under the cached word
-      while (true) {
-        const bool active = !fin && (pos < wend || pos >= end);
-        if (!__any(active)) break;
-        if (active) {
-          const bool inside = pos < end;
-          if (inside && (pos & ~3) != cpos) {   // 4 text bytes per fetch
-            cpos = pos & ~3;
-            if (cpos >= wb) cword = *(const uint32_t*)(myrow + (cpos - wb));   // from the tile (LDS)
-            else cword = *(const uint32_t*)(frame + cpos);                     // behind the window: memory
+      // One step of the search for this lane, given the byte at `pos` (ignored when act is false
+      // or the text has ended).  Branch-free apart from the span store.
+      auto step = [&](bool act, uint32_t byte) {
+        const bool inside = pos < end;
+        const uint32_t e = tab[(state << 8) + byte];
+        const bool alive = act && inside && e != kWsDead;
+        const bool stop = act && !alive;                     // dead entry, or the text has ended
+        const bool ends = stop && state != idle;             // a walk stops here
+        const bool matched = ends && last >= 0;              // matches are never empty on these plans
+        if (MODE == STEP_EMIT) {
+          if (matched) {
+            if (wo < span_cap) { spans[2 * wo] = start - mis; spans[2 * wo + 1] = last - mis; }
+            ++wo;
           }
-          // past the end of the text the walk (if any) ends: DEAD
-          const uint32_t e = inside ? (uint32_t)tab[(state << 8) + ((cword >> ((pos & 3) * 8)) & 0xFFu)] : kWsDead;
-          // branch-free update: every lane executes the same few selects
-          const bool alive = e != kWsDead;
-          const bool begins = alive && (e & kWsStart);
-          const bool ends = !alive && state != idle;        // a walk stops here
-          const bool matched = ends && last >= 0;           // matches are never empty on these plans
-          if (MODE == STEP_EMIT) {
-            if (matched) {
-              if (wo < span_cap) { spans[2 * wo] = start - mis; spans[2 * wo + 1] = last - mis; }
-              ++wo;
-            }
-          }
-          if (MODE == STEP_SEARCH) { if (matched) { rs = start - mis; re = last - mis; } }
-          fin = fin || (!alive && state == idle) || (MODE == STEP_SEARCH && matched);
-          k += matched ? 1 : 0;
-          const int after = ends ? (matched ? last : start + 1) : pos;   // where the search resumes
-          start = begins ? pos : start;
-          last = begins ? -1 : last;
-          const int nxt = pos + 1;
-          last = (alive && (e & kWsAcc)) ? nxt : last;
-          pos = alive ? nxt : after;
-          state = alive ? (int)(e & 0x3FFFu) : idle;
         }
+        if (MODE == STEP_SEARCH) { rs = matched ? start - mis : rs; re = matched ? last - mis : re; }
+        fin = fin || (stop && state == idle) || (MODE == STEP_SEARCH && matched);
+        k += matched ? 1 : 0;
+        const int after = matched ? last : start + 1;        // where the search resumes after a walk
+        const bool begins = alive && (e & kWsStart);
+        start = begins ? pos : start;
+        last = begins ? -1 : last;
+        const int nxt = pos + 1;
+        last = (alive && (e & kWsAcc)) ? nxt : last;
+        pos = alive ? nxt : (ends ? after : pos);
+        state = alive ? (int)(e & 0x3FFFu) : (stop ? idle : state);
+      };
+      while (true) {
+        // fast phase: 32 steps on the tile without any cross-lane vote; lanes that are ahead of the
+        // window, behind it or finished run the same instructions as no-ops
+#pragma unroll 1
+        for (int it = 0; it < 32; ++it) {
+          const int rel = pos - wb;
+          const bool act = !fin && rel >= 0 && (rel < CH || pos >= end);
+          step(act, (uint32_t)myrow[rel & (CH - 1)]);
+        }
+        // a restart moved some lane behind the window: it reads those bytes from memory
+        while (__any(!fin && pos < wb)) {
+          const bool act = !fin && pos < wb;
+          step(act, act && pos >= mis ? (uint32_t)frame[pos] : 0u);
+        }
+        if (!__any(!fin && (pos < wb + CH || pos >= end))) break;
       }
       __builtin_amdgcn_wave_barrier();
       if (__all(fin)) break;
