@@ -173,3 +173,43 @@ def test_config5_lazydfa_semantics_switch():
     for i in range(0, n, 16):
         have = [tuple(int(x) for x in r) for r in sph[pre[i]:pre[i + 1]]]
         assert have == o.match_all(host[i].tobytes()), i
+
+
+def test_long_texts_and_degenerate_batches():
+    """Texts far beyond 64 KiB (32-bit positions, unpacked decode tile), a batch of one, and an
+    empty batch; C oracle on the long texts."""
+    _need_gpu()
+    pat = b"[a-z]+\\d+"
+    rx = M.compile_regex(pat)
+    # empty batch
+    e = M.DeviceBatch(torch.zeros(0, dtype=torch.uint8, device="cuda"), torch.zeros(1, dtype=torch.int64, device="cuda"))
+    pre, sp, tot = rx._dev_findall(e)
+    assert tot == 0 and pre.tolist() == [0]
+    # three long texts, ragged, CSR (frame form) -- 5 MB, 3 MB + 7 bytes, 70 KB
+    g = torch.Generator(device="cuda")
+    g.manual_seed(11)
+    lens = [5 << 20, (3 << 20) + 7, 70000, 0, 1]
+    al = torch.tensor(list(b"abcxyz0123456789 -"), dtype=torch.uint8, device="cuda")
+    data = al[torch.randint(0, al.numel(), (sum(lens),), generator=g, device="cuda")]
+    data[100:200000] = ord("q")               # a 200 KB letter run, then digits: one very long match
+    data[200000:200050] = ord("7")
+    offsets = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int64, device="cuda")
+    batch = M.DeviceBatch(data, offsets)
+    pre, sp, tot = rx._dev_findall(batch)
+    assert M.load_library().mrx_last_kernel_name() == b"k_stream_findall"
+    cd = CDfa(pat)
+    counts, osp, ototal = cd.findall_batch(data.cpu().numpy(), offsets.cpu().numpy())
+    assert tot == ototal
+    assert np.array_equal((pre[1:] - pre[:-1]).cpu().numpy(), counts)
+    assert np.array_equal(sp[:tot].cpu().numpy(), osp)
+    assert int(sp[:tot, 1].max().item()) > 65535
+    s, e2 = rx.match_next(batch)
+    os_, oe_ = cd.span_batch("search", data.cpu().numpy(), offsets.cpu().numpy())
+    assert np.array_equal(s.cpu().numpy(), os_) and np.array_equal(e2.cpu().numpy(), oe_)
+    f, fe = rx.match_first(batch)
+    of_, ofe_ = cd.span_batch("match_first", data.cpu().numpy(), offsets.cpu().numpy())
+    assert np.array_equal(f.cpu().numpy(), of_) and np.array_equal(fe.cpu().numpy(), ofe_)
+    # the same first text alone, at a fixed pitch (strided form, one text)
+    one = M.DeviceBatch.strided(data[: lens[0]].contiguous(), lens[0], length=lens[0])
+    p1, s1, t1 = rx._dev_findall(one)
+    assert t1 == int(counts[0]) and np.array_equal(s1[:t1].cpu().numpy(), osp[: counts[0]])
