@@ -1728,9 +1728,12 @@ int mrx_is_match_dev(const mrx_handle* h, const uint8_t* d, const int64_t* off, 
 }
 static int run_captures_any(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* spans, void* st) {
   if (!h) return fail(MRX_E_ARGUMENT, "null handle");
-  if (g_force_generic || !(h->hp.dev.flags & PF_STREAM_SEARCH) || h->hp.fixed_total < 0 || n <= 0)
+  const uint32_t fl = h->hp.dev.flags;
+  const bool fast_search = (!g_force_generic && (fl & PF_STREAM_SEARCH)) ||
+                           (g_force_generic < 2 && (fl & PF_STEPPABLE) && !(fl & PF_PREFILTER));
+  if (!fast_search || h->hp.fixed_total < 0 || n <= 0)
     return run_match<OP_CAPTURES>(h, lay, n, spans, nullptr, nullptr, st);
-  // streamable plan: search on the streaming kernel, then the groups at their fixed offsets
+  // search on the streaming kernel (or the windowed stepper), then the groups at their fixed offsets
   hipStream_t s = (hipStream_t)st;
   int32_t* tmp = nullptr;
   HIP_TRY(scratch_alloc((void**)&tmp, sizeof(int32_t) * 2 * n, s));
