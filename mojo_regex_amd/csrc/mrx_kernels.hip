@@ -1828,8 +1828,15 @@ int mrx_sub_dev(const mrx_handle* h, const char* repl, size_t repl_len, int64_t 
   if (int rc = check_lds(h)) return rc;
   if (int rc = ensure_device(h)) return rc;
   hipStream_t s = (hipStream_t)st;
-  if (!g_force_generic && (h->hp.dev.flags & PF_STREAM_SEARCH) && !(h->hp.dev.flags & PF_EXACT_LITERAL) && n > 0 &&
-      off) {   // (exact literals: findall spans overlap, sub's own search loop does not)
+  // sub() iterates match_next from the previous match end; on the plain route that is exactly the
+  // findall sequence, so the spans of the streaming kernel or of the windowed stepper serve it.
+  // (Not with a memchr prefilter, which only match_next consults; not for exact literals, whose
+  // findall spans overlap while sub's own search loop does not.)
+  const uint32_t sfl = h->hp.dev.flags;
+  const bool spans_ok = !(sfl & PF_EXACT_LITERAL) &&
+                        ((!g_force_generic && (sfl & PF_STREAM_SEARCH)) ||
+                         (g_force_generic < 2 && (sfl & PF_STEPPABLE) && !(sfl & PF_PREFILTER)));
+  if (spans_ok && n > 0 && off) {
     // replacement as a fixed-length byte map
     std::vector<uint16_t> rmap;
     if (groups) {

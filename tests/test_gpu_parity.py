@@ -818,3 +818,24 @@ def test_generated_patterns_stepper_equals_literal_restatement(seed):
         for j in range(0, len(texts), 17):
             assert got[j] == O.findall(pb, texts[j]), (p, texts[j])
     assert nstep > 150, nstep
+
+
+@pytest.mark.parametrize("pat,repl", [(b"\\w+\\d{2}", b"<W>"), (b"\\d+(\\.\\d+)?", b"N"), (b"(foo|foobar)", b""),
+                                      (b"[a-z]+(-[a-z]+)*", b"_")])
+@pytest.mark.parametrize("count", [0, 2])
+def test_sub_from_stepper_spans(pat, repl, count):
+    """Non-streamable but steppable plans: sub is assembled from the windowed stepper's findall."""
+    _need_gpu()
+    rng = np.random.default_rng(zlib.crc32(pat) + count)
+    texts = _random_texts(rng, 200, 100, b"abcfoxr0123456789.- ") + _random_texts(rng, 20, 900, b"abfoxr019.-  ") + [
+        b"", b"foox", b"foobarx", b"3.14 2.", b"a-b-c", b"ab12"]
+    rx = M.compile_regex(pat)
+    d = rx.describe()
+    assert "device.streamable=no" in d and "device.steppable=yes" in d
+    got = rx.sub(repl, texts, count)
+    assert M.load_library().mrx_last_kernel_name() == b"k_subs_emit"
+    with generic_kernels():
+        want = rx.sub(repl, texts, count)
+    assert got == want
+    for i in range(0, len(texts), 5):
+        assert got[i] == O.sub(pat, repl, texts[i], count), (pat, texts[i])
