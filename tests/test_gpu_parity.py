@@ -839,3 +839,38 @@ def test_sub_from_stepper_spans(pat, repl, count):
     assert got == want
     for i in range(0, len(texts), 5):
         assert got[i] == O.sub(pat, repl, texts[i], count), (pat, texts[i])
+
+
+@pytest.mark.parametrize("pat", [b"[^a-z]+", b"[^0-9]+x", b".+", b"a.c", b"\\w+", b"[\\x80-\\xff]+", b"\\S+" if False else b"\\s+\\w",
+                                 b"[^abc]{2}", b"(a|[^a])b"])
+def test_full_byte_range_texts(pat):
+    """Texts over all 256 byte values (NUL and bytes >= 0x80 included): tables are 256 wide
+    upstream (dfa.mojo:215-254) and nothing may sign-extend a byte."""
+    _need_gpu()
+    rng = np.random.default_rng(zlib.crc32(pat))
+    texts = []
+    for _ in range(150):
+        k = int(rng.integers(0, 300))
+        t = rng.integers(0, 256, size=k).astype(np.uint8)
+        if k > 8 and rng.random() < 0.5:           # sprinkle the pattern's own ASCII bytes in
+            idx = rng.integers(0, k, size=k // 3)
+            t[idx] = rng.choice(np.frombuffer(b"abcx019 \\n_", dtype=np.uint8), size=idx.size)
+        texts.append(t.tobytes())
+    texts += [bytes(range(256)), bytes([0]) * 40, bytes([255]) * 40 + b"x", b""]
+    try:
+        rx = M.compile_regex(pat)
+    except M.RegexSyntaxError:
+        with pytest.raises(Exception):
+            O.compile_regex(pat)
+        return
+    for op in ("findall", "search", "match_first"):
+        try:
+            if op == "findall":
+                got = rx.findall_lists(texts)
+            else:
+                s, e = (rx.match_next if op == "search" else rx.match_first)(texts)
+                got = [(int(a), int(b)) if a >= 0 else None for a, b in zip(s, e)]
+        except M.UnsupportedPattern:
+            continue
+        for t, g in zip(texts, got):
+            assert g == getattr(O, op)(pat, t), (pat, op, t)
