@@ -133,3 +133,55 @@ def test_onepass_routing_and_rejections():
         H.match_first(b"^aaaa.*a$", b"aaaaa")
     with pytest.raises(UnsupportedByOracle):               # search with '$' stays LazyDFA (history dependent)
         H.search(b"^[a-z]+$", b"abc")
+
+
+def test_optimizer_vectors_pin_classifier_and_literal_helpers():
+    """tests/test_optimizer.mojo: classify / is_literal_pattern / get_literal_string /
+    pattern_has_anchors -- the oracle's analysis.py, and (classification) the product's plan."""
+    import json
+    import os
+    from mrx_ref import analysis as A
+    from mrx_ref.frontend import parse
+    import mojo_regex_amd as M
+    names = {A.SIMPLE: "SIMPLE", A.MEDIUM: "MEDIUM", A.COMPLEX: "COMPLEX"}
+    path = os.path.join(os.path.dirname(__file__), "golden", "optimizer_vectors.json")
+    vecs = json.load(open(path))["vectors"]
+    assert len(vecs) >= 53
+    for v in vecs:
+        ast = parse(v["pattern"].encode())
+        if v["fn"] == "classify":
+            assert names[A.classify(ast)] in v["want"], v
+            d = M.CompiledRegex(v["pattern"]).describe()
+            assert any(("complexity=%s\n" % w) in d for w in v["want"]), (v, d[:120])
+        elif v["fn"] == "is_literal_pattern":
+            assert A.is_literal_pattern(ast) == v["want"], v
+        elif v["fn"] == "get_literal_string":
+            assert A.get_literal_string(ast) == v["want"].encode(), v
+        elif v["fn"] == "has_literal_prefix":
+            assert A.has_literal_prefix(ast) == v["want"], v
+        elif v["fn"] == "search":
+            from mrx_ref import hybrid as H
+            assert H.search(v["pattern"].encode(), v["text"].encode())[0] == v["want_start"], v
+        elif v["fn"] == "findall_count":
+            from mrx_ref import hybrid as H
+            assert len(H.findall(v["pattern"].encode(), v["text"].encode())) == v["want"], v
+        else:
+            assert list(A.pattern_has_anchors(ast)) == v["want"], v
+
+
+def test_simd_class_vectors():
+    """tests/test_simd.mojo: CharacterClassSIMD.contains / find_first_nibble_match (a9)."""
+    import json
+    import os
+    from mrx_ref.dfa_engine import ClassMatcher
+    from mrx_ref import hybrid as H
+    path = os.path.join(os.path.dirname(__file__), "golden", "simd_vectors.json")
+    for v in json.load(open(path))["vectors"]:
+        if v["fn"] == "contains":
+            assert ClassMatcher.for_class(v["class"].encode()).contains(ord(v["char"])) == v["want"], v
+        elif v["fn"] == "find_first_nibble_match":
+            t = v["text"].encode()
+            assert ClassMatcher.for_class(v["class"].encode()).find_first_nibble_match(t, v["start"], len(t)) == v["want"], v
+        else:
+            t = v["text"].encode()
+            assert [t[a:b].decode() for a, b in H.findall(v["pattern"].encode(), t)] == v["want"], v
