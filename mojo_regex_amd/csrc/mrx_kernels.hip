@@ -164,7 +164,11 @@ __global__ void k_span_to_flag(int64_t n, const int32_t* __restrict__ start, uin
 }
 
 enum { FA_COUNT = 0, FA_EMIT = 1 };
-enum { STEP_COUNT = 0, STEP_EMIT = 1, STEP_SEARCH = 2 };
+// STEP_SLOTS: count, and park the first kStepSlots spans of every text in a per-text slot row, so
+// that findall usually needs ONE walk over the batch (k_slots_gather moves the rows to their CSR
+// place); STEP_EMIT then only re-walks the texts that have more matches than slots.
+enum { STEP_COUNT = 0, STEP_EMIT = 1, STEP_SEARCH = 2, STEP_SLOTS = 3 };
+constexpr int kStepSlots = 32;
 
 // Windowed stepper for PF_STEPPABLE plans.  Same results as for_each_match() / hybrid_match_next()
 // on those plans, but (1) ONE loop whose every iteration looks at one byte of every lane's text --
@@ -238,6 +242,11 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_wstep(DevPlan p, const uint8_
     int state = idle;
     bool fin = !live || t.len == 0;
     int64_t wo = (MODE == STEP_EMIT && live) ? prefix[i] : 0;
+    if (MODE == STEP_EMIT && counts) {   // after STEP_SLOTS: only texts that overflowed their slots
+      if (live && counts[i] <= kStepSlots) fin = true;
+      if (__all(fin)) continue;
+    }
+    if (MODE == STEP_SLOTS) wo = 0;
     const uint8_t* myrow = tile + lane * kRowPitch;
     const uint8_t* frame = (const uint8_t*)rb;   // frame position f is frame[f] in global memory
     uint4 v[NL];
@@ -270,6 +279,12 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_wstep(DevPlan p, const uint8_
         if (MODE == STEP_EMIT) {
           if (matched) {
             if (wo < span_cap) { spans[2 * wo] = start - mis; spans[2 * wo + 1] = last - mis; }
+            ++wo;
+          }
+        }
+        if (MODE == STEP_SLOTS) {   // spans = slot rows [n][kStepSlots][2]
+          if (matched) {
+            if (wo < kStepSlots) *(int2*)(spans + 2 * (i * kStepSlots + wo)) = make_int2(start - mis, last - mis);
             ++wo;
           }
         }
@@ -306,9 +321,23 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_wstep(DevPlan p, const uint8_
     }
 #undef MRX_WS_LOAD
     if (live) {
-      if (MODE == STEP_COUNT) counts[i] = k;
+      if (MODE == STEP_COUNT || MODE == STEP_SLOTS) counts[i] = k;
       if (MODE == STEP_SEARCH) { out_s[i] = rs; out_e[i] = re; }
     }
+  }
+}
+
+// slot rows -> CSR spans: one lane per text, rows of at most kStepSlots spans
+__global__ __launch_bounds__(kBlock) void k_slots_gather(int64_t n, const int32_t* __restrict__ counts,
+                                                         const int64_t* __restrict__ prefix,
+                                                         const int32_t* __restrict__ slots,
+                                                         int32_t* __restrict__ spans, int64_t span_cap) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = counts[i];
+    if (c > kStepSlots) continue;   // re-walked by k_wstep<STEP_EMIT>
+    const int64_t w = prefix[i];
+    for (int j = 0; j < c; ++j)
+      if (w + j < span_cap) *(int2*)(spans + 2 * (w + j)) = *(const int2*)(slots + 2 * (i * kStepSlots + j));
   }
 }
 
@@ -1421,6 +1450,7 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
   EvRec* d_recs = nullptr;
   int32_t* d_nrecs = nullptr;
   int64_t* d_wbase = nullptr;
+  int32_t* d_slots = nullptr;
   int64_t rec_row = 0;
   if (n > 0) {
     if (stream_ok) {
@@ -1449,7 +1479,12 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
       tm.stop();
     } else {
       ScanTimer tm(s);
-      if (step_ok)
+      if (step_ok && span_cap > 0) {
+        HIP_TRY(scratch_alloc((void**)&d_slots, sizeof(int32_t) * 2 * kStepSlots * (size_t)n, s));
+        hipLaunchKernelGGL(k_wstep<STEP_SLOTS>, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_table_bytes(h->hp.dev.nstates), s, p,
+                           h->d_blob, lay, n, d_counts, (const int64_t*)nullptr, d_slots, (int64_t)0,
+                           (int32_t*)nullptr, (int32_t*)nullptr);
+      } else if (step_ok)
         hipLaunchKernelGGL(k_wstep<STEP_COUNT>, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_table_bytes(h->hp.dev.nstates), s, p,
                            h->d_blob, lay, n, d_counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0,
                            (int32_t*)nullptr, (int32_t*)nullptr);
@@ -1483,11 +1518,14 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
     if (stream_ok) {
       // spans were written by k_decode above
     } else {
-      if (step_ok)
+      if (step_ok) {
+        hipLaunchKernelGGL(k_slots_gather, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, n, d_counts, d_prefix,
+                           d_slots, d_spans, span_cap);
+        // wavefronts without an overflowing text leave at once
         hipLaunchKernelGGL(k_wstep<STEP_EMIT>, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_table_bytes(h->hp.dev.nstates), s, p, h->d_blob,
-                           lay, n, (int32_t*)nullptr, d_prefix, d_spans, span_cap, (int32_t*)nullptr,
+                           lay, n, d_counts, d_prefix, d_spans, span_cap, (int32_t*)nullptr,
                            (int32_t*)nullptr);
-      else
+      } else
         hipLaunchKernelGGL(k_findall<FA_EMIT>, dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s, p,
                            h->d_blob, lay, n, (int32_t*)nullptr, d_prefix, d_spans, span_cap);
     }
@@ -1506,6 +1544,7 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
   if (d_recs) HIP_TRY(scratch_free(d_recs, s));
   if (d_nrecs) HIP_TRY(scratch_free(d_nrecs, s));
   if (d_wbase) HIP_TRY(scratch_free(d_wbase, s));
+  if (d_slots) HIP_TRY(scratch_free(d_slots, s));
   return rc;
 }
 

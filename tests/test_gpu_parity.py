@@ -874,3 +874,18 @@ def test_full_byte_range_texts(pat):
             continue
         for t, g in zip(texts, got):
             assert g == getattr(O, op)(pat, t), (pat, op, t)
+
+
+def test_stepper_slot_overflow_is_rewalked():
+    """k_wstep parks up to 32 spans per text; texts with more are re-walked by the emit pass."""
+    _need_gpu()
+    pat = b"\\d+(\\.\\d+)?"
+    rx = M.compile_regex(pat)
+    assert "device.streamable=no" in rx.describe() and "device.steppable=yes" in rx.describe()
+    texts = [b"1 2.5 x " * 40, b"7", b"", b"3.14 " * 33, b"9 " * 32, b"no digits here", b"4 " * 31, b"1.2.3.4 " * 50]
+    texts = texts * 20
+    got = rx.findall_lists(texts)
+    for t, g in zip(texts[:8], got[:8]):
+        assert g == O.findall(pat, t), t
+    assert got[8:16] == got[:8]
+    assert len(got[0]) == 80 and len(got[4]) == 32 and len(got[6]) == 31
