@@ -455,10 +455,10 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
   __shared__ __align__(16) uint16_t col_lds[256];
   extern __shared__ __align__(16) uint8_t stg_lds[];  // AUTO == 2: cls | trans | accept
   if (AUTO == 1) {
-    const uint16_t* src = (const uint16_t*)(blob + p.off_stcol);
+    const uint16_t* src = (const uint16_t*)(blob + (MODE == ST_FIRST ? p.off_fa_col : p.off_stcol));
     for (int i = threadIdx.x; i < 256; i += blockDim.x) col_lds[i] = src[i];
   } else if (AUTO == 3) {
-    const uint32_t* src = (const uint32_t*)(blob + p.off_stcol);
+    const uint32_t* src = (const uint32_t*)(blob + (MODE == ST_FIRST ? p.off_fa_col : p.off_stcol));
     uint32_t* dst = (uint32_t*)stg_lds;
     for (int i = threadIdx.x; i < 512; i += blockDim.x) dst[i] = src[i];
   } else {
@@ -473,7 +473,9 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
   const uint16_t* tr_lds = (const uint16_t*)(stg_lds + (MODE == ST_FIRST ? p.off_fa_trans - p.off_fa_cls
                                                                         : p.off_stg_trans - p.off_stg_cls));
   const uint8_t* acc_lds = stg_lds + (p.off_stg_acc - p.off_stg_cls);
-  const uint32_t fa_dead = (uint32_t)p.fa_nstates << p.fa_cshift;  // row offset of the dead state
+  // q4 value of the anchored automaton's dead state: its row offset (class table) or field shift (columns)
+  const uint32_t fa_dead = AUTO == 2 ? (uint32_t)p.fa_nstates << p.fa_cshift
+                                     : (uint32_t)p.fa_nstates * (AUTO == 1 ? 4u : 8u);
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   uint8_t* tile = tiles[wave];
@@ -568,16 +570,29 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
       uint32_t pq = 0, pF = 0;
 #pragma unroll
       for (int k = 0; k < 16; ++k) {
-        uint32_t e = tr_lds[pq + cls_lds[(pw[k >> 2] >> ((k & 3) * 8)) & 0xFFu]];
-        if (k < mis || k >= flen) e = pq << 2;
-        pq = e >> 2;
+        const uint32_t b = (pw[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
+        const bool outside = k < mis || k >= flen;
+        uint32_t e;
+        if (AUTO == 2) {
+          e = tr_lds[pq + cls_lds[b]];
+          if (outside) e = pq << 2;
+          pq = e >> 2;
+        } else if (AUTO == 1) {
+          e = (uint32_t)col_lds[b] >> pq;
+          if (outside) e = pq;
+          pq = e & 0xCu;
+        } else {
+          e = (uint32_t)(col64_lds[b] >> pq);
+          if (outside) e = pq;
+          pq = e & 0x38u;
+        }
         pF = __builtin_amdgcn_alignbit(e, pF, 2);
       }
       const uint32_t pem = pF & 0xAAAAAAAAu;
       if (__all(!live || pq == fa_dead || flen <= 16)) {
         if (live) {
           int e_ = pem ? ((31 - __builtin_clz(pem)) >> 1) + 1 - mis : (p.fa_start_acc ? 0 : -1);
-          if (p.off_fa_end >= 0 && stg_lds[(p.off_fa_end - p.off_fa_cls) + (pq >> p.fa_cshift)]) e_ = my_len;
+          if (AUTO == 2 && p.off_fa_end >= 0 && stg_lds[(p.off_fa_end - p.off_fa_cls) + (pq >> p.fa_cshift)]) e_ = my_len;
           out_s[my_text] = e_ >= 0 ? 0 : -1;
           out_e[my_text] = e_;
         }
@@ -729,7 +744,7 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
       if (MODE == ST_FIRST) {
         if (live) {
           // OnePass '$' fixup: the walk reached the end of the text alive in an end-accepting state
-          if (p.off_fa_end >= 0 && stg_lds[(p.off_fa_end - p.off_fa_cls) + (q4 >> p.fa_cshift)]) res_e = my_len;
+          if (AUTO == 2 && p.off_fa_end >= 0 && stg_lds[(p.off_fa_end - p.off_fa_cls) + (q4 >> p.fa_cshift)]) res_e = my_len;
           out_s[my_text] = res_e >= 0 ? 0 : -1;
           out_e[my_text] = res_e;
         }
@@ -1415,8 +1430,9 @@ void launch_stream(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d
   int64_t g = (nw + kStreamWaves - 1) / kStreamWaves;
   if (g > 256 * 8) g = 256 * 8;
   const dim3 grid((unsigned)g), block(64 * kStreamWaves);
-  const bool table = MODE == ST_FIRST || p.st_kind == 2;
-  const bool wide = !table && p.st_kind == 3;
+  const int kind = MODE == ST_FIRST ? p.fa_kind : p.st_kind;   // automaton form of this mode
+  const bool table = kind == 2;
+  const bool wide = kind == 3;
   const size_t lds = wide ? 2048 : !table ? 0 : (size_t)(MODE == ST_FIRST ? p.fa_bytes : p.stg_bytes);
 #define MRX_LAUNCH(AUTO, CSR)                                                                     \
   hipLaunchKernelGGL((k_stream_findall<MODE, MRX_STREAM_CHUNK, AUTO, CSR>), grid, block, lds, s, p, \
@@ -1424,10 +1440,12 @@ void launch_stream(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d
                      d_nrecs, d_recs, rec_row, d_s, d_e)
   if (!strided_fast(lay)) {
     if (table) MRX_LAUNCH(2, 1);
-    else if constexpr (MODE != ST_FIRST) { if (wide) MRX_LAUNCH(3, 1); else MRX_LAUNCH(1, 1); }
+    else if (wide) MRX_LAUNCH(3, 1);
+    else MRX_LAUNCH(1, 1);
   } else {
     if (table) MRX_LAUNCH(2, 0);
-    else if constexpr (MODE != ST_FIRST) { if (wide) MRX_LAUNCH(3, 0); else MRX_LAUNCH(1, 0); }
+    else if (wide) MRX_LAUNCH(3, 0);
+    else MRX_LAUNCH(1, 0);
   }
 #undef MRX_LAUNCH
 }

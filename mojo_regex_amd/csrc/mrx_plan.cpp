@@ -661,6 +661,7 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
   //   otherwise          the table walk (dfa.mojo:1979-2024 / pikevm.mojo:819-867)
   d.fa_bytes = 0; d.fa_nstates = 0; d.fa_start_acc = 0; d.off_fa_cls = d.off_fa_trans = -1; d.fa_cshift = 0;
   d.off_fa_end = -1;
+  d.fa_kind = 0; d.off_fa_col = -1;
   hp.first_stream_why_not.clear();
   if (d.kind == PLAN_ANY) hp.first_stream_why_not = "'.*' shortcut";
   else if (!hp.why_no_match_first.empty()) hp.first_stream_why_not = hp.why_no_match_first;
@@ -722,9 +723,38 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
     int cshift = 0;
     while ((1 << cshift) < fn) ++cshift;
     const int ncp = 1 << cshift;
-    if ((int64_t)(nl + 1) * ncp > 8192) {
+    if (E.empty() && nl + 1 <= 8) {
+      // byte-column forms (no dependent LDS read per byte): field(q) = next | ACC(next) << 1 in the
+      // layouts of the search automaton, the dead state is field nl
+      const bool narrow = nl + 1 <= 4;
+      std::vector<uint64_t> cols(256, 0);
+      for (int c = 0; c < 256; ++c) {
+        for (int q = 0; q <= nl; ++q) {
+          int t = nl;   // dead
+          bool a = false;
+          if (q < nl && N[order[q]][c] >= 0) { t = remap[N[order[q]][c]]; a = A[N[order[q]][c]] != 0; }
+          const uint64_t f = narrow ? (uint64_t)((t << 2) | (a ? 2 : 0)) : (uint64_t)((t << 3) | (a ? 2 : 0));
+          cols[c] |= f << ((narrow ? 4 : 8) * q);
+        }
+      }
+      align(hp.blob, 16);
+      const int begin = (int)hp.blob.size();
+      d.off_fa_col = begin;
+      if (narrow) {
+        std::vector<uint16_t> c16(256);
+        for (int c = 0; c < 256; ++c) c16[c] = (uint16_t)cols[c];
+        put(hp.blob, c16.data(), 512);
+      } else {
+        put(hp.blob, cols.data(), 2048);
+      }
+      align(hp.blob, 16);
+      d.fa_bytes = (int)hp.blob.size() - begin;
+      d.fa_kind = narrow ? 1 : 3;
+      d.fa_nstates = nl; d.fa_start_acc = A[0];
+    } else if ((int64_t)(nl + 1) * ncp > 8192) {
       hp.first_stream_why_not = "anchored automaton too large for the streaming kernel's LDS table";
     } else {
+      d.fa_kind = 2;
       std::vector<uint16_t> tr((size_t)(nl + 1) * ncp, (uint16_t)(((nl << cshift) << 2)));  // default: dead
       for (int c = 0; c < 256; ++c)
         for (int q = 0; q < nl; ++q) {
@@ -827,7 +857,7 @@ std::string describe_plan(const HostPlan& hp) {
     << (((d.flags & PF_STREAMABLE) && !(d.flags & PF_STREAM_SEARCH)) ? " findall_only=1" : "") << "\n";
   o << "device.steppable=" << ((d.flags & PF_STEPPABLE) ? "yes" : "no") << "\n";
   o << "device.first_stream=" << (d.fa_bytes ? "yes" : ("no: " + hp.first_stream_why_not))
-    << " fa_nstates=" << d.fa_nstates << (hp.first_onepass ? " onepass=yes" : "") << "\n";
+    << " fa_nstates=" << d.fa_nstates << " fa_kind=" << d.fa_kind << (hp.first_onepass ? " onepass=yes" : "") << "\n";
   if (d.flags & PF_BITSET)
     o << "device.bitset=yes positions=" << d.bs_npos << " words=" << d.bs_nw << " byte_classes=" << d.bs_ncls << "\n";
   return o.str();

@@ -69,6 +69,9 @@ struct DevPlan {
   // OnePass '$' fixup (onepass.mojo:480-484): u8 per state (dead row included), consulted when the
   // walk reaches the end of the text alive; -1 = the automaton has no such flags
   int32_t off_fa_end;
+  // fa_kind: 2 = class table (above), 1 / 3 = byte-column forms as for the search automaton
+  // (u16 / u64 columns at off_fa_col; the dead state is the last field, entry = next | ACC << 1)
+  int32_t fa_kind, off_fa_col;
   // bitset NFA (PF_BITSET): cls[256] u8, byte masks u64[bs_ncls][bs_nw], follow u64[bs_npos][bs_nw]
   int32_t bs_nw, bs_npos, bs_ncls, off_bs_cls, off_bs_mask, off_bs_follow;
   uint64_t bs_start[4], bs_match[4];
