@@ -1,0 +1,35 @@
+import sys, zlib
+sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/oracle'); sys.path.insert(0,'/root/repo/tests')
+import numpy as np
+import mojo_regex_amd as M
+import mrx_ref as O
+from mrx_ref.hybrid import UnsupportedByOracle
+from pattern_gen import patterns
+def rtexts(rng, n, max_len, alphabet):
+    al = np.frombuffer(alphabet, dtype=np.uint8)
+    lens = rng.integers(0, max_len + 1, size=n)
+    return [bytes(rng.choice(al, size=int(k)).tolist()) for k in lens]
+bad = 0; checked = 0
+for seed in range(30000, 30012):
+    rng = np.random.default_rng(seed)
+    texts = rtexts(rng, 30, 60, b"abcxyz019 -@.") + rtexts(rng, 12, 220, b"abcfoobarhellocatdog0123456789 xyz@.-") + [b"", b"a", b"foobar", b"hello", b"abc123", b"cat dog", b"http://id.no", b"q"*150+b"1"]
+    for p in patterns(seed, 300):
+        pb = p.encode()
+        try: rx = M.compile_regex(pb)
+        except M.RegexSyntaxError: continue
+        for op in ("findall", "search", "match_first"):
+            try:
+                if op == "findall": got = rx.findall_lists(texts)
+                else:
+                    s, e = (rx.match_next if op == "search" else rx.match_first)(texts)
+                    got = [(int(a), int(b)) if a >= 0 else None for a, b in zip(s, e)]
+            except M.UnsupportedPattern:
+                continue
+            for t, g in zip(texts, got):
+                try: w = getattr(O, op)(pb, t)
+                except UnsupportedByOracle: continue
+                checked += 1
+                if g != w:
+                    bad += 1
+                    if bad < 10: print("MISMATCH", repr(p), op, t, g, w)
+    print("seed", seed, "checked", checked, "bad", bad, flush=True)
