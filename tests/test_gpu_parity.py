@@ -889,3 +889,65 @@ def test_stepper_slot_overflow_is_rewalked():
         assert g == O.findall(pat, t), t
     assert got[8:16] == got[:8]
     assert len(got[0]) == 80 and len(got[4]) == 32 and len(got[6]) == 31
+
+
+def test_concurrent_calls_on_one_handle():
+    """include/mrx.h: a handle is immutable after mrx_compile(), so concurrent batch calls on one
+    handle are safe (per-thread scratch arenas, no shared mutable state).  ctypes drops the GIL
+    during the calls, so these threads really overlap."""
+    _need_gpu()
+    import threading
+    rx = M.compile_regex(b"[a-z]+\\d+")
+    rng = np.random.default_rng(5)
+    batches, want = [], []
+    for k in range(4):
+        texts = _random_texts(rng, 400 + 50 * k, 300, b"abcxyz0123 ")
+        b = M.DeviceBatch.from_texts(texts)
+        batches.append(b)
+        want.append(rx._dev_findall(b))
+    errs = []
+
+    def work(k):
+        try:
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                for _ in range(25):
+                    pre, sp, tot = rx._dev_findall(batches[k])
+                    wp, ws, wt = want[k]
+                    if tot != wt or not torch.equal(pre, wp) or not torch.equal(sp[:tot], ws[:wt]):
+                        errs.append(k)
+                        return
+                    cnt = rx.count(batches[k])
+                    if not torch.equal(cnt.to(torch.int64), wp[1:] - wp[:-1]):
+                        errs.append(-k - 1)
+                        return
+        except Exception as exc:  # noqa: BLE001
+            errs.append(repr(exc))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs, errs
+
+
+def test_findall_count_only_and_capacity_error():
+    """span_cap == 0: totals and CSR offsets without spans; a too-small buffer reports the need."""
+    _need_gpu()
+    import ctypes as C
+    rx = M.compile_regex(b"[a-z]+\\d+")
+    texts = [b"a1 b2 c3", b"", b"zz9"] * 50
+    b = M.DeviceBatch.from_texts(texts)
+    lib = M.load_library()
+    prefix = torch.empty(b.n + 1, dtype=torch.int64, device="cuda")
+    total = C.c_int64(0)
+    rc = lib.mrx_findall_dev(rx._h, C.c_void_p(b.data.data_ptr()), C.c_void_p(b.offsets.data_ptr()), b.n,
+                             C.c_void_p(prefix.data_ptr()), None, 0, C.byref(total), None)
+    assert rc == M.api.MRX_E_CAPACITY and total.value == 200      # need reported, nothing written
+    assert prefix[-1].item() == 200 and prefix[3].item() == 4
+    spans = torch.full((10, 2), -5, dtype=torch.int32, device="cuda")
+    rc = lib.mrx_findall_dev(rx._h, C.c_void_p(b.data.data_ptr()), C.c_void_p(b.offsets.data_ptr()), b.n,
+                             C.c_void_p(prefix.data_ptr()), C.c_void_p(spans.data_ptr()), 10, C.byref(total), None)
+    assert rc == M.api.MRX_E_CAPACITY and total.value == 200
+    assert spans[:4].tolist() == [[0, 2], [3, 5], [6, 8], [0, 3]]   # what fits is written, in order
