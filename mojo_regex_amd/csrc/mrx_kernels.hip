@@ -959,7 +959,8 @@ __global__ __launch_bounds__(kBlock) void k_subs_sizes(int64_t n, const int64_t*
 // finds by binary search which replacement precedes its first byte and then walks: replacement
 // bytes come from rmap (literal byte, or 0x8000 | offset into the match for a group byte), kept
 // bytes from the input through an 8-byte register window.
-constexpr int kSubsStage = 256;  // replacements per text staged in LDS (more: read from global)
+constexpr int kSubsStage = 128;  // replacements per text staged in LDS (more: read from global)
+constexpr int kSubsLanes = 16;   // lanes that share one text in k_subs_emit
 
 // bytes src .. src+15 of a text as two little-endian u64 (bytes past the text are unspecified but
 // never fetched from beyond the aligned word that holds the text's last byte)
@@ -981,15 +982,18 @@ __global__ __launch_bounds__(kBlock) void k_subs_emit(int64_t n, const uint8_t* 
                                                       int R, const uint16_t* __restrict__ rmap,
                                                       const int64_t* __restrict__ out_off,
                                                       uint8_t* __restrict__ out) {
-  __shared__ int3 stage_all[kBlock / 64][kSubsStage];  // {rstart, match start, match end}
+  // kSubsLanes lanes share one text (4 texts per wavefront): a 1 KiB text has ~70 output blocks,
+  // which 64 lanes cover in two half-empty rounds; 16 lanes cover them in five full ones, and the
+  // four texts' dependent round trips (offsets -> spans -> bytes) overlap.
+  __shared__ int3 stage_all[kBlock / kSubsLanes][kSubsStage];  // {rstart, match start, match end}
   extern __shared__ __align__(16) uint8_t subs_dyn[];   // the replacement map (R u16 entries)
   uint16_t* rmap_lds = (uint16_t*)subs_dyn;
   for (int r = threadIdx.x; r < R; r += blockDim.x) rmap_lds[r] = rmap[r];
   __syncthreads();
-  const int lane = threadIdx.x & 63;
-  int3* stage = stage_all[threadIdx.x >> 6];
-  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
-  for (int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); i < n; i += nwaves) {
+  const int lane = threadIdx.x & (kSubsLanes - 1);   // lane within the group that owns the text
+  int3* stage = stage_all[threadIdx.x / kSubsLanes];
+  const int64_t ngroups = (int64_t)gridDim.x * (blockDim.x / kSubsLanes);
+  for (int64_t i = (int64_t)blockIdx.x * (blockDim.x / kSubsLanes) + (threadIdx.x / kSubsLanes); i < n; i += ngroups) {
     const int64_t ibase = offsets[i];
     const uint8_t* tptr = data + ibase;
     const int tlen = (int)(offsets[i + 1] - ibase);
@@ -1005,7 +1009,7 @@ __global__ __launch_bounds__(kBlock) void k_subs_emit(int64_t n, const uint8_t* 
     const bool staged = k <= kSubsStage;
     __builtin_amdgcn_wave_barrier();
     if (staged) {
-      for (int m = lane; m < k; m += 64) {
+      for (int m = lane; m < k; m += kSubsLanes) {
         const int2 se = *(const int2*)(sp + 2 * m);
         stage[m] = make_int3(se.x - cm[m] + m * R, se.x, se.y);
       }
@@ -1019,7 +1023,7 @@ __global__ __launch_bounds__(kBlock) void k_subs_emit(int64_t n, const uint8_t* 
       return make_int3(se.x - cm[m] + m * R, se.x, se.y);
     };
     const int head = (int)((uintptr_t)(out + obase) & 15);  // output starts `head` bytes into its first 16-byte block
-    for (int blk = 0; blk * 16 < head + olen; blk += 64) {
+    for (int blk = 0; blk * 16 < head + olen; blk += kSubsLanes) {
       const int p_lo = (blk + lane) * 16 - head;   // first output position of my block (may be < 0)
       int p = p_lo < 0 ? 0 : p_lo;
       const int p_hi = p_lo + 16 < olen ? p_lo + 16 : olen;
@@ -1613,7 +1617,7 @@ int sub_from_spans(const mrx_handle* h, const Layout& lay, int64_t n, const std:
     if (tot > out_cap) {
       rc = fail(MRX_E_CAPACITY, "output buffer too small: need " + std::to_string(tot));
     } else if (tot > 0) {
-      const int64_t blocks = (n + (kBlock / 64) - 1) / (kBlock / 64);
+      const int64_t blocks = (n + (kBlock / kSubsLanes) - 1) / (kBlock / kSubsLanes);
       hipLaunchKernelGGL(k_subs_emit, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(kBlock),
                          (size_t)(2 * R + 16), s, n, lay.data, lay.offsets, d_prefix, d_spans, d_cum, (long long)count, R, d_rmap,
                          out_off, out);
