@@ -926,15 +926,16 @@ __global__ __launch_bounds__(kBlock) void k_subs_sizes(int64_t n, const int64_t*
                                                        const int32_t* __restrict__ spans, long long count,
                                                        int R, int64_t* __restrict__ sizes,
                                                        int32_t* __restrict__ cum) {
-  // one wavefront per text: coalesced span loads, wave prefix sum of the match lengths
-  const int lane = threadIdx.x & 63;
-  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
-  for (int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); i < n; i += nwaves) {
+  // 16 lanes per text: coalesced span loads, prefix sum of the match lengths inside the group
+  constexpr int G = 16;
+  const int lane = threadIdx.x & (G - 1);
+  const int64_t ngroups = (int64_t)gridDim.x * (blockDim.x / G);
+  for (int64_t i = (int64_t)blockIdx.x * (blockDim.x / G) + (threadIdx.x / G); i < n; i += ngroups) {
     const int64_t a = prefix[i];
     int64_t k = prefix[i + 1] - a;
     if (count > 0 && k > count) k = count;
     int carry = 0;
-    for (int64_t m0 = 0; m0 < k; m0 += 64) {
+    for (int64_t m0 = 0; m0 < k; m0 += G) {
       const int64_t m = m0 + lane;
       int len = 0;
       if (m < k) {
@@ -943,12 +944,12 @@ __global__ __launch_bounds__(kBlock) void k_subs_sizes(int64_t n, const int64_t*
       }
       int incl = len;
 #pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const int v = __shfl_up(incl, d);
+      for (int d = 1; d < G; d <<= 1) {
+        const int v = __shfl_up(incl, d, G);
         if (lane >= d) incl += v;
       }
       if (m < k) cum[a + m] = carry + incl - len;
-      carry += __shfl(incl, 63);
+      carry += __shfl(incl, G - 1, G);
     }
     if (lane == 0) sizes[i] = (offsets[i + 1] - offsets[i]) - carry + k * (int64_t)R;
   }
@@ -1603,7 +1604,7 @@ int sub_from_spans(const mrx_handle* h, const Layout& lay, int64_t n, const std:
   HIP_TRY(scratch_alloc((void**)&d_total, sizeof(int64_t), s));
   if (R) HIP_TRY(hipMemcpyAsync(d_rmap, rmap.data(), sizeof(uint16_t) * R, hipMemcpyHostToDevice, s));
   {
-    const int64_t blocks = (n + (kBlock / 64) - 1) / (kBlock / 64);
+    const int64_t blocks = (n + (kBlock / 16) - 1) / (kBlock / 16);
     hipLaunchKernelGGL(k_subs_sizes, dim3((unsigned)(blocks < 65536 * 4 ? blocks : 65536 * 4)), dim3(kBlock), 0, s,
                        n, lay.offsets, d_prefix, d_spans, (long long)count, R, d_sizes, d_cum);
   }
