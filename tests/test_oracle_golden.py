@@ -185,3 +185,20 @@ def test_simd_class_vectors():
         else:
             t = v["text"].encode()
             assert [t[a:b].decode() for a, b in H.findall(v["pattern"].encode(), t)] == v["want"], v
+
+
+def test_patterns_the_reference_requires_to_raise():
+    """tests/test_lexer.mojo / tests/test_parser.mojo `with assert_raises()`: the oracle's front end
+    and the product's (MRX_E_SYNTAX) both refuse these patterns, with the same message."""
+    import json
+    import os
+    import mojo_regex_amd as M
+    from mrx_ref import RegexSyntaxError as OracleSyntaxError
+    from mrx_ref.frontend import parse
+    path = os.path.join(os.path.dirname(__file__), "golden", "syntax_error_vectors.json")
+    for v in json.load(open(path))["vectors"]:
+        with pytest.raises(OracleSyntaxError) as eo:
+            parse(v["pattern"].encode())
+        with pytest.raises(M.RegexSyntaxError) as ep:
+            M.CompiledRegex(v["pattern"])
+        assert str(eo.value) == str(ep.value), v
