@@ -202,3 +202,28 @@ def test_patterns_the_reference_requires_to_raise():
         with pytest.raises(M.RegexSyntaxError) as ep:
             M.CompiledRegex(v["pattern"])
         assert str(eo.value) == str(ep.value), v
+
+
+def test_parser_ast_shape_vectors():
+    """tests/test_parser.mojo: node types, child counts, quantifier bounds, values and negation
+    flags at given child paths (tests/golden/ast_vectors.json, made by extract_ast_vectors.py)."""
+    import json
+    import os
+    from mrx_ref import frontend as F
+    path = os.path.join(os.path.dirname(__file__), "golden", "ast_vectors.json")
+    vecs = json.load(open(path))["vectors"]
+    assert len(vecs) >= 60
+    for v in vecs:
+        node = F.parse(v["pattern"].encode())
+        for i in v["path"]:
+            node = node.get_child(i)
+        a = v["attr"]
+        if a == "type":
+            got = F.TYPE_NAMES[node.type]
+        elif a == "children_len":
+            got = node.get_children_len()
+        elif a == "value":
+            got = node.get_value().decode()
+        else:
+            got = getattr(node, a)
+        assert got == v["want"], v
