@@ -227,3 +227,25 @@ def test_parser_ast_shape_vectors():
         else:
             got = getattr(node, a)
         assert got == v["want"], v
+
+
+def test_lexer_token_vectors():
+    """tests/test_lexer.mojo: token types / characters at given indexes."""
+    import json
+    import os
+    from mrx_ref import frontend as F
+    names = {"ELEMENT": F.T_ELEMENT, "COMMA": F.T_COMMA, "START": F.T_START, "END": F.T_END, "DASH": F.T_DASH,
+             "SPACE": F.T_SPACE, "WILDCARD": F.T_WILDCARD, "LEFTPARENTHESIS": F.T_LPAREN,
+             "RIGHTPARENTHESIS": F.T_RPAREN, "LEFTBRACKET": F.T_LBRACKET, "RIGHTBRACKET": F.T_RBRACKET,
+             "LEFTCURLYBRACE": F.T_LCURLY, "RIGHTCURLYBRACE": F.T_RCURLY, "ASTERISK": F.T_ASTERISK,
+             "PLUS": F.T_PLUS, "QUESTIONMARK": F.T_QMARK, "VERTICALBAR": F.T_VBAR}
+    path = os.path.join(os.path.dirname(__file__), "golden", "lexer_vectors.json")
+    for v in json.load(open(path))["vectors"]:
+        toks = F.scan(v["pattern"].encode())
+        if "len" in v:
+            assert len(toks) == v["len"], v
+            continue
+        t = toks[v["index"]]
+        assert t.type == names[v["type"]], (v, t)
+        if "char" in v:
+            assert t.char == ord(v["char"]), (v, t)
