@@ -10,8 +10,11 @@ Who may import this package: ``tests/``, ``__graft_entry__.smoke()`` and the
 imports, links or executes anything under ``oracle/``.
 
 Parity status: PINNED against the reference's own known-answer tests
-(``tests/golden/reference_vectors.json``, transcribed from the reference's
-``tests/test_*.mojo`` with file:line per vector).  The reference itself cannot
+(``tests/golden/*.json``: matching results, routing and ``sub`` from
+``tests/test_{matcher,dfa,comptime_regex,predefined_classes,split,simd}.mojo``, OnePass,
+classifier / literal helpers, class matcher, lexer tokens, parser AST shapes and required
+syntax errors from the remaining test files -- transcribed as data with file:line per
+vector by the two scripts under ``tests/golden/`` or by hand where noted).  The reference itself cannot
 be executed here (no Mojo toolchain in the image), see DESIGN.md.  One routing
 case is derived from source only and is labelled PARITY-UNPINNED: quantified
 literal alternation such as ``(x|y|foo|bar)+``.
