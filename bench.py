@@ -257,6 +257,11 @@ def main():
                          "traffic": (measured_traffic(n, L) or (None, None))[0],
                          "traffic_source": (measured_traffic(n, L) or (None, None))[1],
                          "kernel_ms": round(scan_ms, 4), "launches_timed": int(launches.value),
+                         # real HBM traffic rate of the kernel next to what a plain float4 copy reaches
+                         # on this part (6.29 TB/s measured, MI355X_MICROARCH.md) -- informational
+                         "traffic_GBps": (round(measured_traffic(n, L)[0] / (scan_ms * 1e-3) / 1e9, 1)
+                                          if measured_traffic(n, L) and scan_ms > 0 else None),
+                         "copy_GBps_measured_on_part": 6290.0,
                          "algorithmic_bytes_per_launch": int(alg_bytes)},
         }
         if other is not None:
