@@ -181,10 +181,16 @@ constexpr int kStepSlots = 32;
 // (register window, 64-bit addressing and bounds logic of the generic Text; rocprof: 92 VALU + 67
 // SALU instructions per byte step on config 4) to ~30.
 constexpr int kWsWaves = 4;
-constexpr uint32_t kWsDead = 0xFFFFu, kWsAcc = 0x8000u, kWsStart = 0x4000u;
+constexpr uint32_t kWsDead = 0xFFFFu, kWsAcc = 0x8000u, kWsStart = 0x4000u, kWsFirst = 0x2000u;
 __host__ __device__ inline size_t wstep_table_bytes(int nstates) { return (size_t)(nstates + 1) * 512; }
 
-template <int MODE>
+// ROUTE 1 = HybridMatcher._match_all_required_byte (matcher.mojo:864-898) as the same kind of
+// flattened machine: SCAN forward for the required byte while tracking where the current run of
+// first-class bytes began (rsb); on a hit jump back to that run start and WALK the table from
+// there (DFAEngine.match_first, anchored); keep the match if it ends past the hit and resume at
+// its end, else resume at hit + 1.  (The required byte is not in the first class, so the run
+// start at hit + 1 is hit + 1; the run start at a match end is remembered when `last` moves.)
+template <int MODE, int ROUTE>
 __global__ __launch_bounds__(64 * kWsWaves) void k_wstep(DevPlan p, const uint8_t* __restrict__ blob, Layout lay,
                                                          int64_t n, int32_t* __restrict__ counts,
                                                          const int64_t* __restrict__ prefix,
@@ -209,6 +215,9 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_wstep(DevPlan p, const uint8_
       if (q < ns) {
         const uint32_t t = g_tr[q * p.ncls + g_cls[b]];
         v = t == 0xFFFFu ? kWsDead : ((t & 0x7FFFu) | ((t & 0x8000u) ? kWsAcc : 0u));
+        if (ROUTE == 1 && v != kWsDead && g_first[b]) v |= kWsFirst;   // walk steps keep tracking the run start
+      } else if (ROUTE == 1) {   // SCAN row: 2 = the required byte, 1 = first-class byte, 0 = other
+        v = b == p.required_byte ? 2u : g_first[b] ? 1u : 0u;
       } else {   // find_first_class + the first step of the walk it starts
         const uint32_t t = g_tr[0 * p.ncls + g_cls[b]];
         v = ((filt && !g_first[b]) || t == 0xFFFFu) ? (uint32_t)idle
@@ -239,6 +248,7 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_wstep(DevPlan p, const uint8_
     for (int off = 32; off > 0; off >>= 1) max_end = max(max_end, __shfl_xor(max_end, off));
 
     int pos = mis, start = mis, last = -1, k = 0, rs = -1, re = -1;
+    int rsb = mis, rsb_last = mis, hit = -1;   // ROUTE 1: run start of first-class bytes (now / at `last`), last hit
     int state = idle;
     bool fin = !live || t.len == 0;
     int64_t wo = (MODE == STEP_EMIT && live) ? prefix[i] : 0;
@@ -272,6 +282,41 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_wstep(DevPlan p, const uint8_
       auto step = [&](bool act, uint32_t byte) {
         const bool inside = pos < end;
         const uint32_t e = tab[(state << 8) + byte];
+        if (ROUTE == 1) {
+          const bool scanning = state == idle;
+          // SCAN
+          const bool s_end = act && scanning && !inside;
+          const bool s_hit = act && scanning && inside && e == 2u;
+          const bool s_adv = act && scanning && inside && e != 2u;
+          // WALK
+          const bool alive = act && !scanning && inside && e != kWsDead;
+          const bool ends = act && !scanning && !alive;
+          const bool matched = ends && last > hit;           // must end past the required byte
+          if (MODE == STEP_EMIT) {
+            if (matched) {
+              if (wo < span_cap) { spans[2 * wo] = start - mis; spans[2 * wo + 1] = last - mis; }
+              ++wo;
+            }
+          }
+          if (MODE == STEP_SLOTS) {
+            if (matched) {
+              if (wo < kStepSlots) *(int2*)(spans + 2 * (i * kStepSlots + wo)) = make_int2(start - mis, last - mis);
+              ++wo;
+            }
+          }
+          fin = fin || s_end;
+          k += matched ? 1 : 0;
+          const int nxt = pos + 1;
+          // run-start tracking: a non-first-class byte moves it past itself
+          const bool moves = (s_adv && e == 0u) || (alive && !(e & kWsFirst));
+          const int rsb_n = moves ? nxt : rsb;
+          if (alive && (e & kWsAcc)) { last = nxt; rsb_last = rsb_n; }
+          if (s_hit) { hit = pos; start = rsb; last = -1; }
+          pos = (s_adv || alive) ? nxt : s_hit ? rsb : ends ? (matched ? last : hit + 1) : pos;
+          rsb = ends ? (matched ? rsb_last : hit + 1) : rsb_n;
+          state = s_hit ? 0 : alive ? (int)(e & 0x1FFFu) : ends ? idle : state;
+          return;
+        }
         const bool alive = act && inside && e != kWsDead;
         const bool stop = act && !alive;                     // dead entry, or the text has ended
         const bool ends = stop && state != idle;             // a walk stops here
@@ -1325,6 +1370,13 @@ int grid_for(int64_t n, int block) {
   return (int)(g < cap ? g : cap);
 }
 
+// k_wstep for findall / count: plain route or required-byte route, by plan
+#define MRX_WSTEP_LAUNCH(MODE, ...)                                                        \
+  do {                                                                                     \
+    if (h->hp.dev.flags & PF_STEP_REQ) hipLaunchKernelGGL((k_wstep<MODE, 1>), __VA_ARGS__); \
+    else hipLaunchKernelGGL((k_wstep<MODE, 0>), __VA_ARGS__);                              \
+  } while (0)
+
 int wstep_grid(int64_t n) {
   const int64_t nw = (n + 63) / 64;
   int64_t g = (nw + kWsWaves - 1) / kWsWaves;
@@ -1402,9 +1454,9 @@ int run_match(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d_s, i
   if (n == 0) return MRX_OK;
   hipStream_t s = (hipStream_t)stream;
   ScanTimer tm(s);
-  if (OP == OP_SEARCH && g_force_generic < 2 && (h->hp.dev.flags & PF_STEPPABLE) &&
+  if (OP == OP_SEARCH && g_force_generic < 2 && (h->hp.dev.flags & PF_STEP_SEARCH) &&
       !(h->hp.dev.flags & PF_PREFILTER)) {   // (the memchr prefilter changes match_next, matcher.mojo:784-796)
-    hipLaunchKernelGGL(k_wstep<STEP_SEARCH>, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_table_bytes(h->hp.dev.nstates), s, h->hp.dev,
+    hipLaunchKernelGGL((k_wstep<STEP_SEARCH, 0>), dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_table_bytes(h->hp.dev.nstates), s, h->hp.dev,
                        h->d_blob, lay, n, (int32_t*)nullptr, (const int64_t*)nullptr, (int32_t*)nullptr,
                        (int64_t)0, d_s, d_e);
     g_last_kernel = "k_step_search";
@@ -1469,7 +1521,7 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
   HIP_TRY(scratch_alloc((void**)&d_total, sizeof(int64_t), s));
   const DevPlan& p = h->hp.dev;
   const bool stream_ok = !g_force_generic && (p.flags & PF_STREAMABLE) && stream_layout_ok(lay, n);
-  const bool step_ok = g_force_generic < 2 && (p.flags & PF_STEPPABLE);
+  const bool step_ok = g_force_generic < 2 && (p.flags & (PF_STEPPABLE | PF_STEP_REQ));
   EvRec* d_recs = nullptr;
   int32_t* d_nrecs = nullptr;
   int64_t* d_wbase = nullptr;
@@ -1504,11 +1556,11 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
       ScanTimer tm(s);
       if (step_ok && span_cap > 0) {
         HIP_TRY(scratch_alloc((void**)&d_slots, sizeof(int32_t) * 2 * kStepSlots * (size_t)n, s));
-        hipLaunchKernelGGL(k_wstep<STEP_SLOTS>, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_table_bytes(h->hp.dev.nstates), s, p,
+        MRX_WSTEP_LAUNCH(STEP_SLOTS, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_table_bytes(h->hp.dev.nstates), s, p,
                            h->d_blob, lay, n, d_counts, (const int64_t*)nullptr, d_slots, (int64_t)0,
                            (int32_t*)nullptr, (int32_t*)nullptr);
       } else if (step_ok)
-        hipLaunchKernelGGL(k_wstep<STEP_COUNT>, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_table_bytes(h->hp.dev.nstates), s, p,
+        MRX_WSTEP_LAUNCH(STEP_COUNT, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_table_bytes(h->hp.dev.nstates), s, p,
                            h->d_blob, lay, n, d_counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0,
                            (int32_t*)nullptr, (int32_t*)nullptr);
       else
@@ -1545,7 +1597,7 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
         hipLaunchKernelGGL(k_slots_gather, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, n, d_counts, d_prefix,
                            d_slots, d_spans, span_cap);
         // wavefronts without an overflowing text leave at once
-        hipLaunchKernelGGL(k_wstep<STEP_EMIT>, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_table_bytes(h->hp.dev.nstates), s, p, h->d_blob,
+        MRX_WSTEP_LAUNCH(STEP_EMIT, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_table_bytes(h->hp.dev.nstates), s, p, h->d_blob,
                            lay, n, d_counts, d_prefix, d_spans, span_cap, (int32_t*)nullptr,
                            (int32_t*)nullptr);
       } else
@@ -1792,7 +1844,7 @@ static int run_captures_any(const mrx_handle* h, const Layout& lay, int64_t n, i
   if (!h) return fail(MRX_E_ARGUMENT, "null handle");
   const uint32_t fl = h->hp.dev.flags;
   const bool fast_search = (!g_force_generic && (fl & PF_STREAM_SEARCH)) ||
-                           (g_force_generic < 2 && (fl & PF_STEPPABLE) && !(fl & PF_PREFILTER));
+                           (g_force_generic < 2 && (fl & PF_STEP_SEARCH) && !(fl & PF_PREFILTER));
   if (!fast_search || h->hp.fixed_total < 0 || n <= 0)
     return run_match<OP_CAPTURES>(h, lay, n, spans, nullptr, nullptr, st);
   // search on the streaming kernel (or the windowed stepper), then the groups at their fixed offsets
@@ -1843,8 +1895,8 @@ static int run_count_any(const mrx_handle* h, const Layout& lay, int64_t n, int3
     launch_stream<ST_COUNT>(h, lay, n, counts, nullptr, nullptr, 0, nullptr, nullptr, s);
     g_last_kernel = "k_stream_count";
   } else {
-    if (g_force_generic < 2 && (h->hp.dev.flags & PF_STEPPABLE)) {
-      hipLaunchKernelGGL(k_wstep<STEP_COUNT>, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_table_bytes(h->hp.dev.nstates), s, h->hp.dev,
+    if (g_force_generic < 2 && (h->hp.dev.flags & (PF_STEPPABLE | PF_STEP_REQ))) {
+      MRX_WSTEP_LAUNCH(STEP_COUNT, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_table_bytes(h->hp.dev.nstates), s, h->hp.dev,
                          h->d_blob, lay, n, counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0,
                          (int32_t*)nullptr, (int32_t*)nullptr);
       g_last_kernel = "k_step_count";

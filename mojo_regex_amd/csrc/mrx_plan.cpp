@@ -649,8 +649,13 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
   if ((d.kind == PLAN_DFA || d.kind == PLAN_LAZY) && hp.why_no_search.empty() &&
       !(d.flags & (PF_START_ANCHOR | PF_END_ANCHOR | PF_PURE_LITERAL | PF_EXACT_LITERAL | PF_START_ACCEPTING |
                    PF_START_DEAD | PF_BITSET | PF_SCAN_ELIGIBLE)) &&
-      d.required_byte < 0 && d.nstates <= 96)   // (nstates + 1) x 512 B byte-indexed table in LDS
-    d.flags |= PF_STEPPABLE;
+      d.nstates <= 96) {   // (nstates + 1) x 512 B byte-indexed table in LDS
+    d.flags |= PF_STEP_SEARCH;                  // match_next never takes the required-byte route
+    if (d.required_byte < 0) d.flags |= PF_STEPPABLE;
+    // findall with a rare required byte (_match_all_required_byte, matcher.mojo:864-898): memchr for
+    // the byte, back up over first-class bytes, anchored walk from there, keep it if it passes the hit
+    else if (d.kind == PLAN_DFA && (d.flags & PF_HAS_MATCHER) && !first[d.required_byte]) d.flags |= PF_STEP_REQ;
+  }
 
   // ---- anchored automaton: regex.match_first as one forward pass ----------------------
   // match_first(text) = engine_match_first(text, 0) keeps no restart loop, so it is a plain
@@ -855,7 +860,8 @@ std::string describe_plan(const HostPlan& hp) {
   o << "device.streamable=" << ((d.flags & PF_STREAMABLE) ? "yes" : ("no: " + hp.streamable_why_not))
     << " st_nstates=" << d.st_nstates << " st_kind=" << d.st_kind
     << (((d.flags & PF_STREAMABLE) && !(d.flags & PF_STREAM_SEARCH)) ? " findall_only=1" : "") << "\n";
-  o << "device.steppable=" << ((d.flags & PF_STEPPABLE) ? "yes" : "no") << "\n";
+  o << "device.steppable=" << ((d.flags & PF_STEPPABLE) ? "yes" : (d.flags & PF_STEP_REQ) ? "required-byte route" : "no")
+    << " step_search=" << ((d.flags & PF_STEP_SEARCH) ? 1 : 0) << "\n";
   o << "device.first_stream=" << (d.fa_bytes ? "yes" : ("no: " + hp.first_stream_why_not))
     << " fa_nstates=" << d.fa_nstates << " fa_kind=" << d.fa_kind << (hp.first_onepass ? " onepass=yes" : "") << "\n";
   if (d.flags & PF_BITSET)

@@ -787,16 +787,18 @@ def test_generated_patterns_stepper_equals_literal_restatement(seed):
     lib = M.load_library()
     rng = np.random.default_rng(seed)
     base = b"abcxyz019 -@.fobrhelcatdg"
-    nstep = 0
+    nstep = nreq = 0
     for p in patterns(seed, 400):
         pb = p.encode()
         try:
             rx = M.compile_regex(pb)
         except M.RegexSyntaxError:
             continue
-        if "device.steppable=yes" not in rx.describe():
+        dsc = rx.describe()
+        if "device.steppable=yes" not in dsc and "device.steppable=required-byte route" not in dsc:
             continue
         nstep += 1
+        nreq += "required-byte route" in dsc
         al = base + bytes(c for c in pb if chr(c).isalnum() or c in b" -@.") * 2
         texts = _random_texts(rng, 90, 70, al) + _random_texts(rng, 12, 400, al)
         for j in range(0, len(texts), 6):
@@ -817,7 +819,7 @@ def test_generated_patterns_stepper_equals_literal_restatement(seed):
         assert np.array_equal(gs, ws) and np.array_equal(ge, we), p
         for j in range(0, len(texts), 17):
             assert got[j] == O.findall(pb, texts[j]), (p, texts[j])
-    assert nstep > 150, nstep
+    assert nstep > 150, (nstep, nreq)
 
 
 @pytest.mark.parametrize("pat,repl", [(b"\\w+\\d{2}", b"<W>"), (b"\\d+(\\.\\d+)?", b"N"), (b"(foo|foobar)", b""),
@@ -951,3 +953,32 @@ def test_findall_count_only_and_capacity_error():
                              C.c_void_p(prefix.data_ptr()), C.c_void_p(spans.data_ptr()), 10, C.byref(total), None)
     assert rc == M.api.MRX_E_CAPACITY and total.value == 200
     assert spans[:4].tolist() == [[0, 2], [3, 5], [6, 8], [0, 3]]   # what fits is written, in order
+
+
+@pytest.mark.parametrize("pat", [b"\\d{3}-\\d{4}", b"\\w+@\\w+\\.com", b"[a-z]+@[a-z]+", b"[a-c]+x[0-9]+y", b"bar\\d[xyz]",
+                                 b"[a-zA-Z0-9._%+-]+@[a-zA-Z0-9.-]+\\.[a-z]{2,}", b"[0-9]+:[0-9]+"])
+def test_required_byte_route_on_the_stepper(pat):
+    """HybridMatcher._match_all_required_byte (matcher.mojo:864-898) as the stepper's second route:
+    findall / count against the literal restatement on every text and the oracle on a sample --
+    including its quirks (the match must pass the hit; starts back up into earlier matches)."""
+    _need_gpu()
+    rx = M.compile_regex(pat)
+    d = rx.describe()
+    if "required-byte route" not in d:
+        pytest.skip("pattern is not on the required-byte route: " + d.split("device.steppable")[1][:60])
+    lib = M.load_library()
+    rng = np.random.default_rng(zlib.crc32(pat))
+    al = b"abcxyz0123456789@.-: " + bytes(c for c in pat if chr(c).isalnum() or c in b"@.-:") * 3
+    texts = _random_texts(rng, 250, 80, al) + _random_texts(rng, 30, 700, al) + [
+        b"", b"555-1234", b"12345-6789", b"call 555-1234 or 555-12345-6789", b"a@b.com", b"aaa@bbb@ccc.com x@y.com",
+        b"user@example.com,other@test.org", b"@", b"-", b"12:30 1:2:3", b"bar5x bar9q", b"@@@@", b"a@" * 50]
+    with no_streaming_kernels():
+        got = rx.findall_lists(texts)
+        assert lib.mrx_last_kernel_name() == b"k_step_count"
+    with generic_kernels():
+        want = rx.findall_lists(texts)
+        assert lib.mrx_last_kernel_name() == b"k_findall_count"
+    assert got == want
+    for i in range(0, len(texts), 4):
+        assert got[i] == O.findall(pat, texts[i]), (pat, texts[i])
+    assert sum(len(g) for g in got) >= 1
