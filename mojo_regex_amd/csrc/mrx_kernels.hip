@@ -1370,10 +1370,10 @@ int grid_for(int64_t n, int block) {
   return (int)(g < cap ? g : cap);
 }
 
-// k_wstep for findall / count: plain route or required-byte route, by plan
+// k_wstep for findall / count: plain route or required-byte route (a bool `use_req_route` in scope)
 #define MRX_WSTEP_LAUNCH(MODE, ...)                                                        \
   do {                                                                                     \
-    if (h->hp.dev.flags & PF_STEP_REQ) hipLaunchKernelGGL((k_wstep<MODE, 1>), __VA_ARGS__); \
+    if (use_req_route) hipLaunchKernelGGL((k_wstep<MODE, 1>), __VA_ARGS__);              \
     else hipLaunchKernelGGL((k_wstep<MODE, 0>), __VA_ARGS__);                              \
   } while (0)
 
@@ -1508,7 +1508,7 @@ void launch_stream(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d
 }
 
 int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_prefix,
-                int32_t* d_spans, int64_t span_cap, int64_t* total, void* stream) {
+                int32_t* d_spans, int64_t span_cap, int64_t* total, void* stream, bool match_next_sequence = false) {
   if (!h) return fail(MRX_E_ARGUMENT, "null handle");
   if (n < 0 || span_cap < 0) return fail(MRX_E_ARGUMENT, "negative size");
   if (int rc = check_search_supported(h)) return rc;
@@ -1521,7 +1521,12 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
   HIP_TRY(scratch_alloc((void**)&d_total, sizeof(int64_t), s));
   const DevPlan& p = h->hp.dev;
   const bool stream_ok = !g_force_generic && (p.flags & PF_STREAMABLE) && stream_layout_ok(lay, n);
-  const bool step_ok = g_force_generic < 2 && (p.flags & (PF_STEPPABLE | PF_STEP_REQ));
+  // match_next_sequence: the caller (sub) wants the matches that iterating match_next from each
+  // match end visits -- the plain walk even on plans whose findall takes the required-byte route
+  const bool use_req_route = (p.flags & PF_STEP_REQ) && !match_next_sequence;
+  const bool step_ok = g_force_generic < 2 &&
+                       (match_next_sequence ? ((p.flags & PF_STEP_SEARCH) && !(p.flags & PF_PREFILTER))
+                                            : (p.flags & (PF_STEPPABLE | PF_STEP_REQ)) != 0);
   EvRec* d_recs = nullptr;
   int32_t* d_nrecs = nullptr;
   int64_t* d_wbase = nullptr;
@@ -1639,7 +1644,7 @@ int sub_from_spans(const mrx_handle* h, const Layout& lay, int64_t n, const std:
   int64_t cap = in_bytes / 8 + n + 64, nm = 0;
   for (int attempt = 0; attempt < 2; ++attempt) {
     HIP_TRY(scratch_alloc((void**)&d_spans, sizeof(int32_t) * 2 * (size_t)cap, s));
-    const int rc = run_findall(h, lay, n, d_prefix, d_spans, cap, &nm, s);
+    const int rc = run_findall(h, lay, n, d_prefix, d_spans, cap, &nm, s, /*match_next_sequence=*/true);
     if (rc == MRX_OK) break;
     HIP_TRY(scratch_free(d_spans, s));
     d_spans = nullptr;
@@ -1895,6 +1900,7 @@ static int run_count_any(const mrx_handle* h, const Layout& lay, int64_t n, int3
     launch_stream<ST_COUNT>(h, lay, n, counts, nullptr, nullptr, 0, nullptr, nullptr, s);
     g_last_kernel = "k_stream_count";
   } else {
+    const bool use_req_route = (h->hp.dev.flags & PF_STEP_REQ) != 0;
     if (g_force_generic < 2 && (h->hp.dev.flags & (PF_STEPPABLE | PF_STEP_REQ))) {
       MRX_WSTEP_LAUNCH(STEP_COUNT, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_table_bytes(h->hp.dev.nstates), s, h->hp.dev,
                          h->d_blob, lay, n, counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0,
@@ -1949,7 +1955,7 @@ int mrx_sub_dev(const mrx_handle* h, const char* repl, size_t repl_len, int64_t 
   const uint32_t sfl = h->hp.dev.flags;
   const bool spans_ok = !(sfl & PF_EXACT_LITERAL) &&
                         ((!g_force_generic && (sfl & PF_STREAM_SEARCH)) ||
-                         (g_force_generic < 2 && (sfl & PF_STEPPABLE) && !(sfl & PF_PREFILTER)));
+                         (g_force_generic < 2 && (sfl & PF_STEP_SEARCH) && !(sfl & PF_PREFILTER)));
   if (spans_ok && n > 0 && off) {
     // replacement as a fixed-length byte map
     std::vector<uint16_t> rmap;

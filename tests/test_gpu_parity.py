@@ -823,7 +823,9 @@ def test_generated_patterns_stepper_equals_literal_restatement(seed):
 
 
 @pytest.mark.parametrize("pat,repl", [(b"\\w+\\d{2}", b"<W>"), (b"\\d+(\\.\\d+)?", b"N"), (b"(foo|foobar)", b""),
-                                      (b"[a-z]+(-[a-z]+)*", b"_")])
+                                      (b"[a-z]+(-[a-z]+)*", b"_"),
+                                      # required-byte plans: sub walks match_next, not the findall route
+                                      (b"[a-z]+@[a-z]+", b"<mail>"), (b"\\d{3}-\\d{4}", b"###-####")])
 @pytest.mark.parametrize("count", [0, 2])
 def test_sub_from_stepper_spans(pat, repl, count):
     """Non-streamable but steppable plans: sub is assembled from the windowed stepper's findall."""
@@ -833,7 +835,8 @@ def test_sub_from_stepper_spans(pat, repl, count):
         b"", b"foox", b"foobarx", b"3.14 2.", b"a-b-c", b"ab12"]
     rx = M.compile_regex(pat)
     d = rx.describe()
-    assert "device.streamable=no" in d and "device.steppable=yes" in d
+    assert "device.streamable=no" in d and "step_search=1" in d
+    texts = texts + [b"aaa@bbb@ccc x@y", b"12345-6789 555-1234", b"a@b", b"555-12345"]
     got = rx.sub(repl, texts, count)
     assert M.load_library().mrx_last_kernel_name() == b"k_subs_emit"
     with generic_kernels():
