@@ -32,4 +32,17 @@ for seed in range(30000, 30012):
                 if g != w:
                     bad += 1
                     if bad < 10: print("MISMATCH", repr(p), op, t, g, w)
+        # regex.sub with a literal replacement (spans route where the plan allows it)
+        try:
+            got = rx.sub(b"#", texts, 0)
+        except M.UnsupportedPattern:
+            got = None
+        if got is not None:
+            for t, g in zip(texts, got):
+                try: w = O.sub(pb, b"#", t, 0)
+                except UnsupportedByOracle: continue
+                checked += 1
+                if g != w:
+                    bad += 1
+                    if bad < 10: print("MISMATCH sub", repr(p), t, g, w)
     print("seed", seed, "checked", checked, "bad", bad, flush=True)
