@@ -823,6 +823,10 @@ constexpr int kDecodeTile = MRX_DECODE_TILE;  // spans per LDS tile and wavefron
 constexpr int kDecodeDirect = MRX_DECODE_DIRECT;  // above this many spans per wavefront: one direct pass
 constexpr int kDecodeBatch = 8;    // independent 16-byte record loads in flight per lane
 
+constexpr int kScanBlock = 256;
+constexpr int kScanItems = 8;  // per thread
+constexpr int kScanTile = kScanBlock * kScanItems;
+
 // PACK16: every position of the batch fits 16 bits (texts of at most 65535 bytes), so a span takes
 // 4 bytes in the LDS tile instead of 8 -- half the LDS per wavefront, twice the resident
 // wavefronts for this latency-bound kernel.
@@ -832,9 +836,10 @@ __global__ __launch_bounds__(kBlock) void k_decode(int64_t n, const int32_t* __r
                                                    const int64_t* __restrict__ offsets,
                                                    const int32_t* __restrict__ counts,
                                                    const int64_t* __restrict__ wave_base,
+                                                   const int64_t* __restrict__ scan_block_sums,
                                                    int64_t* __restrict__ prefix,
                                                    int32_t* __restrict__ spans, int64_t span_cap,
-                                                   int fixed_len) {
+                                                   int fixed_len, int64_t* __restrict__ total_out) {
   using Slot = typename std::conditional<PACK16, uint32_t, int2>::type;
   __shared__ Slot tile_all[kBlock / 64][kDecodeTile];
   const int lane = threadIdx.x & 63;
@@ -846,7 +851,16 @@ __global__ __launch_bounds__(kBlock) void k_decode(int64_t n, const int32_t* __r
     const int64_t first = w << 6;
     const int64_t i = first + lane;
     // CSR offsets of my 64 texts: exclusive scan of their counts on top of the wavefront's base
-    const int64_t pre0 = wave_base[w];
+    // wave_base is exclusive within its k_scan_local tile of kScanTile wavefronts; the tiles before
+    // it (at most a few dozen sums) are added here instead of by two more scan launches
+    int64_t pre0 = wave_base[w];
+    {
+      const int64_t tiles_before = w / kScanTile;
+      int64_t part = 0;
+      for (int64_t b = lane; b < tiles_before; b += 64) part += scan_block_sums[b];
+      for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+      pre0 += part;
+    }
     const int my_cnt = i < n ? counts[i] : 0;
     int incl = my_cnt;
 #pragma unroll
@@ -857,7 +871,7 @@ __global__ __launch_bounds__(kBlock) void k_decode(int64_t n, const int32_t* __r
     const int my_rel = incl - my_cnt;   // start of my text's spans in the wavefront's range
     const int total_spans = __shfl(incl, 63);
     if (i < n) prefix[i] = pre0 + my_rel;
-    if (i == n - 1) prefix[n] = pre0 + incl;
+    if (i == n - 1) { prefix[n] = pre0 + incl; *total_out = pre0 + incl; }
     const int total_recs = wave_nrecs[w];
     const EvRec* wave_recs = recs + (offsets ? rec_region_start(offsets[first], w) : first * rec_row);
     if (total_spans > kDecodeDirect) {
@@ -1162,10 +1176,6 @@ __global__ __launch_bounds__(kBlock) void k_sub(DevPlan p, const uint8_t* __rest
 }
 
 // ---- exclusive scan (counts -> CSR offsets) ---------------------------------------
-constexpr int kScanBlock = 256;
-constexpr int kScanItems = 8;  // per thread
-constexpr int kScanTile = kScanBlock * kScanItems;
-
 template <class T>
 __global__ __launch_bounds__(kScanBlock) void k_scan_local(const T* __restrict__ in, int64_t n,
                                                            int64_t* __restrict__ out,
@@ -1581,15 +1591,23 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
     // prefix sums over the wavefronts' totals only (n/64 values); k_decode derives the per-text
     // offsets from its 64 counts and writes them along with the spans
     const int64_t nw = (n + 63) / 64;
-    if (int rc = device_scan<int32_t>(d_nrecs + nw, nw, d_wbase, d_total, s)) return rc;
+    // one launch: tile-local exclusive sums of the wavefront totals + one sum per tile
+    const int64_t ntiles = (nw + kScanTile - 1) / kScanTile;
+    int64_t* d_tsum = nullptr;
+    HIP_TRY(scratch_alloc((void**)&d_tsum, sizeof(int64_t) * ntiles, s));
+    hipLaunchKernelGGL(k_scan_local<int32_t>, dim3((unsigned)ntiles), dim3(kScanBlock), 0, s, d_nrecs + nw, nw,
+                       d_wbase, d_tsum);
     const bool pack16 = !lay.offsets && (lay.lens ? lay.stride : (int64_t)lay.len) <= 65535;
     if (pack16)
       hipLaunchKernelGGL(k_decode<true>, dim3(grid_for(n, kBlock) * 2), dim3(kBlock), 0, s, n, d_nrecs, d_recs,
-                         rec_row, lay.offsets, d_counts, d_wbase, d_prefix, d_spans, span_cap, p.st_fixed_len);
+                         rec_row, lay.offsets, d_counts, d_wbase, d_tsum, d_prefix, d_spans, span_cap, p.st_fixed_len,
+                         d_total);
     else
       hipLaunchKernelGGL(k_decode<false>, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, n, d_nrecs, d_recs,
-                         rec_row, lay.offsets, d_counts, d_wbase, d_prefix, d_spans, span_cap, p.st_fixed_len);
+                         rec_row, lay.offsets, d_counts, d_wbase, d_tsum, d_prefix, d_spans, span_cap, p.st_fixed_len,
+                         d_total);
     HIP_TRY(hipGetLastError());
+    HIP_TRY(scratch_free(d_tsum, s));
   } else if (int rc = device_scan<int32_t>(d_counts, n, d_prefix, d_total, s)) return rc;
   // Second stage is enqueued before the total is known on the host: both kernels clip
   // at span_cap, so a too-small buffer is reported (MRX_E_CAPACITY) without overrun and
