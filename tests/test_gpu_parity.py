@@ -985,3 +985,33 @@ def test_required_byte_route_on_the_stepper(pat):
     for i in range(0, len(texts), 4):
         assert got[i] == O.findall(pat, texts[i]), (pat, texts[i])
     assert sum(len(g) for g in got) >= 1
+
+
+@pytest.mark.parametrize("pat", [b"\\d+(\\.\\d+)?", b"\\w+\\d{2}", b"[a-z]+@[a-z]+", b"(foo|foobar)"])
+@pytest.mark.parametrize("n,pitch,var", [(130, 256, True), (70, 50, True), (64, 1024, False), (3, 7, True)])
+def test_stepper_on_fixed_pitch_batches(pat, n, pitch, var):
+    """k_wstep's frame form on fixed-pitch batches (aligned and not, with and without lens)."""
+    _need_gpu()
+    rng = np.random.default_rng(n * 31 + pitch + zlib.crc32(pat))
+    al = np.frombuffer(b"abcfoxr0123456789.-@ " + bytes(c for c in pat if chr(c).isalnum()) * 2, dtype=np.uint8)
+    arr = rng.choice(al, size=(n, pitch)).astype(np.uint8)
+    lens = rng.integers(0, pitch + 1, size=n).astype(np.int32) if var else None
+    rx = M.compile_regex(pat)
+    assert "device.streamable=no" in rx.describe()
+    d = torch.from_numpy(arr).cuda().reshape(-1)
+    batch = M.DeviceBatch.strided(d, pitch, length=pitch, lens=torch.from_numpy(lens).cuda() if var else None)
+    lib = M.load_library()
+    pre, sp, tot = rx._dev_findall(batch)
+    assert lib.mrx_last_kernel_name() == b"k_step_count"
+    ss, se = rx.match_next(batch)
+    cnt = rx.count(batch)
+    with generic_kernels():
+        gpre, gsp, gtot = rx._dev_findall(batch)
+        gss, gse = rx.match_next(batch)
+    assert tot == gtot and torch.equal(pre, gpre) and torch.equal(sp[:tot], gsp[:tot])
+    assert torch.equal(ss, gss) and torch.equal(se, gse)
+    assert torch.equal(cnt.to(torch.int64), pre[1:] - pre[:-1])
+    pre_h, sp_h = pre.cpu().numpy(), sp.cpu().numpy()
+    for i in range(0, n, 9):
+        t = arr[i, : (lens[i] if var else pitch)].tobytes()
+        assert [tuple(int(x) for x in r) for r in sp_h[pre_h[i]:pre_h[i + 1]]] == O.findall(pat, t), (pat, i)
