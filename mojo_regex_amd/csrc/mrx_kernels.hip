@@ -1793,6 +1793,21 @@ static int run_search_any(const mrx_handle* h, const Layout& lay, int64_t n, int
                           void* st) {
   if (!h) return fail(MRX_E_ARGUMENT, "null handle");
   const DevPlan& p = h->hp.dev;
+  // '^'-anchored DFA plans: match_next only ever tries position 0 (dfa.mojo:1875-1886), so search is
+  // the anchored automaton's run (the pure-literal case differs: simd_search is not anchored)
+  const bool anchored0 = !g_force_generic && (p.flags & PF_START_ANCHOR) && !(p.flags & (PF_END_ANCHOR | PF_PURE_LITERAL)) &&
+                         p.kind == PLAN_DFA && p.fa_bytes > 0 && !(p.flags & (PF_EXACT_LITERAL | PF_PREFILTER)) &&
+                         h->hp.why_no_search.empty() && stream_layout_ok(lay, n);
+  if (anchored0) {
+    if (int rc = ensure_device(h)) return rc;
+    hipStream_t s = (hipStream_t)st;
+    ScanTimer tm(s);
+    launch_stream<ST_FIRST>(h, lay, n, nullptr, nullptr, nullptr, 0, ds, de, s);
+    g_last_kernel = "k_stream_first";
+    HIP_TRY(hipGetLastError());
+    tm.stop();
+    return MRX_OK;
+  }
   if (g_force_generic || !(p.flags & PF_STREAM_SEARCH) || !stream_layout_ok(lay, n))
     return run_match<OP_SEARCH>(h, lay, n, ds, de, nullptr, st);
   if (int rc = check_search_supported(h)) return rc;

@@ -1015,3 +1015,26 @@ def test_stepper_on_fixed_pitch_batches(pat, n, pitch, var):
     for i in range(0, n, 9):
         t = arr[i, : (lens[i] if var else pitch)].tobytes()
         assert [tuple(int(x) for x in r) for r in sp_h[pre_h[i]:pre_h[i + 1]]] == O.findall(pat, t), (pat, i)
+
+
+@pytest.mark.parametrize("pat", [b"^[a-z]+\\d+", b"^\\d+", b"^[a-z]+[0-9]+x", b"^(foo|bar)", b"^a+b", b"^[a-z]*[0-9]*", b"^hello"])
+def test_start_anchored_search_uses_the_anchored_automaton(pat):
+    """'^'-anchored DFA plans: match_next only tries position 0, so search runs the anchored automaton
+    on the streaming kernel (pure literals keep the generic route: simd_search is not anchored)."""
+    _need_gpu()
+    rx = M.compile_regex(pat)
+    rng = np.random.default_rng(zlib.crc32(pat))
+    texts = _random_texts(rng, 200, 60, b"abfor019x ") + [b"", b"abc123", b"123", b"foo", b"barx", b"aab", b"xxhello", b"hello"]
+    try:
+        s, e = rx.match_next(texts)
+    except M.UnsupportedPattern:
+        pytest.skip("search not supported for this plan")
+    used = M.load_library().mrx_last_kernel_name()
+    with generic_kernels():
+        gs, ge = rx.match_next(texts)
+    assert np.array_equal(s, gs) and np.array_equal(e, ge), pat
+    for i, t in enumerate(texts):
+        w = O.search(pat, t)
+        assert (int(s[i]), int(e[i])) == (w if w else (-1, -1)), (pat, t)
+    if pat != b"^hello" and "engine_type=DFA" in rx.describe():
+        assert used == b"k_stream_first", used
