@@ -32,8 +32,9 @@
  *   - Batch layout: `data` holds the texts back to back, text i occupies
  *     data[offsets[i] .. offsets[i+1]).  The *_strided entry points take texts
  *     at a fixed pitch instead: text i starts at data + i*stride and has length
- *     lens[i] (or `len` for all i when lens == NULL); stride % 16 == 0 and data
- *     16-byte aligned select the streaming kernel.
+ *     lens[i] (or `len` for all i when lens == NULL).  Every layout runs on the
+ *     streaming kernels when the plan allows it; stride % 16 == 0 with a 16-byte
+ *     aligned `data` is the fastest form (no per-text alignment frame).
  *   - Pointers named d_* are DEVICE pointers (HBM); everything else is host
  *     memory.  `stream` is a hipStream_t passed as void* (NULL = default stream).
  *     The *_dev entry points enqueue work and return without synchronising
@@ -101,8 +102,7 @@ int mrx_match_first_dev(const mrx_handle* h, const uint8_t* d_data,
 int mrx_search_dev(const mrx_handle* h, const uint8_t* d_data,
                    const int64_t* d_offsets, int64_t n,
                    int32_t* d_start, int32_t* d_end, void* stream);
-/* Same two operations for texts at a fixed pitch (see header comment); search uses
- * the streaming kernel when the plan allows it. */
+/* Same two operations for texts at a fixed pitch (see header comment). */
 int mrx_match_first_strided_dev(const mrx_handle* h, const uint8_t* d_data, int64_t stride,
                                 const int32_t* d_lens, int32_t len, int64_t n,
                                 int32_t* d_start, int32_t* d_end, void* stream);
