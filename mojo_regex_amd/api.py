@@ -278,6 +278,12 @@ class CompiledRegex:
     search = match_next
 
     def is_match(self, texts) -> np.ndarray:
+        if isinstance(texts, DeviceBatch):   # device tensor uint8[n]
+            import torch
+            f = torch.empty(texts.n, dtype=torch.uint8, device=texts.data.device)
+            _check(self._lib.mrx_is_match_dev(self._h, _ptr(texts.data), _ptr(texts.csr_offsets()), texts.n, _ptr(f),
+                                              self._stream_ptr()))
+            return f
         data, offsets = pack_texts(texts)
         n = len(offsets) - 1
         f = np.empty(n, np.uint8)

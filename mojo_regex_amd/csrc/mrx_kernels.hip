@@ -450,6 +450,10 @@ constexpr int kStreamWaves = 4;
 // bounds it.  Results are WRONG for any value but 0; never set in a product build.
 //   1 no record stores   2 no global loads after a wavefront's first chunk
 //   4 no column lookup   16 no event handling
+// chunk of the class-table form (AUTO == 2): its dependent lookups are latency bound
+#ifndef MRX_STREAM_CHUNK_TABLE
+#define MRX_STREAM_CHUNK_TABLE MRX_STREAM_CHUNK
+#endif
 #ifndef MRX_ABLATE
 #define MRX_ABLATE 0
 #endif
@@ -1502,7 +1506,7 @@ void launch_stream(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d
   const bool wide = kind == 3;
   const size_t lds = wide ? 2048 : !table ? 0 : (size_t)(MODE == ST_FIRST ? p.fa_bytes : p.stg_bytes);
 #define MRX_LAUNCH(AUTO, CSR)                                                                     \
-  hipLaunchKernelGGL((k_stream_findall<MODE, MRX_STREAM_CHUNK, AUTO, CSR>), grid, block, lds, s, p, \
+  hipLaunchKernelGGL((k_stream_findall<MODE, (AUTO == 2 ? MRX_STREAM_CHUNK_TABLE : MRX_STREAM_CHUNK), AUTO, CSR>), grid, block, lds, s, p, \
                      h->d_blob, lay.data, lay.stride, lay.lens, lay.len, lay.offsets, n, d_counts, \
                      d_nrecs, d_recs, rec_row, d_s, d_e)
   if (!strided_fast(lay)) {

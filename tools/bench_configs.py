@@ -44,8 +44,11 @@ def main():
         ("c5 bitset NFA ('+' honoured)", b"(x|y|foo|bar)+", lambda: W.make_alt_batch(1 << 20, 4096), 720,
          dict(lazydfa_semantics=True, bitset_nfa=True)),
     ]
+    only = sys.argv[2] if len(sys.argv) > 2 and sys.argv[1] == "only" else None
     for case in cases:
         name, pat, gen, per_text = case[:4]
+        if only and not name.startswith(only):
+            continue
         opts = case[4] if len(case) > 4 else {}
         d = gen()
         n, L = d.shape

@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""The reference's benchmark list (mojo_regex_amd/bench_suite.py) on one GPU.
+
+Each case's text becomes a batch: n rotations of it (row i = the text rotated by 37 i bytes), n chosen
+so that the batch is about 256 MiB (at most 2^20 texts), fixed pitch, device resident.  The case's
+operation is enqueued REPS times and timed as a whole.  Printed per case: which kernel ran, GB/s of
+input, ns per text, and for scale the oracle's time for the one original text on one host core
+(Python + C restatement -- the checker, not a tuned CPU engine).
+usage: python tools/bench_suite.py [name-prefix]
+"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import torch  # noqa: E402
+import mojo_regex_amd as M  # noqa: E402
+from mojo_regex_amd import bench_suite as B  # noqa: E402
+from mojo_regex_amd.api import UnsupportedPattern  # noqa: E402
+
+TARGET_BYTES = 256 << 20
+REPS = 5
+
+
+def make_batch(text: bytes, csr: bool):
+    L = len(text)
+    pitch = L if csr else (L + 15) // 16 * 16   # sub / is_match take CSR batches: rows back to back
+    n = max(64, min(1 << 20, TARGET_BYTES // pitch))
+    t2 = torch.frombuffer(bytearray(text + text), dtype=torch.uint8).cuda()
+    data = torch.zeros((n, pitch), dtype=torch.uint8, device="cuda")
+    col = torch.arange(L, device="cuda")
+    step = max(1, (64 << 20) // max(L, 1))
+    for lo in range(0, n, step):
+        hi = min(n, lo + step)
+        rot = (torch.arange(lo, hi, device="cuda") * 37) % L
+        data[lo:hi, :L] = t2[rot[:, None] + col[None, :]]
+    if csr:
+        return M.DeviceBatch(data.reshape(-1), torch.arange(0, (n + 1) * L, L, dtype=torch.int64, device="cuda")), n, L
+    return M.DeviceBatch.strided(data.reshape(-1), pitch, length=L), n, L
+
+
+def main():
+    lib = M.load_library()
+    only = sys.argv[1] if len(sys.argv) > 1 else ""
+    from mrx_ref import hybrid as O
+    from mrx_ref import UnsupportedByOracle
+    for case in B.CASES:
+        if not case.name.startswith(only):
+            continue
+        row = {"case": case.name, "op": case.op, "pattern": case.pattern.decode()[:60], "text_bytes": len(case.text)}
+        try:
+            t0 = time.perf_counter()
+            B.oracle_answer(O, case, case.text)
+            row["oracle_us_per_text_1core"] = round((time.perf_counter() - t0) * 1e6, 1)
+        except UnsupportedByOracle:
+            row["oracle_us_per_text_1core"] = None
+        rx = M.compile_regex(case.pattern)
+        row["engine"] = rx.get_engine_type()
+        batch, n, L = make_batch(case.text, case.op in ("sub", "is_match"))
+        row["texts"] = n
+        try:
+            if case.op == "findall":
+                prefix = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+                _, _, total = rx._dev_findall(batch)
+                spans = torch.empty((max(total, 64), 2), dtype=torch.int32, device="cuda")
+                fn = lambda: rx.findall_async(batch, (prefix, spans))  # noqa: E731
+                row["matches"] = total
+            elif case.op == "search":
+                fn = lambda: rx.match_next(batch)  # noqa: E731
+            elif case.op == "match_first":
+                fn = lambda: rx.match_first(batch)  # noqa: E731
+            elif case.op == "is_match":
+                fn = lambda: rx.is_match(batch)  # noqa: E731
+            else:
+                cap = n * (2 * L + 64)
+                fn = lambda: rx.sub_dev(case.repl, batch, case.count, out_cap=cap)  # noqa: E731
+            fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(REPS):
+                fn()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / REPS
+            row.update({"kernel": lib.mrx_last_kernel_name().decode(), "ms": round(dt * 1e3, 3),
+                        "GBps": round(n * L / dt / 1e9, 1), "ns_per_text": round(dt / n * 1e9, 2)})
+        except UnsupportedPattern as e:
+            row["refused"] = str(e)[:100]
+        print(json.dumps(row), flush=True)
+        del batch
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()

@@ -14,6 +14,13 @@ if [ "$1" = build ]; then
   done
   wait
   ls -la $OUT
+elif [ "$1" = cmd ]; then
+  # tools/variants.sh cmd <command...>: run the command once per variant with MRX_LIB set
+  shift
+  for lib in $OUT/libmrx_hip_*.so; do
+    echo "== $(basename $lib)"
+    MRX_LIB=$lib "$@" 2>/dev/null | tail -3
+  done
 else
   for lib in $OUT/libmrx_hip_*.so; do
     line=$(MRX_LIB=$lib python3 $R/bench.py --no-cpu-baseline --steps 20 --warmup 3 2>/dev/null | tail -1)
