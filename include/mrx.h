@@ -191,6 +191,9 @@ const char* mrx_last_kernel_name(void);
 /* Testing aid: route every call to the generic lane-per-text kernels (the streaming kernel is
  * then never used) so that the two implementations can be compared on the same batch. */
 void mrx_debug_force_generic(int on);
+/* Testing aid: the kernels that put one wavefront (instead of one lane) on a text are chosen by the
+ * batch's average text length; 1 = always use them, 2 = never, 0 = by length. */
+void mrx_debug_long_text_kernels(int mode);
 const char* mrx_version(void);
 
 #ifdef __cplusplus

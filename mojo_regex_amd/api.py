@@ -95,6 +95,7 @@ def load_library():
         "mrx_timing_scan_ms": (C.c_double, [C.POINTER(C.c_int64)]),
         "mrx_last_kernel_name": (C.c_char_p, []),
         "mrx_debug_force_generic": (None, [C.c_int]),
+        "mrx_debug_long_text_kernels": (None, [C.c_int]),
         "mrx_release_scratch": (None, []),
         "mrx_version": (C.c_char_p, []),
     }
@@ -115,6 +116,7 @@ EXPORTED_SYMBOLS = [
     "mrx_sub_dev", "mrx_match_first_batch", "mrx_search_batch", "mrx_is_match_batch",
     "mrx_findall_batch", "mrx_captures_batch", "mrx_sub_batch", "mrx_timing_reset",
     "mrx_timing_enable", "mrx_timing_scan_ms", "mrx_last_kernel_name", "mrx_version", "mrx_debug_force_generic", "mrx_release_scratch",
+    "mrx_debug_long_text_kernels",
 ]
 
 

@@ -387,6 +387,203 @@ __global__ __launch_bounds__(kBlock) void k_slots_gather(int64_t n, const int32_
 }
 
 
+// The stepper's two routes for long texts: one WAVEFRONT per text instead of one lane per text.
+// ROUTE 1 (required byte):
+// In HybridMatcher._match_all_required_byte (matcher.mojo:864-898) the attempt made at a hit --
+// back up over first-class bytes, DFAEngine.match_first from there, keep it if it ends past the
+// hit -- depends on the text only; what the loop carries from one hit to the next is `pos` (the
+// hits before it are skipped).  So the wavefront sweeps its text 1 KiB at a time, 16 bytes per
+// lane: every lane finds the required bytes in its 16 bytes and evaluates its first one at or past
+// `pos` (a failed attempt moves the lane to its next hit), then the earliest kept attempt of the
+// wavefront is the next match, `pos` moves to its end, lanes whose attempt now lies before `pos`
+// drop it, and so on until the block has no hit left.  Text bytes come from a three-block LDS
+// window (previous, current, next); a back-up or walk that leaves it reads global memory.
+// ROUTE 0 (DFAEngine.match_all / match_next on PF_STEPPABLE plans, as k_wstep<., 0>) has the same
+// shape: the candidates are the bytes a walk may start on (first-class filter and a live first
+// transition), the attempt is the anchored walk from the candidate itself, it is kept when it
+// reaches an accepting state, and a failed attempt moves on to the lane's next candidate byte.
+constexpr int kRqBlock = 1024, kRqWaves = 4;
+static_assert(kRqBlock == 1 << 10, "byte_at() shifts by 10");
+__host__ __device__ inline size_t reqwave_table_bytes(int nstates) { return (size_t)nstates * 512 + 256; }
+
+template <int MODE, int ROUTE>
+__global__ __launch_bounds__(64 * kRqWaves) void k_req_wave(DevPlan p, const uint8_t* __restrict__ blob, Layout lay,
+                                                            int64_t n, int32_t* __restrict__ counts,
+                                                            const int64_t* __restrict__ prefix,
+                                                            int32_t* __restrict__ spans, int64_t span_cap,
+                                                            int32_t* __restrict__ out_s, int32_t* __restrict__ out_e) {
+  __shared__ __align__(16) uint8_t wins[kRqWaves][3 * kRqBlock];
+  __shared__ int32_t ress[ROUTE == 0 ? kRqWaves : 1][ROUTE == 0 ? kRqBlock : 1];   // ROUTE 0: end of the walk from each byte of the block
+  extern __shared__ __align__(16) uint8_t lds[];
+  uint16_t* tab = (uint16_t*)lds;                 // tab[q * 256 + byte] = next | ACC, or DEAD
+  const int ns = p.nstates;
+  // ROUTE 1: fc[byte] = byte is in the first element's class; ROUTE 0: a walk may start on byte
+  uint8_t* fc = lds + (size_t)ns * 512;
+  {
+    const uint8_t* g_cls = blob + p.off_cls;
+    const uint8_t* g_first = blob + p.off_first;
+    const uint16_t* g_tr = (const uint16_t*)(blob + p.off_trans);
+    for (int e = threadIdx.x; e < ns * 256; e += blockDim.x) {
+      const uint32_t t = g_tr[(e >> 8) * p.ncls + g_cls[e & 255]];
+      tab[e] = (uint16_t)(t == 0xFFFFu ? kWsDead : ((t & 0x7FFFu) | ((t & 0x8000u) ? kWsAcc : 0u)));
+    }
+    const bool filt = (p.flags & PF_HAS_MATCHER) != 0;
+    for (int b = threadIdx.x; b < 256; b += blockDim.x)
+      fc[b] = ROUTE == 1 ? g_first[b] : (uint8_t)!((filt && !g_first[b]) || g_tr[g_cls[b]] == 0xFFFFu);
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint8_t* win = wins[wave];
+  int32_t* res = ress[ROUTE == 0 ? wave : 0];
+  const uint32_t req = (uint32_t)p.required_byte * 0x01010101u;
+  for (int64_t i = (int64_t)blockIdx.x * kRqWaves + wave; i < n; i += (int64_t)gridDim.x * kRqWaves) {
+    const Text t = lay.text(i);
+    if (MODE == STEP_EMIT && counts && counts[i] <= kStepSlots) continue;   // its spans are in the slot row
+    int k = 0, rs = -1, re = -1;
+    if (t.len > 0) {
+      const uintptr_t addr = (uintptr_t)t.ptr;
+      const int mis = (int)(addr & 15);
+      const uint8_t* frame = (const uint8_t*)(addr & ~(uintptr_t)15);   // frame position f is frame[f]
+      const int end = mis + t.len;                                      // the text is frame [mis, end)
+      const int nblk = (end + kRqBlock - 1) / kRqBlock;
+      const int64_t wo = MODE == STEP_EMIT ? prefix[i] : 0;
+      auto load_block = [&](int b) {   // my 16 bytes of block b (zeros past the last 16-byte block of the text)
+        const int o = b * kRqBlock + 16 * lane;
+        return o < end ? mrx_ldg((const uint4*)(frame + o)) : make_uint4(0, 0, 0, 0);
+      };
+      __builtin_amdgcn_wave_barrier();
+      *(uint4*)(win + 16 * lane) = load_block(0);
+      uint4 nxt = nblk > 1 ? load_block(1) : make_uint4(0, 0, 0, 0);
+      int pos = mis;
+      for (int b = 0; b < nblk; ++b) {
+        if (b + 1 < nblk) *(uint4*)(win + ((b + 1) % 3) * kRqBlock + 16 * lane) = nxt;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (b + 2 < nblk) nxt = load_block(b + 2);   // in flight while this block is resolved
+        // byte at frame position f: from the window when f lies in blocks b-1 .. b+1
+        const int wlo = (b > 0 ? b - 1 : 0) * kRqBlock, whi = (b + 2 < nblk ? b + 2 : nblk) * kRqBlock;
+        const int slot_lo = (wlo / kRqBlock) % 3;   // window slot of block wlo / kRqBlock; the next ones follow cyclically
+        auto byte_at = [&](int f) -> uint32_t {
+          const uint32_t d = (uint32_t)(f - wlo);
+          if (d < (uint32_t)(whi - wlo)) {
+            uint32_t sl = slot_lo + (d >> 10);
+            sl = sl >= 3u ? sl - 3u : sl;
+            return win[sl * kRqBlock + (d & (kRqBlock - 1))];
+          }
+          return frame[f];
+        };
+        // required bytes among my 16 bytes
+        const int gpos = b * kRqBlock + 16 * lane;
+        uint32_t hm = 0;
+        {
+          const uint4 v = *(const uint4*)(win + (b % 3) * kRqBlock + 16 * lane);
+          const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const uint32_t x = w4[j] ^ req;   // zero bytes = hits
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              if (ROUTE == 1) { if (((x >> (8 * c)) & 0xFFu) == 0u) hm |= 1u << (4 * j + c); }
+              else if (fc[(w4[j] >> (8 * c)) & 0xFFu]) hm |= 1u << (4 * j + c);
+            }
+          }
+          // keep frame positions in [mis, end)
+          const int lo = mis - gpos, hi = end - gpos;
+          if (lo > 0) hm &= lo >= 16 ? 0u : ~((1u << lo) - 1u);
+          if (hi < 16) hm &= hi <= 0 ? 0u : ((1u << hi) - 1u);
+        }
+        // the anchored walk from frame position st: end of the longest match, or -1
+        auto walk_from = [&](int st) {
+          int q = st, state = 0, last = -1;
+          while (q < end) {
+            const uint32_t e = tab[(state << 8) + byte_at(q)];
+            if (e == kWsDead) break;
+            state = (int)(e & 0x3FFFu);
+            ++q;
+            if (e & kWsAcc) last = q;
+          }
+          return last;
+        };
+        auto emit = [&](bool mine, int cs, int ce) {
+          if (mine) {
+            if (MODE == STEP_EMIT) {
+              if (wo + k < span_cap) *(int2*)(spans + 2 * (wo + k)) = make_int2(cs - mis, ce - mis);
+            }
+            if (MODE == STEP_SLOTS) {
+              if (k < kStepSlots) *(int2*)(spans + 2 * (i * kStepSlots + k)) = make_int2(cs - mis, ce - mis);
+            }
+          }
+        };
+        const int rel0 = pos - gpos;   // candidates before pos are never visited
+        if (rel0 > 0) hm &= rel0 >= 16 ? 0u : ~((1u << rel0) - 1u);
+        if (ROUTE == 0) {
+          // Candidates are dense (every byte a walk may start on): evaluate each of them once, all
+          // lanes busy, and keep the ends; picking the matches is then a chain of mask lookups.  (With
+          // the lazy scheme below a lane whose attempt is overtaken by a match re-walks its remaining
+          // candidates one by one while the other 63 wait.)
+          uint32_t vm = 0, todo = hm;   // vm: my candidates whose walk reached an accepting state
+          while (__any(todo != 0u)) {
+            if (todo != 0u) {
+              const int j = __builtin_ctz(todo);
+              todo &= todo - 1u;
+              const int last = walk_from(gpos + j);
+              if (last >= 0) { vm |= 1u << j; res[16 * lane + j] = last; }
+            }
+          }
+          while (true) {
+            const int rel = pos - gpos;
+            uint32_t m = vm;
+            if (rel > 0) m &= rel >= 16 ? 0u : ~((1u << rel) - 1u);
+            const uint64_t wm = __ballot(m != 0u);
+            if (wm == 0ull) break;
+            const int winner = __builtin_ctzll(wm);
+            const int j = m ? __builtin_ctz(m) : 0;
+            const int ce = m ? res[16 * lane + j] : 0;
+            emit(lane == winner, gpos + j, ce);
+            pos = __builtin_amdgcn_readlane(ce, winner);
+            ++k;
+            if (MODE == STEP_SEARCH) { rs = __builtin_amdgcn_readlane(gpos + j, winner) - mis; re = pos - mis; break; }
+          }
+        } else {
+        int ch = 0, cs = 0, ce = 0;   // my current attempt: hit, start, end (valid while `have`)
+        bool have = false;
+        while (true) {
+          // hits before pos are skipped; an attempt whose hit fell before pos is void
+          const int rel = pos - gpos;
+          if (rel > 0) hm &= rel >= 16 ? 0u : ~((1u << rel) - 1u);
+          if (have && ch < pos) have = false;
+          // every lane with hits left gets a kept attempt (or runs out of hits)
+          while (__any(!have && hm != 0u)) {
+            if (!have && hm != 0u) {
+              const int h = gpos + __builtin_ctz(hm);
+              int st = h;
+              while (st > mis && fc[byte_at(st - 1)]) --st;
+              const int last = walk_from(st);
+              if (last > h) { have = true; ch = h; cs = st; ce = last; }
+              else hm &= hm - 1u;   // failed: on to my next hit
+            }
+          }
+          // lanes hold consecutive 16-byte groups: the earliest kept attempt is the lowest lane's
+          const uint64_t wm = __ballot(have);
+          if (wm == 0ull) break;   // no hit left in this block
+          const int winner = __builtin_ctzll(wm);
+          emit(lane == winner, cs, ce);
+          pos = __builtin_amdgcn_readlane(ce, winner);
+          ++k;
+          if (MODE == STEP_SEARCH) { rs = __builtin_amdgcn_readlane(cs, winner) - mis; re = pos - mis; break; }
+        }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (MODE == STEP_SEARCH && k) break;
+      }
+    }
+    if (lane == 0 && (MODE == STEP_COUNT || MODE == STEP_SLOTS)) counts[i] = k;
+    if (lane == 0 && MODE == STEP_SEARCH) { out_s[i] = rs; out_e[i] = re; }
+  }
+}
+
+
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void k_findall(DevPlan p, const uint8_t* __restrict__ blob,
                                                     Layout lay, int64_t n,
@@ -1279,6 +1476,7 @@ thread_local int64_t g_scan_launches = 0;
 thread_local const char* g_last_kernel = "";
 // mrx_debug_force_generic(): route every call to the generic lane-per-text kernels (tests compare
 // the two implementations; never set in production)
+int g_long_text_mode = 0;   // mrx_debug_long_text_kernels(): 0 by average length, 1 always, 2 never
 int g_force_generic = 0;   // 0 best kernel, 1 no streaming kernel, 2 literal restatement (mrx_device.hpp) only
 
 int fail(int code, const std::string& msg) {
@@ -1391,6 +1589,46 @@ int grid_for(int64_t n, int block) {
     else hipLaunchKernelGGL((k_wstep<MODE, 0>), __VA_ARGS__);                              \
   } while (0)
 
+// The stepper's routes: one wavefront per text (k_req_wave) when the texts are long or too few to
+// fill the device with one lane each, one lane per text (k_wstep) otherwise.  The average length
+// decides; a CSR batch's byte count lives on the device, so that costs one 8-byte read-back.
+int req_wave_pays(const Layout& lay, int64_t n, bool req_route, hipStream_t s, bool* out) {
+  *out = false;
+  if (g_long_text_mode) { *out = g_long_text_mode == 1; return MRX_OK; }
+  if (n <= 0) return MRX_OK;
+  int64_t total = 0;
+  if (lay.offsets) {
+    HIP_TRY(hipMemcpyAsync(&total, lay.offsets + n, sizeof total, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+  } else {
+    total = n * (lay.lens ? lay.stride : (int64_t)lay.len);
+  }
+  const int64_t avg = total / n;
+  // Measured on the reference's benchmark texts (tools/bench_suite.py): with sparse candidates (the
+  // required byte) the wavefront form wins from 2 KiB per text whatever the batch size; with dense
+  // candidates (every byte a walk may start on) it does several times the work of the serial loop and
+  // only pays while one lane per text would leave most of the device idle.
+  *out = req_route ? (avg >= 2048 || (avg >= 512 && n <= 32768)) : (avg >= 1024 && n <= 65536);
+  return MRX_OK;
+}
+int reqwave_grid(int64_t n) {
+  int64_t g = (n + kRqWaves - 1) / kRqWaves;
+  if (g < 1) g = 1;
+  return (int)(g < 256 * 8 ? g : 256 * 8);
+}
+// (a bool `use_req_route` in scope, as for MRX_WSTEP_LAUNCH)
+#define MRX_REQWAVE_LAUNCH(MODE, H, LAY, N, COUNTS, PREFIX, SPANS, CAP, S)                                       \
+  do {                                                                                                           \
+    if (use_req_route)                                                                                           \
+      hipLaunchKernelGGL((k_req_wave<MODE, 1>), dim3(reqwave_grid(N)), dim3(64 * kRqWaves),                      \
+                         reqwave_table_bytes((H)->hp.dev.nstates), S, (H)->hp.dev, (H)->d_blob, LAY, N, COUNTS,  \
+                         PREFIX, SPANS, CAP, (int32_t*)nullptr, (int32_t*)nullptr);                              \
+    else                                                                                                         \
+      hipLaunchKernelGGL((k_req_wave<MODE, 0>), dim3(reqwave_grid(N)), dim3(64 * kRqWaves),                      \
+                         reqwave_table_bytes((H)->hp.dev.nstates), S, (H)->hp.dev, (H)->d_blob, LAY, N, COUNTS,  \
+                         PREFIX, SPANS, CAP, (int32_t*)nullptr, (int32_t*)nullptr);                              \
+  } while (0)
+
 int wstep_grid(int64_t n) {
   const int64_t nw = (n + 63) / 64;
   int64_t g = (nw + kWsWaves - 1) / kWsWaves;
@@ -1470,10 +1708,19 @@ int run_match(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d_s, i
   ScanTimer tm(s);
   if (OP == OP_SEARCH && g_force_generic < 2 && (h->hp.dev.flags & PF_STEP_SEARCH) &&
       !(h->hp.dev.flags & PF_PREFILTER)) {   // (the memchr prefilter changes match_next, matcher.mojo:784-796)
+    bool wave = false;
+    if (int rc = req_wave_pays(lay, n, false, s, &wave)) return rc;
+    if (wave) {
+      hipLaunchKernelGGL((k_req_wave<STEP_SEARCH, 0>), dim3(reqwave_grid(n)), dim3(64 * kRqWaves),
+                         reqwave_table_bytes(h->hp.dev.nstates), s, h->hp.dev, h->d_blob, lay, n, (int32_t*)nullptr,
+                         (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0, d_s, d_e);
+      g_last_kernel = "k_req_wave_search";
+    } else {
     hipLaunchKernelGGL((k_wstep<STEP_SEARCH, 0>), dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_table_bytes(h->hp.dev.nstates), s, h->hp.dev,
                        h->d_blob, lay, n, (int32_t*)nullptr, (const int64_t*)nullptr, (int32_t*)nullptr,
                        (int64_t)0, d_s, d_e);
     g_last_kernel = "k_step_search";
+    }
   } else {
     hipLaunchKernelGGL(k_match<OP>, dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s, h->hp.dev,
                        h->d_blob, lay, n, d_s, d_e, d_flag);
@@ -1541,6 +1788,7 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
   const bool step_ok = g_force_generic < 2 &&
                        (match_next_sequence ? ((p.flags & PF_STEP_SEARCH) && !(p.flags & PF_PREFILTER))
                                             : (p.flags & (PF_STEPPABLE | PF_STEP_REQ)) != 0);
+  bool req_wave = false;   // required-byte route on the wavefront-per-text kernel
   EvRec* d_recs = nullptr;
   int32_t* d_nrecs = nullptr;
   int64_t* d_wbase = nullptr;
@@ -1572,13 +1820,20 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
       HIP_TRY(hipGetLastError());
       tm.stop();
     } else {
+      if (step_ok)
+        if (int rc = req_wave_pays(lay, n, use_req_route, s, &req_wave)) return rc;
       ScanTimer tm(s);
       if (step_ok && span_cap > 0) {
         HIP_TRY(scratch_alloc((void**)&d_slots, sizeof(int32_t) * 2 * kStepSlots * (size_t)n, s));
+        if (req_wave)
+          MRX_REQWAVE_LAUNCH(STEP_SLOTS, h, lay, n, d_counts, (const int64_t*)nullptr, d_slots, (int64_t)0, s);
+        else
         MRX_WSTEP_LAUNCH(STEP_SLOTS, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_table_bytes(h->hp.dev.nstates), s, p,
                            h->d_blob, lay, n, d_counts, (const int64_t*)nullptr, d_slots, (int64_t)0,
                            (int32_t*)nullptr, (int32_t*)nullptr);
-      } else if (step_ok)
+      } else if (step_ok && req_wave)
+        MRX_REQWAVE_LAUNCH(STEP_COUNT, h, lay, n, d_counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0, s);
+      else if (step_ok)
         MRX_WSTEP_LAUNCH(STEP_COUNT, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_table_bytes(h->hp.dev.nstates), s, p,
                            h->d_blob, lay, n, d_counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0,
                            (int32_t*)nullptr, (int32_t*)nullptr);
@@ -1586,7 +1841,7 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
         hipLaunchKernelGGL(k_findall<FA_COUNT>, dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s,
                            p, h->d_blob, lay, n, d_counts, (const int64_t*)nullptr, (int32_t*)nullptr,
                            (int64_t)0);
-      g_last_kernel = step_ok ? "k_step_count" : "k_findall_count";
+      g_last_kernel = req_wave ? "k_req_wave" : step_ok ? "k_step_count" : "k_findall_count";
       HIP_TRY(hipGetLastError());
       tm.stop();
     }
@@ -1624,6 +1879,9 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
         hipLaunchKernelGGL(k_slots_gather, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, n, d_counts, d_prefix,
                            d_slots, d_spans, span_cap);
         // wavefronts without an overflowing text leave at once
+        if (req_wave)
+          MRX_REQWAVE_LAUNCH(STEP_EMIT, h, lay, n, d_counts, d_prefix, d_spans, span_cap, s);
+        else
         MRX_WSTEP_LAUNCH(STEP_EMIT, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_table_bytes(h->hp.dev.nstates), s, p, h->d_blob,
                            lay, n, d_counts, d_prefix, d_spans, span_cap, (int32_t*)nullptr,
                            (int32_t*)nullptr);
@@ -1938,7 +2196,13 @@ static int run_count_any(const mrx_handle* h, const Layout& lay, int64_t n, int3
     g_last_kernel = "k_stream_count";
   } else {
     const bool use_req_route = (h->hp.dev.flags & PF_STEP_REQ) != 0;
-    if (g_force_generic < 2 && (h->hp.dev.flags & (PF_STEPPABLE | PF_STEP_REQ))) {
+    bool req_wave = false;
+    if (g_force_generic < 2 && (h->hp.dev.flags & (PF_STEPPABLE | PF_STEP_REQ)))
+      if (int rc = req_wave_pays(lay, n, use_req_route, s, &req_wave)) return rc;
+    if (req_wave) {
+      MRX_REQWAVE_LAUNCH(STEP_COUNT, h, lay, n, counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0, s);
+      g_last_kernel = "k_req_wave";
+    } else if (g_force_generic < 2 && (h->hp.dev.flags & (PF_STEPPABLE | PF_STEP_REQ))) {
       MRX_WSTEP_LAUNCH(STEP_COUNT, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_table_bytes(h->hp.dev.nstates), s, h->hp.dev,
                          h->d_blob, lay, n, counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0,
                          (int32_t*)nullptr, (int32_t*)nullptr);
@@ -2137,6 +2401,7 @@ double mrx_timing_scan_ms(int64_t* launches) {
 }
 const char* mrx_last_kernel_name(void) { return g_last_kernel; }
 void mrx_debug_force_generic(int on) { g_force_generic = on < 0 ? 0 : on > 2 ? 2 : on; }
+void mrx_debug_long_text_kernels(int mode) { g_long_text_mode = mode < 0 ? 0 : mode > 2 ? 0 : mode; }
 void mrx_release_scratch(void) { scratch_release_all(); }
 
 }  // extern "C"

@@ -183,6 +183,17 @@ def no_streaming_kernels():
         lib.mrx_debug_force_generic(0)
 
 
+@contextlib.contextmanager
+def long_text_kernels(mode):
+    """1 = always the wavefront-per-text kernels, 2 = never (default: by average text length)."""
+    lib = M.load_library()
+    lib.mrx_debug_long_text_kernels(mode)
+    try:
+        yield
+    finally:
+        lib.mrx_debug_long_text_kernels(0)
+
+
 def _random_texts(rng, n, max_len, alphabet):
     al = np.frombuffer(alphabet, dtype=np.uint8)
     lens = rng.integers(0, max_len + 1, size=n)
@@ -987,6 +998,95 @@ def test_required_byte_route_on_the_stepper(pat):
     assert sum(len(g) for g in got) >= 1
 
 
+@pytest.mark.parametrize("pat", [b"\\d{3}-\\d{4}", b"\\w+@\\w+\\.com", b"[a-z]+@[a-z]+", b"[a-c]+x[0-9]+y", b"bar\\d[xyz]",
+                                 b"[a-zA-Z0-9._%+-]+@[a-zA-Z0-9.-]+\\.[a-z]{2,}", b"[0-9]+:[0-9]+",
+                                 b"\\d{3}-\\d{3}-\\d{4}", b"[0-9]+\\.[0-9]+"])
+def test_required_byte_route_one_wavefront_per_text(pat):
+    """k_req_wave (the required-byte route with a wavefront sweeping each text) against the lane-per-text
+    stepper and the oracle: short texts, texts of several 1 KiB blocks, long runs that make the back-up
+    and the walks leave the three-block window, CSR (unaligned) and fixed-pitch batches, findall with
+    more matches than slots, count."""
+    _need_gpu()
+    rx = M.compile_regex(pat)
+    if "required-byte route" not in rx.describe():
+        pytest.skip("pattern is not on the required-byte route")
+    lib = M.load_library()
+    rng = np.random.default_rng(zlib.crc32(pat) + 7)
+    al = b"abcxyz0123456789@.-: " + bytes(c for c in pat if chr(c).isalnum() or c in b"@.-:") * 3
+    texts = (_random_texts(rng, 60, 90, al) + _random_texts(rng, 24, 5000, al) + _random_texts(rng, 6, 40000, al) + [
+        b"", b"-", b"@", b"555-1234", b"a@b.com",
+        b"7" * 5000 + b"-1234 " + b"5" * 3000 + b"-" + b"8" * 4000,          # back-up over runs longer than the window
+        b"ab" * 2000 + b"@" + b"cd" * 3000 + b".com " + b"x@y.com" * 300,     # walks longer than the window
+        (b"call 555-123-4567 or 12:30 or a@b.com, 1.5 and cx9y bar5x " * 200)])
+    with long_text_kernels(1):
+        got = rx.findall_lists(texts)
+        assert lib.mrx_last_kernel_name() == b"k_req_wave"
+    with long_text_kernels(2):
+        want = rx.findall_lists(texts)
+        assert lib.mrx_last_kernel_name() == b"k_step_count"
+    assert got == want
+    for i in list(range(0, 60, 5)) + list(range(60, len(texts))):
+        assert got[i] == O.findall(pat, texts[i]), (pat, i)
+    assert max(len(g) for g in got) > 32          # more matches than slots: the emit pass ran
+    # device-resident batches: CSR and fixed pitch (aligned and not), count
+    data, offsets = M.api.pack_texts(texts)
+    b = M.DeviceBatch(torch.from_numpy(data).cuda(), torch.from_numpy(offsets).cuda())
+    with long_text_kernels(1):
+        cnt = rx.count(b).cpu().numpy()
+        assert lib.mrx_last_kernel_name() == b"k_req_wave"
+    assert cnt.tolist() == [len(g) for g in got]
+    for pitch in (4096, 4099):
+        n = 37
+        arr = rng.choice(np.frombuffer(al, dtype=np.uint8), size=(n, pitch)).astype(np.uint8)
+        lens = rng.integers(0, pitch + 1, size=n).astype(np.int32)
+        sb = M.DeviceBatch.strided(torch.from_numpy(arr).cuda().reshape(-1), pitch, length=pitch,
+                                   lens=torch.from_numpy(lens).cuda())
+        pre, sp, tot = rx._dev_findall(sb)           # by average length: 4 KiB rows take the wavefront kernel
+        assert lib.mrx_last_kernel_name() == b"k_req_wave"
+        with long_text_kernels(2):
+            pre2, sp2, tot2 = rx._dev_findall(sb)
+        assert tot == tot2 and torch.equal(pre, pre2) and torch.equal(sp[:tot], sp2[:tot2])
+
+
+@pytest.mark.parametrize("pat", [b"\\d+(\\.\\d+)?", b"\\w+\\d{2}", b"(foo|foobar)", b"\\(?\\d{3}\\)?[\\s.-]?\\d{3}[\\s.-]?\\d{4}",
+                                 b"[A-Z]{2,4}[0-9]{3,5}", b"(hello|world|test|demo|sample)[0-9]{3}[a-z]{2}",
+                                 b"8(?:00|33|44|55|66|77|88)[2-9]\\d{6}", b"[a-z]+@[a-z]+", b"\\d{3}-\\d{3}-\\d{4}"])
+def test_stepper_one_wavefront_per_text(pat):
+    """k_req_wave<., 0> (DFAEngine.match_all / match_next with a wavefront sweeping each text) against the
+    lane-per-text stepper and the oracle: findall, count, search and sub (which walks match_next even on
+    required-byte plans)."""
+    _need_gpu()
+    rx = M.compile_regex(pat)
+    d = rx.describe()
+    if "step_search=1" not in d:
+        pytest.skip("pattern is not on the stepper")
+    req = "required-byte route" in d
+    lib = M.load_library()
+    rng = np.random.default_rng(zlib.crc32(pat) + 11)
+    al = b"abfoxHELOWRDT0123456789@.-() " + bytes(c for c in pat if chr(c).isalnum()) * 2
+    texts = (_random_texts(rng, 50, 90, al) + _random_texts(rng, 20, 5000, al) + _random_texts(rng, 4, 30000, al) + [
+        b"", b"8", b"foo", b"5" * 9000 + b"-" + b"6" * 3000, b"AB" * 4000 + b"12345 " + b"hello123ab" * 500,
+        (b"(555) 123-4567 8005551234 555-123-4567 foobar x1.5 ABC1234 world456cd a@b " * 150)])
+    with no_streaming_kernels(), long_text_kernels(1):
+        got = rx.findall_lists(texts)
+        k1 = lib.mrx_last_kernel_name()
+        ss, se = rx.match_next(texts)
+        k2 = lib.mrx_last_kernel_name()
+        sub = rx.sub(b"<#>", texts, 3)
+    with no_streaming_kernels(), long_text_kernels(2):
+        want = rx.findall_lists(texts)
+        ws, we = rx.match_next(texts)
+        wsub = rx.sub(b"<#>", texts, 3)
+    assert k1 == b"k_req_wave" and k2 == b"k_req_wave_search"
+    assert got == want and ss.tolist() == ws.tolist() and se.tolist() == we.tolist() and sub == wsub
+    for i in list(range(0, 50, 5)) + list(range(50, len(texts))):
+        assert got[i] == O.findall(pat, texts[i]), (pat, i)
+        m = O.search(pat, texts[i])
+        assert (None if ss[i] < 0 else (int(ss[i]), int(se[i]))) == m, (pat, i)
+        assert sub[i] == O.sub(pat, b"<#>", texts[i], 3), (pat, i)
+    assert sum(len(g) for g in got) >= 1
+
+
 @pytest.mark.parametrize("pat", [b"\\d+(\\.\\d+)?", b"\\w+\\d{2}", b"[a-z]+@[a-z]+", b"(foo|foobar)"])
 @pytest.mark.parametrize("n,pitch,var", [(130, 256, True), (70, 50, True), (64, 1024, False), (3, 7, True)])
 def test_stepper_on_fixed_pitch_batches(pat, n, pitch, var):
@@ -1001,10 +1101,11 @@ def test_stepper_on_fixed_pitch_batches(pat, n, pitch, var):
     d = torch.from_numpy(arr).cuda().reshape(-1)
     batch = M.DeviceBatch.strided(d, pitch, length=pitch, lens=torch.from_numpy(lens).cuda() if var else None)
     lib = M.load_library()
-    pre, sp, tot = rx._dev_findall(batch)
-    assert lib.mrx_last_kernel_name() == b"k_step_count"
-    ss, se = rx.match_next(batch)
-    cnt = rx.count(batch)
+    with long_text_kernels(2):   # this test is about the lane-per-text stepper
+        pre, sp, tot = rx._dev_findall(batch)
+        assert lib.mrx_last_kernel_name() == b"k_step_count"
+        ss, se = rx.match_next(batch)
+        cnt = rx.count(batch)
     with generic_kernels():
         gpre, gsp, gtot = rx._dev_findall(batch)
         gss, gse = rx.match_next(batch)

@@ -44,6 +44,7 @@ def make_batch(text: bytes, csr: bool):
 
 def main():
     lib = M.load_library()
+    lib.mrx_debug_long_text_kernels(int(os.environ.get("MRX_LONG_TEXT_MODE", "0")))   # 1 always, 2 never (A/B runs)
     only = sys.argv[1] if len(sys.argv) > 1 else ""
     from mrx_ref import hybrid as O
     from mrx_ref import UnsupportedByOracle
