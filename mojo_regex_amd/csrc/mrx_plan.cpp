@@ -620,7 +620,29 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
       else sa.allowed.fill(1);
     }
     std::string why;
-    if (!check_streamable(sa, why)) {
+    if (!check_streamable(sa, why) && (d.flags & PF_PURE_LITERAL) && !lit.empty() && lit.size() <= 4000) {
+      // A literal whose prefix is also a suffix ("555-": a later start survives the byte that kills
+      // the walk).  DFAEngine's pure-literal loops are a substring search that resumes at the END of
+      // each occurrence (dfa.mojo:2053-2073, simd_search), i.e. the KMP automaton of the literal with
+      // the full state falling back to the start state; a match is [end - L, end).
+      const int Ln = (int)lit.size();
+      std::vector<std::array<int, 256>> delta(Ln + 1);
+      std::vector<int> fail(Ln + 1, 0);
+      for (int c = 0; c < 256; ++c) delta[0][c] = ((unsigned char)lit[0] == c) ? 1 : 0;
+      for (int q = 1; q <= Ln; ++q) {
+        fail[q] = (q == 1) ? 0 : delta[fail[q - 1]][(unsigned char)lit[q - 1]];
+        for (int c = 0; c < 256; ++c)
+          delta[q][c] = (q < Ln && (unsigned char)lit[q] == c) ? q + 1 : q == Ln ? delta[0][c] : delta[fail[q]][c];
+      }
+      std::vector<std::array<uint16_t, 256>> E(Ln + 1);
+      std::vector<uint8_t> live_acc(Ln + 1, 0);
+      live_acc[Ln] = 1;
+      for (int q = 0; q <= Ln; ++q)
+        for (int c = 0; c < 256; ++c) E[q][c] = (uint16_t)((delta[q][c] << 2) | (q == Ln ? 2 : 0));
+      d.st_fixed_len = Ln;
+      emit_stream_tables(E, live_acc);
+      if (!(d.flags & PF_STREAMABLE)) d.st_fixed_len = 0;
+    } else if (!why.empty()) {
       hp.streamable_why_not = why;
     } else {
       // number the states actually reachable

@@ -743,6 +743,48 @@ EXACT_LITERALS = [b"hello world this is long", b"abcabcabcabcabcabcabcabc", b"aa
                   b"aaaaaaaaaaaaaaaaaaaab", b"xyxyxyxyxyxyxyxyxyxyxyxyxy"]
 
 
+@pytest.mark.parametrize("pat", [b"555-123-4567", b"555\\.123\\.4567", b"aab", b"abab", b"aaa", b"abcab", b"xx"])
+def test_self_overlapping_pure_literal_streams(pat):
+    """DFAEngine's pure-literal loops (dfa.mojo:2053-2073) for a literal whose prefix is also a suffix:
+    the KMP automaton with the full state falling back to the start (matches never overlap); findall,
+    search and count against the generic kernels on every text and the oracle on a sample."""
+    _need_gpu()
+    rx = M.compile_regex(pat)
+    d = rx.describe()
+    assert rx.get_engine_type() == "DFA" and "device.streamable=yes" in d
+    lib = M.load_library()
+    lit = pat.replace(b"\\", b"")
+    rng = np.random.default_rng(zlib.crc32(pat) + 3)
+    al = bytes(set(lit)) + b" z"
+    texts = []
+    for _ in range(200):
+        parts = []
+        for _ in range(int(rng.integers(0, 7))):
+            k = rng.random()
+            if k < 0.4:
+                parts.append(lit)
+            elif k < 0.7:   # runs of the literal's own prefix: candidates that overlap
+                parts.append(lit[: max(1, len(lit) // 3)] * int(rng.integers(1, 30)))
+            else:
+                parts.append(bytes(rng.choice(np.frombuffer(al, dtype=np.uint8), size=int(rng.integers(0, 40))).tolist()))
+        texts.append(b"".join(parts))
+    texts += [b"", lit, lit[:-1], lit + lit, lit[1:] + lit, lit[:1] * 100, (lit[:2] * 50) + lit]
+    got = rx.findall_lists(texts)
+    assert lib.mrx_last_kernel_name() == b"k_stream_findall"
+    s, e = rx.match_next(texts)
+    assert lib.mrx_last_kernel_name() == b"k_stream_search"
+    with generic_kernels():
+        want = rx.findall_lists(texts)
+        gs, ge = rx.match_next(texts)
+    assert got == want and s.tolist() == gs.tolist() and e.tolist() == ge.tolist()
+    assert sum(len(g) for g in got) > 100
+    for i in range(0, len(texts), 3):
+        assert got[i] == O.findall(pat, texts[i]), (pat, texts[i])
+        m = O.search(pat, texts[i])
+        assert (None if s[i] < 0 else (int(s[i]), int(e[i]))) == m
+        assert rx.sub(b"<>", [texts[i]], 0)[0] == O.sub(pat, b"<>", texts[i], 0)
+
+
 @pytest.mark.parametrize("pat", EXACT_LITERALS)
 def test_exact_literal_kmp_streaming(pat):
     """HybridMatcher's exact-literal bypass (matcher.mojo:768-781, 815-847) on the streaming kernel:
