@@ -685,13 +685,20 @@ enum { ST_RECORDS = 0, ST_COUNT = 1, ST_SEARCH = 2, ST_FIRST = 3 };
 //           into its first block (a = address & 15); frame bytes before the text and after its
 //           end are no-ops exactly like the bytes past the end of a short text.  Row base, a and
 //           frame length of every text live in the 16 pad bytes behind its tile row.
-template <int MODE, int CH, int AUTO, int CSR>
+// VIRT = 1 (with CSR = 1): the batch is a list of PIECES of long texts, cut at synchronising bytes of
+// the search automaton (DevPlan::off_st_sync).  Piece v is the bytes [offsets[v], offsets[v] + vlen[v])
+// of `data`, walked from the idle state; its first byte is a synchronising byte (or the first byte of
+// its text), so from there on the walk is the one the whole text's walk takes.  The events of its
+// first vskip[v] & 0x7FFFFFFF bytes belong to the piece before it and are dropped; bit 31 of vskip
+// marks the last piece of a text (the only one that may end a match at the end of the text).
+template <int MODE, int CH, int AUTO, int CSR, int VIRT = 0>
 __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
     DevPlan p, const uint8_t* __restrict__ blob, const uint8_t* __restrict__ data, int64_t stride,
     const int32_t* __restrict__ lens, int32_t common_len, const int64_t* __restrict__ offsets,
     int64_t n, int32_t* __restrict__ counts,
     int32_t* __restrict__ wave_nrecs, EvRec* __restrict__ recs, int64_t rec_row,
-    int32_t* __restrict__ out_s, int32_t* __restrict__ out_e) {
+    int32_t* __restrict__ out_s, int32_t* __restrict__ out_e,
+    const int32_t* __restrict__ vlen = nullptr, const uint32_t* __restrict__ vskip = nullptr) {
   constexpr int kChunk = CH;
   constexpr int kRowPitch = CH + 16;      // +16: the per-lane 16-byte read-back is bank-conflict free
   constexpr int LPR = CH / 16;            // lanes that cover one text row in a load instruction
@@ -742,7 +749,7 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
       int64_t o0;
       if (offsets) {
         o0 = live ? offsets[my_text] : 0;
-        my_len = live ? (int)(offsets[my_text + 1] - o0) : 0;
+        my_len = live ? (VIRT ? vlen[my_text] : (int)(offsets[my_text + 1] - o0)) : 0;
       } else {
         o0 = my_text * stride;
         my_len = live ? (lens ? lens[my_text] : common_len) : 0;
@@ -759,6 +766,8 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
     } else {
       my_len = live ? (lens ? lens[my_text] : common_len) : 0;
     }
+    const uint32_t vsk = (VIRT && live) ? vskip[my_text] : 0u;
+    const int skip = (int)(vsk & 0x7FFFFFFFu);   // VIRT: events before this position are the previous piece's
     const int flen = mis + my_len;  // length of my text's frame
     int max_len = flen;  // longest frame in this wavefront decides the trip count
     for (int off = 32; off > 0; off >>= 1) max_len = max(max_len, __shfl_xor(max_len, off));
@@ -924,9 +933,13 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
             F = __builtin_amdgcn_alignbit(e, F, 2);
           }
         }
-        const uint32_t em = F & 0xAAAAAAAAu;
+        uint32_t em = F & 0xAAAAAAAAu;
         const uint32_t ns = F & 0x55555555u;
         const int gbase = cbase + g * 16 - mis;  // text position of the group's first byte
+        if (VIRT) {
+          const int dsk = skip - gbase;
+          if (dsk > 0) { em &= dsk >= 16 ? 0u : ~((1u << (2 * dsk)) - 1u); F = ns | em; }
+        }
         if (MRX_ABLATE & 16) { cnt += (F == 0x12345u); continue; }
         if (MODE == ST_RECORDS) {
           const uint64_t has = __ballot(em != 0);
@@ -964,7 +977,7 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
     }
     // end of text: a walk that is in an accepting state ends at len
     {
-      const bool tail = MODE != ST_FIRST && live &&
+      const bool tail = MODE != ST_FIRST && live && (!VIRT || (vsk >> 31)) &&
                         (AUTO == 2 ? acc_lds[q4 >> p.st_cshift] != 0
                                    : ((accmask >> (q4 >> (AUTO == 3 ? 3 : 2))) & 1u) != 0);
       if (MODE == ST_RECORDS) {
@@ -1031,7 +1044,10 @@ constexpr int kScanTile = kScanBlock * kScanItems;
 // PACK16: every position of the batch fits 16 bits (texts of at most 65535 bytes), so a span takes
 // 4 bytes in the LDS tile instead of 8 -- half the LDS per wavefront, twice the resident
 // wavefronts for this latency-bound kernel.
-template <bool PACK16>
+// VBASE: pieces of long texts (see k_stream_findall VIRT): positions are piece-relative in the records
+// and become text-relative by adding vbase[piece]; `prefix` is then per piece (k_virt_prefix picks
+// the texts' entries).
+template <bool PACK16, bool VBASE = false>
 __global__ __launch_bounds__(kBlock) void k_decode(int64_t n, const int32_t* __restrict__ wave_nrecs,
                                                    const EvRec* __restrict__ recs, int64_t rec_row,
                                                    const int64_t* __restrict__ offsets,
@@ -1040,7 +1056,9 @@ __global__ __launch_bounds__(kBlock) void k_decode(int64_t n, const int32_t* __r
                                                    const int64_t* __restrict__ scan_block_sums,
                                                    int64_t* __restrict__ prefix,
                                                    int32_t* __restrict__ spans, int64_t span_cap,
-                                                   int fixed_len, int64_t* __restrict__ total_out) {
+                                                   int fixed_len, int64_t* __restrict__ total_out,
+                                                   const int32_t* __restrict__ vbase = nullptr) {
+  static_assert(!(PACK16 && VBASE), "text-relative positions of a long text do not fit 16 bits");
   using Slot = typename std::conditional<PACK16, uint32_t, int2>::type;
   __shared__ Slot tile_all[kBlock / 64][kDecodeTile];
   const int lane = threadIdx.x & 63;
@@ -1075,6 +1093,7 @@ __global__ __launch_bounds__(kBlock) void k_decode(int64_t n, const int32_t* __r
     if (i == n - 1) { prefix[n] = pre0 + incl; *total_out = pre0 + incl; }
     const int total_recs = wave_nrecs[w];
     const EvRec* wave_recs = recs + (offsets ? rec_region_start(offsets[first], w) : first * rec_row);
+    const int my_vb = (VBASE && i < n) ? vbase[i] : 0;
     if (total_spans > kDecodeDirect) {
       // dense matches: the tile passes would re-read the stream total_spans / kDecodeTile
       // times.  One pass with direct 8-byte stores instead; every text's spans are written
@@ -1092,8 +1111,9 @@ __global__ __launch_bounds__(kBlock) void k_decode(int64_t n, const int32_t* __r
         }
 #pragma unroll
         for (int u = 0; u < kDecodeBatch; ++u) {
-          const EvRec r = rr[u];
+          EvRec r = rr[u];
           const int rel_t = __shfl(my_rel, (int)(r.meta >> 26));
+          if (VBASE) { const int vb = __shfl(my_vb, (int)(r.meta >> 26)); r.start += vb; r.pos_base += vb; }
           uint32_t em = r.F & 0xAAAAAAAAu;
           const uint32_t ns = r.F & 0x55555555u;
           int64_t dst = pre0 + rel_t + (int)(r.meta & kRecBeforeMask);
@@ -1125,8 +1145,9 @@ __global__ __launch_bounds__(kBlock) void k_decode(int64_t n, const int32_t* __r
         }
 #pragma unroll
         for (int u = 0; u < kDecodeBatch; ++u) {
-          const EvRec r = rr[u];
+          EvRec r = rr[u];
           const int rel_t = __shfl(my_rel, (int)(r.meta >> 26));
+          if (VBASE) { const int vb = __shfl(my_vb, (int)(r.meta >> 26)); r.start += vb; r.pos_base += vb; }
           uint32_t em = r.F & 0xAAAAAAAAu;
           const uint32_t ns = r.F & 0x55555555u;
           int dst = rel_t + (int)(r.meta & kRecBeforeMask) - tb;
@@ -1158,6 +1179,83 @@ __global__ __launch_bounds__(kBlock) void k_decode(int64_t n, const int32_t* __r
       __builtin_amdgcn_wave_barrier();
     }
   }
+}
+
+// ---- long texts in pieces (k_stream_findall VIRT) -------------------------------------------
+// Text t is cut every C bytes; piece k owns the text bytes [k C, min(len, (k + 1) C)) and starts its
+// walk at the last synchronising byte before k C, at most kVirtBack bytes back.  A cut without such
+// a byte is not made (the piece before it runs on, its own piece is empty).  Every text has cpt
+// pieces (cpt = pieces of the longest text), so piece v belongs to text v / cpt.
+constexpr int kVirtBack = 256;   // < 1008, see rec_region_start: pieces overlap by at most this much
+
+__device__ __forceinline__ int virt_back(const uint8_t* __restrict__ sync, const uint8_t* __restrict__ txt, int c) {
+  for (int b = 1; b <= kVirtBack && b <= c; ++b)
+    if (sync[txt[c - b]]) return b;
+  return -1;
+}
+
+// back[v] for piece v = (t, k): how far before the cut k C its synchronising byte lies; 0 for k = 0,
+// -1 when there is none within kVirtBack bytes (the piece before it then runs on through this one),
+// -2 when the text ends before the cut
+__global__ __launch_bounds__(kBlock) void k_virt_check(Layout lay, int64_t n, int cpt, int C,
+                                                       const uint8_t* __restrict__ sync, int32_t* __restrict__ back) {
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n * cpt; v += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t t = v / cpt;
+    const int k = (int)(v - t * cpt);
+    const Text tx = lay.text(t);
+    const int64_t c = (int64_t)k * C;
+    back[v] = k == 0 ? 0 : c >= tx.len ? -2 : virt_back(sync, tx.ptr, (int)c);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_virt_fill(Layout lay, int64_t n, int cpt, int C,
+                                                      const int32_t* __restrict__ back,
+                                                      int64_t* __restrict__ vstart, int32_t* __restrict__ vlen,
+                                                      uint32_t* __restrict__ vskip, int32_t* __restrict__ vbase) {
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n * cpt; v += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t t = v / cpt;
+    const int k = (int)(v - t * cpt);
+    const Text tx = lay.text(t);
+    const int64_t abs0 = tx.ptr - lay.data;
+    const int b = back[v];
+    const int64_t c = (int64_t)k * C;
+    // an empty piece sits at its cut (or at the end of a shorter text): piece starts never decrease,
+    // which the record regions rely on (rec_region_start)
+    int64_t st = abs0 + (c < tx.len ? c : (int64_t)tx.len);
+    int ln = 0, base = (int)(st - abs0);
+    uint32_t sk = 0;
+    if (b >= 0) {
+      // my piece runs to the next cut that has a synchronising byte, or to the end of the text
+      int j = k + 1;
+      while (j < cpt && back[t * cpt + j] == -1) ++j;
+      const int e = (j == cpt || back[t * cpt + j] == -2) ? tx.len : j * C;
+      st = abs0 + c - b; ln = e - (int)c + b; base = (int)c - b;
+      sk = (uint32_t)b | (e == tx.len ? 0x80000000u : 0u);
+    }
+    vstart[v] = st; vlen[v] = ln; vskip[v] = sk; vbase[v] = base;
+  }
+}
+
+// per-text entries of the per-piece prefix sums / counts
+__global__ __launch_bounds__(kBlock) void k_virt_prefix(int64_t n, int cpt, const int64_t* __restrict__ vprefix,
+                                                        int64_t* __restrict__ prefix) {
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t <= n; t += (int64_t)gridDim.x * blockDim.x)
+    prefix[t] = vprefix[t * cpt];
+}
+__global__ __launch_bounds__(kBlock) void k_virt_sum(int64_t n, int cpt, const int32_t* __restrict__ vcounts,
+                                                     int32_t* __restrict__ counts) {
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+    int c = 0;
+    for (int k = 0; k < cpt; ++k) c += vcounts[t * cpt + k];
+    counts[t] = c;
+  }
+}
+__global__ __launch_bounds__(kBlock) void k_max_len(const int64_t* __restrict__ offsets, int64_t n, int32_t* __restrict__ out) {
+  int m = 0;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x)
+    m = max(m, (int)(offsets[t + 1] - offsets[t]));
+  for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off));
+  if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(out, m);
 }
 
 // ---- sub() -------------------------------------------------------------------------
@@ -1742,7 +1840,8 @@ bool strided_fast(const Layout& lay) {
 
 template <int MODE>
 void launch_stream(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d_counts, int32_t* d_nrecs,
-                   EvRec* d_recs, int64_t rec_row, int32_t* d_s, int32_t* d_e, hipStream_t s) {
+                   EvRec* d_recs, int64_t rec_row, int32_t* d_s, int32_t* d_e, hipStream_t s,
+                   const int32_t* d_vlen = nullptr, const uint32_t* d_vskip = nullptr) {
   const DevPlan& p = h->hp.dev;
   const int64_t nw = (n + 63) / 64;
   int64_t g = (nw + kStreamWaves - 1) / kStreamWaves;
@@ -1756,7 +1855,18 @@ void launch_stream(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d
   hipLaunchKernelGGL((k_stream_findall<MODE, (AUTO == 2 ? MRX_STREAM_CHUNK_TABLE : MRX_STREAM_CHUNK), AUTO, CSR>), grid, block, lds, s, p, \
                      h->d_blob, lay.data, lay.stride, lay.lens, lay.len, lay.offsets, n, d_counts, \
                      d_nrecs, d_recs, rec_row, d_s, d_e)
-  if (!strided_fast(lay)) {
+  if (d_vlen) {   // pieces of long texts: lay.offsets = their start offsets, n = how many
+    if constexpr (MODE == ST_RECORDS || MODE == ST_COUNT) {
+#define MRX_LAUNCH_V(AUTO)                                                                        \
+  hipLaunchKernelGGL((k_stream_findall<MODE, (AUTO == 2 ? MRX_STREAM_CHUNK_TABLE : MRX_STREAM_CHUNK), AUTO, 1, 1>), grid, block, lds, s, p, \
+                     h->d_blob, lay.data, lay.stride, lay.lens, lay.len, lay.offsets, n, d_counts, \
+                     d_nrecs, d_recs, rec_row, d_s, d_e, d_vlen, d_vskip)
+      if (table) MRX_LAUNCH_V(2);
+      else if (wide) MRX_LAUNCH_V(3);
+      else MRX_LAUNCH_V(1);
+#undef MRX_LAUNCH_V
+    }
+  } else if (!strided_fast(lay)) {
     if (table) MRX_LAUNCH(2, 1);
     else if (wide) MRX_LAUNCH(3, 1);
     else MRX_LAUNCH(1, 1);
@@ -1766,6 +1876,122 @@ void launch_stream(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d
     else MRX_LAUNCH(1, 0);
   }
 #undef MRX_LAUNCH
+}
+
+// Long texts on the streaming kernels: cut into pieces at synchronising bytes when one lane per text
+// would leave most of the device idle.
+struct Pieces {
+  bool on = false;
+  int cpt = 0, C = 0;
+  int64_t nv = 0, data_bytes = 0;
+  int64_t* vstart = nullptr;
+  int32_t* vlen = nullptr;
+  uint32_t* vskip = nullptr;
+  int32_t* vbase = nullptr;
+  int32_t* back = nullptr;
+  Layout lay{};   // the pieces as a batch: offsets = vstart
+};
+int pieces_prepare(const mrx_handle* h, const Layout& lay, int64_t n, hipStream_t s, Pieces* pc) {
+  const DevPlan& p = h->hp.dev;
+  pc->on = false;
+  if (p.st_nsync <= 0 || g_long_text_mode == 2 || n <= 0) return MRX_OK;
+  int64_t total = 0, max_len = 0;
+  if (lay.offsets) {
+    int32_t* d_max = nullptr;
+    HIP_TRY(scratch_alloc((void**)&d_max, sizeof(int32_t), s));
+    HIP_TRY(hipMemsetAsync(d_max, 0, sizeof(int32_t), s));
+    hipLaunchKernelGGL(k_max_len, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, lay.offsets, n, d_max);
+    int32_t m = 0;
+    HIP_TRY(hipMemcpyAsync(&m, d_max, sizeof m, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&total, lay.offsets + n, sizeof total, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(scratch_free(d_max, s));
+    max_len = m;
+  } else {
+    max_len = lay.lens ? lay.stride : (int64_t)lay.len;
+    total = n * lay.stride;
+  }
+  int C;
+  if (g_long_text_mode == 1) {
+    C = 200;   // tests: cut even short texts, at positions that are not multiples of 16
+    if (max_len <= C) return MRX_OK;
+  } else {
+    // pays when one lane per text leaves the device mostly idle and the texts are long enough to cut
+    if (max_len < 4096 || n > 131072) return MRX_OK;
+    const int64_t want = (total + 262143) / 262144;   // about 2^18 pieces
+    C = (int)((want + 255) / 256 * 256);
+    if (C < 2048) C = 2048;
+    if (C >= max_len) return MRX_OK;
+  }
+  const int64_t cpt = (max_len + C - 1) / C;
+  if (cpt < 2 || n * cpt > (int64_t(1) << 23)) return MRX_OK;
+  pc->cpt = (int)cpt; pc->C = C; pc->nv = n * cpt; pc->data_bytes = total;
+  HIP_TRY(scratch_alloc((void**)&pc->vstart, sizeof(int64_t) * (pc->nv + 1), s));
+  HIP_TRY(scratch_alloc((void**)&pc->vlen, sizeof(int32_t) * pc->nv, s));
+  HIP_TRY(scratch_alloc((void**)&pc->vskip, sizeof(uint32_t) * pc->nv, s));
+  HIP_TRY(scratch_alloc((void**)&pc->vbase, sizeof(int32_t) * pc->nv, s));
+  HIP_TRY(scratch_alloc((void**)&pc->back, sizeof(int32_t) * pc->nv, s));
+  const uint8_t* sync = h->d_blob + p.off_st_sync;
+  hipLaunchKernelGGL(k_virt_check, dim3(grid_for(pc->nv, kBlock)), dim3(kBlock), 0, s, lay, n, pc->cpt, C, sync, pc->back);
+  hipLaunchKernelGGL(k_virt_fill, dim3(grid_for(pc->nv, kBlock)), dim3(kBlock), 0, s, lay, n, pc->cpt, C, pc->back,
+                     pc->vstart, pc->vlen, pc->vskip, pc->vbase);
+  HIP_TRY(hipGetLastError());
+  pc->lay = Layout{lay.data, pc->vstart, 0, nullptr, 0};
+  pc->on = true;
+  return MRX_OK;
+}
+int pieces_release(Pieces* pc, hipStream_t s) {
+  if (!pc->on) return MRX_OK;
+  HIP_TRY(scratch_free(pc->vstart, s));
+  HIP_TRY(scratch_free(pc->vlen, s));
+  HIP_TRY(scratch_free(pc->vskip, s));
+  HIP_TRY(scratch_free(pc->vbase, s));
+  HIP_TRY(scratch_free(pc->back, s));
+  pc->on = false;
+  return MRX_OK;
+}
+
+// findall over the pieces: scan, prefix sums and decode as for any CSR batch, then the texts'
+// entries of the per-piece prefix sums
+int findall_pieces(const mrx_handle* h, const Pieces& pc, int64_t n, int64_t* d_prefix, int32_t* d_spans,
+                   int64_t span_cap, int64_t* d_total, hipStream_t s) {
+  const DevPlan& p = h->hp.dev;
+  const int64_t nv = pc.nv, nw = (nv + 63) / 64;
+  const size_t nrec = (size_t)(pc.data_bytes / 16 + 256 * nw + 256);
+  int32_t* d_vcounts = nullptr;
+  EvRec* d_recs = nullptr;
+  int32_t* d_nrecs = nullptr;
+  int64_t* d_wbase = nullptr;
+  int64_t* d_vprefix = nullptr;
+  int64_t* d_tsum = nullptr;
+  const int64_t ntiles = (nw + kScanTile - 1) / kScanTile;
+  HIP_TRY(scratch_alloc((void**)&d_vcounts, sizeof(int32_t) * nv, s));
+  HIP_TRY(scratch_alloc((void**)&d_recs, sizeof(EvRec) * nrec, s));
+  HIP_TRY(scratch_alloc((void**)&d_nrecs, sizeof(int32_t) * 2 * nw, s));
+  HIP_TRY(scratch_alloc((void**)&d_wbase, sizeof(int64_t) * (nw + 1), s));
+  HIP_TRY(scratch_alloc((void**)&d_vprefix, sizeof(int64_t) * (nv + 1), s));
+  HIP_TRY(scratch_alloc((void**)&d_tsum, sizeof(int64_t) * ntiles, s));
+  {
+    ScanTimer tm(s);
+    launch_stream<ST_RECORDS>(h, pc.lay, nv, d_vcounts, d_nrecs, d_recs, 0, nullptr, nullptr, s, pc.vlen, pc.vskip);
+    g_last_kernel = "k_stream_findall_pieces";
+    HIP_TRY(hipGetLastError());
+    tm.stop();
+  }
+  hipLaunchKernelGGL(k_scan_local<int32_t>, dim3((unsigned)ntiles), dim3(kScanBlock), 0, s, d_nrecs + nw, nw, d_wbase,
+                     d_tsum);
+  hipLaunchKernelGGL((k_decode<false, true>), dim3(grid_for(nv, kBlock)), dim3(kBlock), 0, s, nv, d_nrecs, d_recs,
+                     (int64_t)0, pc.lay.offsets, d_vcounts, d_wbase, d_tsum, d_vprefix, d_spans, span_cap, p.st_fixed_len,
+                     d_total, pc.vbase);
+  hipLaunchKernelGGL(k_virt_prefix, dim3(grid_for(n + 1, kBlock)), dim3(kBlock), 0, s, n, pc.cpt, d_vprefix, d_prefix);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(scratch_free(d_vcounts, s));
+  HIP_TRY(scratch_free(d_recs, s));
+  HIP_TRY(scratch_free(d_nrecs, s));
+  HIP_TRY(scratch_free(d_wbase, s));
+  HIP_TRY(scratch_free(d_vprefix, s));
+  HIP_TRY(scratch_free(d_tsum, s));
+  return MRX_OK;
 }
 
 int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_prefix,
@@ -1794,7 +2020,14 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
   int64_t* d_wbase = nullptr;
   int32_t* d_slots = nullptr;
   int64_t rec_row = 0;
-  if (n > 0) {
+  Pieces pc;
+  if (n > 0 && stream_ok)
+    if (int rc = pieces_prepare(h, lay, n, s, &pc)) return rc;
+  const bool by_pieces = pc.on;
+  if (pc.on) {
+    if (int rc = findall_pieces(h, pc, n, d_prefix, d_spans, span_cap, d_total, s)) return rc;
+    if (int rc = pieces_release(&pc, s)) return rc;
+  } else if (n > 0) {
     if (stream_ok) {
       const int64_t nw = (n + 63) / 64;
       size_t nrec;
@@ -1846,7 +2079,9 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
       tm.stop();
     }
   }
-  if (stream_ok) {
+  if (by_pieces) {
+    // done over the pieces above
+  } else if (stream_ok) {
     // prefix sums over the wavefronts' totals only (n/64 values); k_decode derives the per-text
     // offsets from its 64 counts and writes them along with the spans
     const int64_t nw = (n + 63) / 64;
@@ -2192,8 +2427,21 @@ static int run_count_any(const mrx_handle* h, const Layout& lay, int64_t n, int3
   hipStream_t s = (hipStream_t)st;
   ScanTimer tm(s);
   if (!g_force_generic && (h->hp.dev.flags & PF_STREAMABLE) && stream_layout_ok(lay, n)) {
+    Pieces pc;
+    if (int rc = pieces_prepare(h, lay, n, s, &pc)) return rc;
+    if (pc.on) {   // long texts: count per piece, then add up each text's pieces
+      int32_t* d_vcounts = nullptr;
+      HIP_TRY(scratch_alloc((void**)&d_vcounts, sizeof(int32_t) * pc.nv, s));
+      launch_stream<ST_COUNT>(h, pc.lay, pc.nv, d_vcounts, nullptr, nullptr, 0, nullptr, nullptr, s, pc.vlen, pc.vskip);
+      hipLaunchKernelGGL(k_virt_sum, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, n, pc.cpt, d_vcounts, counts);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(scratch_free(d_vcounts, s));
+      if (int rc = pieces_release(&pc, s)) return rc;
+      g_last_kernel = "k_stream_count_pieces";
+    } else {
     launch_stream<ST_COUNT>(h, lay, n, counts, nullptr, nullptr, 0, nullptr, nullptr, s);
     g_last_kernel = "k_stream_count";
+    }
   } else {
     const bool use_req_route = (h->hp.dev.flags & PF_STEP_REQ) != 0;
     bool req_wave = false;

@@ -486,6 +486,8 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
 
   // ---- streaming automaton (findall only) -----------------------------------------
   d.off_stcol = -1;
+  d.off_st_sync = -1;
+  d.st_nsync = 0;
   hp.streamable_why_not.clear();
   d.st_kind = 0;
   d.st_fixed_len = 0;
@@ -496,6 +498,26 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
     const int nlive = (int)E.size();
     const uint32_t fl = PF_STREAMABLE | ((d.flags & PF_PREFILTER) ? 0u : (uint32_t)PF_STREAM_SEARCH);
     d.st_nstates = nlive;
+    {
+      std::array<uint8_t, 256> sync{};
+      int nsync = 0;
+      for (int c = 0; c < 256; ++c) {
+        bool same = true, all_new = true;
+        for (int q = 0; q < nlive; ++q) {
+          same = same && (E[q][c] >> 2) == (E[0][c] >> 2);
+          all_new = all_new && (E[q][c] & 1);
+        }
+        // same target for every state, and the start of the walk that is then alive is known: there
+        // is none (idle), it begins at this byte from every state, or starts are not tracked (KMP)
+        sync[c] = same && ((E[0][c] >> 2) == 0 || all_new || d.st_fixed_len > 0);
+        nsync += sync[c];
+      }
+      d.st_nsync = nsync;
+      if (nsync) {
+        d.off_st_sync = (int)hp.blob.size();
+        put(hp.blob, sync.data(), 256);
+      }
+    }
     d.st_accept_mask = 0;
     for (int q = 0; q < nlive && q < 32; ++q)
       if (live_acc[q]) d.st_accept_mask |= 1u << q;
@@ -881,7 +903,8 @@ std::string describe_plan(const HostPlan& hp) {
     << " flags=0x" << std::hex << d.flags << std::dec << " blob_bytes=" << d.blob_bytes << "\n";
   o << "device.streamable=" << ((d.flags & PF_STREAMABLE) ? "yes" : ("no: " + hp.streamable_why_not))
     << " st_nstates=" << d.st_nstates << " st_kind=" << d.st_kind
-    << (((d.flags & PF_STREAMABLE) && !(d.flags & PF_STREAM_SEARCH)) ? " findall_only=1" : "") << "\n";
+    << (((d.flags & PF_STREAMABLE) && !(d.flags & PF_STREAM_SEARCH)) ? " findall_only=1" : "")
+    << " sync_bytes=" << d.st_nsync << "\n";
   o << "device.steppable=" << ((d.flags & PF_STEPPABLE) ? "yes" : (d.flags & PF_STEP_REQ) ? "required-byte route" : "no")
     << " step_search=" << ((d.flags & PF_STEP_SEARCH) ? 1 : 0) << "\n";
   o << "device.first_stream=" << (d.fa_bytes ? "yes" : ("no: " + hp.first_stream_why_not))

@@ -65,6 +65,10 @@ struct DevPlan {
   // kind 2: cls[256] u8, trans[st_nstates][1 << st_cshift] u16 = (next << st_cshift) << 2 | EMIT << 1 | NEWSTART,
   // accept[st_nstates] u8
   int32_t off_stg_cls, off_stg_trans, off_stg_acc, st_cshift, stg_bytes;
+  // synchronising bytes of the search automaton: sync[b] != 0 when byte b takes EVERY state to the
+  // same state with the same start (idle, or a new start at b) -- after such a byte the walk does not
+  // depend on what came before, so a long text can be cut there (st_nsync = how many, 0 = no table)
+  int32_t off_st_sync, st_nsync;
   // anchored automaton for match_first on the streaming kernel (fa_bytes == 0: none); same layout
   // as kind 2 but entry = (next << fa_cshift) << 2 | ACCEPT(next) << 1, last row = dead state
   int32_t off_fa_cls, off_fa_trans, fa_cshift, fa_bytes, fa_nstates, fa_start_acc;

@@ -785,6 +785,61 @@ def test_self_overlapping_pure_literal_streams(pat):
         assert rx.sub(b"<>", [texts[i]], 0)[0] == O.sub(pat, b"<>", texts[i], 0)
 
 
+@pytest.mark.parametrize("pat", [b"[a-z]+\\d+", b"\\d+", b"hello", b"[0-9]{4}", b"[A-Z]{3}", b"a{2,4}", b"555-123-4567",
+                                 b"[0-9]{10}", b"(x|y|foo|bar)+", b"a{1}b{2}c{3}d{4}", b"[a-zA-Z0-9]+"])
+def test_long_texts_in_pieces(pat):
+    """Long texts cut at synchronising bytes (k_stream_findall VIRT): findall equals the uncut walk and
+    the oracle -- matches across cuts, texts without any synchronising byte (they stay whole), empty
+    and short texts between long ones, CSR and fixed-pitch batches."""
+    _need_gpu()
+    rx = M.compile_regex(pat)
+    d = rx.describe()
+    if "device.streamable=yes" not in d or "sync_bytes=0" in d:
+        pytest.skip("no streaming automaton with synchronising bytes")
+    lib = M.load_library()
+    rng = np.random.default_rng(zlib.crc32(pat) + 5)
+    al = b"abxyfor0123456789HELO -.," + bytes(c for c in pat if chr(c).isalnum()) * 2
+    runs = [bytes([c]) * 900 for c in b"a5xA"]          # long runs: cuts with no synchronising byte nearby
+    texts = (_random_texts(rng, 20, 150, al) + _random_texts(rng, 30, 3000, al) + _random_texts(rng, 6, 20000, al) +
+             [b"", b"a1", runs[0] + b"12 " + runs[1], runs[2] + b" " + runs[3] + b"7",
+              b"ab 12 " + runs[0] * 40 + b"77 x1 " + runs[1] * 30 + b" a5 b6",   # > 64 cuts in a row that cannot be made
+              (b"hello abc123 555-123-4567 2024 ABCD xyfoobar aaaa abbcccdddd " * 120),
+              bytes(rng.choice(np.frombuffer(b"abc123 ", dtype=np.uint8), size=5000).tolist()) + runs[1] * 3])
+    with long_text_kernels(1):
+        got = rx.findall_lists(texts)
+        assert lib.mrx_last_kernel_name() == b"k_stream_findall_pieces"
+    with long_text_kernels(2):
+        want = rx.findall_lists(texts)
+        assert lib.mrx_last_kernel_name() == b"k_stream_findall"
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert g == w, (pat, i, len(texts[i]), g[:5], w[:5])
+    for i in list(range(0, 50, 7)) + list(range(50, len(texts))):
+        assert got[i] == O.findall(pat, texts[i]), (pat, i)
+    assert sum(len(g) for g in got) > 50
+    data, offsets = M.api.pack_texts(texts)
+    b = M.DeviceBatch(torch.from_numpy(data).cuda(), torch.from_numpy(offsets).cuda())
+    with long_text_kernels(1):
+        cnt = rx.count(b).cpu().numpy()
+        assert lib.mrx_last_kernel_name() == b"k_stream_count_pieces"
+        sub = rx.sub(b"<#>", texts, 0)
+    assert cnt.tolist() == [len(g) for g in got]
+    for i in range(50, len(texts)):
+        assert sub[i] == O.sub(pat, b"<#>", texts[i], 0), (pat, i)
+    # fixed pitch with per-text lengths (unaligned pitch: frame form)
+    for pitch in (2048, 3001):
+        n = 41
+        arr = rng.choice(np.frombuffer(al, dtype=np.uint8), size=(n, pitch)).astype(np.uint8)
+        lens = rng.integers(0, pitch + 1, size=n).astype(np.int32)
+        sb = M.DeviceBatch.strided(torch.from_numpy(arr).cuda().reshape(-1), pitch, length=pitch,
+                                   lens=torch.from_numpy(lens).cuda())
+        with long_text_kernels(1):
+            pre, sp, tot = rx._dev_findall(sb)
+            assert lib.mrx_last_kernel_name() == b"k_stream_findall_pieces"
+        with long_text_kernels(2):
+            pre2, sp2, tot2 = rx._dev_findall(sb)
+        assert tot == tot2 and torch.equal(pre, pre2) and torch.equal(sp[:tot], sp2[:tot2])
+
+
 @pytest.mark.parametrize("pat", EXACT_LITERALS)
 def test_exact_literal_kmp_streaming(pat):
     """HybridMatcher's exact-literal bypass (matcher.mojo:768-781, 815-847) on the streaming kernel:
