@@ -1250,6 +1250,19 @@ __global__ __launch_bounds__(kBlock) void k_virt_sum(int64_t n, int cpt, const i
     counts[t] = c;
   }
 }
+// search: the first piece of a text that holds a match has the text's first match
+__global__ __launch_bounds__(kBlock) void k_virt_first(int64_t n, int cpt, const int32_t* __restrict__ vs,
+                                                       const int32_t* __restrict__ ve, const int32_t* __restrict__ vbase,
+                                                       int32_t* __restrict__ out_s, int32_t* __restrict__ out_e) {
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+    int rs = -1, re = -1;
+    for (int k = 0; k < cpt; ++k) {
+      const int64_t v = t * cpt + k;
+      if (vs[v] >= 0) { rs = vs[v] + vbase[v]; re = ve[v] + vbase[v]; break; }
+    }
+    out_s[t] = rs; out_e[t] = re;
+  }
+}
 __global__ __launch_bounds__(kBlock) void k_max_len(const int64_t* __restrict__ offsets, int64_t n, int32_t* __restrict__ out) {
   int m = 0;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x)
@@ -1856,7 +1869,7 @@ void launch_stream(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d
                      h->d_blob, lay.data, lay.stride, lay.lens, lay.len, lay.offsets, n, d_counts, \
                      d_nrecs, d_recs, rec_row, d_s, d_e)
   if (d_vlen) {   // pieces of long texts: lay.offsets = their start offsets, n = how many
-    if constexpr (MODE == ST_RECORDS || MODE == ST_COUNT) {
+    if constexpr (MODE == ST_RECORDS || MODE == ST_COUNT || MODE == ST_SEARCH) {
 #define MRX_LAUNCH_V(AUTO)                                                                        \
   hipLaunchKernelGGL((k_stream_findall<MODE, (AUTO == 2 ? MRX_STREAM_CHUNK_TABLE : MRX_STREAM_CHUNK), AUTO, 1, 1>), grid, block, lds, s, p, \
                      h->d_blob, lay.data, lay.stride, lay.lens, lay.len, lay.offsets, n, d_counts, \
@@ -2310,6 +2323,21 @@ static int run_search_any(const mrx_handle* h, const Layout& lay, int64_t n, int
   if (int rc = check_search_supported(h)) return rc;
   if (int rc = ensure_device(h)) return rc;
   hipStream_t s = (hipStream_t)st;
+  Pieces pc;
+  if (int rc = pieces_prepare(h, lay, n, s, &pc)) return rc;
+  if (pc.on) {   // long texts: search every piece, keep each text's first
+    int32_t* d_vs = nullptr;
+    HIP_TRY(scratch_alloc((void**)&d_vs, sizeof(int32_t) * 2 * pc.nv, s));
+    ScanTimer tm(s);
+    launch_stream<ST_SEARCH>(h, pc.lay, pc.nv, nullptr, nullptr, nullptr, 0, d_vs, d_vs + pc.nv, s, pc.vlen, pc.vskip);
+    tm.stop();
+    hipLaunchKernelGGL(k_virt_first, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, n, pc.cpt, d_vs, d_vs + pc.nv,
+                       pc.vbase, ds, de);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(scratch_free(d_vs, s));
+    g_last_kernel = "k_stream_search_pieces";
+    return pieces_release(&pc, s);
+  }
   ScanTimer tm(s);
   launch_stream<ST_SEARCH>(h, lay, n, nullptr, nullptr, nullptr, 0, ds, de, s);
   g_last_kernel = "k_stream_search";

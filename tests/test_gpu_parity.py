@@ -822,7 +822,18 @@ def test_long_texts_in_pieces(pat):
         cnt = rx.count(b).cpu().numpy()
         assert lib.mrx_last_kernel_name() == b"k_stream_count_pieces"
         sub = rx.sub(b"<#>", texts, 0)
+        ss, se = rx.match_next(texts)
+        searched_in_pieces = lib.mrx_last_kernel_name() == b"k_stream_search_pieces"
     assert cnt.tolist() == [len(g) for g in got]
+    assert searched_in_pieces or "findall_only=1" in d
+    # search = the first findall match on these plans (no empty matches, same route)
+    if searched_in_pieces:
+        with long_text_kernels(2):
+            ws, we = rx.match_next(texts)
+        assert ss.tolist() == ws.tolist() and se.tolist() == we.tolist()
+        for i in range(50, len(texts)):
+            m = O.search(pat, texts[i])
+            assert (None if ss[i] < 0 else (int(ss[i]), int(se[i]))) == m, (pat, i)
     for i in range(50, len(texts)):
         assert sub[i] == O.sub(pat, b"<#>", texts[i], 0), (pat, i)
     # fixed pitch with per-text lengths (unaligned pitch: frame form)
