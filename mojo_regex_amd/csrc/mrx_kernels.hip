@@ -405,8 +405,12 @@ __global__ __launch_bounds__(kBlock) void k_slots_gather(int64_t n, const int32_
 constexpr int kRqBlock = 1024, kRqWaves = 4;
 static_assert(kRqBlock == 1 << 10, "byte_at() shifts by 10");
 __host__ __device__ inline size_t reqwave_table_bytes(int nstates) { return (size_t)nstates * 512 + 256; }
+// BIG = 1 (PF_STEP_BIG): automata too large for a byte-indexed table.  The table is then indexed by
+// byte class -- tab[state * ncls + cls[byte]], states kept premultiplied by ncls -- which costs a
+// second LDS read per step, independent of the state.
+__host__ __device__ inline size_t reqwave_big_bytes(int nstates, int ncls) { return (size_t)nstates * ncls * 2 + 512; }
 
-template <int MODE, int ROUTE>
+template <int MODE, int ROUTE, int BIG = 0>
 __global__ __launch_bounds__(64 * kRqWaves) void k_req_wave(DevPlan p, const uint8_t* __restrict__ blob, Layout lay,
                                                             int64_t n, int32_t* __restrict__ counts,
                                                             const int64_t* __restrict__ prefix,
@@ -418,11 +422,19 @@ __global__ __launch_bounds__(64 * kRqWaves) void k_req_wave(DevPlan p, const uin
   uint16_t* tab = (uint16_t*)lds;                 // tab[q * 256 + byte] = next | ACC, or DEAD
   const int ns = p.nstates;
   // ROUTE 1: fc[byte] = byte is in the first element's class; ROUTE 0: a walk may start on byte
-  uint8_t* fc = lds + (size_t)ns * 512;
+  uint8_t* fc = lds + (BIG ? (size_t)ns * p.ncls * 2 : (size_t)ns * 512);
+  uint8_t* clsb = fc + 256;                       // BIG: byte -> class
   {
     const uint8_t* g_cls = blob + p.off_cls;
     const uint8_t* g_first = blob + p.off_first;
     const uint16_t* g_tr = (const uint16_t*)(blob + p.off_trans);
+    if (BIG) {
+      for (int e = threadIdx.x; e < ns * p.ncls; e += blockDim.x) {
+        const uint32_t t = g_tr[e];
+        tab[e] = (uint16_t)(t == 0xFFFFu ? kWsDead : (((t & 0x7FFFu) * p.ncls) | ((t & 0x8000u) ? kWsAcc : 0u)));
+      }
+      for (int b = threadIdx.x; b < 256; b += blockDim.x) clsb[b] = g_cls[b];
+    } else
     for (int e = threadIdx.x; e < ns * 256; e += blockDim.x) {
       const uint32_t t = g_tr[(e >> 8) * p.ncls + g_cls[e & 255]];
       tab[e] = (uint16_t)(t == 0xFFFFu ? kWsDead : ((t & 0x7FFFu) | ((t & 0x8000u) ? kWsAcc : 0u)));
@@ -497,9 +509,9 @@ __global__ __launch_bounds__(64 * kRqWaves) void k_req_wave(DevPlan p, const uin
         auto walk_from = [&](int st) {
           int q = st, state = 0, last = -1;
           while (q < end) {
-            const uint32_t e = tab[(state << 8) + byte_at(q)];
+            const uint32_t e = BIG ? tab[state + clsb[byte_at(q)]] : tab[(state << 8) + byte_at(q)];
             if (e == kWsDead) break;
-            state = (int)(e & 0x3FFFu);
+            state = (int)(e & (BIG ? 0x7FFFu : 0x3FFFu));
             ++q;
             if (e & kWsAcc) last = q;
           }
@@ -1734,6 +1746,10 @@ int reqwave_grid(int64_t n) {
       hipLaunchKernelGGL((k_req_wave<MODE, 1>), dim3(reqwave_grid(N)), dim3(64 * kRqWaves),                      \
                          reqwave_table_bytes((H)->hp.dev.nstates), S, (H)->hp.dev, (H)->d_blob, LAY, N, COUNTS,  \
                          PREFIX, SPANS, CAP, (int32_t*)nullptr, (int32_t*)nullptr);                              \
+    else if ((H)->hp.dev.flags & PF_STEP_BIG)                                                                    \
+      hipLaunchKernelGGL((k_req_wave<MODE, 0, 1>), dim3(reqwave_grid(N)), dim3(64 * kRqWaves),                   \
+                         reqwave_big_bytes((H)->hp.dev.nstates, (H)->hp.dev.ncls), S, (H)->hp.dev, (H)->d_blob,  \
+                         LAY, N, COUNTS, PREFIX, SPANS, CAP, (int32_t*)nullptr, (int32_t*)nullptr);              \
     else                                                                                                         \
       hipLaunchKernelGGL((k_req_wave<MODE, 0>), dim3(reqwave_grid(N)), dim3(64 * kRqWaves),                      \
                          reqwave_table_bytes((H)->hp.dev.nstates), S, (H)->hp.dev, (H)->d_blob, LAY, N, COUNTS,  \
@@ -1820,8 +1836,15 @@ int run_match(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d_s, i
   if (OP == OP_SEARCH && g_force_generic < 2 && (h->hp.dev.flags & PF_STEP_SEARCH) &&
       !(h->hp.dev.flags & PF_PREFILTER)) {   // (the memchr prefilter changes match_next, matcher.mojo:784-796)
     bool wave = false;
-    if (int rc = req_wave_pays(lay, n, false, s, &wave)) return rc;
-    if (wave) {
+    const bool big = (h->hp.dev.flags & PF_STEP_BIG) != 0;   // only the wavefront kernel has its table form
+    if (!big)
+      if (int rc = req_wave_pays(lay, n, false, s, &wave)) return rc;
+    if (big) {
+      hipLaunchKernelGGL((k_req_wave<STEP_SEARCH, 0, 1>), dim3(reqwave_grid(n)), dim3(64 * kRqWaves),
+                         reqwave_big_bytes(h->hp.dev.nstates, h->hp.dev.ncls), s, h->hp.dev, h->d_blob, lay, n,
+                         (int32_t*)nullptr, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0, d_s, d_e);
+      g_last_kernel = "k_req_wave_search";
+    } else if (wave) {
       hipLaunchKernelGGL((k_req_wave<STEP_SEARCH, 0>), dim3(reqwave_grid(n)), dim3(64 * kRqWaves),
                          reqwave_table_bytes(h->hp.dev.nstates), s, h->hp.dev, h->d_blob, lay, n, (int32_t*)nullptr,
                          (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0, d_s, d_e);
@@ -2066,7 +2089,8 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
       HIP_TRY(hipGetLastError());
       tm.stop();
     } else {
-      if (step_ok)
+      if (step_ok && (p.flags & PF_STEP_BIG)) req_wave = true;   // only the wavefront kernel has its table form
+      else if (step_ok)
         if (int rc = req_wave_pays(lay, n, use_req_route, s, &req_wave)) return rc;
       ScanTimer tm(s);
       if (step_ok && span_cap > 0) {
@@ -2473,7 +2497,8 @@ static int run_count_any(const mrx_handle* h, const Layout& lay, int64_t n, int3
   } else {
     const bool use_req_route = (h->hp.dev.flags & PF_STEP_REQ) != 0;
     bool req_wave = false;
-    if (g_force_generic < 2 && (h->hp.dev.flags & (PF_STEPPABLE | PF_STEP_REQ)))
+    if (g_force_generic < 2 && (h->hp.dev.flags & PF_STEP_BIG)) req_wave = true;
+    else if (g_force_generic < 2 && (h->hp.dev.flags & (PF_STEPPABLE | PF_STEP_REQ)))
       if (int rc = req_wave_pays(lay, n, use_req_route, s, &req_wave)) return rc;
     if (req_wave) {
       MRX_REQWAVE_LAUNCH(STEP_COUNT, h, lay, n, counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0, s);

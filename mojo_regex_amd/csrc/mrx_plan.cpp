@@ -693,7 +693,9 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
   if ((d.kind == PLAN_DFA || d.kind == PLAN_LAZY) && hp.why_no_search.empty() &&
       !(d.flags & (PF_START_ANCHOR | PF_END_ANCHOR | PF_PURE_LITERAL | PF_EXACT_LITERAL | PF_START_ACCEPTING |
                    PF_START_DEAD | PF_BITSET | PF_SCAN_ELIGIBLE)) &&
-      d.nstates <= 96) {   // (nstates + 1) x 512 B byte-indexed table in LDS
+      (d.nstates <= 96 ||   // (nstates + 1) x 512 B byte-indexed table in LDS
+       (d.required_byte < 0 && (int64_t)d.nstates * d.ncls < 16384))) {   // or nstates x ncls entries (k_req_wave BIG)
+    if (d.nstates > 96) d.flags |= PF_STEP_BIG;
     d.flags |= PF_STEP_SEARCH;                  // match_next never takes the required-byte route
     if (d.required_byte < 0) d.flags |= PF_STEPPABLE;
     // findall with a rare required byte (_match_all_required_byte, matcher.mojo:864-898): memchr for
@@ -906,7 +908,7 @@ std::string describe_plan(const HostPlan& hp) {
     << (((d.flags & PF_STREAMABLE) && !(d.flags & PF_STREAM_SEARCH)) ? " findall_only=1" : "")
     << " sync_bytes=" << d.st_nsync << "\n";
   o << "device.steppable=" << ((d.flags & PF_STEPPABLE) ? "yes" : (d.flags & PF_STEP_REQ) ? "required-byte route" : "no")
-    << " step_search=" << ((d.flags & PF_STEP_SEARCH) ? 1 : 0) << "\n";
+    << " step_search=" << ((d.flags & PF_STEP_SEARCH) ? 1 : 0) << ((d.flags & PF_STEP_BIG) ? " big_table=1" : "") << "\n";
   o << "device.first_stream=" << (d.fa_bytes ? "yes" : ("no: " + hp.first_stream_why_not))
     << " fa_nstates=" << d.fa_nstates << " fa_kind=" << d.fa_kind << (hp.first_onepass ? " onepass=yes" : "") << "\n";
   if (d.flags & PF_BITSET)

@@ -34,6 +34,8 @@ enum PlanFlags : uint32_t {
   PF_BITSET = 1u << 10,         // PLAN_LAZY walks run on the bitset NFA instead of the DFA table
   PF_STEP_SEARCH = 1u << 13,    // match_next may run on the windowed stepper (plain table walk)
   PF_STEP_REQ = 1u << 14,       // findall / count: the required-byte route on the windowed stepper
+  PF_STEP_BIG = 1u << 15,       // stepper plan whose byte-indexed table does not fit LDS: only the
+                                // wavefront-per-text kernel (class-indexed table) runs it
   PF_STEPPABLE = 1u << 12,      // plain restart-per-position route (no anchors, literals, shortcuts, empty
                                 // matches): findall / search may run on the flattened lane-per-text kernel
   PF_STREAM_SEARCH = 1u << 11   // search / sub / captures may use the streaming kernel too (findall and
