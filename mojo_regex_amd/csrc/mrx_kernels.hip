@@ -1837,9 +1837,12 @@ int run_match(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d_s, i
       !(h->hp.dev.flags & PF_PREFILTER)) {   // (the memchr prefilter changes match_next, matcher.mojo:784-796)
     bool wave = false;
     const bool big = (h->hp.dev.flags & PF_STEP_BIG) != 0;   // only the wavefront kernel has its table form
-    if (!big)
-      if (int rc = req_wave_pays(lay, n, false, s, &wave)) return rc;
-    if (big) {
+    if (int rc = req_wave_pays(lay, n, false, s, &wave)) return rc;
+    if (big && !wave) {   // many short texts: the literal restatement, one lane per text
+      hipLaunchKernelGGL(k_match<OP>, dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s, h->hp.dev,
+                         h->d_blob, lay, n, d_s, d_e, d_flag);
+      g_last_kernel = "k_match";
+    } else if (big) {
       hipLaunchKernelGGL((k_req_wave<STEP_SEARCH, 0, 1>), dim3(reqwave_grid(n)), dim3(64 * kRqWaves),
                          reqwave_big_bytes(h->hp.dev.nstates, h->hp.dev.ncls), s, h->hp.dev, h->d_blob, lay, n,
                          (int32_t*)nullptr, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0, d_s, d_e);
@@ -2047,10 +2050,10 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
   // match_next_sequence: the caller (sub) wants the matches that iterating match_next from each
   // match end visits -- the plain walk even on plans whose findall takes the required-byte route
   const bool use_req_route = (p.flags & PF_STEP_REQ) && !match_next_sequence;
-  const bool step_ok = g_force_generic < 2 &&
-                       (match_next_sequence ? ((p.flags & PF_STEP_SEARCH) && !(p.flags & PF_PREFILTER))
-                                            : (p.flags & (PF_STEPPABLE | PF_STEP_REQ)) != 0);
-  bool req_wave = false;   // required-byte route on the wavefront-per-text kernel
+  bool step_ok = g_force_generic < 2 &&
+                 (match_next_sequence ? ((p.flags & PF_STEP_SEARCH) && !(p.flags & PF_PREFILTER))
+                                      : (p.flags & (PF_STEPPABLE | PF_STEP_REQ)) != 0);
+  bool req_wave = false;   // the stepper's route on the wavefront-per-text kernel
   EvRec* d_recs = nullptr;
   int32_t* d_nrecs = nullptr;
   int64_t* d_wbase = nullptr;
@@ -2089,9 +2092,10 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
       HIP_TRY(hipGetLastError());
       tm.stop();
     } else {
-      if (step_ok && (p.flags & PF_STEP_BIG)) req_wave = true;   // only the wavefront kernel has its table form
-      else if (step_ok)
+      if (step_ok)
         if (int rc = req_wave_pays(lay, n, use_req_route, s, &req_wave)) return rc;
+      // big tables: only the wavefront kernel has their form; many short texts stay on the literal restatement
+      if ((p.flags & PF_STEP_BIG) && !req_wave) step_ok = false;
       ScanTimer tm(s);
       if (step_ok && span_cap > 0) {
         HIP_TRY(scratch_alloc((void**)&d_slots, sizeof(int32_t) * 2 * kStepSlots * (size_t)n, s));
@@ -2497,13 +2501,13 @@ static int run_count_any(const mrx_handle* h, const Layout& lay, int64_t n, int3
   } else {
     const bool use_req_route = (h->hp.dev.flags & PF_STEP_REQ) != 0;
     bool req_wave = false;
-    if (g_force_generic < 2 && (h->hp.dev.flags & PF_STEP_BIG)) req_wave = true;
-    else if (g_force_generic < 2 && (h->hp.dev.flags & (PF_STEPPABLE | PF_STEP_REQ)))
+    if (g_force_generic < 2 && (h->hp.dev.flags & (PF_STEPPABLE | PF_STEP_REQ)))
       if (int rc = req_wave_pays(lay, n, use_req_route, s, &req_wave)) return rc;
+    const bool big_lane = (h->hp.dev.flags & PF_STEP_BIG) && !req_wave;   // -> literal restatement
     if (req_wave) {
       MRX_REQWAVE_LAUNCH(STEP_COUNT, h, lay, n, counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0, s);
       g_last_kernel = "k_req_wave";
-    } else if (g_force_generic < 2 && (h->hp.dev.flags & (PF_STEPPABLE | PF_STEP_REQ))) {
+    } else if (g_force_generic < 2 && !big_lane && (h->hp.dev.flags & (PF_STEPPABLE | PF_STEP_REQ))) {
       MRX_WSTEP_LAUNCH(STEP_COUNT, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_table_bytes(h->hp.dev.nstates), s, h->hp.dev,
                          h->d_blob, lay, n, counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0,
                          (int32_t*)nullptr, (int32_t*)nullptr);

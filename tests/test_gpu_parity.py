@@ -924,9 +924,10 @@ def test_generated_patterns_stepper_equals_literal_restatement(seed):
             k = len(texts[j])
             texts[j] = (bytes([al[int(rng.integers(0, len(al)))]]) * (k // 2) + texts[j])[:k]
         try:
-            with no_streaming_kernels():
+            big = "big_table=1" in dsc   # > 96 states: only the wavefront kernel has the table form
+            with no_streaming_kernels(), long_text_kernels(1 if big else 0):
                 got = rx.findall_lists(texts)
-                assert lib.mrx_last_kernel_name() == (b"k_req_wave" if "big_table=1" in dsc else b"k_step_count")
+                assert lib.mrx_last_kernel_name() == (b"k_req_wave" if big else b"k_step_count")
                 gs, ge = rx.match_next(texts)
         except M.UnsupportedPattern:   # tables beyond the LDS staging budget
             continue
