@@ -1934,6 +1934,9 @@ int pieces_prepare(const mrx_handle* h, const Layout& lay, int64_t n, hipStream_
   const DevPlan& p = h->hp.dev;
   pc->on = false;
   if (p.st_nsync <= 0 || g_long_text_mode == 2 || n <= 0) return MRX_OK;
+  // pays when one lane per text leaves the device mostly idle (checked before anything is launched:
+  // a CSR batch's lengths live on the device and cost a small kernel and an 8-byte read-back)
+  if (g_long_text_mode == 0 && n > 131072) return MRX_OK;
   int64_t total = 0, max_len = 0;
   if (lay.offsets) {
     int32_t* d_max = nullptr;
@@ -1955,8 +1958,7 @@ int pieces_prepare(const mrx_handle* h, const Layout& lay, int64_t n, hipStream_
     C = 200;   // tests: cut even short texts, at positions that are not multiples of 16
     if (max_len <= C) return MRX_OK;
   } else {
-    // pays when one lane per text leaves the device mostly idle and the texts are long enough to cut
-    if (max_len < 4096 || n > 131072) return MRX_OK;
+    if (max_len < 4096) return MRX_OK;   // nothing long enough to cut
     const int64_t want = (total + 262143) / 262144;   // about 2^18 pieces
     C = (int)((want + 255) / 256 * 256);
     if (C < 2048) C = 2048;
