@@ -9,10 +9,17 @@ def rtexts(rng, n, max_len, alphabet):
     al = np.frombuffer(alphabet, dtype=np.uint8)
     lens = rng.integers(0, max_len + 1, size=n)
     return [bytes(rng.choice(al, size=int(k)).tolist()) for k in lens]
+import os
+# MRX_LONG_TEXT_MODE=1: force the wavefront-per-text stepper kernels and the pieces path (200-byte
+# pieces) on every plan that has them, with texts long enough to span several blocks / pieces
+MODE = int(os.environ.get("MRX_LONG_TEXT_MODE", "0"))
+M.load_library().mrx_debug_long_text_kernels(MODE)
 bad = 0; checked = 0
 for seed in range(30000, 30012):
     rng = np.random.default_rng(seed)
     texts = rtexts(rng, 30, 60, b"abcxyz019 -@.") + rtexts(rng, 12, 220, b"abcfoobarhellocatdog0123456789 xyz@.-") + [b"", b"a", b"foobar", b"hello", b"abc123", b"cat dog", b"http://id.no", b"q"*150+b"1"]
+    if MODE:
+        texts += rtexts(rng, 6, 2600, b"abcfoobarhellocatdog0123456789 xyz@.-") + [b"ab" * 700 + b"12 " + b"7" * 1300 + b"-5 x@y.z"]
     for p in patterns(seed, 300):
         pb = p.encode()
         try: rx = M.compile_regex(pb)
