@@ -1358,6 +1358,12 @@ __device__ __forceinline__ void load16(const uint8_t* base, int len, int src, ui
   else { lo = (w0 >> sh) | (w1 << (64 - sh)); hi = (w1 >> sh) | (w2 << (64 - sh)); }
 }
 
+// G = 16: 16 lanes share a text and its replacements are staged whole (up to kSubsStage, more: read
+// from global).  G = kBlock (long texts): a whole workgroup shares a text, and every round -- G output
+// blocks = 4 KiB of output -- stages the window of replacements that can touch it (the last one
+// starting at or before the round's first byte, and the kSubsWindow - 1 after it).
+constexpr int kSubsWindow = 512;
+template <int G>
 __global__ __launch_bounds__(kBlock) void k_subs_emit(int64_t n, const uint8_t* __restrict__ data,
                                                       const int64_t* __restrict__ offsets,
                                                       const int64_t* __restrict__ prefix,
@@ -1369,15 +1375,26 @@ __global__ __launch_bounds__(kBlock) void k_subs_emit(int64_t n, const uint8_t* 
   // kSubsLanes lanes share one text (4 texts per wavefront): a 1 KiB text has ~70 output blocks,
   // which 64 lanes cover in two half-empty rounds; 16 lanes cover them in five full ones, and the
   // four texts' dependent round trips (offsets -> spans -> bytes) overlap.
-  __shared__ int3 stage_all[kBlock / kSubsLanes][kSubsStage];  // {rstart, match start, match end}
+  constexpr bool WIN = G != kSubsLanes;
+  constexpr int STAGE = WIN ? kSubsWindow : kSubsStage;
+  static_assert(G == kSubsLanes || G == kBlock, "a group is 16 lanes or the workgroup");
+  __shared__ int3 stage_all[kBlock / G][STAGE];  // {rstart, match start, match end}
   extern __shared__ __align__(16) uint8_t subs_dyn[];   // the replacement map (R u16 entries)
   uint16_t* rmap_lds = (uint16_t*)subs_dyn;
   for (int r = threadIdx.x; r < R; r += blockDim.x) rmap_lds[r] = rmap[r];
   __syncthreads();
-  const int lane = threadIdx.x & (kSubsLanes - 1);   // lane within the group that owns the text
-  int3* stage = stage_all[threadIdx.x / kSubsLanes];
-  const int64_t ngroups = (int64_t)gridDim.x * (blockDim.x / kSubsLanes);
-  for (int64_t i = (int64_t)blockIdx.x * (blockDim.x / kSubsLanes) + (threadIdx.x / kSubsLanes); i < n; i += ngroups) {
+  auto group_sync = [&]() {
+    if (WIN) __syncthreads();
+    else {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  };
+  const int lane = threadIdx.x & (G - 1);   // lane within the group that owns the text
+  int3* stage = stage_all[threadIdx.x / G];
+  const int64_t ngroups = (int64_t)gridDim.x * (blockDim.x / G);
+  for (int64_t i = (int64_t)blockIdx.x * (blockDim.x / G) + (threadIdx.x / G); i < n; i += ngroups) {
     const int64_t ibase = offsets[i];
     const uint8_t* tptr = data + ibase;
     const int tlen = (int)(offsets[i + 1] - ibase);
@@ -1390,24 +1407,37 @@ __global__ __launch_bounds__(kBlock) void k_subs_emit(int64_t n, const uint8_t* 
     if (olen <= 0) continue;
     const int32_t* sp = spans + 2 * a;
     const int32_t* cm = cum + a;
-    const bool staged = k <= kSubsStage;
-    __builtin_amdgcn_wave_barrier();
-    if (staged) {
-      for (int m = lane; m < k; m += kSubsLanes) {
-        const int2 se = *(const int2*)(sp + 2 * m);
-        stage[m] = make_int3(se.x - cm[m] + m * R, se.x, se.y);
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-    auto repl_at = [&](int m) {  // {rstart, match start, match end} of replacement m
-      if (staged) return stage[m];
+    const bool staged = !WIN && k <= STAGE;
+    auto repl_global = [&](int m) {  // {rstart, match start, match end} of replacement m
       const int2 se = *(const int2*)(sp + 2 * m);
       return make_int3(se.x - cm[m] + m * R, se.x, se.y);
     };
+    group_sync();
+    if (staged) {
+      for (int m = lane; m < k; m += G) stage[m] = repl_global(m);
+      group_sync();
+    }
+    int wbase = 0, wcnt = 0;   // WIN: replacements [wbase, wbase + wcnt) are staged
+    auto repl_at = [&](int m) {
+      if (staged) return stage[m];
+      if (WIN && m >= wbase && m < wbase + wcnt) return stage[m - wbase];
+      return repl_global(m);
+    };
     const int head = (int)((uintptr_t)(out + obase) & 15);  // output starts `head` bytes into its first 16-byte block
-    for (int blk = 0; blk * 16 < head + olen; blk += kSubsLanes) {
+    for (int blk = 0; blk * 16 < head + olen; blk += G) {
+      if (WIN) {
+        group_sync();   // everyone is done with the previous window
+        const int w_lo = blk * 16 - head < 0 ? 0 : blk * 16 - head;   // first output position of this round
+        int lo = -1, hi = k;
+        while (hi - lo > 1) {   // same addresses in every lane: one broadcast load per step
+          const int mid = (lo + hi) >> 1;
+          if (repl_global(mid).x <= w_lo) lo = mid; else hi = mid;
+        }
+        wbase = lo < 0 ? 0 : lo;
+        wcnt = k - wbase < STAGE ? k - wbase : STAGE;
+        for (int m = lane; m < wcnt; m += G) stage[m] = repl_global(wbase + m);
+        group_sync();
+      }
       const int p_lo = (blk + lane) * 16 - head;   // first output position of my block (may be < 0)
       int p = p_lo < 0 ? 0 : p_lo;
       const int p_hi = p_lo + 16 < olen ? p_lo + 16 : olen;
@@ -1468,7 +1498,7 @@ __global__ __launch_bounds__(kBlock) void k_subs_emit(int64_t n, const uint8_t* 
           dst[q] = (uint8_t)((q < 8 ? wlo : whi) >> ((q & 7) * 8));
       }
     }
-    __builtin_amdgcn_wave_barrier();
+    group_sync();
   }
 }
 
@@ -2233,11 +2263,18 @@ int sub_from_spans(const mrx_handle* h, const Layout& lay, int64_t n, const std:
     if (tot > out_cap) {
       rc = fail(MRX_E_CAPACITY, "output buffer too small: need " + std::to_string(tot));
     } else if (tot > 0) {
+      if ((g_long_text_mode == 1 || in_bytes / n >= 4096) && g_long_text_mode != 2) {   // long texts: a workgroup per text
+        hipLaunchKernelGGL(k_subs_emit<kBlock>, dim3((unsigned)(n < 4096 ? n : 4096)), dim3(kBlock),
+                           (size_t)(2 * R + 16), s, n, lay.data, lay.offsets, d_prefix, d_spans, d_cum, (long long)count, R,
+                           d_rmap, out_off, out);
+        g_last_kernel = "k_subs_emit_long";
+      } else {
       const int64_t blocks = (n + (kBlock / kSubsLanes) - 1) / (kBlock / kSubsLanes);
-      hipLaunchKernelGGL(k_subs_emit, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(kBlock),
+      hipLaunchKernelGGL(k_subs_emit<kSubsLanes>, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(kBlock),
                          (size_t)(2 * R + 16), s, n, lay.data, lay.offsets, d_prefix, d_spans, d_cum, (long long)count, R, d_rmap,
                          out_off, out);
       g_last_kernel = "k_subs_emit";
+      }
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipStreamSynchronize(s));
     }

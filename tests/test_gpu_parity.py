@@ -635,6 +635,39 @@ def test_sub_from_spans_equals_generic_and_oracle(pat, repl, count):
         assert got[i] == O.sub(pat, repl, texts[i], count), (pat, repl, texts[i], count)
 
 
+@pytest.mark.parametrize("pat,repl", [(b"[a-z]+\\d+", b"#"), (b"\\d", b""), (b"\\d+", b"<NUM>"), (b"[0-9]+", b"#"),
+                                      (b"(\\d{3})(\\d{3})(\\d{4})", b"\\1-\\2-\\3"), (b"(x|y|foo|bar)+", b"_"),
+                                      (b"hello", b"HELLO WORLD"), (b"\\d{3}-\\d{3}-\\d{4}", b"XXX-XXX-XXXX"), (b"\\s+", b" ")])
+@pytest.mark.parametrize("count", [0, 5])
+def test_sub_emit_with_a_workgroup_per_text(pat, repl, count):
+    """k_subs_emit<kBlock> (long texts: a workgroup per text, replacements staged window by window)
+    against the 16-lanes-per-text form and the oracle: dense replacements (more per 4 KiB window than
+    the window stages), empty replacements of touching matches, texts shorter than one round."""
+    _need_gpu()
+    rng = np.random.default_rng(zlib.crc32(pat + repl) + count + 1)
+    al = b"abcxyz0123456789 -" + bytes(c for c in pat if chr(c).isalnum()) * 2
+    texts = _random_texts(rng, 40, 90, al) + _random_texts(rng, 12, 9000, al) + _random_texts(rng, 3, 40000, al) + [
+        b"", b"1", b"a1", b"1 2 3 4 5 6 7 8 9 " * 900, b"7" * 20000, b"a1" * 9000 + b"  " * 500,
+        b"Call 6502530000 or 415-555-1234 today.  hello " * 400]
+    rx = M.compile_regex(pat)
+    lib = M.load_library()
+    with long_text_kernels(1):
+        got = rx.sub(repl, texts, count)
+        assert lib.mrx_last_kernel_name() == b"k_subs_emit_long"
+    with long_text_kernels(2):
+        want = rx.sub(repl, texts, count)
+        assert lib.mrx_last_kernel_name() == b"k_subs_emit"
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert g == w, (pat, repl, count, i, len(texts[i]))
+    for i in list(range(0, 40, 9)) + list(range(40, len(texts))):
+        assert got[i] == O.sub(pat, repl, texts[i], count), (pat, repl, i, count)
+    # by average length: a batch of long texts takes the workgroup form on its own
+    long_only = [t for t in texts if len(t) >= 9000]
+    got2 = rx.sub(repl, long_only, count)
+    assert lib.mrx_last_kernel_name() == b"k_subs_emit_long"
+    assert got2 == [g for g, t in zip(got, texts) if len(t) >= 9000]
+
+
 @pytest.mark.parametrize("seed", [20260503, 20260504, 20260505, 20260506])
 def test_generated_patterns_results_match_oracle(seed):
     """4 x 300 generated patterns (tests/pattern_gen.py) x 60 random texts: every operation the
