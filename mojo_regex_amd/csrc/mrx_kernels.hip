@@ -1196,8 +1196,8 @@ __global__ __launch_bounds__(kBlock) void k_decode(int64_t n, const int32_t* __r
 // ---- long texts in pieces (k_stream_findall VIRT) -------------------------------------------
 // Text t is cut every C bytes; piece k owns the text bytes [k C, min(len, (k + 1) C)) and starts its
 // walk at the last synchronising byte before k C, at most kVirtBack bytes back.  A cut without such
-// a byte is not made (the piece before it runs on, its own piece is empty).  Every text has cpt
-// pieces (cpt = pieces of the longest text), so piece v belongs to text v / cpt.
+// a byte is not made (the piece before it runs on, its own piece is empty).  Text t has
+// max(1, ceil(len / C)) pieces, numbered vfirst[t] .. vfirst[t + 1] - 1 (vfirst = prefix sums).
 constexpr int kVirtBack = 256;   // < 1008, see rec_region_start: pieces overlap by at most this much
 
 __device__ __forceinline__ int virt_back(const uint8_t* __restrict__ sync, const uint8_t* __restrict__ txt, int c) {
@@ -1205,42 +1205,57 @@ __device__ __forceinline__ int virt_back(const uint8_t* __restrict__ sync, const
     if (sync[txt[c - b]]) return b;
   return -1;
 }
+// the text that owns piece v: last t with vfirst[t] <= v
+__device__ __forceinline__ int64_t virt_text_of(const int64_t* __restrict__ vfirst, int64_t n, int64_t v) {
+  int64_t lo = 0, hi = n;   // vfirst[lo] <= v < vfirst[hi]
+  while (hi - lo > 1) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (vfirst[mid] <= v) lo = mid; else hi = mid;
+  }
+  return lo;
+}
 
-// back[v] for piece v = (t, k): how far before the cut k C its synchronising byte lies; 0 for k = 0,
-// -1 when there is none within kVirtBack bytes (the piece before it then runs on through this one),
-// -2 when the text ends before the cut
-__global__ __launch_bounds__(kBlock) void k_virt_check(Layout lay, int64_t n, int cpt, int C,
-                                                       const uint8_t* __restrict__ sync, int32_t* __restrict__ back) {
-  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n * cpt; v += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t t = v / cpt;
-    const int k = (int)(v - t * cpt);
-    const Text tx = lay.text(t);
-    const int64_t c = (int64_t)k * C;
-    back[v] = k == 0 ? 0 : c >= tx.len ? -2 : virt_back(sync, tx.ptr, (int)c);
+__global__ __launch_bounds__(kBlock) void k_virt_count(Layout lay, int64_t n, int C, int32_t* __restrict__ cnt) {
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+    const int len = lay.text(t).len;
+    cnt[t] = len <= C ? 1 : (len + C - 1) / C;
   }
 }
 
-__global__ __launch_bounds__(kBlock) void k_virt_fill(Layout lay, int64_t n, int cpt, int C,
-                                                      const int32_t* __restrict__ back,
+// back[v] for piece v = (t, k): how far before the cut k C its synchronising byte lies; 0 for k = 0,
+// -1 when there is none within kVirtBack bytes (the piece before it then runs on through this one)
+__global__ __launch_bounds__(kBlock) void k_virt_check(Layout lay, int64_t n, const int64_t* __restrict__ vfirst,
+                                                       int64_t nv, int C, const uint8_t* __restrict__ sync,
+                                                       int32_t* __restrict__ back) {
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t t = virt_text_of(vfirst, n, v);
+    const int k = (int)(v - vfirst[t]);
+    back[v] = k == 0 ? 0 : virt_back(sync, lay.text(t).ptr, k * C);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_virt_fill(Layout lay, int64_t n, const int64_t* __restrict__ vfirst,
+                                                      int64_t nv, int C, const int32_t* __restrict__ back,
                                                       int64_t* __restrict__ vstart, int32_t* __restrict__ vlen,
                                                       uint32_t* __restrict__ vskip, int32_t* __restrict__ vbase) {
-  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n * cpt; v += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t t = v / cpt;
-    const int k = (int)(v - t * cpt);
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t t = virt_text_of(vfirst, n, v);
+    const int64_t v0 = vfirst[t];
+    const int k = (int)(v - v0), cpt = (int)(vfirst[t + 1] - v0);
     const Text tx = lay.text(t);
     const int64_t abs0 = tx.ptr - lay.data;
     const int b = back[v];
-    const int64_t c = (int64_t)k * C;
-    // an empty piece sits at its cut (or at the end of a shorter text): piece starts never decrease,
-    // which the record regions rely on (rec_region_start)
-    int64_t st = abs0 + (c < tx.len ? c : (int64_t)tx.len);
-    int ln = 0, base = (int)(st - abs0);
+    const int64_t c = (int64_t)k * C;   // < len, or 0 for the one piece of an empty text
+    // an empty piece sits at its cut: piece starts never decrease, which the record regions rely on
+    // (rec_region_start)
+    int64_t st = abs0 + c;
+    int ln = 0, base = (int)c;
     uint32_t sk = 0;
     if (b >= 0) {
       // my piece runs to the next cut that has a synchronising byte, or to the end of the text
       int j = k + 1;
-      while (j < cpt && back[t * cpt + j] == -1) ++j;
-      const int e = (j == cpt || back[t * cpt + j] == -2) ? tx.len : j * C;
+      while (j < cpt && back[v0 + j] == -1) ++j;
+      const int e = j == cpt ? tx.len : j * C;
       st = abs0 + c - b; ln = e - (int)c + b; base = (int)c - b;
       sk = (uint32_t)b | (e == tx.len ? 0x80000000u : 0u);
     }
@@ -1249,29 +1264,30 @@ __global__ __launch_bounds__(kBlock) void k_virt_fill(Layout lay, int64_t n, int
 }
 
 // per-text entries of the per-piece prefix sums / counts
-__global__ __launch_bounds__(kBlock) void k_virt_prefix(int64_t n, int cpt, const int64_t* __restrict__ vprefix,
+__global__ __launch_bounds__(kBlock) void k_virt_prefix(int64_t n, const int64_t* __restrict__ vfirst,
+                                                        const int64_t* __restrict__ vprefix,
                                                         int64_t* __restrict__ prefix) {
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t <= n; t += (int64_t)gridDim.x * blockDim.x)
-    prefix[t] = vprefix[t * cpt];
+    prefix[t] = vprefix[vfirst[t]];
 }
-__global__ __launch_bounds__(kBlock) void k_virt_sum(int64_t n, int cpt, const int32_t* __restrict__ vcounts,
+__global__ __launch_bounds__(kBlock) void k_virt_sum(int64_t n, const int64_t* __restrict__ vfirst,
+                                                     const int32_t* __restrict__ vcounts,
                                                      int32_t* __restrict__ counts) {
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
     int c = 0;
-    for (int k = 0; k < cpt; ++k) c += vcounts[t * cpt + k];
+    for (int64_t v = vfirst[t]; v < vfirst[t + 1]; ++v) c += vcounts[v];
     counts[t] = c;
   }
 }
 // search: the first piece of a text that holds a match has the text's first match
-__global__ __launch_bounds__(kBlock) void k_virt_first(int64_t n, int cpt, const int32_t* __restrict__ vs,
+__global__ __launch_bounds__(kBlock) void k_virt_first(int64_t n, const int64_t* __restrict__ vfirst,
+                                                       const int32_t* __restrict__ vs,
                                                        const int32_t* __restrict__ ve, const int32_t* __restrict__ vbase,
                                                        int32_t* __restrict__ out_s, int32_t* __restrict__ out_e) {
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
     int rs = -1, re = -1;
-    for (int k = 0; k < cpt; ++k) {
-      const int64_t v = t * cpt + k;
+    for (int64_t v = vfirst[t]; v < vfirst[t + 1]; ++v)
       if (vs[v] >= 0) { rs = vs[v] + vbase[v]; re = ve[v] + vbase[v]; break; }
-    }
     out_s[t] = rs; out_e[t] = re;
   }
 }
@@ -1951,8 +1967,9 @@ void launch_stream(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d
 // would leave most of the device idle.
 struct Pieces {
   bool on = false;
-  int cpt = 0, C = 0;
+  int C = 0;
   int64_t nv = 0, data_bytes = 0;
+  int64_t* vfirst = nullptr;   // [n + 1]: first piece of every text
   int64_t* vstart = nullptr;
   int32_t* vlen = nullptr;
   uint32_t* vskip = nullptr;
@@ -1964,9 +1981,9 @@ int pieces_prepare(const mrx_handle* h, const Layout& lay, int64_t n, hipStream_
   const DevPlan& p = h->hp.dev;
   pc->on = false;
   if (p.st_nsync <= 0 || g_long_text_mode == 2 || n <= 0) return MRX_OK;
-  // pays when one lane per text leaves the device mostly idle (checked before anything is launched:
-  // a CSR batch's lengths live on the device and cost a small kernel and an 8-byte read-back)
-  if (g_long_text_mode == 0 && n > 131072) return MRX_OK;
+  // pays when one lane per text leaves the device mostly idle, or for outliers of a ragged batch; a
+  // fixed-length batch of many texts is decided before anything is launched
+  if (g_long_text_mode == 0 && n > 131072 && !lay.offsets && !lay.lens) return MRX_OK;
   int64_t total = 0, max_len = 0;
   if (lay.offsets) {
     int32_t* d_max = nullptr;
@@ -1989,23 +2006,44 @@ int pieces_prepare(const mrx_handle* h, const Layout& lay, int64_t n, hipStream_
     if (max_len <= C) return MRX_OK;
   } else {
     if (max_len < 4096) return MRX_OK;   // nothing long enough to cut
+    // batches that fill the device with one lane per text are cut only for the sake of texts far
+    // longer than the rest (ragged batches: one lane would still be walking long after the others)
+    const int64_t avg = total / n;
+    if (n > 131072 && !(max_len >= 32768 && max_len >= 8 * avg && (lay.offsets || lay.lens))) return MRX_OK;
     const int64_t want = (total + 262143) / 262144;   // about 2^18 pieces
     C = (int)((want + 255) / 256 * 256);
     if (C < 2048) C = 2048;
     if (C >= max_len) return MRX_OK;
   }
-  const int64_t cpt = (max_len + C - 1) / C;
-  if (cpt < 2 || n * cpt > (int64_t(1) << 23)) return MRX_OK;
-  pc->cpt = (int)cpt; pc->C = C; pc->nv = n * cpt; pc->data_bytes = total;
+  // pieces per text -> prefix sums -> how many there are
+  int32_t* d_cnt = nullptr;
+  int64_t* d_tot = nullptr;
+  HIP_TRY(scratch_alloc((void**)&d_cnt, sizeof(int32_t) * n, s));
+  HIP_TRY(scratch_alloc((void**)&d_tot, sizeof(int64_t), s));
+  HIP_TRY(scratch_alloc((void**)&pc->vfirst, sizeof(int64_t) * (n + 1), s));
+  hipLaunchKernelGGL(k_virt_count, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, lay, n, C, d_cnt);
+  if (int rc = device_scan<int32_t>(d_cnt, n, pc->vfirst, d_tot, s)) return rc;
+  int64_t nv = 0;
+  HIP_TRY(hipMemcpyAsync(&nv, d_tot, sizeof nv, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  HIP_TRY(scratch_free(d_cnt, s));
+  HIP_TRY(scratch_free(d_tot, s));
+  if (nv <= n || nv > (int64_t(1) << 24)) {   // nothing to cut after all, or an absurd number of pieces
+    HIP_TRY(scratch_free(pc->vfirst, s));
+    pc->vfirst = nullptr;
+    return MRX_OK;
+  }
+  pc->C = C; pc->nv = nv; pc->data_bytes = total;
   HIP_TRY(scratch_alloc((void**)&pc->vstart, sizeof(int64_t) * (pc->nv + 1), s));
   HIP_TRY(scratch_alloc((void**)&pc->vlen, sizeof(int32_t) * pc->nv, s));
   HIP_TRY(scratch_alloc((void**)&pc->vskip, sizeof(uint32_t) * pc->nv, s));
   HIP_TRY(scratch_alloc((void**)&pc->vbase, sizeof(int32_t) * pc->nv, s));
   HIP_TRY(scratch_alloc((void**)&pc->back, sizeof(int32_t) * pc->nv, s));
   const uint8_t* sync = h->d_blob + p.off_st_sync;
-  hipLaunchKernelGGL(k_virt_check, dim3(grid_for(pc->nv, kBlock)), dim3(kBlock), 0, s, lay, n, pc->cpt, C, sync, pc->back);
-  hipLaunchKernelGGL(k_virt_fill, dim3(grid_for(pc->nv, kBlock)), dim3(kBlock), 0, s, lay, n, pc->cpt, C, pc->back,
-                     pc->vstart, pc->vlen, pc->vskip, pc->vbase);
+  hipLaunchKernelGGL(k_virt_check, dim3(grid_for(pc->nv, kBlock)), dim3(kBlock), 0, s, lay, n, pc->vfirst, pc->nv, C, sync,
+                     pc->back);
+  hipLaunchKernelGGL(k_virt_fill, dim3(grid_for(pc->nv, kBlock)), dim3(kBlock), 0, s, lay, n, pc->vfirst, pc->nv, C,
+                     pc->back, pc->vstart, pc->vlen, pc->vskip, pc->vbase);
   HIP_TRY(hipGetLastError());
   pc->lay = Layout{lay.data, pc->vstart, 0, nullptr, 0};
   pc->on = true;
@@ -2013,6 +2051,7 @@ int pieces_prepare(const mrx_handle* h, const Layout& lay, int64_t n, hipStream_
 }
 int pieces_release(Pieces* pc, hipStream_t s) {
   if (!pc->on) return MRX_OK;
+  HIP_TRY(scratch_free(pc->vfirst, s));
   HIP_TRY(scratch_free(pc->vstart, s));
   HIP_TRY(scratch_free(pc->vlen, s));
   HIP_TRY(scratch_free(pc->vskip, s));
@@ -2054,7 +2093,7 @@ int findall_pieces(const mrx_handle* h, const Pieces& pc, int64_t n, int64_t* d_
   hipLaunchKernelGGL((k_decode<false, true>), dim3(grid_for(nv, kBlock)), dim3(kBlock), 0, s, nv, d_nrecs, d_recs,
                      (int64_t)0, pc.lay.offsets, d_vcounts, d_wbase, d_tsum, d_vprefix, d_spans, span_cap, p.st_fixed_len,
                      d_total, pc.vbase);
-  hipLaunchKernelGGL(k_virt_prefix, dim3(grid_for(n + 1, kBlock)), dim3(kBlock), 0, s, n, pc.cpt, d_vprefix, d_prefix);
+  hipLaunchKernelGGL(k_virt_prefix, dim3(grid_for(n + 1, kBlock)), dim3(kBlock), 0, s, n, pc.vfirst, d_vprefix, d_prefix);
   HIP_TRY(hipGetLastError());
   HIP_TRY(scratch_free(d_vcounts, s));
   HIP_TRY(scratch_free(d_recs, s));
@@ -2398,7 +2437,7 @@ static int run_search_any(const mrx_handle* h, const Layout& lay, int64_t n, int
     ScanTimer tm(s);
     launch_stream<ST_SEARCH>(h, pc.lay, pc.nv, nullptr, nullptr, nullptr, 0, d_vs, d_vs + pc.nv, s, pc.vlen, pc.vskip);
     tm.stop();
-    hipLaunchKernelGGL(k_virt_first, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, n, pc.cpt, d_vs, d_vs + pc.nv,
+    hipLaunchKernelGGL(k_virt_first, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, n, pc.vfirst, d_vs, d_vs + pc.nv,
                        pc.vbase, ds, de);
     HIP_TRY(hipGetLastError());
     HIP_TRY(scratch_free(d_vs, s));
@@ -2528,7 +2567,7 @@ static int run_count_any(const mrx_handle* h, const Layout& lay, int64_t n, int3
       int32_t* d_vcounts = nullptr;
       HIP_TRY(scratch_alloc((void**)&d_vcounts, sizeof(int32_t) * pc.nv, s));
       launch_stream<ST_COUNT>(h, pc.lay, pc.nv, d_vcounts, nullptr, nullptr, 0, nullptr, nullptr, s, pc.vlen, pc.vskip);
-      hipLaunchKernelGGL(k_virt_sum, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, n, pc.cpt, d_vcounts, counts);
+      hipLaunchKernelGGL(k_virt_sum, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, n, pc.vfirst, d_vcounts, counts);
       HIP_TRY(hipGetLastError());
       HIP_TRY(scratch_free(d_vcounts, s));
       if (int rc = pieces_release(&pc, s)) return rc;

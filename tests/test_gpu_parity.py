@@ -884,6 +884,38 @@ def test_long_texts_in_pieces(pat):
         assert tot == tot2 and torch.equal(pre, pre2) and torch.equal(sp[:tot], sp2[:tot2])
 
 
+def test_outliers_of_a_ragged_batch_are_cut_into_pieces():
+    """150 000 short texts and three of 100-300 KB in one CSR batch: without pieces the three long ones
+    would each be one lane's work; the batch is cut although it has plenty of texts (per-text piece
+    counts: the short texts are one piece each)."""
+    _need_gpu()
+    pat = b"[a-z]+\\d+"
+    rx = M.compile_regex(pat)
+    lib = M.load_library()
+    rng = np.random.default_rng(77)
+    al = np.frombuffer(b"abcxyz0123456789 -", dtype=np.uint8)
+    lens = rng.integers(0, 120, size=150000)
+    for pos, ln in ((5, 300000), (70001, 100000), (149999, 200000)):
+        lens[pos] = ln
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    data = rng.choice(al, size=int(offsets[-1])).astype(np.uint8)
+    b = M.DeviceBatch(torch.from_numpy(data).cuda(), torch.from_numpy(offsets).cuda())
+    pre, sp, tot = rx._dev_findall(b)
+    assert lib.mrx_last_kernel_name() == b"k_stream_findall_pieces"
+    cnt = rx.count(b)
+    ss, se = rx.match_next(b)
+    with long_text_kernels(2):
+        pre2, sp2, tot2 = rx._dev_findall(b)
+        assert lib.mrx_last_kernel_name() == b"k_stream_findall"
+        cnt2 = rx.count(b)
+        ws, we = rx.match_next(b)
+    assert tot == tot2 and torch.equal(pre, pre2) and torch.equal(sp[:tot], sp2[:tot2])
+    assert torch.equal(cnt, cnt2) and torch.equal(ss, ws) and torch.equal(se, we)
+    t = data[offsets[5]:offsets[6]].tobytes()
+    a, z = int(pre[5].item()), int(pre[6].item())
+    assert [tuple(x) for x in sp[a:z].cpu().numpy().tolist()] == O.findall(pat, t)
+
+
 @pytest.mark.parametrize("pat", EXACT_LITERALS)
 def test_exact_literal_kmp_streaming(pat):
     """HybridMatcher's exact-literal bypass (matcher.mojo:768-781, 815-847) on the streaming kernel:
