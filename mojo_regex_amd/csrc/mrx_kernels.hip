@@ -42,6 +42,9 @@ struct Layout {  // where text i lives
   int64_t stride;          // fixed pitch otherwise
   const int32_t* lens;     // optional per-text length (fixed pitch)
   int32_t len;             // common length when lens == nullptr
+  // Stepper kernels only (ragged batches with a few very long texts): k_wstep leaves texts of at least
+  // `split` bytes to k_req_wave, which in turn skips the shorter ones; 0 = no split
+  int32_t split = 0;
   __device__ __forceinline__ Text text(int64_t i) const {
     if (offsets) {
       const int64_t a = offsets[i], b = offsets[i + 1];
@@ -250,7 +253,8 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_wstep(DevPlan p, const uint8_
     int pos = mis, start = mis, last = -1, k = 0, rs = -1, re = -1;
     int rsb = mis, rsb_last = mis, hit = -1;   // ROUTE 1: run start of first-class bytes (now / at `last`), last hit
     int state = idle;
-    bool fin = !live || t.len == 0;
+    const bool skipped = lay.split > 0 && t.len >= lay.split;   // k_req_wave's text
+    bool fin = !live || t.len == 0 || skipped;
     int64_t wo = (MODE == STEP_EMIT && live) ? prefix[i] : 0;
     if (MODE == STEP_EMIT && counts) {   // after STEP_SLOTS: only texts that overflowed their slots
       if (live && counts[i] <= kStepSlots) fin = true;
@@ -365,7 +369,7 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_wstep(DevPlan p, const uint8_
       if (__all(fin)) break;
     }
 #undef MRX_WS_LOAD
-    if (live) {
+    if (live && !skipped) {
       if (MODE == STEP_COUNT || MODE == STEP_SLOTS) counts[i] = k;
       if (MODE == STEP_SEARCH) { out_s[i] = rs; out_e[i] = re; }
     }
@@ -450,6 +454,7 @@ __global__ __launch_bounds__(64 * kRqWaves) void k_req_wave(DevPlan p, const uin
   const uint32_t req = (uint32_t)p.required_byte * 0x01010101u;
   for (int64_t i = (int64_t)blockIdx.x * kRqWaves + wave; i < n; i += (int64_t)gridDim.x * kRqWaves) {
     const Text t = lay.text(i);
+    if (lay.split > 0 && t.len < lay.split) continue;                       // k_wstep's text
     if (MODE == STEP_EMIT && counts && counts[i] <= kStepSlots) continue;   // its spans are in the slot row
     int k = 0, rs = -1, re = -1;
     if (t.len > 0) {
@@ -1761,14 +1766,23 @@ int grid_for(int64_t n, int block) {
 // The stepper's routes: one wavefront per text (k_req_wave) when the texts are long or too few to
 // fill the device with one lane each, one lane per text (k_wstep) otherwise.  The average length
 // decides; a CSR batch's byte count lives on the device, so that costs one 8-byte read-back.
-int req_wave_pays(const Layout& lay, int64_t n, bool req_route, hipStream_t s, bool* out) {
+int req_wave_pays(const Layout& lay, int64_t n, bool req_route, hipStream_t s, bool* out, int* split = nullptr) {
   *out = false;
+  if (split) *split = 0;
   if (g_long_text_mode) { *out = g_long_text_mode == 1; return MRX_OK; }
   if (n <= 0) return MRX_OK;
-  int64_t total = 0;
+  int64_t total = 0, max_len = 0;
   if (lay.offsets) {
+    int32_t* d_max = nullptr;
+    int32_t m = 0;
+    HIP_TRY(scratch_alloc((void**)&d_max, sizeof(int32_t), s));
+    HIP_TRY(hipMemsetAsync(d_max, 0, sizeof(int32_t), s));
+    hipLaunchKernelGGL(k_max_len, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, lay.offsets, n, d_max);
+    HIP_TRY(hipMemcpyAsync(&m, d_max, sizeof m, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(&total, lay.offsets + n, sizeof total, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(scratch_free(d_max, s));
+    max_len = m;
   } else {
     total = n * (lay.lens ? lay.stride : (int64_t)lay.len);
   }
@@ -1778,6 +1792,9 @@ int req_wave_pays(const Layout& lay, int64_t n, bool req_route, hipStream_t s, b
   // candidates (every byte a walk may start on) it does several times the work of the serial loop and
   // only pays while one lane per text would leave most of the device idle.
   *out = req_route ? (avg >= 2048 || (avg >= 512 && n <= 32768)) : (avg >= 1024 && n <= 65536);
+  // a ragged batch with a few texts far longer than the rest: those go to the wavefront kernel, the
+  // others keep one lane each
+  if (!*out && split && max_len >= 32768 && max_len >= 8 * avg) *split = 16384;
   return MRX_OK;
 }
 int reqwave_grid(int64_t n) {
@@ -1883,7 +1900,10 @@ int run_match(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d_s, i
       !(h->hp.dev.flags & PF_PREFILTER)) {   // (the memchr prefilter changes match_next, matcher.mojo:784-796)
     bool wave = false;
     const bool big = (h->hp.dev.flags & PF_STEP_BIG) != 0;   // only the wavefront kernel has its table form
-    if (int rc = req_wave_pays(lay, n, false, s, &wave)) return rc;
+    int split = 0;
+    if (int rc = req_wave_pays(lay, n, false, s, &wave, big ? nullptr : &split)) return rc;
+    Layout lay2 = lay;
+    lay2.split = split;
     if (big && !wave) {   // many short texts: the literal restatement, one lane per text
       hipLaunchKernelGGL(k_match<OP>, dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s, h->hp.dev,
                          h->d_blob, lay, n, d_s, d_e, d_flag);
@@ -1900,9 +1920,15 @@ int run_match(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d_s, i
       g_last_kernel = "k_req_wave_search";
     } else {
     hipLaunchKernelGGL((k_wstep<STEP_SEARCH, 0>), dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_table_bytes(h->hp.dev.nstates), s, h->hp.dev,
-                       h->d_blob, lay, n, (int32_t*)nullptr, (const int64_t*)nullptr, (int32_t*)nullptr,
+                       h->d_blob, lay2, n, (int32_t*)nullptr, (const int64_t*)nullptr, (int32_t*)nullptr,
                        (int64_t)0, d_s, d_e);
     g_last_kernel = "k_step_search";
+    if (split > 0) {   // the few very long texts of the batch
+      hipLaunchKernelGGL((k_req_wave<STEP_SEARCH, 0>), dim3(reqwave_grid(n)), dim3(64 * kRqWaves),
+                         reqwave_table_bytes(h->hp.dev.nstates), s, h->hp.dev, h->d_blob, lay2, n, (int32_t*)nullptr,
+                         (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0, d_s, d_e);
+      g_last_kernel = "k_step_search+k_req_wave_search";
+    }
     }
   } else {
     hipLaunchKernelGGL(k_match<OP>, dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s, h->hp.dev,
@@ -2125,6 +2151,8 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
                  (match_next_sequence ? ((p.flags & PF_STEP_SEARCH) && !(p.flags & PF_PREFILTER))
                                       : (p.flags & (PF_STEPPABLE | PF_STEP_REQ)) != 0);
   bool req_wave = false;   // the stepper's route on the wavefront-per-text kernel
+  int step_split = 0;      // > 0: lane kernel for texts below this length AND wavefront kernel for the rest
+  Layout lay2 = lay;       // lay + that split
   EvRec* d_recs = nullptr;
   int32_t* d_nrecs = nullptr;
   int64_t* d_wbase = nullptr;
@@ -2164,7 +2192,9 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
       tm.stop();
     } else {
       if (step_ok)
-        if (int rc = req_wave_pays(lay, n, use_req_route, s, &req_wave)) return rc;
+        if (int rc = req_wave_pays(lay, n, use_req_route, s, &req_wave, (p.flags & PF_STEP_BIG) ? nullptr : &step_split))
+          return rc;
+      lay2.split = step_split;
       // big tables: only the wavefront kernel has their form; many short texts stay on the literal restatement
       if ((p.flags & PF_STEP_BIG) && !req_wave) step_ok = false;
       ScanTimer tm(s);
@@ -2173,20 +2203,27 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
         if (req_wave)
           MRX_REQWAVE_LAUNCH(STEP_SLOTS, h, lay, n, d_counts, (const int64_t*)nullptr, d_slots, (int64_t)0, s);
         else
+        {
         MRX_WSTEP_LAUNCH(STEP_SLOTS, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_table_bytes(h->hp.dev.nstates), s, p,
-                           h->d_blob, lay, n, d_counts, (const int64_t*)nullptr, d_slots, (int64_t)0,
+                           h->d_blob, lay2, n, d_counts, (const int64_t*)nullptr, d_slots, (int64_t)0,
                            (int32_t*)nullptr, (int32_t*)nullptr);
+        if (step_split > 0)
+          MRX_REQWAVE_LAUNCH(STEP_SLOTS, h, lay2, n, d_counts, (const int64_t*)nullptr, d_slots, (int64_t)0, s);
+        }
       } else if (step_ok && req_wave)
         MRX_REQWAVE_LAUNCH(STEP_COUNT, h, lay, n, d_counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0, s);
-      else if (step_ok)
+      else if (step_ok) {
         MRX_WSTEP_LAUNCH(STEP_COUNT, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_table_bytes(h->hp.dev.nstates), s, p,
-                           h->d_blob, lay, n, d_counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0,
+                           h->d_blob, lay2, n, d_counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0,
                            (int32_t*)nullptr, (int32_t*)nullptr);
-      else
+        if (step_split > 0)
+          MRX_REQWAVE_LAUNCH(STEP_COUNT, h, lay2, n, d_counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0, s);
+      } else
         hipLaunchKernelGGL(k_findall<FA_COUNT>, dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s,
                            p, h->d_blob, lay, n, d_counts, (const int64_t*)nullptr, (int32_t*)nullptr,
                            (int64_t)0);
-      g_last_kernel = req_wave ? "k_req_wave" : step_ok ? "k_step_count" : "k_findall_count";
+      g_last_kernel = req_wave ? "k_req_wave" : step_ok ? (step_split > 0 ? "k_step_count+k_req_wave" : "k_step_count")
+                                                        : "k_findall_count";
       HIP_TRY(hipGetLastError());
       tm.stop();
     }
@@ -2228,10 +2265,12 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
         // wavefronts without an overflowing text leave at once
         if (req_wave)
           MRX_REQWAVE_LAUNCH(STEP_EMIT, h, lay, n, d_counts, d_prefix, d_spans, span_cap, s);
-        else
+        else {
         MRX_WSTEP_LAUNCH(STEP_EMIT, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_table_bytes(h->hp.dev.nstates), s, p, h->d_blob,
-                           lay, n, d_counts, d_prefix, d_spans, span_cap, (int32_t*)nullptr,
+                           lay2, n, d_counts, d_prefix, d_spans, span_cap, (int32_t*)nullptr,
                            (int32_t*)nullptr);
+        if (step_split > 0) MRX_REQWAVE_LAUNCH(STEP_EMIT, h, lay2, n, d_counts, d_prefix, d_spans, span_cap, s);
+        }
       } else
         hipLaunchKernelGGL(k_findall<FA_EMIT>, dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s, p,
                            h->d_blob, lay, n, (int32_t*)nullptr, d_prefix, d_spans, span_cap);
@@ -2579,17 +2618,25 @@ static int run_count_any(const mrx_handle* h, const Layout& lay, int64_t n, int3
   } else {
     const bool use_req_route = (h->hp.dev.flags & PF_STEP_REQ) != 0;
     bool req_wave = false;
+    int split = 0;
     if (g_force_generic < 2 && (h->hp.dev.flags & (PF_STEPPABLE | PF_STEP_REQ)))
-      if (int rc = req_wave_pays(lay, n, use_req_route, s, &req_wave)) return rc;
+      if (int rc = req_wave_pays(lay, n, use_req_route, s, &req_wave, (h->hp.dev.flags & PF_STEP_BIG) ? nullptr : &split))
+        return rc;
+    Layout lay2 = lay;
+    lay2.split = split;
     const bool big_lane = (h->hp.dev.flags & PF_STEP_BIG) && !req_wave;   // -> literal restatement
     if (req_wave) {
       MRX_REQWAVE_LAUNCH(STEP_COUNT, h, lay, n, counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0, s);
       g_last_kernel = "k_req_wave";
     } else if (g_force_generic < 2 && !big_lane && (h->hp.dev.flags & (PF_STEPPABLE | PF_STEP_REQ))) {
       MRX_WSTEP_LAUNCH(STEP_COUNT, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_table_bytes(h->hp.dev.nstates), s, h->hp.dev,
-                         h->d_blob, lay, n, counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0,
+                         h->d_blob, lay2, n, counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0,
                          (int32_t*)nullptr, (int32_t*)nullptr);
       g_last_kernel = "k_step_count";
+      if (split > 0) {
+        MRX_REQWAVE_LAUNCH(STEP_COUNT, h, lay2, n, counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0, s);
+        g_last_kernel = "k_step_count+k_req_wave";
+      }
     } else {
       hipLaunchKernelGGL(k_findall<FA_COUNT>, dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s,
                          h->hp.dev, h->d_blob, lay, n, counts, (const int64_t*)nullptr, (int32_t*)nullptr,

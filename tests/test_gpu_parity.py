@@ -916,6 +916,42 @@ def test_outliers_of_a_ragged_batch_are_cut_into_pieces():
     assert [tuple(x) for x in sp[a:z].cpu().numpy().tolist()] == O.findall(pat, t)
 
 
+@pytest.mark.parametrize("pat", [b"\\d{3}-\\d{3}-\\d{4}", b"\\w+\\d{2}", b"(foo|foobar)x", b"[a-z]+@[a-z]+"])
+def test_outliers_of_a_ragged_batch_on_the_stepper(pat):
+    """The stepper's routes on a ragged batch with a few very long texts: the lane-per-text kernel takes
+    the short ones, the wavefront-per-text kernel the long ones (Layout::split), in the same call."""
+    _need_gpu()
+    rx = M.compile_regex(pat)
+    if "step_search=1" not in rx.describe():
+        pytest.skip("not a stepper plan")
+    lib = M.load_library()
+    rng = np.random.default_rng(zlib.crc32(pat) + 9)
+    al = np.frombuffer(b"abfox0123456789@.- " + bytes(c for c in pat if chr(c).isalnum()) * 2, dtype=np.uint8)
+    lens = rng.integers(0, 100, size=140000)
+    for pos, ln in ((0, 90000), (77777, 40000), (139999, 150000)):
+        lens[pos] = ln
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    data = rng.choice(al, size=int(offsets[-1])).astype(np.uint8)
+    for o in (offsets[0] + 500, offsets[77777] + 20000):      # something to find in the long texts
+        data[o:o + 30] = np.frombuffer(b" 555-123-4567 foobarx ab12 a@b", dtype=np.uint8)
+    b = M.DeviceBatch(torch.from_numpy(data).cuda(), torch.from_numpy(offsets).cuda())
+    with no_streaming_kernels():
+        pre, sp, tot = rx._dev_findall(b)
+        assert lib.mrx_last_kernel_name() == b"k_step_count+k_req_wave"
+        cnt = rx.count(b)
+        assert lib.mrx_last_kernel_name() == b"k_step_count+k_req_wave"
+        ss, se = rx.match_next(b)
+        assert lib.mrx_last_kernel_name() == b"k_step_search+k_req_wave_search"
+    with no_streaming_kernels(), long_text_kernels(2):
+        pre2, sp2, tot2 = rx._dev_findall(b)
+        assert lib.mrx_last_kernel_name() == b"k_step_count"
+        cnt2 = rx.count(b)
+        ws, we = rx.match_next(b)
+    assert tot == tot2 and torch.equal(pre, pre2) and torch.equal(sp[:tot], sp2[:tot2])
+    assert torch.equal(cnt, cnt2) and torch.equal(ss, ws) and torch.equal(se, we)
+    assert int(cnt[0].item()) >= 1 and int(cnt[77777].item()) >= 1
+
+
 @pytest.mark.parametrize("pat", EXACT_LITERALS)
 def test_exact_literal_kmp_streaming(pat):
     """HybridMatcher's exact-literal bypass (matcher.mojo:768-781, 815-847) on the streaming kernel:
