@@ -124,3 +124,25 @@ def test_arrow_large_binary_is_the_packed_batch_form():
     assert np.array_equal(sl.offsets.numpy(), o2) and np.array_equal(sl.data.numpy(), d2)
     st = M.DeviceBatch.from_arrow(pa.array(["ab12", "cd"]), device="cpu")   # plain string array
     assert st.offsets.tolist() == [0, 4, 6] and bytes(st.data.numpy().tobytes()) == b"ab12cd"
+
+
+def test_synchronising_bytes_and_long_text_plan_flags():
+    """Plan facts the long-text kernels rely on (mrx_plan.cpp): which bytes take every state of the
+    search automaton to the same state with the same start; the KMP automaton with restart for a
+    literal whose prefix is also a suffix; the class-indexed stepper table beyond 96 states."""
+    import re
+    from mojo_regex_amd import api as M
+    from mojo_regex_amd import bench_suite as B
+
+    def line(p, key):
+        return re.search(key + r"=[^\n]*", M.CompiledRegex(p).describe()).group(0)
+
+    assert "sync_bytes=220" in line(b"[a-z]+\\d+", "device.streamable")      # everything outside [a-z0-9]
+    assert "sync_bytes=246" in line(b"\\d+", "device.streamable")            # every non-digit
+    assert "sync_bytes=253" in line(b"hello", "device.streamable")           # non-literal bytes and 'h' (always prefix length 1)
+    assert "sync_bytes=255" in line(b"a{2,4}", "device.streamable")
+    s = line(b"555-123-4567", "device.streamable")                             # "5" is prefix and suffix: KMP with restart
+    assert s.startswith("device.streamable=yes") and "st_nstates=13" in s
+    assert line(b"abab", "device.streamable").startswith("device.streamable=yes")
+    assert "big_table=1" in line(B.NANPA_PATTERN, "device.steppable")          # 154 states > 96
+    assert "big_table" not in line(b"\\w+\\d{2}", "device.steppable")
