@@ -45,6 +45,20 @@ struct Layout {  // where text i lives
   // Stepper kernels only (ragged batches with a few very long texts): k_wstep leaves texts of at least
   // `split` bytes to k_req_wave, which in turn skips the shorter ones; 0 = no split
   int32_t split = 0;
+  // k_req_wave<STEP_SLOTS / STEP_EMIT> and k_slots_gather_wide: slot rows sized by the text (len / 8 + 32
+  // spans, see slot_row()) instead of kStepSlots, so that long texts rarely need the second walk
+  int32_t wide_slots = 0;
+  // first slot of text i's row and the row's capacity (wide rows)
+  __device__ __forceinline__ int64_t slot_row(int64_t i, int* cap) const {
+    if (offsets) {
+      const int64_t a = (offsets[i] >> 3) + 32 * i, b = (offsets[i + 1] >> 3) + 32 * (i + 1);
+      *cap = (int)(b - a);
+      return a;
+    }
+    const int64_t row = (int64_t)((lens ? stride : (int64_t)len) >> 3) + 32;
+    *cap = (int)row;
+    return i * row;
+  }
   __device__ __forceinline__ Text text(int64_t i) const {
     if (offsets) {
       const int64_t a = offsets[i], b = offsets[i + 1];
@@ -455,7 +469,10 @@ __global__ __launch_bounds__(64 * kRqWaves) void k_req_wave(DevPlan p, const uin
   for (int64_t i = (int64_t)blockIdx.x * kRqWaves + wave; i < n; i += (int64_t)gridDim.x * kRqWaves) {
     const Text t = lay.text(i);
     if (lay.split > 0 && t.len < lay.split) continue;                       // k_wstep's text
-    if (MODE == STEP_EMIT && counts && counts[i] <= kStepSlots) continue;   // its spans are in the slot row
+    int slot_cap = kStepSlots;
+    int64_t slot0 = i * kStepSlots;
+    if ((MODE == STEP_EMIT || MODE == STEP_SLOTS) && lay.wide_slots) slot0 = lay.slot_row(i, &slot_cap);
+    if (MODE == STEP_EMIT && counts && counts[i] <= slot_cap) continue;     // its spans are in the slot row
     int k = 0, rs = -1, re = -1;
     if (t.len > 0) {
       const uintptr_t addr = (uintptr_t)t.ptr;
@@ -528,7 +545,7 @@ __global__ __launch_bounds__(64 * kRqWaves) void k_req_wave(DevPlan p, const uin
               if (wo + k < span_cap) *(int2*)(spans + 2 * (wo + k)) = make_int2(cs - mis, ce - mis);
             }
             if (MODE == STEP_SLOTS) {
-              if (k < kStepSlots) *(int2*)(spans + 2 * (i * kStepSlots + k)) = make_int2(cs - mis, ce - mis);
+              if (k < slot_cap) *(int2*)(spans + 2 * (slot0 + k)) = make_int2(cs - mis, ce - mis);
             }
           }
         };
@@ -597,6 +614,24 @@ __global__ __launch_bounds__(64 * kRqWaves) void k_req_wave(DevPlan p, const uin
     }
     if (lane == 0 && (MODE == STEP_COUNT || MODE == STEP_SLOTS)) counts[i] = k;
     if (lane == 0 && MODE == STEP_SEARCH) { out_s[i] = rs; out_e[i] = re; }
+  }
+}
+
+// the same for wide rows (Layout::wide_slots): one wavefront per text
+__global__ __launch_bounds__(kBlock) void k_slots_gather_wide(Layout lay, int64_t n, const int32_t* __restrict__ counts,
+                                                              const int64_t* __restrict__ prefix,
+                                                              const int32_t* __restrict__ slots,
+                                                              int32_t* __restrict__ spans, int64_t span_cap) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  for (int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); i < n; i += nwaves) {
+    int cap;
+    const int64_t row = lay.slot_row(i, &cap);
+    const int c = counts[i];
+    if (c > cap) continue;   // re-walked by k_req_wave<STEP_EMIT>
+    const int64_t w = prefix[i];
+    for (int j = lane; j < c; j += 64)
+      if (w + j < span_cap) *(int2*)(spans + 2 * (w + j)) = *(const int2*)(slots + 2 * (row + j));
   }
 }
 
@@ -1220,6 +1255,11 @@ __device__ __forceinline__ int64_t virt_text_of(const int64_t* __restrict__ vfir
   return lo;
 }
 
+// texts of one length: the same number of pieces each, no prefix sums needed
+__global__ __launch_bounds__(kBlock) void k_virt_uniform(int64_t n, int64_t cpt, int64_t* __restrict__ vfirst) {
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t <= n; t += (int64_t)gridDim.x * blockDim.x)
+    vfirst[t] = t * cpt;
+}
 __global__ __launch_bounds__(kBlock) void k_virt_count(Layout lay, int64_t n, int C, int32_t* __restrict__ cnt) {
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
     const int len = lay.text(t).len;
@@ -2042,18 +2082,24 @@ int pieces_prepare(const mrx_handle* h, const Layout& lay, int64_t n, hipStream_
     if (C >= max_len) return MRX_OK;
   }
   // pieces per text -> prefix sums -> how many there are
-  int32_t* d_cnt = nullptr;
-  int64_t* d_tot = nullptr;
-  HIP_TRY(scratch_alloc((void**)&d_cnt, sizeof(int32_t) * n, s));
-  HIP_TRY(scratch_alloc((void**)&d_tot, sizeof(int64_t), s));
   HIP_TRY(scratch_alloc((void**)&pc->vfirst, sizeof(int64_t) * (n + 1), s));
-  hipLaunchKernelGGL(k_virt_count, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, lay, n, C, d_cnt);
-  if (int rc = device_scan<int32_t>(d_cnt, n, pc->vfirst, d_tot, s)) return rc;
   int64_t nv = 0;
-  HIP_TRY(hipMemcpyAsync(&nv, d_tot, sizeof nv, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
-  HIP_TRY(scratch_free(d_cnt, s));
-  HIP_TRY(scratch_free(d_tot, s));
+  if (!lay.offsets && !lay.lens) {   // one length: nothing to count, nothing to read back
+    const int64_t cpt = (max_len + C - 1) / C;
+    nv = n * cpt;
+    hipLaunchKernelGGL(k_virt_uniform, dim3(grid_for(n + 1, kBlock)), dim3(kBlock), 0, s, n, cpt, pc->vfirst);
+  } else {
+    int32_t* d_cnt = nullptr;
+    int64_t* d_tot = nullptr;
+    HIP_TRY(scratch_alloc((void**)&d_cnt, sizeof(int32_t) * n, s));
+    HIP_TRY(scratch_alloc((void**)&d_tot, sizeof(int64_t), s));
+    hipLaunchKernelGGL(k_virt_count, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, lay, n, C, d_cnt);
+    if (int rc = device_scan<int32_t>(d_cnt, n, pc->vfirst, d_tot, s)) return rc;
+    HIP_TRY(hipMemcpyAsync(&nv, d_tot, sizeof nv, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(scratch_free(d_cnt, s));
+    HIP_TRY(scratch_free(d_tot, s));
+  }
   if (nv <= n || nv > (int64_t(1) << 24)) {   // nothing to cut after all, or an absurd number of pieces
     HIP_TRY(scratch_free(pc->vfirst, s));
     pc->vfirst = nullptr;
@@ -2199,9 +2245,22 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
       if ((p.flags & PF_STEP_BIG) && !req_wave) step_ok = false;
       ScanTimer tm(s);
       if (step_ok && span_cap > 0) {
+        if (req_wave) {
+          // long texts: rows of len / 8 + 32 slots (as many bytes again as the batch) -- the second walk
+          // is then only for texts with a match every 8 bytes
+          int64_t bytes = 0;
+          if (lay.offsets) {
+            HIP_TRY(hipMemcpyAsync(&bytes, lay.offsets + n, sizeof bytes, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+          } else {
+            bytes = n * (lay.lens ? lay.stride : (int64_t)lay.len);
+          }
+          lay2.wide_slots = 1;
+          HIP_TRY(scratch_alloc((void**)&d_slots, sizeof(int32_t) * 2 * (size_t)(bytes / 8 + 32 * n + 64), s));
+        } else
         HIP_TRY(scratch_alloc((void**)&d_slots, sizeof(int32_t) * 2 * kStepSlots * (size_t)n, s));
         if (req_wave)
-          MRX_REQWAVE_LAUNCH(STEP_SLOTS, h, lay, n, d_counts, (const int64_t*)nullptr, d_slots, (int64_t)0, s);
+          MRX_REQWAVE_LAUNCH(STEP_SLOTS, h, lay2, n, d_counts, (const int64_t*)nullptr, d_slots, (int64_t)0, s);
         else
         {
         MRX_WSTEP_LAUNCH(STEP_SLOTS, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_table_bytes(h->hp.dev.nstates), s, p,
@@ -2260,11 +2319,15 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
       // spans were written by k_decode above
     } else {
       if (step_ok) {
+        if (lay2.wide_slots)
+          hipLaunchKernelGGL(k_slots_gather_wide, dim3(grid_for(n * 64, kBlock)), dim3(kBlock), 0, s, lay2, n, d_counts,
+                             d_prefix, d_slots, d_spans, span_cap);
+        else
         hipLaunchKernelGGL(k_slots_gather, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, n, d_counts, d_prefix,
                            d_slots, d_spans, span_cap);
         // wavefronts without an overflowing text leave at once
         if (req_wave)
-          MRX_REQWAVE_LAUNCH(STEP_EMIT, h, lay, n, d_counts, d_prefix, d_spans, span_cap, s);
+          MRX_REQWAVE_LAUNCH(STEP_EMIT, h, lay2, n, d_counts, d_prefix, d_spans, span_cap, s);
         else {
         MRX_WSTEP_LAUNCH(STEP_EMIT, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_table_bytes(h->hp.dev.nstates), s, p, h->d_blob,
                            lay2, n, d_counts, d_prefix, d_spans, span_cap, (int32_t*)nullptr,
