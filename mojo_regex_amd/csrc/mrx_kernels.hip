@@ -45,17 +45,17 @@ struct Layout {  // where text i lives
   // Stepper kernels only (ragged batches with a few very long texts): k_wstep leaves texts of at least
   // `split` bytes to k_req_wave, which in turn skips the shorter ones; 0 = no split
   int32_t split = 0;
-  // k_req_wave<STEP_SLOTS / STEP_EMIT> and k_slots_gather_wide: slot rows sized by the text (len / 8 + 32
-  // spans, see slot_row()) instead of kStepSlots, so that long texts rarely need the second walk
+  // k_wstep / k_req_wave<STEP_SLOTS / STEP_EMIT> and k_slots_gather_wide: slot rows sized by the text
+  // (len / 4 + 32 spans, see slot_row()) instead of kStepSlots, so that long texts rarely need the second walk
   int32_t wide_slots = 0;
   // first slot of text i's row and the row's capacity (wide rows)
   __device__ __forceinline__ int64_t slot_row(int64_t i, int* cap) const {
     if (offsets) {
-      const int64_t a = (offsets[i] >> 3) + 32 * i, b = (offsets[i + 1] >> 3) + 32 * (i + 1);
+      const int64_t a = (offsets[i] >> 2) + 32 * i, b = (offsets[i + 1] >> 2) + 32 * (i + 1);
       *cap = (int)(b - a);
       return a;
     }
-    const int64_t row = (int64_t)((lens ? stride : (int64_t)len) >> 3) + 32;
+    const int64_t row = (int64_t)((lens ? stride : (int64_t)len) >> 2) + 32;
     *cap = (int)row;
     return i * row;
   }
@@ -270,8 +270,11 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_wstep(DevPlan p, const uint8_
     const bool skipped = lay.split > 0 && t.len >= lay.split;   // k_req_wave's text
     bool fin = !live || t.len == 0 || skipped;
     int64_t wo = (MODE == STEP_EMIT && live) ? prefix[i] : 0;
+    int slot_cap = kStepSlots;           // my slot row (wide rows: sized by the text, Layout::slot_row)
+    int64_t slot0 = i * kStepSlots;
+    if ((MODE == STEP_EMIT || MODE == STEP_SLOTS) && lay.wide_slots && live) slot0 = lay.slot_row(i, &slot_cap);
     if (MODE == STEP_EMIT && counts) {   // after STEP_SLOTS: only texts that overflowed their slots
-      if (live && counts[i] <= kStepSlots) fin = true;
+      if (live && counts[i] <= slot_cap) fin = true;
       if (__all(fin)) continue;
     }
     if (MODE == STEP_SLOTS) wo = 0;
@@ -318,7 +321,7 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_wstep(DevPlan p, const uint8_
           }
           if (MODE == STEP_SLOTS) {
             if (matched) {
-              if (wo < kStepSlots) *(int2*)(spans + 2 * (i * kStepSlots + wo)) = make_int2(start - mis, last - mis);
+              if (wo < slot_cap) *(int2*)(spans + 2 * (slot0 + wo)) = make_int2(start - mis, last - mis);
               ++wo;
             }
           }
@@ -347,7 +350,7 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_wstep(DevPlan p, const uint8_
         }
         if (MODE == STEP_SLOTS) {   // spans = slot rows [n][kStepSlots][2]
           if (matched) {
-            if (wo < kStepSlots) *(int2*)(spans + 2 * (i * kStepSlots + wo)) = make_int2(start - mis, last - mis);
+            if (wo < slot_cap) *(int2*)(spans + 2 * (slot0 + wo)) = make_int2(start - mis, last - mis);
             ++wo;
           }
         }
@@ -2246,8 +2249,8 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
       ScanTimer tm(s);
       if (step_ok && span_cap > 0) {
         if (req_wave) {
-          // long texts: rows of len / 8 + 32 slots (as many bytes again as the batch) -- the second walk
-          // is then only for texts with a match every 8 bytes
+          // long texts: rows of len / 4 + 32 slots (twice the bytes of the batch) -- the second walk
+          // is then only for texts with a match every 4 bytes
           int64_t bytes = 0;
           if (lay.offsets) {
             HIP_TRY(hipMemcpyAsync(&bytes, lay.offsets + n, sizeof bytes, hipMemcpyDeviceToHost, s));
@@ -2256,7 +2259,12 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
             bytes = n * (lay.lens ? lay.stride : (int64_t)lay.len);
           }
           lay2.wide_slots = 1;
-          HIP_TRY(scratch_alloc((void**)&d_slots, sizeof(int32_t) * 2 * (size_t)(bytes / 8 + 32 * n + 64), s));
+          HIP_TRY(scratch_alloc((void**)&d_slots, sizeof(int32_t) * 2 * (size_t)(bytes / 4 + 32 * n + 64), s));
+        } else if (!lay.offsets && step_split == 0 && (lay.lens ? lay.stride : (int64_t)lay.len) >= 2048) {
+          // one lane per text, but texts long enough to hold more than kStepSlots matches as a rule
+          lay2.wide_slots = 1;
+          HIP_TRY(scratch_alloc((void**)&d_slots,
+                                sizeof(int32_t) * 2 * (size_t)(n * ((lay.lens ? lay.stride : (int64_t)lay.len) / 4 + 32) + 64), s));
         } else
         HIP_TRY(scratch_alloc((void**)&d_slots, sizeof(int32_t) * 2 * kStepSlots * (size_t)n, s));
         if (req_wave)

@@ -1280,7 +1280,7 @@ def test_stepper_one_wavefront_per_text(pat):
     al = b"abfoxHELOWRDT0123456789@.-() " + bytes(c for c in pat if chr(c).isalnum()) * 2
     texts = (_random_texts(rng, 50, 90, al) + _random_texts(rng, 20, 5000, al) + _random_texts(rng, 4, 30000, al) + [
         b"", b"8", b"foo", b"5" * 9000 + b"-" + b"6" * 3000, b"AB" * 4000 + b"12345 " + b"hello123ab" * 500,
-        b"foo" * 700, b"a@b " * 600, b"x1.5" * 500,   # a match every 3-4 bytes: more than a wide slot row holds
+        b"foo" * 700, b"a@b " * 600, b"x1.5" * 500, b"x1 " * 900,   # a match every 3-4 bytes: more than a wide slot row holds
         (b"(555) 123-4567 8005551234 555-123-4567 2125551234 foobar x1.5 ABC1234 world456cd a@b " * 150)])
     with no_streaming_kernels(), long_text_kernels(1):
         got = rx.findall_lists(texts)
@@ -1304,7 +1304,8 @@ def test_stepper_one_wavefront_per_text(pat):
 
 
 @pytest.mark.parametrize("pat", [b"\\d+(\\.\\d+)?", b"\\w+\\d{2}", b"[a-z]+@[a-z]+", b"(foo|foobar)"])
-@pytest.mark.parametrize("n,pitch,var", [(130, 256, True), (70, 50, True), (64, 1024, False), (3, 7, True)])
+@pytest.mark.parametrize("n,pitch,var", [(130, 256, True), (70, 50, True), (64, 1024, False), (3, 7, True),
+                                         (40, 2304, True), (33, 2051, False)])   # >= 2 KiB: slot rows sized by the text
 def test_stepper_on_fixed_pitch_batches(pat, n, pitch, var):
     """k_wstep's frame form on fixed-pitch batches (aligned and not, with and without lens)."""
     _need_gpu()
