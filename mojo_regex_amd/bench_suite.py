@@ -194,19 +194,3 @@ def case_rows(case: Case, rows: int) -> List[bytes]:
         out.append(t[k:] + t[:k])
     return out
 
-
-def oracle_answer(O, case: Case, text: bytes):
-    """The case's operation on one text through the oracle module `O` (oracle/mrx_ref/hybrid.py);
-    only tests and tools pass one in."""
-    rx = O.compile_regex(case.pattern)
-    if case.op == "match_first":
-        return rx.match_first(text)
-    if case.op == "search":
-        return rx.match_next(text, 0)
-    if case.op == "findall":
-        return rx.match_all(text)
-    if case.op == "is_match":
-        return rx.is_match(text)
-    if case.op == "sub":
-        return O.sub(case.pattern, case.repl, text, case.count)
-    raise ValueError(case.op)

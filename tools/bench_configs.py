@@ -70,20 +70,6 @@ def main():
                "search_GBps": round(nbytes / t_search / 1e9, 1),
                "count_GBps": round(nbytes / t_count / 1e9, 1),
                "match_first_ms": round(t_first * 1e3, 3)}
-        if name.startswith("c2 "):
-            # match_first's algorithmic bytes are data dependent -- sum of
-            # min(len, bytes consumed + 1) -- so they come from the oracle's C port (sample: first
-            # 65536 texts), and the rate is quoted against them as well as against the whole batch
-            sys.path.insert(0, os.path.join(ROOT, "oracle"))
-            import numpy as np
-            from mrx_ref.cfast import CDfa
-            m = 1 << 16
-            host = d[:m].cpu().numpy()
-            offs = np.arange(0, (m + 1) * L, L, dtype=np.int64)
-            alg = CDfa(pat).match_first_bytes(host.reshape(-1), offs)
-            frac = alg / float(m * L)
-            row["match_first_algorithmic_fraction"] = round(frac, 4)
-            row["match_first_algorithmic_GBps"] = round(frac * nbytes / t_first / 1e9, 1)
         out.append(row)
         print(json.dumps(row), flush=True)
         del d, batch, prefix, spans

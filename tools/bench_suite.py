@@ -4,8 +4,8 @@
 Each case's text becomes a batch: n rotations of it (row i = the text rotated by 37 i bytes), n chosen
 so that the batch is about 256 MiB (at most 2^20 texts), fixed pitch, device resident.  The case's
 operation is enqueued REPS times and timed as a whole.  Printed per case: which kernel ran, GB/s of
-input, ns per text, and for scale the oracle's time for the one original text on one host core
-(Python + C restatement -- the checker, not a tuned CPU engine).
+input, ns per text.  (Parity of every case is tests/test_gpu_bench_suite.py's business; nothing here
+touches the oracle.)
 usage: python tools/bench_suite.py [name-prefix]
 """
 import json
@@ -15,7 +15,6 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import torch  # noqa: E402
 import mojo_regex_amd as M  # noqa: E402
 from mojo_regex_amd import bench_suite as B  # noqa: E402
@@ -46,18 +45,10 @@ def main():
     lib = M.load_library()
     lib.mrx_debug_long_text_kernels(int(os.environ.get("MRX_LONG_TEXT_MODE", "0")))   # 1 always, 2 never (A/B runs)
     only = sys.argv[1] if len(sys.argv) > 1 else ""
-    from mrx_ref import hybrid as O
-    from mrx_ref import UnsupportedByOracle
     for case in B.CASES:
         if not case.name.startswith(only):
             continue
         row = {"case": case.name, "op": case.op, "pattern": case.pattern.decode()[:60], "text_bytes": len(case.text)}
-        try:
-            t0 = time.perf_counter()
-            B.oracle_answer(O, case, case.text)
-            row["oracle_us_per_text_1core"] = round((time.perf_counter() - t0) * 1e6, 1)
-        except UnsupportedByOracle:
-            row["oracle_us_per_text_1core"] = None
         rx = M.compile_regex(case.pattern)
         row["engine"] = rx.get_engine_type()
         batch, n, L = make_batch(case.text, case.op in ("sub", "is_match"))
