@@ -716,6 +716,14 @@ struct EvRec {   // 16 bytes
   uint32_t meta;     // (lane << 26) | matches of this text before this group
 };
 constexpr uint32_t kRecBeforeMask = (1u << 26) - 1u;
+// REC32: fixed-pitch batches of texts up to kRec32MaxLen bytes.  Positions fit 16 bits, so one 16-byte
+// record carries the event words of TWO adjacent groups (32 text bytes): {F of the even group, F of the
+// odd group, start | (pos_base + 16) << 16, meta}, start / pos_base / matches-before taken at the even
+// group.  Fewer records for the same events: 13 instead of 19 per KiB on the bench workload.
+#ifndef MRX_REC32_MAX_LEN
+#define MRX_REC32_MAX_LEN 65500
+#endif
+constexpr int kRec32MaxLen = MRX_REC32_MAX_LEN;
 
 __host__ __device__ inline int64_t rec_row_len(int64_t max_len) { return max_len / 16 + 2; }
 // CSR batches: wavefront w's record region.  A text yields at most len/16 + 3 records (its frame
@@ -746,7 +754,7 @@ enum { ST_RECORDS = 0, ST_COUNT = 1, ST_SEARCH = 2, ST_FIRST = 3 };
 // its text), so from there on the walk is the one the whole text's walk takes.  The events of its
 // first vskip[v] & 0x7FFFFFFF bytes belong to the piece before it and are dropped; bit 31 of vskip
 // marks the last piece of a text (the only one that may end a match at the end of the text).
-template <int MODE, int CH, int AUTO, int CSR, int VIRT = 0>
+template <int MODE, int CH, int AUTO, int CSR, int VIRT = 0, int REC32 = 0>
 __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
     DevPlan p, const uint8_t* __restrict__ blob, const uint8_t* __restrict__ data, int64_t stride,
     const int32_t* __restrict__ lens, int32_t common_len, const int64_t* __restrict__ offsets,
@@ -932,6 +940,7 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
       const int lim = flen - cbase;    // frame bytes [lo, lim) of this chunk are text (lim may be <= 0 or > CH)
       const int lo = mis - cbase;      // > 0 only in a misaligned text's first chunk (CSR)
       const bool full = __all(lim >= kChunk && lo <= 0);
+      uint32_t F_even = 0, meta_even = 0, sp_even = 0;   // REC32: the even group of the current pair
 #pragma unroll
       for (int g = 0; g < kChunk / 16; ++g) {
         const uint4 wv = *(const uint4*)(tile + lane * kRowPitch + g * 16);
@@ -996,7 +1005,24 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
           if (dsk > 0) { em &= dsk >= 16 ? 0u : ~((1u << (2 * dsk)) - 1u); F = ns | em; }
         }
         if (MRX_ABLATE & 16) { cnt += (F == 0x12345u); continue; }
-        if (MODE == ST_RECORDS) {
+        if (MODE == ST_RECORDS && REC32) {
+          if ((g & 1) == 0) {
+            F_even = F;
+            sp_even = (uint32_t)start | ((uint32_t)(gbase + 16) << 16);
+            meta_even = ((uint32_t)lane << 26) | ((uint32_t)cnt & kRecBeforeMask);
+          } else {
+            const bool any = ((F_even | F) & 0xAAAAAAAAu) != 0u;
+            const uint64_t has = __ballot(any);
+            if (has) {  // wave uniform
+              if (any) {
+                const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(has >> 32),
+                                                           __builtin_amdgcn_mbcnt_lo((uint32_t)has, 0));
+                *(uint4*)(wave_recs + wrec + rank) = make_uint4(F_even, F, sp_even, meta_even);
+              }
+              wrec += __builtin_popcountll(has);
+            }
+          }
+        } else if (MODE == ST_RECORDS) {
           const uint64_t has = __ballot(em != 0);
           if (has) {  // wave uniform
             if (em) {
@@ -1043,6 +1069,8 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
           EvRec r;
           r.F = 2u; r.start = start; r.pos_base = my_len;  // EMIT at byte 0 of a group placed at len
           r.meta = ((uint32_t)lane << 26) | ((uint32_t)cnt & kRecBeforeMask);
+          if (REC32) *(uint4*)(wave_recs + wrec + rank) = make_uint4(2u, 0u, (uint32_t)start | ((uint32_t)(my_len + 16) << 16), r.meta);
+          else
           wave_recs[wrec + rank] = r;
         }
         wrec += __builtin_popcountll(has);
@@ -1102,7 +1130,7 @@ constexpr int kScanTile = kScanBlock * kScanItems;
 // VBASE: pieces of long texts (see k_stream_findall VIRT): positions are piece-relative in the records
 // and become text-relative by adding vbase[piece]; `prefix` is then per piece (k_virt_prefix picks
 // the texts' entries).
-template <bool PACK16, bool VBASE = false>
+template <bool PACK16, bool VBASE = false, bool REC32 = false>
 __global__ __launch_bounds__(kBlock) void k_decode(int64_t n, const int32_t* __restrict__ wave_nrecs,
                                                    const EvRec* __restrict__ recs, int64_t rec_row,
                                                    const int64_t* __restrict__ offsets,
@@ -1169,17 +1197,28 @@ __global__ __launch_bounds__(kBlock) void k_decode(int64_t n, const int32_t* __r
           EvRec r = rr[u];
           const int rel_t = __shfl(my_rel, (int)(r.meta >> 26));
           if (VBASE) { const int vb = __shfl(my_vb, (int)(r.meta >> 26)); r.start += vb; r.pos_base += vb; }
-          uint32_t em = r.F & 0xAAAAAAAAu;
-          const uint32_t ns = r.F & 0x55555555u;
           int64_t dst = pre0 + rel_t + (int)(r.meta & kRecBeforeMask);
-          while (em) {
-            const int kk = __builtin_ctz(em) >> 1;
-            const uint32_t nsb = ns & ((1u << (2 * kk)) - 1u);
-            int st = nsb ? r.pos_base + ((31 - __builtin_clz(nsb)) >> 1) : r.start;
-            if (fixed_len > 0) st = r.pos_base + kk - fixed_len;
-            if (dst < span_cap) *(int2*)(spans + 2 * dst) = make_int2(st, r.pos_base + kk);
-            ++dst;
-            em &= em - 1;
+          uint32_t Fw = r.F;
+          int pb = REC32 ? (int)((uint32_t)r.pos_base >> 16) - 16 : r.pos_base;
+          int rstart = REC32 ? (int)((uint32_t)r.pos_base & 0xFFFFu) : r.start;
+#pragma unroll
+          for (int half = 0; half < (REC32 ? 2 : 1); ++half) {
+            uint32_t em = Fw & 0xAAAAAAAAu;
+            const uint32_t ns = Fw & 0x55555555u;
+            while (em) {
+              const int kk = __builtin_ctz(em) >> 1;
+              const uint32_t nsb = ns & ((1u << (2 * kk)) - 1u);
+              int st = nsb ? pb + ((31 - __builtin_clz(nsb)) >> 1) : rstart;
+              if (fixed_len > 0) st = pb + kk - fixed_len;
+              if (dst < span_cap) *(int2*)(spans + 2 * dst) = make_int2(st, pb + kk);
+              ++dst;
+              em &= em - 1;
+            }
+            if (REC32) {
+              if (ns) rstart = pb + ((31 - __builtin_clz(ns)) >> 1);
+              pb += 16;
+              Fw = (uint32_t)r.start;
+            }
           }
         }
       }
@@ -1203,20 +1242,32 @@ __global__ __launch_bounds__(kBlock) void k_decode(int64_t n, const int32_t* __r
           EvRec r = rr[u];
           const int rel_t = __shfl(my_rel, (int)(r.meta >> 26));
           if (VBASE) { const int vb = __shfl(my_vb, (int)(r.meta >> 26)); r.start += vb; r.pos_base += vb; }
-          uint32_t em = r.F & 0xAAAAAAAAu;
-          const uint32_t ns = r.F & 0x55555555u;
           int dst = rel_t + (int)(r.meta & kRecBeforeMask) - tb;
-          while (em) {
-            const int kk = __builtin_ctz(em) >> 1;              // byte of this EMIT
-            const uint32_t nsb = ns & ((1u << (2 * kk)) - 1u);   // NEWSTARTs strictly before it
-            int st = nsb ? r.pos_base + ((31 - __builtin_clz(nsb)) >> 1) : r.start;
-            if (fixed_len > 0) st = r.pos_base + kk - fixed_len;
-            if (dst >= 0 && dst < kDecodeTile) {
-              if constexpr (PACK16) tile[dst] = ((uint32_t)st << 16) | (uint32_t)(r.pos_base + kk);
-              else tile[dst] = make_int2(st, r.pos_base + kk);
+          // REC32: {F even, F odd, start | (pos + 16) << 16, meta} -- two event words per record
+          uint32_t Fw = r.F;
+          int pb = REC32 ? (int)((uint32_t)r.pos_base >> 16) - 16 : r.pos_base;
+          int rstart = REC32 ? (int)((uint32_t)r.pos_base & 0xFFFFu) : r.start;
+#pragma unroll
+          for (int half = 0; half < (REC32 ? 2 : 1); ++half) {
+            uint32_t em = Fw & 0xAAAAAAAAu;
+            const uint32_t ns = Fw & 0x55555555u;
+            while (em) {
+              const int kk = __builtin_ctz(em) >> 1;              // byte of this EMIT
+              const uint32_t nsb = ns & ((1u << (2 * kk)) - 1u);   // NEWSTARTs strictly before it
+              int st = nsb ? pb + ((31 - __builtin_clz(nsb)) >> 1) : rstart;
+              if (fixed_len > 0) st = pb + kk - fixed_len;
+              if (dst >= 0 && dst < kDecodeTile) {
+                if constexpr (PACK16) tile[dst] = ((uint32_t)st << 16) | (uint32_t)(pb + kk);
+                else tile[dst] = make_int2(st, pb + kk);
+              }
+              ++dst;
+              em &= em - 1;
             }
-            ++dst;
-            em &= em - 1;
+            if (REC32) {   // on to the odd group: the walk alive at its start began at the even group's last NEWSTART
+              if (ns) rstart = pb + ((31 - __builtin_clz(ns)) >> 1);
+              pb += 16;
+              Fw = (uint32_t)r.start;
+            }
           }
         }
       }
@@ -1995,7 +2046,7 @@ bool strided_fast(const Layout& lay) {
 template <int MODE>
 void launch_stream(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d_counts, int32_t* d_nrecs,
                    EvRec* d_recs, int64_t rec_row, int32_t* d_s, int32_t* d_e, hipStream_t s,
-                   const int32_t* d_vlen = nullptr, const uint32_t* d_vskip = nullptr) {
+                   const int32_t* d_vlen = nullptr, const uint32_t* d_vskip = nullptr, bool rec32 = false) {
   const DevPlan& p = h->hp.dev;
   const int64_t nw = (n + 63) / 64;
   int64_t g = (nw + kStreamWaves - 1) / kStreamWaves;
@@ -2005,10 +2056,16 @@ void launch_stream(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d
   const bool table = kind == 2;
   const bool wide = kind == 3;
   const size_t lds = wide ? 2048 : !table ? 0 : (size_t)(MODE == ST_FIRST ? p.fa_bytes : p.stg_bytes);
-#define MRX_LAUNCH(AUTO, CSR)                                                                     \
-  hipLaunchKernelGGL((k_stream_findall<MODE, (AUTO == 2 ? MRX_STREAM_CHUNK_TABLE : MRX_STREAM_CHUNK), AUTO, CSR>), grid, block, lds, s, p, \
+#define MRX_LAUNCH_R(AUTO, CSR, R32)                                                              \
+  hipLaunchKernelGGL((k_stream_findall<MODE, (AUTO == 2 ? MRX_STREAM_CHUNK_TABLE : MRX_STREAM_CHUNK), AUTO, CSR, 0, R32>), grid, block, lds, s, p, \
                      h->d_blob, lay.data, lay.stride, lay.lens, lay.len, lay.offsets, n, d_counts, \
                      d_nrecs, d_recs, rec_row, d_s, d_e)
+#define MRX_LAUNCH(AUTO, CSR)                                                                     \
+  do {                                                                                            \
+    if constexpr (MODE == ST_RECORDS) {                                                           \
+      if (rec32) MRX_LAUNCH_R(AUTO, CSR, 1); else MRX_LAUNCH_R(AUTO, CSR, 0);                     \
+    } else MRX_LAUNCH_R(AUTO, CSR, 0);                                                            \
+  } while (0)
   if (d_vlen) {   // pieces of long texts: lay.offsets = their start offsets, n = how many
     if constexpr (MODE == ST_RECORDS || MODE == ST_COUNT || MODE == ST_SEARCH) {
 #define MRX_LAUNCH_V(AUTO)                                                                        \
@@ -2030,6 +2087,7 @@ void launch_stream(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d
     else MRX_LAUNCH(1, 0);
   }
 #undef MRX_LAUNCH
+#undef MRX_LAUNCH_R
 }
 
 // Long texts on the streaming kernels: cut into pieces at synchronising bytes when one lane per text
@@ -2199,6 +2257,7 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
   bool step_ok = g_force_generic < 2 &&
                  (match_next_sequence ? ((p.flags & PF_STEP_SEARCH) && !(p.flags & PF_PREFILTER))
                                       : (p.flags & (PF_STEPPABLE | PF_STEP_REQ)) != 0);
+  bool rec32 = false;      // streaming path: one record per two groups (fixed pitch, positions fit 16 bits)
   bool req_wave = false;   // the stepper's route on the wavefront-per-text kernel
   int step_split = 0;      // > 0: lane kernel for texts below this length AND wavefront kernel for the rest
   Layout lay2 = lay;       // lay + that split
@@ -2231,11 +2290,12 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
         rec_row = rec_row_len(lay.lens ? lay.stride : lay.len) + (strided_fast(lay) ? 0 : 1);  // frame: one more group
         nrec = (size_t)rec_row * n;
       }
+      rec32 = !lay.offsets && (lay.lens ? lay.stride : (int64_t)lay.len) <= kRec32MaxLen;
       HIP_TRY(scratch_alloc((void**)&d_recs, sizeof(EvRec) * nrec, s));
       HIP_TRY(scratch_alloc((void**)&d_nrecs, sizeof(int32_t) * 2 * nw, s));  // records | matches per wavefront
       HIP_TRY(scratch_alloc((void**)&d_wbase, sizeof(int64_t) * (nw + 1), s));
       ScanTimer tm(s);
-      launch_stream<ST_RECORDS>(h, lay, n, d_counts, d_nrecs, d_recs, rec_row, nullptr, nullptr, s);
+      launch_stream<ST_RECORDS>(h, lay, n, d_counts, d_nrecs, d_recs, rec_row, nullptr, nullptr, s, nullptr, nullptr, rec32);
       g_last_kernel = "k_stream_findall";
       HIP_TRY(hipGetLastError());
       tm.stop();
@@ -2308,7 +2368,11 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
     hipLaunchKernelGGL(k_scan_local<int32_t>, dim3((unsigned)ntiles), dim3(kScanBlock), 0, s, d_nrecs + nw, nw,
                        d_wbase, d_tsum);
     const bool pack16 = !lay.offsets && (lay.lens ? lay.stride : (int64_t)lay.len) <= 65535;
-    if (pack16)
+    if (pack16 && rec32)
+      hipLaunchKernelGGL((k_decode<true, false, true>), dim3(grid_for(n, kBlock) * 2), dim3(kBlock), 0, s, n, d_nrecs, d_recs,
+                         rec_row, lay.offsets, d_counts, d_wbase, d_tsum, d_prefix, d_spans, span_cap, p.st_fixed_len,
+                         d_total);
+    else if (pack16)
       hipLaunchKernelGGL(k_decode<true>, dim3(grid_for(n, kBlock) * 2), dim3(kBlock), 0, s, n, d_nrecs, d_recs,
                          rec_row, lay.offsets, d_counts, d_wbase, d_tsum, d_prefix, d_spans, span_cap, p.st_fixed_len,
                          d_total);
