@@ -1118,7 +1118,10 @@ constexpr int kDecodeTile = MRX_DECODE_TILE;  // spans per LDS tile and wavefron
 #define MRX_DECODE_DIRECT (3 * kDecodeTile)
 #endif
 constexpr int kDecodeDirect = MRX_DECODE_DIRECT;  // above this many spans per wavefront: one direct pass
-constexpr int kDecodeBatch = 8;    // independent 16-byte record loads in flight per lane
+#ifndef MRX_DECODE_BATCH
+#define MRX_DECODE_BATCH 8
+#endif
+constexpr int kDecodeBatch = MRX_DECODE_BATCH;    // independent 16-byte record loads in flight per lane
 
 constexpr int kScanBlock = 256;
 constexpr int kScanItems = 8;  // per thread
