@@ -213,3 +213,35 @@ def test_long_texts_and_degenerate_batches():
     one = M.DeviceBatch.strided(data[: lens[0]].contiguous(), lens[0], length=lens[0])
     p1, s1, t1 = rx._dev_findall(one)
     assert t1 == int(counts[0]) and np.array_equal(s1[:t1].cpu().numpy(), osp[: counts[0]])
+
+
+@pytest.mark.parametrize("L", [65500, 65504, 65535, 65536])
+def test_record_forms_at_the_16_bit_position_boundary(L):
+    """Fixed pitch just below / above the limits of the two-group records (65 500 bytes) and of the
+    16-bit decode tile (65 535): spans near the end of the text must come out exact (C oracle)."""
+    _need_gpu()
+    pat = b"[a-z]+\\d+"
+    rx = M.compile_regex(pat)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(L)
+    al = torch.tensor(list(b"abcxyz0123456789 -"), dtype=torch.uint8, device="cuda")
+    n = 5
+    data = al[torch.randint(0, al.numel(), (n * L,), generator=g, device="cuda")]
+    tail = torch.tensor(list(b" zz99"), dtype=torch.uint8, device="cuda")
+    for i in range(n):
+        data[(i + 1) * L - 5:(i + 1) * L] = tail          # a match that ends exactly at the end of the text
+    batch = M.DeviceBatch.strided(data, L, length=L)
+    pre, sp, tot = rx._dev_findall(batch)
+    assert M.load_library().mrx_last_kernel_name() in (b"k_stream_findall", b"k_stream_findall_pieces")
+    offsets = np.arange(0, (n + 1) * L, L, dtype=np.int64)
+    counts, osp, ototal = CDfa(pat).findall_batch(data.cpu().numpy(), offsets)
+    assert tot == ototal and np.array_equal((pre[1:] - pre[:-1]).cpu().numpy(), counts)
+    assert np.array_equal(sp[:tot].cpu().numpy(), osp)
+    assert int(sp[:tot, 1].max().item()) == L
+    with_lens = M.DeviceBatch.strided(data, L, length=L, lens=torch.full((n,), L - 3, dtype=torch.int32, device="cuda"))
+    pre2, sp2, tot2 = rx._dev_findall(with_lens)
+    offs2 = np.stack([np.arange(n) * L, np.arange(n) * L + L - 3], axis=1)
+    host = data.cpu().numpy()
+    packed = np.concatenate([host[a:b] for a, b in offs2])
+    c2, o2, t2 = CDfa(pat).findall_batch(packed, np.arange(0, (n + 1) * (L - 3), L - 3, dtype=np.int64))
+    assert tot2 == t2 and np.array_equal(sp2[:tot2].cpu().numpy(), o2)
