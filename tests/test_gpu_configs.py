@@ -231,17 +231,25 @@ def test_record_forms_at_the_16_bit_position_boundary(L):
     for i in range(n):
         data[(i + 1) * L - 5:(i + 1) * L] = tail          # a match that ends exactly at the end of the text
     batch = M.DeviceBatch.strided(data, L, length=L)
-    pre, sp, tot = rx._dev_findall(batch)
-    assert M.load_library().mrx_last_kernel_name() in (b"k_stream_findall", b"k_stream_findall_pieces")
+    lib = M.load_library()
     offsets = np.arange(0, (n + 1) * L, L, dtype=np.int64)
     counts, osp, ototal = CDfa(pat).findall_batch(data.cpu().numpy(), offsets)
-    assert tot == ototal and np.array_equal((pre[1:] - pre[:-1]).cpu().numpy(), counts)
-    assert np.array_equal(sp[:tot].cpu().numpy(), osp)
-    assert int(sp[:tot, 1].max().item()) == L
+    for mode, kernel in ((0, b"k_stream_findall_pieces"), (2, b"k_stream_findall")):   # cut into pieces / one lane per text
+        lib.mrx_debug_long_text_kernels(mode)
+        try:
+            pre, sp, tot = rx._dev_findall(batch)
+        finally:
+            lib.mrx_debug_long_text_kernels(0)
+        assert lib.mrx_last_kernel_name() == kernel
+        assert tot == ototal and np.array_equal((pre[1:] - pre[:-1]).cpu().numpy(), counts)
+        assert np.array_equal(sp[:tot].cpu().numpy(), osp)
+        assert int(sp[:tot, 1].max().item()) == L
+    lib.mrx_debug_long_text_kernels(2)
     with_lens = M.DeviceBatch.strided(data, L, length=L, lens=torch.full((n,), L - 3, dtype=torch.int32, device="cuda"))
     pre2, sp2, tot2 = rx._dev_findall(with_lens)
     offs2 = np.stack([np.arange(n) * L, np.arange(n) * L + L - 3], axis=1)
     host = data.cpu().numpy()
     packed = np.concatenate([host[a:b] for a, b in offs2])
     c2, o2, t2 = CDfa(pat).findall_batch(packed, np.arange(0, (n + 1) * (L - 3), L - 3, dtype=np.int64))
+    lib.mrx_debug_long_text_kernels(0)
     assert tot2 == t2 and np.array_equal(sp2[:tot2].cpu().numpy(), o2)
