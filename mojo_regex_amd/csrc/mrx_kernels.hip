@@ -1398,7 +1398,13 @@ __global__ __launch_bounds__(kBlock) void k_max_len(const int64_t* __restrict__ 
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x)
     m = max(m, (int)(offsets[t + 1] - offsets[t]));
   for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off));
-  if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(out, m);
+  __shared__ int wmax[kBlock / 64];
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {   // one atomic per workgroup
+    for (int w = 1; w < kBlock / 64; ++w) m = max(m, wmax[w]);
+    if (m > 0) atomicMax(out, m);
+  }
 }
 
 // ---- sub() -------------------------------------------------------------------------
@@ -1874,7 +1880,7 @@ int req_wave_pays(const Layout& lay, int64_t n, bool req_route, hipStream_t s, b
     int32_t m = 0;
     HIP_TRY(scratch_alloc((void**)&d_max, sizeof(int32_t), s));
     HIP_TRY(hipMemsetAsync(d_max, 0, sizeof(int32_t), s));
-    hipLaunchKernelGGL(k_max_len, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, lay.offsets, n, d_max);
+    hipLaunchKernelGGL(k_max_len, dim3(grid_for(n, kBlock * 8)), dim3(kBlock), 0, s, lay.offsets, n, d_max);
     HIP_TRY(hipMemcpyAsync(&m, d_max, sizeof m, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(&total, lay.offsets + n, sizeof total, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -2107,25 +2113,37 @@ struct Pieces {
   int32_t* back = nullptr;
   Layout lay{};   // the pieces as a batch: offsets = vstart
 };
-int pieces_prepare(const mrx_handle* h, const Layout& lay, int64_t n, hipStream_t s, Pieces* pc) {
+// byte count and longest text of a CSR batch: both live on the device (one small kernel, one sync)
+int csr_stats(const Layout& lay, int64_t n, hipStream_t s, int64_t* total, int64_t* max_len) {
+  int32_t* d_max = nullptr;
+  int32_t m = 0;
+  HIP_TRY(scratch_alloc((void**)&d_max, sizeof(int32_t), s));
+  HIP_TRY(hipMemsetAsync(d_max, 0, sizeof(int32_t), s));
+  hipLaunchKernelGGL(k_max_len, dim3(grid_for(n, kBlock * 8)), dim3(kBlock), 0, s, lay.offsets, n, d_max);
+  HIP_TRY(hipMemcpyAsync(&m, d_max, sizeof m, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(total, lay.offsets + n, sizeof *total, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  HIP_TRY(scratch_free(d_max, s));
+  *max_len = m;
+  return MRX_OK;
+}
+// known_total / known_max: csr_stats() of the batch when the caller has them already (< 0: not)
+int pieces_prepare(const mrx_handle* h, const Layout& lay, int64_t n, hipStream_t s, Pieces* pc,
+                   int64_t known_total = -1, int64_t known_max = -1) {
   const DevPlan& p = h->hp.dev;
   pc->on = false;
   if (p.st_nsync <= 0 || g_long_text_mode == 2 || n <= 0) return MRX_OK;
   // pays when one lane per text leaves the device mostly idle, or for outliers of a ragged batch; a
   // fixed-length batch of many texts is decided before anything is launched
   if (g_long_text_mode == 0 && n > 131072 && !lay.offsets && !lay.lens) return MRX_OK;
+  // count / search of a large CSR batch stay free of any host synchronisation: its outliers are only
+  // looked for where the caller has the batch's statistics anyway (findall)
+  if (g_long_text_mode == 0 && n > 131072 && lay.offsets && known_total < 0) return MRX_OK;
   int64_t total = 0, max_len = 0;
-  if (lay.offsets) {
-    int32_t* d_max = nullptr;
-    HIP_TRY(scratch_alloc((void**)&d_max, sizeof(int32_t), s));
-    HIP_TRY(hipMemsetAsync(d_max, 0, sizeof(int32_t), s));
-    hipLaunchKernelGGL(k_max_len, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, lay.offsets, n, d_max);
-    int32_t m = 0;
-    HIP_TRY(hipMemcpyAsync(&m, d_max, sizeof m, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(&total, lay.offsets + n, sizeof total, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    HIP_TRY(scratch_free(d_max, s));
-    max_len = m;
+  if (lay.offsets && known_total >= 0) {
+    total = known_total; max_len = known_max;
+  } else if (lay.offsets) {
+    if (int rc = csr_stats(lay, n, s, &total, &max_len)) return rc;
   } else {
     max_len = lay.lens ? lay.stride : (int64_t)lay.len;
     total = n * lay.stride;
@@ -2260,7 +2278,8 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
   bool step_ok = g_force_generic < 2 &&
                  (match_next_sequence ? ((p.flags & PF_STEP_SEARCH) && !(p.flags & PF_PREFILTER))
                                       : (p.flags & (PF_STEPPABLE | PF_STEP_REQ)) != 0);
-  bool rec32 = false;      // streaming path: one record per two groups (fixed pitch, positions fit 16 bits)
+  bool rec32 = false;      // streaming path: one record per two groups (positions fit 16 bits)
+  int64_t max_text = int64_t(1) << 40;   // longest text of the batch, where known
   bool req_wave = false;   // the stepper's route on the wavefront-per-text kernel
   int step_split = 0;      // > 0: lane kernel for texts below this length AND wavefront kernel for the rest
   Layout lay2 = lay;       // lay + that split
@@ -2270,8 +2289,13 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
   int32_t* d_slots = nullptr;
   int64_t rec_row = 0;
   Pieces pc;
+  int64_t csr_total = -1, csr_max = -1;   // CSR batches on the streaming path: byte count and longest text
+  if (n > 0 && stream_ok && lay.offsets) {
+    if (int rc = csr_stats(lay, n, s, &csr_total, &csr_max)) return rc;
+    if (csr_total < 0) return fail(MRX_E_ARGUMENT, "offsets[n] is negative");
+  }
   if (n > 0 && stream_ok)
-    if (int rc = pieces_prepare(h, lay, n, s, &pc)) return rc;
+    if (int rc = pieces_prepare(h, lay, n, s, &pc, csr_total, csr_max)) return rc;
   const bool by_pieces = pc.on;
   if (pc.on) {
     if (int rc = findall_pieces(h, pc, n, d_prefix, d_spans, span_cap, d_total, s)) return rc;
@@ -2281,19 +2305,16 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
       const int64_t nw = (n + 63) / 64;
       size_t nrec;
       if (lay.offsets) {
-        // the record buffer is sized by the batch's byte count, which only the device knows:
-        // one 8-byte read-back (the only host synchronisation the CSR path adds)
-        int64_t total_bytes = 0;
-        HIP_TRY(hipMemcpyAsync(&total_bytes, lay.offsets + n, sizeof total_bytes, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        if (total_bytes < 0) return fail(MRX_E_ARGUMENT, "offsets[n] is negative");
-        nrec = (size_t)(total_bytes / 16 + 256 * nw + 256);
+        // the record buffer is sized by the batch's byte count, which only the device knows
+        // (csr_stats above: the only host synchronisation the CSR path adds)
+        nrec = (size_t)(csr_total / 16 + 256 * nw + 256);
       } else {
         // one 16-byte record per 16-byte group at most (+1 for the match that ends at len)
         rec_row = rec_row_len(lay.lens ? lay.stride : lay.len) + (strided_fast(lay) ? 0 : 1);  // frame: one more group
         nrec = (size_t)rec_row * n;
       }
-      rec32 = !lay.offsets && (lay.lens ? lay.stride : (int64_t)lay.len) <= kRec32MaxLen;
+      max_text = lay.offsets ? csr_max : (lay.lens ? lay.stride : (int64_t)lay.len);
+      rec32 = max_text <= kRec32MaxLen;
       HIP_TRY(scratch_alloc((void**)&d_recs, sizeof(EvRec) * nrec, s));
       HIP_TRY(scratch_alloc((void**)&d_nrecs, sizeof(int32_t) * 2 * nw, s));  // records | matches per wavefront
       HIP_TRY(scratch_alloc((void**)&d_wbase, sizeof(int64_t) * (nw + 1), s));
@@ -2370,7 +2391,7 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
     HIP_TRY(scratch_alloc((void**)&d_tsum, sizeof(int64_t) * ntiles, s));
     hipLaunchKernelGGL(k_scan_local<int32_t>, dim3((unsigned)ntiles), dim3(kScanBlock), 0, s, d_nrecs + nw, nw,
                        d_wbase, d_tsum);
-    const bool pack16 = !lay.offsets && (lay.lens ? lay.stride : (int64_t)lay.len) <= 65535;
+    const bool pack16 = max_text <= 65535;
     if (pack16 && rec32)
       hipLaunchKernelGGL((k_decode<true, false, true>), dim3(grid_for(n, kBlock) * 2), dim3(kBlock), 0, s, n, d_nrecs, d_recs,
                          rec_row, lay.offsets, d_counts, d_wbase, d_tsum, d_prefix, d_spans, span_cap, p.st_fixed_len,
