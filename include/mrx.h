@@ -177,7 +177,17 @@ int mrx_sub_batch(const mrx_handle* h, const char* repl, size_t repl_len, int64_
 
 /* Per-call scratch (counts, event records, block sums) is kept in a grow-only arena per calling
  * thread and stream and reused by the next call on that stream.  mrx_release_scratch() frees the
- * calling thread's arenas (it synchronises their streams first). */
+ * calling thread's arenas (it synchronises their streams first).  Size: findall needs up to one
+ * byte of records per text byte (+ 4 KiB per 64 texts); on the stepper kernels with texts of 2 KiB
+ * and more, two bytes of span slots per text byte.  The arena settles within two calls of a new
+ * batch shape (a call that had to grow it is followed by one that merges its chunks).
+ *
+ * Batch shape and kernel choice (all automatic, results never depend on it): one lane per text by
+ * default; batches of few long texts put a wavefront on each text (stepper plans) or cut the texts
+ * into pieces at bytes after which the scan does not depend on its past (streaming plans); ragged
+ * CSR batches with a few texts far longer than the rest are handled the same way for findall.
+ * CSR entry points read the batch's byte count (and longest text) back once per call; the strided
+ * entry points with total == NULL never synchronise. */
 void mrx_release_scratch(void);
 
 /* ---- measurement hooks -------------------------------------------------------- */

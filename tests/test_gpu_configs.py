@@ -244,12 +244,14 @@ def test_record_forms_at_the_16_bit_position_boundary(L):
         assert tot == ototal and np.array_equal((pre[1:] - pre[:-1]).cpu().numpy(), counts)
         assert np.array_equal(sp[:tot].cpu().numpy(), osp)
         assert int(sp[:tot, 1].max().item()) == L
-    lib.mrx_debug_long_text_kernels(2)
     with_lens = M.DeviceBatch.strided(data, L, length=L, lens=torch.full((n,), L - 3, dtype=torch.int32, device="cuda"))
-    pre2, sp2, tot2 = rx._dev_findall(with_lens)
+    lib.mrx_debug_long_text_kernels(2)
+    try:
+        pre2, sp2, tot2 = rx._dev_findall(with_lens)
+    finally:
+        lib.mrx_debug_long_text_kernels(0)
     offs2 = np.stack([np.arange(n) * L, np.arange(n) * L + L - 3], axis=1)
     host = data.cpu().numpy()
     packed = np.concatenate([host[a:b] for a, b in offs2])
     c2, o2, t2 = CDfa(pat).findall_batch(packed, np.arange(0, (n + 1) * (L - 3), L - 3, dtype=np.int64))
-    lib.mrx_debug_long_text_kernels(0)
     assert tot2 == t2 and np.array_equal(sp2[:tot2].cpu().numpy(), o2)
