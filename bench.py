@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--settle", type=int, default=64, help="untimed steps before the warm-up (arena, clocks)")
     ap.add_argument("--texts", type=int, default=1 << 20, help="texts per GPU")
     ap.add_argument("--length", type=int, default=1024)
     ap.add_argument("--cpu-sample", type=int, default=1 << 16)
@@ -154,6 +155,12 @@ def main():
         with torch.cuda.stream(streams[k]):
             rx.findall_async(batch, outs[k])
 
+    torch.cuda.synchronize()
+    # Untimed set-up, not part of the W warm-up steps: the per-stream scratch arena settles within two
+    # calls of a new batch shape, and the part needs some tens of ms of load to reach its steady
+    # clocks (20 steps = 7 ms; measured 0.356 ms per step cold against 0.323 ms with 100 steps).
+    for _ in range(args.settle):
+        step()
     torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
@@ -249,7 +256,7 @@ def main():
                        "texts_per_gpu": n, "text_bytes": L, "pattern": PATTERN.decode(),
                        "op": "findall", "matches_per_batch": int(total),
                        "parallelism": "texts sharded, %d rank(s), no data-path collective" % world,
-                       "streams": nstreams},
+                       "streams": nstreams, "settle_steps": args.settle},
             "hbm_frac_of_peak_whole_step": round(value / world / HBM_PEAK_GBS, 4),
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
