@@ -769,6 +769,24 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
   constexpr int NL = 64 / RPI;            // load instructions per chunk (= CH / 16)
   __shared__ __align__(16) uint8_t tiles[kStreamWaves][64 * kRowPitch];
   __shared__ __align__(16) uint16_t col_lds[256];
+  // pmask[x]: the first x bytes of a 16-byte group set.  Texts that end (or, in a frame, begin) inside
+  // a group: when the automaton has a reset byte (DevPlan::st_reset_byte -- every state goes idle, no
+  // walk starts, accepting states emit), the bytes outside the text are replaced by it and the group
+  // takes the same branch-free steps as a full one; the match that runs to the end of the text is then
+  // emitted by the first byte behind it, at the same position the end-of-text rule gives.
+  __shared__ __align__(16) uint4 pmask[17];
+  if (threadIdx.x < 17) {
+    const int x = threadIdx.x;
+    uint32_t w[4];
+    for (int j = 0; j < 4; ++j) {
+      const int nb = x - 4 * j;
+      w[j] = nb <= 0 ? 0u : nb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1u);
+    }
+    pmask[x] = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+  // (not for pieces: a piece that is not the last of its text must not end a match at its end)
+  const bool use_fill = MODE != ST_FIRST && !VIRT && p.st_reset_byte >= 0;
+  const uint32_t fillw = (uint32_t)(p.st_reset_byte & 0xFF) * 0x01010101u;
   extern __shared__ __align__(16) uint8_t stg_lds[];  // AUTO == 2: cls | trans | accept
   if (AUTO == 1) {
     const uint16_t* src = (const uint16_t*)(blob + (MODE == ST_FIRST ? p.off_fa_col : p.off_stcol));
@@ -939,12 +957,20 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
 
       const int lim = flen - cbase;    // frame bytes [lo, lim) of this chunk are text (lim may be <= 0 or > CH)
       const int lo = mis - cbase;      // > 0 only in a misaligned text's first chunk (CSR)
-      const bool full = __all(lim >= kChunk && lo <= 0);
+      const bool all_inside = __all(lim >= kChunk && lo <= 0);
+      const bool full = all_inside || use_fill;   // branch-free steps: no byte needs a predicate
       uint32_t F_even = 0, meta_even = 0, sp_even = 0;   // REC32: the even group of the current pair
 #pragma unroll
       for (int g = 0; g < kChunk / 16; ++g) {
         const uint4 wv = *(const uint4*)(tile + lane * kRowPitch + g * 16);
-        const uint32_t words[4] = {wv.x, wv.y, wv.z, wv.w};
+        uint32_t words[4] = {wv.x, wv.y, wv.z, wv.w};
+        if (use_fill && !all_inside) {   // wave uniform
+          const int a = min(max(lo - g * 16, 0), 16), b = min(max(lim - g * 16, 0), 16);   // inside: [a, b)
+          const uint4 pa = pmask[a], pb = pmask[b > a ? b : a];
+          const uint32_t m[4] = {pb.x & ~pa.x, pb.y & ~pa.y, pb.z & ~pa.z, pb.w & ~pa.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) words[j] = (words[j] & m[j]) | (fillw & ~m[j]);
+        }
         uint32_t F = 0;
         if (AUTO == 2) {
           uint32_t cc[16];

@@ -488,6 +488,7 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
   d.off_stcol = -1;
   d.off_st_sync = -1;
   d.st_nsync = 0;
+  d.st_reset_byte = -1;
   hp.streamable_why_not.clear();
   d.st_kind = 0;
   d.st_fixed_len = 0;
@@ -511,6 +512,13 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
         // is none (idle), it begins at this byte from every state, or starts are not tracked (KMP)
         sync[c] = same && ((E[0][c] >> 2) == 0 || all_new || d.st_fixed_len > 0);
         nsync += sync[c];
+      }
+      d.st_reset_byte = -1;
+      for (int c = 255; c >= 0 && d.st_reset_byte < 0; --c) {
+        bool ok = true;
+        for (int q = 0; q < nlive && ok; ++q)
+          ok = (E[q][c] >> 2) == 0 && !(E[q][c] & 1) && (((E[q][c] >> 1) & 1) == (live_acc[q] ? 1 : 0));
+        if (ok) d.st_reset_byte = c;
       }
       d.st_nsync = nsync;
       if (nsync) {
@@ -906,7 +914,7 @@ std::string describe_plan(const HostPlan& hp) {
   o << "device.streamable=" << ((d.flags & PF_STREAMABLE) ? "yes" : ("no: " + hp.streamable_why_not))
     << " st_nstates=" << d.st_nstates << " st_kind=" << d.st_kind
     << (((d.flags & PF_STREAMABLE) && !(d.flags & PF_STREAM_SEARCH)) ? " findall_only=1" : "")
-    << " sync_bytes=" << d.st_nsync << "\n";
+    << " sync_bytes=" << d.st_nsync << " reset_byte=" << d.st_reset_byte << "\n";
   o << "device.steppable=" << ((d.flags & PF_STEPPABLE) ? "yes" : (d.flags & PF_STEP_REQ) ? "required-byte route" : "no")
     << " step_search=" << ((d.flags & PF_STEP_SEARCH) ? 1 : 0) << ((d.flags & PF_STEP_BIG) ? " big_table=1" : "") << "\n";
   o << "device.first_stream=" << (d.fa_bytes ? "yes" : ("no: " + hp.first_stream_why_not))

@@ -71,6 +71,9 @@ struct DevPlan {
   // same state with the same start (idle, or a new start at b) -- after such a byte the walk does not
   // depend on what came before, so a long text can be cut there (st_nsync = how many, 0 = no table)
   int32_t off_st_sync, st_nsync;
+  // a byte that takes every state to idle without starting a walk and emits exactly from the accepting
+  // states: bytes of a frame that lie outside the text may be replaced by it (-1: no such byte)
+  int32_t st_reset_byte;
   // anchored automaton for match_first on the streaming kernel (fa_bytes == 0: none); same layout
   // as kind 2 but entry = (next << fa_cshift) << 2 | ACCEPT(next) << 1, last row = dead state
   int32_t off_fa_cls, off_fa_trans, fa_cshift, fa_bytes, fa_nstates, fa_start_acc;
