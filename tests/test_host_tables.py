@@ -141,6 +141,8 @@ def test_synchronising_bytes_and_long_text_plan_flags():
     assert "sync_bytes=246" in line(b"\\d+", "device.streamable")            # every non-digit
     assert "sync_bytes=253" in line(b"hello", "device.streamable")           # non-literal bytes and 'h' (always prefix length 1)
     assert "sync_bytes=255" in line(b"a{2,4}", "device.streamable")
+    assert "reset_byte=255" in line(b"[a-z]+\\d+", "device.streamable")        # all states -> idle, accepting ones emit
+    assert "reset_byte=-1" in line(b"[^a]+b", "device.streamable")              # (not streamable at all)
     s = line(b"555-123-4567", "device.streamable")                             # "5" is prefix and suffix: KMP with restart
     assert s.startswith("device.streamable=yes") and "st_nstates=13" in s
     assert line(b"abab", "device.streamable").startswith("device.streamable=yes")
