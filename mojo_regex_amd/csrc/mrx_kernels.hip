@@ -740,6 +740,8 @@ __host__ __device__ inline int64_t rec_region_start(int64_t first_off, int64_t w
 enum { ST_RECORDS = 0, ST_COUNT = 1, ST_SEARCH = 2, ST_FIRST = 3 };
 
 // AUTO = 1: byte-column automaton (<= 4 states, described above).
+// AUTO = 4: the class-table automaton two bytes at a time (DevPlan::off_stg_pair): half as many
+//           dependent lookups; only with a reset byte (no per-byte predicates) and never for pieces.
 // AUTO = 2: class-table automaton for any streamable plan: cls[byte] (u8, LDS) is looked
 //           up ahead for the whole group, then trans[state_row + cls] (u16, LDS) is a
 //           dependent lookup per byte -- latency bound, hidden by the other wavefronts.
@@ -807,6 +809,7 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
   const uint16_t* tr_lds = (const uint16_t*)(stg_lds + (MODE == ST_FIRST ? p.off_fa_trans - p.off_fa_cls
                                                                         : p.off_stg_trans - p.off_stg_cls));
   const uint8_t* acc_lds = stg_lds + (p.off_stg_acc - p.off_stg_cls);
+  const uint32_t* pair_lds = (const uint32_t*)(stg_lds + (p.off_stg_pair - p.off_stg_cls));   // AUTO == 4
   // q4 value of the anchored automaton's dead state: its row offset (class table) or field shift (columns)
   const uint32_t fa_dead = AUTO == 2 ? (uint32_t)p.fa_nstates << p.fa_cshift
                                      : (uint32_t)p.fa_nstates * (AUTO == 1 ? 4u : 8u);
@@ -972,7 +975,20 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
           for (int j = 0; j < 4; ++j) words[j] = (words[j] & m[j]) | (fillw & ~m[j]);
         }
         uint32_t F = 0;
-        if (AUTO == 2) {
+        if (AUTO == 4) {
+          uint32_t cc[16], pi[8];
+#pragma unroll
+          for (int k = 0; k < 16; ++k)
+            cc[k] = cls_lds[(words[k >> 2] >> ((k & 3) * 8)) & 0xFFu];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) pi[k] = (cc[2 * k] << p.st_cshift) | cc[2 * k + 1];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const uint32_t e = pair_lds[q4 + pi[k]];            // q4 = row offset of the state in the pair table
+            q4 = e >> 4;
+            F = __builtin_amdgcn_alignbit(e, F, 4);             // the flags of both bytes
+          }
+        } else if (AUTO == 2) {
           uint32_t cc[16];
 #pragma unroll
           for (int k = 0; k < 16; ++k)
@@ -1085,7 +1101,8 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
     // end of text: a walk that is in an accepting state ends at len
     {
       const bool tail = MODE != ST_FIRST && live && (!VIRT || (vsk >> 31)) &&
-                        (AUTO == 2 ? acc_lds[q4 >> p.st_cshift] != 0
+                        (AUTO == 4 ? acc_lds[q4 >> (2 * p.st_cshift)] != 0
+                         : AUTO == 2 ? acc_lds[q4 >> p.st_cshift] != 0
                                    : ((accmask >> (q4 >> (AUTO == 3 ? 3 : 2))) & 1u) != 0);
       if (MODE == ST_RECORDS) {
         const uint64_t has = __ballot(tail);
@@ -1779,6 +1796,7 @@ thread_local int64_t g_scan_launches = 0;
 thread_local const char* g_last_kernel = "";
 // mrx_debug_force_generic(): route every call to the generic lane-per-text kernels (tests compare
 // the two implementations; never set in production)
+int g_pair_tables = 1;      // MRX_NO_PAIR_TABLES=1 in the environment: measure the one-byte class table
 int g_long_text_mode = 0;   // mrx_debug_long_text_kernels(): 0 by average length, 1 always, 2 never
 int g_force_generic = 0;   // 0 best kernel, 1 no streaming kernel, 2 literal restatement (mrx_device.hpp) only
 
@@ -2090,6 +2108,8 @@ void launch_stream(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d
   const int kind = MODE == ST_FIRST ? p.fa_kind : p.st_kind;   // automaton form of this mode
   const bool table = kind == 2;
   const bool wide = kind == 3;
+  // class table walked two bytes per lookup (plans with a reset byte; never the anchored automaton, never pieces)
+  const bool pairs = MODE != ST_FIRST && table && p.off_stg_pair >= 0 && !d_vlen && g_pair_tables;
   const size_t lds = wide ? 2048 : !table ? 0 : (size_t)(MODE == ST_FIRST ? p.fa_bytes : p.stg_bytes);
 #define MRX_LAUNCH_R(AUTO, CSR, R32)                                                              \
   hipLaunchKernelGGL((k_stream_findall<MODE, (AUTO == 2 ? MRX_STREAM_CHUNK_TABLE : MRX_STREAM_CHUNK), AUTO, CSR, 0, R32>), grid, block, lds, s, p, \
@@ -2113,11 +2133,13 @@ void launch_stream(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d
 #undef MRX_LAUNCH_V
     }
   } else if (!strided_fast(lay)) {
-    if (table) MRX_LAUNCH(2, 1);
+    if (table && pairs) { if constexpr (MODE != ST_FIRST) MRX_LAUNCH(4, 1); }
+    else if (table) MRX_LAUNCH(2, 1);
     else if (wide) MRX_LAUNCH(3, 1);
     else MRX_LAUNCH(1, 1);
   } else {
-    if (table) MRX_LAUNCH(2, 0);
+    if (table && pairs) { if constexpr (MODE != ST_FIRST) MRX_LAUNCH(4, 0); }
+    else if (table) MRX_LAUNCH(2, 0);
     else if (wide) MRX_LAUNCH(3, 0);
     else MRX_LAUNCH(1, 0);
   }
@@ -2585,6 +2607,7 @@ int mrx_compile(const char* pattern, size_t pattern_len, mrx_handle** out) {
 }
 
 int mrx_compile_ex(const char* pattern, size_t pattern_len, uint32_t options, mrx_handle** out) {
+  if (const char* e = getenv("MRX_NO_PAIR_TABLES")) g_pair_tables = !(e[0] == '1');
   if (!out || (!pattern && pattern_len)) return fail(MRX_E_ARGUMENT, "null argument");
   if (options & ~(uint32_t)(MRX_COMPILE_LAZYDFA_SEMANTICS | MRX_COMPILE_BITSET_NFA))
     return fail(MRX_E_ARGUMENT, "unknown compile option");

@@ -487,6 +487,7 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
   // ---- streaming automaton (findall only) -----------------------------------------
   d.off_stcol = -1;
   d.off_st_sync = -1;
+  d.off_stg_pair = -1;
   d.st_nsync = 0;
   d.st_reset_byte = -1;
   hp.streamable_why_not.clear();
@@ -589,6 +590,27 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
       put(hp.blob, tr.data(), tr.size() * 2);
       d.off_stg_acc = (int)hp.blob.size();
       put(hp.blob, live_acc.data(), live_acc.size());
+      // two bytes per lookup: the chain of dependent LDS reads is what bounds this form
+      const int ncp2 = ncp * ncp;
+      if (d.st_reset_byte >= 0 && (int64_t)nlive * ncp2 <= 4096) {
+        // a representative byte of every class
+        std::vector<int> rep(ncp, -1);
+        for (int c = 0; c < 256; ++c)
+          if (rep[scls[c]] < 0) rep[scls[c]] = c;
+        std::vector<uint32_t> pair((size_t)nlive * ncp2, 0);
+        for (int q = 0; q < nlive; ++q)
+          for (int c0 = 0; c0 < ncp; ++c0)
+            for (int c1 = 0; c1 < ncp; ++c1) {
+              if (rep[c0] < 0 || rep[c1] < 0) continue;   // padding classes are never looked up
+              const uint16_t e0 = E[q][rep[c0]];
+              const uint16_t e1 = E[e0 >> 2][rep[c1]];
+              pair[(size_t)q * ncp2 + ((size_t)c0 << cshift) + c1] =
+                  ((uint32_t)((e1 >> 2) * ncp2) << 4) | ((uint32_t)(e1 & 3) << 2) | (uint32_t)(e0 & 3);
+            }
+        align(hp.blob, 4);
+        d.off_stg_pair = (int)hp.blob.size();
+        put(hp.blob, pair.data(), pair.size() * 4);
+      }
       align(hp.blob, 16);
       d.stg_bytes = (int)hp.blob.size() - begin;
     }
@@ -914,7 +936,8 @@ std::string describe_plan(const HostPlan& hp) {
   o << "device.streamable=" << ((d.flags & PF_STREAMABLE) ? "yes" : ("no: " + hp.streamable_why_not))
     << " st_nstates=" << d.st_nstates << " st_kind=" << d.st_kind
     << (((d.flags & PF_STREAMABLE) && !(d.flags & PF_STREAM_SEARCH)) ? " findall_only=1" : "")
-    << " sync_bytes=" << d.st_nsync << " reset_byte=" << d.st_reset_byte << "\n";
+    << " sync_bytes=" << d.st_nsync << " reset_byte=" << d.st_reset_byte
+    << (d.off_stg_pair >= 0 ? " pair_table=1" : "") << "\n";
   o << "device.steppable=" << ((d.flags & PF_STEPPABLE) ? "yes" : (d.flags & PF_STEP_REQ) ? "required-byte route" : "no")
     << " step_search=" << ((d.flags & PF_STEP_SEARCH) ? 1 : 0) << ((d.flags & PF_STEP_BIG) ? " big_table=1" : "") << "\n";
   o << "device.first_stream=" << (d.fa_bytes ? "yes" : ("no: " + hp.first_stream_why_not))

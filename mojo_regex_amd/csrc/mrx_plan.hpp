@@ -67,6 +67,10 @@ struct DevPlan {
   // kind 2: cls[256] u8, trans[st_nstates][1 << st_cshift] u16 = (next << st_cshift) << 2 | EMIT << 1 | NEWSTART,
   // accept[st_nstates] u8
   int32_t off_stg_cls, off_stg_trans, off_stg_acc, st_cshift, stg_bytes;
+  // kind 2 with a reset byte and a small class count: pair[st_nstates][1 << 2 st_cshift] u32 -- two bytes
+  // per dependent lookup: (row offset of the state after both bytes) << 4 | flags of byte 1 << 2 | flags
+  // of byte 0, indexed by row offset + (class of byte 0 << st_cshift | class of byte 1); -1: none
+  int32_t off_stg_pair;
   // synchronising bytes of the search automaton: sync[b] != 0 when byte b takes EVERY state to the
   // same state with the same start (idle, or a new start at b) -- after such a byte the walk does not
   // depend on what came before, so a long text can be cut there (st_nsync = how many, 0 = no table)
