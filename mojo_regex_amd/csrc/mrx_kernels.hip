@@ -786,8 +786,9 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
     }
     pmask[x] = make_uint4(w[0], w[1], w[2], w[3]);
   }
-  // (not for pieces: a piece that is not the last of its text must not end a match at its end)
-  const bool use_fill = MODE != ST_FIRST && !VIRT && p.st_reset_byte >= 0;
+  // (a piece that is not the last of its text must not end a match at its end: its walk simply runs on
+  // into the bytes behind it -- they are the text's own -- and the events from there on are dropped)
+  const bool use_fill = MODE != ST_FIRST && p.st_reset_byte >= 0;
   const uint32_t fillw = (uint32_t)(p.st_reset_byte & 0xFF) * 0x01010101u;
   extern __shared__ __align__(16) uint8_t stg_lds[];  // AUTO == 2: cls | trans | accept
   if (AUTO == 1) {
@@ -968,7 +969,8 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
         const uint4 wv = *(const uint4*)(tile + lane * kRowPitch + g * 16);
         uint32_t words[4] = {wv.x, wv.y, wv.z, wv.w};
         if (use_fill && !all_inside) {   // wave uniform
-          const int a = min(max(lo - g * 16, 0), 16), b = min(max(lim - g * 16, 0), 16);   // inside: [a, b)
+          const int limf = (VIRT && !(vsk >> 31)) ? 0x3FFFFFFF : lim;   // no fill behind a piece that is not the last
+          const int a = min(max(lo - g * 16, 0), 16), b = min(max(limf - g * 16, 0), 16);   // inside: [a, b)
           const uint4 pa = pmask[a], pb = pmask[b > a ? b : a];
           const uint32_t m[4] = {pb.x & ~pa.x, pb.y & ~pa.y, pb.z & ~pa.z, pb.w & ~pa.w};
 #pragma unroll
@@ -1045,6 +1047,10 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
         if (VIRT) {
           const int dsk = skip - gbase;
           if (dsk > 0) { em &= dsk >= 16 ? 0u : ~((1u << (2 * dsk)) - 1u); F = ns | em; }
+          if (use_fill && !(vsk >> 31)) {   // the events at and behind my piece's end are the next piece's
+            const int de = my_len - gbase;
+            if (de < 16) { em &= de <= 0 ? 0u : ((1u << (2 * de)) - 1u); F = ns | em; }
+          }
         }
         if (MRX_ABLATE & 16) { cnt += (F == 0x12345u); continue; }
         if (MODE == ST_RECORDS && REC32) {
@@ -2109,7 +2115,7 @@ void launch_stream(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d
   const bool table = kind == 2;
   const bool wide = kind == 3;
   // class table walked two bytes per lookup (plans with a reset byte; never the anchored automaton, never pieces)
-  const bool pairs = MODE != ST_FIRST && table && p.off_stg_pair >= 0 && !d_vlen && g_pair_tables;
+  const bool pairs = MODE != ST_FIRST && table && p.off_stg_pair >= 0 && g_pair_tables;
   const size_t lds = wide ? 2048 : !table ? 0 : (size_t)(MODE == ST_FIRST ? p.fa_bytes : p.stg_bytes);
 #define MRX_LAUNCH_R(AUTO, CSR, R32)                                                              \
   hipLaunchKernelGGL((k_stream_findall<MODE, (AUTO == 2 ? MRX_STREAM_CHUNK_TABLE : MRX_STREAM_CHUNK), AUTO, CSR, 0, R32>), grid, block, lds, s, p, \
@@ -2127,7 +2133,8 @@ void launch_stream(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d
   hipLaunchKernelGGL((k_stream_findall<MODE, (AUTO == 2 ? MRX_STREAM_CHUNK_TABLE : MRX_STREAM_CHUNK), AUTO, 1, 1>), grid, block, lds, s, p, \
                      h->d_blob, lay.data, lay.stride, lay.lens, lay.len, lay.offsets, n, d_counts, \
                      d_nrecs, d_recs, rec_row, d_s, d_e, d_vlen, d_vskip)
-      if (table) MRX_LAUNCH_V(2);
+      if (pairs) MRX_LAUNCH_V(4);
+      else if (table) MRX_LAUNCH_V(2);
       else if (wide) MRX_LAUNCH_V(3);
       else MRX_LAUNCH_V(1);
 #undef MRX_LAUNCH_V
