@@ -788,7 +788,10 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
   }
   // (a piece that is not the last of its text must not end a match at its end: its walk simply runs on
   // into the bytes behind it -- they are the text's own -- and the events from there on are dropped)
-  const bool use_fill = MODE != ST_FIRST && p.st_reset_byte >= 0;
+  // (not in the count-only variants of the one-byte class table and the wide columns -- plans without a
+  // pair table, rare: there the compiler hoists the mask lookups of all eight groups and ends up at 200+
+  // VGPRs; they keep the per-byte predicates)
+  const bool use_fill = MODE != ST_FIRST && p.st_reset_byte >= 0 && !(MODE == ST_COUNT && (AUTO == 2 || AUTO == 3));
   const uint32_t fillw = (uint32_t)(p.st_reset_byte & 0xFF) * 0x01010101u;
   extern __shared__ __align__(16) uint8_t stg_lds[];  // AUTO == 2: cls | trans | accept
   if (AUTO == 1) {
@@ -2114,9 +2117,10 @@ void launch_stream(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d
   const int kind = MODE == ST_FIRST ? p.fa_kind : p.st_kind;   // automaton form of this mode
   const bool table = kind == 2;
   const bool wide = kind == 3;
-  // class table walked two bytes per lookup (plans with a reset byte; never the anchored automaton, never pieces)
-  const bool pairs = MODE != ST_FIRST && table && p.off_stg_pair >= 0 && g_pair_tables;
-  const size_t lds = wide ? 2048 : !table ? 0 : (size_t)(MODE == ST_FIRST ? p.fa_bytes : p.stg_bytes);
+  // class table walked two bytes per lookup (plans with a reset byte; never the anchored automaton)
+  const bool pairs = MODE != ST_FIRST && (table || wide) && p.off_stg_pair >= 0 && g_pair_tables;
+  const size_t lds = pairs ? (size_t)p.stg_bytes
+                           : wide ? 2048 : !table ? 0 : (size_t)(MODE == ST_FIRST ? p.fa_bytes : p.stg_bytes);
 #define MRX_LAUNCH_R(AUTO, CSR, R32)                                                              \
   hipLaunchKernelGGL((k_stream_findall<MODE, (AUTO == 2 ? MRX_STREAM_CHUNK_TABLE : MRX_STREAM_CHUNK), AUTO, CSR, 0, R32>), grid, block, lds, s, p, \
                      h->d_blob, lay.data, lay.stride, lay.lens, lay.len, lay.offsets, n, d_counts, \
@@ -2140,12 +2144,12 @@ void launch_stream(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d
 #undef MRX_LAUNCH_V
     }
   } else if (!strided_fast(lay)) {
-    if (table && pairs) { if constexpr (MODE != ST_FIRST) MRX_LAUNCH(4, 1); }
+    if (pairs) { if constexpr (MODE != ST_FIRST) MRX_LAUNCH(4, 1); }
     else if (table) MRX_LAUNCH(2, 1);
     else if (wide) MRX_LAUNCH(3, 1);
     else MRX_LAUNCH(1, 1);
   } else {
-    if (table && pairs) { if constexpr (MODE != ST_FIRST) MRX_LAUNCH(4, 0); }
+    if (pairs) { if constexpr (MODE != ST_FIRST) MRX_LAUNCH(4, 0); }
     else if (table) MRX_LAUNCH(2, 0);
     else if (wide) MRX_LAUNCH(3, 0);
     else MRX_LAUNCH(1, 0);
