@@ -1342,6 +1342,51 @@ __global__ __launch_bounds__(kBlock) void k_decode(int64_t n, const int32_t* __r
   }
 }
 
+// match_first of a "one or more bytes of a class" plan on long texts (DevPlan::off_fa_run): the match is
+// the run of class bytes at 0, so a wavefront sweeps its text 1 KiB at a time and stops at the first byte
+// outside the class instead of one lane walking it all (the reference's range_* / predefined_word
+// benchmarks: one 10 KB match per text).
+__global__ __launch_bounds__(kBlock) void k_first_run(DevPlan p, const uint8_t* __restrict__ blob, Layout lay, int64_t n,
+                                                      int32_t* __restrict__ out_s, int32_t* __restrict__ out_e) {
+  __shared__ uint8_t in_cls[256];
+  for (int b = threadIdx.x; b < 256; b += blockDim.x) in_cls[b] = blob[p.off_fa_run + b];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  for (int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); i < n; i += nwaves) {
+    const Text t = lay.text(i);
+    int run = t.len;   // no byte outside the class: the whole text
+    if (t.len > 0) {
+      const uintptr_t addr = (uintptr_t)t.ptr;
+      const int mis = (int)(addr & 15);
+      const uint8_t* frame = (const uint8_t*)(addr & ~(uintptr_t)15);
+      const int end = mis + t.len;
+      for (int blk = 0; blk < end; blk += 1024) {
+        const int o = blk + 16 * lane;
+        uint32_t bad = 0;   // bit k: frame byte o + k is text and outside the class
+        if (o < end) {
+          const uint4 v = mrx_ldg((const uint4*)(frame + o));
+          const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int k = 0; k < 16; ++k)
+            if (!in_cls[(w4[k >> 2] >> ((k & 3) * 8)) & 0xFFu]) bad |= 1u << k;
+          const int lo = mis - o, hi = end - o;
+          if (lo > 0) bad &= lo >= 16 ? 0u : ~((1u << lo) - 1u);
+          if (hi < 16) bad &= hi <= 0 ? 0u : ((1u << hi) - 1u);
+        }
+        const uint64_t any = __ballot(bad != 0u);
+        if (any) {
+          const int w = __builtin_ctzll(any);
+          const int pos = __builtin_amdgcn_readlane(o + (bad ? __builtin_ctz(bad) : 0), w);
+          run = pos - mis;
+          break;
+        }
+      }
+    }
+    if (lane == 0) { out_s[i] = run > 0 ? 0 : -1; out_e[i] = run > 0 ? run : -1; }
+  }
+}
+
 // ---- long texts in pieces (k_stream_findall VIRT) -------------------------------------------
 // Text t is cut every C bytes; piece k owns the text bytes [k C, min(len, (k + 1) C)) and starts its
 // walk at the last synchronising byte before k C, at most kVirtBack bytes back.  A cut without such
@@ -2719,6 +2764,16 @@ static int run_first_any(const mrx_handle* h, const Layout& lay, int64_t n, int3
   if (!h->hp.why_no_match_first.empty()) return fail(MRX_E_UNSUPPORTED, h->hp.why_no_match_first);
   if (int rc = ensure_device(h)) return rc;
   hipStream_t s = (hipStream_t)st;
+  // a single class run on long texts of a fixed-pitch batch: a wavefront per text (k_first_run)
+  if (p.off_fa_run >= 0 && !lay.offsets && g_long_text_mode != 2 &&
+      (g_long_text_mode == 1 || ((lay.lens ? lay.stride : (int64_t)lay.len) >= 2048 && n <= 131072))) {
+    ScanTimer tm(s);
+    hipLaunchKernelGGL(k_first_run, dim3(grid_for(n * 64, kBlock)), dim3(kBlock), 0, s, p, h->d_blob, lay, n, ds, de);
+    g_last_kernel = "k_first_run";
+    HIP_TRY(hipGetLastError());
+    tm.stop();
+    return MRX_OK;
+  }
   ScanTimer tm(s);
   launch_stream<ST_FIRST>(h, lay, n, nullptr, nullptr, nullptr, 0, ds, de, s);
   g_last_kernel = "k_stream_first";

@@ -749,7 +749,7 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
   //   otherwise          the table walk (dfa.mojo:1979-2024 / pikevm.mojo:819-867)
   d.fa_bytes = 0; d.fa_nstates = 0; d.fa_start_acc = 0; d.off_fa_cls = d.off_fa_trans = -1; d.fa_cshift = 0;
   d.off_fa_end = -1;
-  d.fa_kind = 0; d.off_fa_col = -1;
+  d.fa_kind = 0; d.off_fa_col = -1; d.off_fa_run = -1;
   hp.first_stream_why_not.clear();
   if (d.kind == PLAN_ANY) hp.first_stream_why_not = "'.*' shortcut";
   else if (!hp.why_no_match_first.empty()) hp.first_stream_why_not = hp.why_no_match_first;
@@ -839,6 +839,21 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
       d.fa_bytes = (int)hp.blob.size() - begin;
       d.fa_kind = narrow ? 1 : 3;
       d.fa_nstates = nl; d.fa_start_acc = A[0];
+      if (nl == 2 && !A[order[0]] && A[order[1]]) {
+        // start -C-> s, s -C-> s over one byte class C, nothing else: match_first = the run of C at 0
+        bool run = true;
+        std::array<uint8_t, 256> in{};
+        for (int c = 0; c < 256 && run; ++c) {
+          const int t0 = N[order[0]][c], t1 = N[order[1]][c];
+          in[c] = t0 >= 0;
+          run = (t0 >= 0) == (t1 >= 0) && (t0 < 0 || (remap[t0] == 1 && remap[t1] == 1));
+        }
+        if (run) {
+          d.off_fa_run = (int)hp.blob.size();
+          put(hp.blob, in.data(), 256);
+          align(hp.blob, 16);
+        }
+      }
     } else if ((int64_t)(nl + 1) * ncp > 8192) {
       hp.first_stream_why_not = "anchored automaton too large for the streaming kernel's LDS table";
     } else {
@@ -948,7 +963,8 @@ std::string describe_plan(const HostPlan& hp) {
   o << "device.steppable=" << ((d.flags & PF_STEPPABLE) ? "yes" : (d.flags & PF_STEP_REQ) ? "required-byte route" : "no")
     << " step_search=" << ((d.flags & PF_STEP_SEARCH) ? 1 : 0) << ((d.flags & PF_STEP_BIG) ? " big_table=1" : "") << "\n";
   o << "device.first_stream=" << (d.fa_bytes ? "yes" : ("no: " + hp.first_stream_why_not))
-    << " fa_nstates=" << d.fa_nstates << " fa_kind=" << d.fa_kind << (hp.first_onepass ? " onepass=yes" : "") << "\n";
+    << " fa_nstates=" << d.fa_nstates << " fa_kind=" << d.fa_kind << (hp.first_onepass ? " onepass=yes" : "")
+    << (d.off_fa_run >= 0 ? " class_run=1" : "") << "\n";
   if (d.flags & PF_BITSET)
     o << "device.bitset=yes positions=" << d.bs_npos << " words=" << d.bs_nw << " byte_classes=" << d.bs_ncls << "\n";
   return o.str();

@@ -84,6 +84,9 @@ struct DevPlan {
   // OnePass '$' fixup (onepass.mojo:480-484): u8 per state (dead row included), consulted when the
   // walk reaches the end of the text alive; -1 = the automaton has no such flags
   int32_t off_fa_end;
+  // the anchored automaton is "one or more bytes of a class" (start -C-> s, s -C-> s, s accepts): u8[256]
+  // membership table; match_first is then the length of the class run at 0 (k_first_run); -1: not so
+  int32_t off_fa_run;
   // fa_kind: 2 = class table (above), 1 / 3 = byte-column forms as for the search automaton
   // (u16 / u64 columns at off_fa_col; the dead state is the last field, entry = next | ACC << 1)
   int32_t fa_kind, off_fa_col;

@@ -952,6 +952,42 @@ def test_outliers_of_a_ragged_batch_on_the_stepper(pat):
     assert int(cnt[0].item()) >= 1 and int(cnt[77777].item()) >= 1
 
 
+@pytest.mark.parametrize("pat", [b"[a-z]+", b"\\w+", b"\\d+", b"a+", b"[a-zA-Z0-9]+"])
+@pytest.mark.parametrize("pitch", [4096, 3001, 64])
+def test_match_first_of_a_class_run_with_a_wavefront_per_text(pat, pitch):
+    """k_first_run (match_first = the run of class bytes at 0, one wavefront per text) against the anchored
+    walk of the streaming kernel and the oracle: runs that end in the first block, in a later one, at the
+    end of the text, empty runs, empty texts, unaligned pitch."""
+    _need_gpu()
+    rx = M.compile_regex(pat)
+    assert "class_run=1" in rx.describe()
+    lib = M.load_library()
+    rng = np.random.default_rng(zlib.crc32(pat) + pitch)
+    n = 70
+    arr = rng.choice(np.frombuffer(b"abcxyzABC0123456789_ -", dtype=np.uint8), size=(n, pitch)).astype(np.uint8)
+    fill = {b"\\d+": b"7", b"a+": b"a"}.get(pat, b"q")
+    lens = rng.integers(0, pitch + 1, size=n).astype(np.int32)
+    for i in range(0, n, 3):       # long runs: up to the whole text
+        k = int(rng.integers(0, pitch + 1))
+        arr[i, :k] = fill[0]
+    lens[0], lens[1] = pitch, 0
+    arr[0, :] = fill[0]
+    sb = M.DeviceBatch.strided(torch.from_numpy(arr).cuda().reshape(-1), pitch, length=pitch,
+                               lens=torch.from_numpy(lens).cuda())
+    with long_text_kernels(1):
+        s1, e1 = rx.match_first(sb)
+        assert lib.mrx_last_kernel_name() == b"k_first_run"
+    with long_text_kernels(2):
+        s2, e2 = rx.match_first(sb)
+        assert lib.mrx_last_kernel_name() == b"k_stream_first"
+    assert torch.equal(s1, s2) and torch.equal(e1, e2)
+    s1, e1 = s1.cpu().numpy(), e1.cpu().numpy()
+    for i in range(n):
+        w = O.match_first(pat, arr[i, :lens[i]].tobytes())
+        assert (int(s1[i]), int(e1[i])) == (w if w else (-1, -1)), (pat, i)
+    assert int(e1[0]) == pitch and int(e1[1]) == -1
+
+
 @pytest.mark.parametrize("pat", EXACT_LITERALS)
 def test_exact_literal_kmp_streaming(pat):
     """HybridMatcher's exact-literal bypass (matcher.mojo:768-781, 815-847) on the streaming kernel:
