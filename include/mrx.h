@@ -114,6 +114,9 @@ int mrx_search_strided_dev(const mrx_handle* h, const uint8_t* d_data, int64_t s
 int mrx_is_match_dev(const mrx_handle* h, const uint8_t* d_data,
                      const int64_t* d_offsets, int64_t n, uint8_t* d_flag,
                      void* stream);
+int mrx_is_match_strided_dev(const mrx_handle* h, const uint8_t* d_data, int64_t stride,
+                             const int32_t* d_lens, int32_t len, int64_t n, uint8_t* d_flag,
+                             void* stream);
 /* regex.findall(pattern, text), matcher.mojo:1341-1354.
  * d_counts_prefix[n+1]: exclusive prefix sum of matches per text (CSR);
  * d_spans[2*k], d_spans[2*k+1] = start, end of match k (text-relative), in text

@@ -72,6 +72,7 @@ def load_library():
         "mrx_search_strided_dev": (C.c_int, [H, u8p, C.c_int64, i32p, C.c_int32, C.c_int64, i32p, i32p,
                                              C.c_void_p]),
         "mrx_is_match_dev": (C.c_int, [H, u8p, i64p, C.c_int64, u8p, C.c_void_p]),
+        "mrx_is_match_strided_dev": (C.c_int, [H, u8p, C.c_int64, i32p, C.c_int32, C.c_int64, u8p, C.c_void_p]),
         "mrx_findall_dev": (C.c_int, [H, u8p, i64p, C.c_int64, i64p, i32p, C.c_int64,
                                       C.POINTER(C.c_int64), C.c_void_p]),
         "mrx_findall_strided_dev": (C.c_int, [H, u8p, C.c_int64, i32p, C.c_int32, C.c_int64, i64p,
@@ -110,7 +111,7 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "mrx_compile", "mrx_compile_ex", "mrx_free", "mrx_last_error", "mrx_engine_type", "mrx_stats", "mrx_describe",
     "mrx_num_groups", "mrx_match_first_dev", "mrx_search_dev", "mrx_match_first_strided_dev",
-    "mrx_search_strided_dev", "mrx_is_match_dev",
+    "mrx_search_strided_dev", "mrx_is_match_dev", "mrx_is_match_strided_dev",
     "mrx_findall_dev", "mrx_findall_strided_dev", "mrx_count_dev", "mrx_count_strided_dev",
     "mrx_captures_strided_dev", "mrx_captures_dev",
     "mrx_sub_dev", "mrx_match_first_batch", "mrx_search_batch", "mrx_is_match_batch",
@@ -283,8 +284,12 @@ class CompiledRegex:
         if isinstance(texts, DeviceBatch):   # device tensor uint8[n]
             import torch
             f = torch.empty(texts.n, dtype=torch.uint8, device=texts.data.device)
-            _check(self._lib.mrx_is_match_dev(self._h, _ptr(texts.data), _ptr(texts.csr_offsets()), texts.n, _ptr(f),
-                                              self._stream_ptr()))
+            if texts.offsets is not None:
+                _check(self._lib.mrx_is_match_dev(self._h, _ptr(texts.data), _ptr(texts.offsets), texts.n, _ptr(f),
+                                                  self._stream_ptr()))
+            else:
+                _check(self._lib.mrx_is_match_strided_dev(self._h, _ptr(texts.data), texts.stride, _ptr(texts.lens),
+                                                          texts.length, texts.n, _ptr(f), self._stream_ptr()))
             return f
         data, offsets = pack_texts(texts)
         n = len(offsets) - 1

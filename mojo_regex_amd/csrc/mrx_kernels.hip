@@ -2805,14 +2805,13 @@ int mrx_match_first_strided_dev(const mrx_handle* h, const uint8_t* d, int64_t s
   if (!lens && (len < 0 || len > stride)) return fail(MRX_E_ARGUMENT, "len must be in [0, stride]");
   return run_first_any(h, Layout{d, nullptr, stride, lens, len}, n, ds, de, st);
 }
-int mrx_is_match_dev(const mrx_handle* h, const uint8_t* d, const int64_t* off, int64_t n,
-                     uint8_t* f, void* st) {
+static int run_is_match_any(const mrx_handle* h, const Layout& lay, int64_t n, uint8_t* f, void* st) {
   if (h && h->hp.first_onepass && n > 0) {
     // NFA-routed: is_match = match_first(text, 0) is not None (matcher.mojo:721-731)
     hipStream_t s = (hipStream_t)st;
     int32_t* tmp = nullptr;
     HIP_TRY(scratch_alloc((void**)&tmp, sizeof(int32_t) * 2 * n, s));
-    int rc = run_first_any(h, Layout{d, off, 0, nullptr, 0}, n, tmp, tmp + n, st);
+    int rc = run_first_any(h, lay, n, tmp, tmp + n, st);
     if (rc == MRX_OK) {
       hipLaunchKernelGGL(k_span_to_flag, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, n, tmp, f);
       HIP_TRY(hipGetLastError());
@@ -2820,7 +2819,18 @@ int mrx_is_match_dev(const mrx_handle* h, const uint8_t* d, const int64_t* off, 
     HIP_TRY(scratch_free(tmp, s));
     return rc;
   }
-  return run_match<OP_IS_MATCH>(h, Layout{d, off, 0, nullptr, 0}, n, nullptr, nullptr, f, st);
+  return run_match<OP_IS_MATCH>(h, lay, n, nullptr, nullptr, f, st);
+}
+int mrx_is_match_dev(const mrx_handle* h, const uint8_t* d, const int64_t* off, int64_t n,
+                     uint8_t* f, void* st) {
+  if (!off) return fail(MRX_E_ARGUMENT, "null offsets");
+  return run_is_match_any(h, Layout{d, off, 0, nullptr, 0}, n, f, st);
+}
+int mrx_is_match_strided_dev(const mrx_handle* h, const uint8_t* d, int64_t stride, const int32_t* lens,
+                             int32_t len, int64_t n, uint8_t* f, void* st) {
+  if (stride <= 0) return fail(MRX_E_ARGUMENT, "stride must be positive");
+  if (!lens && (len < 0 || len > stride)) return fail(MRX_E_ARGUMENT, "len must be in [0, stride]");
+  return run_is_match_any(h, Layout{d, nullptr, stride, lens, len}, n, f, st);
 }
 static int run_captures_any(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* spans, void* st) {
   if (!h) return fail(MRX_E_ARGUMENT, "null handle");

@@ -988,6 +988,23 @@ def test_match_first_of_a_class_run_with_a_wavefront_per_text(pat, pitch):
     assert int(e1[0]) == pitch and int(e1[1]) == -1
 
 
+@pytest.mark.parametrize("pat", [b"[a-z]+", b"\\d+", b"hello", b"[a-z]+\\d+", b"^\\d+$", b"^[a-z]+[0-9]+$"])
+def test_is_match_on_fixed_pitch_batches(pat):
+    """mrx_is_match_strided_dev equals the CSR entry point and the oracle (is_match quirk included)."""
+    _need_gpu()
+    rx = M.compile_regex(pat)
+    rng = np.random.default_rng(zlib.crc32(pat) + 2)
+    n, pitch = 90, 41
+    arr = rng.choice(np.frombuffer(b"abhelo0123456789+-. ", dtype=np.uint8), size=(n, pitch)).astype(np.uint8)
+    lens = rng.integers(0, pitch + 1, size=n).astype(np.int32)
+    texts = [arr[i, :lens[i]].tobytes() for i in range(n)]
+    sb = M.DeviceBatch.strided(torch.from_numpy(arr).cuda().reshape(-1), pitch, length=pitch, lens=torch.from_numpy(lens).cuda())
+    got = rx.is_match(sb).cpu().numpy().astype(bool).tolist()
+    assert got == [bool(x) for x in rx.is_match(texts)]
+    orx = O.compile_regex(pat)
+    assert got == [bool(orx.is_match(t)) for t in texts]
+
+
 @pytest.mark.parametrize("pat", EXACT_LITERALS)
 def test_exact_literal_kmp_streaming(pat):
     """HybridMatcher's exact-literal bypass (matcher.mojo:768-781, 815-847) on the streaming kernel:
