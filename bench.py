@@ -2,7 +2,10 @@
 """bench.py -- BASELINE.json's headline metric on MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by torch.distributed.run, one rank per GPU)
+  N > 1: one rank per GPU under torch.distributed.run.  Started WITHOUT the torchrun
+  environment (WORLD_SIZE unset) the script starts the N ranks itself, as fresh child
+  processes, before anything in this process touches the GPU, and exits with their code.
+  WORLD_SIZE != --gpus is an error (never a silent 1-GPU run).
 
 Workload (BASELINE.json configs[1]): findall of `[a-z]+\\d+` over 2^20 synthetic
 1 KiB ASCII texts PER GPU (SURVEY.md 8(d) mix: 40 % full / 30 % tokens / 20 % noise
@@ -84,6 +87,29 @@ def measured_traffic(n: int, L: int):
     return best
 
 
+def launch_ranks(n: int, share: bool) -> int:
+    """Start `python -m torch.distributed.run --nproc-per-node n bench.py <same args>` as a child
+    process (one rank per GPU over RCCL) and return its exit code.  Called before this process has
+    made any HIP call; the parent only waits."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()   # counts devices without initialising the GPU
+    if have < n and not share:
+        print("bench.py: --gpus %d but this node has %d GPU(s) (MRX_BENCH_SHARE_GPU=1 rehearses the "
+              "N-rank flow on fewer GPUs over gloo)" % (n, have), file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -105,21 +131,33 @@ def main():
                          "spans to every rank); reported as an extra object, never as `value`")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    share = bool(os.environ.get("MRX_BENCH_SHARE_GPU"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # Not under torchrun: start the ranks as fresh children.  Nothing in this process has
+        # touched the GPU yet (device_count() does not initialise it on this image).
+        sys.exit(launch_ranks(args.gpus, share))
+
     import torch
     import mojo_regex_amd as M
     from mojo_regex_amd import dist as D
     from mojo_regex_amd.workloads import make_c2_batch
 
     rank, local_rank, world = D.env_world()
-    if world != args.gpus and world > 1:
-        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+    if world != args.gpus:
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d): refusing to report a %d-rank run as --gpus %d"
+                         % (world, args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    # MRX_BENCH_BACKEND=gloo + MRX_BENCH_SHARE_GPU=1: rehearsal of the N>1 flow on a box with
-    # fewer GPUs than ranks (ranks share cuda:0, rendezvous over gloo).  The driver's real
-    # runs use one GPU per rank and nccl (= RCCL).
-    backend = os.environ.get("MRX_BENCH_BACKEND", "nccl")
-    dev_index = local_rank % torch.cuda.device_count() if os.environ.get("MRX_BENCH_SHARE_GPU") else local_rank
+    # MRX_BENCH_SHARE_GPU=1: rehearsal of the N>1 flow on a box with fewer GPUs than ranks (ranks
+    # share the GPUs round-robin, rendezvous over gloo -- RCCL refuses two ranks on one device).
+    # The driver's real runs use one GPU per rank and nccl (= RCCL).
+    backend = os.environ.get("MRX_BENCH_BACKEND", "gloo" if share else "nccl")
+    if not share and world > torch.cuda.device_count():
+        raise SystemExit("%d ranks but %d GPU(s) (MRX_BENCH_SHARE_GPU=1 rehearses on fewer)"
+                         % (world, torch.cuda.device_count()))
+    dev_index = local_rank % torch.cuda.device_count() if share else local_rank
     torch.cuda.set_device(dev_index)
     dev = "cuda:%d" % dev_index
     if world > 1:
@@ -181,32 +219,60 @@ def main():
                                      "matches": float(total) * args.steps},
                     device=dev if backend == "nccl" else "cpu")
 
+    # ---- N > 1, weak run: the same job at FIXED TOTAL size next to it (strong scaling) ----------
+    # One 1-GPU batch (--texts texts in all) split over the ranks by contiguous index ranges; same
+    # barrier + max-over-ranks timing.  Extra object `strong`, never `value`.
+    strong_info = None
+    if world > 1 and not args.strong:
+        lo, hi = D.shard_range(args.texts, rank, world)
+        ns = hi - lo
+        sbatch = M.DeviceBatch.strided(batch_t[:ns].reshape(-1), L, length=L)
+        sout = (prefix[:ns + 1], spans)
+        for _ in range(args.warmup + 8):
+            rx.findall_async(sbatch, sout)
+        torch.cuda.synchronize()
+        D.barrier(world, dev if backend == "nccl" else None)
+        s0 = time.perf_counter()
+        for _ in range(args.steps):
+            rx.findall_async(sbatch, sout)
+        torch.cuda.synchronize()
+        D.barrier(world, dev if backend == "nccl" else None)
+        sel = time.perf_counter() - s0
+        sagg = D.combine(world, sel, {"bytes": float(ns) * L * args.steps},
+                         device=dev if backend == "nccl" else "cpu")
+        strong_info = {"value": round(sagg["bytes"] / sagg["elapsed_s"] / 1e9, 3), "unit": "GB/s",
+                       "ms_per_step": round(sagg["elapsed_s"] / args.steps * 1e3, 4),
+                       "total_texts": args.texts, "texts_per_gpu": ns,
+                       "note": "fixed total job (one GPU's batch) split over the ranks; each rank's "
+                               "share is the prefix of its weak-run batch"}
+        for _ in range(2):   # put the arena back into the weak run's shape for the legs below
+            step()
+        torch.cuda.synchronize()
+
     # ---- optional: scan + results exchange (results stay sharded in the headline) -----
     gather_info = None
     if args.gather and world > 1:
-        try:
-            gsteps = max(3, min(args.steps, 10))
-            gdev = dev if backend == "nccl" else None
-            def gstep():
-                rx.findall_async(batch, out)
-                tot = int(prefix[n].item())          # the exchange needs the per-rank totals
-                return D.gather_spans(world, prefix, spans, tot)
+        # (no try/except: a rank that left the exchange alone would leave the others blocked in it)
+        gsteps = max(3, min(args.steps, 10))
+        gdev = dev if backend == "nccl" else None
+        def gstep():
+            rx.findall_async(batch, out)
+            tot = int(prefix[n].item())          # the exchange needs the per-rank totals
+            return D.gather_spans(world, prefix, spans, tot)
+        gp, gs = gstep()
+        torch.cuda.synchronize()
+        D.barrier(world, gdev)
+        g0 = time.perf_counter()
+        for _ in range(gsteps):
             gp, gs = gstep()
-            torch.cuda.synchronize()
-            D.barrier(world, gdev)
-            g0 = time.perf_counter()
-            for _ in range(gsteps):
-                gp, gs = gstep()
-            torch.cuda.synchronize()
-            D.barrier(world, gdev)
-            gel = time.perf_counter() - g0
-            gagg = D.combine(world, gel, {"bytes": float(n) * L * gsteps}, device=dev if backend == "nccl" else "cpu")
-            gather_info = {"ms_per_step": round(gagg["elapsed_s"] / gsteps * 1e3, 4),
-                           "GBps_scan_plus_gather": round(gagg["bytes"] / gagg["elapsed_s"] / 1e9, 3),
-                           "gathered_span_bytes_per_rank": int(gs.shape[0]) * 8,
-                           "global_texts": int(gp.shape[0]) - 1, "steps": gsteps}
-        except Exception as e:  # the headline line must survive a failing exchange
-            gather_info = {"error": "%s: %s" % (type(e).__name__, e)}
+        torch.cuda.synchronize()
+        D.barrier(world, gdev)
+        gel = time.perf_counter() - g0
+        gagg = D.combine(world, gel, {"bytes": float(n) * L * gsteps}, device=dev if backend == "nccl" else "cpu")
+        gather_info = {"ms_per_step": round(gagg["elapsed_s"] / gsteps * 1e3, 4),
+                       "GBps_scan_plus_gather": round(gagg["bytes"] / gagg["elapsed_s"] / 1e9, 3),
+                       "gathered_span_bytes_per_rank": int(gs.shape[0]) * 8,
+                       "global_texts": int(gp.shape[0]) - 1, "steps": gsteps, "backend": backend}
 
     # ---- roofline of the dominant kernel: HIP events on its own launch stream -------
     lib.mrx_timing_enable(1)
@@ -247,7 +313,9 @@ def main():
             "metric": "GB/s input scanned + matches/sec, 1M x 1KiB batch, [a-z]+\\d+ DFA",
             "value": round(value, 3), "unit": "GB/s",
             "matches_per_s": round(agg["matches"] / agg["elapsed_s"], 1),
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "steps": args.steps,
+            # every untimed step before the timed region: the settle phase plus the W asked for
+            "warmup": args.settle + args.warmup, "warmup_requested": args.warmup,
             "ms_per_step": round(agg["elapsed_s"] / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
@@ -275,6 +343,8 @@ def main():
             line["other_ops"] = other
         if gather_info is not None:
             line["scan_plus_gather"] = gather_info
+        if strong_info is not None:
+            line["strong"] = strong_info
         if world == 1 and not args.no_cpu_baseline:
             m = min(args.cpu_sample, n)
             host = batch_t[:m].cpu().numpy()

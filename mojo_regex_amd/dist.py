@@ -85,6 +85,9 @@ def all_gather_v(local, rows_per_rank: List[int]):
     import torch.distributed as dist
     world, rank = dist.get_world_size(), dist.get_rank()
     assert len(rows_per_rank) == world and local.shape[0] == rows_per_rank[rank]
+    if dist.get_backend() != "nccl" and local.is_cuda:
+        # gloo rehearsal with device-resident results: exchange through host memory
+        return all_gather_v(local.cpu(), rows_per_rank).to(local.device)
     out = torch.empty((sum(rows_per_rank),) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     views, lo = [], 0
     for r in range(world):

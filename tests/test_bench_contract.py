@@ -21,7 +21,8 @@ def test_bench_prints_one_contract_line():
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["unit"] == "GB/s" and d["dtype"] == "u8" and d["data"] == "synthetic" and d["vs_baseline"] is None
-    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup_requested"] == 1 and d["scaling"] == "weak"
+    assert d["warmup"] == 1 + d["config"]["settle_steps"]   # every untimed step is counted
     assert "workload" in d["config"] and "model" not in d["config"]
     rf = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):

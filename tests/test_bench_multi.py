@@ -1,0 +1,53 @@
+"""bench.py --gpus N: never a silent 1-GPU run.  Without the torchrun environment the script starts
+its N ranks itself; WORLD_SIZE != --gpus is an error.  The GPU test rehearses N = 2 on the one-GPU
+box (ranks share cuda:0 over gloo; RCCL refuses two ranks on one device) and runs the results
+exchange of SURVEY.md 8(e)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env(**kw):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(kw)
+    return env
+
+
+def test_world_size_mismatch_is_an_error():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "4"], capture_output=True, text=True, timeout=300,
+                       env=_env(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0
+    assert "WORLD_SIZE (2) != --gpus (4)" in (r.stderr + r.stdout)
+
+
+def test_more_ranks_than_gpus_is_an_error_not_a_smaller_run():
+    import torch
+    have = torch.cuda.device_count()
+    r = subprocess.run([sys.executable, BENCH, "--gpus", str(have + 1) if have else "2"], capture_output=True, text=True,
+                       timeout=300, env=_env())
+    assert r.returncode != 0
+    assert "GPU(s)" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+@pytest.mark.gpu
+def test_two_ranks_self_launched_with_results_exchange():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--gather", "--texts", "16384", "--steps", "3",
+                        "--warmup", "1", "--settle", "2"], capture_output=True, text=True, timeout=900,
+                       env=_env(MRX_BENCH_SHARE_GPU="1"))
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 3
+    assert d["config"]["texts_per_gpu"] == 16384
+    g = d["scan_plus_gather"]
+    assert "error" not in g and g["global_texts"] == 2 * 16384 and g["ms_per_step"] > 0
+    s = d["strong"]
+    assert s["total_texts"] == 16384 and s["texts_per_gpu"] == 8192 and s["value"] > 0
+    assert "cpu_baseline" not in d   # rank 0 at N = 1 only
