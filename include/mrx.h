@@ -193,20 +193,6 @@ int mrx_sub_batch(const mrx_handle* h, const char* repl, size_t repl_len, int64_
  * entry points with total == NULL never synchronise. */
 void mrx_release_scratch(void);
 
-/* ---- measurement hooks -------------------------------------------------------- */
-/* Average duration (ms) of the dominant scan kernel over the launches made by
- * this thread since the last reset, measured with HIP events on the launch
- * stream; launches = number of scan-kernel launches measured. */
-void mrx_timing_reset(void);
-void mrx_timing_enable(int on);
-double mrx_timing_scan_ms(int64_t* launches);
-const char* mrx_last_kernel_name(void);
-/* Testing aid: route every call to the generic lane-per-text kernels (the streaming kernel is
- * then never used) so that the two implementations can be compared on the same batch. */
-void mrx_debug_force_generic(int on);
-/* Testing aid: the kernels that put one wavefront (instead of one lane) on a text are chosen by the
- * batch's average text length; 1 = always use them, 2 = never, 0 = by length. */
-void mrx_debug_long_text_kernels(int mode);
 const char* mrx_version(void);
 
 #ifdef __cplusplus

@@ -1,0 +1,38 @@
+/*
+ * mrx_testing.h -- measurement and testing hooks of libmrx_hip.so.
+ *
+ * NOT part of the drop-in boundary (include/mrx.h): nothing here corresponds to a reference
+ * interface.  bench.py uses the timing hooks for the roofline object; the parity tests use the
+ * debug switches to run one batch through two kernel families and compare them text by text.
+ * The switches are process-wide; set them while no call is in flight.
+ */
+#ifndef MRX_TESTING_H
+#define MRX_TESTING_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Average duration (ms) of the dominant scan kernel over the launches made by
+ * this thread since the last reset, measured with HIP events on the launch
+ * stream; launches = number of scan-kernel launches measured. */
+void mrx_timing_reset(void);
+void mrx_timing_enable(int on);
+double mrx_timing_scan_ms(int64_t* launches);
+const char* mrx_last_kernel_name(void);
+/* Testing aid: route every call to the generic lane-per-text kernels (the streaming kernel is
+ * then never used) so that the two implementations can be compared on the same batch. */
+void mrx_debug_force_generic(int on);
+/* Testing aid: the kernels that put one wavefront (instead of one lane) on a text are chosen by the
+ * batch's average text length; 1 = always use them, 2 = never, 0 = by length. */
+void mrx_debug_long_text_kernels(int mode);
+/* Bytes of device memory the calling thread's scratch arenas hold (see mrx_release_scratch). */
+size_t mrx_debug_scratch_bytes(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MRX_TESTING_H */

@@ -98,6 +98,7 @@ def load_library():
         "mrx_debug_force_generic": (None, [C.c_int]),
         "mrx_debug_long_text_kernels": (None, [C.c_int]),
         "mrx_release_scratch": (None, []),
+        "mrx_debug_scratch_bytes": (C.c_size_t, []),
         "mrx_version": (C.c_char_p, []),
     }
     for name, (res, args) in sigs.items():
@@ -108,6 +109,7 @@ def load_library():
     return lib
 
 
+# include/mrx.h (the drop-in boundary) and include/mrx_testing.h (measurement / testing hooks)
 EXPORTED_SYMBOLS = [
     "mrx_compile", "mrx_compile_ex", "mrx_free", "mrx_last_error", "mrx_engine_type", "mrx_stats", "mrx_describe",
     "mrx_num_groups", "mrx_match_first_dev", "mrx_search_dev", "mrx_match_first_strided_dev",
@@ -115,9 +117,11 @@ EXPORTED_SYMBOLS = [
     "mrx_findall_dev", "mrx_findall_strided_dev", "mrx_count_dev", "mrx_count_strided_dev",
     "mrx_captures_strided_dev", "mrx_captures_dev",
     "mrx_sub_dev", "mrx_match_first_batch", "mrx_search_batch", "mrx_is_match_batch",
-    "mrx_findall_batch", "mrx_captures_batch", "mrx_sub_batch", "mrx_timing_reset",
-    "mrx_timing_enable", "mrx_timing_scan_ms", "mrx_last_kernel_name", "mrx_version", "mrx_debug_force_generic", "mrx_release_scratch",
-    "mrx_debug_long_text_kernels",
+    "mrx_findall_batch", "mrx_captures_batch", "mrx_sub_batch", "mrx_version", "mrx_release_scratch",
+]
+TESTING_SYMBOLS = [
+    "mrx_timing_reset", "mrx_timing_enable", "mrx_timing_scan_ms", "mrx_last_kernel_name",
+    "mrx_debug_force_generic", "mrx_debug_long_text_kernels", "mrx_debug_scratch_bytes",
 ]
 
 
@@ -156,16 +160,38 @@ class DeviceBatch:
     """
 
     def __init__(self, data, offsets=None, *, stride: int = 0, length: int = 0, lens=None, n=None):
+        import torch
+        if data.dtype != torch.uint8 or not data.is_contiguous():
+            raise MrxError("batch data must be a contiguous uint8 tensor")
         self.data, self.offsets, self.stride, self.length, self.lens = data, offsets, stride, length, lens
         if offsets is not None:
+            if offsets.dtype != torch.int64 or not offsets.is_contiguous() or offsets.device != data.device:
+                raise MrxError("offsets must be a contiguous int64 tensor on the data's device")
+            if offsets.numel() < 1:
+                raise MrxError("offsets needs n + 1 entries")
             self.n = int(offsets.numel()) - 1
         else:
             self.n = int(n)
 
     @classmethod
-    def strided(cls, data, stride: int, length: int = 0, lens=None):
+    def strided(cls, data, stride: int, length: Optional[int] = None, lens=None):
+        """Texts at a fixed pitch: text i = data[i*stride : i*stride + (lens[i] | length)].  Exactly one
+        of `length` (common to all texts) and `lens` (int32[n] on the data's device) must be given;
+        lens[i] <= stride is the caller's contract (the kernels read lens[i] bytes of row i)."""
+        import torch
+        stride = int(stride)
+        if stride <= 0 or data.numel() % stride:
+            raise MrxError("data size %d is not a multiple of the stride %d" % (data.numel(), stride))
         n = data.numel() // stride
-        return cls(data, None, stride=stride, length=length, lens=lens, n=n)
+        if (length is None) == (lens is None):
+            raise MrxError("give either length= or lens=")
+        if lens is not None:
+            if lens.dtype != torch.int32 or not lens.is_contiguous() or lens.device != data.device or lens.numel() != n:
+                raise MrxError("lens must be a contiguous int32[n] tensor on the data's device")
+            length = 0
+        elif not 0 <= int(length) <= stride:
+            raise MrxError("length must be in [0, stride]")
+        return cls(data, None, stride=stride, length=int(length), lens=lens, n=n)
 
     @classmethod
     def from_texts(cls, texts: Sequence, device="cuda"):
@@ -280,7 +306,9 @@ class CompiledRegex:
 
     search = match_next
 
-    def is_match(self, texts) -> np.ndarray:
+    def is_match(self, texts):
+        """CompiledRegex.is_match(text, 0): uint8[n] -- numpy for host texts, a device tensor for a
+        DeviceBatch."""
         if isinstance(texts, DeviceBatch):   # device tensor uint8[n]
             import torch
             f = torch.empty(texts.n, dtype=torch.uint8, device=texts.data.device)
@@ -298,9 +326,12 @@ class CompiledRegex:
                                             f.ctypes.data))
         return f
 
-    def test(self, texts) -> np.ndarray:
-        """CompiledRegex.test (matcher.mojo:1091-1101): does search() match."""
+    def test(self, texts):
+        """CompiledRegex.test (matcher.mojo:1091-1101): does search() match.  bool[n]: numpy for host
+        texts, a device tensor for a DeviceBatch."""
         s, _ = self.match_next(texts)
+        if isinstance(texts, DeviceBatch):
+            return s >= 0
         return (np.asarray(s) >= 0)
 
     def match_all(self, texts):

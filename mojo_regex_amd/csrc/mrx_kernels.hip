@@ -13,6 +13,7 @@
 //   k_scan_*           exclusive prefix sums (counts -> CSR offsets)
 // All tables are staged from the plan blob into LDS once per workgroup.
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <map>
 #include <type_traits>
 #include <unordered_map>
@@ -25,6 +26,7 @@
 #include <vector>
 
 #include "../../include/mrx.h"
+#include "../../include/mrx_testing.h"
 #include "mrx_device.hpp"
 
 using namespace mrx;
@@ -1834,11 +1836,16 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_add(int64_t* __restrict__ o
 // ============================================================================
 // host side
 // ============================================================================
+// The compiled tables live once per device that has used the handle (uploaded on first use there,
+// never freed or replaced before mrx_free): concurrent calls on one handle from threads bound to
+// different GPUs each see their own device's copy.
+constexpr int kMaxDevices = 64;
 struct mrx_handle {
   HostPlan hp;
-  uint8_t* d_blob = nullptr;
-  int device = -1;
+  std::atomic<uint8_t*> d_blobs[kMaxDevices];
+  std::mutex mu;   // serialises the first upload per device
   std::string describe_cache;
+  mrx_handle() { for (auto& b : d_blobs) b.store(nullptr, std::memory_order_relaxed); }
 };
 
 namespace {
@@ -1850,9 +1857,10 @@ thread_local int64_t g_scan_launches = 0;
 thread_local const char* g_last_kernel = "";
 // mrx_debug_force_generic(): route every call to the generic lane-per-text kernels (tests compare
 // the two implementations; never set in production)
-int g_pair_tables = 1;      // MRX_NO_PAIR_TABLES=1 in the environment: measure the one-byte class table
-int g_long_text_mode = 0;   // mrx_debug_long_text_kernels(): 0 by average length, 1 always, 2 never
-int g_force_generic = 0;   // 0 best kernel, 1 no streaming kernel, 2 literal restatement (mrx_device.hpp) only
+// (process-wide switches of include/mrx_testing.h; relaxed atomics: set while no call is in flight)
+std::atomic<int> g_pair_tables{1};      // MRX_NO_PAIR_TABLES=1 in the environment: measure the one-byte class table
+std::atomic<int> g_long_text_mode{0};   // mrx_debug_long_text_kernels(): 0 by average length, 1 always, 2 never
+std::atomic<int> g_force_generic{0};   // 0 best kernel, 1 no streaming kernel, 2 literal restatement (mrx_device.hpp) only
 
 int fail(int code, const std::string& msg) {
   g_err = msg;
@@ -1876,6 +1884,7 @@ struct ScratchArena {
   struct Chunk { uint8_t* base; size_t cap, used; };
   std::vector<Chunk> chunks;
   int live = 0;
+  int depth = 0;   // nested ScratchScopes (entry points call each other)
 };
 // keyed by (device, stream): the null stream of two devices must not share an arena
 thread_local std::map<std::pair<int, hipStream_t>, ScratchArena> g_scratch;
@@ -1924,6 +1933,26 @@ hipError_t scratch_free(void* p, hipStream_t s) {
     for (auto& c : a.chunks) c.used = 0;
   return hipSuccess;
 }
+// One per API call (entry points nest: sub -> findall): whatever exit path the outermost call takes,
+// bad-argument and HIP-error returns included, its allocations are returned to the arena, so the
+// next call reuses the same bytes instead of growing the arena.
+struct ScratchScope {
+  ScratchArena& a;
+  explicit ScratchScope(hipStream_t s) : a(scratch_arena(s)) { ++a.depth; }
+  ~ScratchScope() {
+    if (--a.depth == 0 && a.live != 0) {
+      a.live = 0;
+      for (auto& c : a.chunks) c.used = 0;
+    }
+  }
+  ScratchScope(const ScratchScope&) = delete;
+  ScratchScope& operator=(const ScratchScope&) = delete;
+};
+size_t scratch_bytes_reserved() {   // testing: total bytes held by the calling thread's arenas
+  size_t t = 0;
+  for (auto& kv : g_scratch) for (auto& c : kv.second.chunks) t += c.cap;
+  return t;
+}
 void scratch_release_all() {
   int cur = 0;
   (void)hipGetDevice(&cur);
@@ -1936,24 +1965,45 @@ void scratch_release_all() {
   g_scratch.clear();
 }
 
+// The calling thread's current device, set by ensure_device() at the start of every entry point;
+// H_BLOB(h) is the handle's table copy on that device.
+thread_local int t_dev = 0;
+#define H_BLOB(h) ((h)->d_blobs[t_dev].load(std::memory_order_acquire))
+
 int ensure_device(const mrx_handle* hc) {
   mrx_handle* h = const_cast<mrx_handle*>(hc);
-  static std::mutex mu;
-  std::lock_guard<std::mutex> lk(mu);
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
-  if (h->d_blob && h->device == dev) return MRX_OK;
-  if (h->d_blob) { (void)hipFree(h->d_blob); h->d_blob = nullptr; }
-  HIP_TRY(hipMalloc((void**)&h->d_blob, h->hp.blob.size()));
-  HIP_TRY(hipMemcpy(h->d_blob, h->hp.blob.data(), h->hp.blob.size(), hipMemcpyHostToDevice));
-  h->device = dev;
+  if (dev < 0 || dev >= kMaxDevices) return fail(MRX_E_NO_DEVICE, "device ordinal out of range");
+  t_dev = dev;
+  if (h->d_blobs[dev].load(std::memory_order_acquire)) return MRX_OK;
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (h->d_blobs[dev].load(std::memory_order_acquire)) return MRX_OK;
+  uint8_t* p = nullptr;
+  HIP_TRY(hipMalloc((void**)&p, h->hp.blob.size()));
+  const hipError_t e = hipMemcpy(p, h->hp.blob.data(), h->hp.blob.size(), hipMemcpyHostToDevice);
+  if (e != hipSuccess) { (void)hipFree(p); return fail(MRX_E_NO_DEVICE, std::string("hipMemcpy: ") + hipGetErrorString(e)); }
+  h->d_blobs[dev].store(p, std::memory_order_release);
   return MRX_OK;
+}
+
+// workgroups that fill the current device: 8 per CU (CU count queried once per device)
+int grid_cap() {
+  static std::atomic<int> cus[kMaxDevices];
+  int c = cus[t_dev].load(std::memory_order_relaxed);
+  if (c <= 0) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, t_dev) != hipSuccess || v <= 0) v = 256;
+    cus[t_dev].store(v, std::memory_order_relaxed);
+    c = v;
+  }
+  return c * 8;
 }
 
 int grid_for(int64_t n, int block) {
   int64_t g = (n + block - 1) / block;
   if (g < 1) g = 1;
-  const int64_t cap = 256 * 8;  // 256 CUs x 8 workgroups
+  const int64_t cap = grid_cap();
   return (int)(g < cap ? g : cap);
 }
 
@@ -2001,22 +2051,22 @@ int req_wave_pays(const Layout& lay, int64_t n, bool req_route, hipStream_t s, b
 int reqwave_grid(int64_t n) {
   int64_t g = (n + kRqWaves - 1) / kRqWaves;
   if (g < 1) g = 1;
-  return (int)(g < 256 * 8 ? g : 256 * 8);
+  return (int)(g < grid_cap() ? g : grid_cap());
 }
 // (a bool `use_req_route` in scope, as for MRX_WSTEP_LAUNCH)
 #define MRX_REQWAVE_LAUNCH(MODE, H, LAY, N, COUNTS, PREFIX, SPANS, CAP, S)                                       \
   do {                                                                                                           \
     if (use_req_route)                                                                                           \
       hipLaunchKernelGGL((k_req_wave<MODE, 1>), dim3(reqwave_grid(N)), dim3(64 * kRqWaves),                      \
-                         reqwave_table_bytes((H)->hp.dev.nstates), S, (H)->hp.dev, (H)->d_blob, LAY, N, COUNTS,  \
+                         reqwave_table_bytes((H)->hp.dev.nstates), S, (H)->hp.dev, H_BLOB(H), LAY, N, COUNTS,  \
                          PREFIX, SPANS, CAP, (int32_t*)nullptr, (int32_t*)nullptr);                              \
     else if ((H)->hp.dev.flags & PF_STEP_BIG)                                                                    \
       hipLaunchKernelGGL((k_req_wave<MODE, 0, 1>), dim3(reqwave_grid(N)), dim3(64 * kRqWaves),                   \
-                         reqwave_big_bytes((H)->hp.dev.nstates, (H)->hp.dev.ncls), S, (H)->hp.dev, (H)->d_blob,  \
+                         reqwave_big_bytes((H)->hp.dev.nstates, (H)->hp.dev.ncls), S, (H)->hp.dev, H_BLOB(H),  \
                          LAY, N, COUNTS, PREFIX, SPANS, CAP, (int32_t*)nullptr, (int32_t*)nullptr);              \
     else                                                                                                         \
       hipLaunchKernelGGL((k_req_wave<MODE, 0>), dim3(reqwave_grid(N)), dim3(64 * kRqWaves),                      \
-                         reqwave_table_bytes((H)->hp.dev.nstates), S, (H)->hp.dev, (H)->d_blob, LAY, N, COUNTS,  \
+                         reqwave_table_bytes((H)->hp.dev.nstates), S, (H)->hp.dev, H_BLOB(H), LAY, N, COUNTS,  \
                          PREFIX, SPANS, CAP, (int32_t*)nullptr, (int32_t*)nullptr);                              \
   } while (0)
 
@@ -2024,7 +2074,7 @@ int wstep_grid(int64_t n) {
   const int64_t nw = (n + 63) / 64;
   int64_t g = (nw + kWsWaves - 1) / kWsWaves;
   if (g < 1) g = 1;
-  return (int)(g < 256 * 8 ? g : 256 * 8);
+  return (int)(g < grid_cap() ? g : grid_cap());
 }
 
 struct ScanTimer {  // HIP events around the dominant scan kernel, on its own stream
@@ -2079,6 +2129,7 @@ int check_lds(const mrx_handle* h) {
 template <int OP>
 int run_match(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d_s, int32_t* d_e,
               uint8_t* d_flag, void* stream) {
+  ScratchScope scratch_scope_((hipStream_t)stream);
   if (!h) return fail(MRX_E_ARGUMENT, "null handle");
   if (n < 0) return fail(MRX_E_ARGUMENT, "negative batch size");
   if (OP == OP_MATCH_FIRST || OP == OP_IS_MATCH) {
@@ -2107,33 +2158,33 @@ int run_match(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d_s, i
     lay2.split = split;
     if (big && !wave) {   // many short texts: the literal restatement, one lane per text
       hipLaunchKernelGGL(k_match<OP>, dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s, h->hp.dev,
-                         h->d_blob, lay, n, d_s, d_e, d_flag);
+                         H_BLOB(h), lay, n, d_s, d_e, d_flag);
       g_last_kernel = "k_match";
     } else if (big) {
       hipLaunchKernelGGL((k_req_wave<STEP_SEARCH, 0, 1>), dim3(reqwave_grid(n)), dim3(64 * kRqWaves),
-                         reqwave_big_bytes(h->hp.dev.nstates, h->hp.dev.ncls), s, h->hp.dev, h->d_blob, lay, n,
+                         reqwave_big_bytes(h->hp.dev.nstates, h->hp.dev.ncls), s, h->hp.dev, H_BLOB(h), lay, n,
                          (int32_t*)nullptr, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0, d_s, d_e);
       g_last_kernel = "k_req_wave_search";
     } else if (wave) {
       hipLaunchKernelGGL((k_req_wave<STEP_SEARCH, 0>), dim3(reqwave_grid(n)), dim3(64 * kRqWaves),
-                         reqwave_table_bytes(h->hp.dev.nstates), s, h->hp.dev, h->d_blob, lay, n, (int32_t*)nullptr,
+                         reqwave_table_bytes(h->hp.dev.nstates), s, h->hp.dev, H_BLOB(h), lay, n, (int32_t*)nullptr,
                          (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0, d_s, d_e);
       g_last_kernel = "k_req_wave_search";
     } else {
     hipLaunchKernelGGL((k_wstep<STEP_SEARCH, 0>), dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_table_bytes(h->hp.dev.nstates), s, h->hp.dev,
-                       h->d_blob, lay2, n, (int32_t*)nullptr, (const int64_t*)nullptr, (int32_t*)nullptr,
+                       H_BLOB(h), lay2, n, (int32_t*)nullptr, (const int64_t*)nullptr, (int32_t*)nullptr,
                        (int64_t)0, d_s, d_e);
     g_last_kernel = "k_step_search";
     if (split > 0) {   // the few very long texts of the batch
       hipLaunchKernelGGL((k_req_wave<STEP_SEARCH, 0>), dim3(reqwave_grid(n)), dim3(64 * kRqWaves),
-                         reqwave_table_bytes(h->hp.dev.nstates), s, h->hp.dev, h->d_blob, lay2, n, (int32_t*)nullptr,
+                         reqwave_table_bytes(h->hp.dev.nstates), s, h->hp.dev, H_BLOB(h), lay2, n, (int32_t*)nullptr,
                          (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0, d_s, d_e);
       g_last_kernel = "k_step_search+k_req_wave_search";
     }
     }
   } else {
     hipLaunchKernelGGL(k_match<OP>, dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s, h->hp.dev,
-                       h->d_blob, lay, n, d_s, d_e, d_flag);
+                       H_BLOB(h), lay, n, d_s, d_e, d_flag);
     g_last_kernel = "k_match";
   }
   HIP_TRY(hipGetLastError());
@@ -2141,6 +2192,9 @@ int run_match(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d_s, i
   return MRX_OK;
 }
 
+// longest text the event records of the streaming findall can describe (see run_findall)
+constexpr int64_t kStreamMaxText = int64_t(1) << 26;
+bool stream_text_too_long(int64_t max_text) { return max_text >= kStreamMaxText; }
 // can this batch layout go through the streaming kernel?
 bool stream_layout_ok(const Layout&, int64_t n) { return n > 0; }  // every layout has a streaming form
 // fixed pitch, 16-byte aligned, 64 rows within 32-bit offsets: the fast strided form; otherwise the
@@ -2157,7 +2211,7 @@ void launch_stream(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d
   const DevPlan& p = h->hp.dev;
   const int64_t nw = (n + 63) / 64;
   int64_t g = (nw + kStreamWaves - 1) / kStreamWaves;
-  if (g > 256 * 8) g = 256 * 8;
+  if (g > grid_cap()) g = grid_cap();
   const dim3 grid((unsigned)g), block(64 * kStreamWaves);
   const int kind = MODE == ST_FIRST ? p.fa_kind : p.st_kind;   // automaton form of this mode
   const bool table = kind == 2;
@@ -2168,7 +2222,7 @@ void launch_stream(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d
                            : wide ? 2048 : !table ? 0 : (size_t)(MODE == ST_FIRST ? p.fa_bytes : p.stg_bytes);
 #define MRX_LAUNCH_R(AUTO, CSR, R32)                                                              \
   hipLaunchKernelGGL((k_stream_findall<MODE, (AUTO == 2 ? MRX_STREAM_CHUNK_TABLE : MRX_STREAM_CHUNK), AUTO, CSR, 0, R32>), grid, block, lds, s, p, \
-                     h->d_blob, lay.data, lay.stride, lay.lens, lay.len, lay.offsets, n, d_counts, \
+                     H_BLOB(h), lay.data, lay.stride, lay.lens, lay.len, lay.offsets, n, d_counts, \
                      d_nrecs, d_recs, rec_row, d_s, d_e)
 #define MRX_LAUNCH(AUTO, CSR)                                                                     \
   do {                                                                                            \
@@ -2180,7 +2234,7 @@ void launch_stream(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d
     if constexpr (MODE == ST_RECORDS || MODE == ST_COUNT || MODE == ST_SEARCH) {
 #define MRX_LAUNCH_V(AUTO)                                                                        \
   hipLaunchKernelGGL((k_stream_findall<MODE, (AUTO == 2 ? MRX_STREAM_CHUNK_TABLE : MRX_STREAM_CHUNK), AUTO, 1, 1>), grid, block, lds, s, p, \
-                     h->d_blob, lay.data, lay.stride, lay.lens, lay.len, lay.offsets, n, d_counts, \
+                     H_BLOB(h), lay.data, lay.stride, lay.lens, lay.len, lay.offsets, n, d_counts, \
                      d_nrecs, d_recs, rec_row, d_s, d_e, d_vlen, d_vskip)
       if (pairs) MRX_LAUNCH_V(4);
       else if (table) MRX_LAUNCH_V(2);
@@ -2297,7 +2351,7 @@ int pieces_prepare(const mrx_handle* h, const Layout& lay, int64_t n, hipStream_
   HIP_TRY(scratch_alloc((void**)&pc->vskip, sizeof(uint32_t) * pc->nv, s));
   HIP_TRY(scratch_alloc((void**)&pc->vbase, sizeof(int32_t) * pc->nv, s));
   HIP_TRY(scratch_alloc((void**)&pc->back, sizeof(int32_t) * pc->nv, s));
-  const uint8_t* sync = h->d_blob + p.off_st_sync;
+  const uint8_t* sync = H_BLOB(h) + p.off_st_sync;
   hipLaunchKernelGGL(k_virt_check, dim3(grid_for(pc->nv, kBlock)), dim3(kBlock), 0, s, lay, n, pc->vfirst, pc->nv, C, sync,
                      pc->back);
   hipLaunchKernelGGL(k_virt_fill, dim3(grid_for(pc->nv, kBlock)), dim3(kBlock), 0, s, lay, n, pc->vfirst, pc->nv, C,
@@ -2364,6 +2418,7 @@ int findall_pieces(const mrx_handle* h, const Pieces& pc, int64_t n, int64_t* d_
 
 int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_prefix,
                 int32_t* d_spans, int64_t span_cap, int64_t* total, void* stream, bool match_next_sequence = false) {
+  ScratchScope scratch_scope_((hipStream_t)stream);
   if (!h) return fail(MRX_E_ARGUMENT, "null handle");
   if (n < 0 || span_cap < 0) return fail(MRX_E_ARGUMENT, "negative size");
   if (int rc = check_search_supported(h)) return rc;
@@ -2375,7 +2430,7 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
   HIP_TRY(scratch_alloc((void**)&d_counts, sizeof(int32_t) * (n > 0 ? n : 1), s));
   HIP_TRY(scratch_alloc((void**)&d_total, sizeof(int64_t), s));
   const DevPlan& p = h->hp.dev;
-  const bool stream_ok = !g_force_generic && (p.flags & PF_STREAMABLE) && stream_layout_ok(lay, n);
+  bool stream_ok = !g_force_generic && (p.flags & PF_STREAMABLE) && stream_layout_ok(lay, n);
   // match_next_sequence: the caller (sub) wants the matches that iterating match_next from each
   // match end visits -- the plain walk even on plans whose findall takes the required-byte route
   const bool use_req_route = (p.flags & PF_STEP_REQ) && !match_next_sequence;
@@ -2398,6 +2453,11 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
     if (int rc = csr_stats(lay, n, s, &csr_total, &csr_max)) return rc;
     if (csr_total < 0) return fail(MRX_E_ARGUMENT, "offsets[n] is negative");
   }
+  // An event record counts the matches of its text in front of it in 26 bits (kRecBeforeMask), and a
+  // text of 2^26 bytes can hold that many (one-byte matches, no synchronising byte to cut at): such
+  // texts take the lane-per-text kernels, whose span cursor is 64 bits wide.
+  if (stream_ok && stream_text_too_long(lay.offsets ? csr_max : (lay.lens ? lay.stride : (int64_t)lay.len)))
+    stream_ok = false;
   if (n > 0 && stream_ok)
     if (int rc = pieces_prepare(h, lay, n, s, &pc, csr_total, csr_max)) return rc;
   const bool by_pieces = pc.on;
@@ -2460,7 +2520,7 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
         else
         {
         MRX_WSTEP_LAUNCH(STEP_SLOTS, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_table_bytes(h->hp.dev.nstates), s, p,
-                           h->d_blob, lay2, n, d_counts, (const int64_t*)nullptr, d_slots, (int64_t)0,
+                           H_BLOB(h), lay2, n, d_counts, (const int64_t*)nullptr, d_slots, (int64_t)0,
                            (int32_t*)nullptr, (int32_t*)nullptr);
         if (step_split > 0)
           MRX_REQWAVE_LAUNCH(STEP_SLOTS, h, lay2, n, d_counts, (const int64_t*)nullptr, d_slots, (int64_t)0, s);
@@ -2469,13 +2529,13 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
         MRX_REQWAVE_LAUNCH(STEP_COUNT, h, lay, n, d_counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0, s);
       else if (step_ok) {
         MRX_WSTEP_LAUNCH(STEP_COUNT, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_table_bytes(h->hp.dev.nstates), s, p,
-                           h->d_blob, lay2, n, d_counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0,
+                           H_BLOB(h), lay2, n, d_counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0,
                            (int32_t*)nullptr, (int32_t*)nullptr);
         if (step_split > 0)
           MRX_REQWAVE_LAUNCH(STEP_COUNT, h, lay2, n, d_counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0, s);
       } else
         hipLaunchKernelGGL(k_findall<FA_COUNT>, dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s,
-                           p, h->d_blob, lay, n, d_counts, (const int64_t*)nullptr, (int32_t*)nullptr,
+                           p, H_BLOB(h), lay, n, d_counts, (const int64_t*)nullptr, (int32_t*)nullptr,
                            (int64_t)0);
       g_last_kernel = req_wave ? "k_req_wave" : step_ok ? (step_split > 0 ? "k_step_count+k_req_wave" : "k_step_count")
                                                         : "k_findall_count";
@@ -2529,14 +2589,14 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
         if (req_wave)
           MRX_REQWAVE_LAUNCH(STEP_EMIT, h, lay2, n, d_counts, d_prefix, d_spans, span_cap, s);
         else {
-        MRX_WSTEP_LAUNCH(STEP_EMIT, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_table_bytes(h->hp.dev.nstates), s, p, h->d_blob,
+        MRX_WSTEP_LAUNCH(STEP_EMIT, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_table_bytes(h->hp.dev.nstates), s, p, H_BLOB(h),
                            lay2, n, d_counts, d_prefix, d_spans, span_cap, (int32_t*)nullptr,
                            (int32_t*)nullptr);
         if (step_split > 0) MRX_REQWAVE_LAUNCH(STEP_EMIT, h, lay2, n, d_counts, d_prefix, d_spans, span_cap, s);
         }
       } else
         hipLaunchKernelGGL(k_findall<FA_EMIT>, dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s, p,
-                           h->d_blob, lay, n, (int32_t*)nullptr, d_prefix, d_spans, span_cap);
+                           H_BLOB(h), lay, n, (int32_t*)nullptr, d_prefix, d_spans, span_cap);
     }
     HIP_TRY(hipGetLastError());
   }
@@ -2685,7 +2745,11 @@ int mrx_compile_ex(const char* pattern, size_t pattern_len, uint32_t options, mr
 
 void mrx_free(mrx_handle* h) {
   if (!h) return;
-  if (h->d_blob) (void)hipFree(h->d_blob);
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  for (int d = 0; d < kMaxDevices; ++d)
+    if (uint8_t* p = h->d_blobs[d].load()) { (void)hipSetDevice(d); (void)hipFree(p); }
+  (void)hipSetDevice(cur);
   delete h;
 }
 
@@ -2710,6 +2774,7 @@ size_t mrx_describe(const mrx_handle* h, char* buf, size_t cap) {
 // layout allow it, the generic lane-per-text kernel otherwise
 static int run_search_any(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* ds, int32_t* de,
                           void* st) {
+  ScratchScope scratch_scope_((hipStream_t)st);
   if (!h) return fail(MRX_E_ARGUMENT, "null handle");
   const DevPlan& p = h->hp.dev;
   // '^'-anchored DFA plans: match_next only ever tries position 0 (dfa.mojo:1875-1886), so search is
@@ -2756,6 +2821,7 @@ static int run_search_any(const mrx_handle* h, const Layout& lay, int64_t n, int
 }
 static int run_first_any(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* ds, int32_t* de,
                          void* st) {
+  ScratchScope scratch_scope_((hipStream_t)st);
   if (!h) return fail(MRX_E_ARGUMENT, "null handle");
   const DevPlan& p = h->hp.dev;
   if (n == 0 && h->hp.why_no_match_first.empty()) return MRX_OK;
@@ -2768,7 +2834,7 @@ static int run_first_any(const mrx_handle* h, const Layout& lay, int64_t n, int3
   if (p.off_fa_run >= 0 && !lay.offsets && g_long_text_mode != 2 &&
       (g_long_text_mode == 1 || ((lay.lens ? lay.stride : (int64_t)lay.len) >= 2048 && n <= 131072))) {
     ScanTimer tm(s);
-    hipLaunchKernelGGL(k_first_run, dim3(grid_for(n * 64, kBlock)), dim3(kBlock), 0, s, p, h->d_blob, lay, n, ds, de);
+    hipLaunchKernelGGL(k_first_run, dim3(grid_for(n * 64, kBlock)), dim3(kBlock), 0, s, p, H_BLOB(h), lay, n, ds, de);
     g_last_kernel = "k_first_run";
     HIP_TRY(hipGetLastError());
     tm.stop();
@@ -2806,6 +2872,7 @@ int mrx_match_first_strided_dev(const mrx_handle* h, const uint8_t* d, int64_t s
   return run_first_any(h, Layout{d, nullptr, stride, lens, len}, n, ds, de, st);
 }
 static int run_is_match_any(const mrx_handle* h, const Layout& lay, int64_t n, uint8_t* f, void* st) {
+  ScratchScope scratch_scope_((hipStream_t)st);
   if (h && h->hp.first_onepass && n > 0) {
     // NFA-routed: is_match = match_first(text, 0) is not None (matcher.mojo:721-731)
     hipStream_t s = (hipStream_t)st;
@@ -2833,6 +2900,7 @@ int mrx_is_match_strided_dev(const mrx_handle* h, const uint8_t* d, int64_t stri
   return run_is_match_any(h, Layout{d, nullptr, stride, lens, len}, n, f, st);
 }
 static int run_captures_any(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* spans, void* st) {
+  ScratchScope scratch_scope_((hipStream_t)st);
   if (!h) return fail(MRX_E_ARGUMENT, "null handle");
   const uint32_t fl = h->hp.dev.flags;
   const bool fast_search = (!g_force_generic && (fl & PF_STREAM_SEARCH)) ||
@@ -2876,6 +2944,7 @@ int mrx_findall_strided_dev(const mrx_handle* h, const uint8_t* d, int64_t strid
 }
 
 static int run_count_any(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* counts, void* st) {
+  ScratchScope scratch_scope_((hipStream_t)st);
   if (!h) return fail(MRX_E_ARGUMENT, "null handle");
   if (int rc = check_search_supported(h)) return rc;
   if (int rc = check_lds(h)) return rc;
@@ -2914,7 +2983,7 @@ static int run_count_any(const mrx_handle* h, const Layout& lay, int64_t n, int3
       g_last_kernel = "k_req_wave";
     } else if (g_force_generic < 2 && !big_lane && (h->hp.dev.flags & (PF_STEPPABLE | PF_STEP_REQ))) {
       MRX_WSTEP_LAUNCH(STEP_COUNT, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_table_bytes(h->hp.dev.nstates), s, h->hp.dev,
-                         h->d_blob, lay2, n, counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0,
+                         H_BLOB(h), lay2, n, counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0,
                          (int32_t*)nullptr, (int32_t*)nullptr);
       g_last_kernel = "k_step_count";
       if (split > 0) {
@@ -2923,7 +2992,7 @@ static int run_count_any(const mrx_handle* h, const Layout& lay, int64_t n, int3
       }
     } else {
       hipLaunchKernelGGL(k_findall<FA_COUNT>, dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s,
-                         h->hp.dev, h->d_blob, lay, n, counts, (const int64_t*)nullptr, (int32_t*)nullptr,
+                         h->hp.dev, H_BLOB(h), lay, n, counts, (const int64_t*)nullptr, (int32_t*)nullptr,
                          (int64_t)0);
       g_last_kernel = "k_findall_count";
     }
@@ -2947,6 +3016,7 @@ int mrx_count_strided_dev(const mrx_handle* h, const uint8_t* d, int64_t stride,
 int mrx_sub_dev(const mrx_handle* h, const char* repl, size_t repl_len, int64_t count,
                 const uint8_t* d, const int64_t* off, int64_t n, int64_t* out_off, uint8_t* out,
                 int64_t out_cap, int64_t* total_bytes, void* st) {
+  ScratchScope scratch_scope_((hipStream_t)st);
   if (!h) return fail(MRX_E_ARGUMENT, "null handle");
   if (n < 0) return fail(MRX_E_ARGUMENT, "negative batch size");
   if (int rc = check_search_supported(h)) return rc;
@@ -3003,7 +3073,7 @@ int mrx_sub_dev(const mrx_handle* h, const char* repl, size_t repl_len, int64_t 
   if (n > 0) {
     ScanTimer tm(s);
     hipLaunchKernelGGL(k_sub<SUB_SIZE>, dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s,
-                       h->hp.dev, h->d_blob, lay, n, d_repl, (int)r.size(), groups ? 1 : 0, d_tpl,
+                       h->hp.dev, H_BLOB(h), lay, n, d_repl, (int)r.size(), groups ? 1 : 0, d_tpl,
                        (int)tpl.size(), (long long)count, d_sizes, (const int64_t*)nullptr,
                        (uint8_t*)nullptr, (int64_t)0);
     g_last_kernel = "k_sub_size";
@@ -3020,7 +3090,7 @@ int mrx_sub_dev(const mrx_handle* h, const char* repl, size_t repl_len, int64_t 
     rc = fail(MRX_E_CAPACITY, "output buffer too small: need " + std::to_string(tot));
   } else if (n > 0 && tot > 0) {
     hipLaunchKernelGGL(k_sub<SUB_EMIT>, dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s,
-                       h->hp.dev, h->d_blob, lay, n, d_repl, (int)r.size(), groups ? 1 : 0, d_tpl,
+                       h->hp.dev, H_BLOB(h), lay, n, d_repl, (int)r.size(), groups ? 1 : 0, d_tpl,
                        (int)tpl.size(), (long long)count, (int64_t*)nullptr, out_off, out, out_cap);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s));
@@ -3117,5 +3187,6 @@ const char* mrx_last_kernel_name(void) { return g_last_kernel; }
 void mrx_debug_force_generic(int on) { g_force_generic = on < 0 ? 0 : on > 2 ? 2 : on; }
 void mrx_debug_long_text_kernels(int mode) { g_long_text_mode = mode < 0 ? 0 : mode > 2 ? 0 : mode; }
 void mrx_release_scratch(void) { scratch_release_all(); }
+size_t mrx_debug_scratch_bytes(void) { return scratch_bytes_reserved(); }
 
 }  // extern "C"

@@ -1,5 +1,5 @@
 """GPU parity on the reference's own benchmark list (benchmarks/bench_engine.mojo:578-1100, restated
-as data in mojo_regex_amd/bench_suite.py): every case's operation on the case's text and on rotations
+as data in tests/bench_engine_cases.py): every case's operation on the case's text and on rotations
 of it, bit-exact against the oracle; the cases the reference sends to its backtracking NFA must be
 refused, not approximated."""
 import numpy as np
@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 import mojo_regex_amd as M  # noqa: E402
-from mojo_regex_amd import bench_suite as B  # noqa: E402
+import bench_engine_cases as B  # noqa: E402
 from mojo_regex_amd.api import UnsupportedPattern  # noqa: E402
 from mrx_ref import hybrid as O  # noqa: E402  (oracle: checker only)
 from mrx_ref import UnsupportedByOracle  # noqa: E402

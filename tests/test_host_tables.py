@@ -73,6 +73,11 @@ def test_library_exports_every_header_symbol():
     assert sorted(api.EXPORTED_SYMBOLS) == declared
     for name in declared:
         assert hasattr(lib, name), name
+    hdr = open(os.path.join(ROOT, "include", "mrx_testing.h")).read()
+    hooks = sorted(set(re.findall(r"\b(mrx_[a-z_]+)\s*\(", hdr)))
+    assert sorted(api.TESTING_SYMBOLS) == hooks
+    for name in hooks:
+        assert hasattr(lib, name), name
     assert b"gfx950" in lib.mrx_version()
 
 
@@ -132,7 +137,7 @@ def test_synchronising_bytes_and_long_text_plan_flags():
     literal whose prefix is also a suffix; the class-indexed stepper table beyond 96 states."""
     import re
     from mojo_regex_amd import api as M
-    from mojo_regex_amd import bench_suite as B
+    import bench_engine_cases as B
 
     def line(p, key):
         return re.search(key + r"=[^\n]*", M.CompiledRegex(p).describe()).group(0)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""The reference's benchmark list (mojo_regex_amd/bench_suite.py) on one GPU.
+"""The reference's benchmark list (tests/bench_engine_cases.py) on one GPU.
 
 Each case's text becomes a batch: n rotations of it (row i = the text rotated by 37 i bytes), n chosen
 so that the batch is about 256 MiB (at most 2^20 texts), fixed pitch, device resident.  The case's
@@ -15,9 +15,10 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))   # bench_engine_cases: the reference's benchmark list as data
 import torch  # noqa: E402
 import mojo_regex_amd as M  # noqa: E402
-from mojo_regex_amd import bench_suite as B  # noqa: E402
+import bench_engine_cases as B  # noqa: E402
 from mojo_regex_amd.api import UnsupportedPattern  # noqa: E402
 
 TARGET_BYTES = 256 << 20
