@@ -29,6 +29,11 @@ void mrx_debug_force_generic(int on);
 /* Testing aid: the kernels that put one wavefront (instead of one lane) on a text are chosen by the
  * batch's average text length; 1 = always use them, 2 = never, 0 = by length. */
 void mrx_debug_long_text_kernels(int mode);
+/* findall of streamable plans runs as three launches (scan -> prefix sums -> decode; the default, and
+ * the faster form as measured) or as ONE (scan, CSR offsets by decoupled look-back and spans fused);
+ * same results either way.  0 = three launches, 1 = one launch when a 64-text task has at least
+ * 32 KiB, 2 = one launch for short texts too.  Environment: MRX_FUSED=0|1|2 at compile time. */
+void mrx_debug_fused_findall(int mode);
 /* Bytes of device memory the calling thread's scratch arenas hold (see mrx_release_scratch). */
 size_t mrx_debug_scratch_bytes(void);
 

@@ -20,6 +20,7 @@
 #include <chrono>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -718,6 +719,10 @@ struct EvRec {   // 16 bytes
   uint32_t meta;     // (lane << 26) | matches of this text before this group
 };
 constexpr uint32_t kRecBeforeMask = (1u << 26) - 1u;
+#ifndef MRX_FUSED_BATCH
+#define MRX_FUSED_BATCH 8
+#endif
+constexpr int kFusedBatch = MRX_FUSED_BATCH;   // ST_FUSED: independent record loads in flight per lane
 // REC32: fixed-pitch batches of texts up to kRec32MaxLen bytes.  Positions fit 16 bits, so one 16-byte
 // record carries the event words of TWO adjacent groups (32 text bytes): {F of the even group, F of the
 // odd group, start | (pos_base + 16) << 16, meta}, start / pos_base / matches-before taken at the even
@@ -739,7 +744,210 @@ __host__ __device__ inline int64_t rec_region_start(int64_t first_off, int64_t w
 // ST_SEARCH: first match only (regex.search).  ST_FIRST: regex.match_first -- the plan's anchored
 // automaton (DevPlan::off_fa_*) run from byte 0, EMIT bit = "the state entered accepts"; a lane is
 // finished when it enters the dead state, finished rows are no longer fetched.
-enum { ST_RECORDS = 0, ST_COUNT = 1, ST_SEARCH = 2, ST_FIRST = 3 };
+// ST_FUSED: findall in ONE launch.  As ST_RECORDS, but a wavefront keeps the event records of its 64
+// texts in a region of its own (reused task after task, so the lines stay in L2 / Infinity Cache
+// instead of streaming out to HBM and back), and when it reaches the end of its texts it (1) publishes
+// the number of matches of its 64 texts, (2) obtains the number of matches of all texts before them
+// from the wavefronts that own those texts (decoupled look-back over one 8-byte {status, count}
+// descriptor per 64 texts), and (3) expands its own records straight into their final CSR position --
+// no record stream through HBM, no second and third launch.  64-text tasks are handed out in text
+// order through a ticket counter: a wavefront only ever waits for tasks with lower numbers, and those
+// are held by wavefronts that are already running.
+enum { ST_RECORDS = 0, ST_COUNT = 1, ST_SEARCH = 2, ST_FIRST = 3, ST_FUSED = 4 };
+
+struct FusedArgs {
+  // [0] ticket counter, [1] error word, [2 ..] one descriptor per 64-text task, then two words per
+  // group of 64 tasks (span count + reports so far; running total at the group's start); zeroed per call
+  unsigned long long* ctrl;
+  int64_t* prefix;            // [n + 1] CSR offsets of the texts' spans (output)
+  int32_t* spans;             // [span_cap][2] (output)
+  int64_t span_cap;
+  int64_t* total_out;         // number of spans of the batch
+  int64_t rec_cap;            // records a wavefront's region holds (>= the most one task can produce)
+  int32_t debug;              // measurement only (MRX_FUSED_DEBUG): 1 no record expansion, 2 no look-back, 4 no span stores
+};
+constexpr unsigned long long kDescValid = 1ull << 62, kDescVal = (1ull << 62) - 1ull;
+// group word: bits 0..39 = spans of the group's tasks that have reported, bits 40..47 = how many have
+constexpr int kGroupCountShift = 40;
+constexpr unsigned long long kGroupSumMask = (1ull << kGroupCountShift) - 1ull;
+constexpr uint32_t kLookbackSpinLimit = 1u << 22;   // insurance only: a predecessor is always a running wavefront
+
+// The end of a task's scan: its span count goes out at once, as the task's own descriptor and added
+// to its group's word (64 consecutive tasks form a group; fire-and-forget atomic, one word per group).
+// Every word is one 8-byte relaxed agent-scope access whose value IS the flag, so no fence is involved.
+__device__ __forceinline__ void fused_publish(unsigned long long* ctrl, int64_t w, int64_t nw, uint32_t total, int lane) {
+  if (lane == 0) {
+    unsigned long long* desc = ctrl + 2;
+    __hip_atomic_store(desc + w, kDescValid | (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    (void)__hip_atomic_fetch_add(desc + nw + (w >> 6), (unsigned long long)total + (1ull << kGroupCountShift),
+                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// Spans of all tasks before task w = (tasks of my group before me, one window of task descriptors)
+// + (whole groups before mine, windows of 64 group words, cut short at the nearest group whose first
+// task has already published the running total at the group's start).  Nothing here waits for another
+// wavefront's look-back -- only for scans, and this runs one task late, so as a rule nothing waits at all.
+__device__ __forceinline__ int64_t fused_lookback(unsigned long long* ctrl, int64_t w, int64_t nw, int lane) {
+  unsigned long long* desc = ctrl + 2;
+  unsigned long long* gsum = desc + nw;
+  unsigned long long* ginc = gsum + ((nw + 63) >> 6);
+  const int64_t G = w >> 6;
+  const int r = (int)(w & 63);
+  int64_t base = 0;
+  bool level1 = true;
+  uint32_t spins = 0;
+  for (int64_t g0 = G - 1;;) {
+    unsigned long long d1 = kDescValid;
+    if (level1 && lane < r) d1 = __hip_atomic_load(desc + (w - 1 - lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int64_t g = g0 - lane;
+    unsigned long long gs = 64ull << kGroupCountShift, gi = kDescValid;   // in front of group 0: nothing, total 0
+    if (g >= 0) {
+      gs = __hip_atomic_load(gsum + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      gi = __hip_atomic_load(ginc + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const uint64_t inc_m = __ballot((gi & kDescValid) != 0ull);
+    const int F = inc_m ? __builtin_ctzll(inc_m) : 64;   // nearest group whose starting total is known
+    const bool need = lane <= F;
+    const bool ok = (d1 & kDescValid) != 0ull && (!need || (gs >> kGroupCountShift) == 64ull);
+    if (!__all(ok)) {   // a scan in front of me has not reported yet
+      if (++spins > kLookbackSpinLimit) {
+        if (lane == 0) __hip_atomic_fetch_or(ctrl + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+      continue;
+    }
+    int64_t v = (level1 && lane < r ? (int64_t)(d1 & kDescVal) : 0) + (need ? (int64_t)(gs & kGroupSumMask) : 0) +
+                (lane == F ? (int64_t)(gi & kDescVal) : 0);
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    base += v;
+    level1 = false;
+    if (F < 64) break;
+    g0 -= 64;
+  }
+  if (r == 0 && lane == 0)   // the running total at the start of my group, for the groups behind
+    __hip_atomic_store(ginc + G, kDescValid | (unsigned long long)base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return base;
+}
+
+// A wavefront's own records -> spans at their final CSR position.  lane = record here, so the per-match
+// work is spread evenly whatever the texts look like.  fused_fill_tile places the spans [tb, tb + tile)
+// of the wavefront's range in an LDS tile (the text tile, free once the scan is over) -- that needs my_rel
+// (spans of the wavefront's texts before each lane's) only, so it runs while the look-back is still in
+// flight; fused_store_tile writes the tile out in coalesced 8-byte stores once `base` (spans of all texts
+// before the wavefront's) is known.  DIRECT: a wavefront with more spans than three tiles hold writes
+// them straight to memory instead of re-reading its records once per tile.
+template <bool REC32, bool DIRECT>
+__device__ __forceinline__ void fused_fill_tile(const EvRec* __restrict__ wave_recs, int total_recs, int my_rel, int tb,
+                                                int64_t base, uint8_t* tile_bytes, int tile_nbytes,
+                                                int32_t* __restrict__ spans, int64_t span_cap, int fixed_len, int lane) {
+  using Slot = typename std::conditional<REC32, uint32_t, int2>::type;   // REC32: positions fit 16 bits
+  Slot* tile = (Slot*)tile_bytes;
+  const int tile_cap = tile_nbytes / (int)sizeof(Slot);
+  for (int j = 0; j < total_recs; j += 64 * kFusedBatch) {
+    uint4 rr[kFusedBatch];
+#pragma unroll
+    for (int u = 0; u < kFusedBatch; ++u) {
+      const int o = j + u * 64 + lane;
+      rr[u] = make_uint4(0, 0, 0, 0);
+      if (o < total_recs) rr[u] = mrx_ldg((const uint4*)(wave_recs + o));   // L1 bypassed: my own stores, read from L2
+    }
+#pragma unroll
+    for (int u = 0; u < kFusedBatch; ++u) {
+      const uint4 r = rr[u];   // {F, start, pos_base, meta} / REC32: {F even, F odd, start | (pos + 16) << 16, meta}
+      const int rel_t = __shfl(my_rel, (int)(r.w >> 26));
+      int dst = rel_t + (int)(r.w & kRecBeforeMask) - tb;
+      uint32_t Fw = r.x;
+      int pb = REC32 ? (int)(r.z >> 16) - 16 : (int)r.z;
+      int rstart = REC32 ? (int)(r.z & 0xFFFFu) : (int)r.y;
+#pragma unroll
+      for (int half = 0; half < (REC32 ? 2 : 1); ++half) {
+        uint32_t em = Fw & 0xAAAAAAAAu;
+        const uint32_t ns = Fw & 0x55555555u;
+        while (em) {
+          const int kk = __builtin_ctz(em) >> 1;              // byte of this EMIT
+          const uint32_t nsb = ns & ((1u << (2 * kk)) - 1u);   // NEWSTARTs strictly before it
+          int st = nsb ? pb + ((31 - __builtin_clz(nsb)) >> 1) : rstart;
+          if (fixed_len > 0) st = pb + kk - fixed_len;
+          if (DIRECT) {
+            if (base + dst < span_cap) mrx_stg_span(spans + 2 * (base + dst), st, pb + kk);
+          } else if (dst >= 0 && dst < tile_cap) {
+            if constexpr (REC32) tile[dst] = ((uint32_t)st << 16) | (uint32_t)(pb + kk);
+            else tile[dst] = make_int2(st, pb + kk);
+          }
+          ++dst;
+          em &= em - 1;
+        }
+        if (REC32) {   // on to the odd group
+          if (ns) rstart = pb + ((31 - __builtin_clz(ns)) >> 1);
+          pb += 16;
+          Fw = r.y;
+        }
+      }
+    }
+  }
+}
+template <bool REC32>
+__device__ __forceinline__ void fused_store_tile(const uint8_t* tile_bytes, int cnt, int64_t dst0,
+                                                 int32_t* __restrict__ spans, int64_t span_cap, int lane) {
+  using Slot = typename std::conditional<REC32, uint32_t, int2>::type;
+  const Slot* tile = (const Slot*)tile_bytes;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  for (int k = lane; k < cnt; k += 64) {
+    const int64_t dst = dst0 + k;
+    if (dst < span_cap) {
+      if constexpr (REC32) { const uint32_t v = tile[k]; mrx_stg_span(spans + 2 * dst, (int)(v >> 16), (int)(v & 0xFFFFu)); }
+      else { const int2 v = tile[k]; mrx_stg_span(spans + 2 * dst, v.x, v.y); }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+// Finish a scanned task: base from the look-back, CSR offsets of its 64 texts, its records -> spans.
+template <bool REC32>
+__device__ __forceinline__ void fused_finish(const FusedArgs& fz, const EvRec* __restrict__ wave_recs, int64_t w,
+                                             int64_t nw, int64_t n, int my_cnt, int wrec, uint8_t* tile, int tile_bytes,
+                                             int fixed_len, int lane) {
+  // matches of my texts before this lane's, of the wavefront, and of the batch before the wavefront
+  int incl = my_cnt;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int v_ = __shfl_up(incl, d);
+    if (lane >= d) incl += v_;
+  }
+  const int my_rel = incl - my_cnt;
+  const int total_spans = __shfl(incl, 63);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my record stores have reached L2
+  __builtin_amdgcn_wave_barrier();
+  const int tile_cap = tile_bytes / (REC32 ? 4 : 8);
+  int64_t base;
+  if (total_spans <= tile_cap) {
+    // the usual case: all spans of the wavefront fit one tile -- expand the records while the
+    // look-back is in flight, write the tile out when the base has arrived
+    if (!(fz.debug & 1))
+    fused_fill_tile<REC32, false>(wave_recs, wrec, my_rel, 0, 0, tile, tile_bytes, fz.spans, fz.span_cap, fixed_len, lane);
+    base = (fz.debug & 2) ? 0 : fused_lookback(fz.ctrl, w, nw, lane);
+    if (!(fz.debug & 4))
+    fused_store_tile<REC32>(tile, total_spans, base, fz.spans, fz.span_cap, lane);
+  } else {
+    base = fused_lookback(fz.ctrl, w, nw, lane);
+    if (total_spans > 3 * tile_cap) {
+      fused_fill_tile<REC32, true>(wave_recs, wrec, my_rel, 0, base, tile, tile_bytes, fz.spans, fz.span_cap, fixed_len, lane);
+    } else {
+      for (int tb = 0; tb < total_spans; tb += tile_cap) {
+        fused_fill_tile<REC32, false>(wave_recs, wrec, my_rel, tb, 0, tile, tile_bytes, fz.spans, fz.span_cap, fixed_len, lane);
+        fused_store_tile<REC32>(tile, total_spans - tb < tile_cap ? total_spans - tb : tile_cap, base + tb, fz.spans,
+                                fz.span_cap, lane);
+      }
+    }
+  }
+  const int64_t my_text = (w << 6) + lane;
+  if (my_text < n) fz.prefix[my_text] = base + my_rel;
+  if (my_text == n - 1) { fz.prefix[n] = base + incl; *fz.total_out = base + incl; }
+}
 
 // AUTO = 1: byte-column automaton (<= 4 states, described above).
 // AUTO = 4: the class-table automaton two bytes at a time (DevPlan::off_stg_pair): half as many
@@ -759,13 +967,23 @@ enum { ST_RECORDS = 0, ST_COUNT = 1, ST_SEARCH = 2, ST_FIRST = 3 };
 // first vskip[v] & 0x7FFFFFFF bytes belong to the piece before it and are dropped; bit 31 of vskip
 // marks the last piece of a text (the only one that may end a match at the end of the text).
 template <int MODE, int CH, int AUTO, int CSR, int VIRT = 0, int REC32 = 0>
-__global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
+#ifndef MRX_FUSED_WAVES
+#define MRX_FUSED_WAVES 4
+#endif
+__global__ __launch_bounds__(64 * kStreamWaves, (MODE == ST_FUSED ? MRX_FUSED_WAVES : 1)) void k_stream_findall(
     DevPlan p, const uint8_t* __restrict__ blob, const uint8_t* __restrict__ data, int64_t stride,
     const int32_t* __restrict__ lens, int32_t common_len, const int64_t* __restrict__ offsets,
     int64_t n, int32_t* __restrict__ counts,
     int32_t* __restrict__ wave_nrecs, EvRec* __restrict__ recs, int64_t rec_row,
     int32_t* __restrict__ out_s, int32_t* __restrict__ out_e,
-    const int32_t* __restrict__ vlen = nullptr, const uint32_t* __restrict__ vskip = nullptr) {
+    const int32_t* __restrict__ vlen = nullptr, const uint32_t* __restrict__ vskip = nullptr,
+    const FusedArgs* __restrict__ fzp = nullptr) {
+  // (ST_FUSED's arguments sit in device memory -- written by k_fused_init, which also zeroes the ticket
+  // word and the descriptors -- and are read where they are used, once per task: as kernel arguments
+  // they would be live in scalar registers across the scan loop, which has none to spare)
+#define fz (*fzp)
+  constexpr bool RECS = MODE == ST_RECORDS || MODE == ST_FUSED;   // event records are produced
+  static_assert(!(MODE == ST_FUSED && VIRT), "pieces of long texts keep the three-launch form");
   constexpr int kChunk = CH;
   constexpr int kRowPitch = CH + 16;      // +16: the per-lane 16-byte read-back is bank-conflict free
   constexpr int LPR = CH / 16;            // lanes that cover one text row in a load instruction
@@ -793,6 +1011,16 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
   // (not in the count-only variants of the one-byte class table and the wide columns -- plans without a
   // pair table, rare: there the compiler hoists the mask lookups of all eight groups and ends up at 200+
   // VGPRs; they keep the per-byte predicates)
+  // ST_FUSED: tasks are handed out in text order by a ticket counter, four at a time: ONE atomic per
+  // workgroup and round (asked for wavefront by wavefront, the tickets of a grid queue up at the counter
+  // word for tens of microseconds, and a wavefront's loads cannot complete past its own pending atomic).
+  // Wavefront 0 asks one round ahead and hands the answer over through an LDS ring {round + 1, first task}.
+  __shared__ unsigned long long blk_ticket[4];
+  if (MODE == ST_FUSED && threadIdx.x == 0) {
+    blk_ticket[1] = blk_ticket[2] = blk_ticket[3] = 0ull;
+    blk_ticket[0] = (1ull << 32) | (uint32_t)__hip_atomic_fetch_add(fz.ctrl, (unsigned long long)kStreamWaves, __ATOMIC_RELAXED,
+                                                                    __HIP_MEMORY_SCOPE_AGENT);
+  }
   const bool use_fill = MODE != ST_FIRST && p.st_reset_byte >= 0 && !(MODE == ST_COUNT && (AUTO == 2 || AUTO == 3));
   const uint32_t fillw = (uint32_t)(p.st_reset_byte & 0xFF) * 0x01010101u;
   extern __shared__ __align__(16) uint8_t stg_lds[];  // AUTO == 2: cls | trans | accept
@@ -827,8 +1055,40 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
   const int seg = lane % LPR;
   const int rsub = lane / LPR;
 
-  for (int64_t w = (int64_t)blockIdx.x * kStreamWaves + wave; w < nwaves_total;
-       w += (int64_t)gridDim.x * kStreamWaves) {
+  // ST_FUSED: tasks come from the ticket counter, one 64-text task per ticket, always asked for one
+  // task ahead.  (Several consecutive tasks per ticket would serialise the launch: a ticket's first
+  // task could only learn its base after the previous ticket's owner had scanned ALL its tasks.)
+  // The look-back and the expansion of a task's records run one task LATE, after the scan of the
+  // wavefront's next task: by then the wavefronts in front have long published their counts, so
+  // the differences in speed between wavefronts (every task has to wait for ALL tasks before it) are
+  // absorbed instead of stalling the fast ones.  Two record regions per wavefront, used alternately.
+  unsigned long long tk_next = 0ull;   // wavefront 0: the atomic whose answer is the next round's first task
+  bool tk_asked = false;
+  uint32_t round = 0;
+  bool pend = false;       // a scanned task whose spans are not written yet
+  int64_t pend_w = 0;
+  int pend_cnt = 0, pend_wrec = 0, pend_half = 0, half = 0;
+  for (int64_t w = (int64_t)blockIdx.x * kStreamWaves + wave;; w += (int64_t)gridDim.x * kStreamWaves) {
+    if (MODE == ST_FUSED) {
+      unsigned long long tv;
+      while (true) {
+        tv = *(volatile unsigned long long*)&blk_ticket[round & 3u];
+        if ((uint32_t)(tv >> 32) == round + 1u) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+      const int64_t first = (int64_t)__builtin_amdgcn_readfirstlane((uint32_t)tv);
+      w = first + wave;
+      tk_asked = wave == 0 && first < nwaves_total;
+      if (tk_asked) {   // the next round's tasks: the answer is back long before the scan below is over
+        if (lane == 0)
+          tk_next = __hip_atomic_fetch_add(fz.ctrl, (unsigned long long)kStreamWaves, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("" ::: "memory");
+      } else if (wave == 0 && lane == 0) {   // nothing left: tell the others
+        blk_ticket[(round + 1u) & 3u] = ((unsigned long long)(round + 2u) << 32) | (uint32_t)nwaves_total;
+      }
+      ++round;
+    }
+    if (w >= nwaves_total) break;
     const int64_t base_text = w << 6;
     const int64_t my_text = base_text + lane;
     const bool live = my_text < n;
@@ -900,7 +1160,8 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
     bool done = !live;          // ST_SEARCH / ST_FIRST: this lane has its answer
     int res_s = -1, res_e = (MODE == ST_FIRST && live && p.fa_start_acc) ? 0 : -1;
     EvRec* wave_recs = (MODE == ST_RECORDS)
-        ? recs + ((CSR && offsets) ? rec_region_start(offsets[base_text], w) : base_text * rec_row) : nullptr;
+        ? recs + ((CSR && offsets) ? rec_region_start(offsets[base_text], w) : base_text * rec_row)
+        : (MODE == ST_FUSED) ? recs + (((int64_t)blockIdx.x * kStreamWaves + wave) * 2 + half) * fz.rec_cap : nullptr;
 
     if (MODE == ST_FIRST) {
       // Probe: most anchored walks end within a few bytes.  Every lane reads the first 16 bytes
@@ -960,6 +1221,11 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
       if (MODE == ST_FIRST) {
         skip_rows = __ballot(done || cbase + kChunk >= flen);
         if (__all(done)) break;
+      }
+      if (MODE == ST_FUSED && tk_asked) {   // (wave uniform) the first chunk is here, so is the older atomic's answer
+        const uint32_t nf = __builtin_amdgcn_readfirstlane((uint32_t)tk_next);
+        if (lane == 0) blk_ticket[round & 3u] = ((unsigned long long)(round + 1u) << 32) | nf;
+        tk_asked = false;
       }
       if (!(MRX_ABLATE & 2))
       if (cbase + kChunk < max_len) MRX_LOAD_CHUNK(cbase + kChunk);  // prefetch next chunk
@@ -1058,7 +1324,7 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
           }
         }
         if (MRX_ABLATE & 16) { cnt += (F == 0x12345u); continue; }
-        if (MODE == ST_RECORDS && REC32) {
+        if (RECS && REC32) {
           if ((g & 1) == 0) {
             F_even = F;
             sp_even = (uint32_t)start | ((uint32_t)(gbase + 16) << 16);
@@ -1075,7 +1341,7 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
               wrec += __builtin_popcountll(has);
             }
           }
-        } else if (MODE == ST_RECORDS) {
+        } else if (RECS) {
           const uint64_t has = __ballot(em != 0);
           if (has) {  // wave uniform
             if (em) {
@@ -1109,13 +1375,18 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
       }
       __builtin_amdgcn_wave_barrier();
     }
+    if (MODE == ST_FUSED && tk_asked) {   // a task without a single chunk (64 empty texts)
+      const uint32_t nf = __builtin_amdgcn_readfirstlane((uint32_t)tk_next);
+      if (lane == 0) blk_ticket[round & 3u] = ((unsigned long long)(round + 1u) << 32) | nf;
+      tk_asked = false;
+    }
     // end of text: a walk that is in an accepting state ends at len
     {
       const bool tail = MODE != ST_FIRST && live && (!VIRT || (vsk >> 31)) &&
                         (AUTO == 4 ? acc_lds[q4 >> (2 * p.st_cshift)] != 0
                          : AUTO == 2 ? acc_lds[q4 >> p.st_cshift] != 0
                                    : ((accmask >> (q4 >> (AUTO == 3 ? 3 : 2))) & 1u) != 0);
-      if (MODE == ST_RECORDS) {
+      if (RECS) {
         const uint64_t has = __ballot(tail);
         if (tail) {
           const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(has >> 32),
@@ -1128,7 +1399,7 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
           wave_recs[wrec + rank] = r;
         }
         wrec += __builtin_popcountll(has);
-        if (lane == 0) wave_nrecs[w] = wrec;
+        if (MODE == ST_RECORDS && lane == 0) wave_nrecs[w] = wrec;
       }
       if (tail) ++cnt;
       if (MODE == ST_RECORDS) {
@@ -1150,12 +1421,35 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_findall(
           out_s[my_text] = res_s;
           out_e[my_text] = res_e;
         }
+      } else if (MODE == ST_FUSED) {
+        // my task's count goes out at once; the task scanned before it is finished now
+        int wt = live ? cnt : 0;
+        for (int off = 32; off > 0; off >>= 1) wt += __shfl_xor(wt, off);
+        fused_publish(fz.ctrl, w, nwaves_total, (uint32_t)wt, lane);
+        if (pend)
+          fused_finish<REC32 != 0>(fz, recs + (((int64_t)blockIdx.x * kStreamWaves + wave) * 2 + pend_half) * fz.rec_cap,
+                                   pend_w, nwaves_total, n, pend_cnt, pend_wrec, tile, 64 * kRowPitch, p.st_fixed_len, lane);
+        pend = true; pend_w = w; pend_cnt = live ? cnt : 0; pend_wrec = wrec; pend_half = half;
+        half ^= 1;
       } else {
         if (live) counts[my_text] = cnt;
       }
     }
   }
+  if (MODE == ST_FUSED && pend)
+    fused_finish<REC32 != 0>(fz, recs + (((int64_t)blockIdx.x * kStreamWaves + wave) * 2 + pend_half) * fz.rec_cap,
+                             pend_w, nwaves_total, n, pend_cnt, pend_wrec, tile, 64 * kRowPitch, p.st_fixed_len, lane);
 #undef MRX_LOAD_CHUNK
+#undef fz
+}
+
+// ST_FUSED set-up, one small launch in front of the scan: zero the ticket word, the error word and the
+// descriptors, and place the scan's arguments in device memory.
+__global__ __launch_bounds__(kBlock) void k_fused_init(unsigned long long* __restrict__ ctrl, int64_t words,
+                                                       FusedArgs* __restrict__ dst, FusedArgs args) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (int64_t)gridDim.x * blockDim.x)
+    ctrl[i] = 0ull;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *dst = args;
 }
 
 // records -> CSR spans.  One wavefront per 64 consecutive texts (the wavefront that
@@ -2192,6 +2486,23 @@ int run_match(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d_s, i
   return MRX_OK;
 }
 
+// ST_FUSED launch shape.  Grid: the workgroups that are resident at once (4 per CU at the kernel's
+// ~118 VGPRs / 37 KiB LDS; more would only queue behind them -- harmless, tasks are handed out by
+// ticket -- but each wavefront of the grid owns a record region).
+// Off by default: measured on the headline workload (profiles/r02_fused_findall.md) the one launch takes
+// 0.35 ms against 0.32 ms for scan -> sums -> decode.  The scan loop is bound by instruction issue as much
+// as by HBM, so the record expansion costs the same issue slots whether it runs in the scan's launch or in
+// its own, and what the fusion saves (0.46 GB of record traffic, two launch boundaries) is less than what
+// the per-task hand-offs add.  MRX_FUSED=1 / mrx_debug_fused_findall(1): on for tasks of >= 32 KiB, 2: always.
+std::atomic<int> g_fused{0};
+std::atomic<int> g_fused_bpc{0};      // MRX_FUSED_BPC: workgroups per CU (measurement)
+int64_t fused_grid_cap() {
+  const int bpc = g_fused_bpc.load() > 0 ? g_fused_bpc.load() : 4;
+  return (int64_t)(grid_cap() / 8) * bpc;
+}
+// Every 64-text task takes one ticket from ONE counter word (about 88 atomics per microsecond at best):
+// tasks of less than 32 KiB would queue up there, so batches of short texts keep the three-launch form.
+constexpr int64_t kFusedMinTaskBytes = 32768;
 // longest text the event records of the streaming findall can describe (see run_findall)
 constexpr int64_t kStreamMaxText = int64_t(1) << 26;
 bool stream_text_too_long(int64_t max_text) { return max_text >= kStreamMaxText; }
@@ -2207,11 +2518,14 @@ bool strided_fast(const Layout& lay) {
 template <int MODE>
 void launch_stream(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d_counts, int32_t* d_nrecs,
                    EvRec* d_recs, int64_t rec_row, int32_t* d_s, int32_t* d_e, hipStream_t s,
-                   const int32_t* d_vlen = nullptr, const uint32_t* d_vskip = nullptr, bool rec32 = false) {
+                   const int32_t* d_vlen = nullptr, const uint32_t* d_vskip = nullptr, bool rec32 = false,
+                   const FusedArgs* fused = nullptr, int fused_grid = 0) {
   const DevPlan& p = h->hp.dev;
   const int64_t nw = (n + 63) / 64;
   int64_t g = (nw + kStreamWaves - 1) / kStreamWaves;
   if (g > grid_cap()) g = grid_cap();
+  if (MODE == ST_FUSED) g = fused_grid;   // one record region per wavefront of this grid
+  const FusedArgs* fzv = fused;   // device copy (k_fused_init)
   const dim3 grid((unsigned)g), block(64 * kStreamWaves);
   const int kind = MODE == ST_FIRST ? p.fa_kind : p.st_kind;   // automaton form of this mode
   const bool table = kind == 2;
@@ -2223,10 +2537,10 @@ void launch_stream(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d
 #define MRX_LAUNCH_R(AUTO, CSR, R32)                                                              \
   hipLaunchKernelGGL((k_stream_findall<MODE, (AUTO == 2 ? MRX_STREAM_CHUNK_TABLE : MRX_STREAM_CHUNK), AUTO, CSR, 0, R32>), grid, block, lds, s, p, \
                      H_BLOB(h), lay.data, lay.stride, lay.lens, lay.len, lay.offsets, n, d_counts, \
-                     d_nrecs, d_recs, rec_row, d_s, d_e)
+                     d_nrecs, d_recs, rec_row, d_s, d_e, (const int32_t*)nullptr, (const uint32_t*)nullptr, fzv)
 #define MRX_LAUNCH(AUTO, CSR)                                                                     \
   do {                                                                                            \
-    if constexpr (MODE == ST_RECORDS) {                                                           \
+    if constexpr (MODE == ST_RECORDS || MODE == ST_FUSED) {                                       \
       if (rec32) MRX_LAUNCH_R(AUTO, CSR, 1); else MRX_LAUNCH_R(AUTO, CSR, 0);                     \
     } else MRX_LAUNCH_R(AUTO, CSR, 0);                                                            \
   } while (0)
@@ -2437,6 +2751,8 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
   bool step_ok = g_force_generic < 2 &&
                  (match_next_sequence ? ((p.flags & PF_STEP_SEARCH) && !(p.flags & PF_PREFILTER))
                                       : (p.flags & (PF_STEPPABLE | PF_STEP_REQ)) != 0);
+  bool fused = false;      // streaming path: scan, CSR offsets and spans in one launch (ST_FUSED)
+  unsigned long long* d_ctrl = nullptr;   // its ticket word, error word and descriptors
   bool rec32 = false;      // streaming path: one record per two groups (positions fit 16 bits)
   int64_t max_text = int64_t(1) << 40;   // longest text of the batch, where known
   bool req_wave = false;   // the stepper's route on the wavefront-per-text kernel
@@ -2479,6 +2795,36 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
       }
       max_text = lay.offsets ? csr_max : (lay.lens ? lay.stride : (int64_t)lay.len);
       rec32 = max_text <= kRec32MaxLen;
+      // One launch (ST_FUSED) when a record region per resident wavefront -- sized for the most one
+      // 64-text task can produce -- stays within twice the record stream of the three-launch form
+      // (ragged batches whose longest text is far above the average do not: they are cut into pieces
+      // above, or keep the stream that is sized by the batch's byte count).
+      const int64_t fz_per_text = (rec32 ? max_text / 32 : max_text / 16) + 4;
+      int64_t fz_grid = (nw + kStreamWaves - 1) / kStreamWaves;
+      if (fz_grid > fused_grid_cap()) fz_grid = fused_grid_cap();
+      const size_t fz_nrec = (size_t)(64 * fz_per_text + 64) * (size_t)(fz_grid * kStreamWaves) * 2;   // two regions per wavefront
+      const int64_t batch_bytes = lay.offsets ? csr_total : n * (lay.lens ? lay.stride : (int64_t)lay.len);
+      fused = g_fused && span_cap > 0 && fz_nrec <= 2 * nrec + (size_t(8) << 20) && (g_fused == 2 || batch_bytes >= nw * kFusedMinTaskBytes);
+      if (fused) {
+        // ticket | error | one descriptor per task | two words per group of 64 tasks; a 16-byte multiple
+        const size_t ctrl_words = (size_t)((2 + nw + 2 * ((nw + 63) / 64) + 1) & ~int64_t(1));
+        HIP_TRY(scratch_alloc((void**)&d_ctrl, sizeof(unsigned long long) * ctrl_words, s));   // first: starts its own 256-byte block
+        HIP_TRY(scratch_alloc((void**)&d_recs, sizeof(EvRec) * fz_nrec, s));
+        FusedArgs* d_fz = nullptr;
+        HIP_TRY(scratch_alloc((void**)&d_fz, sizeof(FusedArgs), s));
+        FusedArgs fz;
+        fz.ctrl = d_ctrl; fz.prefix = d_prefix; fz.spans = d_spans; fz.span_cap = span_cap; fz.total_out = d_total;
+        fz.rec_cap = 64 * fz_per_text + (getenv("MRX_FUSED_SKEW") ? atoi(getenv("MRX_FUSED_SKEW")) : 0);
+        fz.debug = getenv("MRX_FUSED_DEBUG") ? atoi(getenv("MRX_FUSED_DEBUG")) : 0;
+        hipLaunchKernelGGL(k_fused_init, dim3((unsigned)((ctrl_words + kBlock * 8 - 1) / (kBlock * 8))), dim3(kBlock), 0, s,
+                           d_ctrl, (int64_t)ctrl_words, d_fz, fz);
+        ScanTimer tm(s);
+        launch_stream<ST_FUSED>(h, lay, n, nullptr, nullptr, d_recs, 0, nullptr, nullptr, s, nullptr, nullptr, rec32, d_fz,
+                                (int)fz_grid);
+        g_last_kernel = "k_stream_findall_fused";
+        HIP_TRY(hipGetLastError());
+        tm.stop();
+      } else {
       HIP_TRY(scratch_alloc((void**)&d_recs, sizeof(EvRec) * nrec, s));
       HIP_TRY(scratch_alloc((void**)&d_nrecs, sizeof(int32_t) * 2 * nw, s));  // records | matches per wavefront
       HIP_TRY(scratch_alloc((void**)&d_wbase, sizeof(int64_t) * (nw + 1), s));
@@ -2487,6 +2833,7 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
       g_last_kernel = "k_stream_findall";
       HIP_TRY(hipGetLastError());
       tm.stop();
+      }
     } else {
       if (step_ok)
         if (int rc = req_wave_pays(lay, n, use_req_route, s, &req_wave, (p.flags & PF_STEP_BIG) ? nullptr : &step_split))
@@ -2543,8 +2890,8 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
       tm.stop();
     }
   }
-  if (by_pieces) {
-    // done over the pieces above
+  if (by_pieces || fused) {
+    // done over the pieces above / by the one launch
   } else if (stream_ok) {
     // prefix sums over the wavefronts' totals only (n/64 values); k_decode derives the per-text
     // offsets from its 64 counts and writes them along with the spans
@@ -2603,13 +2950,17 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
   int rc = MRX_OK;
   if (total) {
     int64_t tot = 0;
+    unsigned long long fused_err = 0;
     HIP_TRY(hipMemcpyAsync(&tot, d_total, sizeof tot, hipMemcpyDeviceToHost, s));
+    if (d_ctrl) HIP_TRY(hipMemcpyAsync(&fused_err, d_ctrl + 1, sizeof fused_err, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     *total = tot;
+    if (fused_err) return fail(MRX_E_NO_DEVICE, "internal: a wavefront gave up waiting for its predecessors' span counts");
     if (tot > span_cap) rc = fail(MRX_E_CAPACITY, "span buffer too small: need " + std::to_string(tot));
   }  // total == NULL: fully asynchronous; d_counts_prefix[n] holds the total when the stream drains
   HIP_TRY(scratch_free(d_counts, s));
   HIP_TRY(scratch_free(d_total, s));
+  if (d_ctrl) { HIP_TRY(scratch_free(d_ctrl, s)); HIP_TRY(scratch_free(d_ctrl, s)); }   // ctrl block and the argument copy
   if (d_recs) HIP_TRY(scratch_free(d_recs, s));
   if (d_nrecs) HIP_TRY(scratch_free(d_nrecs, s));
   if (d_wbase) HIP_TRY(scratch_free(d_wbase, s));
@@ -2724,6 +3075,8 @@ int mrx_compile(const char* pattern, size_t pattern_len, mrx_handle** out) {
 
 int mrx_compile_ex(const char* pattern, size_t pattern_len, uint32_t options, mrx_handle** out) {
   if (const char* e = getenv("MRX_NO_PAIR_TABLES")) g_pair_tables = !(e[0] == '1');
+  if (const char* e = getenv("MRX_FUSED")) g_fused = atoi(e) < 0 ? 0 : atoi(e) > 2 ? 2 : atoi(e);
+  if (const char* e = getenv("MRX_FUSED_BPC")) g_fused_bpc = atoi(e);
   if (!out || (!pattern && pattern_len)) return fail(MRX_E_ARGUMENT, "null argument");
   if (options & ~(uint32_t)(MRX_COMPILE_LAZYDFA_SEMANTICS | MRX_COMPILE_BITSET_NFA))
     return fail(MRX_E_ARGUMENT, "unknown compile option");
@@ -3186,6 +3539,7 @@ double mrx_timing_scan_ms(int64_t* launches) {
 const char* mrx_last_kernel_name(void) { return g_last_kernel; }
 void mrx_debug_force_generic(int on) { g_force_generic = on < 0 ? 0 : on > 2 ? 2 : on; }
 void mrx_debug_long_text_kernels(int mode) { g_long_text_mode = mode < 0 ? 0 : mode > 2 ? 0 : mode; }
+void mrx_debug_fused_findall(int mode) { g_fused = mode < 0 ? 0 : mode > 2 ? 0 : mode; }
 void mrx_release_scratch(void) { scratch_release_all(); }
 size_t mrx_debug_scratch_bytes(void) { return scratch_bytes_reserved(); }
 

@@ -13,6 +13,9 @@ from mojo_regex_amd.workloads import make_digits_batch, make_phone_batch, make_a
 from mrx_ref.cfast import CDfa  # noqa: E402  (oracle: checker only)
 
 
+STREAM_FINDALL = (b"k_stream_findall_fused", b"k_stream_findall")
+
+
 def _need_gpu():
     if not torch.cuda.is_available():
         pytest.fail("gpu-marked test run without a GPU: the HIP path has no fallback")
@@ -124,7 +127,7 @@ def test_config5_alternation_at_full_size():
     rx = M.compile_regex(pat)
     batch = M.DeviceBatch.strided(d.reshape(-1), L, length=L)
     prefix, spans, total = rx._dev_findall(batch, span_cap=n * 720)
-    assert M.load_library().mrx_last_kernel_name() == b"k_stream_findall"
+    assert M.load_library().mrx_last_kernel_name() in STREAM_FINDALL
     assert total == int(prefix[n].item()) > n * 600
     blk = 1 << 19
     for a in range(0, n, blk):

@@ -159,6 +159,21 @@ ALPHABETS = {
 
 import contextlib
 
+# findall of a streamable plan: one launch (scan + CSR offsets + spans fused), or scan -> sums -> decode
+STREAM_FINDALL = (b"k_stream_findall_fused", b"k_stream_findall")
+
+
+@contextlib.contextmanager
+def fused_findall(mode=2):
+    """The streaming findall as ONE launch (scan + look-back + record expansion) instead of the default
+    scan -> prefix sums -> decode; mode 2 = for short texts too."""
+    lib = M.load_library()
+    lib.mrx_debug_fused_findall(mode)
+    try:
+        yield
+    finally:
+        lib.mrx_debug_fused_findall(0)
+
 
 @contextlib.contextmanager
 def generic_kernels():
@@ -320,14 +335,14 @@ def test_streaming_kernel_equals_generic_and_oracle(pat, n, pitch, var):
     dl = torch.from_numpy(lens).cuda() if var else None
     batch = M.DeviceBatch.strided(d, pitch, length=pitch, lens=dl)
     prefix, spans, total = rx._dev_findall(batch)
-    assert M.load_library().mrx_last_kernel_name() in (b"k_stream_findall",)
+    assert M.load_library().mrx_last_kernel_name() in STREAM_FINDALL
     prefix, spans = prefix.cpu().numpy(), spans.cpu().numpy()
     texts = [arr[i, : (lens[i] if var else pitch)].tobytes() for i in range(n)]
     with generic_kernels():
         generic = rx.findall_lists(texts)
         assert M.load_library().mrx_last_kernel_name() == b"k_findall_count"
     assert rx.findall_lists(texts) == generic   # CSR batch -> streaming kernel, ragged frame
-    assert M.load_library().mrx_last_kernel_name() == b"k_stream_findall"
+    assert M.load_library().mrx_last_kernel_name() in STREAM_FINDALL
     assert int(prefix[-1]) == total == sum(len(x) for x in generic)
     # search on the same strided batch runs the streaming kernel in first-match mode
     ss, se = rx.match_next(batch)
@@ -549,7 +564,7 @@ def test_streaming_csr_ragged_unaligned(pat, shift):
     rx = M.compile_regex(pat)
     lib = M.load_library()
     prefix, spans, total = rx._dev_findall(batch)
-    assert lib.mrx_last_kernel_name() == b"k_stream_findall"
+    assert lib.mrx_last_kernel_name() in STREAM_FINDALL
     ss, se = rx.match_next(batch)
     assert lib.mrx_last_kernel_name() == b"k_stream_search"
     fs, fe = rx.match_first(batch)
@@ -750,7 +765,7 @@ def test_generated_patterns_streaming_equals_generic(seed):
         if streamable:
             nstream += 1
             pre, sp, tot = rx._dev_findall(batch)
-            assert lib.mrx_last_kernel_name() == b"k_stream_findall"
+            assert lib.mrx_last_kernel_name() in STREAM_FINDALL
             ss, se = rx.match_next(batch)
             cnt = rx.count(batch)
         if first_stream:
@@ -803,7 +818,7 @@ def test_self_overlapping_pure_literal_streams(pat):
         texts.append(b"".join(parts))
     texts += [b"", lit, lit[:-1], lit + lit, lit[1:] + lit, lit[:1] * 100, (lit[:2] * 50) + lit]
     got = rx.findall_lists(texts)
-    assert lib.mrx_last_kernel_name() == b"k_stream_findall"
+    assert lib.mrx_last_kernel_name() in STREAM_FINDALL
     s, e = rx.match_next(texts)
     assert lib.mrx_last_kernel_name() == b"k_stream_search"
     with generic_kernels():
@@ -843,7 +858,7 @@ def test_long_texts_in_pieces(pat):
         assert lib.mrx_last_kernel_name() == b"k_stream_findall_pieces"
     with long_text_kernels(2):
         want = rx.findall_lists(texts)
-        assert lib.mrx_last_kernel_name() == b"k_stream_findall"
+        assert lib.mrx_last_kernel_name() in STREAM_FINDALL
     for i, (g, w) in enumerate(zip(got, want)):
         assert g == w, (pat, i, len(texts[i]), g[:5], w[:5])
     for i in list(range(0, 50, 7)) + list(range(50, len(texts))):
@@ -906,7 +921,7 @@ def test_outliers_of_a_ragged_batch_are_cut_into_pieces():
     ss, se = rx.match_next(b)
     with long_text_kernels(2):
         pre2, sp2, tot2 = rx._dev_findall(b)
-        assert lib.mrx_last_kernel_name() == b"k_stream_findall"
+        assert lib.mrx_last_kernel_name() in STREAM_FINDALL
         cnt2 = rx.count(b)
         ws, we = rx.match_next(b)
     assert tot == tot2 and torch.equal(pre, pre2) and torch.equal(sp[:tot], sp2[:tot2])
@@ -1031,7 +1046,7 @@ def test_exact_literal_kmp_streaming(pat):
         texts.append(b"".join(parts))
     texts += [b"", pat, pat[:-1], pat + pat, pat[1:] + pat]
     got = rx.findall_lists(texts)
-    assert lib.mrx_last_kernel_name() == b"k_stream_findall"
+    assert lib.mrx_last_kernel_name() in STREAM_FINDALL
     s, e = rx.match_next(texts)
     assert lib.mrx_last_kernel_name() == b"k_stream_search"
     cnt_total = sum(len(g) for g in got)
@@ -1409,3 +1424,84 @@ def test_start_anchored_search_uses_the_anchored_automaton(pat):
         assert (int(s[i]), int(e[i])) == (w if w else (-1, -1)), (pat, t)
     if pat != b"^hello" and "engine_type=DFA" in rx.describe():
         assert used == b"k_stream_first", used
+
+
+@pytest.mark.parametrize("pat", [b"[a-z]+\\d+", b"\\d+", b"hello", b"(\\d{3})(\\d{3})(\\d{4})", b"(x|y|foo|bar)+", b"a",
+                                 b"abab", b"[a-c]+[0-9]+[x-z]+[0-9]+"])
+@pytest.mark.parametrize("shape", ["strided", "strided_lens", "csr", "frame"])
+def test_fused_findall_equals_three_launch_form(pat, shape):
+    """ST_FUSED (opt-in: records kept by the wavefront, tickets, look-back over task and group words for
+    the CSR base, spans written in place) against the default three-launch form on the same batches:
+    identical CSR offsets and spans.  Sizes
+    chosen so that several tickets, a partial last wavefront, empty texts, wavefronts below one LDS
+    tile, across several tiles and on the direct-store path all occur."""
+    _need_gpu()
+    lib = M.load_library()
+    rx = M.compile_regex(pat)
+    assert "device.streamable=yes" in rx.describe()
+    rng = np.random.default_rng(zlib.crc32(pat) + len(shape))
+    al = np.frombuffer(b"abcxyz0189 -fobar5" + bytes(c for c in pat if chr(c).isalnum()) * 2, dtype=np.uint8)
+    for n, pitch in ((1, 16), (63, 48), (64 * 9 + 5, 208), (4099, 64), (300, 1024), (70, 4096)):
+        if shape == "frame":
+            pitch += 3   # not a multiple of 16: frame form with a fixed pitch
+        arr = rng.choice(al, size=(n, pitch)).astype(np.uint8)
+        for i in range(0, n, 3):   # dense rows: a match every two or three bytes
+            body = np.frombuffer((b"a1 " * pitch)[:pitch], dtype=np.uint8)
+            arr[i] = body if i % 2 == 0 else np.frombuffer((b"x" * pitch), dtype=np.uint8)
+        if shape in ("strided", "frame"):
+            batch = M.DeviceBatch.strided(torch.from_numpy(arr).cuda().reshape(-1), pitch, length=pitch)
+        elif shape == "strided_lens":
+            lens = rng.integers(0, pitch + 1, size=n).astype(np.int32)
+            lens[:: 11] = 0
+            batch = M.DeviceBatch.strided(torch.from_numpy(arr).cuda().reshape(-1), pitch, lens=torch.from_numpy(lens).cuda())
+        else:
+            lens = rng.integers(0, pitch + 1, size=n)
+            lens[:: 7] = 0
+            batch = M.DeviceBatch.from_texts([arr[i, : lens[i]].tobytes() for i in range(n)])
+        with long_text_kernels(2):   # (the 4 KiB texts would otherwise be cut into pieces)
+            with fused_findall():
+                p1, s1, t1 = rx._dev_findall(batch)
+                assert lib.mrx_last_kernel_name() == b"k_stream_findall_fused"
+            p3, s3, t3 = rx._dev_findall(batch)
+            assert lib.mrx_last_kernel_name() == b"k_stream_findall"
+        assert t1 == t3 and torch.equal(p1, p3) and torch.equal(s1[:t1], s3[:t3]), (pat, shape, n, pitch)
+        # a span buffer that is too small: what fits is written in order, the need is reported
+        if t1 > 8:
+            cap = t1 // 2
+            pre = torch.empty(batch.n + 1, dtype=torch.int64, device="cuda")
+            sp = torch.full((cap + 4, 2), -9, dtype=torch.int32, device="cuda")
+            with long_text_kernels(2), fused_findall():
+                rx.findall_async(batch, (pre, sp[:cap]))
+                assert lib.mrx_last_kernel_name() == b"k_stream_findall_fused"
+            torch.cuda.synchronize()
+            assert int(pre[-1]) == t1 and torch.equal(pre, p1)
+            assert torch.equal(sp[:cap], s1[:cap]) and bool((sp[cap:] == -9).all())
+
+
+def test_fused_findall_back_to_back_calls_reuse_their_scratch():
+    """The ticket word and descriptors are zeroed per call, the record regions are reused task after
+    task and call after call: many calls in a row (two streams) give the same answer, and the arena
+    stops growing."""
+    _need_gpu()
+    lib = M.load_library()
+    rx = M.compile_regex(b"[a-z]+\\d+")
+    batch_t = make_c2_batch(1 << 14, 1024, seed=5, device="cuda")
+    batch = M.DeviceBatch.strided(batch_t.reshape(-1), 1024, length=1024)
+    p0, s0, t0 = rx._dev_findall(batch)
+    assert lib.mrx_last_kernel_name() == b"k_stream_findall"
+    size0 = None
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [(torch.empty_like(p0), torch.empty_like(s0)) for _ in streams]
+    with fused_findall(1):
+        for it in range(40):
+            k = it % 2
+            with torch.cuda.stream(streams[k]):
+                rx.findall_async(batch, outs[k])
+                assert lib.mrx_last_kernel_name() == b"k_stream_findall_fused"
+            if it == 9:
+                torch.cuda.synchronize()
+                size0 = lib.mrx_debug_scratch_bytes()
+        torch.cuda.synchronize()
+    assert lib.mrx_debug_scratch_bytes() == size0
+    for pre, sp in outs:
+        assert torch.equal(pre, p0) and torch.equal(sp[:t0], s0[:t0])
