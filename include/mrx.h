@@ -117,6 +117,33 @@ int mrx_is_match_dev(const mrx_handle* h, const uint8_t* d_data,
 int mrx_is_match_strided_dev(const mrx_handle* h, const uint8_t* d_data, int64_t stride,
                              const int32_t* d_lens, int32_t len, int64_t n, uint8_t* d_flag,
                              void* stream);
+/* The same three operations from a start position -- Engine.match_first(text, start)
+ * (src/regex/engine.mojo:4-37), RegexMatcher / CompiledRegex.match_first / match_next / is_match
+ * (matcher.mojo:181-209, 1049-1115): text i is matched from start (all texts) or d_starts[i]
+ * (d_starts != NULL; int32[n] on the device).  Results are offsets from the beginning of the text, as
+ * the reference's Match carries them.  Reference rules kept: a '^' pattern on the DFA or OnePass route
+ * answers None for start > 0 (dfa.mojo:1866-1867, 1887-1891; onepass.mojo:445) while the LazyDFA treats
+ * '^' as satisfied at every start (pikevm.mojo:714); start == len matches the empty rest; start > len
+ * gives None, except that LazyDFA / OnePass match_first (and is_match, and DFAEngine.is_match with a
+ * first-byte matcher) report the empty match (start, start) when the start state accepts, as upstream
+ * does (pikevm.mojo:820-867, dfa.mojo:1832-1836).  start < 0 (undefined upstream) gives None.
+ * match_first here is the engine-level operation: a match, if any, begins AT start. */
+int mrx_match_first_at_dev(const mrx_handle* h, const uint8_t* d_data, const int64_t* d_offsets, int64_t n,
+                           int32_t start, const int32_t* d_starts, int32_t* d_start, int32_t* d_end,
+                           void* stream);
+int mrx_search_at_dev(const mrx_handle* h, const uint8_t* d_data, const int64_t* d_offsets, int64_t n,
+                      int32_t start, const int32_t* d_starts, int32_t* d_start, int32_t* d_end, void* stream);
+int mrx_is_match_at_dev(const mrx_handle* h, const uint8_t* d_data, const int64_t* d_offsets, int64_t n,
+                        int32_t start, const int32_t* d_starts, uint8_t* d_flag, void* stream);
+int mrx_match_first_at_strided_dev(const mrx_handle* h, const uint8_t* d_data, int64_t stride,
+                                   const int32_t* d_lens, int32_t len, int64_t n, int32_t start,
+                                   const int32_t* d_starts, int32_t* d_start, int32_t* d_end, void* stream);
+int mrx_search_at_strided_dev(const mrx_handle* h, const uint8_t* d_data, int64_t stride,
+                              const int32_t* d_lens, int32_t len, int64_t n, int32_t start,
+                              const int32_t* d_starts, int32_t* d_start, int32_t* d_end, void* stream);
+int mrx_is_match_at_strided_dev(const mrx_handle* h, const uint8_t* d_data, int64_t stride,
+                                const int32_t* d_lens, int32_t len, int64_t n, int32_t start,
+                                const int32_t* d_starts, uint8_t* d_flag, void* stream);
 /* regex.findall(pattern, text), matcher.mojo:1341-1354.
  * d_counts_prefix[n+1]: exclusive prefix sum of matches per text (CSR);
  * d_spans[2*k], d_spans[2*k+1] = start, end of match k (text-relative), in text

@@ -73,6 +73,15 @@ def load_library():
                                              C.c_void_p]),
         "mrx_is_match_dev": (C.c_int, [H, u8p, i64p, C.c_int64, u8p, C.c_void_p]),
         "mrx_is_match_strided_dev": (C.c_int, [H, u8p, C.c_int64, i32p, C.c_int32, C.c_int64, u8p, C.c_void_p]),
+        "mrx_match_first_at_dev": (C.c_int, [H, u8p, i64p, C.c_int64, C.c_int32, i32p, i32p, i32p, C.c_void_p]),
+        "mrx_search_at_dev": (C.c_int, [H, u8p, i64p, C.c_int64, C.c_int32, i32p, i32p, i32p, C.c_void_p]),
+        "mrx_is_match_at_dev": (C.c_int, [H, u8p, i64p, C.c_int64, C.c_int32, i32p, u8p, C.c_void_p]),
+        "mrx_match_first_at_strided_dev": (C.c_int, [H, u8p, C.c_int64, i32p, C.c_int32, C.c_int64, C.c_int32, i32p,
+                                                     i32p, i32p, C.c_void_p]),
+        "mrx_search_at_strided_dev": (C.c_int, [H, u8p, C.c_int64, i32p, C.c_int32, C.c_int64, C.c_int32, i32p,
+                                                i32p, i32p, C.c_void_p]),
+        "mrx_is_match_at_strided_dev": (C.c_int, [H, u8p, C.c_int64, i32p, C.c_int32, C.c_int64, C.c_int32, i32p,
+                                                  u8p, C.c_void_p]),
         "mrx_findall_dev": (C.c_int, [H, u8p, i64p, C.c_int64, i64p, i32p, C.c_int64,
                                       C.POINTER(C.c_int64), C.c_void_p]),
         "mrx_findall_strided_dev": (C.c_int, [H, u8p, C.c_int64, i32p, C.c_int32, C.c_int64, i64p,
@@ -117,6 +126,8 @@ EXPORTED_SYMBOLS = [
     "mrx_search_strided_dev", "mrx_is_match_dev", "mrx_is_match_strided_dev",
     "mrx_findall_dev", "mrx_findall_strided_dev", "mrx_count_dev", "mrx_count_strided_dev",
     "mrx_captures_strided_dev", "mrx_captures_dev",
+    "mrx_match_first_at_dev", "mrx_search_at_dev", "mrx_is_match_at_dev", "mrx_match_first_at_strided_dev",
+    "mrx_search_at_strided_dev", "mrx_is_match_at_strided_dev",
     "mrx_sub_dev", "mrx_match_first_batch", "mrx_search_batch", "mrx_is_match_batch",
     "mrx_findall_batch", "mrx_captures_batch", "mrx_sub_batch", "mrx_version", "mrx_release_scratch",
 ]
@@ -177,16 +188,16 @@ class DeviceBatch:
 
     @classmethod
     def strided(cls, data, stride: int, length: Optional[int] = None, lens=None):
-        """Texts at a fixed pitch: text i = data[i*stride : i*stride + (lens[i] | length)].  Exactly one
-        of `length` (common to all texts) and `lens` (int32[n] on the data's device) must be given;
+        """Texts at a fixed pitch: text i = data[i*stride : i*stride + (lens[i] | length)].  `length`
+        (common to all texts) or `lens` (int32[n] on the data's device; takes precedence) must be given;
         lens[i] <= stride is the caller's contract (the kernels read lens[i] bytes of row i)."""
         import torch
         stride = int(stride)
         if stride <= 0 or data.numel() % stride:
             raise MrxError("data size %d is not a multiple of the stride %d" % (data.numel(), stride))
         n = data.numel() // stride
-        if (length is None) == (lens is None):
-            raise MrxError("give either length= or lens=")
+        if length is None and lens is None:
+            raise MrxError("give length= (common to all texts) or lens= (per text; it takes precedence)")
         if lens is not None:
             if lens.dtype != torch.int32 or not lens.is_contiguous() or lens.device != data.device or lens.numel() != n:
                 raise MrxError("lens must be a contiguous int32[n] tensor on the data's device")
@@ -327,6 +338,48 @@ class CompiledRegex:
         _check(self._lib.mrx_is_match_batch(self._h, data.ctypes.data, offsets.ctypes.data, n,
                                             f.ctypes.data))
         return f
+
+    # -- the Engine / RegexMatcher seam with its `start` argument (engine.mojo:4-37) ------------------
+    def _at(self, op: str, texts, start):
+        """op in {"match_first", "search", "is_match"}; start: one int for all texts, or int32[n]
+        (numpy / device tensor).  Host texts are uploaded; a DeviceBatch is used in place."""
+        import torch
+        batch = texts if isinstance(texts, DeviceBatch) else DeviceBatch.from_texts(texts)
+        dev = batch.data.device
+        d_starts = None
+        s0 = 0
+        if isinstance(start, (int, np.integer)):
+            s0 = int(start)
+        else:
+            d_starts = start if isinstance(start, torch.Tensor) else torch.from_numpy(np.asarray(start, dtype=np.int32))
+            d_starts = d_starts.to(device=dev, dtype=torch.int32).contiguous()
+            if d_starts.numel() != batch.n:
+                raise MrxError("starts needs one entry per text")
+        csr = batch.offsets is not None
+        lay = ([_ptr(batch.data), _ptr(batch.offsets), batch.n] if csr else
+               [_ptr(batch.data), batch.stride, _ptr(batch.lens), batch.length, batch.n])
+        if op == "is_match":
+            f = torch.empty(batch.n, dtype=torch.uint8, device=dev)
+            fn = self._lib.mrx_is_match_at_dev if csr else self._lib.mrx_is_match_at_strided_dev
+            _check(fn(self._h, *lay, s0, _ptr(d_starts), _ptr(f), self._stream_ptr()))
+            return f if isinstance(texts, DeviceBatch) else f.cpu().numpy()
+        s = torch.empty(batch.n, dtype=torch.int32, device=dev)
+        e = torch.empty(batch.n, dtype=torch.int32, device=dev)
+        name = "mrx_%s_at_%sdev" % ("match_first" if op == "match_first" else "search", "" if csr else "strided_")
+        _check(getattr(self._lib, name)(self._h, *lay, s0, _ptr(d_starts), _ptr(s), _ptr(e), self._stream_ptr()))
+        return (s, e) if isinstance(texts, DeviceBatch) else (s.cpu().numpy(), e.cpu().numpy())
+
+    def match_first_at(self, texts, start):
+        """CompiledRegex.match_first(text, start) (matcher.mojo:1049-1062): a match beginning at start."""
+        return self._at("match_first", texts, start)
+
+    def match_next_at(self, texts, start):
+        """CompiledRegex.match_next(text, start) (matcher.mojo:1064-1077): leftmost match from start on."""
+        return self._at("search", texts, start)
+
+    def is_match_at(self, texts, start):
+        """CompiledRegex.is_match(text, start) (matcher.mojo:1103-1115)."""
+        return self._at("is_match", texts, start)
 
     def test(self, texts):
         """CompiledRegex.test (matcher.mojo:1091-1101): does search() match.  bool[n]: numpy for host

@@ -51,6 +51,10 @@ struct Layout {  // where text i lives
   // k_wstep / k_req_wave<STEP_SLOTS / STEP_EMIT> and k_slots_gather_wide: slot rows sized by the text
   // (len / 4 + 32 spans, see slot_row()) instead of kStepSlots, so that long texts rarely need the second walk
   int32_t wide_slots = 0;
+  // Views (the `start` argument, mrx_*_at_*): with offsets != nullptr, text i is the vlen[i] bytes at
+  // data + offsets[i] (offsets need not be contiguous); nullptr = plain CSR
+  const int32_t* vlen = nullptr;
+  const uint32_t* vskip = nullptr;   // with vlen: the per-text word k_stream_findall's VIRT form expects
   // first slot of text i's row and the row's capacity (wide rows)
   __device__ __forceinline__ int64_t slot_row(int64_t i, int* cap) const {
     if (offsets) {
@@ -64,8 +68,8 @@ struct Layout {  // where text i lives
   }
   __device__ __forceinline__ Text text(int64_t i) const {
     if (offsets) {
-      const int64_t a = offsets[i], b = offsets[i + 1];
-      return Text(data + a, (int)(b - a));
+      const int64_t a = offsets[i];
+      return Text(data + a, vlen ? vlen[i] : (int)(offsets[i + 1] - a));
     }
     return Text(data + i * stride, lens ? lens[i] : len);
   }
@@ -1786,6 +1790,54 @@ __global__ __launch_bounds__(kBlock) void k_virt_first(int64_t n, const int64_t*
     out_s[t] = rs; out_e[t] = re;
   }
 }
+// ---- the `start` argument (Engine.match_first(text, start), engine.mojo:4-37) ------------------
+// Every route of the reference treats match_first / match_next / is_match at `start` as the same
+// operation at 0 on the bytes [start, len) with `start` added to the result (DFAEngine
+// ._try_match_at_position and the search loops only ever look at text[pos:], dfa.mojo:1875-2026;
+// LazyDFA builds its start state once, pikevm.mojo:714; exact-literal and prefilter paths call
+// find(literal, start), matcher.mojo:768-796).  What differs is decided per text by k_view_fix: a
+// '^' plan on the DFA or OnePass route answers None for start > 0 (dfa.mojo:1866-1867, 1887-1891,
+// onepass.mojo:445), and start > len has its own answers (View::beyond_*).  So the kernels run
+// unchanged on a view of the batch: text i = [offsets[i] + start_i, len_i - start_i).
+__global__ __launch_bounds__(kBlock) void k_view_build(Layout lay, int64_t n, int32_t start, const int32_t* __restrict__ starts,
+                                                       int64_t* __restrict__ vstart, int32_t* __restrict__ vlen,
+                                                       uint32_t* __restrict__ vskip) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += (int64_t)gridDim.x * blockDim.x) {
+    if (i == n) {   // an end offset for the kernels that size things by the batch's byte count
+      vstart[n] = lay.offsets ? lay.offsets[n] : n * lay.stride;
+      break;
+    }
+    const int64_t a = lay.offsets ? lay.offsets[i] : i * lay.stride;
+    const int len = lay.offsets ? (int)(lay.offsets[i + 1] - a) : (lay.lens ? lay.lens[i] : lay.len);
+    const int s0 = starts ? starts[i] : start;
+    const int sc = s0 < 0 ? 0 : s0 > len ? len : s0;
+    vstart[i] = a + sc;
+    vlen[i] = len - sc;
+    vskip[i] = 0x80000000u;   // k_stream_findall VIRT: a whole text (nothing skipped, may end a match at its end)
+  }
+}
+// results of the view -> results of the text.  rule bits: 1 = None for start > 0 ('^' on the DFA /
+// OnePass route), 2 = match_first at start > len is the empty match (start, start), 4 = is_match at
+// start > len is true, 8 = is_match operation (out_flag), else spans
+__global__ __launch_bounds__(kBlock) void k_view_fix(Layout lay, int64_t n, int32_t start, const int32_t* __restrict__ starts,
+                                                     int rules, int32_t* __restrict__ out_s, int32_t* __restrict__ out_e,
+                                                     uint8_t* __restrict__ out_flag) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int len = lay.offsets ? (int)(lay.offsets[i + 1] - lay.offsets[i]) : (lay.lens ? lay.lens[i] : lay.len);
+    const int s0 = starts ? starts[i] : start;
+    const bool none = s0 < 0 || ((rules & 1) && s0 > 0);
+    const bool beyond = s0 > len;
+    if (rules & 8) {
+      if (none) out_flag[i] = 0;
+      else if (beyond) out_flag[i] = (rules & 4) ? 1 : 0;
+    } else {
+      if (none || (beyond && !(rules & 2))) { out_s[i] = -1; out_e[i] = -1; }
+      else if (beyond) { out_s[i] = s0; out_e[i] = s0; }
+      else if (out_s[i] >= 0) { out_s[i] += s0; out_e[i] += s0; }
+    }
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void k_max_len(const int64_t* __restrict__ offsets, int64_t n, int32_t* __restrict__ out) {
   int m = 0;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x)
@@ -2544,13 +2596,13 @@ void launch_stream(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d
       if (rec32) MRX_LAUNCH_R(AUTO, CSR, 1); else MRX_LAUNCH_R(AUTO, CSR, 0);                     \
     } else MRX_LAUNCH_R(AUTO, CSR, 0);                                                            \
   } while (0)
-  if (d_vlen) {   // pieces of long texts: lay.offsets = their start offsets, n = how many
-    if constexpr (MODE == ST_RECORDS || MODE == ST_COUNT || MODE == ST_SEARCH) {
+  if (d_vlen) {   // pieces of long texts / views: lay.offsets = their start offsets, n = how many
+    if constexpr (MODE == ST_RECORDS || MODE == ST_COUNT || MODE == ST_SEARCH || MODE == ST_FIRST) {
 #define MRX_LAUNCH_V(AUTO)                                                                        \
   hipLaunchKernelGGL((k_stream_findall<MODE, (AUTO == 2 ? MRX_STREAM_CHUNK_TABLE : MRX_STREAM_CHUNK), AUTO, 1, 1>), grid, block, lds, s, p, \
                      H_BLOB(h), lay.data, lay.stride, lay.lens, lay.len, lay.offsets, n, d_counts, \
                      d_nrecs, d_recs, rec_row, d_s, d_e, d_vlen, d_vskip)
-      if (pairs) MRX_LAUNCH_V(4);
+      if (pairs) { if constexpr (MODE != ST_FIRST) MRX_LAUNCH_V(4); }
       else if (table) MRX_LAUNCH_V(2);
       else if (wide) MRX_LAUNCH_V(3);
       else MRX_LAUNCH_V(1);
@@ -3139,7 +3191,7 @@ static int run_search_any(const mrx_handle* h, const Layout& lay, int64_t n, int
     if (int rc = ensure_device(h)) return rc;
     hipStream_t s = (hipStream_t)st;
     ScanTimer tm(s);
-    launch_stream<ST_FIRST>(h, lay, n, nullptr, nullptr, nullptr, 0, ds, de, s);
+    launch_stream<ST_FIRST>(h, lay, n, nullptr, nullptr, nullptr, 0, ds, de, s, lay.vlen, lay.vskip);
     g_last_kernel = "k_stream_first";
     HIP_TRY(hipGetLastError());
     tm.stop();
@@ -3151,7 +3203,8 @@ static int run_search_any(const mrx_handle* h, const Layout& lay, int64_t n, int
   if (int rc = ensure_device(h)) return rc;
   hipStream_t s = (hipStream_t)st;
   Pieces pc;
-  if (int rc = pieces_prepare(h, lay, n, s, &pc)) return rc;
+  if (!lay.vlen)   // (a view is searched as it stands)
+    if (int rc = pieces_prepare(h, lay, n, s, &pc)) return rc;
   if (pc.on) {   // long texts: search every piece, keep each text's first
     int32_t* d_vs = nullptr;
     HIP_TRY(scratch_alloc((void**)&d_vs, sizeof(int32_t) * 2 * pc.nv, s));
@@ -3166,7 +3219,7 @@ static int run_search_any(const mrx_handle* h, const Layout& lay, int64_t n, int
     return pieces_release(&pc, s);
   }
   ScanTimer tm(s);
-  launch_stream<ST_SEARCH>(h, lay, n, nullptr, nullptr, nullptr, 0, ds, de, s);
+  launch_stream<ST_SEARCH>(h, lay, n, nullptr, nullptr, nullptr, 0, ds, de, s, lay.vlen, lay.vskip);
   g_last_kernel = "k_stream_search";
   HIP_TRY(hipGetLastError());
   tm.stop();
@@ -3184,7 +3237,7 @@ static int run_first_any(const mrx_handle* h, const Layout& lay, int64_t n, int3
   if (int rc = ensure_device(h)) return rc;
   hipStream_t s = (hipStream_t)st;
   // a single class run on long texts of a fixed-pitch batch: a wavefront per text (k_first_run)
-  if (p.off_fa_run >= 0 && !lay.offsets && g_long_text_mode != 2 &&
+  if (p.off_fa_run >= 0 && !lay.offsets && !lay.vlen && g_long_text_mode != 2 &&
       (g_long_text_mode == 1 || ((lay.lens ? lay.stride : (int64_t)lay.len) >= 2048 && n <= 131072))) {
     ScanTimer tm(s);
     hipLaunchKernelGGL(k_first_run, dim3(grid_for(n * 64, kBlock)), dim3(kBlock), 0, s, p, H_BLOB(h), lay, n, ds, de);
@@ -3194,7 +3247,7 @@ static int run_first_any(const mrx_handle* h, const Layout& lay, int64_t n, int3
     return MRX_OK;
   }
   ScanTimer tm(s);
-  launch_stream<ST_FIRST>(h, lay, n, nullptr, nullptr, nullptr, 0, ds, de, s);
+  launch_stream<ST_FIRST>(h, lay, n, nullptr, nullptr, nullptr, 0, ds, de, s, lay.vlen, lay.vskip);
   g_last_kernel = "k_stream_first";
   HIP_TRY(hipGetLastError());
   tm.stop();
@@ -3252,6 +3305,97 @@ int mrx_is_match_strided_dev(const mrx_handle* h, const uint8_t* d, int64_t stri
   if (!lens && (len < 0 || len > stride)) return fail(MRX_E_ARGUMENT, "len must be in [0, stride]");
   return run_is_match_any(h, Layout{d, nullptr, stride, lens, len}, n, f, st);
 }
+// match_first / match_next / is_match at a start position (see k_view_build): the operation runs on a
+// view of the batch, k_view_fix turns the view's answers into the text's.
+enum { AT_FIRST = 0, AT_SEARCH = 1, AT_IS_MATCH = 2 };
+static int run_at(int op, const mrx_handle* h, const Layout& lay, int64_t n, int32_t start, const int32_t* d_starts,
+                  int32_t* ds, int32_t* de, uint8_t* flag, void* st) {
+  if (!h) return fail(MRX_E_ARGUMENT, "null handle");
+  if (n < 0) return fail(MRX_E_ARGUMENT, "negative batch size");
+  hipStream_t s = (hipStream_t)st;
+  ScratchScope scratch_scope_(s);
+  if (start == 0 && !d_starts) {
+    return op == AT_FIRST ? run_first_any(h, lay, n, ds, de, st)
+         : op == AT_SEARCH ? run_search_any(h, lay, n, ds, de, st) : run_is_match_any(h, lay, n, flag, st);
+  }
+  // refusals first (nothing is launched for an operation the plan does not support)
+  if (op == AT_SEARCH) { if (int rc = check_search_supported(h)) return rc; }
+  else if (!h->hp.why_no_match_first.empty()) return fail(MRX_E_UNSUPPORTED, h->hp.why_no_match_first);
+  if (n == 0) return MRX_OK;
+  if (int rc = ensure_device(h)) return rc;
+  int64_t* vstart = nullptr;
+  int32_t* vlen = nullptr;
+  uint32_t* vskip = nullptr;
+  HIP_TRY(scratch_alloc((void**)&vstart, sizeof(int64_t) * (n + 1), s));
+  HIP_TRY(scratch_alloc((void**)&vlen, sizeof(int32_t) * n, s));
+  HIP_TRY(scratch_alloc((void**)&vskip, sizeof(uint32_t) * n, s));
+  hipLaunchKernelGGL(k_view_build, dim3(grid_for(n + 1, kBlock)), dim3(kBlock), 0, s, lay, n, start, d_starts, vstart, vlen, vskip);
+  Layout view{lay.data, vstart, 0, nullptr, 0};
+  view.vlen = vlen;
+  view.vskip = vskip;
+  const HostPlan& hp = h->hp;
+  const DevPlan& p = hp.dev;
+  // '^': DFAEngine.match_first / match_next / is_match (dfa.mojo:1866-1867, 1887-1891, 1828-1829) and
+  // OnePassNFA.match_first (onepass.mojo:445) answer None at start > 0; the LazyDFA does not (quirk A.6 #9)
+  const bool caret = p.kind == PLAN_DFA ? (p.flags & PF_START_ANCHOR) != 0
+                                         : (hp.first_onepass && hp.onepass.has_start_anchor && op != AT_SEARCH);
+  int rules = caret ? 1 : 0;
+  // start > len.  match_first: DFAEngine None (dfa.mojo:1922-1923), ".*" None (matcher.mojo:741-745); LazyDFA
+  // ._run_lazy and OnePassNFA.match_first run no step and report the empty match (start, start) when the
+  // start state accepts (pikevm.mojo:820-867, onepass.mojo:447-488).  match_next: None on every route.
+  // is_match: DFAEngine with a first-byte matcher = "start state accepts" (dfa.mojo:1832-1836), without one
+  // None; NFA route = bool(match_first).
+  const bool start_acc = hp.first_onepass ? p.fa_start_acc != 0 : (p.flags & PF_START_ACCEPTING) != 0;
+  if (hp.first_onepass ? start_acc : (p.kind == PLAN_LAZY && start_acc && !(p.flags & PF_START_DEAD))) rules |= 2 | 4;
+  if (p.kind == PLAN_DFA && (p.flags & PF_HAS_MATCHER) && start_acc) rules |= 4;
+  int rc = MRX_OK;
+  if (op == AT_FIRST) rc = run_first_any(h, view, n, ds, de, st);
+  else if (op == AT_SEARCH) { rules &= ~2; rc = run_search_any(h, view, n, ds, de, st); }
+  else { rules |= 8; rc = run_is_match_any(h, view, n, flag, st); }
+  if (rc == MRX_OK) {
+    hipLaunchKernelGGL(k_view_fix, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, lay, n, start, d_starts, rules, ds, de, flag);
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(scratch_free(vstart, s));
+  HIP_TRY(scratch_free(vlen, s));
+  HIP_TRY(scratch_free(vskip, s));
+  return rc;
+}
+#define MRX_CHECK_STRIDED()                                                                        \
+  if (stride <= 0) return fail(MRX_E_ARGUMENT, "stride must be positive");                         \
+  if (!lens && (len < 0 || len > stride)) return fail(MRX_E_ARGUMENT, "len must be in [0, stride]")
+int mrx_match_first_at_dev(const mrx_handle* h, const uint8_t* d, const int64_t* off, int64_t n, int32_t start,
+                           const int32_t* d_starts, int32_t* s, int32_t* e, void* st) {
+  if (!off) return fail(MRX_E_ARGUMENT, "null offsets");
+  return run_at(AT_FIRST, h, Layout{d, off, 0, nullptr, 0}, n, start, d_starts, s, e, nullptr, st);
+}
+int mrx_search_at_dev(const mrx_handle* h, const uint8_t* d, const int64_t* off, int64_t n, int32_t start,
+                      const int32_t* d_starts, int32_t* s, int32_t* e, void* st) {
+  if (!off) return fail(MRX_E_ARGUMENT, "null offsets");
+  return run_at(AT_SEARCH, h, Layout{d, off, 0, nullptr, 0}, n, start, d_starts, s, e, nullptr, st);
+}
+int mrx_is_match_at_dev(const mrx_handle* h, const uint8_t* d, const int64_t* off, int64_t n, int32_t start,
+                        const int32_t* d_starts, uint8_t* f, void* st) {
+  if (!off) return fail(MRX_E_ARGUMENT, "null offsets");
+  return run_at(AT_IS_MATCH, h, Layout{d, off, 0, nullptr, 0}, n, start, d_starts, nullptr, nullptr, f, st);
+}
+int mrx_match_first_at_strided_dev(const mrx_handle* h, const uint8_t* d, int64_t stride, const int32_t* lens, int32_t len,
+                                   int64_t n, int32_t start, const int32_t* d_starts, int32_t* s, int32_t* e, void* st) {
+  MRX_CHECK_STRIDED();
+  return run_at(AT_FIRST, h, Layout{d, nullptr, stride, lens, len}, n, start, d_starts, s, e, nullptr, st);
+}
+int mrx_search_at_strided_dev(const mrx_handle* h, const uint8_t* d, int64_t stride, const int32_t* lens, int32_t len,
+                              int64_t n, int32_t start, const int32_t* d_starts, int32_t* s, int32_t* e, void* st) {
+  MRX_CHECK_STRIDED();
+  return run_at(AT_SEARCH, h, Layout{d, nullptr, stride, lens, len}, n, start, d_starts, s, e, nullptr, st);
+}
+int mrx_is_match_at_strided_dev(const mrx_handle* h, const uint8_t* d, int64_t stride, const int32_t* lens, int32_t len,
+                                int64_t n, int32_t start, const int32_t* d_starts, uint8_t* f, void* st) {
+  MRX_CHECK_STRIDED();
+  return run_at(AT_IS_MATCH, h, Layout{d, nullptr, stride, lens, len}, n, start, d_starts, nullptr, nullptr, f, st);
+}
+#undef MRX_CHECK_STRIDED
+
 static int run_captures_any(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* spans, void* st) {
   ScratchScope scratch_scope_((hipStream_t)st);
   if (!h) return fail(MRX_E_ARGUMENT, "null handle");

@@ -57,22 +57,16 @@ class ProductBackend:
         return M.split(p, [t], maxsplit)[0]
 
     def obj_match_first(self, p, t, start=0):
-        if start != 0:
-            raise Unsupported("start offset is not part of the batch ABI")
-        return self._one(self._rx(p).match_first([t]))  # same as engine match_first at 0
+        return self._one(self._rx(p).match_first_at([t], start))   # engine-level match_first(text, start)
 
     def obj_match_next(self, p, t, start=0):
-        if start != 0:
-            raise Unsupported("start offset is not part of the batch ABI")
-        return self.search(p, t)
+        return self._one(self._rx(p).match_next_at([t], start))
 
     def obj_test(self, p, t):
         return bool(self._rx(p).test([t])[0])
 
     def obj_is_match(self, p, t, start=0):
-        if start != 0:
-            raise Unsupported("start offset is not part of the batch ABI")
-        return bool(self._rx(p).is_match([t])[0])
+        return bool(self._rx(p).is_match_at([t], start)[0])
 
     def engine_type(self, p):
         return self._rx(p).get_engine_type()
@@ -98,6 +92,15 @@ class ProductBackend:
         return self.findall(p, t)
 
     def _dfa_pat(self, build):
+        if build["kind"] == "literal" and build["literal"].isalnum():
+            # DFAEngine.compile_pattern(literal, anchors) is what compile_dfa_pattern builds for ^literal$
+            # (dfa.mojo:2385-2410): reach it through the pattern
+            p = (("^" if build.get("start_anchor") else "") + build["literal"] +
+                 ("$" if build.get("end_anchor") else "")).encode()
+            self._ct_ok(p)
+            if "pure_literal=1" not in self._rx(p).describe():
+                raise Unsupported("literal does not take the DFA literal route")
+            return p
         if build["kind"] != "pattern":
             raise Unsupported("direct DFAEngine construction is not an ABI entry point")
         p = build["pattern"].encode()
@@ -105,16 +108,11 @@ class ProductBackend:
         return p
 
     def dfa_match_first(self, build, t, start=0):
-        if start != 0:
-            raise Unsupported("start offset")
-        s, e = self._rx(self._dfa_pat(build)).match_first([t])
-        # DFAEngine.match_first does not filter on start == 0, but with start=0 it cannot differ
-        return self._one((s, e))
+        # DFAEngine.match_first(text, start) == the engine-level operation of the ABI
+        return self._one(self._rx(self._dfa_pat(build)).match_first_at([t], start))
 
     def dfa_match_next(self, build, t, start=0):
-        if start != 0:
-            raise Unsupported("start offset")
-        return self.search(self._dfa_pat(build), t)
+        return self._one(self._rx(self._dfa_pat(build)).match_next_at([t], start))
 
     def dfa_match_all(self, build, t):
         return self.findall(self._dfa_pat(build), t)
@@ -1505,3 +1503,65 @@ def test_fused_findall_back_to_back_calls_reuse_their_scratch():
     assert lib.mrx_debug_scratch_bytes() == size0
     for pre, sp in outs:
         assert torch.equal(pre, p0) and torch.equal(sp[:t0], s0[:t0])
+
+
+AT_PATTERNS = [b"hello", b"[a-z]+\\d+", b"\\d+", b"[0-9]*", b"[a-z]*[0-9]+", b"^abc", b"^[a-z]+", b"a$", b"^abc$", b".*", b"",
+               b"(x|y|foo|bar)+", b"(\\d{3})(\\d{3})(\\d{4})", b"hello world this is long", b"\\w+@\\w+\\.com", b"\\d{3}-\\d{4}",
+               b"(foo|foobar)x", b"\\d+(\\.\\d+)?", b"[a-c]+[x-z]?", b"^[a-z]+[0-9]+$", b"^\\d+$", b"(a|b)*c", b"^(a|b)*c",
+               b"abab", b"[^0-9]+", b"x*"]
+
+
+@pytest.mark.parametrize("pat", AT_PATTERNS)
+def test_start_argument_matches_oracle(pat):
+    """mrx_{match_first,search,is_match}_at_*: Engine.match_first(text, start) and friends
+    (engine.mojo:4-37, matcher.mojo:1049-1115) for every start in [0, len + 2] and start = -1, one
+    start for the whole batch and one per text, CSR and fixed-pitch batches, against the oracle's
+    CompiledRegex.match_first / match_next / is_match with the same start."""
+    _need_gpu()
+    rx = M.compile_regex(pat)
+    orx = O.compile_regex(pat)
+    rng = np.random.default_rng(zlib.crc32(pat))
+    al = b"abcxyz0189 -.@fobarhelo w" + bytes(c for c in pat if chr(c).isalnum()) * 2
+    texts = _random_texts(rng, 96, 40, al)
+    texts += [b"hello world this is long", b"abc", b"abcabc", b"123-4567 555-1234", b"foobarx foox", b"a@b.com xx@yy.com",
+              b"6502530000 4155551234", b"ab12", b"", b"x", b"3.14 15"]
+    n = len(texts)
+    pitch = 48
+    arr = np.zeros((n, pitch), dtype=np.uint8)
+    lens = np.zeros(n, dtype=np.int32)
+    for i, t in enumerate(texts):
+        arr[i, : len(t)] = np.frombuffer(t, dtype=np.uint8)
+        lens[i] = len(t)
+    csr = M.DeviceBatch.from_texts(texts)
+    strided = M.DeviceBatch.strided(torch.from_numpy(arr).cuda().reshape(-1), pitch, lens=torch.from_numpy(lens).cuda())
+
+    def want(op, t, s):
+        try:
+            if op == "is_match":
+                return bool(orx.is_match(t, s)) if s >= 0 else False
+            r = (orx.match_first if op == "match_first" else orx.match_next)(t, s) if s >= 0 else None
+            return r if r else (-1, -1)
+        except UnsupportedByOracle:
+            return "unsupported"
+
+    per_text = rng.integers(-1, 44, size=n).astype(np.int32)
+    per_text[:8] = [0, 1, 2, 0, 40, 41, -1, 3]
+    cases = [("scalar", s) for s in (0, 1, 2, 3, 5, 11, 24, 25, 39, 40, 41, 42, -1)] + [("per_text", per_text)]
+    for op in ("match_first", "search", "is_match"):
+        for kind, start in cases:
+            for batch in (csr, strided):
+                try:
+                    got = rx._at(op, batch, start)
+                except M.UnsupportedPattern:
+                    assert want(op, texts[0], 0) == "unsupported", (pat, op)
+                    continue
+                if op == "is_match":
+                    got = got.cpu().numpy()
+                else:
+                    got = np.stack([got[0].cpu().numpy(), got[1].cpu().numpy()], axis=1)
+                for i, t in enumerate(texts):
+                    s = int(start[i]) if kind == "per_text" else start
+                    w = want(op, t, s)
+                    assert w != "unsupported", (pat, op)
+                    h = bool(got[i]) if op == "is_match" else (int(got[i][0]), int(got[i][1]))
+                    assert h == w, (pat, op, kind, s, t, h, w)
