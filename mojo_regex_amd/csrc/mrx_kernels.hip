@@ -214,7 +214,17 @@ __host__ __device__ inline size_t wstep_table_bytes(int nstates) { return (size_
 // there (DFAEngine.match_first, anchored); keep the match if it ends past the hit and resume at
 // its end, else resume at hit + 1.  (The required byte is not in the first class, so the run
 // start at hit + 1 is hit + 1; the run start at a match end is remembered when `last` moves.)
-template <int MODE, int ROUTE>
+// BITS = 1 (PF_BSTEP, ROUTE 0 only): the bitset-NFA form of the same loop for LazyDFA plans that have no
+// determinised table (PikeVM semantics, pikevm.mojo:497-648 / 754-867).  The state of a walk is the SET of
+// live program positions (one 64-bit word per lane; the empty set = "looking for a start"), and a step is
+//     x = set & mask[byte];   next = OR over the 8-bit chunks j of x of  follow8[j][chunk j of x]
+// with mask[b] = positions whose instruction consumes byte b and follow8[j][v] = union of the closures
+// after the positions 8 j + k, k in v (both built in LDS per workgroup from the plan's per-position
+// follow sets): one mask read and ceil(positions / 8) table reads per byte, whatever the number of live
+// positions and without any data-dependent loop -- the lanes of a wavefront stay in step.
+__host__ __device__ inline size_t bstep_table_bytes(int npos) { return 2048 + (size_t)((npos + 7) / 8) * 2048 + 256; }
+
+template <int MODE, int ROUTE, int BITS = 0>
 __global__ __launch_bounds__(64 * kWsWaves) void k_wstep(DevPlan p, const uint8_t* __restrict__ blob, Layout lay,
                                                          int64_t n, int32_t* __restrict__ counts,
                                                          const int64_t* __restrict__ prefix,
@@ -226,8 +236,33 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_wstep(DevPlan p, const uint8_
   // One byte-indexed table for the whole step: row q < nstates is DFA state q, row nstates is
   // "looking for a start".  Entry = next | ACC | START, or DEAD.  (Built from the plan's class
   // tables, so a step costs one dependent LDS read instead of three.)
+  static_assert(!(BITS && ROUTE), "the bitset form has the plain route only");
   uint16_t* tab = (uint16_t*)lds;
   const int ns = p.nstates, idle = ns;
+  // BITS: mask[256] | follow8[nch][256] | first-byte filter[256]
+  uint64_t* bmask = (uint64_t*)lds;
+  const int nch = (p.bs_npos + 7) >> 3;
+  uint64_t* bfol = bmask + 256;
+  uint8_t* bfirst = (uint8_t*)(bfol + (size_t)nch * 256);
+  const uint64_t bstart = p.bs_start[0], bmatch = p.bs_match[0];
+  if (BITS) {
+    const uint8_t* g_bcls = blob + p.off_bs_cls;
+    const uint64_t* g_mask = (const uint64_t*)(blob + p.off_bs_mask);
+    const uint64_t* g_fol = (const uint64_t*)(blob + p.off_bs_follow);
+    const uint8_t* g_first = blob + p.off_first;
+    const bool filt = (p.flags & PF_HAS_MATCHER) != 0;   // LazyDFA has_filter (pikevm.mojo:367-416)
+    for (int e = threadIdx.x; e < 256; e += blockDim.x) {
+      bmask[e] = g_mask[g_bcls[e]];
+      bfirst[e] = filt ? g_first[e] : (uint8_t)1;
+    }
+    for (int e = threadIdx.x; e < nch * 256; e += blockDim.x) {
+      const int j = e >> 8, v = e & 255;
+      uint64_t u = 0;
+      for (int k = 0; k < 8; ++k)
+        if (((v >> k) & 1) && 8 * j + k < p.bs_npos) u |= g_fol[8 * j + k];
+      bfol[e] = u;
+    }
+  } else
   {
     const uint8_t* g_cls = blob + p.off_cls;
     const uint8_t* g_first = blob + p.off_first;
@@ -274,6 +309,7 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_wstep(DevPlan p, const uint8_
     int pos = mis, start = mis, last = -1, k = 0, rs = -1, re = -1;
     int rsb = mis, rsb_last = mis, hit = -1;   // ROUTE 1: run start of first-class bytes (now / at `last`), last hit
     int state = idle;
+    uint64_t bset = 0;   // BITS: live positions of the current walk (0 = looking for a start)
     const bool skipped = lay.split > 0 && t.len >= lay.split;   // k_req_wave's text
     bool fin = !live || t.len == 0 || skipped;
     int64_t wo = (MODE == STEP_EMIT && live) ? prefix[i] : 0;
@@ -309,6 +345,42 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_wstep(DevPlan p, const uint8_
       // or the text has ended).  Branch-free apart from the span store.
       auto step = [&](bool act, uint32_t byte) {
         const bool inside = pos < end;
+        if (BITS) {
+          const bool idl = bset == 0ull;
+          const uint64_t src = idl ? (bfirst[byte] ? bstart : 0ull) : bset;   // a candidate byte starts a walk
+          const uint64_t x = src & bmask[byte];
+          uint64_t nx = 0;
+          for (int j = 0; j < nch; ++j) nx |= bfol[(j << 8) + (int)((x >> (8 * j)) & 0xFFull)];
+          const bool alive = act && inside && nx != 0ull;        // a walk goes on, or begins on this byte
+          const bool skip = act && inside && idl && nx == 0ull;   // no walk starts here
+          const bool stop = act && !alive && !skip;              // the text has ended, or the walk died
+          const bool ends = stop && !idl;
+          const bool matched = ends && last >= 0;
+          if (MODE == STEP_EMIT) {
+            if (matched) {
+              if (wo < span_cap) { spans[2 * wo] = start - mis; spans[2 * wo + 1] = last - mis; }
+              ++wo;
+            }
+          }
+          if (MODE == STEP_SLOTS) {
+            if (matched) {
+              if (wo < slot_cap) *(int2*)(spans + 2 * (slot0 + wo)) = make_int2(start - mis, last - mis);
+              ++wo;
+            }
+          }
+          if (MODE == STEP_SEARCH) { rs = matched ? start - mis : rs; re = matched ? last - mis : re; }
+          fin = fin || (stop && idl) || (MODE == STEP_SEARCH && matched);
+          k += matched ? 1 : 0;
+          const int after = matched ? last : start + 1;
+          const bool begins = alive && idl;
+          start = begins ? pos : start;
+          last = begins ? -1 : last;
+          const int nxt = pos + 1;
+          last = (alive && (nx & bmatch)) ? nxt : last;   // LazyDFA is_match of the state entered (pikevm.mojo:834-835, 861-862)
+          pos = (alive || skip) ? nxt : (ends ? after : pos);
+          bset = alive ? nx : (stop ? 0ull : bset);   // (a lane that is not stepping keeps its walk)
+          return;
+        }
         const uint32_t e = tab[(state << 8) + byte];
         if (ROUTE == 1) {
           const bool scanning = state == idle;
@@ -397,6 +469,134 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_wstep(DevPlan p, const uint8_
       if (MODE == STEP_COUNT || MODE == STEP_SLOTS) counts[i] = k;
       if (MODE == STEP_SEARCH) { out_s[i] = rs; out_e[i] = re; }
     }
+  }
+}
+
+// ---- bitset NFA, first pass: the union automaton -------------------------------------------------
+// PF_BSTEP plans.  The restart-per-position search of the reference (LazyDFA.match_next / match_all,
+// pikevm.mojo:754-817) walks the bytes of a failing region once per start position.  What it can find
+// is bounded by a single linear pass: run ALL starts at once -- the set U of positions alive in ANY walk
+// begun at a candidate byte so far,
+//     U' = follow8[ ((U & mask[b]) | (start & mask[b] if b may start a walk)) ]
+// -- and note where U' holds MATCH: exactly the positions where SOME walk (from some start) is in a
+// matching state, i.e. a superset of the ends of the matches the reference reports (it resumes behind
+// each match, so walks begun inside one do not count for it; a superset is all that is needed).  So
+//   * a text without such a position has no match at all, and
+//   * behind the last such position nothing can match; a match reported by the restart-per-position
+//     search ends at one of them, so truncating the text there changes no result.
+// k_bscan makes that pass (one lane per text, text through the LDS tile in coalesced 128-byte rows, one
+// table read for mask | start-mask and ceil(positions / 8) follow reads per byte, no restarts, lanes in
+// lockstep) and writes for every text the length the second pass (k_wstep<., 0, 1>) has to look at:
+// mode 0 (search) the whole text if it has a match end, else 0; mode 1 (count / findall) the last match
+// end, 0 if none.  W32: at most 32 positions -- 32-bit sets.
+__host__ __device__ inline size_t bscan_table_bytes(int npos) {
+  return npos <= 32 ? (size_t)2048 + (size_t)((npos + 7) / 8) * 1024 : (size_t)4096 + (size_t)((npos + 7) / 8) * 2048;
+}
+template <int W32>
+__global__ __launch_bounds__(64 * kWsWaves) void k_bscan(DevPlan p, const uint8_t* __restrict__ blob, Layout lay,
+                                                         int64_t n, int mode, int32_t* __restrict__ limit) {
+  constexpr int CH = 128, kRowPitch = CH + 16, LPR = CH / 16, RPI = 64 / LPR, NL = 64 / RPI;
+  using Set = typename std::conditional<W32 != 0, uint32_t, uint64_t>::type;
+  struct Ent { Set mask, sm; };   // positions that consume the byte; those of them a walk starting on it holds
+  __shared__ __align__(16) uint8_t tiles[kWsWaves][64 * kRowPitch];
+  extern __shared__ __align__(16) uint8_t lds[];
+  Ent* tbl = (Ent*)lds;
+  Set* fol = (Set*)(tbl + 256);
+  const int nch = (p.bs_npos + 7) >> 3;
+  const Set bmatch = (Set)p.bs_match[0];
+  {
+    const uint8_t* g_bcls = blob + p.off_bs_cls;
+    const uint64_t* g_mask = (const uint64_t*)(blob + p.off_bs_mask);
+    const uint64_t* g_fol = (const uint64_t*)(blob + p.off_bs_follow);
+    const uint8_t* g_first = blob + p.off_first;
+    const bool filt = (p.flags & PF_HAS_MATCHER) != 0;
+    for (int e = threadIdx.x; e < 256; e += blockDim.x) {
+      const uint64_t m = g_mask[g_bcls[e]];
+      Ent t;
+      t.mask = (Set)m;
+      t.sm = (Set)((!filt || g_first[e]) ? (p.bs_start[0] & m) : 0ull);
+      tbl[e] = t;
+    }
+    for (int e = threadIdx.x; e < nch * 256; e += blockDim.x) {
+      const int j = e >> 8, v = e & 255;
+      uint64_t u = 0;
+      for (int k = 0; k < 8; ++k)
+        if (((v >> k) & 1) && 8 * j + k < p.bs_npos) u |= g_fol[8 * j + k];
+      fol[e] = (Set)u;
+    }
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint8_t* tile = tiles[wave];
+  const int seg = lane % LPR, rsub = lane / LPR;
+  const int64_t nw = (n + 63) >> 6;
+  for (int64_t w = (int64_t)blockIdx.x * kWsWaves + wave; w < nw; w += (int64_t)gridDim.x * kWsWaves) {
+    const int64_t i = (w << 6) + lane;
+    const bool live = i < n;
+    const Text t = live ? lay.text(i) : Text(blob, 0);
+    const uintptr_t addr = t.len > 0 ? (uintptr_t)t.ptr : (uintptr_t)blob;   // empty rows park on the blob
+    const int mis = t.len > 0 ? (int)(addr & 15) : 0;
+    const uintptr_t rb = addr & ~(uintptr_t)15;
+    const int end = mis + t.len;   // frame coordinates: the text is [mis, end)
+    __builtin_amdgcn_wave_barrier();
+    *(uint4*)(tile + lane * kRowPitch + CH) = make_uint4((uint32_t)rb, (uint32_t)((uint64_t)rb >> 32), (uint32_t)end, 0u);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    int max_end = end;
+    for (int off = 32; off > 0; off >>= 1) max_end = max(max_end, __shfl_xor(max_end, off));
+    const uint8_t* myrow = tile + lane * kRowPitch;
+    uint4 v[NL];
+#define MRX_BS_LOAD(CB)                                                                   \
+    do {                                                                                  \
+      _Pragma("unroll") for (int j_ = 0; j_ < NL; ++j_) {                                  \
+        const uint4 rs_ = *(const uint4*)(tile + (RPI * j_ + rsub) * kRowPitch + CH);      \
+        uint32_t fo_ = (uint32_t)(CB) + seg * 16;                                          \
+        if (fo_ >= rs_.z) fo_ = 0;                                                         \
+        v[j_] = mrx_ldg((const uint4*)((const uint8_t*)(((uint64_t)rs_.y << 32) | rs_.x) + fo_)); \
+      }                                                                                    \
+    } while (0)
+    Set U = 0;
+    int last_end = 0;       // frame position behind the last byte after which U held MATCH (0: none; > mis otherwise)
+    bool found = false;
+    if (max_end > 0) MRX_BS_LOAD(0);
+    for (int wb = 0; wb < max_end; wb += CH) {
+#pragma unroll
+      for (int j = 0; j < NL; ++j) *(uint4*)(tile + (RPI * j + rsub) * kRowPitch + seg * 16) = v[j];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (wb + CH < max_end) MRX_BS_LOAD(wb + CH);   // next window, in flight while this one is stepped
+#pragma unroll 2
+      for (int g = 0; g < CH / 16; ++g) {
+        const uint4 wv = *(const uint4*)(myrow + g * 16);
+        const uint32_t words[4] = {wv.x, wv.y, wv.z, wv.w};
+        uint32_t hits = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          const uint32_t b = (words[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
+          const Ent e = tbl[b];
+          const Set x = (U & e.mask) | e.sm;
+          Set nx = 0;
+          if (W32) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (j < nch) nx |= fol[(j << 8) + (int)((x >> (8 * j)) & 0xFFu)];   // (wave uniform)
+          } else {
+            for (int j = 0; j < nch; ++j) nx |= fol[(j << 8) + (int)((x >> (8 * j)) & 0xFFu)];
+          }
+          const int f = wb + g * 16 + k;
+          const bool inside = f >= mis && f < end;
+          U = inside ? nx : (Set)0;
+          hits |= (inside && (nx & bmatch)) ? (1u << k) : 0u;
+        }
+        if (hits) { last_end = wb + g * 16 + (32 - __builtin_clz(hits)); found = true; }
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (mode == 0 && __all(found || wb + CH >= end)) break;   // search: every text has its answer
+    }
+#undef MRX_BS_LOAD
+    if (live) limit[i] = mode == 0 ? (found ? t.len : 0) : (found ? last_end - mis : 0);
   }
 }
 
@@ -2354,11 +2554,38 @@ int grid_for(int64_t n, int block) {
 }
 
 // k_wstep for findall / count: plain route or required-byte route (a bool `use_req_route` in scope)
+// (and a DevPlan `p` or handle `h` whose flags say whether the bitset form runs: `wstep_bits`)
 #define MRX_WSTEP_LAUNCH(MODE, ...)                                                        \
   do {                                                                                     \
-    if (use_req_route) hipLaunchKernelGGL((k_wstep<MODE, 1>), __VA_ARGS__);              \
+    if (wstep_bits) hipLaunchKernelGGL((k_wstep<MODE, 0, 1>), __VA_ARGS__);                \
+    else if (use_req_route) hipLaunchKernelGGL((k_wstep<MODE, 1>), __VA_ARGS__);         \
     else hipLaunchKernelGGL((k_wstep<MODE, 0>), __VA_ARGS__);                              \
   } while (0)
+// dynamic LDS of k_wstep for this plan
+size_t wstep_lds(const DevPlan& p) {
+  return (p.flags & PF_BSTEP) ? bstep_table_bytes(p.bs_npos) : wstep_table_bytes(p.nstates);
+}
+// Bitset NFA, first pass (k_bscan): on return *out is `lay` with every text cut to what the second pass
+// has to look at (mode 0 search, 1 count / findall); *d_limit is scratch the caller frees.
+int bscan_limits(const mrx_handle* h, const Layout& lay, int64_t n, int mode, hipStream_t s, Layout* out,
+                 int32_t** d_limit) {
+  const DevPlan& p = h->hp.dev;
+  HIP_TRY(scratch_alloc((void**)d_limit, sizeof(int32_t) * (n > 0 ? n : 1), s));
+  const int64_t nw = (n + 63) / 64;
+  int64_t g = (nw + kWsWaves - 1) / kWsWaves;
+  if (g < 1) g = 1;
+  if (g > grid_cap()) g = grid_cap();
+  if (p.bs_npos <= 32)
+    hipLaunchKernelGGL((k_bscan<1>), dim3((unsigned)g), dim3(64 * kWsWaves), bscan_table_bytes(p.bs_npos), s, p, H_BLOB(h),
+                       lay, n, mode, *d_limit);
+  else
+    hipLaunchKernelGGL((k_bscan<0>), dim3((unsigned)g), dim3(64 * kWsWaves), bscan_table_bytes(p.bs_npos), s, p, H_BLOB(h),
+                       lay, n, mode, *d_limit);
+  HIP_TRY(hipGetLastError());
+  *out = lay;
+  if (lay.offsets) out->vlen = *d_limit; else out->lens = *d_limit;
+  return MRX_OK;
+}
 
 // The stepper's routes: one wavefront per text (k_req_wave) when the texts are long or too few to
 // fill the device with one lane each, one lane per text (k_wstep) otherwise.  The average length
@@ -2498,10 +2725,21 @@ int run_match(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d_s, i
       !(h->hp.dev.flags & PF_PREFILTER)) {   // (the memchr prefilter changes match_next, matcher.mojo:784-796)
     bool wave = false;
     const bool big = (h->hp.dev.flags & PF_STEP_BIG) != 0;   // only the wavefront kernel has its table form
+    const bool bits = (h->hp.dev.flags & PF_BSTEP) != 0;     // bitset NFA: the lane-per-text stepper only
     int split = 0;
-    if (int rc = req_wave_pays(lay, n, false, s, &wave, big ? nullptr : &split)) return rc;
+    if (!bits)
+      if (int rc = req_wave_pays(lay, n, false, s, &wave, big ? nullptr : &split)) return rc;
     Layout lay2 = lay;
     lay2.split = split;
+    if (bits) {   // union automaton first: texts without any match end are not searched at all
+      int32_t* d_limit = nullptr;
+      if (int rc = bscan_limits(h, lay, n, 0, s, &lay2, &d_limit)) return rc;
+      hipLaunchKernelGGL((k_wstep<STEP_SEARCH, 0, 1>), dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_lds(h->hp.dev), s,
+                         h->hp.dev, H_BLOB(h), lay2, n, (int32_t*)nullptr, (const int64_t*)nullptr, (int32_t*)nullptr,
+                         (int64_t)0, d_s, d_e);
+      HIP_TRY(scratch_free(d_limit, s));
+      g_last_kernel = "k_bstep_search";
+    } else
     if (big && !wave) {   // many short texts: the literal restatement, one lane per text
       hipLaunchKernelGGL(k_match<OP>, dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s, h->hp.dev,
                          H_BLOB(h), lay, n, d_s, d_e, d_flag);
@@ -2517,7 +2755,7 @@ int run_match(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d_s, i
                          (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0, d_s, d_e);
       g_last_kernel = "k_req_wave_search";
     } else {
-    hipLaunchKernelGGL((k_wstep<STEP_SEARCH, 0>), dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_table_bytes(h->hp.dev.nstates), s, h->hp.dev,
+    hipLaunchKernelGGL((k_wstep<STEP_SEARCH, 0>), dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_lds(h->hp.dev), s, h->hp.dev,
                        H_BLOB(h), lay2, n, (int32_t*)nullptr, (const int64_t*)nullptr, (int32_t*)nullptr,
                        (int64_t)0, d_s, d_e);
     g_last_kernel = "k_step_search";
@@ -2800,11 +3038,13 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
   // match_next_sequence: the caller (sub) wants the matches that iterating match_next from each
   // match end visits -- the plain walk even on plans whose findall takes the required-byte route
   const bool use_req_route = (p.flags & PF_STEP_REQ) && !match_next_sequence;
+  const bool wstep_bits = (p.flags & PF_BSTEP) != 0;   // bitset NFA on the lane-per-text stepper
   bool step_ok = g_force_generic < 2 &&
                  (match_next_sequence ? ((p.flags & PF_STEP_SEARCH) && !(p.flags & PF_PREFILTER))
                                       : (p.flags & (PF_STEPPABLE | PF_STEP_REQ)) != 0);
   bool fused = false;      // streaming path: scan, CSR offsets and spans in one launch (ST_FUSED)
   unsigned long long* d_ctrl = nullptr;   // its ticket word, error word and descriptors
+  int32_t* d_blimit = nullptr;            // bitset NFA: per-text limits of the first pass
   bool rec32 = false;      // streaming path: one record per two groups (positions fit 16 bits)
   int64_t max_text = int64_t(1) << 40;   // longest text of the batch, where known
   bool req_wave = false;   // the stepper's route on the wavefront-per-text kernel
@@ -2887,10 +3127,13 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
       tm.stop();
       }
     } else {
-      if (step_ok)
+      if (step_ok && !wstep_bits)
         if (int rc = req_wave_pays(lay, n, use_req_route, s, &req_wave, (p.flags & PF_STEP_BIG) ? nullptr : &step_split))
           return rc;
       lay2.split = step_split;
+      if (step_ok && wstep_bits) {   // bitset NFA: cut every text behind its last possible match end first
+        if (int rc = bscan_limits(h, lay, n, 1, s, &lay2, &d_blimit)) return rc;
+      }
       // big tables: only the wavefront kernel has their form; many short texts stay on the literal restatement
       if ((p.flags & PF_STEP_BIG) && !req_wave) step_ok = false;
       ScanTimer tm(s);
@@ -2909,16 +3152,17 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
           HIP_TRY(scratch_alloc((void**)&d_slots, sizeof(int32_t) * 2 * (size_t)(bytes / 4 + 32 * n + 64), s));
         } else if (!lay.offsets && step_split == 0 && (lay.lens ? lay.stride : (int64_t)lay.len) >= 2048) {
           // one lane per text, but texts long enough to hold more than kStepSlots matches as a rule
+          // (rows sized as Layout::slot_row sizes them for lay2 -- the bitset first pass gives it per-text lengths)
           lay2.wide_slots = 1;
           HIP_TRY(scratch_alloc((void**)&d_slots,
-                                sizeof(int32_t) * 2 * (size_t)(n * ((lay.lens ? lay.stride : (int64_t)lay.len) / 4 + 32) + 64), s));
+                                sizeof(int32_t) * 2 * (size_t)(n * ((lay2.lens ? lay2.stride : (int64_t)lay2.len) / 4 + 32) + 64), s));
         } else
         HIP_TRY(scratch_alloc((void**)&d_slots, sizeof(int32_t) * 2 * kStepSlots * (size_t)n, s));
         if (req_wave)
           MRX_REQWAVE_LAUNCH(STEP_SLOTS, h, lay2, n, d_counts, (const int64_t*)nullptr, d_slots, (int64_t)0, s);
         else
         {
-        MRX_WSTEP_LAUNCH(STEP_SLOTS, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_table_bytes(h->hp.dev.nstates), s, p,
+        MRX_WSTEP_LAUNCH(STEP_SLOTS, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_lds(h->hp.dev), s, p,
                            H_BLOB(h), lay2, n, d_counts, (const int64_t*)nullptr, d_slots, (int64_t)0,
                            (int32_t*)nullptr, (int32_t*)nullptr);
         if (step_split > 0)
@@ -2927,7 +3171,7 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
       } else if (step_ok && req_wave)
         MRX_REQWAVE_LAUNCH(STEP_COUNT, h, lay, n, d_counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0, s);
       else if (step_ok) {
-        MRX_WSTEP_LAUNCH(STEP_COUNT, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_table_bytes(h->hp.dev.nstates), s, p,
+        MRX_WSTEP_LAUNCH(STEP_COUNT, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_lds(h->hp.dev), s, p,
                            H_BLOB(h), lay2, n, d_counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0,
                            (int32_t*)nullptr, (int32_t*)nullptr);
         if (step_split > 0)
@@ -2936,7 +3180,7 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
         hipLaunchKernelGGL(k_findall<FA_COUNT>, dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s,
                            p, H_BLOB(h), lay, n, d_counts, (const int64_t*)nullptr, (int32_t*)nullptr,
                            (int64_t)0);
-      g_last_kernel = req_wave ? "k_req_wave" : step_ok ? (step_split > 0 ? "k_step_count+k_req_wave" : "k_step_count")
+      g_last_kernel = req_wave ? "k_req_wave" : step_ok ? (wstep_bits ? "k_bstep_count" : step_split > 0 ? "k_step_count+k_req_wave" : "k_step_count")
                                                         : "k_findall_count";
       HIP_TRY(hipGetLastError());
       tm.stop();
@@ -2988,7 +3232,7 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
         if (req_wave)
           MRX_REQWAVE_LAUNCH(STEP_EMIT, h, lay2, n, d_counts, d_prefix, d_spans, span_cap, s);
         else {
-        MRX_WSTEP_LAUNCH(STEP_EMIT, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_table_bytes(h->hp.dev.nstates), s, p, H_BLOB(h),
+        MRX_WSTEP_LAUNCH(STEP_EMIT, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_lds(h->hp.dev), s, p, H_BLOB(h),
                            lay2, n, d_counts, d_prefix, d_spans, span_cap, (int32_t*)nullptr,
                            (int32_t*)nullptr);
         if (step_split > 0) MRX_REQWAVE_LAUNCH(STEP_EMIT, h, lay2, n, d_counts, d_prefix, d_spans, span_cap, s);
@@ -3017,6 +3261,7 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
   if (d_nrecs) HIP_TRY(scratch_free(d_nrecs, s));
   if (d_wbase) HIP_TRY(scratch_free(d_wbase, s));
   if (d_slots) HIP_TRY(scratch_free(d_slots, s));
+  if (d_blimit) HIP_TRY(scratch_free(d_blimit, s));
   return rc;
 }
 
@@ -3467,22 +3712,26 @@ static int run_count_any(const mrx_handle* h, const Layout& lay, int64_t n, int3
     }
   } else {
     const bool use_req_route = (h->hp.dev.flags & PF_STEP_REQ) != 0;
+    const bool wstep_bits = (h->hp.dev.flags & PF_BSTEP) != 0;
     bool req_wave = false;
     int split = 0;
-    if (g_force_generic < 2 && (h->hp.dev.flags & (PF_STEPPABLE | PF_STEP_REQ)))
+    if (g_force_generic < 2 && !wstep_bits && (h->hp.dev.flags & (PF_STEPPABLE | PF_STEP_REQ)))
       if (int rc = req_wave_pays(lay, n, use_req_route, s, &req_wave, (h->hp.dev.flags & PF_STEP_BIG) ? nullptr : &split))
         return rc;
     Layout lay2 = lay;
     lay2.split = split;
+    int32_t* d_blimit = nullptr;
+    if (g_force_generic < 2 && wstep_bits)   // bitset NFA: cut every text behind its last possible match end first
+      if (int rc = bscan_limits(h, lay, n, 1, s, &lay2, &d_blimit)) return rc;
     const bool big_lane = (h->hp.dev.flags & PF_STEP_BIG) && !req_wave;   // -> literal restatement
     if (req_wave) {
       MRX_REQWAVE_LAUNCH(STEP_COUNT, h, lay, n, counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0, s);
       g_last_kernel = "k_req_wave";
     } else if (g_force_generic < 2 && !big_lane && (h->hp.dev.flags & (PF_STEPPABLE | PF_STEP_REQ))) {
-      MRX_WSTEP_LAUNCH(STEP_COUNT, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_table_bytes(h->hp.dev.nstates), s, h->hp.dev,
+      MRX_WSTEP_LAUNCH(STEP_COUNT, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_lds(h->hp.dev), s, h->hp.dev,
                          H_BLOB(h), lay2, n, counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0,
                          (int32_t*)nullptr, (int32_t*)nullptr);
-      g_last_kernel = "k_step_count";
+      g_last_kernel = wstep_bits ? "k_bstep_count" : "k_step_count";
       if (split > 0) {
         MRX_REQWAVE_LAUNCH(STEP_COUNT, h, lay2, n, counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0, s);
         g_last_kernel = "k_step_count+k_req_wave";

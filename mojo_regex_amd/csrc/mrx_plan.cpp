@@ -740,6 +740,12 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
     else if (d.kind == PLAN_DFA && (d.flags & PF_HAS_MATCHER) && !first[d.required_byte]) d.flags |= PF_STEP_REQ;
   }
 
+  // The same plain route for a LazyDFA that is walked as a bitset NFA (pikevm.mojo:754-817 over the state
+  // sets of pikevm.mojo:497-648): one 64-bit word of live positions per lane, no determinised table.
+  if (d.kind == PLAN_LAZY && (d.flags & PF_BITSET) && hp.bitset.nw == 1 && hp.why_no_search.empty() &&
+      !(d.flags & (PF_EXACT_LITERAL | PF_START_ACCEPTING | PF_START_DEAD)))
+    d.flags |= PF_BSTEP | PF_STEP_SEARCH | PF_STEPPABLE;
+
   // ---- anchored automaton: regex.match_first as one forward pass ----------------------
   // match_first(text) = engine_match_first(text, 0) keeps no restart loop, so it is a plain
   // automaton run from byte 0 that remembers the last accepting position:
@@ -961,7 +967,8 @@ std::string describe_plan(const HostPlan& hp) {
     << " sync_bytes=" << d.st_nsync << " reset_byte=" << d.st_reset_byte
     << (d.off_stg_pair >= 0 ? " pair_table=1" : "") << "\n";
   o << "device.steppable=" << ((d.flags & PF_STEPPABLE) ? "yes" : (d.flags & PF_STEP_REQ) ? "required-byte route" : "no")
-    << " step_search=" << ((d.flags & PF_STEP_SEARCH) ? 1 : 0) << ((d.flags & PF_STEP_BIG) ? " big_table=1" : "") << "\n";
+    << " step_search=" << ((d.flags & PF_STEP_SEARCH) ? 1 : 0) << ((d.flags & PF_STEP_BIG) ? " big_table=1" : "")
+    << ((d.flags & PF_BSTEP) ? " bitset=1" : "") << "\n";
   o << "device.first_stream=" << (d.fa_bytes ? "yes" : ("no: " + hp.first_stream_why_not))
     << " fa_nstates=" << d.fa_nstates << " fa_kind=" << d.fa_kind << (hp.first_onepass ? " onepass=yes" : "")
     << (d.off_fa_run >= 0 ? " class_run=1" : "") << "\n";

@@ -38,6 +38,9 @@ enum PlanFlags : uint32_t {
                                 // wavefront-per-text kernel (class-indexed table) runs it
   PF_STEPPABLE = 1u << 12,      // plain restart-per-position route (no anchors, literals, shortcuts, empty
                                 // matches): findall / search may run on the flattened lane-per-text kernel
+  PF_BSTEP = 1u << 16,          // PF_BITSET plan of at most 64 positions on the windowed stepper's plain route:
+                                // the state is the set of live positions, a step is mask + follow-table lookups
+                                // in LDS (k_wstep<., 0, 1>); PF_STEP_SEARCH / PF_STEPPABLE are set with it
   PF_STREAM_SEARCH = 1u << 11   // search / sub / captures may use the streaming kernel too (findall and
                                 // count may whenever PF_STREAMABLE is set): not with a memchr prefilter,
                                 // which only match_next consults (matcher.mojo:784-796)

@@ -258,3 +258,49 @@ def test_record_forms_at_the_16_bit_position_boundary(L):
     packed = np.concatenate([host[a:b] for a, b in offs2])
     c2, o2, t2 = CDfa(pat).findall_batch(packed, np.arange(0, (n + 1) * (L - 3), L - 3, dtype=np.int64))
     assert tot2 == t2 and np.array_equal(sp2[:tot2].cpu().numpy(), o2)
+
+
+def test_config4_program_on_the_bitset_nfa_kernel_at_full_size():
+    """BASELINE config 4, "(\\d{3})(\\d{3})(\\d{4}) capture-group NFA fallback, 1M strings, 1 GPU (bitset-NFA
+    kernel)": the pattern's PikeVM program (pikevm.mojo:124-333; 11 positions) walked as a bitset NFA by
+    k_wstep<., 0, 1> -- no determinised table -- over 2^20 x 1 KiB texts.  search, count and findall must
+    equal the LazyDFA table kernels' answers on every text (the same function of the text computed two
+    ways) and the oracle's NFAMatcher (PikeVM / LazyDFA restatement) on a sample."""
+    _need_gpu()
+    import sys
+    from mrx_ref.hybrid import CompiledRegex as OracleRegex
+    pat = b"(\\d{3})(\\d{3})(\\d{4})"
+    n, L = 1 << 20, 1024
+    d = make_phone_batch(n, L)
+    batch = M.DeviceBatch.strided(d.reshape(-1), L, length=L)
+    lib = M.load_library()
+    nfa = M.compile_regex(pat, lazydfa_semantics=True, bitset_nfa=True)
+    desc = nfa.describe()
+    assert "device.bitset=yes positions=11 words=1" in desc and "bitset=1" in desc, desc
+    tab = M.compile_regex(pat, lazydfa_semantics=True)
+    assert "device.bitset" not in tab.describe()
+    s1, e1 = nfa.match_next(batch)
+    assert lib.mrx_last_kernel_name() == b"k_bstep_search"
+    s2, e2 = tab.match_next(batch)
+    assert lib.mrx_last_kernel_name() != b"k_bstep_search"
+    assert torch.equal(s1, s2) and torch.equal(e1, e2)
+    c1 = nfa.count(batch)
+    assert lib.mrx_last_kernel_name() == b"k_bstep_count"
+    c2 = tab.count(batch)
+    assert torch.equal(c1, c2)
+    p1, sp1, t1 = nfa._dev_findall(batch)
+    assert lib.mrx_last_kernel_name() == b"k_bstep_count"
+    p2, sp2, t2 = tab._dev_findall(batch)
+    assert t1 == t2 and torch.equal(p1, p2) and torch.equal(sp1[:t1], sp2[:t2])
+    # oracle sample (NFAMatcher: PikeVM program + LazyDFA, the route the option selects)
+    o = OracleRegex(pat, force_nfa=True)
+    idx = np.linspace(0, n - 1, 48).astype(np.int64)
+    rows = d[torch.from_numpy(idx).cuda()].cpu().numpy()
+    pre = p1.cpu().numpy()
+    for j, i in enumerate(idx.tolist()):
+        t = rows[j].tobytes()
+        want = o.match_all(t)
+        have = [tuple(int(x) for x in r) for r in sp1[int(pre[i]):int(pre[i + 1])].cpu().numpy()]
+        assert have == want, i
+        w = o.match_next(t, 0)
+        assert (int(s1[i]), int(e1[i])) == (w if w else (-1, -1)), i
