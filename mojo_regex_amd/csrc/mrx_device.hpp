@@ -31,6 +31,10 @@ struct Ctx {
   const uint8_t* bs_cls;       // [256] byte -> mask row
   const uint64_t* bs_mask;     // [bs_ncls][bs_nw] positions that consume a byte of the class
   const uint64_t* bs_follow;   // [bs_npos][bs_nw] closure after position i
+  // backtracking matcher as a flat program (DevPlan::bt_*)
+  const BtItem* bt_items;
+  const uint8_t* bt_tbl;       // 32-byte membership bitmaps, 3 per leaf
+  const uint8_t* bt_lit;       // NFAEngine.literal_prefix
 };
 
 // One lane's text.  Reads go through an 8-byte register window: the generic kernels
@@ -411,13 +415,178 @@ __device__ inline void for_each_match(const Ctx& c, const Text& t, Emit&& emit) 
   }
 }
 
+// ---- NFAEngine's backtracking matcher on its flat program (BtProg, mrx_engines.hpp) ---------------
+struct BtCaps {   // spans of the capture groups 0..9 of one attempt; -1 = the group did not close
+  int s[10], e[10];
+  __device__ __forceinline__ void clear() {
+#pragma unroll
+    for (int g = 0; g < 10; ++g) s[g] = e[g] = -1;
+  }
+};
+__device__ __forceinline__ bool bt_in(const Ctx& c, int tbl, int which, int byte) {
+  return (c.bt_tbl[(tbl * 3 + which) * 32 + (byte >> 3)] >> (byte & 7)) & 1;
+}
+// consecutive bytes of the set from pos on, at most maxc; positions beyond `stop_after` are not looked at
+__device__ inline int bt_run(const Ctx& c, const Text& t, int tbl, int which, int pos, int maxc, int stop_after) {
+  int k = 0;
+  while (k < maxc && pos + k < t.len && pos + k <= stop_after && bt_in(c, tbl, which, t.at(pos + k))) ++k;
+  return k;
+}
+// One attempt: NFAEngine._match_node(root, text, start, matches, match_first_mode, required_start_pos),
+// nfa.mojo:657-1443 on the flat program.  Returns the end of the match or -1; caps receives the groups
+// that closed (the last closing of a group wins, as the reference's append-only list read back to front).
+constexpr int kBtChoices = 32, kBtDepth = 17;
+__device__ inline int bt_match_at(const Ctx& c, const Text& t, int start, BtCaps& caps, bool mfm, int req) {
+  const int n = t.len, nitems = c.p.bt_nitems;
+  uint8_t ch_ip[kBtChoices], ch_depth[kBtChoices];
+  int ch_pos[kBtChoices], ch_cnt[kBtChoices];
+  int gstart[kBtDepth];
+  int ip = 0, pos = start, depth = 0, sp = 0;
+  const int far100 = (mfm && req >= 0) ? req + 100 : 0x7FFFFFFF;   // match_first_mode cut-offs
+  const int far50 = (mfm && req >= 0) ? req + 50 : 0x7FFFFFFF;
+  bool failing = false;
+  while (true) {
+    if (failing) {   // back to the innermost open choice with a smaller count left (nfa.mojo:1276-1309)
+      bool resumed = false;
+      while (sp > 0) {
+        --sp;
+        const BtItem it = c.bt_items[ch_ip[sp]];
+        const int cnt = ch_cnt[sp] - 1;
+        if (cnt < it.min) continue;
+        if (ch_pos[sp] + cnt > far100) continue;   // "new_pos > required_start_pos + 100": the choice is given up
+        pos = ch_pos[sp] + cnt;
+        ip = ch_ip[sp] + 1;
+        depth = ch_depth[sp];
+        if (cnt > it.min) { ch_cnt[sp] = cnt; ++sp; }
+        resumed = true;
+        break;
+      }
+      if (!resumed) return -1;
+      failing = false;
+      continue;
+    }
+    if (ip >= nitems) return pos;
+    const BtItem it = c.bt_items[ip];
+    if (it.kind == BT_START) { if (pos != 0) failing = true; else ++ip; continue; }
+    if (it.kind == BT_END) { if (pos != n) failing = true; else ++ip; continue; }
+    if (it.kind == BT_OPEN) { gstart[depth < kBtDepth ? depth : kBtDepth - 1] = pos; ++depth; ++ip; continue; }
+    if (it.kind == BT_CLOSE) {
+      --depth;
+      while (sp > 0 && ch_depth[sp - 1] > depth) --sp;   // the group's sequence has returned: no way back in
+      if ((it.flags & BTF_CAPTURING) && it.gid >= 0 && it.gid < 10) { caps.s[it.gid] = gstart[depth]; caps.e[it.gid] = pos; }
+      ++ip;
+      continue;
+    }
+    // LEAF
+    const int maxc = it.max == -1 ? n - pos : it.max;
+    if ((it.flags & BTF_QUANT) && !(it.flags & BTF_LAST)) {
+      // _match_with_backtracking: the largest count _try_match_count accepts, smaller ones on failure
+      const int r = bt_run(c, t, it.tbl, 1, pos, maxc, far100);
+      int cnt;
+      if (it.min == maxc) {
+        if (r < it.min) { failing = true; continue; }
+        cnt = it.min;
+      } else {
+        cnt = r < maxc ? r : maxc;
+        if (cnt < it.min) { failing = true; continue; }
+        if (pos + cnt > far100) { failing = true; continue; }
+        if (cnt > it.min) {
+          if (sp >= kBtChoices) return -1;   // (the host refuses programs that could get here)
+          ch_ip[sp] = (uint8_t)ip; ch_depth[sp] = (uint8_t)depth; ch_pos[sp] = pos; ch_cnt[sp] = cnt; ++sp;
+        }
+      }
+      pos += cnt;
+      ++ip;
+      continue;
+    }
+    // the leaf matcher itself (nfa.mojo:757-995) and _apply_quantifier (nfa.mojo:1375-1443)
+    int consumed;
+    if (pos >= n) {
+      if ((it.flags & BTF_ZERO_OK) && it.min == 0) consumed = 0; else { failing = true; continue; }
+    } else if (bt_in(c, it.tbl, 0, t.at(pos))) {
+      consumed = 1;
+    } else if ((it.flags & BTF_ZERO_OK) && it.min == 0) {
+      consumed = 0;
+    } else { failing = true; continue; }
+    if (it.min == 1 && maxc == 1) { pos += consumed; ++ip; continue; }
+    const bool cached = (it.flags & BTF_SIMD_TYPE) && (maxc > 8 || (it.flags & BTF_RANGE_LONG));
+    const int cnt = cached ? bt_run(c, t, it.tbl, 2, pos, maxc, 0x7FFFFFFF) : bt_run(c, t, it.tbl, 1, pos, maxc, far50);
+    if (cnt < it.min) { failing = true; continue; }
+    pos += cnt;
+    ++ip;
+  }
+}
+// NFAEngine._match_contains_literal, nfa.mojo:642-655
+__device__ inline bool bt_contains_literal(const Ctx& c, const Text& t, int start, int end) {
+  if (!(c.p.bt_flags & 1) || c.p.bt_lit_len == 0) return true;
+  const int pos = find_literal(c.bt_lit, c.p.bt_lit_len, t, start);
+  return pos >= 0 && pos + c.p.bt_lit_len <= end;
+}
+// NFAEngine.match_next_with_groups, nfa.mojo:500-574
+__device__ inline bool bt_match_next_with_groups(const Ctx& c, const Text& t, int start, int& ms, int& me, BtCaps& caps) {
+  int search_pos = start;
+  if (c.p.bt_flags & 1) {   // literal prefilter
+    while (search_pos <= t.len) {
+      const int lp = find_literal(c.bt_lit, c.p.bt_lit_len, t, search_pos);
+      if (lp < 0) return false;
+      int try_pos = lp;
+      if (c.p.bt_lit_len > 0 && !(c.p.bt_flags & 2)) try_pos = lp - c.p.bt_pattern_len > 0 ? lp - c.p.bt_pattern_len : 0;
+      while (try_pos <= lp) {
+        caps.clear();
+        const int end = bt_match_at(c, t, try_pos, caps, false, -1);
+        if (end >= 0 && bt_contains_literal(c, t, try_pos, end)) { ms = try_pos; me = end; return true; }
+        ++try_pos;
+      }
+      search_pos = lp + 1;
+    }
+    return false;
+  }
+  while (search_pos <= t.len) {
+    caps.clear();
+    const int end = bt_match_at(c, t, search_pos, caps, false, -1);
+    if (end >= 0) { ms = search_pos; me = end; return true; }
+    ++search_pos;
+  }
+  return false;
+}
+
 // _sub_impl_with_repl.  `out` is a sink with bytes(ptr, n); `tpl` the parsed
 // replacement template (only read when use_groups).
+// use_groups: 0 = literal replacement, 1 = fixed-width group form, 2 = general groups
+// (NFAEngine.match_next_with_groups, matcher.mojo:1781-1822)
 template <class Sink>
 __device__ inline void sub_text(const Ctx& c, const Text& t, const uint8_t* repl, int repl_len,
-                                bool use_groups, const ReplSeg* tpl, int ntpl, long long count,
+                                int use_groups, const ReplSeg* tpl, int ntpl, long long count,
                                 Sink& out) {
   if (t.len == 0) return;
+  if (use_groups == 2) {
+    int pos = 0, ms, me;
+    long long reps = 0;
+    BtCaps caps;
+    while (pos <= t.len) {
+      if (!bt_match_next_with_groups(c, t, pos, ms, me, caps)) break;
+      if (ms > pos) out.bytes(t.ptr + pos, ms - pos);
+      for (int k = 0; k < ntpl; ++k) {   // _apply_template_groups, matcher.mojo:1624-1646
+        const ReplSeg sg = tpl[k];
+        if (sg.group_ref > 0) {
+          if (sg.group_ref <= 9 && caps.s[sg.group_ref] >= 0)
+            out.bytes(t.ptr + caps.s[sg.group_ref], caps.e[sg.group_ref] - caps.s[sg.group_ref]);
+        } else {
+          out.bytes(repl + sg.start, sg.length);
+        }
+      }
+      ++reps;
+      if (me == ms) {
+        if (pos < t.len) out.bytes(t.ptr + pos, 1);
+        pos = me + 1;
+      } else {
+        pos = me;
+      }
+      if (count > 0 && reps >= count) break;
+    }
+    if (pos < t.len) out.bytes(t.ptr + pos, t.len - pos);
+    return;
+  }
   auto apply_tpl = [&](int match_start) {  // _apply_template_fixed, matcher.mojo:1592-1621
     for (int k = 0; k < ntpl; ++k) {
       const ReplSeg s = tpl[k];

@@ -120,4 +120,47 @@ struct BitsetNfa {
 };
 void build_bitset(const Program& p, BitsetNfa& out);
 
+// ---- the backtracking matcher as a flat program (capture groups) ----------------------
+// NFAEngine._match_node (nfa.mojo:657-1731) is a recursive walk of the AST.  For ASTs without
+// alternation and without quantified groups its control flow is a linear program over the
+// leaves with three kinds of events -- which is what the GPU interprets (bt_match_at in
+// mrx_device.hpp):
+//   LEAF   one byte class with {min, max}.  Not the last child of its sequence and quantified:
+//          a CHOICE (nfa.mojo:1231-1311, counts from min(max, run) down to min, the rest of the
+//          sequence decides); otherwise one greedy run (_apply_quantifier, nfa.mojo:1375-1443).
+//   OPEN / CLOSE of a group.  CLOSE drops the choices made inside the group (a group's sequence
+//          returns its first success and is never re-entered, nfa.mojo:1082-1103) and records the
+//          group's span when it captures (appended, never rolled back: the last one wins,
+//          matcher.mojo:1797-1802).
+//   START / END anchors.
+// Every leaf carries three membership tables because the reference tests bytes three ways: the
+// leaf matcher's own first-byte test (nfa.mojo:757-995), ASTNode.is_match_char (ast.mojo:415-462;
+// choices and short runs) and the cached "SIMD" matchers of long runs (nfa.mojo:1446-1647), and
+// they differ (\s: the nibble tables also hold NUL and ")*+,-"; [a-z0-9]-style classes in long
+// runs are searched as plain strings).
+enum BtKind : uint8_t { BT_LEAF = 0, BT_OPEN = 1, BT_CLOSE = 2, BT_START = 3, BT_END = 4 };
+enum BtFlags : uint8_t {
+  BTF_LAST = 1,        // leaf: last child of its sequence
+  BTF_ZERO_OK = 2,     // \d, \w: zero repetitions on a non-matching byte / at the end when min == 0
+  BTF_SIMD_TYPE = 4,   // \s \d \w [..]: long runs use the cached matcher's set
+  BTF_RANGE_LONG = 8,  // [..] whose text is longer than 8 bytes: always the cached matcher's set
+  BTF_CAPTURING = 16,  // OPEN / CLOSE
+  BTF_QUANT = 32       // min != 1 or max != 1
+};
+struct BtItem {   // 12 bytes, device layout
+  uint8_t kind, flags;
+  int8_t gid;     // OPEN / CLOSE: group id (0 = the implicit root group)
+  uint8_t tbl;    // LEAF: its tables are tbl * 3 + {0 first byte, 1 is_match_char, 2 cached matcher}
+  int32_t min, max;
+};
+struct BtProg {
+  bool ok = false;
+  std::string why_not;
+  std::vector<BtItem> items;
+  std::vector<std::array<uint8_t, 32>> tables;   // 256-bit membership bitmaps
+  int ngroups = 0;                                  // highest capturing group id (1..9 are addressable)
+  int max_depth = 0;
+};
+void build_bt(const Ast& a, BtProg& out);
+
 }  // namespace mrx

@@ -93,6 +93,9 @@ __device__ __forceinline__ Ctx stage_tables(const DevPlan& p, const uint8_t* __r
   c.bs_cls = lds + p.off_bs_cls;
   c.bs_mask = (const uint64_t*)(lds + p.off_bs_mask);
   c.bs_follow = (const uint64_t*)(lds + p.off_bs_follow);
+  c.bt_items = (const BtItem*)(lds + (p.off_bt_items >= 0 ? p.off_bt_items : 0));
+  c.bt_tbl = lds + (p.off_bt_tbl >= 0 ? p.off_bt_tbl : 0);
+  c.bt_lit = lds + (p.off_bt_lit >= 0 ? p.off_bt_lit : 0);
   return c;
 }
 
@@ -146,6 +149,19 @@ __global__ __launch_bounds__(kBlock) void k_match(DevPlan p, const uint8_t* __re
     } else if (OP == OP_IS_MATCH) {
       out_flag[i] = hybrid_is_match(c, t, 0) ? 1 : 0;
     } else {
+      if (p.fixed_total < 0) {
+        // general groups: NFAEngine.match_next_with_groups (nfa.mojo:500-574) on the flat program
+        const int g = p.bt_ngroups;
+        int32_t* o = out_s + i * (int64_t)(g + 1) * 2;
+        BtCaps caps;
+        if (bt_match_next_with_groups(c, t, 0, ms, me, caps)) {
+          for (int k = 1; k <= g; ++k) { o[(k - 1) * 2] = caps.s[k]; o[(k - 1) * 2 + 1] = caps.e[k]; }
+          o[g * 2] = ms; o[g * 2 + 1] = me;
+        } else {
+          for (int k = 0; k < (g + 1) * 2; ++k) o[k] = -1;
+        }
+        continue;
+      }
       // search + fixed-width groups in NFAEngine._match_group order (nfa.mojo:1057-1103)
       const int g = p.fixed_ngroups;
       int32_t* o = out_s + i * (int64_t)(g + 1) * 2;
@@ -2289,11 +2305,11 @@ __global__ __launch_bounds__(kBlock) void k_sub(DevPlan p, const uint8_t* __rest
     const Text t = lay.text(i);
     if (MODE == SUB_SIZE) {
       SizeSink s;
-      sub_text(c, t, repl, repl_len, use_groups != 0, tpl, ntpl, count, s);
+      sub_text(c, t, repl, repl_len, use_groups, tpl, ntpl, count, s);
       sizes[i] = s.n;
     } else {
       WriteSink s{out, out_off[i], out_cap};
-      sub_text(c, t, repl, repl_len, use_groups != 0, tpl, ntpl, count, s);
+      sub_text(c, t, repl, repl_len, use_groups, tpl, ntpl, count, s);
     }
   }
 }
@@ -2709,13 +2725,16 @@ int run_match(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d_s, i
     if (!h->hp.why_no_match_first.empty()) return fail(MRX_E_UNSUPPORTED, h->hp.why_no_match_first);
     if (h->hp.first_onepass)  // only the streaming kernel carries the OnePass tables
       return fail(MRX_E_UNSUPPORTED, "internal: OnePass plans have no generic kernel");
+  } else if (OP == OP_CAPTURES && h->hp.fixed_total < 0) {
+    // general groups: NFAEngine.match_next_with_groups on the flat program, whatever engine searches
+    if (!h->hp.bt.ok)
+      return fail(MRX_E_UNSUPPORTED,
+                  "capture groups of this pattern need the reference's recursive backtracking matcher "
+                  "(nfa.mojo:500-574, 1057-1156); its flat-program form does not cover: " +
+                      (h->hp.bt.why_not.empty() ? std::string("'.*'") : h->hp.bt.why_not));
   } else {
     if (int rc = check_search_supported(h)) return rc;
   }
-  if (OP == OP_CAPTURES && h->hp.fixed_total < 0)
-    return fail(MRX_E_UNSUPPORTED,
-                "capture groups outside the fixed-width (\\d{N}) form need the reference's "
-                "backtracking NFA (nfa.mojo:500-574)");
   if (int rc = check_lds(h)) return rc;
   if (int rc = ensure_device(h)) return rc;
   if (n == 0) return MRX_OK;
@@ -2897,10 +2916,11 @@ int pieces_prepare(const mrx_handle* h, const Layout& lay, int64_t n, hipStream_
   if (p.st_nsync <= 0 || g_long_text_mode == 2 || n <= 0) return MRX_OK;
   // pays when one lane per text leaves the device mostly idle, or for outliers of a ragged batch; a
   // fixed-length batch of many texts is decided before anything is launched
-  if (g_long_text_mode == 0 && n > 131072 && !lay.offsets && !lay.lens) return MRX_OK;
+  const bool env_pieces = getenv("MRX_PIECE_C") != nullptr;   // measurement
+  if (g_long_text_mode == 0 && n > 131072 && !lay.offsets && !lay.lens && !env_pieces) return MRX_OK;
   // count / search of a large CSR batch stay free of any host synchronisation: its outliers are only
   // looked for where the caller has the batch's statistics anyway (findall)
-  if (g_long_text_mode == 0 && n > 131072 && lay.offsets && known_total < 0) return MRX_OK;
+  if (g_long_text_mode == 0 && n > 131072 && lay.offsets && known_total < 0 && !env_pieces) return MRX_OK;
   int64_t total = 0, max_len = 0;
   if (lay.offsets && known_total >= 0) {
     total = known_total; max_len = known_max;
@@ -2911,6 +2931,11 @@ int pieces_prepare(const mrx_handle* h, const Layout& lay, int64_t n, hipStream_
     total = n * lay.stride;
   }
   int C;
+  static const int env_c = getenv("MRX_PIECE_C") ? atoi(getenv("MRX_PIECE_C")) : 0;   // measurement: piece size
+  if (env_c > 0 && g_long_text_mode == 0) {
+    C = env_c;
+    if (max_len <= C) return MRX_OK;
+  } else
   if (g_long_text_mode == 1) {
     C = 200;   // tests: cut even short texts, at positions that are not multiples of 16
     if (max_len <= C) return MRX_OK;
@@ -3406,7 +3431,11 @@ void mrx_free(mrx_handle* h) {
 const char* mrx_last_error(void) { return g_err.c_str(); }
 const char* mrx_engine_type(const mrx_handle* h) { return h ? h->hp.engine_type.c_str() : ""; }
 const char* mrx_stats(const mrx_handle* h) { return h ? h->hp.stats.c_str() : ""; }
-int mrx_num_groups(const mrx_handle* h) { return (h && h->hp.fixed_total >= 0) ? h->hp.fixed_ngroups : 0; }
+int mrx_num_groups(const mrx_handle* h) {
+  if (!h) return 0;
+  if (h->hp.fixed_total >= 0) return h->hp.fixed_ngroups;
+  return h->hp.bt.ok ? h->hp.bt.ngroups : 0;
+}
 const char* mrx_version(void) { return "mrx-hip 0.1 (gfx950)"; }
 
 size_t mrx_describe(const mrx_handle* h, char* buf, size_t cap) {
@@ -3765,17 +3794,22 @@ int mrx_sub_dev(const mrx_handle* h, const char* repl, size_t repl_len, int64_t 
   ScratchScope scratch_scope_((hipStream_t)st);
   if (!h) return fail(MRX_E_ARGUMENT, "null handle");
   if (n < 0) return fail(MRX_E_ARGUMENT, "negative batch size");
-  if (int rc = check_search_supported(h)) return rc;
   const std::string r(repl ? repl : "", repl_len);
   const bool groups = repl_has_group_refs(r);
+  // group references on a pattern outside the fixed-width form: every match comes from
+  // NFAEngine.match_next_with_groups (matcher.mojo:1781-1822), not from the search engines
+  const bool general_groups = groups && h->hp.fixed_total < 0;
   std::vector<ReplSeg> tpl;
-  if (groups) {
-    if (h->hp.fixed_total < 0)
+  if (general_groups) {
+    if (!h->hp.bt.ok)
       return fail(MRX_E_UNSUPPORTED,
-                  "sub() with \\1..\\9 on a pattern outside the fixed-width (\\d{N}) group form "
-                  "uses NFAEngine.match_next_with_groups (backtracking NFA, nfa.mojo:500-574)");
-    tpl = parse_repl_template(r);
+                  "sub() with \\1..\\9 on this pattern uses NFAEngine.match_next_with_groups (recursive "
+                  "backtracking matcher, nfa.mojo:500-574); its flat-program form does not cover: " +
+                      (h->hp.bt.why_not.empty() ? std::string("'.*'") : h->hp.bt.why_not));
+  } else if (int rc = check_search_supported(h)) {
+    return rc;
   }
+  if (groups) tpl = parse_repl_template(r);
   if (int rc = check_lds(h)) return rc;
   if (int rc = ensure_device(h)) return rc;
   hipStream_t s = (hipStream_t)st;
@@ -3787,7 +3821,7 @@ int mrx_sub_dev(const mrx_handle* h, const char* repl, size_t repl_len, int64_t 
   const bool spans_ok = !(sfl & PF_EXACT_LITERAL) &&
                         ((!g_force_generic && (sfl & PF_STREAM_SEARCH)) ||
                          (g_force_generic < 2 && (sfl & PF_STEP_SEARCH) && !(sfl & PF_PREFILTER)));
-  if (spans_ok && n > 0 && off) {
+  if (spans_ok && !general_groups && n > 0 && off) {
     // replacement as a fixed-length byte map
     std::vector<uint16_t> rmap;
     if (groups) {
@@ -3819,7 +3853,7 @@ int mrx_sub_dev(const mrx_handle* h, const char* repl, size_t repl_len, int64_t 
   if (n > 0) {
     ScanTimer tm(s);
     hipLaunchKernelGGL(k_sub<SUB_SIZE>, dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s,
-                       h->hp.dev, H_BLOB(h), lay, n, d_repl, (int)r.size(), groups ? 1 : 0, d_tpl,
+                       h->hp.dev, H_BLOB(h), lay, n, d_repl, (int)r.size(), general_groups ? 2 : groups ? 1 : 0, d_tpl,
                        (int)tpl.size(), (long long)count, d_sizes, (const int64_t*)nullptr,
                        (uint8_t*)nullptr, (int64_t)0);
     g_last_kernel = "k_sub_size";
@@ -3836,7 +3870,7 @@ int mrx_sub_dev(const mrx_handle* h, const char* repl, size_t repl_len, int64_t 
     rc = fail(MRX_E_CAPACITY, "output buffer too small: need " + std::to_string(tot));
   } else if (n > 0 && tot > 0) {
     hipLaunchKernelGGL(k_sub<SUB_EMIT>, dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s,
-                       h->hp.dev, H_BLOB(h), lay, n, d_repl, (int)r.size(), groups ? 1 : 0, d_tpl,
+                       h->hp.dev, H_BLOB(h), lay, n, d_repl, (int)r.size(), general_groups ? 2 : groups ? 1 : 0, d_tpl,
                        (int)tpl.size(), (long long)count, (int64_t*)nullptr, out_off, out, out_cap);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s));

@@ -390,4 +390,182 @@ void build_bitset(const Program& p, BitsetNfa& out) {
   out.ok = true;
 }
 
+// ---- backtracking matcher -> flat program ---------------------------------------------------
+namespace {
+// ast.mojo:672-725
+bool bt_has_range_seq(std::string_view p, int lo, int hi) {
+  for (size_t i = 0; i + 2 < p.size(); ++i)
+    if ((uint8_t)p[i] == lo && p[i + 1] == '-' && (uint8_t)p[i + 2] == hi) return true;
+  return false;
+}
+enum { RK_LOWER = 1, RK_UPPER, RK_DIGITS, RK_ALNUM, RK_ALPHA, RK_COMPLEX_ALNUM, RK_OTHER };
+int bt_range_kind(std::string_view p) {
+  if (p.empty()) return RK_OTHER;
+  if (p == "[a-z]") return RK_LOWER;
+  if (p == "[A-Z]") return RK_UPPER;
+  if (p == "[0-9]") return RK_DIGITS;
+  if (p == "[a-zA-Z0-9]" || p == "[0-9a-zA-Z]") return RK_ALNUM;
+  if (p == "[a-zA-Z]") return RK_ALPHA;
+  if (p.front() == '[' && p.back() == ']' && p.size() - 2 > 10 && bt_has_range_seq(p, 'a', 'z') &&
+      bt_has_range_seq(p, 'A', 'Z') && bt_has_range_seq(p, '0', '9'))
+    return RK_COMPLEX_ALNUM;
+  return RK_OTHER;
+}
+bool bt_lower(int c) { return c >= 'a' && c <= 'z'; }
+bool bt_upper(int c) { return c >= 'A' && c <= 'Z'; }
+bool bt_digit(int c) { return c >= '0' && c <= '9'; }
+bool bt_word(int c) { return bt_lower(c) || bt_upper(c) || bt_digit(c) || c == '_'; }
+bool bt_space5(int c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\f'; }
+// NibbleBasedMatcher.contains with the whitespace tables, simd_matchers.mojo:129-147, 285-342
+bool bt_space_lut(int c) { return ((c & 15) == 0 || ((c & 15) >= 9 && (c & 15) <= 13)) && ((c >> 4) == 0 || (c >> 4) == 2); }
+// ast.mojo:480-508
+bool bt_code_matches_range(int ch, std::string_view syn) {
+  size_t i = (!syn.empty() && syn[0] == '^') ? 1 : 0;
+  while (i < syn.size()) {
+    if (i + 2 < syn.size() && syn[i + 1] == '-') {
+      if ((uint8_t)syn[i] <= ch && ch <= (uint8_t)syn[i + 2]) return true;
+      i += 3;
+    } else {
+      if ((uint8_t)syn[i] == ch) return true;
+      i += 1;
+    }
+  }
+  return false;
+}
+bool bt_in_string(int ch, std::string_view s) { return s.find((char)ch) != std::string_view::npos; }
+// ast.mojo:464-478
+bool bt_in_range_by_code(int ch, std::string_view pat) {
+  if (!pat.empty() && pat[0] == '[') return bt_code_matches_range(ch, pat.substr(1, pat.size() >= 2 ? pat.size() - 2 : 0));
+  return bt_in_string(ch, pat);
+}
+// NFAEngine._match_char_in_range, nfa.mojo:1650-1670
+bool bt_match_char_in_range(std::string_view pat, int ch) {
+  if (pat.size() >= 2 && pat.front() == '[' && pat.back() == ']') {
+    const std::string_view inner = pat.substr(1, pat.size() - 2);
+    if (inner.size() == 3 && inner[1] == '-') return (uint8_t)inner[0] <= ch && ch <= (uint8_t)inner[2];
+    return bt_in_string(ch, inner);
+  }
+  return bt_in_string(ch, pat);
+}
+bool bt_kind_member(int kind, int ch, std::string_view v) {   // the class tests shared by _match_range and the long-run loops
+  switch (kind) {
+    case RK_ALNUM: return bt_lower(ch) || bt_upper(ch) || bt_digit(ch);
+    case RK_LOWER: return bt_lower(ch);
+    case RK_UPPER: return bt_upper(ch);
+    case RK_DIGITS: return bt_digit(ch);
+    case RK_ALPHA: return bt_lower(ch) || bt_upper(ch);
+    case RK_COMPLEX_ALNUM:
+      return bt_lower(ch) || bt_upper(ch) || bt_digit(ch) || (v.size() >= 2 && bt_in_string(ch, v.substr(1, v.size() - 2)));
+    default: return false;
+  }
+}
+
+struct BtBuilder {
+  const Ast& a;
+  BtProg& out;
+  int depth = 0;
+  void fail(const std::string& why) { if (out.why_not.empty()) out.why_not = why; }
+  void set(std::array<uint8_t, 32>& t, int c, bool v) { if (v) t[c >> 3] |= (uint8_t)(1u << (c & 7)); }
+  void leaf(const Node& n, bool last) {
+    BtItem it{};
+    it.kind = BT_LEAF;
+    it.min = n.min; it.max = n.max;
+    if (last) it.flags |= BTF_LAST;
+    if (n.min != 1 || n.max != 1) it.flags |= BTF_QUANT;
+    if (n.type == N_DIGIT || n.type == N_WORD) it.flags |= BTF_ZERO_OK;
+    if (n.type == N_SPACE || n.type == N_DIGIT || n.type == N_WORD || n.type == N_RANGE) it.flags |= BTF_SIMD_TYPE;
+    const std::string_view v = a.value(n);
+    if (n.type == N_RANGE && v.empty()) { fail("character class without text"); return; }
+    if (n.type == N_RANGE && v.size() > 8) it.flags |= BTF_RANGE_LONG;
+    if (out.tables.size() / 3 >= 255) { fail("more than 255 leaves"); return; }
+    it.tbl = (uint8_t)(out.tables.size() / 3);
+    std::array<uint8_t, 32> first{}, scalar{}, cached{};
+    const int kind = n.type == N_RANGE ? bt_range_kind(v) : 0;
+    for (int c = 0; c < 256; ++c) {
+      bool f = false, s = false, m = false;
+      switch (n.type) {
+        case N_ELEMENT:   // nfa.mojo:771-776 compares the first byte; ast.mojo:419-427 wants a one-byte value
+          f = !v.empty() && (uint8_t)v[0] == c;
+          s = v.size() == 1 && (uint8_t)v[0] == c;
+          m = s;
+          break;
+        case N_WILDCARD: f = s = m = c != '\n'; break;
+        case N_SPACE: f = s = bt_space5(c); m = bt_space_lut(c); break;
+        case N_DIGIT: f = s = m = bt_digit(c); break;
+        case N_WORD: f = s = m = bt_word(c); break;
+        case N_RANGE: {
+          bool found = false;   // _match_range, nfa.mojo:930-995
+          if (kind != RK_OTHER) found = bt_kind_member(kind, c, v);
+          else if (!v.empty()) found = bt_in_range_by_code(c, v);
+          f = found == n.positive;
+          s = !((!v.empty() && bt_in_range_by_code(c, v)) ^ n.positive);   // ast.mojo:448-456
+          bool run = false;     // _apply_quantifier_simd, nfa.mojo:1476-1645 (needs a value)
+          if (!v.empty()) run = (kind != RK_OTHER ? bt_kind_member(kind, c, v) : bt_match_char_in_range(v, c)) == n.positive;
+          m = run;
+          break;
+        }
+        default: break;
+      }
+      set(first, c, f); set(scalar, c, s); set(cached, c, m);
+    }
+    out.tables.push_back(first); out.tables.push_back(scalar); out.tables.push_back(cached);
+    out.items.push_back(it);
+  }
+  void seq(const Node& parent) {
+    const int k = a.nkids(parent);
+    for (int i = 0; i < k && out.why_not.empty(); ++i) node(a.child(parent, i), i == k - 1);
+  }
+  void node(const Node& n, bool last) {
+    switch (n.type) {
+      case N_ELEMENT: case N_WILDCARD: case N_SPACE: case N_DIGIT: case N_WORD: case N_RANGE:
+        leaf(n, last);
+        break;
+      case N_START: case N_END: {
+        if (n.min != 1 || n.max != 1) { fail("quantified anchor"); return; }
+        BtItem it{};
+        it.kind = n.type == N_START ? BT_START : BT_END;
+        it.min = it.max = 1;
+        out.items.push_back(it);
+        break;
+      }
+      case N_GROUP: {
+        if (n.min != 1 || n.max != 1) { fail("quantified group (nfa.mojo:1105-1156)"); return; }
+        if (++depth > 16) { fail("groups nested deeper than 16"); return; }
+        if (depth > out.max_depth) out.max_depth = depth;
+        BtItem o{};
+        o.kind = BT_OPEN;
+        o.gid = (int8_t)(n.group_id >= 0 ? (n.group_id > 127 ? 127 : n.group_id) : 0);
+        if (n.capturing) o.flags |= BTF_CAPTURING;
+        o.min = o.max = 1;
+        out.items.push_back(o);
+        seq(n);
+        BtItem c = o;
+        c.kind = BT_CLOSE;
+        out.items.push_back(c);
+        if (n.capturing && n.group_id > out.ngroups) out.ngroups = n.group_id;
+        --depth;
+        break;
+      }
+      case N_OR: fail("alternation (nfa.mojo:1019-1055)"); break;
+      default: fail("node type outside the flat form"); break;
+    }
+  }
+};
+}  // namespace
+
+void build_bt(const Ast& a, BtProg& out) {
+  out = BtProg();
+  BtBuilder b{a, out};
+  // _match_re, nfa.mojo:1351-1373: the root RE node matches its first child (the implicit root group)
+  if (a.root.type == N_RE) {
+    if (a.nkids(a.root) > 0) b.node(a.child(a.root, 0), true);
+  } else {
+    b.node(a.root, true);
+  }
+  if (!out.why_not.empty()) return;
+  if (out.items.size() > 240) { out.why_not = "more than 240 program items"; return; }
+  if (out.ngroups > 9) out.ngroups = 9;   // \1..\9 (matcher.mojo:1797-1802)
+  out.ok = true;
+}
+
 }  // namespace mrx

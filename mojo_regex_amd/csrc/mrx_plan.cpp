@@ -285,6 +285,7 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
       if (const LiteralInfo* b = ls.best_literal()) {
         if (b->is_prefix && b->is_required && b->literal.size() >= 1) hp.nfa_has_literal_opt = true;
         else if (b->is_required && b->literal.size() >= 3) hp.nfa_has_literal_opt = true;
+        if (hp.nfa_has_literal_opt) hp.nfa_literal = b->literal;
       }
       auto ends = [&](const char* s) {
         const size_t k = std::strlen(s);
@@ -296,6 +297,7 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
         if (pattern.size() > 2 && (pattern[2] == '?' || pattern[2] == '*' || pattern[2] == '+'))
           hp.nfa_starts_dotstar = false;
       }
+      build_bt(ast, hp.bt);
       compile_program(ast, hp.program);
       build_lazy(hp.program, hp.lazy, /*max_dfa_states=*/4096);
       build_bitset(hp.program, hp.bitset);
@@ -482,6 +484,23 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
   }
   if (d.nstates >= 0x7FFF) {
     hp.why_no_match_first = hp.why_no_search = "more than 32766 DFA states";
+  }
+  d.bt_nitems = 0; d.off_bt_items = d.off_bt_tbl = d.off_bt_lit = -1; d.bt_ngroups = 0; d.bt_lit_len = 0; d.bt_flags = 0;
+  d.bt_pattern_len = (int)pattern.size();
+  if (hp.bt.ok) {
+    align(hp.blob, 4);
+    d.bt_nitems = (int)hp.bt.items.size();
+    d.bt_ngroups = hp.bt.ngroups;
+    d.off_bt_items = (int)hp.blob.size();
+    put(hp.blob, hp.bt.items.data(), hp.bt.items.size() * sizeof(BtItem));
+    d.off_bt_tbl = (int)hp.blob.size();
+    for (const auto& t : hp.bt.tables) put(hp.blob, t.data(), 32);
+    d.off_bt_lit = (int)hp.blob.size();
+    d.bt_lit_len = (int)hp.nfa_literal.size();
+    put(hp.blob, hp.nfa_literal.data(), hp.nfa_literal.size());
+    if (hp.nfa_has_literal_opt) d.bt_flags |= 1;
+    if (!hp.nfa_literal.empty() && pattern.compare(0, hp.nfa_literal.size(), hp.nfa_literal) == 0) d.bt_flags |= 2;
+    align(hp.blob, 8);
   }
 
   // ---- streaming automaton (findall only) -----------------------------------------
@@ -972,6 +991,10 @@ std::string describe_plan(const HostPlan& hp) {
   o << "device.first_stream=" << (d.fa_bytes ? "yes" : ("no: " + hp.first_stream_why_not))
     << " fa_nstates=" << d.fa_nstates << " fa_kind=" << d.fa_kind << (hp.first_onepass ? " onepass=yes" : "")
     << (d.off_fa_run >= 0 ? " class_run=1" : "") << "\n";
+  o << "device.backtrack=" << (hp.bt.ok ? "yes" : ("no: " + (hp.bt.why_not.empty() ? std::string("'.*' shortcut") : hp.bt.why_not)));
+  if (hp.bt.ok) o << " items=" << d.bt_nitems << " groups=" << d.bt_ngroups << " literal_opt=" << (d.bt_flags & 1)
+                  << " prefix_literal=" << ((d.bt_flags >> 1) & 1);
+  o << "\n";
   if (d.flags & PF_BITSET)
     o << "device.bitset=yes positions=" << d.bs_npos << " words=" << d.bs_nw << " byte_classes=" << d.bs_ncls << "\n";
   return o.str();

@@ -96,6 +96,10 @@ struct DevPlan {
   // bitset NFA (PF_BITSET): cls[256] u8, byte masks u64[bs_ncls][bs_nw], follow u64[bs_npos][bs_nw]
   int32_t bs_nw, bs_npos, bs_ncls, off_bs_cls, off_bs_mask, off_bs_follow;
   uint64_t bs_start[4], bs_match[4];
+  // the backtracking matcher as a flat program (BtProg, mrx_engines.hpp; bt_nitems == 0: none): BtItem
+  // [bt_nitems], membership bitmaps u8[32] x 3 per leaf, and NFAEngine's literal prefilter facts
+  // (nfa.mojo:86-143): bt_flags bit 0 = has_literal_optimization, bit 1 = is_prefix_literal
+  int32_t off_bt_items, bt_nitems, off_bt_tbl, bt_ngroups, off_bt_lit, bt_lit_len, bt_flags, bt_pattern_len;
 };
 
 struct HostPlan {
@@ -117,6 +121,8 @@ struct HostPlan {
   LazyTables lazy;
   BitsetNfa bitset;
   OnePassTables onepass;
+  BtProg bt;                   // NFAEngine's recursive matcher as a flat program (general capture groups)
+  std::string nfa_literal;     // NFAEngine.literal_prefix (nfa.mojo:108-125)
   bool first_onepass = false;  // match_first runs the OnePass tables (NFA-routed '$' pattern)
   bool force_bitset = false;  // MRX_COMPILE_BITSET_NFA
   bool nfa_has_literal_opt = false, nfa_starts_dotstar = false, nfa_ends_dotstar = false;

@@ -6,10 +6,10 @@ CompiledRegex (:929-1163), module functions search/findall/split/match_first
 (:1325-1415) and sub with its template and fixed-width-group fast path
 (:1418-1917); NFAEngine's constructor flags (src/regex/nfa.mojo:86-143).
 
-The recursive backtracking interpreter (nfa.mojo:657-1769) and OnePass
-(onepass.mojo) are outside the hot path this repo covers: whenever the
-reference would route a call to them the oracle raises UnsupportedByOracle
-rather than guess.
+The recursive backtracking interpreter (nfa.mojo:657-1769) is restated in
+backtrack.py; calls the reference routes to it are answered from there.  What is
+still refused (UnsupportedByOracle): LazyDFA search / findall of '$' programs,
+whose results depend on the transition cache's history (pikevm.mojo:697-700).
 """
 from __future__ import annotations
 
@@ -21,6 +21,7 @@ from .analysis import (classify, should_use_pure_dfa, extract_literals,
 from .dfa_engine import compile_dfa_pattern, DFACompileError, DFAEngine
 from .pikevm import compile_ast, PikeVMEngine, LazyDFA, OP_END_ANCHOR
 from .onepass import compile_onepass
+from .backtrack import BacktrackNFA
 
 Span = Tuple[int, int]
 
@@ -128,6 +129,11 @@ class NFAMatcher:
 
     def __init__(self, ast: Node, pattern: bytes):
         self.engine = NFAEngineFlags(pattern)
+        try:   # NFAEngine parses the pattern itself; a failure leaves it without an AST (nfa.mojo:98-129)
+            own_ast = parse(pattern)
+        except Exception:
+            own_ast = None
+        self.backtrack = BacktrackNFA(pattern, own_ast, self.engine)   # NFAMatcher.engine's matching half
         vm = PikeVMEngine(compile_ast(ast))
         self.program = vm.program
         self.onepass = None   # OnePassNFA, only for '$' programs that compile one-pass (:310-313)
@@ -150,7 +156,7 @@ class NFAMatcher:
             return self.lazy.match_first(text, start)
         if self.onepass is not None:
             return self.onepass.match_first(text, start)
-        raise UnsupportedByOracle("match_first routed to the backtracking NFA")
+        return self.backtrack.match_first(text, start)
 
     def match_next(self, text: bytes, start: int = 0):
         if self._use_lazy_dfa_for_search():
@@ -159,7 +165,8 @@ class NFAMatcher:
                     "LazyDFA search with '$' depends on cache history "
                     "(pikevm.mojo:697-700)")
             return self.lazy.match_next(text, start)
-        raise UnsupportedByOracle("search routed to OnePass/backtracking NFA")
+        # (_use_onepass_for_search needs the LazyDFA branch above to have been taken: unreachable)
+        return self.backtrack.match_next(text, start)
 
     def match_all(self, text: bytes):
         if self._use_lazy_dfa_for_search():
@@ -167,7 +174,7 @@ class NFAMatcher:
                 raise UnsupportedByOracle(
                     "LazyDFA findall with '$' depends on cache history")
             return self.lazy.match_all(text)
-        raise UnsupportedByOracle("findall routed to OnePass/backtracking NFA")
+        return self.backtrack.match_all(text)
 
 
 class HybridMatcher:
@@ -539,9 +546,37 @@ def _sub_impl(compiled: CompiledRegex, repl: bytes, text: bytes, count: int = 0)
                 if count > 0 and reps >= count:
                     break
         else:
-            raise UnsupportedByOracle(
-                "sub() with group references on a non-fixed-width pattern uses "
-                "NFAEngine.match_next_with_groups (backtracking NFA)")
+            # general group path, matcher.mojo:1781-1822
+            if compiled.matcher.nfa_matcher is None:
+                raise UnsupportedByOracle("'.*' has no NFA matcher to ask for groups")
+            bt = compiled.matcher.nfa_matcher.backtrack
+            while pos <= tl:
+                m, groups = bt.match_next_with_groups(text, pos)
+                if m is None:
+                    break
+                ms, me = m
+                if ms > pos:
+                    result += text[pos:ms]
+                group_idx = [-1] * 10
+                for gi, (gid, _gs, _ge) in enumerate(groups):
+                    if 1 <= gid <= 9:
+                        group_idx[gid] = gi          # a later entry of the same group wins
+                for (gref, s_, ln) in template:      # _apply_template_groups, matcher.mojo:1624-1646
+                    if gref > 0:
+                        idx = group_idx[gref] if gref <= 9 else -1
+                        if idx >= 0:
+                            result += text[groups[idx][1]:groups[idx][2]]
+                    else:
+                        result += repl[s_:s_ + ln]
+                reps += 1
+                if me == ms:
+                    if pos < tl:
+                        result += text[pos:pos + 1]
+                    pos = me + 1
+                else:
+                    pos = me
+                if count > 0 and reps >= count:
+                    break
     else:
         while pos <= tl:
             m = compiled.match_next(text, pos)

@@ -298,8 +298,12 @@ def test_captures_fixed_width_groups():
         else:
             # a18 order: groups 1..g, then the whole match
             assert [tuple(int(x) for x in r) for r in got[i]] == [(s, e) for (_, s, e) in w]
+    # general groups come from the backtracking matcher's flat program (round 2); the forms it does not
+    # cover are refused
+    got = M.compile_regex(b"(\\w+) (\\w+)").captures([b"hello world"])
+    assert got[0].tolist() == [[0, 5], [6, 11], [0, 11]]
     with pytest.raises(M.UnsupportedPattern):
-        M.compile_regex(b"(\\w+) (\\w+)").captures([b"hello world"])
+        M.compile_regex(b"(a|b)(c)").captures([b"ac"])
 
 
 STREAM_PATTERNS = [b"[a-z]+\\d+", b"\\d+", b"[a-z]+", b"\\w+\\s+", b"[^0-9]+", b"[a-z][0-9]", b"[a-z]{1,}",
@@ -1565,3 +1569,59 @@ def test_start_argument_matches_oracle(pat):
                     assert w != "unsupported", (pat, op)
                     h = bool(got[i]) if op == "is_match" else (int(got[i][0]), int(got[i][1]))
                     assert h == w, (pat, op, kind, s, t, h, w)
+
+
+GROUP_PATTERNS = [
+    (b"(\\w+) (\\w+)", b"\\2 \\1"), (b"(\\d+)", b"[\\1,\\1]"), (b"(?:hello) (\\w+)", b"\\1"), (b"(\\d+)", b"[\\1]"),
+    (b"(\\w+)@(\\w+)\\.com", b"\\2 at \\1"), (b"([a-z]+)(\\d*)x", b"<\\1|\\2>"), (b"^(\\w+)\\s+(\\w+)$", b"\\2,\\1"),
+    (b"(a*)(b+)c", b"\\2\\1"), (b"\\s*(\\d+)\\s*", b"(\\1)"), (b"([a-z0-9]+)-([^-]+)", b"\\2-\\1"),
+    (b"(\\d{2,4})-(\\d+)", b"\\2/\\1"), (b"x(.*)y", b"[\\1]"), (b"([a-zA-Z0-9._%+-]+)@([a-zA-Z0-9.-]+)", b"\\1 AT \\2"),
+    (b"(\\w+)\\s(\\s*)(\\w*)", b"\\3\\2\\1"), (b"((\\w+)-(\\d+))", b"\\3:\\2:\\1"), (b"(\\d+)\\.(\\d+)", b"\\2.\\1 \\9"),
+    (b"(h.llo) (w.*d)", b"\\2 \\1"), (b"([A-Z][a-z]+) ([A-Z][a-z]+)", b"\\2, \\1"), (b"(\\s+)(\\S?)", b"_\\2"),
+]
+
+
+@pytest.mark.parametrize("pat,repl", GROUP_PATTERNS)
+def test_general_capture_groups_match_the_backtracking_oracle(pat, repl):
+    """a18: regex.sub with \\1..\\9 on patterns outside the fixed-width group form, and the group spans
+    themselves (mrx_captures_*): NFAEngine.match_next_with_groups (nfa.mojo:500-574) -- the recursive
+    backtracking matcher, run on the GPU as a flat program -- against the oracle's restatement of
+    nfa.mojo:657-1731 (oracle/mrx_ref/backtrack.py)."""
+    _need_gpu()
+    rx = M.compile_regex(pat)
+    assert "device.backtrack=yes" in rx.describe(), rx.describe()
+    orx = O.compile_regex(pat)
+    assert orx.fixed_total_width < 0
+    rng = np.random.default_rng(zlib.crc32(pat))
+    al = b"abcxyz0189 -.@helowrdHW_\t,+" + bytes(c for c in pat if chr(c).isalnum()) * 2
+    texts = _random_texts(rng, 160, 60, al) + _random_texts(rng, 20, 300, al)
+    texts += [b"hello world", b"42 and 99", b"abc 123 def 456", b"john@example.com mary@test.com", b"ab12x cdx", b"foo  bar",
+              b"aabbc bc abc", b"  17  ", b"k9-zz-top", b"2024-12 19-1", b"xaayxbby", b"a.b@c.d e@f", b"3.14 2.718", b"",
+              b"hello world said Hello World", b"Ada Lovelace and Alan Turing"]
+    for count in (0, 1):
+        got = rx.sub(repl, texts, count)
+        for i, t in enumerate(texts):
+            assert got[i] == orx.sub(repl, t, count), (pat, repl, count, t, got[i])
+    caps = rx.captures(texts)
+    g = rx.num_groups
+    bt = orx.matcher.nfa_matcher.backtrack
+    for i, t in enumerate(texts):
+        m, groups = bt.match_next_with_groups(t, 0)
+        want = [(-1, -1)] * (g + 1)
+        if m is not None:
+            for gid, gs, ge in groups:
+                if 1 <= gid <= g:
+                    want[gid - 1] = (gs, ge)      # the last entry of a group wins (matcher.mojo:1797-1802)
+            want[g] = m
+        assert [tuple(int(x) for x in r) for r in caps[i]] == want, (pat, t)
+
+
+@pytest.mark.parametrize("pat", [b"(a|b)(c)", b"(ab)+(c)", b"(\\w+)|(\\d+)", b"((a)|b)x"])
+def test_capture_groups_outside_the_flat_form_are_refused(pat):
+    """Alternation and quantified groups keep the recursive matcher's append-without-rollback list
+    semantics that the flat program does not model: refused, never guessed."""
+    _need_gpu()
+    rx = M.compile_regex(pat)
+    assert "device.backtrack=no" in rx.describe()
+    with pytest.raises(M.UnsupportedPattern):
+        rx.sub(b"\\1", [b"abc"])

@@ -2,9 +2,10 @@
 
 tests/golden/reference_vectors.json holds the vectors transcribed from the
 reference's tests/test_*.mojo (file:line per vector).  This is what pins the
-oracle: every vector the reference would run on the DFA / LazyDFA path must
-pass; vectors the reference routes to its backtracking NFA or OnePass engine
-are out of this repo's scope and must be *declared* unsupported, not guessed.
+oracle: every vector must pass -- the DFA / LazyDFA / OnePass routes and, since
+round 2, the vectors the reference routes to its backtracking matcher
+(oracle/mrx_ref/backtrack.py; 15 matching vectors and the regex.sub vectors with
+group references).
 """
 import collections
 
@@ -35,10 +36,8 @@ def test_oracle_passes_every_in_scope_reference_vector(oracle_backend):
         else:
             passed += 1
     assert not failures, "\n".join(failures[:20])
-    # the out-of-scope set is small and known (OnePass '$' patterns, general
-    # capture groups, literal-prefiltered backtracker searches)
-    assert passed >= 440, (passed, sum(unsupported.values()))
-    assert sum(unsupported.values()) <= 40, unsupported
+    # with the backtracking matcher restated (oracle/mrx_ref/backtrack.py) every vector is answered
+    assert passed == len(VECS) and not unsupported, (passed, unsupported)
 
 
 # the SURVEY.md Appendix B pins for the five BASELINE.json configs, spelled out
@@ -129,8 +128,12 @@ def test_onepass_routing_and_rejections():
     assert H.match_first(b"^a|b$", b"a") == (0, 1)        # '^a' branch accepts mid-text (onepass.mojo:449-453)
     assert H.match_first(b"^a|b$", b"ab") == (0, 1)
     assert H.match_first(b"^\\d+$", b"12345") == (0, 5)
-    with pytest.raises(UnsupportedByOracle):               # `.` and `a` both fire: not one-pass
-        H.match_first(b"^aaaa.*a$", b"aaaaa")
+    # `.` and `a` both fire: not one-pass -> the backtracking matcher (oracle/mrx_ref/backtrack.py).  Its
+    # greedy `.*` leaves nothing for the final `a` and a quantified leaf followed by siblings is only
+    # backed off inside _match_with_backtracking: the reference's own answer, whatever re.match says.
+    r = H.compile_regex(b"^aaaa.*a$")
+    assert r.matcher.nfa_matcher.onepass is None
+    assert H.match_first(b"^aaaa.*a$", b"aaaaa") == r.matcher.nfa_matcher.backtrack.match_first(b"aaaaa", 0)
     with pytest.raises(UnsupportedByOracle):               # search with '$' stays LazyDFA (history dependent)
         H.search(b"^[a-z]+$", b"abc")
 
