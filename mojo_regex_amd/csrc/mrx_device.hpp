@@ -78,343 +78,6 @@ __device__ inline int find_literal(const uint8_t* needle, int nlen, const Text& 
   return -1;
 }
 
-// table walk from `start`; returns the last accepting position or -1
-__device__ inline int walk(const Ctx& c, const Text& t, int start) {
-  int state = 0;
-  int pos = start;
-  int last = flag(c, PF_START_ACCEPTING) ? pos : -1;
-  const int ncls = c.p.ncls;
-  while (pos < t.len) {
-    const uint32_t e = c.trans[state * ncls + c.cls[t.at(pos)]];
-    if (e == 0xFFFFu) break;
-    state = e & 0x7FFF;
-    ++pos;
-    if (e & 0x8000u) last = pos;
-  }
-  return last;
-}
-
-__device__ inline int count_consecutive(const Ctx& c, const Text& t, int start) {
-  int pos = start;
-  while (pos < t.len && c.first[t.at(pos)]) ++pos;
-  return pos - start;
-}
-
-__device__ inline int find_first_class(const Ctx& c, const Text& t, int start) {
-  for (int pos = start; pos < t.len; ++pos)
-    if (c.first[t.at(pos)]) return pos;
-  return -1;
-}
-
-// DFAEngine._try_match_at_position.  On success sets ms/me and returns true.
-__device__ inline bool try_match_at(const Ctx& c, const Text& t, int start_pos, bool exact,
-                                    int& ms, int& me) {
-  if (start_pos > t.len) return false;
-  if (flag(c, PF_PURE_LITERAL)) {
-    const int plen = c.p.lit_len;
-    if (exact) {
-      if (start_pos + plen > t.len) return false;  // verify_match, simd_ops.mojo:937-960
-      for (int k = 0; k < plen; ++k)
-        if (t.at(start_pos + k) != c.lit[k]) return false;
-      ms = start_pos; me = start_pos + plen;
-      return true;
-    }
-    const int pos = find_literal(c.lit, plen, t, start_pos);
-    if (pos < 0) return false;
-    ms = pos; me = pos + plen;
-    return true;
-  }
-  if (flag(c, PF_HAS_MATCHER) && (flag(c, PF_SCAN_ELIGIBLE) || flag(c, PF_START_ACCEPTING))) {
-    // _try_match_simd: the first class's run, or an empty match if the start accepts
-    const int n = count_consecutive(c, t, start_pos);
-    bool valid = false;
-    int end = start_pos + n;
-    if (n == 0) { if (flag(c, PF_START_ACCEPTING)) { valid = true; end = start_pos; } }
-    else valid = true;
-    if (valid && !(flag(c, PF_END_ANCHOR) && end != t.len)) {
-      ms = start_pos; me = end;
-      return true;
-    }
-  }
-  if (start_pos == t.len) {
-    if (flag(c, PF_START_ACCEPTING)) { ms = me = start_pos; return true; }
-    return false;
-  }
-  const int last = walk(c, t, start_pos);
-  if (last < 0) return false;
-  if (flag(c, PF_END_ANCHOR) && last != t.len) return false;
-  ms = start_pos; me = last;
-  return true;
-}
-
-// The same walk on the bitset NFA: the state is the set of live PikeVM positions
-// (pikevm.mojo:497-602 thread list, as a bit mask) instead of the id of its determinised
-// LazyDFA state; transitions are computed, not looked up:
-//     next = OR_{i in set & mask[byte]} follow[i],  dead iff next is empty.
-// One lane still owns one text; the per-byte cost grows with the number of live positions.
-template <int NW>
-__device__ __noinline__ int walk_bitset(const Ctx& c, const Text& t, int start) {
-  uint64_t S[NW];
-#pragma unroll
-  for (int w = 0; w < NW; ++w) S[w] = c.p.bs_start[w];
-  int pos = start;
-  int last = flag(c, PF_START_ACCEPTING) ? pos : -1;
-  while (pos < t.len) {
-    const uint64_t* m = c.bs_mask + (int)c.bs_cls[t.at(pos)] * NW;
-    uint64_t N[NW];
-#pragma unroll
-    for (int w = 0; w < NW; ++w) N[w] = 0;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) {
-      uint64_t hit = S[w] & m[w];
-      while (hit) {
-        const int i = w * 64 + __builtin_ctzll(hit);
-        hit &= hit - 1;
-        const uint64_t* f = c.bs_follow + i * NW;
-#pragma unroll
-        for (int v = 0; v < NW; ++v) N[v] |= f[v];
-      }
-    }
-    uint64_t any = 0, acc = 0;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) { any |= N[w]; acc |= N[w] & c.p.bs_match[w]; S[w] = N[w]; }
-    if (!any) break;  // LAZY_DFA_DEAD
-    ++pos;
-    if (acc) last = pos;
-  }
-  return last;
-}
-
-__device__ inline int lazy_walk(const Ctx& c, const Text& t, int start) {
-  if (!flag(c, PF_BITSET)) return walk(c, t, start);
-  if (c.p.bs_nw == 1) return walk_bitset<1>(c, t, start);
-  if (c.p.bs_nw == 2) return walk_bitset<2>(c, t, start);
-  return walk_bitset<4>(c, t, start);
-}
-
-// LazyDFA._run_lazy
-__device__ inline bool lazy_run(const Ctx& c, const Text& t, int start, int& ms, int& me) {
-  if (flag(c, PF_START_DEAD)) return false;
-  if (start > t.len) {  // no byte is read; the start set alone decides (pikevm.mojo:861-866)
-    if (!flag(c, PF_START_ACCEPTING)) return false;
-    ms = me = start;
-    return true;
-  }
-  const int last = lazy_walk(c, t, start);
-  if (last < 0) return false;
-  ms = start; me = last;
-  return true;
-}
-
-__device__ inline bool engine_match_first(const Ctx& c, const Text& t, int start, int& ms, int& me) {
-  if (c.p.kind == PLAN_LAZY) return lazy_run(c, t, start, ms, me);
-  if (flag(c, PF_START_ANCHOR) && start > 0) return false;   // dfa.mojo:1866-1867
-  return try_match_at(c, t, start, true, ms, me);
-}
-
-__device__ inline bool engine_match_next(const Ctx& c, const Text& t, int start, int& ms, int& me) {
-  if (c.p.kind == PLAN_LAZY) {
-    if (flag(c, PF_HAS_MATCHER)) {  // first-byte filter
-      int pos = start;
-      while (pos < t.len) {
-        const int cand = find_first_class(c, t, pos);
-        if (cand < 0) break;
-        if (lazy_run(c, t, cand, ms, me)) return true;
-        pos = cand + 1;
-      }
-      return lazy_run(c, t, t.len, ms, me);
-    }
-    for (int p = start; p <= t.len; ++p)
-      if (lazy_run(c, t, p, ms, me)) return true;
-    return false;
-  }
-  if (flag(c, PF_START_ANCHOR)) {
-    if (start == 0) return try_match_at(c, t, 0, false, ms, me);
-    return false;
-  }
-  if (flag(c, PF_HAS_MATCHER) && !flag(c, PF_END_ANCHOR)) {
-    // _optimized_simd_search
-    int pos = start;
-    if (flag(c, PF_SCAN_ELIGIBLE)) {
-      while (pos < t.len) {
-        const int mp = find_first_class(c, t, pos);
-        if (mp < 0) return false;
-        const int ml = count_consecutive(c, t, mp);
-        if (ml > 0) { ms = mp; me = mp + ml; return true; }
-        pos = mp + 1;
-      }
-      return false;
-    }
-    while (pos < t.len) {
-      const int fp = find_first_class(c, t, pos);
-      if (fp < 0) return false;
-      if (try_match_at(c, t, fp, false, ms, me)) return true;
-      pos = fp + 1;
-    }
-    return false;
-  }
-  if (flag(c, PF_PURE_LITERAL)) {
-    // every try_pos runs simd_search from try_pos: the first hit is the answer
-    if (start > t.len) return false;
-    return try_match_at(c, t, start, false, ms, me);
-  }
-  for (int p = start; p <= t.len; ++p)
-    if (try_match_at(c, t, p, false, ms, me)) return true;
-  return false;
-}
-
-// HybridMatcher.match_first, matcher.mojo:733-753
-__device__ inline bool hybrid_match_first(const Ctx& c, const Text& t, int start, int& ms, int& me) {
-  if (c.p.kind == PLAN_ANY) {
-    if (start <= t.len) { ms = start; me = t.len; return true; }
-    return false;
-  }
-  return engine_match_first(c, t, start, ms, me);
-}
-
-// HybridMatcher.match_next, matcher.mojo:755-802
-__device__ inline bool hybrid_match_next(const Ctx& c, const Text& t, int start, int& ms, int& me) {
-  if (c.p.kind == PLAN_ANY) {
-    if (start <= t.len) { ms = start; me = t.len; return true; }
-    return false;
-  }
-  if (flag(c, PF_EXACT_LITERAL)) {
-    if (start >= t.len) return false;
-    const int pos = find_literal(c.lit, c.p.lit_len, t, start);
-    if (pos < 0 || pos + c.p.lit_len > t.len) return false;
-    ms = pos; me = pos + c.p.lit_len;
-    return true;
-  }
-  if (flag(c, PF_PREFILTER)) {
-    if (start >= t.len) return false;
-    const int cand = find_literal(c.pre, c.p.pre_len, t, start);
-    if (cand < 0) return false;
-    return engine_match_next(c, t, cand, ms, me);
-  }
-  return engine_match_next(c, t, start, ms, me);
-}
-
-// DFAEngine.is_match through HybridMatcher.is_match, matcher.mojo:721-731, dfa.mojo:1815-1849
-__device__ inline bool hybrid_is_match(const Ctx& c, const Text& t, int start) {
-  int ms, me;
-  if (c.p.kind == PLAN_ANY) return start <= t.len;
-  if (c.p.kind == PLAN_LAZY) return lazy_run(c, t, start, ms, me);
-  if (flag(c, PF_START_ANCHOR) && start > 0) return false;
-  if (flag(c, PF_HAS_MATCHER) && c.p.nstates > 0) {
-    if (start >= t.len) return flag(c, PF_START_ACCEPTING);
-    if (c.first[t.at(start)]) return true;
-    return flag(c, PF_START_ACCEPTING);
-  }
-  return try_match_at(c, t, start, true, ms, me);
-}
-
-// HybridMatcher.match_all: calls emit(start, end) for every match, in order.
-template <class Emit>
-__device__ inline void for_each_match(const Ctx& c, const Text& t, Emit&& emit) {
-  int ms, me;
-  if (c.p.kind == PLAN_ANY) { emit(0, t.len); return; }
-  if (flag(c, PF_EXACT_LITERAL)) {
-    // matcher.mojo:815-847: start = pos + 1, i.e. overlapping occurrences
-    const int ll = c.p.lit_len;
-    if (ll > t.len) return;
-    const int max_start = t.len - ll;
-    int start = 0;
-    while (start <= max_start) {
-      const int pos = find_literal(c.lit, ll, t, start);
-      if (pos < 0) break;
-      emit(pos, pos + ll);
-      start = pos + 1;
-    }
-    return;
-  }
-  if (c.p.required_byte >= 0) {
-    // _match_all_required_byte, matcher.mojo:864-898
-    int pos = 0;
-    while (pos < t.len) {
-      int hit = -1;
-      for (int k = pos; k < t.len; ++k)
-        if (t.at(k) == c.p.required_byte) { hit = k; break; }
-      if (hit < 0) break;
-      int start = hit;
-      while (start > 0 && c.first[t.at(start - 1)]) --start;
-      if (engine_match_first(c, t, start, ms, me) && me > hit) {
-        emit(ms, me);
-        pos = me;
-        if (pos <= hit) pos = hit + 1;
-      } else {
-        pos = hit + 1;
-      }
-    }
-    return;
-  }
-  if (c.p.kind == PLAN_LAZY) {
-    int pos = 0;
-    if (flag(c, PF_HAS_MATCHER)) {
-      while (pos < t.len) {
-        const int cand = find_first_class(c, t, pos);
-        if (cand < 0) break;
-        pos = cand;
-        if (lazy_run(c, t, pos, ms, me)) { emit(ms, me); pos = (pos + 1 > me) ? pos + 1 : me; }
-        else ++pos;
-      }
-      return;
-    }
-    while (pos <= t.len) {
-      if (lazy_run(c, t, pos, ms, me)) { emit(ms, me); pos = (pos + 1 > me) ? pos + 1 : me; }
-      else ++pos;
-    }
-    return;
-  }
-  // DFAEngine.match_all
-  if (flag(c, PF_START_ANCHOR) || flag(c, PF_END_ANCHOR)) {
-    if (engine_match_next(c, t, 0, ms, me)) emit(ms, me);
-    return;
-  }
-  int pos = 0;
-  if (flag(c, PF_PURE_LITERAL)) {
-    const int plen = c.p.lit_len;
-    while (pos <= t.len - plen) {
-      const int hit = find_literal(c.lit, plen, t, pos);
-      if (hit < 0) break;
-      emit(hit, hit + plen);
-      pos = hit + plen;
-    }
-    return;
-  }
-  if (flag(c, PF_HAS_MATCHER) && c.p.nstates > 0) {
-    if (flag(c, PF_SCAN_ELIGIBLE)) {
-      while (pos < t.len) {
-        const int mp = find_first_class(c, t, pos);
-        if (mp < 0) break;
-        const int ml = count_consecutive(c, t, mp);
-        if (ml > 0) { emit(mp, mp + ml); pos = mp + ml; }
-        else pos = mp + 1;
-      }
-      return;
-    }
-    while (pos < t.len) {
-      const int np = find_first_class(c, t, pos);
-      if (np < 0) break;
-      pos = np;
-      if (try_match_at(c, t, pos, false, ms, me)) {
-        emit(ms, me);
-        pos = (me == ms) ? pos + 1 : me;
-      } else {
-        ++pos;
-      }
-    }
-    return;
-  }
-  while (pos <= t.len) {
-    if (try_match_at(c, t, pos, false, ms, me)) {
-      emit(ms, me);
-      pos = (me == ms) ? pos + 1 : me;
-    } else {
-      ++pos;
-    }
-  }
-}
-
 // ---- NFAEngine's backtracking matcher on its flat program (BtProg, mrx_engines.hpp) ---------------
 struct BtCaps {   // spans of the capture groups 0..9 of one attempt; -1 = the group did not close
   int s[10], e[10];
@@ -548,6 +211,460 @@ __device__ inline bool bt_match_next_with_groups(const Ctx& c, const Text& t, in
     ++search_pos;
   }
   return false;
+}
+
+// NFAEngine.match_first, nfa.mojo:342-389 (match_first_mode, required_start_pos = start)
+__device__ inline bool bt_engine_match_first(const Ctx& c, const Text& t, int start, int& ms, int& me) {
+  BtCaps caps;
+  const int end = bt_match_at(c, t, start, caps, true, start);
+  if (end < 0) return false;
+  ms = start; me = end;
+  return true;
+}
+__device__ inline bool bt_has_newline(const Text& t) {
+  for (int i = 0; i < t.len; ++i)
+    if (t.at(i) == '\n') return true;
+  return false;
+}
+// String.rfind(literal) (NFAEngine._find_last_literal, nfa.mojo:577-585)
+__device__ inline int bt_rfind_literal(const Ctx& c, const Text& t) {
+  const int ll = c.p.bt_lit_len;
+  for (int pos = t.len - ll; pos >= 0; --pos) {
+    int k = 0;
+    while (k < ll && t.at(pos + k) == c.bt_lit[k]) ++k;
+    if (k == ll) return pos;
+  }
+  return -1;
+}
+// NFAEngine.match_next, nfa.mojo:391-498.  starts_dotstar / ends_dotstar: DevPlan::bt_flags bits 2 / 3.
+__device__ inline bool bt_engine_match_next(const Ctx& c, const Text& t, int start, int& ms, int& me) {
+  const bool lit_opt = (c.p.bt_flags & 1) != 0, prefix_lit = (c.p.bt_flags & 2) != 0;
+  if ((c.p.bt_flags & 4) && lit_opt && !bt_has_newline(t)) {   // .* prefix with a literal behind it
+    const int last = bt_rfind_literal(c, t);
+    if (last >= start && last >= 0) { ms = start; me = last + c.p.bt_lit_len; return true; }
+    return false;
+  }
+  if ((c.p.bt_flags & 8) && lit_opt && prefix_lit && !bt_has_newline(t)) {   // LITERAL.*: to the end of the text
+    const int pos = find_literal(c.bt_lit, c.p.bt_lit_len, t, start);
+    if (pos >= 0) { ms = pos; me = t.len; return true; }
+    return false;
+  }
+  BtCaps caps;
+  int search_pos = start;
+  if (lit_opt) {
+    while (search_pos <= t.len) {
+      const int lp = find_literal(c.bt_lit, c.p.bt_lit_len, t, search_pos);
+      if (lp < 0) return false;
+      int try_pos = lp;
+      if (c.p.bt_lit_len > 0 && !prefix_lit) try_pos = lp - c.p.bt_pattern_len > 0 ? lp - c.p.bt_pattern_len : 0;
+      while (try_pos <= lp) {
+        const int end = bt_match_at(c, t, try_pos, caps, false, -1);
+        if (end >= 0 && bt_contains_literal(c, t, try_pos, end)) { ms = try_pos; me = end; return true; }
+        ++try_pos;
+      }
+      search_pos = lp + 1;
+    }
+    return false;
+  }
+  while (search_pos <= t.len) {
+    const int end = bt_match_at(c, t, search_pos, caps, false, -1);
+    if (end >= 0) { ms = search_pos; me = end; return true; }
+    ++search_pos;
+  }
+  return false;
+}
+// NFAEngine.match_all, nfa.mojo:169-340
+template <class Emit>
+__device__ inline void bt_engine_match_all(const Ctx& c, const Text& t, Emit&& emit) {
+  const bool lit_opt = (c.p.bt_flags & 1) != 0, prefix_lit = (c.p.bt_flags & 2) != 0;
+  int current_pos = 0;
+  if ((c.p.bt_flags & 4) && lit_opt && !bt_has_newline(t)) {
+    const int last = bt_rfind_literal(c, t);
+    if (last >= 0) emit(current_pos, last + c.p.bt_lit_len);
+    return;
+  }
+  if ((c.p.bt_flags & 8) && lit_opt && prefix_lit && !bt_has_newline(t)) {
+    if (current_pos < t.len) {
+      const int pos = find_literal(c.bt_lit, c.p.bt_lit_len, t, current_pos);
+      if (pos >= 0) emit(pos, t.len);
+    }
+    return;
+  }
+  BtCaps caps;
+  if (lit_opt) {
+    while (current_pos <= t.len) {
+      const int lp = find_literal(c.bt_lit, c.p.bt_lit_len, t, current_pos);
+      if (lp < 0) break;
+      int try_pos = lp;
+      if (c.p.bt_lit_len > 0 && !prefix_lit) try_pos = lp - 10 > current_pos ? lp - 10 : current_pos;   // search_window = 10
+      bool found = false;
+      const int max_positions = lp - try_pos + 1 < 5 ? lp - try_pos + 1 : 5;
+      int tried = 0;
+      while (try_pos <= lp && try_pos <= t.len && tried < max_positions) {
+        const int end = bt_match_at(c, t, try_pos, caps, false, -1);
+        if (end >= 0 && bt_contains_literal(c, t, try_pos, end)) {
+          emit(try_pos, end);
+          current_pos = end == try_pos ? try_pos + 1 : end;
+          found = true;
+          break;
+        }
+        ++try_pos;
+        ++tried;
+      }
+      if (!found) current_pos = lp + 1;
+    }
+    return;
+  }
+  while (current_pos <= t.len) {
+    const int end = bt_match_at(c, t, current_pos, caps, false, -1);
+    if (end >= 0) {
+      emit(current_pos, end);
+      current_pos = end == current_pos ? current_pos + 1 : end;
+    } else {
+      ++current_pos;
+    }
+  }
+}
+
+// table walk from `start`; returns the last accepting position or -1
+__device__ inline int walk(const Ctx& c, const Text& t, int start) {
+  int state = 0;
+  int pos = start;
+  int last = flag(c, PF_START_ACCEPTING) ? pos : -1;
+  const int ncls = c.p.ncls;
+  while (pos < t.len) {
+    const uint32_t e = c.trans[state * ncls + c.cls[t.at(pos)]];
+    if (e == 0xFFFFu) break;
+    state = e & 0x7FFF;
+    ++pos;
+    if (e & 0x8000u) last = pos;
+  }
+  return last;
+}
+
+__device__ inline int count_consecutive(const Ctx& c, const Text& t, int start) {
+  int pos = start;
+  while (pos < t.len && c.first[t.at(pos)]) ++pos;
+  return pos - start;
+}
+
+__device__ inline int find_first_class(const Ctx& c, const Text& t, int start) {
+  for (int pos = start; pos < t.len; ++pos)
+    if (c.first[t.at(pos)]) return pos;
+  return -1;
+}
+
+// DFAEngine._try_match_at_position.  On success sets ms/me and returns true.
+__device__ inline bool try_match_at(const Ctx& c, const Text& t, int start_pos, bool exact,
+                                    int& ms, int& me) {
+  if (start_pos > t.len) return false;
+  if (flag(c, PF_PURE_LITERAL)) {
+    const int plen = c.p.lit_len;
+    if (exact) {
+      if (start_pos + plen > t.len) return false;  // verify_match, simd_ops.mojo:937-960
+      for (int k = 0; k < plen; ++k)
+        if (t.at(start_pos + k) != c.lit[k]) return false;
+      ms = start_pos; me = start_pos + plen;
+      return true;
+    }
+    const int pos = find_literal(c.lit, plen, t, start_pos);
+    if (pos < 0) return false;
+    ms = pos; me = pos + plen;
+    return true;
+  }
+  if (flag(c, PF_HAS_MATCHER) && (flag(c, PF_SCAN_ELIGIBLE) || flag(c, PF_START_ACCEPTING))) {
+    // _try_match_simd: the first class's run, or an empty match if the start accepts
+    const int n = count_consecutive(c, t, start_pos);
+    bool valid = false;
+    int end = start_pos + n;
+    if (n == 0) { if (flag(c, PF_START_ACCEPTING)) { valid = true; end = start_pos; } }
+    else valid = true;
+    if (valid && !(flag(c, PF_END_ANCHOR) && end != t.len)) {
+      ms = start_pos; me = end;
+      return true;
+    }
+  }
+  if (start_pos == t.len) {
+    if (flag(c, PF_START_ACCEPTING)) { ms = me = start_pos; return true; }
+    return false;
+  }
+  const int last = walk(c, t, start_pos);
+  if (last < 0) return false;
+  if (flag(c, PF_END_ANCHOR) && last != t.len) return false;
+  ms = start_pos; me = last;
+  return true;
+}
+
+// The same walk on the bitset NFA: the state is the set of live PikeVM positions
+// (pikevm.mojo:497-602 thread list, as a bit mask) instead of the id of its determinised
+// LazyDFA state; transitions are computed, not looked up:
+//     next = OR_{i in set & mask[byte]} follow[i],  dead iff next is empty.
+// One lane still owns one text; the per-byte cost grows with the number of live positions.
+template <int NW>
+__device__ __noinline__ int walk_bitset(const Ctx& c, const Text& t, int start) {
+  uint64_t S[NW];
+#pragma unroll
+  for (int w = 0; w < NW; ++w) S[w] = c.p.bs_start[w];
+  int pos = start;
+  int last = flag(c, PF_START_ACCEPTING) ? pos : -1;
+  while (pos < t.len) {
+    const uint64_t* m = c.bs_mask + (int)c.bs_cls[t.at(pos)] * NW;
+    uint64_t N[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) N[w] = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      uint64_t hit = S[w] & m[w];
+      while (hit) {
+        const int i = w * 64 + __builtin_ctzll(hit);
+        hit &= hit - 1;
+        const uint64_t* f = c.bs_follow + i * NW;
+#pragma unroll
+        for (int v = 0; v < NW; ++v) N[v] |= f[v];
+      }
+    }
+    uint64_t any = 0, acc = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { any |= N[w]; acc |= N[w] & c.p.bs_match[w]; S[w] = N[w]; }
+    if (!any) break;  // LAZY_DFA_DEAD
+    ++pos;
+    if (acc) last = pos;
+  }
+  return last;
+}
+
+__device__ inline int lazy_walk(const Ctx& c, const Text& t, int start) {
+  if (!flag(c, PF_BITSET)) return walk(c, t, start);
+  if (c.p.bs_nw == 1) return walk_bitset<1>(c, t, start);
+  if (c.p.bs_nw == 2) return walk_bitset<2>(c, t, start);
+  return walk_bitset<4>(c, t, start);
+}
+
+// LazyDFA._run_lazy
+__device__ inline bool lazy_run(const Ctx& c, const Text& t, int start, int& ms, int& me) {
+  if (flag(c, PF_START_DEAD)) return false;
+  if (start > t.len) {  // no byte is read; the start set alone decides (pikevm.mojo:861-866)
+    if (!flag(c, PF_START_ACCEPTING)) return false;
+    ms = me = start;
+    return true;
+  }
+  const int last = lazy_walk(c, t, start);
+  if (last < 0) return false;
+  ms = start; me = last;
+  return true;
+}
+
+__device__ inline bool engine_match_first(const Ctx& c, const Text& t, int start, int& ms, int& me) {
+  if (flag(c, PF_BT_FIRST)) return bt_engine_match_first(c, t, start, ms, me);   // NFAMatcher -> NFAEngine, matcher.mojo:380
+  if (c.p.kind == PLAN_LAZY) return lazy_run(c, t, start, ms, me);
+  if (flag(c, PF_START_ANCHOR) && start > 0) return false;   // dfa.mojo:1866-1867
+  return try_match_at(c, t, start, true, ms, me);
+}
+
+__device__ inline bool engine_match_next(const Ctx& c, const Text& t, int start, int& ms, int& me) {
+  if (flag(c, PF_BT_SEARCH)) return bt_engine_match_next(c, t, start, ms, me);   // matcher.mojo:419
+  if (c.p.kind == PLAN_LAZY) {
+    if (flag(c, PF_HAS_MATCHER)) {  // first-byte filter
+      int pos = start;
+      while (pos < t.len) {
+        const int cand = find_first_class(c, t, pos);
+        if (cand < 0) break;
+        if (lazy_run(c, t, cand, ms, me)) return true;
+        pos = cand + 1;
+      }
+      return lazy_run(c, t, t.len, ms, me);
+    }
+    for (int p = start; p <= t.len; ++p)
+      if (lazy_run(c, t, p, ms, me)) return true;
+    return false;
+  }
+  if (flag(c, PF_START_ANCHOR)) {
+    if (start == 0) return try_match_at(c, t, 0, false, ms, me);
+    return false;
+  }
+  if (flag(c, PF_HAS_MATCHER) && !flag(c, PF_END_ANCHOR)) {
+    // _optimized_simd_search
+    int pos = start;
+    if (flag(c, PF_SCAN_ELIGIBLE)) {
+      while (pos < t.len) {
+        const int mp = find_first_class(c, t, pos);
+        if (mp < 0) return false;
+        const int ml = count_consecutive(c, t, mp);
+        if (ml > 0) { ms = mp; me = mp + ml; return true; }
+        pos = mp + 1;
+      }
+      return false;
+    }
+    while (pos < t.len) {
+      const int fp = find_first_class(c, t, pos);
+      if (fp < 0) return false;
+      if (try_match_at(c, t, fp, false, ms, me)) return true;
+      pos = fp + 1;
+    }
+    return false;
+  }
+  if (flag(c, PF_PURE_LITERAL)) {
+    // every try_pos runs simd_search from try_pos: the first hit is the answer
+    if (start > t.len) return false;
+    return try_match_at(c, t, start, false, ms, me);
+  }
+  for (int p = start; p <= t.len; ++p)
+    if (try_match_at(c, t, p, false, ms, me)) return true;
+  return false;
+}
+
+// HybridMatcher.match_first, matcher.mojo:733-753
+__device__ inline bool hybrid_match_first(const Ctx& c, const Text& t, int start, int& ms, int& me) {
+  if (c.p.kind == PLAN_ANY) {
+    if (start <= t.len) { ms = start; me = t.len; return true; }
+    return false;
+  }
+  return engine_match_first(c, t, start, ms, me);
+}
+
+// HybridMatcher.match_next, matcher.mojo:755-802
+__device__ inline bool hybrid_match_next(const Ctx& c, const Text& t, int start, int& ms, int& me) {
+  if (c.p.kind == PLAN_ANY) {
+    if (start <= t.len) { ms = start; me = t.len; return true; }
+    return false;
+  }
+  if (flag(c, PF_EXACT_LITERAL)) {
+    if (start >= t.len) return false;
+    const int pos = find_literal(c.lit, c.p.lit_len, t, start);
+    if (pos < 0 || pos + c.p.lit_len > t.len) return false;
+    ms = pos; me = pos + c.p.lit_len;
+    return true;
+  }
+  if (flag(c, PF_PREFILTER)) {
+    if (start >= t.len) return false;
+    const int cand = find_literal(c.pre, c.p.pre_len, t, start);
+    if (cand < 0) return false;
+    return engine_match_next(c, t, cand, ms, me);
+  }
+  return engine_match_next(c, t, start, ms, me);
+}
+
+// DFAEngine.is_match through HybridMatcher.is_match, matcher.mojo:721-731, dfa.mojo:1815-1849
+__device__ inline bool hybrid_is_match(const Ctx& c, const Text& t, int start) {
+  int ms, me;
+  if (c.p.kind == PLAN_ANY) return start <= t.len;
+  if (flag(c, PF_BT_FIRST)) return bt_engine_match_first(c, t, start, ms, me);
+  if (c.p.kind == PLAN_LAZY) return lazy_run(c, t, start, ms, me);
+  if (flag(c, PF_START_ANCHOR) && start > 0) return false;
+  if (flag(c, PF_HAS_MATCHER) && c.p.nstates > 0) {
+    if (start >= t.len) return flag(c, PF_START_ACCEPTING);
+    if (c.first[t.at(start)]) return true;
+    return flag(c, PF_START_ACCEPTING);
+  }
+  return try_match_at(c, t, start, true, ms, me);
+}
+
+// HybridMatcher.match_all: calls emit(start, end) for every match, in order.
+template <class Emit>
+__device__ inline void for_each_match(const Ctx& c, const Text& t, Emit&& emit) {
+  int ms, me;
+  if (c.p.kind == PLAN_ANY) { emit(0, t.len); return; }
+  if (flag(c, PF_EXACT_LITERAL)) {
+    // matcher.mojo:815-847: start = pos + 1, i.e. overlapping occurrences
+    const int ll = c.p.lit_len;
+    if (ll > t.len) return;
+    const int max_start = t.len - ll;
+    int start = 0;
+    while (start <= max_start) {
+      const int pos = find_literal(c.lit, ll, t, start);
+      if (pos < 0) break;
+      emit(pos, pos + ll);
+      start = pos + 1;
+    }
+    return;
+  }
+  if (c.p.required_byte >= 0) {
+    // _match_all_required_byte, matcher.mojo:864-898
+    int pos = 0;
+    while (pos < t.len) {
+      int hit = -1;
+      for (int k = pos; k < t.len; ++k)
+        if (t.at(k) == c.p.required_byte) { hit = k; break; }
+      if (hit < 0) break;
+      int start = hit;
+      while (start > 0 && c.first[t.at(start - 1)]) --start;
+      if (engine_match_first(c, t, start, ms, me) && me > hit) {
+        emit(ms, me);
+        pos = me;
+        if (pos <= hit) pos = hit + 1;
+      } else {
+        pos = hit + 1;
+      }
+    }
+    return;
+  }
+  if (flag(c, PF_BT_SEARCH)) { bt_engine_match_all(c, t, emit); return; }   // matcher.mojo:431
+  if (c.p.kind == PLAN_LAZY) {
+    int pos = 0;
+    if (flag(c, PF_HAS_MATCHER)) {
+      while (pos < t.len) {
+        const int cand = find_first_class(c, t, pos);
+        if (cand < 0) break;
+        pos = cand;
+        if (lazy_run(c, t, pos, ms, me)) { emit(ms, me); pos = (pos + 1 > me) ? pos + 1 : me; }
+        else ++pos;
+      }
+      return;
+    }
+    while (pos <= t.len) {
+      if (lazy_run(c, t, pos, ms, me)) { emit(ms, me); pos = (pos + 1 > me) ? pos + 1 : me; }
+      else ++pos;
+    }
+    return;
+  }
+  // DFAEngine.match_all
+  if (flag(c, PF_START_ANCHOR) || flag(c, PF_END_ANCHOR)) {
+    if (engine_match_next(c, t, 0, ms, me)) emit(ms, me);
+    return;
+  }
+  int pos = 0;
+  if (flag(c, PF_PURE_LITERAL)) {
+    const int plen = c.p.lit_len;
+    while (pos <= t.len - plen) {
+      const int hit = find_literal(c.lit, plen, t, pos);
+      if (hit < 0) break;
+      emit(hit, hit + plen);
+      pos = hit + plen;
+    }
+    return;
+  }
+  if (flag(c, PF_HAS_MATCHER) && c.p.nstates > 0) {
+    if (flag(c, PF_SCAN_ELIGIBLE)) {
+      while (pos < t.len) {
+        const int mp = find_first_class(c, t, pos);
+        if (mp < 0) break;
+        const int ml = count_consecutive(c, t, mp);
+        if (ml > 0) { emit(mp, mp + ml); pos = mp + ml; }
+        else pos = mp + 1;
+      }
+      return;
+    }
+    while (pos < t.len) {
+      const int np = find_first_class(c, t, pos);
+      if (np < 0) break;
+      pos = np;
+      if (try_match_at(c, t, pos, false, ms, me)) {
+        emit(ms, me);
+        pos = (me == ms) ? pos + 1 : me;
+      } else {
+        ++pos;
+      }
+    }
+    return;
+  }
+  while (pos <= t.len) {
+    if (try_match_at(c, t, pos, false, ms, me)) {
+      emit(ms, me);
+      pos = (me == ms) ? pos + 1 : me;
+    } else {
+      ++pos;
+    }
+  }
 }
 
 // _sub_impl_with_repl.  `out` is a sink with bytes(ptr, n); `tpl` the parsed

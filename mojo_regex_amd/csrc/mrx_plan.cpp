@@ -331,20 +331,30 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
   const bool too_large = hp.lazy.too_large && !use_bitset;
   const bool lazy_ok = hp.lazy.supported && !too_large;
   const bool nfa_end = hp.program.has_end_anchor();
+  bool bt_first = false, bt_search = false;   // operations the reference sends to NFAEngine's backtracking matcher
   if (!hp.wildcard_any && !hp.use_dfa) {
     // NFAMatcher.match_first, matcher.mojo:361-380
     if (lazy_ok && nfa_end && hp.onepass.ok)
       hp.first_onepass = true;  // matcher.mojo:378-379
-    else if (!(lazy_ok && !nfa_end))
+    else if (!(lazy_ok && !nfa_end)) {
+      // the reference falls through to NFAEngine.match_first (matcher.mojo:380): served by the flat
+      // program of the backtracking matcher when the pattern has one
+      if (!too_large && hp.bt.ok) bt_first = true;
+      else
       hp.why_no_match_first = too_large
           ? "LazyDFA determinisation exceeds the state budget"
           : "reference routes match_first to the backtracking NFA ('$' in an NFA-routed pattern that is "
-            "not one-pass)";
+            "not one-pass); its flat-program form does not cover: " + hp.bt.why_not;
+    }
     // NFAMatcher.match_next / match_all, matcher.mojo:383-431
     const bool fast_absent = !hp.nfa_has_literal_opt && !hp.nfa_starts_dotstar && !hp.nfa_ends_dotstar;
-    if (!(hp.lazy.supported && fast_absent))
+    if (!(hp.lazy.supported && fast_absent)) {
+      if (hp.bt.ok) bt_search = true;   // NFAEngine.match_next / match_all (matcher.mojo:419, 431)
+      else
       hp.why_no_search = "reference routes search/findall to the backtracking NFA "
-                         "(literal prefilter or leading/trailing .* fast path)";
+                         "(literal prefilter or leading/trailing .* fast path); its flat-program form does "
+                         "not cover: " + hp.bt.why_not;
+    }
     else if (nfa_end)
       hp.why_no_search = "LazyDFA search with '$' depends on the transition cache history "
                          "(pikevm.mojo:697-700); not reproducible";
@@ -403,6 +413,8 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
     d.required_byte = hp.required_byte;
   } else {
     d.kind = PLAN_LAZY;
+    if (bt_first) d.flags |= PF_BT_FIRST;
+    if (bt_search) d.flags |= PF_BT_SEARCH;
     const LazyTables& z = hp.lazy;
     if (z.start_dead || !lazy_ok) d.flags |= PF_START_DEAD;
     if (use_bitset) d.flags |= PF_BITSET;
@@ -499,6 +511,8 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
     d.bt_lit_len = (int)hp.nfa_literal.size();
     put(hp.blob, hp.nfa_literal.data(), hp.nfa_literal.size());
     if (hp.nfa_has_literal_opt) d.bt_flags |= 1;
+    if (hp.nfa_starts_dotstar) d.bt_flags |= 4;
+    if (hp.nfa_ends_dotstar) d.bt_flags |= 8;
     if (!hp.nfa_literal.empty() && pattern.compare(0, hp.nfa_literal.size(), hp.nfa_literal) == 0) d.bt_flags |= 2;
     align(hp.blob, 8);
   }
@@ -672,6 +686,7 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
     }
   }
   else if (d.flags & PF_START_DEAD) hp.streamable_why_not = "dead start state";
+  else if (d.flags & PF_BT_SEARCH) hp.streamable_why_not = "backtracking matcher route (NFAEngine.match_all)";
   else if (d.flags & PF_BITSET) hp.streamable_why_not = "bitset NFA walk (no determinised table)";
   else if (d.flags & (PF_START_ANCHOR | PF_END_ANCHOR)) hp.streamable_why_not = "anchored";
   else if (d.required_byte >= 0) hp.streamable_why_not = "required-byte findall path";
@@ -748,7 +763,7 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
   // Everything that takes another branch upstream keeps the literal restatement in mrx_device.hpp.
   if ((d.kind == PLAN_DFA || d.kind == PLAN_LAZY) && hp.why_no_search.empty() &&
       !(d.flags & (PF_START_ANCHOR | PF_END_ANCHOR | PF_PURE_LITERAL | PF_EXACT_LITERAL | PF_START_ACCEPTING |
-                   PF_START_DEAD | PF_BITSET | PF_SCAN_ELIGIBLE)) &&
+                   PF_START_DEAD | PF_BITSET | PF_SCAN_ELIGIBLE | PF_BT_SEARCH)) &&
       (d.nstates <= 96 ||   // (nstates + 1) x 512 B byte-indexed table in LDS
        (d.required_byte < 0 && (int64_t)d.nstates * d.ncls < 16384))) {   // or nstates x ncls entries (k_req_wave BIG)
     if (d.nstates > 96) d.flags |= PF_STEP_BIG;
@@ -762,7 +777,7 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
   // The same plain route for a LazyDFA that is walked as a bitset NFA (pikevm.mojo:754-817 over the state
   // sets of pikevm.mojo:497-648): one 64-bit word of live positions per lane, no determinised table.
   if (d.kind == PLAN_LAZY && (d.flags & PF_BITSET) && hp.bitset.nw == 1 && hp.why_no_search.empty() &&
-      !(d.flags & (PF_EXACT_LITERAL | PF_START_ACCEPTING | PF_START_DEAD)))
+      !(d.flags & (PF_EXACT_LITERAL | PF_START_ACCEPTING | PF_START_DEAD | PF_BT_SEARCH)))
     d.flags |= PF_BSTEP | PF_STEP_SEARCH | PF_STEPPABLE;
 
   // ---- anchored automaton: regex.match_first as one forward pass ----------------------
@@ -778,6 +793,7 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
   hp.first_stream_why_not.clear();
   if (d.kind == PLAN_ANY) hp.first_stream_why_not = "'.*' shortcut";
   else if (!hp.why_no_match_first.empty()) hp.first_stream_why_not = hp.why_no_match_first;
+  else if (d.flags & PF_BT_FIRST) hp.first_stream_why_not = "backtracking matcher route (NFAEngine.match_first)";
   else if (!hp.first_onepass && (d.flags & PF_START_DEAD)) hp.first_stream_why_not = "dead start state";
   else if (!hp.first_onepass && (d.flags & PF_BITSET)) hp.first_stream_why_not = "bitset NFA walk (no determinised table)";
   else if (d.flags & PF_END_ANCHOR) hp.first_stream_why_not = "'$' needs the end-of-text check of both paths";

@@ -41,6 +41,9 @@ enum PlanFlags : uint32_t {
   PF_BSTEP = 1u << 16,          // PF_BITSET plan of at most 64 positions on the windowed stepper's plain route:
                                 // the state is the set of live positions, a step is mask + follow-table lookups
                                 // in LDS (k_wstep<., 0, 1>); PF_STEP_SEARCH / PF_STEPPABLE are set with it
+  PF_BT_FIRST = 1u << 17,       // match_first / is_match: NFAMatcher falls through to NFAEngine.match_first
+                                // (matcher.mojo:380) -- the backtracking matcher, run as its flat program
+  PF_BT_SEARCH = 1u << 18,      // match_next / match_all: NFAEngine.match_next / match_all (matcher.mojo:419, 431)
   PF_STREAM_SEARCH = 1u << 11   // search / sub / captures may use the streaming kernel too (findall and
                                 // count may whenever PF_STREAMABLE is set): not with a memchr prefilter,
                                 // which only match_next consults (matcher.mojo:784-796)
@@ -98,7 +101,8 @@ struct DevPlan {
   uint64_t bs_start[4], bs_match[4];
   // the backtracking matcher as a flat program (BtProg, mrx_engines.hpp; bt_nitems == 0: none): BtItem
   // [bt_nitems], membership bitmaps u8[32] x 3 per leaf, and NFAEngine's literal prefilter facts
-  // (nfa.mojo:86-143): bt_flags bit 0 = has_literal_optimization, bit 1 = is_prefix_literal
+  // (nfa.mojo:86-143): bt_flags bit 0 = has_literal_optimization, 1 = is_prefix_literal, 2 = starts_with_dotstar,
+  // 3 = ends_with_dotstar
   int32_t off_bt_items, bt_nitems, off_bt_tbl, bt_ngroups, off_bt_lit, bt_lit_len, bt_flags, bt_pattern_len;
 };
 

@@ -1625,3 +1625,46 @@ def test_capture_groups_outside_the_flat_form_are_refused(pat):
     assert "device.backtrack=no" in rx.describe()
     with pytest.raises(M.UnsupportedPattern):
         rx.sub(b"\\1", [b"abc"])
+
+
+BACKTRACKER_ROUTED = [b"hello.*", b".*@example\\.com", b".*world", b"^aaaa.*a$", b"a.*b$", b"hello.*world", b"\\w+@example\\.com$",
+                      b".*\\d+", b"x.*", b"^\\s*hello.*", b"[a-z]+ing\\b" if False else b"[a-z]+ing.*"]
+
+
+@pytest.mark.parametrize("pat", BACKTRACKER_ROUTED)
+def test_backtracker_routed_operations_match_oracle(pat):
+    """match_first / search / findall / is_match / sub of NFA-routed patterns that NFAMatcher hands to
+    NFAEngine -- literal-prefiltered searches, leading / trailing '.*' fast paths, '$' patterns that are
+    not one-pass (matcher.mojo:361-431, nfa.mojo:169-498) -- served by the backtracking matcher's flat
+    program on the generic kernels, against the oracle's restatement (backtrack.py)."""
+    _need_gpu()
+    rx = M.compile_regex(pat)
+    d = rx.describe()
+    orx = O.compile_regex(pat)
+    if orx.matcher.use_dfa:
+        pytest.skip("DFA-routed after all")
+    rng = np.random.default_rng(zlib.crc32(pat))
+    al = b"abxhelowrd @.cmpying019\n " + bytes(c for c in pat if chr(c).isalnum()) * 2
+    texts = _random_texts(rng, 200, 50, al) + _random_texts(rng, 20, 400, al)
+    texts += [b"hello world", b"say hello there world", b"bob@example.com, eve@example.com", b"aaaaa", b"aaaaba", b"a b\nab",
+              b"hello\nworld hello world", b"", b"x", b"singing and dancing", b"  hello you", b"line1\nuser@example.com"]
+    supported_search = "support.search=yes" in d
+    supported_first = "support.match_first=yes" in d
+    assert supported_search or supported_first, d
+    if supported_first:
+        fs, fe = rx.match_first(texts)
+        im = rx.is_match(texts)
+    if supported_search:
+        ss, se = rx.match_next(texts)
+        lists = rx.findall_lists(texts)
+        subs = rx.sub(b"<>", texts)
+    for i, t in enumerate(texts):
+        if supported_first:
+            w = O.match_first(pat, t)
+            assert (int(fs[i]), int(fe[i])) == (w if w else (-1, -1)), (pat, "match_first", t)
+            assert bool(im[i]) == bool(orx.is_match(t, 0)), (pat, "is_match", t)
+        if supported_search:
+            w = O.search(pat, t)
+            assert (int(ss[i]), int(se[i])) == (w if w else (-1, -1)), (pat, "search", t)
+            assert lists[i] == O.findall(pat, t), (pat, "findall", t)
+            assert subs[i] == O.sub(pat, b"<>", t), (pat, "sub", t)

@@ -99,13 +99,17 @@ def test_config_plans():
 
 def test_out_of_scope_patterns_fail_loudly_without_a_gpu():
     # routed by the reference to OnePass / the backtracking NFA: refused, never guessed
-    rx = M.CompiledRegex("^aaaa.*a$")   # '$' program that is not one-pass: backtracker
+    rx = M.CompiledRegex("^aaaa.*a$")   # '$' program that is not one-pass: the backtracking matcher's flat program
     d = rx.describe()
-    assert "support.match_first=reference routes" in d
+    assert "support.match_first=yes" in d and "device.backtrack=yes" in d
+    d = M.CompiledRegex("^(a|b)*a.*a$").describe()   # ... unless the pattern is outside the flat form: refused
+    assert "support.match_first=reference routes" in d and "device.backtrack=no: quantified group" in d
     d = M.CompiledRegex("^[a-z]+[0-9]+$").describe()   # one-pass: match_first on the OnePass tables
     assert "support.match_first=yes" in d and "onepass=yes" in d
     assert "support.search=LazyDFA search with '$'" in d
-    rx = M.CompiledRegex("hello.world")
+    rx = M.CompiledRegex("hello.world")   # literal-prefiltered backtracker search: flat program
+    assert "support.search=yes" in rx.describe() and "literal_opt=1" in rx.describe()
+    rx = M.CompiledRegex("hello(a|b)*world")
     assert "support.search=reference routes" in rx.describe()
     with pytest.raises(M.RegexSyntaxError, match=r"Missing closing '\]'"):
         M.CompiledRegex("[abc")
