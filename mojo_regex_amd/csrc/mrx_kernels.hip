@@ -3595,7 +3595,11 @@ static int run_at(int op, const mrx_handle* h, const Layout& lay, int64_t n, int
   // refusals first (nothing is launched for an operation the plan does not support)
   if (op == AT_SEARCH) { if (int rc = check_search_supported(h)) return rc; }
   else if (!h->hp.why_no_match_first.empty()) return fail(MRX_E_UNSUPPORTED, h->hp.why_no_match_first);
-  if (h->hp.dev.flags & (op == AT_SEARCH ? PF_BT_SEARCH : PF_BT_FIRST))
+  // (a program without '^', '.*' fast paths and look-back -- a prefix literal or none -- only ever looks at
+  // text[start:], like the other engines)
+  bool bt_abs = (h->hp.dev.bt_flags & (4 | 8)) != 0 || ((h->hp.dev.bt_flags & 1) && !(h->hp.dev.bt_flags & 2));
+  for (const BtItem& it : h->hp.bt.items) bt_abs = bt_abs || it.kind == BT_START;
+  if (bt_abs && (h->hp.dev.flags & (op == AT_SEARCH ? PF_BT_SEARCH : PF_BT_FIRST)))
     return fail(MRX_E_UNSUPPORTED,
                 "start != 0 on an operation the reference runs on its backtracking matcher: '^' and the literal "
                 "prefilter's look-back use absolute text positions (nfa.mojo:998-1006, 466-467), which the view "

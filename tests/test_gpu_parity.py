@@ -716,21 +716,20 @@ def test_generated_patterns_results_match_oracle(seed):
                     got = [(int(a), int(b)) if a >= 0 else None for a, b in zip(s, e)]
             except M.UnsupportedPattern as exc:
                 checked["refused"] += 1
-                try:
-                    for t in texts:
-                        getattr(O, op)(pb, t)
-                except UnsupportedByOracle:
-                    continue
-                # The oracle got through every text: only the two documented conservative refusals
-                # may do that -- the product refuses per pattern, the oracle per text (a literal
-                # prefilter that finds nothing never reaches the backtracker), and nibble-table
-                # false positives are modelled by the oracle for one SIMD width only.
-                assert ("literal prefilter" in str(exc)) or ("nibble-table" in str(exc)), (p, op, str(exc))
+                # The oracle restates the recursive backtracking matcher and answers (nearly) everything; the
+                # product refuses, per pattern and with the reason, what the reference runs on that matcher
+                # when the pattern is outside its flat-program form, the history-dependent LazyDFA '$' searches,
+                # SIMD-width-dependent nibble-table false positives and tables beyond its budgets.
+                reason = str(exc)
+                assert any(k in reason for k in ("flat-program form does not cover", "nibble-table",
+                                                 "transition cache history", "state budget", "DFA states",
+                                                 "LDS staging budget")), (p, op, reason)
                 continue
             for t, g in zip(texts, got):
                 assert g == getattr(O, op)(pb, t), (p, op, t)
             checked[op] += 1
     assert checked["findall"] > 100 and checked["match_first"] > 150, checked
+    assert checked["refused"] < 0.25 * (checked["findall"] + checked["search"] + checked["match_first"]), checked
 
 
 @pytest.mark.parametrize("seed", [20260601, 20260602, 20260603])
@@ -1512,7 +1511,7 @@ def test_fused_findall_back_to_back_calls_reuse_their_scratch():
 AT_PATTERNS = [b"hello", b"[a-z]+\\d+", b"\\d+", b"[0-9]*", b"[a-z]*[0-9]+", b"^abc", b"^[a-z]+", b"a$", b"^abc$", b".*", b"",
                b"(x|y|foo|bar)+", b"(\\d{3})(\\d{3})(\\d{4})", b"hello world this is long", b"\\w+@\\w+\\.com", b"\\d{3}-\\d{4}",
                b"(foo|foobar)x", b"\\d+(\\.\\d+)?", b"[a-c]+[x-z]?", b"^[a-z]+[0-9]+$", b"^\\d+$", b"(a|b)*c", b"^(a|b)*c",
-               b"abab", b"[^0-9]+", b"x*"]
+               b"abab", b"[^0-9]+", b"x*", b"hello.*", b".*@b\\.com", b"^aaaa.*a$"]
 
 
 @pytest.mark.parametrize("pat", AT_PATTERNS)
@@ -1556,8 +1555,11 @@ def test_start_argument_matches_oracle(pat):
             for batch in (csr, strided):
                 try:
                     got = rx._at(op, batch, start)
-                except M.UnsupportedPattern:
-                    assert want(op, texts[0], 0) == "unsupported", (pat, op)
+                except M.UnsupportedPattern as exc:
+                    # (operations the reference runs on its backtracking matcher with absolute positions)
+                    assert want(op, texts[0], 0) == "unsupported" or "start != 0 on an operation" in str(exc), (pat, op)
+                    if "start != 0 on an operation" in str(exc):
+                        assert kind == "per_text" or start != 0
                     continue
                 if op == "is_match":
                     got = got.cpu().numpy()
