@@ -508,18 +508,59 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_wstep(DevPlan p, const uint8_
 __host__ __device__ inline size_t bscan_table_bytes(int npos) {
   return npos <= 32 ? (size_t)2048 + (size_t)((npos + 7) / 8) * 1024 : (size_t)4096 + (size_t)((npos + 7) / 8) * 2048;
 }
-template <int W32>
+// DFA = 1: the same pass for a table plan of the stepper's plain route (PF_STEPPABLE, at most 32 states):
+// U is the set of DFA STATES some walk is in.  A state's successor depends on the byte, so the follow
+// tables are per byte class -- follow8[class][j][v] = { delta(8 j + k, class) : k in v } -- and a byte's
+// entry holds the offset of its class's tables instead of a mask; a walk beginning on the byte adds
+// delta(start state, byte).  MATCH = an accepting state.
+__host__ __device__ inline size_t bscan_dfa_table_bytes(int nstates, int ncls) {
+  return (size_t)2048 + (size_t)ncls * ((nstates + 7) / 8) * 1024;
+}
+template <int W32, int DFA = 0>
 __global__ __launch_bounds__(64 * kWsWaves) void k_bscan(DevPlan p, const uint8_t* __restrict__ blob, Layout lay,
                                                          int64_t n, int mode, int32_t* __restrict__ limit) {
   constexpr int CH = 128, kRowPitch = CH + 16, LPR = CH / 16, RPI = 64 / LPR, NL = 64 / RPI;
+  static_assert(!DFA || W32, "the state-set form is 32 bits wide");
   using Set = typename std::conditional<W32 != 0, uint32_t, uint64_t>::type;
-  struct Ent { Set mask, sm; };   // positions that consume the byte; those of them a walk starting on it holds
+  struct Ent { Set mask, sm; };   // positions that consume the byte (DFA: offset of the class's follow tables); what a walk starting on it adds
   __shared__ __align__(16) uint8_t tiles[kWsWaves][64 * kRowPitch];
   extern __shared__ __align__(16) uint8_t lds[];
   Ent* tbl = (Ent*)lds;
   Set* fol = (Set*)(tbl + 256);
-  const int nch = (p.bs_npos + 7) >> 3;
-  const Set bmatch = (Set)p.bs_match[0];
+  const int nch = DFA ? (p.nstates + 7) >> 3 : (p.bs_npos + 7) >> 3;
+  Set bmatch = (Set)p.bs_match[0];
+  if (DFA) {
+    const uint8_t* g_cls = blob + p.off_cls;
+    const uint8_t* g_first = blob + p.off_first;
+    const uint16_t* g_tr = (const uint16_t*)(blob + p.off_trans);
+    const bool filt = (p.flags & PF_HAS_MATCHER) != 0;
+    const int ns = p.nstates, ncls = p.ncls;
+    for (int e = threadIdx.x; e < 256; e += blockDim.x) {
+      Ent t;
+      t.mask = (Set)(g_cls[e] * nch * 256);
+      const uint32_t t0 = g_tr[g_cls[e]];   // from the start state
+      t.sm = (Set)(((filt && !g_first[e]) || t0 == 0xFFFFu) ? 0u : 1u << (t0 & 0x7FFFu));
+      tbl[e] = t;
+    }
+    for (int e = threadIdx.x; e < ncls * nch * 256; e += blockDim.x) {
+      const int c = e / (nch * 256), j = (e >> 8) % nch, v = e & 255;
+      uint32_t u = 0;
+      for (int k = 0; k < 8; ++k) {
+        const int q = 8 * j + k;
+        if (((v >> k) & 1) && q < ns) {
+          const uint32_t t = g_tr[q * ncls + c];
+          if (t != 0xFFFFu) u |= 1u << (t & 0x7FFFu);
+        }
+      }
+      fol[e] = (Set)u;
+    }
+    uint32_t acc = 0;   // accepting states: bit 15 of any transition into them (every non-start state is entered by one)
+    for (int e = 0; e < ns * ncls; ++e) {
+      const uint32_t t = g_tr[e];
+      if (t != 0xFFFFu && (t & 0x8000u)) acc |= 1u << (t & 0x7FFFu);
+    }
+    bmatch = (Set)acc;
+  } else
   {
     const uint8_t* g_bcls = blob + p.off_bs_cls;
     const uint64_t* g_mask = (const uint64_t*)(blob + p.off_bs_mask);
@@ -592,9 +633,13 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_bscan(DevPlan p, const uint8_
         for (int k = 0; k < 16; ++k) {
           const uint32_t b = (words[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
           const Ent e = tbl[b];
-          const Set x = (U & e.mask) | e.sm;
-          Set nx = 0;
-          if (W32) {
+          const Set x = DFA ? U : ((U & e.mask) | e.sm);
+          Set nx = DFA ? e.sm : (Set)0;
+          if (DFA) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (j < nch) nx |= fol[(int)e.mask + (j << 8) + (int)((x >> (8 * j)) & 0xFFu)];   // (wave uniform)
+          } else if (W32) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
               if (j < nch) nx |= fol[(j << 8) + (int)((x >> (8 * j)) & 0xFFu)];   // (wave uniform)
@@ -2581,6 +2626,15 @@ int grid_for(int64_t n, int block) {
 size_t wstep_lds(const DevPlan& p) {
   return (p.flags & PF_BSTEP) ? bstep_table_bytes(p.bs_npos) : wstep_table_bytes(p.nstates);
 }
+// Table plans of the stepper's plain route get the same first pass when their state sets fit 32 bits and the
+// per-class follow tables fit LDS next to the text tiles (MRX_NO_UNION_PASS=1: off, for measurement).
+// search: match_next always takes the plain route (PF_STEP_SEARCH); findall / count only without a required byte.
+bool union_pass_for_table_plan(const DevPlan& p, bool search) {
+  static const bool off = getenv("MRX_NO_UNION_PASS") && getenv("MRX_NO_UNION_PASS")[0] == '1';
+  const bool plain = search ? (p.flags & PF_STEP_SEARCH) != 0 : ((p.flags & PF_STEPPABLE) && !(p.flags & PF_STEP_REQ));
+  return !off && plain && !(p.flags & (PF_BSTEP | PF_STEP_BIG)) && p.nstates <= 32 &&
+         bscan_dfa_table_bytes(p.nstates, p.ncls) <= 26 * 1024;
+}
 // Bitset NFA, first pass (k_bscan): on return *out is `lay` with every text cut to what the second pass
 // has to look at (mode 0 search, 1 count / findall); *d_limit is scratch the caller frees.
 int bscan_limits(const mrx_handle* h, const Layout& lay, int64_t n, int mode, hipStream_t s, Layout* out,
@@ -2591,7 +2645,10 @@ int bscan_limits(const mrx_handle* h, const Layout& lay, int64_t n, int mode, hi
   int64_t g = (nw + kWsWaves - 1) / kWsWaves;
   if (g < 1) g = 1;
   if (g > grid_cap()) g = grid_cap();
-  if (p.bs_npos <= 32)
+  if (!(p.flags & PF_BSTEP))   // a table plan: sets of DFA states
+    hipLaunchKernelGGL((k_bscan<1, 1>), dim3((unsigned)g), dim3(64 * kWsWaves), bscan_dfa_table_bytes(p.nstates, p.ncls), s, p,
+                       H_BLOB(h), lay, n, mode, *d_limit);
+  else if (p.bs_npos <= 32)
     hipLaunchKernelGGL((k_bscan<1>), dim3((unsigned)g), dim3(64 * kWsWaves), bscan_table_bytes(p.bs_npos), s, p, H_BLOB(h),
                        lay, n, mode, *d_limit);
   else
@@ -2774,9 +2831,13 @@ int run_match(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d_s, i
                          (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0, d_s, d_e);
       g_last_kernel = "k_req_wave_search";
     } else {
+    int32_t* d_limit = nullptr;
+    if (split == 0 && union_pass_for_table_plan(h->hp.dev, true))   // texts in which no walk from any start reaches an accepting state are not searched
+      if (int rc = bscan_limits(h, lay, n, 0, s, &lay2, &d_limit)) return rc;
     hipLaunchKernelGGL((k_wstep<STEP_SEARCH, 0>), dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_lds(h->hp.dev), s, h->hp.dev,
                        H_BLOB(h), lay2, n, (int32_t*)nullptr, (const int64_t*)nullptr, (int32_t*)nullptr,
                        (int64_t)0, d_s, d_e);
+    if (d_limit) HIP_TRY(scratch_free(d_limit, s));
     g_last_kernel = "k_step_search";
     if (split > 0) {   // the few very long texts of the batch
       hipLaunchKernelGGL((k_req_wave<STEP_SEARCH, 0>), dim3(reqwave_grid(n)), dim3(64 * kRqWaves),
@@ -3156,8 +3217,11 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
         if (int rc = req_wave_pays(lay, n, use_req_route, s, &req_wave, (p.flags & PF_STEP_BIG) ? nullptr : &step_split))
           return rc;
       lay2.split = step_split;
-      if (step_ok && wstep_bits) {   // bitset NFA: cut every text behind its last possible match end first
-        if (int rc = bscan_limits(h, lay, n, 1, s, &lay2, &d_blimit)) return rc;
+      if (step_ok && (wstep_bits || (!req_wave && step_split == 0 && !use_req_route && union_pass_for_table_plan(p, false)))) {
+        // union automaton first: texts in which no walk from any start reaches MATCH are not walked at all
+        // (mode 0: a wavefront stops as soon as each of its texts has shown one match end, so on texts full
+        // of matches the pass costs next to nothing; cutting tails -- mode 1 -- would scan everything)
+        if (int rc = bscan_limits(h, lay, n, 0, s, &lay2, &d_blimit)) return rc;
       }
       // big tables: only the wavefront kernel has their form; many short texts stay on the literal restatement
       if ((p.flags & PF_STEP_BIG) && !req_wave) step_ok = false;
@@ -3759,8 +3823,8 @@ static int run_count_any(const mrx_handle* h, const Layout& lay, int64_t n, int3
     Layout lay2 = lay;
     lay2.split = split;
     int32_t* d_blimit = nullptr;
-    if (g_force_generic < 2 && wstep_bits)   // bitset NFA: cut every text behind its last possible match end first
-      if (int rc = bscan_limits(h, lay, n, 1, s, &lay2, &d_blimit)) return rc;
+    if (g_force_generic < 2 && (wstep_bits || (!req_wave && split == 0 && !use_req_route && union_pass_for_table_plan(h->hp.dev, false))))
+      if (int rc = bscan_limits(h, lay, n, 0, s, &lay2, &d_blimit)) return rc;   // union automaton first
     const bool big_lane = (h->hp.dev.flags & PF_STEP_BIG) && !req_wave;   // -> literal restatement
     if (req_wave) {
       MRX_REQWAVE_LAUNCH(STEP_COUNT, h, lay, n, counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0, s);
