@@ -198,6 +198,26 @@ __global__ void k_expand_captures(DevPlan p, int64_t n, const int32_t* __restric
   }
 }
 
+// DFAEngine.is_match with a first-byte matcher (dfa.mojo:1832-1843): "is the first byte in the first
+// element's class, or does the start state accept" -- one byte per text, nothing is walked
+__global__ __launch_bounds__(kBlock) void k_is_match_byte(Layout lay, int64_t n, const uint8_t* __restrict__ first,
+                                                          int start_accepts, uint8_t* __restrict__ flag) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const Text t = lay.text(i);
+    flag[i] = (uint8_t)((t.len > 0 && first[t.ptr[0]]) || start_accepts);
+  }
+}
+// '^'-anchored DFA plans: match_all is one match_next, which only tries position 0 (dfa.mojo:2046-2050,
+// 1887-1891) -- so findall / count are the anchored automaton's run: one span or none per text
+__global__ void k_first_to_counts(int64_t n, const int32_t* __restrict__ start, int32_t* __restrict__ counts) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    counts[i] = start[i] >= 0 ? 1 : 0;
+}
+__global__ void k_first_to_spans(int64_t n, const int32_t* __restrict__ start, const int32_t* __restrict__ end,
+                                 const int64_t* __restrict__ prefix, int32_t* __restrict__ spans, int64_t span_cap) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    if (start[i] >= 0 && prefix[i] < span_cap) { spans[2 * prefix[i]] = start[i]; spans[2 * prefix[i] + 1] = end[i]; }
+}
 __global__ void k_span_to_flag(int64_t n, const int32_t* __restrict__ start, uint8_t* __restrict__ flag) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     flag[i] = start[i] >= 0 ? 1 : 0;
@@ -2873,6 +2893,13 @@ int64_t fused_grid_cap() {
 // Every 64-text task takes one ticket from ONE counter word (about 88 atomics per microsecond at best):
 // tasks of less than 32 KiB would queue up there, so batches of short texts keep the three-launch form.
 constexpr int64_t kFusedMinTaskBytes = 32768;
+// '^'-anchored DFA plan whose search / findall / count are the anchored automaton's run from byte 0 (not the
+// pure-literal case: simd_search is not anchored; not with '$'; not behind the exact-literal / prefilter paths)
+bool anchored_at_zero(const mrx_handle* h) {
+  const DevPlan& p = h->hp.dev;
+  return !g_force_generic && (p.flags & PF_START_ANCHOR) && !(p.flags & (PF_END_ANCHOR | PF_PURE_LITERAL)) &&
+         p.kind == PLAN_DFA && p.fa_bytes > 0 && !(p.flags & (PF_EXACT_LITERAL | PF_PREFILTER)) && h->hp.why_no_search.empty();
+}
 // longest text the event records of the streaming findall can describe (see run_findall)
 constexpr int64_t kStreamMaxText = int64_t(1) << 26;
 bool stream_text_too_long(int64_t max_text) { return max_text >= kStreamMaxText; }
@@ -3120,6 +3147,32 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
   HIP_TRY(scratch_alloc((void**)&d_counts, sizeof(int32_t) * (n > 0 ? n : 1), s));
   HIP_TRY(scratch_alloc((void**)&d_total, sizeof(int64_t), s));
   const DevPlan& p = h->hp.dev;
+  if (n > 0 && anchored_at_zero(h) && stream_layout_ok(lay, n)) {
+    int32_t* d_se = nullptr;
+    HIP_TRY(scratch_alloc((void**)&d_se, sizeof(int32_t) * 2 * n, s));
+    {
+      ScanTimer tm(s);
+      launch_stream<ST_FIRST>(h, lay, n, nullptr, nullptr, nullptr, 0, d_se, d_se + n, s, lay.vlen, lay.vskip);
+      HIP_TRY(hipGetLastError());
+      tm.stop();
+    }
+    hipLaunchKernelGGL(k_first_to_counts, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, n, d_se, d_counts);
+    if (int rc = device_scan<int32_t>(d_counts, n, d_prefix, d_total, s)) return rc;
+    if (span_cap > 0)
+      hipLaunchKernelGGL(k_first_to_spans, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, n, d_se, d_se + n, d_prefix, d_spans,
+                         span_cap);
+    HIP_TRY(hipGetLastError());
+    g_last_kernel = "k_stream_first_findall";
+    int rc = MRX_OK;
+    if (total) {
+      int64_t tot = 0;
+      HIP_TRY(hipMemcpyAsync(&tot, d_total, sizeof tot, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      *total = tot;
+      if (tot > span_cap) rc = fail(MRX_E_CAPACITY, "span buffer too small: need " + std::to_string(tot));
+    }
+    return rc;
+  }
   bool stream_ok = !g_force_generic && (p.flags & PF_STREAMABLE) && stream_layout_ok(lay, n);
   // match_next_sequence: the caller (sub) wants the matches that iterating match_next from each
   // match end visits -- the plain walk even on plans whose findall takes the required-byte route
@@ -3522,9 +3575,7 @@ static int run_search_any(const mrx_handle* h, const Layout& lay, int64_t n, int
   const DevPlan& p = h->hp.dev;
   // '^'-anchored DFA plans: match_next only ever tries position 0 (dfa.mojo:1875-1886), so search is
   // the anchored automaton's run (the pure-literal case differs: simd_search is not anchored)
-  const bool anchored0 = !g_force_generic && (p.flags & PF_START_ANCHOR) && !(p.flags & (PF_END_ANCHOR | PF_PURE_LITERAL)) &&
-                         p.kind == PLAN_DFA && p.fa_bytes > 0 && !(p.flags & (PF_EXACT_LITERAL | PF_PREFILTER)) &&
-                         h->hp.why_no_search.empty() && stream_layout_ok(lay, n);
+  const bool anchored0 = anchored_at_zero(h) && stream_layout_ok(lay, n);
   if (anchored0) {
     if (int rc = ensure_device(h)) return rc;
     hipStream_t s = (hipStream_t)st;
@@ -3617,7 +3668,23 @@ int mrx_match_first_strided_dev(const mrx_handle* h, const uint8_t* d, int64_t s
 }
 static int run_is_match_any(const mrx_handle* h, const Layout& lay, int64_t n, uint8_t* f, void* st) {
   ScratchScope scratch_scope_((hipStream_t)st);
-  if (h && h->hp.first_onepass && n > 0) {
+  if (h && n > 0 && !g_force_generic && h->hp.why_no_match_first.empty() && h->hp.dev.kind == PLAN_DFA &&
+      (h->hp.dev.flags & PF_HAS_MATCHER) && h->hp.dev.nstates > 0) {
+    // the first-byte quirk (A.6 #8): no walk at all
+    if (int rc = ensure_device(h)) return rc;
+    hipStream_t s = (hipStream_t)st;
+    hipLaunchKernelGGL(k_is_match_byte, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, lay, n, H_BLOB(h) + h->hp.dev.off_first,
+                       (h->hp.dev.flags & PF_START_ACCEPTING) ? 1 : 0, f);
+    g_last_kernel = "k_is_match_byte";
+    HIP_TRY(hipGetLastError());
+    return MRX_OK;
+  }
+  // everything else is "match_first(text, 0) is not None" (dfa.mojo:1845-1849, matcher.mojo:721-731): the
+  // anchored automaton on the streaming kernel where the plan has one
+  const bool via_first = h && n > 0 && (h->hp.first_onepass ||
+                                        (!g_force_generic && h->hp.why_no_match_first.empty() && h->hp.dev.kind != PLAN_ANY &&
+                                         h->hp.dev.fa_bytes > 0));
+  if (via_first) {
     // NFA-routed: is_match = match_first(text, 0) is not None (matcher.mojo:721-731)
     hipStream_t s = (hipStream_t)st;
     int32_t* tmp = nullptr;
@@ -3795,6 +3862,18 @@ static int run_count_any(const mrx_handle* h, const Layout& lay, int64_t n, int3
   if (int rc = ensure_device(h)) return rc;
   if (n <= 0) return MRX_OK;
   hipStream_t s = (hipStream_t)st;
+  if (anchored_at_zero(h) && stream_layout_ok(lay, n)) {
+    int32_t* d_se = nullptr;
+    HIP_TRY(scratch_alloc((void**)&d_se, sizeof(int32_t) * 2 * n, s));
+    ScanTimer tm(s);
+    launch_stream<ST_FIRST>(h, lay, n, nullptr, nullptr, nullptr, 0, d_se, d_se + n, s, lay.vlen, lay.vskip);
+    HIP_TRY(hipGetLastError());
+    tm.stop();
+    hipLaunchKernelGGL(k_first_to_counts, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, n, d_se, counts);
+    HIP_TRY(hipGetLastError());
+    g_last_kernel = "k_stream_first_count";
+    return MRX_OK;
+  }
   ScanTimer tm(s);
   if (!g_force_generic && (h->hp.dev.flags & PF_STREAMABLE) && stream_layout_ok(lay, n)) {
     Pieces pc;
