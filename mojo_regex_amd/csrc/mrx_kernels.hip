@@ -681,6 +681,87 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_bscan(DevPlan p, const uint8_
   }
 }
 
+// First occurrence of a literal of at most 32 bytes in every text (the MemchrPrefilter of
+// HybridMatcher.match_next, matcher.mojo:784-796: find(literal, start), then the engine searches from
+// there).  Shift-and: bit k of R = "the last k + 1 bytes are the literal's first k + 1"; one mask read
+// and three register operations per byte, the text through the same LDS tile as k_bscan, a wavefront
+// stops when each of its texts has its answer.  starts[i] = position of the occurrence, -1 = none.
+__global__ __launch_bounds__(64 * kWsWaves) void k_litscan(const uint8_t* __restrict__ lit, int lit_len, const uint8_t* __restrict__ blob,
+                                                           Layout lay, int64_t n, int32_t* __restrict__ starts) {
+  constexpr int CH = 128, kRowPitch = CH + 16, LPR = CH / 16, RPI = 64 / LPR, NL = 64 / RPI;
+  __shared__ __align__(16) uint8_t tiles[kWsWaves][64 * kRowPitch];
+  __shared__ uint32_t maskt[256];
+  for (int b = threadIdx.x; b < 256; b += blockDim.x) {
+    uint32_t m = 0;
+    for (int k = 0; k < lit_len; ++k) if (lit[k] == b) m |= 1u << k;
+    maskt[b] = m;
+  }
+  __syncthreads();
+  const uint32_t full = 1u << (lit_len - 1);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint8_t* tile = tiles[wave];
+  const int seg = lane % LPR, rsub = lane / LPR;
+  const int64_t nw = (n + 63) >> 6;
+  for (int64_t w = (int64_t)blockIdx.x * kWsWaves + wave; w < nw; w += (int64_t)gridDim.x * kWsWaves) {
+    const int64_t i = (w << 6) + lane;
+    const bool live = i < n;
+    const Text t = live ? lay.text(i) : Text(blob, 0);
+    const uintptr_t addr = t.len > 0 ? (uintptr_t)t.ptr : (uintptr_t)blob;
+    const int mis = t.len > 0 ? (int)(addr & 15) : 0;
+    const uintptr_t rb = addr & ~(uintptr_t)15;
+    const int end = mis + t.len;
+    __builtin_amdgcn_wave_barrier();
+    *(uint4*)(tile + lane * kRowPitch + CH) = make_uint4((uint32_t)rb, (uint32_t)((uint64_t)rb >> 32), (uint32_t)end, 0u);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    int max_end = end;
+    for (int off = 32; off > 0; off >>= 1) max_end = max(max_end, __shfl_xor(max_end, off));
+    const uint8_t* myrow = tile + lane * kRowPitch;
+    uint4 v[NL];
+#define MRX_LS_LOAD(CB)                                                                   \
+    do {                                                                                  \
+      _Pragma("unroll") for (int j_ = 0; j_ < NL; ++j_) {                                  \
+        const uint4 rs_ = *(const uint4*)(tile + (RPI * j_ + rsub) * kRowPitch + CH);      \
+        uint32_t fo_ = (uint32_t)(CB) + seg * 16;                                          \
+        if (fo_ >= rs_.z) fo_ = 0;                                                         \
+        v[j_] = mrx_ldg((const uint4*)((const uint8_t*)(((uint64_t)rs_.y << 32) | rs_.x) + fo_)); \
+      }                                                                                    \
+    } while (0)
+    uint32_t R = 0;
+    int found_at = -1;   // frame position of the first occurrence's last byte
+    if (max_end > 0) MRX_LS_LOAD(0);
+    for (int wb = 0; wb < max_end; wb += CH) {
+#pragma unroll
+      for (int j = 0; j < NL; ++j) *(uint4*)(tile + (RPI * j + rsub) * kRowPitch + seg * 16) = v[j];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (wb + CH < max_end) MRX_LS_LOAD(wb + CH);
+#pragma unroll 2
+      for (int g = 0; g < CH / 16; ++g) {
+        const uint4 wv = *(const uint4*)(myrow + g * 16);
+        const uint32_t words[4] = {wv.x, wv.y, wv.z, wv.w};
+        uint32_t hits = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          const uint32_t b = (words[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
+          R = ((R << 1) | 1u) & maskt[b];
+          const int f = wb + g * 16 + k;
+          const bool inside = f >= mis && f < end;
+          R = inside ? R : 0u;
+          hits |= (R & full) ? (1u << k) : 0u;
+        }
+        if (hits && found_at < 0) found_at = wb + g * 16 + __builtin_ctz(hits);
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (__all(found_at >= 0 || wb + CH >= end)) break;
+    }
+#undef MRX_LS_LOAD
+    if (live) starts[i] = found_at >= 0 ? found_at - mis - (lit_len - 1) : -1;
+  }
+}
+
 // slot rows -> CSR spans: one lane per text, rows of at most kStepSlots spans
 __global__ __launch_bounds__(kBlock) void k_slots_gather(int64_t n, const int32_t* __restrict__ counts,
                                                          const int64_t* __restrict__ prefix,
@@ -2088,8 +2169,9 @@ __global__ __launch_bounds__(kBlock) void k_view_build(Layout lay, int64_t n, in
       vstart[n] = lay.offsets ? lay.offsets[n] : n * lay.stride;
       break;
     }
-    const int64_t a = lay.offsets ? lay.offsets[i] : i * lay.stride;
-    const int len = lay.offsets ? (int)(lay.offsets[i + 1] - a) : (lay.lens ? lay.lens[i] : lay.len);
+    const Text tx = lay.text(i);   // (also a view: the prefilter's view of a view)
+    const int64_t a = tx.ptr - lay.data;
+    const int len = tx.len;
     const int s0 = starts ? starts[i] : start;
     const int sc = s0 < 0 ? 0 : s0 > len ? len : s0;
     vstart[i] = a + sc;
@@ -2104,7 +2186,7 @@ __global__ __launch_bounds__(kBlock) void k_view_fix(Layout lay, int64_t n, int3
                                                      int rules, int32_t* __restrict__ out_s, int32_t* __restrict__ out_e,
                                                      uint8_t* __restrict__ out_flag) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const int len = lay.offsets ? (int)(lay.offsets[i + 1] - lay.offsets[i]) : (lay.lens ? lay.lens[i] : lay.len);
+    const int len = lay.text(i).len;
     const int s0 = starts ? starts[i] : start;
     const bool none = s0 < 0 || ((rules & 1) && s0 > 0);
     const bool beyond = s0 > len;
@@ -2482,6 +2564,9 @@ thread_local bool g_timing = false;
 thread_local double g_scan_ms = 0.0;
 thread_local int64_t g_scan_launches = 0;
 thread_local const char* g_last_kernel = "";
+// set while a search runs on the view behind each text's first prefilter-literal occurrence: the memchr
+// prefilter of HybridMatcher.match_next has been consulted, the engine's own search is what is left
+thread_local bool t_prefilter_done = false;
 // mrx_debug_force_generic(): route every call to the generic lane-per-text kernels (tests compare
 // the two implementations; never set in production)
 // (process-wide switches of include/mrx_testing.h; relaxed atomics: set while no call is in flight)
@@ -2818,7 +2903,7 @@ int run_match(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d_s, i
   hipStream_t s = (hipStream_t)stream;
   ScanTimer tm(s);
   if (OP == OP_SEARCH && g_force_generic < 2 && (h->hp.dev.flags & PF_STEP_SEARCH) &&
-      !(h->hp.dev.flags & PF_PREFILTER)) {   // (the memchr prefilter changes match_next, matcher.mojo:784-796)
+      (!(h->hp.dev.flags & PF_PREFILTER) || t_prefilter_done)) {   // (the memchr prefilter changes match_next, matcher.mojo:784-796)
     bool wave = false;
     const bool big = (h->hp.dev.flags & PF_STEP_BIG) != 0;   // only the wavefront kernel has its table form
     const bool bits = (h->hp.dev.flags & PF_BSTEP) != 0;     // bitset NFA: the lane-per-text stepper only
@@ -3586,7 +3671,43 @@ static int run_search_any(const mrx_handle* h, const Layout& lay, int64_t n, int
     tm.stop();
     return MRX_OK;
   }
-  if (g_force_generic || !(p.flags & PF_STREAM_SEARCH) || !stream_layout_ok(lay, n))
+  // Memchr prefilter (matcher.mojo:784-796): match_next = "find the literal from start on, then let the engine
+  // search from THERE" -- first occurrence per text by shift-and (k_litscan), then the engine's search on the
+  // view of each text from that occurrence on (streaming kernel or stepper), offsets added back
+  if (!g_force_generic && (p.flags & PF_PREFILTER) && !t_prefilter_done && p.pre_len >= 1 && p.pre_len <= 32 && n > 0 &&
+      h->hp.why_no_search.empty() && (p.flags & (PF_STREAMABLE | PF_STEP_SEARCH))) {
+    if (int rc = ensure_device(h)) return rc;
+    hipStream_t s = (hipStream_t)st;
+    int32_t* d_cand = nullptr;
+    int64_t* vstart = nullptr;
+    int32_t* vlen = nullptr;
+    uint32_t* vskip = nullptr;
+    HIP_TRY(scratch_alloc((void**)&d_cand, sizeof(int32_t) * n, s));
+    HIP_TRY(scratch_alloc((void**)&vstart, sizeof(int64_t) * (n + 1), s));
+    HIP_TRY(scratch_alloc((void**)&vlen, sizeof(int32_t) * n, s));
+    HIP_TRY(scratch_alloc((void**)&vskip, sizeof(uint32_t) * n, s));
+    {
+      const int64_t nw = (n + 63) / 64;
+      int64_t g = (nw + kWsWaves - 1) / kWsWaves;
+      if (g > grid_cap()) g = grid_cap();
+      hipLaunchKernelGGL(k_litscan, dim3((unsigned)g), dim3(64 * kWsWaves), 0, s, H_BLOB(h) + p.off_pre, p.pre_len, H_BLOB(h), lay, n,
+                         d_cand);
+    }
+    hipLaunchKernelGGL(k_view_build, dim3(grid_for(n + 1, kBlock)), dim3(kBlock), 0, s, lay, n, 0, d_cand, vstart, vlen, vskip);
+    HIP_TRY(hipGetLastError());
+    Layout view{lay.data, vstart, 0, nullptr, 0};
+    view.vlen = vlen;
+    view.vskip = vskip;
+    t_prefilter_done = true;
+    const int rc = run_search_any(h, view, n, ds, de, st);
+    t_prefilter_done = false;
+    if (rc != MRX_OK) return rc;
+    hipLaunchKernelGGL(k_view_fix, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, lay, n, 0, d_cand, 0, ds, de, (uint8_t*)nullptr);
+    HIP_TRY(hipGetLastError());
+    return MRX_OK;
+  }
+  if (g_force_generic || !((p.flags & PF_STREAM_SEARCH) || ((p.flags & PF_STREAMABLE) && t_prefilter_done)) ||
+      !stream_layout_ok(lay, n))
     return run_match<OP_SEARCH>(h, lay, n, ds, de, nullptr, st);
   if (int rc = check_search_supported(h)) return rc;
   if (int rc = ensure_device(h)) return rc;
@@ -3815,7 +3936,9 @@ static int run_captures_any(const mrx_handle* h, const Layout& lay, int64_t n, i
   if (!h) return fail(MRX_E_ARGUMENT, "null handle");
   const uint32_t fl = h->hp.dev.flags;
   const bool fast_search = (!g_force_generic && (fl & PF_STREAM_SEARCH)) ||
-                           (g_force_generic < 2 && (fl & PF_STEP_SEARCH) && !(fl & PF_PREFILTER));
+                           (g_force_generic < 2 && (fl & PF_STEP_SEARCH) && !(fl & PF_PREFILTER)) ||
+                           (!g_force_generic && (fl & PF_PREFILTER) && (fl & (PF_STREAMABLE | PF_STEP_SEARCH)) &&
+                            h->hp.dev.pre_len >= 1 && h->hp.dev.pre_len <= 32);   // literal scan + view (run_search_any)
   if (!fast_search || h->hp.fixed_total < 0 || n <= 0)
     return run_match<OP_CAPTURES>(h, lay, n, spans, nullptr, nullptr, st);
   // search on the streaming kernel (or the windowed stepper), then the groups at their fixed offsets
