@@ -36,25 +36,79 @@ PATTERN = b"[a-z]+\\d+"
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def _host_info():
+    model, mem = "unknown", None
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemTotal"):
+                mem = round(int(line.split()[1]) / (1 << 20), 1)
+                break
+    except OSError:
+        pass
+    return model, mem
+
+
+def _median_time(fn, repeats: int):
+    ts = []
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        r = fn()
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    return ts[len(ts) // 2], r
+
+
 def cpu_baseline(host_rows, pattern: bytes):
-    """Oracle C port on a bounded sample (checker code, used here only as the
-    reported CPU baseline -- never on the measured GPU path)."""
+    """Oracle C port on a bounded sample (checker code, used here only as the reported CPU
+    baseline -- never on the measured GPU path).  SURVEY.md 8(d): the same algorithm as the
+    reference (scalar table walk, dfa.mojo:1996-2009; AVX2 range-compare skip scan,
+    simd_ops.mojo:585-692), built -O3 -march=native on this box, one thread like the reference,
+    timed after a warm-up run as the median of three."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import numpy as np
+    from mrx_ref import cfast
     from mrx_ref.cfast import CDfa
     n, L = host_rows.shape
-    cd = CDfa(pattern)
+    native = bool(cfast.build_native())
+    cd = CDfa(pattern, native=native)
     offsets = np.arange(0, (n + 1) * L, L, dtype=np.int64)
     data = host_rows.reshape(-1)
-    t0 = time.perf_counter()
-    counts, _, total = cd.findall_batch(data, offsets, want_spans=False)
-    dt = time.perf_counter() - t0
+    warm = min(n, 2048)
+    cd.findall_batch(data[: warm * L], offsets[: warm + 1], want_spans=False)   # warm-up (tables, page faults)
+    dt, (counts, _, total) = _median_time(lambda: cd.findall_batch(data, offsets, want_spans=False), 3)
+    model, mem_gib = _host_info()
     out = {
         "value": round(n * L / dt / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
-        "sample": "first %d texts (%d MiB) of the same batch, findall, oracle/c/mrx_oracle.c, "
-                  "%.1f s, %d matches" % (n, n * L >> 20, dt, total),
+        "sample": "first %d texts (%d MiB) of the same batch, findall, oracle/c/mrx_oracle.c (%s), warm-up + "
+                  "median of 3 runs, %.2f s per run, %d matches" % (n, n * L >> 20, "-O3 -march=native" if native else
+                                                                     "-O3 -march=x86-64-v3, no compiler on this box", dt, total),
         "matches_per_s": round(total / dt, 1),
+        "cpu_model": model, "host_mem_GiB": mem_gib,
     }
+    # per text kind (the mix of SURVEY.md 8(d)): the reference's restart-per-position search is quadratic on
+    # the adversarial rows, which dominate the figure above
+    last = host_rows[:, L - 1]
+    has_space = (host_rows == 32).any(axis=1)
+    all_lower_but_last = ((host_rows[:, : L - 1] >= 97) & (host_rows[:, : L - 1] <= 122)).all(axis=1)
+    alnum = (((host_rows >= 97) & (host_rows <= 122)) | ((host_rows >= 48) & (host_rows <= 57))).all(axis=1)
+    alnum_sp = (((host_rows >= 97) & (host_rows <= 122)) | ((host_rows >= 48) & (host_rows <= 57)) | (host_rows == 32)).all(axis=1)
+    kinds = {"adversarial": all_lower_but_last & (last == 33), "full": alnum, "tokens": has_space & alnum_sp}
+    kinds["noise"] = ~(kinds["adversarial"] | kinds["full"] | kinds["tokens"])
+    by_kind = {}
+    for name, sel in kinds.items():
+        rows = np.ascontiguousarray(host_rows[sel][:4096])
+        m = rows.shape[0]
+        if m == 0:
+            continue
+        offs = np.arange(0, (m + 1) * L, L, dtype=np.int64)
+        kd, _ = _median_time(lambda: cd.findall_batch(rows.reshape(-1), offs, want_spans=False), 3)
+        by_kind[name] = {"texts_timed": int(m), "share_of_sample": round(float(sel.mean()), 3),
+                         "GBps": round(m * L / kd / 1e9, 4)}
+    out["by_text_kind"] = by_kind
     # second leg (SURVEY.md 8(d)): the same scan with the texts split over all host cores this
     # process may use; the reference itself is single threaded, so `value` stays the 1-thread figure
     try:
@@ -62,9 +116,8 @@ def cpu_baseline(host_rows, pattern: bytes):
     except AttributeError:
         cores = os.cpu_count() or 1
     if cores > 1:
-        t0 = time.perf_counter()
-        counts_mt, total_mt = cd.count_batch_mt(data, offsets, cores)
-        dt = time.perf_counter() - t0
+        cd.count_batch_mt(data, offsets, cores)   # warm-up (thread pool)
+        dt, (counts_mt, total_mt) = _median_time(lambda: cd.count_batch_mt(data, offsets, cores), 3)
         out["all_cores"] = {"value": round(n * L / dt / 1e9, 4), "unit": "GB/s", "cores": cores,
                             "seconds": round(dt, 2), "same_counts": bool((counts_mt == counts).all())}
     return out, counts
@@ -118,7 +171,7 @@ def main():
     ap.add_argument("--settle", type=int, default=64, help="untimed steps before the warm-up (arena, clocks)")
     ap.add_argument("--texts", type=int, default=1 << 20, help="texts per GPU")
     ap.add_argument("--length", type=int, default=1024)
-    ap.add_argument("--cpu-sample", type=int, default=1 << 16)
+    ap.add_argument("--cpu-sample", type=int, default=1 << 15, help="texts of the batch the CPU baseline is timed on")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: --texts is the WHOLE job, split over the ranks by contiguous "

@@ -36,7 +36,26 @@ typedef struct {
   const uint8_t* literal;
   int32_t literal_len;
   int32_t simd_width;        /* SIMD_WIDTH of the modelled reference build */
+  const uint8_t* ranges;     /* [2 * num_ranges] lo, hi of the class's contiguous ranges (1..3), else NULL */
 } mrx_dfa;
+
+/* The reference scans for the first-class byte 32 bytes at a time with range compares
+ * (simd_ops.mojo:585-631: (c - lo) <= (hi - lo) per range, OR, movemask) and counts runs the same
+ * way (simd_ops.mojo:682-692).  The CPU baseline does the same when built for an AVX2 machine; the
+ * results are those of the scalar loops (every branch is exact for 1..3 ranges). */
+#ifdef __AVX2__
+#include <immintrin.h>
+static inline uint32_t class_mask32(const mrx_dfa* d, const uint8_t* p) {
+  const __m256i v = _mm256_loadu_si256((const __m256i*)p);
+  __m256i in = _mm256_setzero_si256();
+  for (int r = 0; r < d->num_ranges; ++r) {
+    const __m256i x = _mm256_sub_epi8(v, _mm256_set1_epi8((char)d->ranges[2 * r]));
+    const __m256i span = _mm256_set1_epi8((char)(d->ranges[2 * r + 1] - d->ranges[2 * r]));
+    in = _mm256_or_si256(in, _mm256_cmpeq_epi8(_mm256_min_epu8(x, span), x));
+  }
+  return (uint32_t)_mm256_movemask_epi8(in);
+}
+#endif
 
 typedef struct { int64_t s, e; } span_t;
 
@@ -44,6 +63,13 @@ typedef struct { int64_t s, e; } span_t;
 static int64_t find_first_nibble_match(const mrx_dfa* d, const uint8_t* t, int64_t start, int64_t len) {
   int64_t pos = start;
   if (d->num_ranges >= 1 && d->num_ranges <= 3) {
+#ifdef __AVX2__
+    if (d->ranges)
+      for (; pos + 32 <= len; pos += 32) {
+        const uint32_t m = class_mask32(d, t + pos);
+        if (m) return pos + __builtin_ctz(m);
+      }
+#endif
     for (; pos < len; ++pos)
       if (d->lookup[t[pos]]) return pos;
     return -1;
@@ -66,6 +92,13 @@ static int64_t find_first_nibble_match(const mrx_dfa* d, const uint8_t* t, int64
 /* simd_ops.mojo:651-786 (every branch is exact) */
 static int64_t count_consecutive_matches(const mrx_dfa* d, const uint8_t* t, int64_t start, int64_t len) {
   int64_t pos = start;
+#ifdef __AVX2__
+  if (d->ranges && d->num_ranges >= 1 && d->num_ranges <= 3)
+    for (; pos + 32 <= len; pos += 32) {
+      const uint32_t m = ~class_mask32(d, t + pos);
+      if (m) return pos + __builtin_ctz(m) - start;
+    }
+#endif
   while (pos < len && d->lookup[t[pos]]) ++pos;
   return pos - start;
 }

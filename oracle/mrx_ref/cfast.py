@@ -28,35 +28,61 @@ class _Dfa(C.Structure):
         ("is_pure_literal", C.c_int32), ("has_simd_matcher", C.c_int32),
         ("simd_scan_eligible", C.c_int32), ("lookup", C.c_void_p), ("num_ranges", C.c_int32),
         ("lo_tbl", C.c_void_p), ("hi_tbl", C.c_void_p), ("literal", C.c_void_p),
-        ("literal_len", C.c_int32), ("simd_width", C.c_int32),
+        ("literal_len", C.c_int32), ("simd_width", C.c_int32), ("ranges", C.c_void_p),
     ]
 
 
-def load():
+_NATIVE_SO = None
+
+
+def build_native() -> str:
+    """The same C file built -O3 -march=native on THIS machine (bench.py's cpu_baseline leg, SURVEY.md
+    8(d)); the checked-in Makefile target is -march=x86-64-v3 so that one binary runs on every box.
+    Falls back to the portable build when there is no compiler here."""
+    global _NATIVE_SO
+    if _NATIVE_SO is None:
+        import tempfile
+        out = os.path.join(tempfile.gettempdir(), "libmrx_oracle_native_%d.so" % os.getuid())
+        src = os.path.join(_ORACLE_DIR, "c", "mrx_oracle.c")
+        try:
+            subprocess.run(["gcc", "-O3", "-march=native", "-fPIC", "-std=c11", "-fopenmp", "-shared", "-o", out, src],
+                           check=True, capture_output=True)
+            _NATIVE_SO = out
+        except Exception:
+            _NATIVE_SO = ""
+    return _NATIVE_SO
+
+
+def load(native: bool = False):
     global _lib
+    if native and build_native():
+        return _bind(C.CDLL(build_native()))
     if _lib is None:
         if not os.path.exists(_SO):
             subprocess.run(["make", "-s", "-C", _ORACLE_DIR], check=True)
-        lib = C.CDLL(_SO)
-        P = C.POINTER(_Dfa)
-        lib.mrx_oracle_findall_batch.restype = C.c_int64
-        lib.mrx_oracle_findall_batch.argtypes = [P, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
-                                                 C.c_void_p, C.c_int64]
-        lib.mrx_oracle_count_batch_mt.restype = C.c_int64
-        lib.mrx_oracle_count_batch_mt.argtypes = [P, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]
-        lib.mrx_oracle_span_batch.restype = None
-        lib.mrx_oracle_span_batch.argtypes = [P, C.c_int, C.c_void_p, C.c_void_p, C.c_int64,
-                                              C.c_void_p, C.c_void_p]
-        lib.mrx_oracle_match_first_bytes.restype = C.c_int64
-        lib.mrx_oracle_match_first_bytes.argtypes = [P, C.c_void_p, C.c_void_p, C.c_int64]
-        _lib = lib
+        _lib = _bind(C.CDLL(_SO))
     return _lib
+
+
+def _bind(lib):
+    P = C.POINTER(_Dfa)
+    lib.mrx_oracle_findall_batch.restype = C.c_int64
+    lib.mrx_oracle_findall_batch.argtypes = [P, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                             C.c_void_p, C.c_int64]
+    lib.mrx_oracle_count_batch_mt.restype = C.c_int64
+    lib.mrx_oracle_count_batch_mt.argtypes = [P, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]
+    lib.mrx_oracle_span_batch.restype = None
+    lib.mrx_oracle_span_batch.argtypes = [P, C.c_int, C.c_void_p, C.c_void_p, C.c_int64,
+                                          C.c_void_p, C.c_void_p]
+    lib.mrx_oracle_match_first_bytes.restype = C.c_int64
+    lib.mrx_oracle_match_first_bytes.argtypes = [P, C.c_void_p, C.c_void_p, C.c_int64]
+    return lib
 
 
 class CDfa:
     """A DFAEngine of the Python oracle, frozen into C-readable arrays."""
 
-    def __init__(self, pattern: bytes):
+    def __init__(self, pattern: bytes, native: bool = False):
         c = CompiledRegex(pattern)
         m = c.matcher
         if (m.is_wildcard_match_any or not m.use_dfa or m.is_exact_literal
@@ -86,8 +112,22 @@ class CDfa:
         d.literal = self._lit.ctypes.data
         d.literal_len = len(e.literal_pattern)
         d.simd_width = SIMD_WIDTH
+        # contiguous ranges of the first class (CharacterClassSIMD._detect_ranges, simd_ops.mojo:364-401)
+        self._ranges = None
+        if 1 <= e.matcher.num_ranges <= 3:
+            rs, inside = [], False
+            for c_ in range(257):
+                m_ = c_ < 256 and self._lookup[c_] != 0
+                if m_ and not inside:
+                    rs.append(c_)
+                elif not m_ and inside:
+                    rs.append(c_ - 1)
+                inside = m_
+            if len(rs) == 2 * e.matcher.num_ranges:
+                self._ranges = np.array(rs, dtype=np.uint8)
+        d.ranges = self._ranges.ctypes.data if self._ranges is not None else None
         self._d = d
-        self._lib = load()
+        self._lib = load(native)
 
     def findall_batch(self, data: np.ndarray, offsets: np.ndarray, want_spans: bool = True):
         """(counts int32[n], spans int32[total,2] or None, total)."""
