@@ -34,6 +34,9 @@ void mrx_debug_long_text_kernels(int mode);
  * same results either way.  0 = three launches, 1 = one launch when a 64-text task has at least
  * 32 KiB, 2 = one launch for short texts too.  Environment: MRX_FUSED=0|1|2 at compile time. */
 void mrx_debug_fused_findall(int mode);
+/* Ragged (CSR) batches of streamable plans with a reset byte are scanned by k_stream_dyn -- 256-text tasks,
+ * a lane takes the next text when its own ends -- from 16384 texts up; 1 = always, 2 = never, 0 = by size. */
+void mrx_debug_dynamic_texts(int mode);
 /* Bytes of device memory the calling thread's scratch arenas hold (see mrx_release_scratch). */
 size_t mrx_debug_scratch_bytes(void);
 

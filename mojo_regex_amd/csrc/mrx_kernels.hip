@@ -1809,6 +1809,316 @@ __global__ __launch_bounds__(64 * kStreamWaves, (MODE == ST_FUSED ? MRX_FUSED_WA
 #undef fz
 }
 
+// ---- ragged batches: texts handed to lanes as the lanes fall free -----------------------------------
+// k_stream_findall gives a wavefront 64 consecutive texts, one per lane, and runs as long as the longest
+// of them: with lengths U[64, 1024] 46 % of the lane-steps are idle.  Here a wavefront owns kDynTexts
+// consecutive texts and a lane that reaches the end of its text takes the next unassigned one -- at the
+// next 128-byte chunk boundary, because the text tile is filled chunk by chunk for all 64 rows at once.
+// A row's descriptor in the tile's pad bytes is {base, frame end, fallback offset}; for a text taken over
+// at chunk c the base is moved back by c x 128 bytes, so the common chunk counter keeps addressing every
+// row, and the lane's frame coordinates carry the same shift (mis = c x 128 + address & 15).  The lanes
+// that will finish inside the current chunk are known before it is processed (frame end <= chunk end), so
+// their next texts are chosen -- ballot, rank, one wave-uniform cursor -- and their descriptors rewritten
+// BEFORE the next chunk is prefetched.  Needs the reset byte (DevPlan::st_reset_byte): bytes of a chunk
+// outside the lane's text are replaced by it and every group takes the branch-free steps, which also
+// emits the match that runs to the end of a text unless the text ends exactly on the chunk boundary
+// (checked when the lane lets go of the text).  Records name the text by its index in the task (8 bits)
+// next to 24 bits of "matches of this text so far"; k_decode<., ., ., DYN> reads them that way.
+#ifndef MRX_DYN_TEXTS
+#define MRX_DYN_TEXTS 256
+#endif
+constexpr int kDynTexts = MRX_DYN_TEXTS;   // 256, 512 or 1024
+constexpr int kDynShift = kDynTexts <= 256 ? 24 : kDynTexts <= 512 ? 23 : 22;   // record meta: text index above, matches so far below
+constexpr uint32_t kDynBeforeMask = (1u << kDynShift) - 1u;
+static_assert(kDynTexts % 64 == 0 && kDynTexts <= 1024, "task size");
+// record region of task w: a text yields at most len / 16 + 3 records, so kDynTexts of them starting at byte
+// first_off need at most bytes / 16 + 3 kDynTexts slots; regions floor(off / 16) + 4 kDynTexts w apart cannot overlap
+__host__ __device__ inline int64_t rec_region_dyn(int64_t first_off, int64_t w) { return (first_off >> 4) + 4 * kDynTexts * w; }
+
+template <int MODE, int AUTO, int REC32>
+__global__ __launch_bounds__(64 * kStreamWaves) void k_stream_dyn(
+    DevPlan p, const uint8_t* __restrict__ blob, const uint8_t* __restrict__ data, const int64_t* __restrict__ offsets,
+    const int32_t* __restrict__ vlen, int64_t n, int32_t* __restrict__ counts, int32_t* __restrict__ wave_nrecs,
+    EvRec* __restrict__ recs, int32_t* __restrict__ out_s, int32_t* __restrict__ out_e) {
+  static_assert(MODE == ST_RECORDS || MODE == ST_COUNT || MODE == ST_SEARCH, "search modes only");
+  constexpr int CH = 128, kRowPitch = CH + 16, LPR = CH / 16, RPI = 64 / LPR, NL = 64 / RPI;
+  __shared__ __align__(16) uint8_t tiles[kStreamWaves][64 * kRowPitch];
+  __shared__ __align__(16) uint16_t col_lds[256];
+  __shared__ __align__(16) uint4 pmask[17];   // pmask[x]: the first x bytes of a 16-byte group set
+  if (threadIdx.x < 17) {
+    const int x = threadIdx.x;
+    uint32_t w[4];
+    for (int j = 0; j < 4; ++j) {
+      const int nb = x - 4 * j;
+      w[j] = nb <= 0 ? 0u : nb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1u);
+    }
+    pmask[x] = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+  const uint32_t fillw = (uint32_t)(p.st_reset_byte & 0xFF) * 0x01010101u;
+  extern __shared__ __align__(16) uint8_t stg_lds[];
+  if (AUTO == 1) {
+    const uint16_t* src = (const uint16_t*)(blob + p.off_stcol);
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) col_lds[i] = src[i];
+  } else if (AUTO == 3) {
+    const uint32_t* src = (const uint32_t*)(blob + p.off_stcol);
+    uint32_t* dst = (uint32_t*)stg_lds;
+    for (int i = threadIdx.x; i < 512; i += blockDim.x) dst[i] = src[i];
+  } else {
+    const uint32_t* src = (const uint32_t*)(blob + p.off_stg_cls);
+    uint32_t* dst = (uint32_t*)stg_lds;
+    for (int i = threadIdx.x; i < (p.stg_bytes >> 2); i += blockDim.x) dst[i] = src[i];
+  }
+  __syncthreads();
+  const uint64_t* col64_lds = (const uint64_t*)stg_lds;   // AUTO == 3
+  const uint8_t* cls_lds = stg_lds;
+  const uint16_t* tr_lds = (const uint16_t*)(stg_lds + (p.off_stg_trans - p.off_stg_cls));
+  const uint8_t* acc_lds = stg_lds + (p.off_stg_acc - p.off_stg_cls);
+  const uint32_t* pair_lds = (const uint32_t*)(stg_lds + (p.off_stg_pair - p.off_stg_cls));   // AUTO == 4
+  const uint32_t accmask = p.st_accept_mask;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint8_t* tile = tiles[wave];
+  const int seg = lane % LPR, rsub = lane / LPR;
+  const int64_t ntasks = (n + kDynTexts - 1) / kDynTexts;
+  auto accepting = [&](uint32_t q4) -> bool {
+    return AUTO == 4 ? acc_lds[q4 >> (2 * p.st_cshift)] != 0
+         : AUTO == 2 ? acc_lds[q4 >> p.st_cshift] != 0
+                     : ((accmask >> (q4 >> (AUTO == 3 ? 3 : 2))) & 1u) != 0;
+  };
+  for (int64_t task = (int64_t)blockIdx.x * kStreamWaves + wave; task < ntasks; task += (int64_t)gridDim.x * kStreamWaves) {
+    const int64_t T0 = task * kDynTexts;
+    const int64_t T1 = T0 + kDynTexts < n ? T0 + kDynTexts : n;
+    int64_t next = T0 + 64;                       // first text nobody has taken (wave uniform)
+    // what a lane knows about the text it is walking
+    int64_t my_text = T0 + lane;
+    bool active = my_text < T1;
+    int my_len = 0, mis = 0, flen = 0;           // flen: frame position behind the text's last byte
+    // row descriptor of a text (byte offset o0, length len; t < 0: none) taken over at chunk `shift`
+    auto describe = [&](int64_t t, int64_t o0, int len, int shift, int& len_o, int& mis_o, int& flen_o) {
+      uintptr_t addr = (uintptr_t)blob;
+      if (t < 0) len = 0;
+      if (len > 0) addr = (uintptr_t)(data + o0);
+      const int m0 = len > 0 ? (int)(addr & 15) : 0;
+      const uintptr_t rb = (addr & ~(uintptr_t)15) - (uintptr_t)shift;
+      len_o = len; mis_o = shift + m0; flen_o = shift + m0 + len;
+      // (no text, or an empty one: frame end 0 -- every load of the row falls back to the row's first block)
+      *(uint4*)(tile + lane * kRowPitch + CH) =
+          make_uint4((uint32_t)rb, (uint32_t)((uint64_t)rb >> 32), len > 0 ? (uint32_t)flen_o : 0u, (uint32_t)shift);
+    };
+    // where a text lies: lane l keeps the offsets (and view lengths) of text next + l, loaded one chunk ahead, so
+    // that a lane taking text next + rank gets them by a cross-lane read instead of a dependent global load
+    // in front of the next chunk's prefetch
+    auto load_window = [&](int64_t first, int64_t& w0, int64_t& w1, int& wl) {
+      const int64_t t = first + lane < T1 ? first + lane : T1 - 1;   // (clamped: entries at or past T1 are never handed out)
+      w0 = offsets[t];
+      w1 = vlen ? 0 : offsets[t + 1];
+      wl = vlen ? vlen[t] : 0;
+    };
+    int64_t win0, win1;
+    int winl;
+    load_window(T0, win0, win1, winl);
+    __builtin_amdgcn_wave_barrier();
+    describe(active ? my_text : -1, win0, vlen ? winl : (int)(win1 - win0), 0, my_len, mis, flen);
+    load_window(next, win0, win1, winl);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    uint32_t q4 = 0;
+    int start = 0, cnt = 0, wtotal = 0;
+    int wrec = 0;
+    bool done = false;
+    int res_s = -1, res_e = -1;
+    EvRec* wave_recs = MODE == ST_RECORDS ? recs + rec_region_dyn(offsets[T0], task) : nullptr;
+    uint4 v[NL];
+#define MRX_DYN_LOAD(CB)                                                                  \
+    do {                                                                                  \
+      _Pragma("unroll") for (int j_ = 0; j_ < NL; ++j_) {                                  \
+        const uint4 rs_ = *(const uint4*)(tile + (RPI * j_ + rsub) * kRowPitch + CH);      \
+        uint32_t fo_ = (uint32_t)(CB) + seg * 16;                                          \
+        if (fo_ >= rs_.z) fo_ = rs_.w;   /* outside the row's frame: its first block */    \
+        v[j_] = MRX_LDG((const uint4*)((const uint8_t*)(((uint64_t)rs_.y << 32) | rs_.x) + fo_)); \
+      }                                                                                    \
+    } while (0)
+    MRX_DYN_LOAD(0);
+    uint8_t* wr = tile + rsub * kRowPitch + seg * 16;
+    for (int cbase = 0;; cbase += CH) {
+#pragma unroll
+      for (int j = 0; j < NL; ++j) *(uint4*)(wr + j * RPI * kRowPitch) = v[j];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      // lanes that are through with their text once this chunk is done take their next one now
+      const bool fin = active && (flen <= cbase + CH || (MODE == ST_SEARCH && done));
+      const uint64_t fm = __ballot(fin);
+      int64_t n_text = -1;
+      int n_len = 0, n_mis = 0, n_flen = 0;
+      if (fm) {   // wave uniform
+        const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0));
+        const int64_t c0 = __shfl(win0, rank), c1 = __shfl(win1, rank);   // (all lanes take part in the cross-lane reads)
+        const int cl = __shfl(winl, rank);
+        if (fin) {
+          const int64_t cand = next + rank;
+          n_text = cand < T1 ? cand : -1;
+          describe(n_text, c0, vlen ? cl : (int)(c1 - c0), cbase + CH, n_len, n_mis, n_flen);
+        }
+        next += __builtin_popcountll(fm);
+        load_window(next, win0, win1, winl);   // in flight while this chunk is walked
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+      const bool any_next = __any((active && !fin) || n_text >= 0);
+      if (any_next) MRX_DYN_LOAD(cbase + CH);   // next chunk, in flight while this one is walked
+
+      const int lim = active ? flen - cbase : 0;   // frame bytes [lo, lim) of this chunk are my text
+      const int lo = active ? mis - cbase : 0;
+      const bool all_inside = __all(lim >= CH && lo <= 0);
+      uint32_t F_even = 0, meta_even = 0, sp_even = 0;
+      // (count: the groups are independent but for two registers, and fully unrolled the compiler interleaves
+      // all eight -- 180-256 VGPRs; two at a time keeps it at the other modes' size)
+      constexpr int kUnroll = MODE == ST_COUNT ? 2 : CH / 16;
+#pragma unroll kUnroll
+      for (int g = 0; g < CH / 16; ++g) {
+        const uint4 wv = *(const uint4*)(tile + lane * kRowPitch + g * 16);
+        uint32_t words[4] = {wv.x, wv.y, wv.z, wv.w};
+        if (!all_inside) {   // wave uniform
+          const int a = min(max(lo - g * 16, 0), 16), b = min(max(lim - g * 16, 0), 16);   // inside: [a, b)
+          const uint4 pa = pmask[a], pb = pmask[b > a ? b : a];
+          const uint32_t m[4] = {pb.x & ~pa.x, pb.y & ~pa.y, pb.z & ~pa.z, pb.w & ~pa.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) words[j] = (words[j] & m[j]) | (fillw & ~m[j]);
+        }
+        uint32_t F = 0;
+        if (AUTO == 4) {
+          uint32_t cc[16], pi[8];
+#pragma unroll
+          for (int k = 0; k < 16; ++k) cc[k] = cls_lds[(words[k >> 2] >> ((k & 3) * 8)) & 0xFFu];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) pi[k] = (cc[2 * k] << p.st_cshift) | cc[2 * k + 1];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const uint32_t e = pair_lds[q4 + pi[k]];
+            q4 = e >> 4;
+            F = __builtin_amdgcn_alignbit(e, F, 4);
+          }
+        } else if (AUTO == 2) {
+          uint32_t cc[16];
+#pragma unroll
+          for (int k = 0; k < 16; ++k) cc[k] = cls_lds[(words[k >> 2] >> ((k & 3) * 8)) & 0xFFu];
+#pragma unroll
+          for (int k = 0; k < 16; ++k) {
+            const uint32_t e = tr_lds[q4 + cc[k]];
+            q4 = e >> 2;
+            F = __builtin_amdgcn_alignbit(e, F, 2);
+          }
+        } else if (AUTO == 3) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            uint64_t cw[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) cw[k] = col64_lds[(words[(8 * h + k) >> 2] >> ((k & 3) * 8)) & 0xFFu];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              const uint32_t e = (uint32_t)(cw[k] >> q4);
+              q4 = e & 0x38u;
+              F = __builtin_amdgcn_alignbit(e, F, 2);
+            }
+          }
+        } else {
+          uint32_t cv[16];
+#pragma unroll
+          for (int k = 0; k < 16; ++k) cv[k] = col_lds[(words[k >> 2] >> ((k & 3) * 8)) & 0xFFu];
+#pragma unroll
+          for (int k = 0; k < 16; ++k) {
+            const uint32_t e = cv[k] >> q4;
+            q4 = e & 0xCu;
+            F = __builtin_amdgcn_alignbit(e, F, 2);
+          }
+        }
+        const uint32_t em = F & 0xAAAAAAAAu;
+        const uint32_t ns = F & 0x55555555u;
+        const int gbase = cbase + g * 16 - mis;   // text position of the group's first byte
+        const uint32_t tix = (uint32_t)(my_text - T0) << kDynShift;
+        if (MODE == ST_RECORDS && REC32) {
+          if ((g & 1) == 0) {
+            F_even = F;
+            sp_even = (uint32_t)start | ((uint32_t)(gbase + 16) << 16);
+            meta_even = tix | ((uint32_t)cnt & kDynBeforeMask);
+          } else {
+            const bool any = ((F_even | F) & 0xAAAAAAAAu) != 0u;
+            const uint64_t has = __ballot(any);
+            if (has) {
+              if (any) {
+                const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(has >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)has, 0));
+                *(uint4*)(wave_recs + wrec + rank) = make_uint4(F_even, F, sp_even, meta_even);
+              }
+              wrec += __builtin_popcountll(has);
+            }
+          }
+        } else if (MODE == ST_RECORDS) {
+          const uint64_t has = __ballot(em != 0);
+          if (has) {
+            if (em) {
+              const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(has >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)has, 0));
+              *(uint4*)(wave_recs + wrec + rank) = make_uint4(F, (uint32_t)start, (uint32_t)gbase, tix | ((uint32_t)cnt & kDynBeforeMask));
+            }
+            wrec += __builtin_popcountll(has);
+          }
+        }
+        if (MODE == ST_SEARCH) {
+          if (!done && em) {
+            const int kk = __builtin_ctz(em) >> 1;
+            const uint32_t nsb = ns & ((1u << (2 * kk)) - 1u);
+            res_s = nsb ? gbase + ((31 - __builtin_clz(nsb)) >> 1) : start;
+            res_e = gbase + kk;
+            if (p.st_fixed_len > 0) res_s = res_e - p.st_fixed_len;
+            done = true;
+          }
+        }
+        cnt += __builtin_popcount(em);
+        if (ns) start = gbase + ((31 - __builtin_clz(ns)) >> 1);
+      }
+      __builtin_amdgcn_wave_barrier();
+      // let go of finished texts: a walk still in an accepting state ends at the end of its text (only when
+      // the text ended exactly on the chunk boundary -- otherwise the reset byte behind it has emitted it)
+      {
+        const bool tail = fin && accepting(q4) && !(MODE == ST_SEARCH && done);
+        if (MODE == ST_RECORDS) {
+          const uint64_t has = __ballot(tail);
+          if (has) {
+            if (tail) {
+              const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(has >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)has, 0));
+              const uint32_t meta = ((uint32_t)(my_text - T0) << kDynShift) | ((uint32_t)cnt & kDynBeforeMask);
+              if (REC32) *(uint4*)(wave_recs + wrec + rank) = make_uint4(2u, 0u, (uint32_t)start | ((uint32_t)(my_len + 16) << 16), meta);
+              else *(uint4*)(wave_recs + wrec + rank) = make_uint4(2u, (uint32_t)start, (uint32_t)my_len, meta);
+            }
+            wrec += __builtin_popcountll(has);
+          }
+        }
+        if (fin) {
+          if (tail) ++cnt;
+          if (MODE == ST_SEARCH) {
+            if (!done && tail) { res_s = p.st_fixed_len > 0 ? my_len - p.st_fixed_len : start; res_e = my_len; }
+            out_s[my_text] = res_s;
+            out_e[my_text] = res_e;
+          } else {
+            counts[my_text] = cnt;
+            wtotal += cnt;
+          }
+          my_text = n_text; active = n_text >= 0;
+          my_len = n_len; mis = n_mis; flen = active ? n_flen : 0;
+          q4 = 0; start = 0; cnt = 0; done = false; res_s = -1; res_e = -1;
+        }
+      }
+      if (!any_next) break;
+    }
+#undef MRX_DYN_LOAD
+    if (MODE == ST_RECORDS) {
+      for (int off = 32; off > 0; off >>= 1) wtotal += __shfl_xor(wtotal, off);
+      if (lane == 0) { wave_nrecs[task] = wrec; wave_nrecs[ntasks + task] = wtotal; }
+    }
+  }
+}
+
 // ST_FUSED set-up, one small launch in front of the scan: zero the ticket word, the error word and the
 // descriptors, and place the scan's arguments in device memory.
 __global__ __launch_bounds__(kBlock) void k_fused_init(unsigned long long* __restrict__ ctrl, int64_t words,
@@ -1847,7 +2157,9 @@ constexpr int kScanTile = kScanBlock * kScanItems;
 // VBASE: pieces of long texts (see k_stream_findall VIRT): positions are piece-relative in the records
 // and become text-relative by adding vbase[piece]; `prefix` is then per piece (k_virt_prefix picks
 // the texts' entries).
-template <bool PACK16, bool VBASE = false, bool REC32 = false>
+// DYN: the records of k_stream_dyn -- a stream per task of kDynTexts texts, records name their text by its
+// index in the task (meta >> 24) and count its matches so far in 24 bits.
+template <bool PACK16, bool VBASE = false, bool REC32 = false, bool DYN = false>
 __global__ __launch_bounds__(kBlock) void k_decode(int64_t n, const int32_t* __restrict__ wave_nrecs,
                                                    const EvRec* __restrict__ recs, int64_t rec_row,
                                                    const int64_t* __restrict__ offsets,
@@ -1859,15 +2171,21 @@ __global__ __launch_bounds__(kBlock) void k_decode(int64_t n, const int32_t* __r
                                                    int fixed_len, int64_t* __restrict__ total_out,
                                                    const int32_t* __restrict__ vbase = nullptr) {
   static_assert(!(PACK16 && VBASE), "text-relative positions of a long text do not fit 16 bits");
+  static_assert(!(DYN && VBASE), "pieces are not handed out dynamically");
   using Slot = typename std::conditional<PACK16, uint32_t, int2>::type;
   __shared__ Slot tile_all[kBlock / 64][kDecodeTile];
+  __shared__ int rel_all[DYN ? kBlock / 64 : 1][DYN ? kDynTexts : 1];   // DYN: spans of the task's texts before each text
+  constexpr int kTexts = DYN ? kDynTexts : 64;
+  constexpr uint32_t kBefore = DYN ? kDynBeforeMask : kRecBeforeMask;
+  constexpr int kTextShift = DYN ? kDynShift : 26;
   const int lane = threadIdx.x & 63;
   Slot* tile = tile_all[threadIdx.x >> 6];
-  const int64_t nw = (n + 63) >> 6;
+  int* rel_lds = rel_all[DYN ? (threadIdx.x >> 6) : 0];
+  const int64_t nw = (n + kTexts - 1) / kTexts;
   const int waves_per_block = blockDim.x >> 6;
   for (int64_t w = (int64_t)blockIdx.x * waves_per_block + (threadIdx.x >> 6); w < nw;
        w += (int64_t)gridDim.x * waves_per_block) {
-    const int64_t first = w << 6;
+    const int64_t first = w * kTexts;
     const int64_t i = first + lane;
     // CSR offsets of my 64 texts: exclusive scan of their counts on top of the wavefront's base
     // wave_base is exclusive within its k_scan_local tile of kScanTile wavefronts; the tiles before
@@ -1880,6 +2198,29 @@ __global__ __launch_bounds__(kBlock) void k_decode(int64_t n, const int32_t* __r
       for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
       pre0 += part;
     }
+    int my_rel = 0, total_spans = 0;
+    if (DYN) {
+      __builtin_amdgcn_wave_barrier();
+      int carry = 0;
+      for (int sb = 0; sb < kDynTexts; sb += 64) {
+        const int64_t t = first + sb + lane;
+        const int c = t < n ? counts[t] : 0;
+        int incl = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const int v = __shfl_up(incl, d);
+          if (lane >= d) incl += v;
+        }
+        rel_lds[sb + lane] = carry + incl - c;
+        if (t < n) prefix[t] = pre0 + carry + incl - c;
+        if (t == n - 1) { prefix[n] = pre0 + carry + incl; *total_out = pre0 + carry + incl; }
+        carry += __shfl(incl, 63);
+      }
+      total_spans = carry;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
     const int my_cnt = i < n ? counts[i] : 0;
     int incl = my_cnt;
 #pragma unroll
@@ -1887,12 +2228,14 @@ __global__ __launch_bounds__(kBlock) void k_decode(int64_t n, const int32_t* __r
       const int v = __shfl_up(incl, d);
       if (lane >= d) incl += v;
     }
-    const int my_rel = incl - my_cnt;   // start of my text's spans in the wavefront's range
-    const int total_spans = __shfl(incl, 63);
+    my_rel = incl - my_cnt;   // start of my text's spans in the wavefront's range
+    total_spans = __shfl(incl, 63);
     if (i < n) prefix[i] = pre0 + my_rel;
     if (i == n - 1) { prefix[n] = pre0 + incl; *total_out = pre0 + incl; }
+    }
     const int total_recs = wave_nrecs[w];
-    const EvRec* wave_recs = recs + (offsets ? rec_region_start(offsets[first], w) : first * rec_row);
+    const EvRec* wave_recs = recs + (DYN ? rec_region_dyn(offsets[first], w)
+                                         : offsets ? rec_region_start(offsets[first], w) : first * rec_row);
     const int my_vb = (VBASE && i < n) ? vbase[i] : 0;
     if (total_spans > kDecodeDirect) {
       // dense matches: the tile passes would re-read the stream total_spans / kDecodeTile
@@ -1912,9 +2255,9 @@ __global__ __launch_bounds__(kBlock) void k_decode(int64_t n, const int32_t* __r
 #pragma unroll
         for (int u = 0; u < kDecodeBatch; ++u) {
           EvRec r = rr[u];
-          const int rel_t = __shfl(my_rel, (int)(r.meta >> 26));
+          const int rel_t = DYN ? rel_lds[r.meta >> kTextShift] : __shfl(my_rel, (int)(r.meta >> 26));
           if (VBASE) { const int vb = __shfl(my_vb, (int)(r.meta >> 26)); r.start += vb; r.pos_base += vb; }
-          int64_t dst = pre0 + rel_t + (int)(r.meta & kRecBeforeMask);
+          int64_t dst = pre0 + rel_t + (int)(r.meta & kBefore);
           uint32_t Fw = r.F;
           int pb = REC32 ? (int)((uint32_t)r.pos_base >> 16) - 16 : r.pos_base;
           int rstart = REC32 ? (int)((uint32_t)r.pos_base & 0xFFFFu) : r.start;
@@ -1957,9 +2300,9 @@ __global__ __launch_bounds__(kBlock) void k_decode(int64_t n, const int32_t* __r
 #pragma unroll
         for (int u = 0; u < kDecodeBatch; ++u) {
           EvRec r = rr[u];
-          const int rel_t = __shfl(my_rel, (int)(r.meta >> 26));
+          const int rel_t = DYN ? rel_lds[r.meta >> kTextShift] : __shfl(my_rel, (int)(r.meta >> 26));
           if (VBASE) { const int vb = __shfl(my_vb, (int)(r.meta >> 26)); r.start += vb; r.pos_base += vb; }
-          int dst = rel_t + (int)(r.meta & kRecBeforeMask) - tb;
+          int dst = rel_t + (int)(r.meta & kBefore) - tb;
           // REC32: {F even, F odd, start | (pos + 16) << 16, meta} -- two event words per record
           uint32_t Fw = r.F;
           int pb = REC32 ? (int)((uint32_t)r.pos_base >> 16) - 16 : r.pos_base;
@@ -3053,6 +3396,44 @@ void launch_stream(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d
 #undef MRX_LAUNCH_R
 }
 
+// Ragged CSR batches on k_stream_dyn (texts handed to lanes as they fall free): plans with a reset byte, and
+// batches whose 256-text tasks fill at least three quarters of the device's wavefront slots (16 per CU) --
+// the lanes are busy 71 % of the time instead of 51 % (lengths U[64, 1024]), which only pays while there
+// are enough tasks; below that the 64-text wavefronts of k_stream_findall keep more of the device busy.
+// mrx_debug_dynamic_texts(): 1 always, 2 never.
+std::atomic<int> g_dyn_mode{0};
+bool dyn_ok(const mrx_handle* h, const Layout& lay, int64_t n) {
+  const DevPlan& p = h->hp.dev;
+  if (g_dyn_mode == 2 || !lay.offsets || p.st_reset_byte < 0 || n <= 0) return false;
+  return g_dyn_mode == 1 || n >= (int64_t)kDynTexts * (grid_cap() / 8) * 16 * 3 / 4;
+}
+template <int MODE>
+void launch_stream_dyn(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d_counts, int32_t* d_nrecs, EvRec* d_recs,
+                       int32_t* d_s, int32_t* d_e, hipStream_t s, bool rec32) {
+  const DevPlan& p = h->hp.dev;
+  const int64_t ntasks = (n + kDynTexts - 1) / kDynTexts;
+  int64_t g = (ntasks + kStreamWaves - 1) / kStreamWaves;
+  if (g > grid_cap()) g = grid_cap();
+  const dim3 grid((unsigned)g), block(64 * kStreamWaves);
+  const bool table = p.st_kind == 2, wide = p.st_kind == 3;
+  const bool pairs = (table || wide) && p.off_stg_pair >= 0 && g_pair_tables;
+  const size_t lds = pairs ? (size_t)p.stg_bytes : wide ? 2048 : !table ? 0 : (size_t)p.stg_bytes;
+#define MRX_DYN_R(AUTO, R32)                                                                          \
+  hipLaunchKernelGGL((k_stream_dyn<MODE, AUTO, R32>), grid, block, lds, s, p, H_BLOB(h), lay.data, lay.offsets, lay.vlen, n, \
+                     d_counts, d_nrecs, d_recs, d_s, d_e)
+#define MRX_DYN(AUTO)                                                                                  \
+  do {                                                                                                 \
+    if constexpr (MODE == ST_RECORDS) { if (rec32) MRX_DYN_R(AUTO, 1); else MRX_DYN_R(AUTO, 0); }      \
+    else MRX_DYN_R(AUTO, 0);                                                                           \
+  } while (0)
+  if (pairs) MRX_DYN(4);
+  else if (table) MRX_DYN(2);
+  else if (wide) MRX_DYN(3);
+  else MRX_DYN(1);
+#undef MRX_DYN
+#undef MRX_DYN_R
+}
+
 // Long texts on the streaming kernels: cut into pieces at synchronising bytes when one lane per text
 // would leave most of the device idle.
 struct Pieces {
@@ -3267,6 +3648,7 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
                  (match_next_sequence ? ((p.flags & PF_STEP_SEARCH) && !(p.flags & PF_PREFILTER))
                                       : (p.flags & (PF_STEPPABLE | PF_STEP_REQ)) != 0);
   bool fused = false;      // streaming path: scan, CSR offsets and spans in one launch (ST_FUSED)
+  bool dyn = false;        // streaming path: ragged CSR batch on k_stream_dyn (256-text tasks)
   unsigned long long* d_ctrl = nullptr;   // its ticket word, error word and descriptors
   int32_t* d_blimit = nullptr;            // bitset NFA: per-text limits of the first pass
   bool rec32 = false;      // streaming path: one record per two groups (positions fit 16 bits)
@@ -3311,6 +3693,7 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
       }
       max_text = lay.offsets ? csr_max : (lay.lens ? lay.stride : (int64_t)lay.len);
       rec32 = max_text <= kRec32MaxLen;
+      dyn = dyn_ok(h, lay, n) && max_text < (int64_t(1) << kDynShift);
       // One launch (ST_FUSED) when a record region per resident wavefront -- sized for the most one
       // 64-text task can produce -- stays within twice the record stream of the three-launch form
       // (ragged batches whose longest text is far above the average do not: they are cut into pieces
@@ -3320,7 +3703,7 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
       if (fz_grid > fused_grid_cap()) fz_grid = fused_grid_cap();
       const size_t fz_nrec = (size_t)(64 * fz_per_text + 64) * (size_t)(fz_grid * kStreamWaves) * 2;   // two regions per wavefront
       const int64_t batch_bytes = lay.offsets ? csr_total : n * (lay.lens ? lay.stride : (int64_t)lay.len);
-      fused = g_fused && span_cap > 0 && fz_nrec <= 2 * nrec + (size_t(8) << 20) && (g_fused == 2 || batch_bytes >= nw * kFusedMinTaskBytes);
+      fused = !dyn && g_fused && span_cap > 0 && fz_nrec <= 2 * nrec + (size_t(8) << 20) && (g_fused == 2 || batch_bytes >= nw * kFusedMinTaskBytes);
       if (fused) {
         // ticket | error | one descriptor per task | two words per group of 64 tasks; a 16-byte multiple
         const size_t ctrl_words = (size_t)((2 + nw + 2 * ((nw + 63) / 64) + 1) & ~int64_t(1));
@@ -3338,6 +3721,16 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
         launch_stream<ST_FUSED>(h, lay, n, nullptr, nullptr, d_recs, 0, nullptr, nullptr, s, nullptr, nullptr, rec32, d_fz,
                                 (int)fz_grid);
         g_last_kernel = "k_stream_findall_fused";
+        HIP_TRY(hipGetLastError());
+        tm.stop();
+      } else if (dyn) {
+        const int64_t nt = (n + kDynTexts - 1) / kDynTexts;
+        HIP_TRY(scratch_alloc((void**)&d_recs, sizeof(EvRec) * (size_t)(csr_total / 16 + 4 * kDynTexts * (nt + 1)), s));
+        HIP_TRY(scratch_alloc((void**)&d_nrecs, sizeof(int32_t) * 2 * nt, s));   // records | matches per task
+        HIP_TRY(scratch_alloc((void**)&d_wbase, sizeof(int64_t) * (nt + 1), s));
+        ScanTimer tm(s);
+        launch_stream_dyn<ST_RECORDS>(h, lay, n, d_counts, d_nrecs, d_recs, nullptr, nullptr, s, rec32);
+        g_last_kernel = "k_stream_findall_dyn";
         HIP_TRY(hipGetLastError());
         tm.stop();
       } else {
@@ -3418,7 +3811,7 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
   } else if (stream_ok) {
     // prefix sums over the wavefronts' totals only (n/64 values); k_decode derives the per-text
     // offsets from its 64 counts and writes them along with the spans
-    const int64_t nw = (n + 63) / 64;
+    const int64_t nw = dyn ? (n + kDynTexts - 1) / kDynTexts : (n + 63) / 64;
     // one launch: tile-local exclusive sums of the wavefront totals + one sum per tile
     const int64_t ntiles = (nw + kScanTile - 1) / kScanTile;
     int64_t* d_tsum = nullptr;
@@ -3426,6 +3819,18 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
     hipLaunchKernelGGL(k_scan_local<int32_t>, dim3((unsigned)ntiles), dim3(kScanBlock), 0, s, d_nrecs + nw, nw,
                        d_wbase, d_tsum);
     const bool pack16 = max_text <= 65535;
+    if (dyn) {
+      const dim3 dg((unsigned)grid_for(nw * 64, kBlock) * 2), db(kBlock);
+      if (pack16 && rec32)
+        hipLaunchKernelGGL((k_decode<true, false, true, true>), dg, db, 0, s, n, d_nrecs, d_recs, rec_row, lay.offsets, d_counts,
+                           d_wbase, d_tsum, d_prefix, d_spans, span_cap, p.st_fixed_len, d_total);
+      else if (pack16)
+        hipLaunchKernelGGL((k_decode<true, false, false, true>), dg, db, 0, s, n, d_nrecs, d_recs, rec_row, lay.offsets, d_counts,
+                           d_wbase, d_tsum, d_prefix, d_spans, span_cap, p.st_fixed_len, d_total);
+      else
+        hipLaunchKernelGGL((k_decode<false, false, false, true>), dg, db, 0, s, n, d_nrecs, d_recs, rec_row, lay.offsets, d_counts,
+                           d_wbase, d_tsum, d_prefix, d_spans, span_cap, p.st_fixed_len, d_total);
+    } else
     if (pack16 && rec32)
       hipLaunchKernelGGL((k_decode<true, false, true>), dim3(grid_for(n, kBlock) * 2), dim3(kBlock), 0, s, n, d_nrecs, d_recs,
                          rec_row, lay.offsets, d_counts, d_wbase, d_tsum, d_prefix, d_spans, span_cap, p.st_fixed_len,
@@ -3729,6 +4134,13 @@ static int run_search_any(const mrx_handle* h, const Layout& lay, int64_t n, int
     return pieces_release(&pc, s);
   }
   ScanTimer tm(s);
+  if (dyn_ok(h, lay, n)) {
+    launch_stream_dyn<ST_SEARCH>(h, lay, n, nullptr, nullptr, nullptr, ds, de, s, false);
+    g_last_kernel = "k_stream_search_dyn";
+    HIP_TRY(hipGetLastError());
+    tm.stop();
+    return MRX_OK;
+  }
   launch_stream<ST_SEARCH>(h, lay, n, nullptr, nullptr, nullptr, 0, ds, de, s, lay.vlen, lay.vskip);
   g_last_kernel = "k_stream_search";
   HIP_TRY(hipGetLastError());
@@ -4010,6 +4422,9 @@ static int run_count_any(const mrx_handle* h, const Layout& lay, int64_t n, int3
       HIP_TRY(scratch_free(d_vcounts, s));
       if (int rc = pieces_release(&pc, s)) return rc;
       g_last_kernel = "k_stream_count_pieces";
+    } else if (dyn_ok(h, lay, n)) {
+      launch_stream_dyn<ST_COUNT>(h, lay, n, counts, nullptr, nullptr, nullptr, nullptr, s, false);
+      g_last_kernel = "k_stream_count_dyn";
     } else {
     launch_stream<ST_COUNT>(h, lay, n, counts, nullptr, nullptr, 0, nullptr, nullptr, s);
     g_last_kernel = "k_stream_count";
@@ -4242,6 +4657,7 @@ const char* mrx_last_kernel_name(void) { return g_last_kernel; }
 void mrx_debug_force_generic(int on) { g_force_generic = on < 0 ? 0 : on > 2 ? 2 : on; }
 void mrx_debug_long_text_kernels(int mode) { g_long_text_mode = mode < 0 ? 0 : mode > 2 ? 0 : mode; }
 void mrx_debug_fused_findall(int mode) { g_fused = mode < 0 ? 0 : mode > 2 ? 0 : mode; }
+void mrx_debug_dynamic_texts(int mode) { g_dyn_mode = mode < 0 ? 0 : mode > 2 ? 0 : mode; }
 void mrx_release_scratch(void) { scratch_release_all(); }
 size_t mrx_debug_scratch_bytes(void) { return scratch_bytes_reserved(); }
 

@@ -1670,3 +1670,71 @@ def test_backtracker_routed_operations_match_oracle(pat):
             assert (int(ss[i]), int(se[i])) == (w if w else (-1, -1)), (pat, "search", t)
             assert lists[i] == O.findall(pat, t), (pat, "findall", t)
             assert subs[i] == O.sub(pat, b"<>", t), (pat, "sub", t)
+
+
+@contextlib.contextmanager
+def dynamic_texts(mode):
+    """1 = ragged batches always on k_stream_dyn (texts handed to lanes as they fall free), 2 = never."""
+    lib = M.load_library()
+    lib.mrx_debug_dynamic_texts(mode)
+    try:
+        yield
+    finally:
+        lib.mrx_debug_dynamic_texts(0)
+
+
+@pytest.mark.parametrize("pat", [b"[a-z]+\\d+", b"\\d+", b"hello", b"(\\d{3})(\\d{3})(\\d{4})", b"(x|y|foo|bar)+", b"a", b"abab",
+                                 b"[a-c]+[0-9]+[x-z]+[0-9]+", b"[a-z]+", b"(cat|dog)+"])
+@pytest.mark.parametrize("lens_kind", ["uniform_ragged", "short", "with_long", "chunk_multiples"])
+def test_dynamic_text_assignment_equals_static(pat, lens_kind):
+    """k_stream_dyn (a lane takes the wavefront's next text when its own ends; records carry the text's
+    index in a 256-text task) against k_stream_findall's one-text-per-lane form on the same ragged CSR
+    batches: findall (offsets and spans), count and search identical; oracle on a sample.  Lengths cover
+    empty texts, texts that end exactly on a 128-byte chunk boundary, texts of several chunks among
+    short ones, a partial last task and fewer than 64 texts."""
+    _need_gpu()
+    lib = M.load_library()
+    rx = M.compile_regex(pat)
+    d = rx.describe()
+    assert "device.streamable=yes" in d
+    if "reset_byte=-1" in d:
+        pytest.skip("no reset byte: the plan keeps the static form")
+    rng = np.random.default_rng(zlib.crc32(pat) + len(lens_kind))
+    al = np.frombuffer(b"abcxyz0189 -fobarhelcatdg5" + bytes(c for c in pat if chr(c).isalnum()) * 2, dtype=np.uint8)
+    for n in (40, 256 * 3 + 17, 5000):
+        if lens_kind == "uniform_ragged":
+            lens = rng.integers(0, 600, size=n)
+        elif lens_kind == "short":
+            lens = rng.integers(0, 40, size=n)
+        elif lens_kind == "with_long":
+            lens = rng.integers(0, 200, size=n)
+            lens[rng.integers(0, n, size=max(1, n // 50))] = rng.integers(1500, 6000, size=max(1, n // 50))
+        else:
+            lens = rng.choice([0, 16, 112, 128, 129, 256, 384, 127, 1], size=n)
+        lens[:: 9] = 0
+        texts = []
+        for L in lens:
+            t = rng.choice(al, size=int(L)).astype(np.uint8)
+            if L > 3 and rng.random() < 0.3:
+                t[-3:] = np.frombuffer(b"a12"[: 3], dtype=np.uint8)    # a match that runs to the end of the text
+            texts.append(t.tobytes())
+        batch = M.DeviceBatch.from_texts(texts)
+        with long_text_kernels(2):
+            with dynamic_texts(1):
+                p1, s1, t1 = rx._dev_findall(batch)
+                assert lib.mrx_last_kernel_name() == b"k_stream_findall_dyn"
+                c1 = rx.count(batch)
+                assert lib.mrx_last_kernel_name() == b"k_stream_count_dyn"
+                a1, b1 = rx.match_next(batch)
+                assert lib.mrx_last_kernel_name() == b"k_stream_search_dyn"
+            with dynamic_texts(2):
+                p2, s2, t2 = rx._dev_findall(batch)
+                assert lib.mrx_last_kernel_name() == b"k_stream_findall"
+                c2 = rx.count(batch)
+                a2, b2 = rx.match_next(batch)
+        assert t1 == t2 and torch.equal(p1, p2) and torch.equal(s1[:t1], s2[:t2]), (pat, lens_kind, n)
+        assert torch.equal(c1, c2) and torch.equal(a1, a2) and torch.equal(b1, b2), (pat, lens_kind, n)
+        pre, sp = p1.cpu().numpy(), s1.cpu().numpy()
+        for i in range(0, n, max(1, n // 40)):
+            have = [tuple(int(x) for x in r) for r in sp[pre[i]:pre[i + 1]]]
+            assert have == O.findall(pat, texts[i]), (pat, lens_kind, n, i)

@@ -26,6 +26,8 @@ def timeit(fn, reps=10):
 
 def main():
     lib = M.load_library()
+    if os.environ.get("MRX_DYN_MODE"):
+        lib.mrx_debug_dynamic_texts(int(os.environ["MRX_DYN_MODE"]))   # 1 always k_stream_dyn, 2 never
     lo = int(sys.argv[1]) if len(sys.argv) > 1 else 64
     d = W.make_c2_batch(1 << 20, 1024)
     data, offsets = W.to_ragged(d, lo)
