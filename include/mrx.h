@@ -172,7 +172,8 @@ int mrx_count_strided_dev(const mrx_handle* h, const uint8_t* d_data, int64_t st
 /* search + capture groups, in the order NFAEngine._match_group appends them
  * (src/regex/nfa.mojo:1057-1103): groups 1..g, then group 0 (whole match).
  * d_spans[(i*(g+1) + k)*2 + {0,1}]; -1 when text i has no match.
- * Only the fixed-width (\d{N}) group form is on the hot path. */
+ * Fixed-width (\d{N}) groups run on the streaming kernel; other group structures on the flat-program
+ * backtracker (no alternation, no quantified groups -- refused with that reason otherwise). */
 int mrx_captures_dev(const mrx_handle* h, const uint8_t* d_data,
                      const int64_t* d_offsets, int64_t n, int32_t* d_spans,
                      void* stream);
@@ -181,7 +182,8 @@ int mrx_captures_strided_dev(const mrx_handle* h, const uint8_t* d_data, int64_t
                              void* stream);
 /* regex.sub(pattern, repl, text, count), matcher.mojo:1679-1854.
  * d_out_offsets[n+1] (CSR of output bytes), d_out_data (capacity out_cap bytes).
- * Synchronises once to return *total_bytes; MRX_E_CAPACITY if it exceeds out_cap. */
+ * Waits for the sizes to return *total_bytes (MRX_E_CAPACITY if it exceeds out_cap); the output bytes
+ * themselves are written by work enqueued on `stream`, like the results of every other _dev call. */
 int mrx_sub_dev(const mrx_handle* h, const char* repl, size_t repl_len, int64_t count,
                 const uint8_t* d_data, const int64_t* d_offsets, int64_t n,
                 int64_t* d_out_offsets, uint8_t* d_out_data, int64_t out_cap,

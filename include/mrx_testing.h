@@ -37,6 +37,10 @@ void mrx_debug_fused_findall(int mode);
 /* Ragged (CSR) batches of streamable plans with a reset byte are scanned by k_stream_dyn -- 256-text tasks,
  * a lane takes the next text when its own ends -- from 16384 texts up; 1 = always, 2 = never, 0 = by size. */
 void mrx_debug_dynamic_texts(int mode);
+/* sub assembled from findall spans: lanes that share one text in k_subs_wave (16, 32 or 64; texts whose
+ * frame or output exceed the group's LDS tiles go to k_subs_emit); 0 = k_subs_emit for every text,
+ * anything else = chosen from the average text length. */
+void mrx_debug_subs_group(int lanes);
 /* Bytes of device memory the calling thread's scratch arenas hold (see mrx_release_scratch). */
 size_t mrx_debug_scratch_bytes(void);
 

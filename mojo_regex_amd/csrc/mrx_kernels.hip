@@ -2573,6 +2573,26 @@ struct WriteSink {
   }
 };
 
+// Inclusive scan over the G lanes of a group (16, 32 or 64: groups are aligned rows of 16 lanes) on the
+// DPP path: row_shr 1 / 2 / 4 / 8 inside a row, row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2
+// and 3 -- one VALU instruction per step where __shfl_up costs a ds_bpermute round trip and a select.
+template <int G, bool XOR>
+__device__ __forceinline__ int group_scan(int x) {
+#define MRX_DPP_STEP(CTRL, ROWS)                                                      \
+  do {                                                                                \
+    const int y = __builtin_amdgcn_update_dpp(0, x, CTRL, ROWS, 0xF, false);          \
+    x = XOR ? (x ^ y) : (x + y);                                                      \
+  } while (0)
+  MRX_DPP_STEP(0x111, 0xF);   // row_shr:1
+  MRX_DPP_STEP(0x112, 0xF);   // row_shr:2
+  MRX_DPP_STEP(0x114, 0xF);   // row_shr:4
+  MRX_DPP_STEP(0x118, 0xF);   // row_shr:8
+  if (G >= 32) MRX_DPP_STEP(0x142, 0xA);   // row_bcast:15 -> rows 1, 3
+  if (G >= 64) MRX_DPP_STEP(0x143, 0xC);   // row_bcast:31 -> rows 2, 3
+#undef MRX_DPP_STEP
+  return x;
+}
+
 // ---- sub() from findall spans (streamable plans) -----------------------------------------
 // For plans whose findall runs on the streaming kernel, regex.sub is assembled from the CSR spans:
 // the first `count` matches of a text (all when count == 0) are replaced, matches are never empty,
@@ -2583,8 +2603,11 @@ __global__ __launch_bounds__(kBlock) void k_subs_sizes(int64_t n, const int64_t*
                                                        const int64_t* __restrict__ prefix,
                                                        const int32_t* __restrict__ spans, long long count,
                                                        int R, int64_t* __restrict__ sizes,
-                                                       int32_t* __restrict__ cum) {
+                                                       int32_t* __restrict__ cum, int64_t span_cap,
+                                                       const int32_t* __restrict__ left) {
   // 16 lanes per text: coalesced span loads, prefix sum of the match lengths inside the group
+  if (prefix[n] > span_cap) return;   // the findall in front did not have room for its spans: the host retries
+  if (left && *left == 0) return;     // cum[] is wanted for the texts k_subs_wave left over: there are none
   constexpr int G = 16;
   const int lane = threadIdx.x & (G - 1);
   const int64_t ngroups = (int64_t)gridDim.x * (blockDim.x / G);
@@ -2609,7 +2632,53 @@ __global__ __launch_bounds__(kBlock) void k_subs_sizes(int64_t n, const int64_t*
       if (m < k) cum[a + m] = carry + incl - len;
       carry += __shfl(incl, G - 1, G);
     }
-    if (lane == 0) sizes[i] = (offsets[i + 1] - offsets[i]) - carry + k * (int64_t)R;
+    if (lane == 0 && sizes) sizes[i] = (offsets[i + 1] - offsets[i]) - carry + k * (int64_t)R;
+  }
+}
+
+// k_subs_sizes_flat (count == 0: every match is replaced): output length of every text without a dependent
+// round trip per text.  A wavefront owns 64 consecutive texts, whose spans are one contiguous range of the
+// CSR; it streams that range 256 spans at a time, keeps the running sum of the match lengths, and lane t
+// picks the sum's value at its text's first and one-past-last span as they pass (two cross-lane reads per
+// 64 spans).  cum[] -- matched bytes before each match, which only k_subs_emit reads -- is not written here.
+__global__ __launch_bounds__(kBlock) void k_subs_sizes_flat(int64_t n, const int64_t* __restrict__ offsets,
+                                                            const int64_t* __restrict__ prefix,
+                                                            const int32_t* __restrict__ spans, int R,
+                                                            int64_t* __restrict__ sizes, int64_t span_cap) {
+  if (prefix[n] > span_cap) return;   // as k_subs_sizes
+  const int lane = threadIdx.x & 63;
+  const int64_t nw = (n + 63) / 64;
+  for (int64_t w = (int64_t)blockIdx.x * (kBlock / 64) + threadIdx.x / 64; w < nw; w += (int64_t)gridDim.x * (kBlock / 64)) {
+    const int64_t i = w * 64 + lane;
+    const bool live = i < n;
+    const int64_t pa = live ? prefix[i] : 0, pb = live ? prefix[i + 1] : 0;
+    const int64_t tbytes = live ? offsets[i + 1] - offsets[i] : 0;
+    const int64_t i_last = (w * 64 + 64 < n ? w * 64 + 64 : n);
+    const int64_t A = __shfl(pa, 0), B = prefix[i_last];
+    int run = 0;                 // matched bytes of spans [A, c), modulo 2^32 (differences are what is used)
+    int at_a = 0, at_b = 0;      // the running sum in front of span pa / pb (both 0 while pa == A / pb == A)
+    for (int64_t c = A; c < B; c += 256) {
+      int len[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t m = c + 64 * j + lane;
+        int2 sp = make_int2(0, 0);
+        if (m < B) sp = *(const int2*)(spans + 2 * m);
+        len[j] = sp.y - sp.x;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t c0 = c + 64 * j;
+        const int incl = (int)((uint32_t)run + (uint32_t)group_scan<64, false>(len[j]));   // sum of spans [A, c0 + lane]
+        // the sum in front of span x, x in (c0, c0 + 64]: lane x - 1 - c0 holds it
+        const int64_t ja = pa - 1 - c0, jb = pb - 1 - c0;
+        const int va = __shfl(incl, (int)(ja & 63)), vb = __shfl(incl, (int)(jb & 63));
+        if (ja >= 0 && ja < 64) at_a = va;
+        if (jb >= 0 && jb < 64) at_b = vb;
+        run = __shfl(incl, 63);
+      }
+    }
+    if (live) sizes[i] = tbytes - (int64_t)((uint32_t)at_b - (uint32_t)at_a) + (pb - pa) * (int64_t)R;
   }
 }
 
@@ -2638,6 +2707,10 @@ __device__ __forceinline__ void load16(const uint8_t* base, int len, int src, ui
 // blocks = 4 KiB of output -- stages the window of replacements that can touch it (the last one
 // starting at or before the round's first byte, and the kSubsWindow - 1 after it).
 constexpr int kSubsWindow = 512;
+// texts k_subs_wave<G> takes (the rest is k_subs_emit's): frame and output fit the group's LDS tiles
+__host__ __device__ inline bool subs_wave_takes(int G, int tlen, int mis, int olen, int head) {
+  return tlen + mis <= 32 * G + 16 && olen + head <= 64 * G;
+}
 template <int G>
 __global__ __launch_bounds__(kBlock) void k_subs_emit(int64_t n, const uint8_t* __restrict__ data,
                                                       const int64_t* __restrict__ offsets,
@@ -2646,7 +2719,9 @@ __global__ __launch_bounds__(kBlock) void k_subs_emit(int64_t n, const uint8_t* 
                                                       const int32_t* __restrict__ cum, long long count,
                                                       int R, const uint16_t* __restrict__ rmap,
                                                       const int64_t* __restrict__ out_off,
-                                                      uint8_t* __restrict__ out) {
+                                                      uint8_t* __restrict__ out, int skip_g,
+                                                      const int32_t* __restrict__ left) {
+  if (skip_g && *left == 0) return;   // k_subs_wave<skip_g> took every text
   // kSubsLanes lanes share one text (4 texts per wavefront): a 1 KiB text has ~70 output blocks,
   // which 64 lanes cover in two half-empty rounds; 16 lanes cover them in five full ones, and the
   // four texts' dependent round trips (offsets -> spans -> bytes) overlap.
@@ -2680,6 +2755,8 @@ __global__ __launch_bounds__(kBlock) void k_subs_emit(int64_t n, const uint8_t* 
     const int64_t obase = out_off[i];
     const int olen = (int)(out_off[i + 1] - obase);
     if (olen <= 0) continue;
+    if (skip_g && subs_wave_takes(skip_g, tlen, (int)((uintptr_t)tptr & 15), olen, (int)((uintptr_t)(out + obase) & 15)))
+      continue;   // k_subs_wave<skip_g> wrote this text
     const int32_t* sp = spans + 2 * a;
     const int32_t* cm = cum + a;
     const bool staged = !WIN && k <= STAGE;
@@ -2774,6 +2851,199 @@ __global__ __launch_bounds__(kBlock) void k_subs_emit(int64_t n, const uint8_t* 
       }
     }
     group_sync();
+  }
+}
+
+// k_subs_wave<G>: G lanes (a wavefront, half or quarter of one) assemble one text's output in LDS without a
+// search and without a per-byte branch.  Text positions are kept in the frame of the 16-byte blocks that
+// hold the text (mis = address & 15), the output tile in the frame of the output address (head).
+//   matches, one lane each:  the start and end position of every replaced match set a bit in two LDS
+//     bitmaps; matched bytes before the match come from a prefix sum over the lanes' match lengths, so the
+//     replacement's R bytes go straight to  head + start - matched_before + m R  in the output tile;
+//   frame blocks, one lane each:  T = starts ^ ends of the block; "inside a match" at byte t is the parity
+//     of the T bits at or below t (matches are non-empty and do not overlap; an end that is the next
+//     match's start cancels), carried across lanes by a prefix sum that also gives the kept bytes and the
+//     match starts before the block, i.e. where the block's first kept byte goes; the 16 bytes are then
+//     placed with predicated byte writes;
+//   output blocks, one lane each:  16-byte stores (byte stores where a block is shared with a neighbour).
+// Texts whose frame or output exceeds the tiles (32 G + 16 / 64 G bytes) are left to k_subs_emit.
+template <int G>
+__global__ __launch_bounds__(kBlock) void k_subs_wave(int64_t n, const uint8_t* __restrict__ data,
+                                                      const int64_t* __restrict__ offsets,
+                                                      const int64_t* __restrict__ prefix,
+                                                      const int32_t* __restrict__ spans, long long count,
+                                                      int R, const uint16_t* __restrict__ rmap,
+                                                      const int64_t* __restrict__ out_off,
+                                                      uint8_t* __restrict__ out, int32_t* __restrict__ left, int dbg) {
+  constexpr int NG = kBlock / G, F = 32 * G + 16, O = 64 * G, BW = F / 32 + 1;
+  static_assert(G == 64 || G == 32 || G == 16, "group = wavefront, half or quarter");
+  __shared__ __align__(16) uint8_t text_all[NG][F];
+  __shared__ __align__(16) uint8_t out_all[NG][O];
+  __shared__ uint32_t sbits_all[NG][BW], ebits_all[NG][BW];
+  __shared__ uint32_t spare_all[kBlock];
+  extern __shared__ __align__(16) uint8_t subs_dyn[];   // the replacement map (R u16 entries)
+  uint16_t* rmap_lds = (uint16_t*)subs_dyn;
+  for (int r = threadIdx.x; r < R; r += blockDim.x) rmap_lds[r] = rmap[r];
+  __syncthreads();
+  auto group_sync = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  const int lane = threadIdx.x & (G - 1), grp = threadIdx.x / G;
+  uint8_t* text = text_all[grp];
+  uint8_t* otile = out_all[grp];
+  uint32_t* sbits = sbits_all[grp];
+  uint32_t* ebits = ebits_all[grp];
+  const int64_t ngroups = (int64_t)gridDim.x * NG;
+  // Two texts ahead: the descriptor (offsets, prefix, out_off: one round trip); one text ahead: its frame
+  // blocks and its first G spans, in registers -- the global round trips of text i + 1 run under the LDS
+  // phases of text i.
+  struct Desc { int64_t ibase, a, obase; int tlen, k, olen; };
+  auto load_desc = [&](int64_t i) {
+    Desc d{0, 0, 0, 0, 0, 0};
+    if (i < n) {
+      d.ibase = offsets[i];
+      d.tlen = (int)(offsets[i + 1] - d.ibase);
+      d.a = prefix[i];
+      int64_t k64 = prefix[i + 1] - d.a;
+      if (count > 0 && k64 > count) k64 = count;
+      d.k = (int)k64;
+      d.obase = out_off[i];
+      d.olen = (int)(out_off[i + 1] - d.obase);
+    }
+    return d;
+  };
+  uint4 tx[3];
+  int2 sp_first;
+  auto issue = [&](const Desc& d) {
+    const uint8_t* tptr = data + d.ibase;
+    const int mis = (int)((uintptr_t)tptr & 15);
+    const uint8_t* fptr = tptr - mis;
+    int nfb = d.olen > 0 ? (mis + d.tlen + 15) >> 4 : 0;
+    if (nfb > 2 * G + 1) nfb = 2 * G + 1;   // a longer text is not this kernel's
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int b = lane + r * G;
+      tx[r] = b < nfb ? MRX_LDG((const uint4*)(fptr + 16 * b)) : make_uint4(0, 0, 0, 0);
+    }
+    sp_first = (d.olen > 0 && lane < d.k) ? *(const int2*)(spans + 2 * (d.a + lane)) : make_int2(0, 0);
+  };
+  int64_t i = (int64_t)blockIdx.x * NG + grp;
+  Desc d0 = load_desc(i), d1 = load_desc(i + ngroups);
+  issue(d0);
+  for (; i < n; i += ngroups) {
+    const Desc d = d0;
+    d0 = d1;
+    d1 = load_desc(i + 2 * ngroups);
+    const uint8_t* tptr = data + d.ibase;
+    const int tlen = d.tlen, k = d.k, olen = d.olen;
+    const int64_t a = d.a, obase = d.obase;
+    const int mis = (int)((uintptr_t)tptr & 15), head = (int)((uintptr_t)(out + obase) & 15);
+    if (olen <= 0 || !subs_wave_takes(G, tlen, mis, olen, head)) {
+      if (olen > 0 && lane == 0) *left = 1;   // k_subs_emit, launched behind this kernel, looks
+      issue(d0);
+      continue;
+    }
+    const int nfb = (mis + tlen + 15) >> 4;
+    group_sync();   // the previous text's tiles are free
+    for (int w = lane; w < BW; w += G) { sbits[w] = 0; ebits[w] = 0; }
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+      if (lane + r * G < nfb) *(uint4*)(text + 16 * (lane + r * G)) = tx[r];
+    const int2 sp_cur = sp_first;
+    issue(d0);
+    group_sync();
+    // ---- matches: boundary bits, replacement bytes
+    int carry = 0;
+    for (int m0 = 0; m0 < k; m0 += G) {
+      const int m = m0 + lane;
+      int ms = 0, me = 0;
+      if (m < k) {
+        const int2 sp = m0 == 0 ? sp_cur : *(const int2*)(spans + 2 * (a + m));
+        ms = sp.x; me = sp.y;
+      }
+      const int len = me - ms;
+      const int incl = group_scan<G, false>(len);
+      const int before = carry + incl - len;
+      carry += __shfl(incl, G - 1, G);
+      if (m < k) {
+        if (!(dbg & 8)) {
+        atomicOr(&sbits[(mis + ms) >> 5], 1u << ((mis + ms) & 31));
+        atomicOr(&ebits[(mis + me) >> 5], 1u << ((mis + me) & 31));
+        }
+        uint8_t* dst = otile + (head + ms - before + m * R);
+        const uint8_t* msrc = text + mis + ms;
+        if (!(dbg & 2))
+        for (int t = 0; t < R; ++t) {
+          const uint32_t r = rmap_lds[t];
+          dst[t] = (r & 0x8000u) ? msrc[r & 0x7FFFu] : (uint8_t)r;
+        }
+      }
+    }
+    group_sync();
+    // ---- frame blocks: kept bytes
+    int kept_carry = 0, starts_carry = 0, inside_carry = 0;
+    if (!(dbg & 1))
+    for (int b0 = 0; b0 < nfb; b0 += G) {
+      const int b = b0 + lane;
+      uint32_t S = 0, T = 0, valid = 0;
+      uint4 bx = make_uint4(0, 0, 0, 0);
+      if (b < nfb) {
+        const int sh = (b & 1) * 16;
+        S = (sbits[b >> 1] >> sh) & 0xFFFFu;
+        T = S ^ ((ebits[b >> 1] >> sh) & 0xFFFFu);
+        const int lo = b == 0 ? mis : 0;
+        const int hi = mis + tlen - 16 * b < 16 ? mis + tlen - 16 * b : 16;
+        valid = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+        bx = *(const uint4*)(text + 16 * b);
+      }
+      uint32_t P = T;   // P bit t = parity of the T bits at or below t
+      P ^= P << 1; P ^= P << 2; P ^= P << 4; P ^= P << 8;
+      P &= 0xFFFFu;
+      const uint32_t keep0 = valid & ~P, keep1 = valid & P;   // kept bytes if the block begins outside / inside a match
+      // kept bytes | match starts << 12 | parity << 24, for both entry states the counts differ: scan the
+      // parity first (it decides which), then the counts
+      const int par = (int)(P >> 15);
+      const int pin = group_scan<G, true>(par);
+      const int inside = inside_carry ^ pin ^ par;   // state on entry to my block
+      inside_carry ^= __shfl(pin, G - 1, G);
+      const uint32_t keep = inside ? keep1 : keep0;
+      const int cnt = __popc(keep) | (__popc(S) << 12);
+      const int cin = group_scan<G, false>(cnt);
+      const int ex = cin - cnt;
+      int po = head + kept_carry + (ex & 0xFFF) + (starts_carry + (ex >> 12)) * R;
+      const int tot = __shfl(cin, G - 1, G);
+      kept_carry += tot & 0xFFF;
+      starts_carry += tot >> 12;
+      // 16 unconditional byte writes: a byte that is not kept goes to the lane's own spare word (a select costs
+      // less than an execution-mask round trip per byte); a wavefront without any kept byte skips them
+      if (__builtin_amdgcn_ballot_w64(keep != 0) == 0) continue;
+      const uint32_t wv[4] = {bx.x, bx.y, bx.z, bx.w};
+      uint8_t* const spare = (uint8_t*)&spare_all[threadIdx.x];
+      const int Rs = S ? R : 0;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        po += (int)((S >> t) & 1u) * Rs;
+        const uint32_t kb = (keep >> t) & 1u;
+        uint8_t* const wp = kb ? otile + po : spare;
+        *wp = (uint8_t)(wv[t >> 2] >> ((t & 3) * 8));
+        po += (int)kb;
+      }
+    }
+    group_sync();
+    // ---- output blocks
+    uint8_t* dst0 = out + obase - head;
+    const int nob = (head + olen + 15) >> 4;
+    if (!(dbg & 4))
+    for (int b = lane; b < nob; b += G) {
+      if (16 * b >= head && 16 * b + 16 <= head + olen) {
+        *(uint4*)(dst0 + 16 * b) = *(const uint4*)(otile + 16 * b);
+      } else {   // block shared with a neighbouring text
+        const int q1 = 16 * b + 16 < head + olen ? 16 * b + 16 : head + olen;
+        for (int q = 16 * b < head ? head : 16 * b; q < q1; ++q) dst0[q] = otile[q];
+      }
+    }
   }
 }
 
@@ -3600,7 +3870,8 @@ int findall_pieces(const mrx_handle* h, const Pieces& pc, int64_t n, int64_t* d_
 }
 
 int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_prefix,
-                int32_t* d_spans, int64_t span_cap, int64_t* total, void* stream, bool match_next_sequence = false) {
+                int32_t* d_spans, int64_t span_cap, int64_t* total, void* stream, bool match_next_sequence = false,
+                int64_t known_total = -1, int64_t known_max = -1) {
   ScratchScope scratch_scope_((hipStream_t)stream);
   if (!h) return fail(MRX_E_ARGUMENT, "null handle");
   if (n < 0 || span_cap < 0) return fail(MRX_E_ARGUMENT, "negative size");
@@ -3664,7 +3935,8 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
   Pieces pc;
   int64_t csr_total = -1, csr_max = -1;   // CSR batches on the streaming path: byte count and longest text
   if (n > 0 && stream_ok && lay.offsets) {
-    if (int rc = csr_stats(lay, n, s, &csr_total, &csr_max)) return rc;
+    if (known_total >= 0) { csr_total = known_total; csr_max = known_max; }   // the caller (sub) has read them
+    else if (int rc = csr_stats(lay, n, s, &csr_total, &csr_max)) return rc;
     if (csr_total < 0) return fail(MRX_E_ARGUMENT, "offsets[n] is negative");
   }
   // An event record counts the matches of its text in front of it in 26 bits (kRecBeforeMask), and a
@@ -3693,7 +3965,9 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
       }
       max_text = lay.offsets ? csr_max : (lay.lens ? lay.stride : (int64_t)lay.len);
       rec32 = max_text <= kRec32MaxLen;
-      dyn = dyn_ok(h, lay, n) && max_text < (int64_t(1) << kDynShift);
+      // (a CSR batch of equal-length texts leaves no lane idle: the 64-text wavefronts and their decode are faster)
+      dyn = dyn_ok(h, lay, n) && max_text < (int64_t(1) << kDynShift) &&
+            (g_dyn_mode == 1 || csr_total < max_text * n - max_text * n / 8);
       // One launch (ST_FUSED) when a record region per resident wavefront -- sized for the most one
       // 64-text task can produce -- stays within twice the record stream of the three-launch form
       // (ragged batches whose longest text is far above the average do not: they are cut into pieces
@@ -3900,64 +4174,106 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
 }  // namespace
 
 namespace {
+// mrx_debug_subs_group(): lanes per text in k_subs_wave (16 / 32 / 64), 0 = k_subs_emit only, -1 = by text length
+std::atomic<int> g_subs_group{[] { const char* e = getenv("MRX_SUBS_G"); return e ? atoi(e) : -1; }()};
 // regex.sub for streamable plans: streaming findall -> sizes -> prefix sums -> emit (see k_subs_*)
 int sub_from_spans(const mrx_handle* h, const Layout& lay, int64_t n, const std::vector<uint16_t>& rmap,
                    int64_t count, int64_t* out_off, uint8_t* out, int64_t out_cap, int64_t* total_bytes,
                    hipStream_t s) {
-  int64_t in_bytes = 0;
-  HIP_TRY(hipMemcpyAsync(&in_bytes, lay.offsets + n, sizeof in_bytes, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
+  // Two host synchronisations per call: the batch's byte count and longest text (sizes the span buffer
+  // and, handed on, spares findall its own look), and the two totals -- matches and output bytes -- behind
+  // findall, sizes and prefix sums, all enqueued without waiting.
+  int64_t in_bytes = 0, max_len = 0;
+  if (int rc0 = csr_stats(lay, n, s, &in_bytes, &max_len)) return rc0;
+  if (in_bytes < 0) return fail(MRX_E_ARGUMENT, "offsets[n] is negative");
+  const int R = (int)rmap.size();
   int64_t* d_prefix = nullptr;
   int32_t* d_spans = nullptr;
-  HIP_TRY(scratch_alloc((void**)&d_prefix, sizeof(int64_t) * (n + 1), s));
-  int64_t cap = in_bytes / 8 + n + 64, nm = 0;
-  for (int attempt = 0; attempt < 2; ++attempt) {
-    HIP_TRY(scratch_alloc((void**)&d_spans, sizeof(int32_t) * 2 * (size_t)cap, s));
-    const int rc = run_findall(h, lay, n, d_prefix, d_spans, cap, &nm, s, /*match_next_sequence=*/true);
-    if (rc == MRX_OK) break;
-    HIP_TRY(scratch_free(d_spans, s));
-    d_spans = nullptr;
-    if (rc != MRX_E_CAPACITY || attempt == 1) { (void)scratch_free(d_prefix, s); return rc; }
-    cap = nm;
-  }
-  const int R = (int)rmap.size();
   uint16_t* d_rmap = nullptr;
   int32_t* d_cum = nullptr;
   int64_t *d_sizes = nullptr, *d_total = nullptr;
+  int32_t* d_left = nullptr;
+  HIP_TRY(scratch_alloc((void**)&d_prefix, sizeof(int64_t) * (n + 1), s));
   HIP_TRY(scratch_alloc((void**)&d_rmap, sizeof(uint16_t) * (R + 8), s));
-  HIP_TRY(scratch_alloc((void**)&d_cum, sizeof(int32_t) * (size_t)(nm + 1), s));
   HIP_TRY(scratch_alloc((void**)&d_sizes, sizeof(int64_t) * n, s));
   HIP_TRY(scratch_alloc((void**)&d_total, sizeof(int64_t), s));
+  HIP_TRY(scratch_alloc((void**)&d_left, sizeof(int32_t), s));
   if (R) HIP_TRY(hipMemcpyAsync(d_rmap, rmap.data(), sizeof(uint16_t) * R, hipMemcpyHostToDevice, s));
-  {
-    const int64_t blocks = (n + (kBlock / 16) - 1) / (kBlock / 16);
-    hipLaunchKernelGGL(k_subs_sizes, dim3((unsigned)(blocks < 65536 * 4 ? blocks : 65536 * 4)), dim3(kBlock), 0, s,
-                       n, lay.offsets, d_prefix, d_spans, (long long)count, R, d_sizes, d_cum);
-  }
-  HIP_TRY(hipGetLastError());
-  int rc = device_scan<int64_t>(d_sizes, n, out_off, d_total, s);
-  int64_t tot = 0;
-  if (rc == MRX_OK) {
+  int64_t cap = in_bytes / 8 + n + 64, nm = 0, tot = 0;
+  int rc = MRX_OK;
+  bool cum_later = false;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    HIP_TRY(scratch_alloc((void**)&d_spans, sizeof(int32_t) * 2 * (size_t)cap, s));
+    HIP_TRY(scratch_alloc((void**)&d_cum, sizeof(int32_t) * (size_t)(cap + 1), s));
+    rc = run_findall(h, lay, n, d_prefix, d_spans, cap, nullptr, s, /*match_next_sequence=*/true, in_bytes, max_len);
+    if (rc != MRX_OK) return rc;
+    const int64_t avg0 = in_bytes / (n > 0 ? n : 1);
+    // cum[] (matched bytes before each match) is k_subs_emit's: when k_subs_wave runs in front of it, it is
+    // only computed if that kernel leaves texts over (cum_later)
+    const bool long_texts = (g_long_text_mode == 1 || avg0 >= 4096) && g_long_text_mode != 2;
+    cum_later = count == 0 && !long_texts && g_subs_group != 0 && R <= 1024;
+    if (cum_later) {
+      const int64_t blocks = ((n + 63) / 64 + (kBlock / 64) - 1) / (kBlock / 64);
+      hipLaunchKernelGGL(k_subs_sizes_flat, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(kBlock), 0, s,
+                         n, lay.offsets, d_prefix, d_spans, R, d_sizes, cap);
+    } else {
+      const int64_t blocks = (n + (kBlock / 16) - 1) / (kBlock / 16);
+      hipLaunchKernelGGL(k_subs_sizes, dim3((unsigned)(blocks < 65536 * 4 ? blocks : 65536 * 4)), dim3(kBlock), 0, s,
+                         n, lay.offsets, d_prefix, d_spans, (long long)count, R, d_sizes, d_cum, cap, (const int32_t*)nullptr);
+    }
+    HIP_TRY(hipGetLastError());
+    rc = device_scan<int64_t>(d_sizes, n, out_off, d_total, s);
+    if (rc != MRX_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(&nm, d_prefix + n, sizeof nm, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(&tot, d_total, sizeof tot, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    if (nm <= cap) break;
+    if (attempt == 1) return fail(MRX_E_NO_DEVICE, "sub: match count changed between two passes");
+    HIP_TRY(scratch_free(d_spans, s));
+    HIP_TRY(scratch_free(d_cum, s));
+    cap = nm;   // more matches than one per eight bytes: once more with room for all of them
+  }
+  {
     if (total_bytes) *total_bytes = tot;
     if (tot > out_cap) {
       rc = fail(MRX_E_CAPACITY, "output buffer too small: need " + std::to_string(tot));
     } else if (tot > 0) {
-      if ((g_long_text_mode == 1 || in_bytes / n >= 4096) && g_long_text_mode != 2) {   // long texts: a workgroup per text
+      const int64_t avg = in_bytes / n;
+      if ((g_long_text_mode == 1 || avg >= 4096) && g_long_text_mode != 2) {   // long texts: a workgroup per text
         hipLaunchKernelGGL(k_subs_emit<kBlock>, dim3((unsigned)(n < 4096 ? n : 4096)), dim3(kBlock),
                            (size_t)(2 * R + 16), s, n, lay.data, lay.offsets, d_prefix, d_spans, d_cum, (long long)count, R,
-                           d_rmap, out_off, out);
+                           d_rmap, out_off, out, 0, (const int32_t*)nullptr);
         g_last_kernel = "k_subs_emit_long";
       } else {
-      const int64_t blocks = (n + (kBlock / kSubsLanes) - 1) / (kBlock / kSubsLanes);
-      hipLaunchKernelGGL(k_subs_emit<kSubsLanes>, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(kBlock),
-                         (size_t)(2 * R + 16), s, n, lay.data, lay.offsets, d_prefix, d_spans, d_cum, (long long)count, R, d_rmap,
-                         out_off, out);
-      g_last_kernel = "k_subs_emit";
+        // short texts: G lanes assemble a text in LDS (k_subs_wave); what does not fit its tiles is left to
+        // k_subs_emit, which returns at once when nothing was left
+        const int force_g = g_subs_group;
+        int G = force_g >= 0 ? force_g : (avg > 1024 ? 64 : avg > 224 ? 32 : 16);   // measured on 1 KiB texts: 32 lanes 1.41 ms, 64 lanes 1.56
+        if (R > 1024) G = 0;   // one lane writes a replacement: long templates stay on the block kernel
+        HIP_TRY(hipMemsetAsync(d_left, 0, sizeof(int32_t), s));
+#define MRX_SUBS_WAVE(GG)                                                                                        \
+  do {                                                                                                           \
+    const int64_t blocks = (n + (kBlock / GG) - 1) / (kBlock / GG);                                              \
+    hipLaunchKernelGGL(k_subs_wave<GG>, dim3((unsigned)(blocks < grid_cap() ? blocks : grid_cap())), dim3(kBlock), \
+                       (size_t)(2 * R + 16), s, n, lay.data, lay.offsets, d_prefix, d_spans, (long long)count, R,   \
+                       d_rmap, out_off, out, d_left, getenv("MRX_SUBS_DBG") ? atoi(getenv("MRX_SUBS_DBG")) : 0);      \
+  } while (0)
+        if (G == 64) MRX_SUBS_WAVE(64);
+        else if (G == 32) MRX_SUBS_WAVE(32);
+        else if (G == 16) MRX_SUBS_WAVE(16);
+#undef MRX_SUBS_WAVE
+        HIP_TRY(hipGetLastError());
+        const int64_t blocks = (n + (kBlock / kSubsLanes) - 1) / (kBlock / kSubsLanes);
+        if (cum_later)
+          hipLaunchKernelGGL(k_subs_sizes, dim3((unsigned)(blocks < 65536 * 4 ? blocks : 65536 * 4)), dim3(kBlock), 0, s,
+                             n, lay.offsets, d_prefix, d_spans, (long long)count, R, (int64_t*)nullptr, d_cum, cap,
+                             (const int32_t*)d_left);
+        hipLaunchKernelGGL(k_subs_emit<kSubsLanes>, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(kBlock),
+                           (size_t)(2 * R + 16), s, n, lay.data, lay.offsets, d_prefix, d_spans, d_cum, (long long)count, R,
+                           d_rmap, out_off, out, G, (const int32_t*)d_left);
+        g_last_kernel = G ? "k_subs_wave" : "k_subs_emit";
       }
-      HIP_TRY(hipGetLastError());
-      HIP_TRY(hipStreamSynchronize(s));
+      HIP_TRY(hipGetLastError());   // the output bytes are complete when `s` reaches this point, as with every _dev call
     }
   }
   HIP_TRY(scratch_free(d_prefix, s));
@@ -3966,6 +4282,7 @@ int sub_from_spans(const mrx_handle* h, const Layout& lay, int64_t n, const std:
   HIP_TRY(scratch_free(d_cum, s));
   HIP_TRY(scratch_free(d_sizes, s));
   HIP_TRY(scratch_free(d_total, s));
+  HIP_TRY(scratch_free(d_left, s));
   return rc;
 }
 }  // namespace
@@ -4563,7 +4880,6 @@ int mrx_sub_dev(const mrx_handle* h, const char* repl, size_t repl_len, int64_t 
                        h->hp.dev, H_BLOB(h), lay, n, d_repl, (int)r.size(), general_groups ? 2 : groups ? 1 : 0, d_tpl,
                        (int)tpl.size(), (long long)count, (int64_t*)nullptr, out_off, out, out_cap);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(s));
   }
   HIP_TRY(scratch_free(d_repl, s));
   HIP_TRY(scratch_free(d_tpl, s));
@@ -4658,6 +4974,7 @@ void mrx_debug_force_generic(int on) { g_force_generic = on < 0 ? 0 : on > 2 ? 2
 void mrx_debug_long_text_kernels(int mode) { g_long_text_mode = mode < 0 ? 0 : mode > 2 ? 0 : mode; }
 void mrx_debug_fused_findall(int mode) { g_fused = mode < 0 ? 0 : mode > 2 ? 0 : mode; }
 void mrx_debug_dynamic_texts(int mode) { g_dyn_mode = mode < 0 ? 0 : mode > 2 ? 0 : mode; }
+void mrx_debug_subs_group(int g) { g_subs_group = (g == 0 || g == 16 || g == 32 || g == 64) ? g : -1; }
 void mrx_release_scratch(void) { scratch_release_all(); }
 size_t mrx_debug_scratch_bytes(void) { return scratch_bytes_reserved(); }
 

@@ -635,21 +635,36 @@ def test_onepass_match_first_matches_oracle(pat):
 @pytest.mark.parametrize("count", [0, 1, 3])
 def test_sub_from_spans_equals_generic_and_oracle(pat, repl, count):
     """regex.sub assembled from streaming findall spans (k_subs_*) vs the generic lane-per-text
-    sub kernel on every text and vs the oracle's _sub_impl on a sample."""
+    sub kernel on every text and vs the oracle's _sub_impl on a sample.  Every form of the assembly:
+    k_subs_wave with 16 / 32 / 64 lanes per text (texts beyond the group's LDS tiles -- frame over
+    32 G + 16 bytes or output over 64 G -- fall to k_subs_emit inside the same call), k_subs_emit alone,
+    and the form picked from the average text length."""
     _need_gpu()
     rng = np.random.default_rng(zlib.crc32(pat + repl) + count)
     al = b"abcxyz0123456789 -" + bytes(c for c in pat if chr(c).isalnum()) * 2
-    texts = _random_texts(rng, 300, 90, al) + _random_texts(rng, 40, 1500, al) + [
+    texts = _random_texts(rng, 300, 90, al) + _random_texts(rng, 40, 1500, al) + _random_texts(rng, 6, 5000, al) + [
         b"", b"6502530000", b"Call 6502530000 or 4155551234 today.", b"123", b"1", b"a1b2c3", b"hellohello",
-        b"q" * 600 + b"1", b"9" * 333]
+        b"q" * 600 + b"1", b"9" * 333, b"1 2 3 4 " * 200, b"ab1 " * 127, b"ab1 " * 128, b"x" * 511 + b"1", b"y1" * 256,
+        b"7" * 1024, b"hello" * 300, b"6502530000" * 51, b"a" * 1023 + b"1", b"foo bar " * 260]
     rx = M.compile_regex(pat)
-    got = rx.sub(repl, texts, count)
-    assert M.load_library().mrx_last_kernel_name() == b"k_subs_emit"
+    lib = M.load_library()
     with generic_kernels():
         want = rx.sub(repl, texts, count)
-    assert got == want
+    for g in (-1, 16, 32, 64, 0):
+        with subs_group(g):
+            got = rx.sub(repl, texts, count)
+            assert lib.mrx_last_kernel_name() == (b"k_subs_emit" if g == 0 else b"k_subs_wave")
+        for i, (a, b) in enumerate(zip(got, want)):
+            assert a == b, (pat, repl, count, g, i, texts[i][:60], len(texts[i]))
     for i in range(0, len(texts), 7):
-        assert got[i] == O.sub(pat, repl, texts[i], count), (pat, repl, texts[i], count)
+        assert want[i] == O.sub(pat, repl, texts[i], count), (pat, repl, texts[i], count)
+    # texts at every alignment of the input (CSR: back to back) with one lane group per text
+    shifted = [texts[i % len(texts)][: 40 + i] for i in range(64)]
+    with generic_kernels():
+        want = rx.sub(repl, shifted, count)
+    for g in (16, 64):
+        with subs_group(g):
+            assert rx.sub(repl, shifted, count) == want, (pat, repl, count, g)
 
 
 @pytest.mark.parametrize("pat,repl", [(b"[a-z]+\\d+", b"#"), (b"\\d", b""), (b"\\d+", b"<NUM>"), (b"[0-9]+", b"#"),
@@ -671,7 +686,7 @@ def test_sub_emit_with_a_workgroup_per_text(pat, repl, count):
     with long_text_kernels(1):
         got = rx.sub(repl, texts, count)
         assert lib.mrx_last_kernel_name() == b"k_subs_emit_long"
-    with long_text_kernels(2):
+    with long_text_kernels(2), subs_group(0):
         want = rx.sub(repl, texts, count)
         assert lib.mrx_last_kernel_name() == b"k_subs_emit"
     for i, (g, w) in enumerate(zip(got, want)):
@@ -1128,7 +1143,7 @@ def test_sub_from_stepper_spans(pat, repl, count):
     assert "device.streamable=no" in d and "step_search=1" in d
     texts = texts + [b"aaa@bbb@ccc x@y", b"12345-6789 555-1234", b"a@b", b"555-12345"]
     got = rx.sub(repl, texts, count)
-    assert M.load_library().mrx_last_kernel_name() == b"k_subs_emit"
+    assert M.load_library().mrx_last_kernel_name() == b"k_subs_wave"
     with generic_kernels():
         want = rx.sub(repl, texts, count)
     assert got == want
@@ -1670,6 +1685,17 @@ def test_backtracker_routed_operations_match_oracle(pat):
             assert (int(ss[i]), int(se[i])) == (w if w else (-1, -1)), (pat, "search", t)
             assert lists[i] == O.findall(pat, t), (pat, "findall", t)
             assert subs[i] == O.sub(pat, b"<>", t), (pat, "sub", t)
+
+
+@contextlib.contextmanager
+def subs_group(lanes):
+    """Lanes per text in k_subs_wave (16 / 32 / 64), 0 = k_subs_emit for every text, -1 = by average length."""
+    lib = M.load_library()
+    lib.mrx_debug_subs_group(lanes)
+    try:
+        yield
+    finally:
+        lib.mrx_debug_subs_group(-1)
 
 
 @contextlib.contextmanager
