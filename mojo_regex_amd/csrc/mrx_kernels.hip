@@ -2303,6 +2303,12 @@ __global__ __launch_bounds__(kBlock) void k_decode(int64_t n, const int32_t* __r
           const int rel_t = DYN ? rel_lds[r.meta >> kTextShift] : __shfl(my_rel, (int)(r.meta >> 26));
           if (VBASE) { const int vb = __shfl(my_vb, (int)(r.meta >> 26)); r.start += vb; r.pos_base += vb; }
           int dst = rel_t + (int)(r.meta & kBefore) - tb;
+          // a record whose spans all lie in another tile pass costs nothing here (tasks of k_stream_dyn need
+          // two or three passes; without this every pass expanded every record)
+          if (DYN) {
+            const int nem = __popc(r.F & 0xAAAAAAAAu) + (REC32 ? __popc((uint32_t)r.start & 0xAAAAAAAAu) : 0);
+            if (dst >= kDecodeTile || dst + nem <= 0) continue;
+          }
           // REC32: {F even, F odd, start | (pos + 16) << 16, meta} -- two event words per record
           uint32_t Fw = r.F;
           int pb = REC32 ? (int)((uint32_t)r.pos_base >> 16) - 16 : r.pos_base;
@@ -2874,7 +2880,7 @@ __global__ __launch_bounds__(kBlock) void k_subs_wave(int64_t n, const uint8_t* 
                                                       const int32_t* __restrict__ spans, long long count,
                                                       int R, const uint16_t* __restrict__ rmap,
                                                       const int64_t* __restrict__ out_off,
-                                                      uint8_t* __restrict__ out, int32_t* __restrict__ left, int dbg) {
+                                                      uint8_t* __restrict__ out, int32_t* __restrict__ left) {
   constexpr int NG = kBlock / G, F = 32 * G + 16, O = 64 * G, BW = F / 32 + 1;
   static_assert(G == 64 || G == 32 || G == 16, "group = wavefront, half or quarter");
   __shared__ __align__(16) uint8_t text_all[NG][F];
@@ -2968,13 +2974,10 @@ __global__ __launch_bounds__(kBlock) void k_subs_wave(int64_t n, const uint8_t* 
       const int before = carry + incl - len;
       carry += __shfl(incl, G - 1, G);
       if (m < k) {
-        if (!(dbg & 8)) {
         atomicOr(&sbits[(mis + ms) >> 5], 1u << ((mis + ms) & 31));
         atomicOr(&ebits[(mis + me) >> 5], 1u << ((mis + me) & 31));
-        }
         uint8_t* dst = otile + (head + ms - before + m * R);
         const uint8_t* msrc = text + mis + ms;
-        if (!(dbg & 2))
         for (int t = 0; t < R; ++t) {
           const uint32_t r = rmap_lds[t];
           dst[t] = (r & 0x8000u) ? msrc[r & 0x7FFFu] : (uint8_t)r;
@@ -2984,7 +2987,6 @@ __global__ __launch_bounds__(kBlock) void k_subs_wave(int64_t n, const uint8_t* 
     group_sync();
     // ---- frame blocks: kept bytes
     int kept_carry = 0, starts_carry = 0, inside_carry = 0;
-    if (!(dbg & 1))
     for (int b0 = 0; b0 < nfb; b0 += G) {
       const int b = b0 + lane;
       uint32_t S = 0, T = 0, valid = 0;
@@ -3035,7 +3037,6 @@ __global__ __launch_bounds__(kBlock) void k_subs_wave(int64_t n, const uint8_t* 
     // ---- output blocks
     uint8_t* dst0 = out + obase - head;
     const int nob = (head + olen + 15) >> 4;
-    if (!(dbg & 4))
     for (int b = lane; b < nob; b += G) {
       if (16 * b >= head && 16 * b + 16 <= head + olen) {
         *(uint4*)(dst0 + 16 * b) = *(const uint4*)(otile + 16 * b);
@@ -4256,7 +4257,7 @@ int sub_from_spans(const mrx_handle* h, const Layout& lay, int64_t n, const std:
     const int64_t blocks = (n + (kBlock / GG) - 1) / (kBlock / GG);                                              \
     hipLaunchKernelGGL(k_subs_wave<GG>, dim3((unsigned)(blocks < grid_cap() ? blocks : grid_cap())), dim3(kBlock), \
                        (size_t)(2 * R + 16), s, n, lay.data, lay.offsets, d_prefix, d_spans, (long long)count, R,   \
-                       d_rmap, out_off, out, d_left, getenv("MRX_SUBS_DBG") ? atoi(getenv("MRX_SUBS_DBG")) : 0);      \
+                       d_rmap, out_off, out, d_left);                                                            \
   } while (0)
         if (G == 64) MRX_SUBS_WAVE(64);
         else if (G == 32) MRX_SUBS_WAVE(32);
@@ -4265,7 +4266,7 @@ int sub_from_spans(const mrx_handle* h, const Layout& lay, int64_t n, const std:
         HIP_TRY(hipGetLastError());
         const int64_t blocks = (n + (kBlock / kSubsLanes) - 1) / (kBlock / kSubsLanes);
         if (cum_later)
-          hipLaunchKernelGGL(k_subs_sizes, dim3((unsigned)(blocks < 65536 * 4 ? blocks : 65536 * 4)), dim3(kBlock), 0, s,
+          hipLaunchKernelGGL(k_subs_sizes, dim3((unsigned)(blocks < grid_cap() ? blocks : grid_cap())), dim3(kBlock), 0, s,
                              n, lay.offsets, d_prefix, d_spans, (long long)count, R, (int64_t*)nullptr, d_cum, cap,
                              (const int32_t*)d_left);
         hipLaunchKernelGGL(k_subs_emit<kSubsLanes>, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(kBlock),
