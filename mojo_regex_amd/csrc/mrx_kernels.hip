@@ -2882,19 +2882,60 @@ __global__ __launch_bounds__(kBlock) void k_subs_wave(int64_t n, const uint8_t* 
                                                       const int64_t* __restrict__ out_off,
                                                       uint8_t* __restrict__ out, int32_t* __restrict__ left) {
   constexpr int NG = kBlock / G, F = 32 * G + 16, O = 64 * G, BW = F / 32 + 1;
-  static_assert(G == 64 || G == 32 || G == 16, "group = wavefront, half or quarter");
+  static_assert(G == 256 || G == 64 || G == 32 || G == 16, "group = workgroup, wavefront, half or quarter of one");
+  constexpr bool BLK = G > 64;   // the workgroup shares one text: barriers instead of wavefront order, prefix
+                                 // sums carried across its four wavefronts through LDS
+  static_assert(!BLK || G == kBlock, "a group beyond a wavefront is the whole workgroup");
   __shared__ __align__(16) uint8_t text_all[NG][F];
   __shared__ __align__(16) uint8_t out_all[NG][O];
   __shared__ uint32_t sbits_all[NG][BW], ebits_all[NG][BW];
   __shared__ uint32_t spare_all[kBlock];
+  __shared__ int xw_all[3][BLK ? kBlock / 64 : 1];   // BLK: per-wavefront totals of the three prefix sums
   extern __shared__ __align__(16) uint8_t subs_dyn[];   // the replacement map (R u16 entries)
   uint16_t* rmap_lds = (uint16_t*)subs_dyn;
   for (int r = threadIdx.x; r < R; r += blockDim.x) rmap_lds[r] = rmap[r];
   __syncthreads();
   auto group_sync = [&]() {
+    if (BLK) { __syncthreads(); return; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  // inclusive prefix over the group's lanes and the group's total (xw: one of the three LDS rows; a row is
+  // used once per round, and the rounds are separated by the barriers of the other two)
+  auto scan_add = [&](int x, int* xw, int& total) {
+    if constexpr (!BLK) {
+      const int incl = group_scan<BLK ? 64 : G, false>(x);
+      total = __shfl(incl, G - 1, G);
+      return incl;
+    }
+    int incl = group_scan<64, false>(x);
+    const int wv = threadIdx.x >> 6;
+    __syncthreads();   // the row's previous readers are done
+    if ((threadIdx.x & 63) == 63) xw[wv] = incl;
+    __syncthreads();
+    int before = 0, tot = 0;
+#pragma unroll
+    for (int q = 0; q < kBlock / 64; ++q) { const int v = xw[q]; tot += v; if (q < wv) before += v; }
+    total = tot;
+    return incl + before;
+  };
+  auto scan_xor = [&](int x, int* xw, int& total) {
+    if constexpr (!BLK) {
+      const int incl = group_scan<BLK ? 64 : G, true>(x);
+      total = __shfl(incl, G - 1, G);
+      return incl;
+    }
+    int incl = group_scan<64, true>(x);
+    const int wv = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 63) xw[wv] = incl;
+    __syncthreads();
+    int before = 0, tot = 0;
+#pragma unroll
+    for (int q = 0; q < kBlock / 64; ++q) { const int v = xw[q]; tot ^= v; if (q < wv) before ^= v; }
+    total = tot;
+    return incl ^ before;
   };
   const int lane = threadIdx.x & (G - 1), grp = threadIdx.x / G;
   uint8_t* text = text_all[grp];
@@ -2970,9 +3011,10 @@ __global__ __launch_bounds__(kBlock) void k_subs_wave(int64_t n, const uint8_t* 
         ms = sp.x; me = sp.y;
       }
       const int len = me - ms;
-      const int incl = group_scan<G, false>(len);
+      int round_total;
+      const int incl = scan_add(len, xw_all[0], round_total);
       const int before = carry + incl - len;
-      carry += __shfl(incl, G - 1, G);
+      carry += round_total;
       if (m < k) {
         atomicOr(&sbits[(mis + ms) >> 5], 1u << ((mis + ms) & 31));
         atomicOr(&ebits[(mis + me) >> 5], 1u << ((mis + me) & 31));
@@ -3007,17 +3049,18 @@ __global__ __launch_bounds__(kBlock) void k_subs_wave(int64_t n, const uint8_t* 
       // kept bytes | match starts << 12 | parity << 24, for both entry states the counts differ: scan the
       // parity first (it decides which), then the counts
       const int par = (int)(P >> 15);
-      const int pin = group_scan<G, true>(par);
+      int par_total;
+      const int pin = scan_xor(par, xw_all[1], par_total);
       const int inside = inside_carry ^ pin ^ par;   // state on entry to my block
-      inside_carry ^= __shfl(pin, G - 1, G);
+      inside_carry ^= par_total;
       const uint32_t keep = inside ? keep1 : keep0;
-      const int cnt = __popc(keep) | (__popc(S) << 12);
-      const int cin = group_scan<G, false>(cnt);
+      const int cnt = __popc(keep) | (__popc(S) << 16);   // kept bytes (<= 16 G) | match starts
+      int tot;
+      const int cin = scan_add(cnt, xw_all[2], tot);
       const int ex = cin - cnt;
-      int po = head + kept_carry + (ex & 0xFFF) + (starts_carry + (ex >> 12)) * R;
-      const int tot = __shfl(cin, G - 1, G);
-      kept_carry += tot & 0xFFF;
-      starts_carry += tot >> 12;
+      int po = head + kept_carry + (ex & 0xFFFF) + (starts_carry + (ex >> 16)) * R;
+      kept_carry += tot & 0xFFFF;
+      starts_carry += tot >> 16;
       // 16 unconditional byte writes: a byte that is not kept goes to the lane's own spare word (a select costs
       // less than an execution-mask round trip per byte); a wavefront without any kept byte skips them
       if (__builtin_amdgcn_ballot_w64(keep != 0) == 0) continue;
@@ -4203,16 +4246,23 @@ int sub_from_spans(const mrx_handle* h, const Layout& lay, int64_t n, const std:
   int64_t cap = in_bytes / 8 + n + 64, nm = 0, tot = 0;
   int rc = MRX_OK;
   bool cum_later = false;
+  int G = 0;
   for (int attempt = 0; attempt < 2; ++attempt) {
     HIP_TRY(scratch_alloc((void**)&d_spans, sizeof(int32_t) * 2 * (size_t)cap, s));
     HIP_TRY(scratch_alloc((void**)&d_cum, sizeof(int32_t) * (size_t)(cap + 1), s));
     rc = run_findall(h, lay, n, d_prefix, d_spans, cap, nullptr, s, /*match_next_sequence=*/true, in_bytes, max_len);
     if (rc != MRX_OK) return rc;
     const int64_t avg0 = in_bytes / (n > 0 ? n : 1);
+    // lanes per text in k_subs_wave by average text length (1 KiB texts: 32 lanes 1.41 ms, 64 lanes 1.56 ms);
+    // 0 = k_subs_emit alone: long replacement templates (one lane writes a replacement), forced, or texts
+    // beyond the workgroup form's tiles, which take k_subs_emit<kBlock>
+    const bool long_texts = (g_long_text_mode == 1 || avg0 > 6144) && g_long_text_mode != 2;
+    const int force_g = g_subs_group;
+    G = force_g >= 0 ? force_g : (avg0 > 2048 ? 256 : avg0 > 1024 ? 64 : avg0 > 224 ? 32 : 16);
+    if (R > 1024 || long_texts) G = 0;
     // cum[] (matched bytes before each match) is k_subs_emit's: when k_subs_wave runs in front of it, it is
     // only computed if that kernel leaves texts over (cum_later)
-    const bool long_texts = (g_long_text_mode == 1 || avg0 >= 4096) && g_long_text_mode != 2;
-    cum_later = count == 0 && !long_texts && g_subs_group != 0 && R <= 1024;
+    cum_later = count == 0 && G != 0;
     if (cum_later) {
       const int64_t blocks = ((n + 63) / 64 + (kBlock / 64) - 1) / (kBlock / 64);
       hipLaunchKernelGGL(k_subs_sizes_flat, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(kBlock), 0, s,
@@ -4239,8 +4289,7 @@ int sub_from_spans(const mrx_handle* h, const Layout& lay, int64_t n, const std:
     if (tot > out_cap) {
       rc = fail(MRX_E_CAPACITY, "output buffer too small: need " + std::to_string(tot));
     } else if (tot > 0) {
-      const int64_t avg = in_bytes / n;
-      if ((g_long_text_mode == 1 || avg >= 4096) && g_long_text_mode != 2) {   // long texts: a workgroup per text
+      if (G == 0 && (g_long_text_mode == 1 || in_bytes / n >= 4096) && g_long_text_mode != 2) {   // long texts: a workgroup per text
         hipLaunchKernelGGL(k_subs_emit<kBlock>, dim3((unsigned)(n < 4096 ? n : 4096)), dim3(kBlock),
                            (size_t)(2 * R + 16), s, n, lay.data, lay.offsets, d_prefix, d_spans, d_cum, (long long)count, R,
                            d_rmap, out_off, out, 0, (const int32_t*)nullptr);
@@ -4248,9 +4297,6 @@ int sub_from_spans(const mrx_handle* h, const Layout& lay, int64_t n, const std:
       } else {
         // short texts: G lanes assemble a text in LDS (k_subs_wave); what does not fit its tiles is left to
         // k_subs_emit, which returns at once when nothing was left
-        const int force_g = g_subs_group;
-        int G = force_g >= 0 ? force_g : (avg > 1024 ? 64 : avg > 224 ? 32 : 16);   // measured on 1 KiB texts: 32 lanes 1.41 ms, 64 lanes 1.56
-        if (R > 1024) G = 0;   // one lane writes a replacement: long templates stay on the block kernel
         HIP_TRY(hipMemsetAsync(d_left, 0, sizeof(int32_t), s));
 #define MRX_SUBS_WAVE(GG)                                                                                        \
   do {                                                                                                           \
@@ -4259,7 +4305,8 @@ int sub_from_spans(const mrx_handle* h, const Layout& lay, int64_t n, const std:
                        (size_t)(2 * R + 16), s, n, lay.data, lay.offsets, d_prefix, d_spans, (long long)count, R,   \
                        d_rmap, out_off, out, d_left);                                                            \
   } while (0)
-        if (G == 64) MRX_SUBS_WAVE(64);
+        if (G == 256) MRX_SUBS_WAVE(256);
+        else if (G == 64) MRX_SUBS_WAVE(64);
         else if (G == 32) MRX_SUBS_WAVE(32);
         else if (G == 16) MRX_SUBS_WAVE(16);
 #undef MRX_SUBS_WAVE
@@ -4975,7 +5022,7 @@ void mrx_debug_force_generic(int on) { g_force_generic = on < 0 ? 0 : on > 2 ? 2
 void mrx_debug_long_text_kernels(int mode) { g_long_text_mode = mode < 0 ? 0 : mode > 2 ? 0 : mode; }
 void mrx_debug_fused_findall(int mode) { g_fused = mode < 0 ? 0 : mode > 2 ? 0 : mode; }
 void mrx_debug_dynamic_texts(int mode) { g_dyn_mode = mode < 0 ? 0 : mode > 2 ? 0 : mode; }
-void mrx_debug_subs_group(int g) { g_subs_group = (g == 0 || g == 16 || g == 32 || g == 64) ? g : -1; }
+void mrx_debug_subs_group(int g) { g_subs_group = (g == 0 || g == 16 || g == 32 || g == 64 || g == 256) ? g : -1; }
 void mrx_release_scratch(void) { scratch_release_all(); }
 size_t mrx_debug_scratch_bytes(void) { return scratch_bytes_reserved(); }
 

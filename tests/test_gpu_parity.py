@@ -636,13 +636,14 @@ def test_onepass_match_first_matches_oracle(pat):
 def test_sub_from_spans_equals_generic_and_oracle(pat, repl, count):
     """regex.sub assembled from streaming findall spans (k_subs_*) vs the generic lane-per-text
     sub kernel on every text and vs the oracle's _sub_impl on a sample.  Every form of the assembly:
-    k_subs_wave with 16 / 32 / 64 lanes per text (texts beyond the group's LDS tiles -- frame over
+    k_subs_wave with 16 / 32 / 64 / 256 lanes per text (texts beyond the group's LDS tiles -- frame over
     32 G + 16 bytes or output over 64 G -- fall to k_subs_emit inside the same call), k_subs_emit alone,
     and the form picked from the average text length."""
     _need_gpu()
     rng = np.random.default_rng(zlib.crc32(pat + repl) + count)
     al = b"abcxyz0123456789 -" + bytes(c for c in pat if chr(c).isalnum()) * 2
-    texts = _random_texts(rng, 300, 90, al) + _random_texts(rng, 40, 1500, al) + _random_texts(rng, 6, 5000, al) + [
+    texts = _random_texts(rng, 300, 90, al) + _random_texts(rng, 40, 1500, al) + _random_texts(rng, 6, 5000, al) + \
+        _random_texts(rng, 3, 12000, al) + [b"ab12 " * 1638, b"0" * 8192, b"x1" * 4200] + [
         b"", b"6502530000", b"Call 6502530000 or 4155551234 today.", b"123", b"1", b"a1b2c3", b"hellohello",
         b"q" * 600 + b"1", b"9" * 333, b"1 2 3 4 " * 200, b"ab1 " * 127, b"ab1 " * 128, b"x" * 511 + b"1", b"y1" * 256,
         b"7" * 1024, b"hello" * 300, b"6502530000" * 51, b"a" * 1023 + b"1", b"foo bar " * 260]
@@ -650,7 +651,7 @@ def test_sub_from_spans_equals_generic_and_oracle(pat, repl, count):
     lib = M.load_library()
     with generic_kernels():
         want = rx.sub(repl, texts, count)
-    for g in (-1, 16, 32, 64, 0):
+    for g in (-1, 16, 32, 64, 256, 0):
         with subs_group(g):
             got = rx.sub(repl, texts, count)
             assert lib.mrx_last_kernel_name() == (b"k_subs_emit" if g == 0 else b"k_subs_wave")
@@ -662,7 +663,7 @@ def test_sub_from_spans_equals_generic_and_oracle(pat, repl, count):
     shifted = [texts[i % len(texts)][: 40 + i] for i in range(64)]
     with generic_kernels():
         want = rx.sub(repl, shifted, count)
-    for g in (16, 64):
+    for g in (16, 64, 256):
         with subs_group(g):
             assert rx.sub(repl, shifted, count) == want, (pat, repl, count, g)
 
