@@ -42,9 +42,14 @@ struct Ctx {
 // instead of one dependent byte load per step.  The window is aligned on the
 // ADDRESS, so it may cover up to 7 bytes before/after the text inside the same
 // aligned word (never another page); those bytes are loaded but never returned.
+constexpr int kPreUnknown = (int)0x80000000;
 struct Text {
   const uint8_t* ptr;
   int len;
+  // what a pass over the whole batch found out about this text before the lane-per-text kernel started
+  // (k_litscan, for the backtracking matcher's literal prefilter): first occurrence of the plan's literal
+  // (-1 none, kPreUnknown: no such pass ran) and its last occurrence << 1 | "the text holds a newline"
+  int pre_first = kPreUnknown, pre_last_nl = 0;
   mutable uint64_t win = 0;
   mutable int win_lo = 0x40000000;  // index of the window's first byte; invalid at start
   __device__ __forceinline__ Text(const uint8_t* p, int n) : ptr(p), len(n) {}
@@ -179,10 +184,19 @@ __device__ inline int bt_match_at(const Ctx& c, const Text& t, int start, BtCaps
     ++ip;
   }
 }
+// String.find(literal, start) for the plan's literal: answered from the batch-wide pass where it can be
+// (no occurrence at all; or the first one, when start does not lie behind it)
+__device__ inline int bt_find_literal(const Ctx& c, const Text& t, int start) {
+  if (t.pre_first != kPreUnknown && c.p.bt_lit_len > 0) {
+    if (t.pre_first < 0) return -1;
+    if (start <= t.pre_first) return t.pre_first;
+  }
+  return find_literal(c.bt_lit, c.p.bt_lit_len, t, start);
+}
 // NFAEngine._match_contains_literal, nfa.mojo:642-655
 __device__ inline bool bt_contains_literal(const Ctx& c, const Text& t, int start, int end) {
   if (!(c.p.bt_flags & 1) || c.p.bt_lit_len == 0) return true;
-  const int pos = find_literal(c.bt_lit, c.p.bt_lit_len, t, start);
+  const int pos = bt_find_literal(c, t, start);
   return pos >= 0 && pos + c.p.bt_lit_len <= end;
 }
 // NFAEngine.match_next_with_groups, nfa.mojo:500-574
@@ -190,7 +204,7 @@ __device__ inline bool bt_match_next_with_groups(const Ctx& c, const Text& t, in
   int search_pos = start;
   if (c.p.bt_flags & 1) {   // literal prefilter
     while (search_pos <= t.len) {
-      const int lp = find_literal(c.bt_lit, c.p.bt_lit_len, t, search_pos);
+      const int lp = bt_find_literal(c, t, search_pos);
       if (lp < 0) return false;
       int try_pos = lp;
       if (c.p.bt_lit_len > 0 && !(c.p.bt_flags & 2)) try_pos = lp - c.p.bt_pattern_len > 0 ? lp - c.p.bt_pattern_len : 0;
@@ -222,12 +236,14 @@ __device__ inline bool bt_engine_match_first(const Ctx& c, const Text& t, int st
   return true;
 }
 __device__ inline bool bt_has_newline(const Text& t) {
+  if (t.pre_first != kPreUnknown) return (t.pre_last_nl & 1) != 0;
   for (int i = 0; i < t.len; ++i)
     if (t.at(i) == '\n') return true;
   return false;
 }
 // String.rfind(literal) (NFAEngine._find_last_literal, nfa.mojo:577-585)
 __device__ inline int bt_rfind_literal(const Ctx& c, const Text& t) {
+  if (t.pre_first != kPreUnknown) return t.pre_last_nl >> 1;   // (-1 << 1 | nl) >> 1 == -1
   const int ll = c.p.bt_lit_len;
   for (int pos = t.len - ll; pos >= 0; --pos) {
     int k = 0;
@@ -245,7 +261,7 @@ __device__ inline bool bt_engine_match_next(const Ctx& c, const Text& t, int sta
     return false;
   }
   if ((c.p.bt_flags & 8) && lit_opt && prefix_lit && !bt_has_newline(t)) {   // LITERAL.*: to the end of the text
-    const int pos = find_literal(c.bt_lit, c.p.bt_lit_len, t, start);
+    const int pos = bt_find_literal(c, t, start);
     if (pos >= 0) { ms = pos; me = t.len; return true; }
     return false;
   }
@@ -253,7 +269,7 @@ __device__ inline bool bt_engine_match_next(const Ctx& c, const Text& t, int sta
   int search_pos = start;
   if (lit_opt) {
     while (search_pos <= t.len) {
-      const int lp = find_literal(c.bt_lit, c.p.bt_lit_len, t, search_pos);
+      const int lp = bt_find_literal(c, t, search_pos);
       if (lp < 0) return false;
       int try_pos = lp;
       if (c.p.bt_lit_len > 0 && !prefix_lit) try_pos = lp - c.p.bt_pattern_len > 0 ? lp - c.p.bt_pattern_len : 0;
@@ -285,7 +301,7 @@ __device__ inline void bt_engine_match_all(const Ctx& c, const Text& t, Emit&& e
   }
   if ((c.p.bt_flags & 8) && lit_opt && prefix_lit && !bt_has_newline(t)) {
     if (current_pos < t.len) {
-      const int pos = find_literal(c.bt_lit, c.p.bt_lit_len, t, current_pos);
+      const int pos = bt_find_literal(c, t, current_pos);
       if (pos >= 0) emit(pos, t.len);
     }
     return;
@@ -293,7 +309,7 @@ __device__ inline void bt_engine_match_all(const Ctx& c, const Text& t, Emit&& e
   BtCaps caps;
   if (lit_opt) {
     while (current_pos <= t.len) {
-      const int lp = find_literal(c.bt_lit, c.p.bt_lit_len, t, current_pos);
+      const int lp = bt_find_literal(c, t, current_pos);
       if (lp < 0) break;
       int try_pos = lp;
       if (c.p.bt_lit_len > 0 && !prefix_lit) try_pos = lp - 10 > current_pos ? lp - 10 : current_pos;   // search_window = 10
@@ -537,7 +553,11 @@ __device__ inline bool hybrid_match_next(const Ctx& c, const Text& t, int start,
   }
   if (flag(c, PF_PREFILTER)) {
     if (start >= t.len) return false;
-    const int cand = find_literal(c.pre, c.p.pre_len, t, start);
+    // (a batch-wide pass only runs for this plan when its literal is the prefilter's: bt_prepass())
+    int cand;
+    if (t.pre_first != kPreUnknown && t.pre_first < 0) return false;
+    if (t.pre_first != kPreUnknown && start <= t.pre_first) cand = t.pre_first;
+    else cand = find_literal(c.pre, c.p.pre_len, t, start);
     if (cand < 0) return false;
     return engine_match_next(c, t, cand, ms, me);
   }

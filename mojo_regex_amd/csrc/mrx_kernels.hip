@@ -55,6 +55,9 @@ struct Layout {  // where text i lives
   // data + offsets[i] (offsets need not be contiguous); nullptr = plain CSR
   const int32_t* vlen = nullptr;
   const uint32_t* vskip = nullptr;   // with vlen: the per-text word k_stream_findall's VIRT form expects
+  // per text: first occurrence of the backtracking matcher's literal, last occurrence << 1 | has-newline
+  // (k_litscan in front of the lane-per-text kernels, see bt_prepass()); nullptr = not computed
+  const int2* pre = nullptr;
   // first slot of text i's row and the row's capacity (wide rows)
   __device__ __forceinline__ int64_t slot_row(int64_t i, int* cap) const {
     if (offsets) {
@@ -67,11 +70,10 @@ struct Layout {  // where text i lives
     return i * row;
   }
   __device__ __forceinline__ Text text(int64_t i) const {
-    if (offsets) {
-      const int64_t a = offsets[i];
-      return Text(data + a, vlen ? vlen[i] : (int)(offsets[i + 1] - a));
-    }
-    return Text(data + i * stride, lens ? lens[i] : len);
+    Text t = offsets ? Text(data + offsets[i], vlen ? vlen[i] : (int)(offsets[i + 1] - offsets[i]))
+                     : Text(data + i * stride, lens ? lens[i] : len);
+    if (pre) { const int2 v = pre[i]; t.pre_first = v.x; t.pre_last_nl = v.y; }
+    return t;
   }
 };
 
@@ -686,8 +688,12 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_bscan(DevPlan p, const uint8_
 // there).  Shift-and: bit k of R = "the last k + 1 bytes are the literal's first k + 1"; one mask read
 // and three register operations per byte, the text through the same LDS tile as k_bscan, a wavefront
 // stops when each of its texts has its answer.  starts[i] = position of the occurrence, -1 = none.
+// FULL: no early exit; pre[i] = {first occurrence or -1, last occurrence << 1 | "a newline in the text"} --
+// what NFAEngine's '.*' fast paths look at (nfa.mojo:577-585, 403-430), once per text instead of once per lane.
+template <bool FULL>
 __global__ __launch_bounds__(64 * kWsWaves) void k_litscan(const uint8_t* __restrict__ lit, int lit_len, const uint8_t* __restrict__ blob,
-                                                           Layout lay, int64_t n, int32_t* __restrict__ starts) {
+                                                           Layout lay, int64_t n, int32_t* __restrict__ starts,
+                                                           int2* __restrict__ pre) {
   constexpr int CH = 128, kRowPitch = CH + 16, LPR = CH / 16, RPI = 64 / LPR, NL = 64 / RPI;
   __shared__ __align__(16) uint8_t tiles[kWsWaves][64 * kRowPitch];
   __shared__ uint32_t maskt[256];
@@ -730,6 +736,8 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_litscan(const uint8_t* __rest
     } while (0)
     uint32_t R = 0;
     int found_at = -1;   // frame position of the first occurrence's last byte
+    int last_at = -1;    // FULL: of the last occurrence's
+    uint32_t nl = 0;     // FULL: a newline inside the text
     if (max_end > 0) MRX_LS_LOAD(0);
     for (int wb = 0; wb < max_end; wb += CH) {
 #pragma unroll
@@ -751,14 +759,21 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_litscan(const uint8_t* __rest
           const bool inside = f >= mis && f < end;
           R = inside ? R : 0u;
           hits |= (R & full) ? (1u << k) : 0u;
+          if (FULL) nl |= (inside && b == 10u) ? 1u : 0u;
         }
         if (hits && found_at < 0) found_at = wb + g * 16 + __builtin_ctz(hits);
+        if (FULL && hits) last_at = wb + g * 16 + (31 - __builtin_clz(hits));
       }
       __builtin_amdgcn_wave_barrier();
-      if (__all(found_at >= 0 || wb + CH >= end)) break;
+      if (!FULL && __all(found_at >= 0 || wb + CH >= end)) break;
     }
 #undef MRX_LS_LOAD
-    if (live) starts[i] = found_at >= 0 ? found_at - mis - (lit_len - 1) : -1;
+    const int first_pos = found_at >= 0 ? found_at - mis - (lit_len - 1) : -1;
+    if (live && starts) starts[i] = first_pos;
+    if (live && pre) {
+      const int last_pos = last_at >= 0 ? last_at - mis - (lit_len - 1) : -1;
+      pre[i] = make_int2(first_pos, FULL ? (int)(((uint32_t)last_pos << 1) | nl) : 0);
+    }
   }
 }
 
@@ -3534,6 +3549,37 @@ int check_lds(const mrx_handle* h) {
   return MRX_OK;
 }
 
+// NFAEngine's literal prefilter (nfa.mojo:86-143, 391-498, 169-340) in front of the lane-per-text kernels:
+// every backtracker-routed search starts with String.find(literal) -- and, on the '.*' fast paths, with a
+// look for a newline and String.rfind(literal) -- over the WHOLE text, per lane and byte by byte in the
+// literal restatement.  k_litscan answers all three for the whole batch in one coalesced pass (shift-and on
+// the LDS text tile); the lanes then read their text's answers (Layout::pre -> Text::pre_*): a text without
+// the literal is done at once, a '.*' pattern on a text without newlines needs no byte of it.
+// mrx_debug_force_generic(2) runs without it (the parity tests compare the two).
+int bt_prepass(const mrx_handle* h, const Layout& lay, int64_t n, hipStream_t s, Layout* out) {
+  *out = lay;
+  const DevPlan& p = h->hp.dev;
+  if (g_force_generic == 2 || n <= 0 || p.bt_nitems <= 0 || !(p.bt_flags & 1) || p.bt_lit_len < 1 || p.bt_lit_len > 32)
+    return MRX_OK;
+  // HybridMatcher's own memchr prefilter (matcher.mojo:784-796) reads the same answers: only when its literal
+  // is this one
+  if ((p.flags & PF_PREFILTER) && h->hp.prefilter_literal != h->hp.nfa_literal) return MRX_OK;
+  int2* d_pre = nullptr;
+  HIP_TRY(scratch_alloc((void**)&d_pre, sizeof(int2) * n, s));
+  const int64_t nw = (n + 63) / 64;
+  int64_t g = (nw + kWsWaves - 1) / kWsWaves;
+  if (g > grid_cap()) g = grid_cap();
+  if (p.bt_flags & (4 | 8))
+    hipLaunchKernelGGL(k_litscan<true>, dim3((unsigned)g), dim3(64 * kWsWaves), 0, s, H_BLOB(h) + p.off_bt_lit, p.bt_lit_len,
+                       H_BLOB(h), lay, n, (int32_t*)nullptr, d_pre);
+  else
+    hipLaunchKernelGGL(k_litscan<false>, dim3((unsigned)g), dim3(64 * kWsWaves), 0, s, H_BLOB(h) + p.off_bt_lit, p.bt_lit_len,
+                       H_BLOB(h), lay, n, (int32_t*)nullptr, d_pre);
+  HIP_TRY(hipGetLastError());
+  out->pre = d_pre;
+  return MRX_OK;
+}
+
 template <int OP>
 int run_match(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d_s, int32_t* d_e,
               uint8_t* d_flag, void* stream) {
@@ -3609,8 +3655,11 @@ int run_match(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d_s, i
     }
     }
   } else {
+    Layout layp = lay;
+    if ((OP == OP_SEARCH && (h->hp.dev.flags & PF_BT_SEARCH)) || (OP == OP_CAPTURES && h->hp.fixed_total < 0))
+      if (int rc = bt_prepass(h, lay, n, s, &layp)) return rc;
     hipLaunchKernelGGL(k_match<OP>, dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s, h->hp.dev,
-                       H_BLOB(h), lay, n, d_s, d_e, d_flag);
+                       H_BLOB(h), layp, n, d_s, d_e, d_flag);
     g_last_kernel = "k_match";
   }
   HIP_TRY(hipGetLastError());
@@ -3977,6 +4026,7 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
   int32_t* d_slots = nullptr;
   int64_t rec_row = 0;
   Pieces pc;
+  Layout lay_pre = lay;                   // literal restatement of a backtracker-routed plan: lay + bt_prepass()
   int64_t csr_total = -1, csr_max = -1;   // CSR batches on the streaming path: byte count and longest text
   if (n > 0 && stream_ok && lay.offsets) {
     if (known_total >= 0) { csr_total = known_total; csr_max = known_max; }   // the caller (sub) has read them
@@ -4114,10 +4164,13 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
                            (int32_t*)nullptr, (int32_t*)nullptr);
         if (step_split > 0)
           MRX_REQWAVE_LAUNCH(STEP_COUNT, h, lay2, n, d_counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0, s);
-      } else
+      } else {
+        if (p.flags & PF_BT_SEARCH)
+          if (int rc = bt_prepass(h, lay, n, s, &lay_pre)) return rc;
         hipLaunchKernelGGL(k_findall<FA_COUNT>, dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s,
-                           p, H_BLOB(h), lay, n, d_counts, (const int64_t*)nullptr, (int32_t*)nullptr,
+                           p, H_BLOB(h), lay_pre, n, d_counts, (const int64_t*)nullptr, (int32_t*)nullptr,
                            (int64_t)0);
+      }
       g_last_kernel = req_wave ? "k_req_wave" : step_ok ? (wstep_bits ? "k_bstep_count" : step_split > 0 ? "k_step_count+k_req_wave" : "k_step_count")
                                                         : "k_findall_count";
       HIP_TRY(hipGetLastError());
@@ -4189,7 +4242,7 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
         }
       } else
         hipLaunchKernelGGL(k_findall<FA_EMIT>, dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s, p,
-                           H_BLOB(h), lay, n, (int32_t*)nullptr, d_prefix, d_spans, span_cap);
+                           H_BLOB(h), lay_pre, n, (int32_t*)nullptr, d_prefix, d_spans, span_cap);
     }
     HIP_TRY(hipGetLastError());
   }
@@ -4460,8 +4513,8 @@ static int run_search_any(const mrx_handle* h, const Layout& lay, int64_t n, int
       const int64_t nw = (n + 63) / 64;
       int64_t g = (nw + kWsWaves - 1) / kWsWaves;
       if (g > grid_cap()) g = grid_cap();
-      hipLaunchKernelGGL(k_litscan, dim3((unsigned)g), dim3(64 * kWsWaves), 0, s, H_BLOB(h) + p.off_pre, p.pre_len, H_BLOB(h), lay, n,
-                         d_cand);
+      hipLaunchKernelGGL(k_litscan<false>, dim3((unsigned)g), dim3(64 * kWsWaves), 0, s, H_BLOB(h) + p.off_pre, p.pre_len, H_BLOB(h), lay, n,
+                         d_cand, (int2*)nullptr);
     }
     hipLaunchKernelGGL(k_view_build, dim3(grid_for(n + 1, kBlock)), dim3(kBlock), 0, s, lay, n, 0, d_cand, vstart, vlen, vskip);
     HIP_TRY(hipGetLastError());
@@ -4821,8 +4874,11 @@ static int run_count_any(const mrx_handle* h, const Layout& lay, int64_t n, int3
         g_last_kernel = "k_step_count+k_req_wave";
       }
     } else {
+      Layout layp = lay;
+      if (h->hp.dev.flags & PF_BT_SEARCH)
+        if (int rc = bt_prepass(h, lay, n, s, &layp)) return rc;
       hipLaunchKernelGGL(k_findall<FA_COUNT>, dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s,
-                         h->hp.dev, H_BLOB(h), lay, n, counts, (const int64_t*)nullptr, (int32_t*)nullptr,
+                         h->hp.dev, H_BLOB(h), layp, n, counts, (const int64_t*)nullptr, (int32_t*)nullptr,
                          (int64_t)0);
       g_last_kernel = "k_findall_count";
     }
@@ -4904,7 +4960,11 @@ int mrx_sub_dev(const mrx_handle* h, const char* repl, size_t repl_len, int64_t 
   if (!r.empty()) HIP_TRY(hipMemcpyAsync(d_repl, r.data(), r.size(), hipMemcpyHostToDevice, s));
   if (!tpl.empty())
     HIP_TRY(hipMemcpyAsync(d_tpl, tpl.data(), sizeof(ReplSeg) * tpl.size(), hipMemcpyHostToDevice, s));
-  const Layout lay{d, off, 0, nullptr, 0};
+  Layout lay{d, off, 0, nullptr, 0};
+  if ((h->hp.dev.flags & PF_BT_SEARCH) || general_groups) {
+    const Layout plain = lay;
+    if (int rc = bt_prepass(h, plain, n, s, &lay)) return rc;
+  }
   if (n > 0) {
     ScanTimer tm(s);
     hipLaunchKernelGGL(k_sub<SUB_SIZE>, dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s,

@@ -1666,6 +1666,11 @@ def test_backtracker_routed_operations_match_oracle(pat):
     texts = _random_texts(rng, 200, 50, al) + _random_texts(rng, 20, 400, al)
     texts += [b"hello world", b"say hello there world", b"bob@example.com, eve@example.com", b"aaaaa", b"aaaaba", b"a b\nab",
               b"hello\nworld hello world", b"", b"x", b"singing and dancing", b"  hello you", b"line1\nuser@example.com"]
+    # the batch-wide literal pass (bt_prepass / k_litscan) in front of the lanes: occurrences at chunk borders,
+    # at the very end, only behind a newline, long texts, the literal alone
+    texts += [b"q" * 127 + b"hello", b"q" * 120 + b"hello world", b"z" * 300 + b"@example.com", b"p" * 1000 + b"\n" + b"hello w" + b"r" * 700,
+              b"hello", b"world", b"@example.com", b"k" * 3000 + b"hello" + b"m" * 2000 + b"world", b"w" * 255 + b"x", b"ing",
+              b"sing" * 70, b"hell" * 40 + b"o", b"\n" * 10 + b"hello.*", b"aaaa" + b"b" * 200 + b"a"]
     supported_search = "support.search=yes" in d
     supported_first = "support.match_first=yes" in d
     assert supported_search or supported_first, d
@@ -1686,6 +1691,15 @@ def test_backtracker_routed_operations_match_oracle(pat):
             assert (int(ss[i]), int(se[i])) == (w if w else (-1, -1)), (pat, "search", t)
             assert lists[i] == O.findall(pat, t), (pat, "findall", t)
             assert subs[i] == O.sub(pat, b"<>", t), (pat, "sub", t)
+    if supported_search:   # and without the batch-wide literal pass (every lane looks for itself)
+        batch = M.DeviceBatch.from_texts(texts)
+        cnt = rx.count(batch).cpu().numpy()
+        with generic_kernels():
+            ss2, se2 = rx.match_next(texts)
+            assert rx.findall_lists(texts) == lists and rx.sub(b"<>", texts) == subs
+            assert (rx.count(batch).cpu().numpy() == cnt).all()
+        assert (np.asarray(ss2) == np.asarray(ss)).all() and (np.asarray(se2) == np.asarray(se)).all()
+        assert [len(x) for x in lists] == [int(c) for c in cnt]
 
 
 @contextlib.contextmanager
