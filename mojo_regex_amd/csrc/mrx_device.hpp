@@ -106,8 +106,13 @@ __device__ inline int bt_run(const Ctx& c, const Text& t, int tbl, int which, in
 constexpr int kBtChoices = 32, kBtDepth = 17;
 __device__ inline int bt_match_at(const Ctx& c, const Text& t, int start, BtCaps& caps, bool mfm, int req) {
   const int n = t.len, nitems = c.p.bt_nitems;
+  // choice stack: the newest entry lives in registers (top_*), the rest in per-lane arrays -- a greedy leaf
+  // that is retried count by count ('.*' in front of something that fails) then never touches the arrays,
+  // which the compiler keeps in scratch memory (dynamic indexing): 3.7 ms -> 0.x ms on one such 1 KiB text
   uint8_t ch_ip[kBtChoices], ch_depth[kBtChoices];
   int ch_pos[kBtChoices], ch_cnt[kBtChoices];
+  int top_ip = 0, top_depth = 0, top_pos = 0, top_cnt = 0;
+  bool have_top = false;
   int gstart[kBtDepth];
   int ip = 0, pos = start, depth = 0, sp = 0;
   const int far100 = (mfm && req >= 0) ? req + 100 : 0x7FFFFFFF;   // match_first_mode cut-offs
@@ -116,16 +121,17 @@ __device__ inline int bt_match_at(const Ctx& c, const Text& t, int start, BtCaps
   while (true) {
     if (failing) {   // back to the innermost open choice with a smaller count left (nfa.mojo:1276-1309)
       bool resumed = false;
-      while (sp > 0) {
-        --sp;
-        const BtItem it = c.bt_items[ch_ip[sp]];
-        const int cnt = ch_cnt[sp] - 1;
+      while (have_top || sp > 0) {
+        if (!have_top) { --sp; top_ip = ch_ip[sp]; top_depth = ch_depth[sp]; top_pos = ch_pos[sp]; top_cnt = ch_cnt[sp]; }
+        have_top = false;   // popped
+        const BtItem it = c.bt_items[top_ip];
+        const int cnt = top_cnt - 1;
         if (cnt < it.min) continue;
-        if (ch_pos[sp] + cnt > far100) continue;   // "new_pos > required_start_pos + 100": the choice is given up
-        pos = ch_pos[sp] + cnt;
-        ip = ch_ip[sp] + 1;
-        depth = ch_depth[sp];
-        if (cnt > it.min) { ch_cnt[sp] = cnt; ++sp; }
+        if (top_pos + cnt > far100) continue;   // "new_pos > required_start_pos + 100": the choice is given up
+        pos = top_pos + cnt;
+        ip = top_ip + 1;
+        depth = top_depth;
+        if (cnt > it.min) { top_cnt = cnt; have_top = true; }   // back on the stack, still in registers
         resumed = true;
         break;
       }
@@ -140,7 +146,9 @@ __device__ inline int bt_match_at(const Ctx& c, const Text& t, int start, BtCaps
     if (it.kind == BT_OPEN) { gstart[depth < kBtDepth ? depth : kBtDepth - 1] = pos; ++depth; ++ip; continue; }
     if (it.kind == BT_CLOSE) {
       --depth;
-      while (sp > 0 && ch_depth[sp - 1] > depth) --sp;   // the group's sequence has returned: no way back in
+      // the group's sequence has returned: no way back in
+      if (have_top && top_depth > depth) have_top = false;
+      if (!have_top) while (sp > 0 && ch_depth[sp - 1] > depth) --sp;
       if ((it.flags & BTF_CAPTURING) && it.gid >= 0 && it.gid < 10) { caps.s[it.gid] = gstart[depth]; caps.e[it.gid] = pos; }
       ++ip;
       continue;
@@ -159,8 +167,9 @@ __device__ inline int bt_match_at(const Ctx& c, const Text& t, int start, BtCaps
         if (cnt < it.min) { failing = true; continue; }
         if (pos + cnt > far100) { failing = true; continue; }
         if (cnt > it.min) {
-          if (sp >= kBtChoices) return -1;   // (the host refuses programs that could get here)
-          ch_ip[sp] = (uint8_t)ip; ch_depth[sp] = (uint8_t)depth; ch_pos[sp] = pos; ch_cnt[sp] = cnt; ++sp;
+          if (sp + (have_top ? 1 : 0) >= kBtChoices) return -1;   // (the host refuses programs that could get here)
+          if (have_top) { ch_ip[sp] = (uint8_t)top_ip; ch_depth[sp] = (uint8_t)top_depth; ch_pos[sp] = top_pos; ch_cnt[sp] = top_cnt; ++sp; }
+          top_ip = ip; top_depth = depth; top_pos = pos; top_cnt = cnt; have_top = true;
         }
       }
       pos += cnt;
