@@ -2318,12 +2318,6 @@ __global__ __launch_bounds__(kBlock) void k_decode(int64_t n, const int32_t* __r
           const int rel_t = DYN ? rel_lds[r.meta >> kTextShift] : __shfl(my_rel, (int)(r.meta >> 26));
           if (VBASE) { const int vb = __shfl(my_vb, (int)(r.meta >> 26)); r.start += vb; r.pos_base += vb; }
           int dst = rel_t + (int)(r.meta & kBefore) - tb;
-          // a record whose spans all lie in another tile pass costs nothing here (tasks of k_stream_dyn need
-          // two or three passes; without this every pass expanded every record)
-          if (DYN) {
-            const int nem = __popc(r.F & 0xAAAAAAAAu) + (REC32 ? __popc((uint32_t)r.start & 0xAAAAAAAAu) : 0);
-            if (dst >= kDecodeTile || dst + nem <= 0) continue;
-          }
           // REC32: {F even, F odd, start | (pos + 16) << 16, meta} -- two event words per record
           uint32_t Fw = r.F;
           int pb = REC32 ? (int)((uint32_t)r.pos_base >> 16) - 16 : r.pos_base;
@@ -3440,7 +3434,11 @@ int bscan_limits(const mrx_handle* h, const Layout& lay, int64_t n, int mode, hi
 // The stepper's routes: one wavefront per text (k_req_wave) when the texts are long or too few to
 // fill the device with one lane each, one lane per text (k_wstep) otherwise.  The average length
 // decides; a CSR batch's byte count lives on the device, so that costs one 8-byte read-back.
-int req_wave_pays(const Layout& lay, int64_t n, bool req_route, hipStream_t s, bool* out, int* split = nullptr) {
+// big: the plan's table only exists in the wavefront kernel's class-indexed form (PF_STEP_BIG); the
+// alternative is the literal restatement (50 GB/s), so the wavefront form takes every batch of texts of
+// half a KiB and more
+int req_wave_pays(const Layout& lay, int64_t n, bool req_route, hipStream_t s, bool* out, int* split = nullptr,
+                  bool big = false) {
   *out = false;
   if (split) *split = 0;
   if (g_long_text_mode) { *out = g_long_text_mode == 1; return MRX_OK; }
@@ -3466,6 +3464,7 @@ int req_wave_pays(const Layout& lay, int64_t n, bool req_route, hipStream_t s, b
   // candidates (every byte a walk may start on) it does several times the work of the serial loop and
   // only pays while one lane per text would leave most of the device idle.
   *out = req_route ? (avg >= 2048 || (avg >= 512 && n <= 32768)) : (avg >= 1024 && n <= 65536);
+  if (big && avg >= 512) *out = true;
   // a ragged batch with a few texts far longer than the rest: those go to the wavefront kernel, the
   // others keep one lane each
   if (!*out && split && max_len >= 32768 && max_len >= 8 * avg) *split = 16384;
@@ -3612,7 +3611,7 @@ int run_match(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d_s, i
     const bool bits = (h->hp.dev.flags & PF_BSTEP) != 0;     // bitset NFA: the lane-per-text stepper only
     int split = 0;
     if (!bits)
-      if (int rc = req_wave_pays(lay, n, false, s, &wave, big ? nullptr : &split)) return rc;
+      if (int rc = req_wave_pays(lay, n, false, s, &wave, big ? nullptr : &split)) return rc;   // (not the `big` rule: search stops at the first match)
     Layout lay2 = lay;
     lay2.split = split;
     if (bits) {   // union automaton first: texts without any match end are not searched at all
@@ -4113,7 +4112,8 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
       }
     } else {
       if (step_ok && !wstep_bits)
-        if (int rc = req_wave_pays(lay, n, use_req_route, s, &req_wave, (p.flags & PF_STEP_BIG) ? nullptr : &step_split))
+        if (int rc = req_wave_pays(lay, n, use_req_route, s, &req_wave, (p.flags & PF_STEP_BIG) ? nullptr : &step_split,
+                                   (p.flags & PF_STEP_BIG) != 0))
           return rc;
       lay2.split = step_split;
       if (step_ok && (wstep_bits || (!req_wave && step_split == 0 && !use_req_route && union_pass_for_table_plan(p, false)))) {
@@ -4853,7 +4853,8 @@ static int run_count_any(const mrx_handle* h, const Layout& lay, int64_t n, int3
     bool req_wave = false;
     int split = 0;
     if (g_force_generic < 2 && !wstep_bits && (h->hp.dev.flags & (PF_STEPPABLE | PF_STEP_REQ)))
-      if (int rc = req_wave_pays(lay, n, use_req_route, s, &req_wave, (h->hp.dev.flags & PF_STEP_BIG) ? nullptr : &split))
+      if (int rc = req_wave_pays(lay, n, use_req_route, s, &req_wave, (h->hp.dev.flags & PF_STEP_BIG) ? nullptr : &split,
+                                 (h->hp.dev.flags & PF_STEP_BIG) != 0))
         return rc;
     Layout lay2 = lay;
     lay2.split = split;
