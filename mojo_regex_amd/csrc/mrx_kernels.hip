@@ -3684,10 +3684,12 @@ int64_t fused_grid_cap() {
 // tasks of less than 32 KiB would queue up there, so batches of short texts keep the three-launch form.
 constexpr int64_t kFusedMinTaskBytes = 32768;
 // '^'-anchored DFA plan whose search / findall / count are the anchored automaton's run from byte 0 (not the
-// pure-literal case: simd_search is not anchored; not with '$'; not behind the exact-literal / prefilter paths)
+// pure-literal case: simd_search is not anchored; with '$' only where the automaton carries end-of-text flags;
+// not behind the exact-literal / prefilter paths)
 bool anchored_at_zero(const mrx_handle* h) {
   const DevPlan& p = h->hp.dev;
-  return !g_force_generic && (p.flags & PF_START_ANCHOR) && !(p.flags & (PF_END_ANCHOR | PF_PURE_LITERAL)) &&
+  return !g_force_generic && (p.flags & PF_START_ANCHOR) && !(p.flags & PF_PURE_LITERAL) &&
+         (!(p.flags & PF_END_ANCHOR) || p.off_fa_end >= 0) &&   // '^...$': the anchored automaton with end-of-text flags
          p.kind == PLAN_DFA && p.fa_bytes > 0 && !(p.flags & (PF_EXACT_LITERAL | PF_PREFILTER)) && h->hp.why_no_search.empty();
 }
 // longest text the event records of the streaming findall can describe (see run_findall)

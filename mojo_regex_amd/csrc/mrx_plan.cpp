@@ -796,7 +796,12 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
   else if (d.flags & PF_BT_FIRST) hp.first_stream_why_not = "backtracking matcher route (NFAEngine.match_first)";
   else if (!hp.first_onepass && (d.flags & PF_START_DEAD)) hp.first_stream_why_not = "dead start state";
   else if (!hp.first_onepass && (d.flags & PF_BITSET)) hp.first_stream_why_not = "bitset NFA walk (no determinised table)";
-  else if (d.flags & PF_END_ANCHOR) hp.first_stream_why_not = "'$' needs the end-of-text check of both paths";
+  else if ((d.flags & PF_END_ANCHOR) &&
+           (d.kind != PLAN_DFA || (d.flags & PF_PURE_LITERAL) ||
+            ((d.flags & PF_HAS_MATCHER) && (d.flags & (PF_SCAN_ELIGIBLE | PF_START_ACCEPTING)))))
+    // (with the _try_match_simd shortcut in play a '$' match is "the class run reaches the end, or else the
+    // table walk does": two walks; pure literals return before the '$' check, dfa.mojo:1915-1925)
+    hp.first_stream_why_not = "'$' needs the end-of-text check of both paths";
   else {
     std::vector<std::array<int, 256>> N;  // -1 = dead
     std::vector<uint8_t> A, E;            // E: OnePass end-of-text flags (empty otherwise)
@@ -818,9 +823,14 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
                          (d.flags & (PF_SCAN_ELIGIBLE | PF_START_ACCEPTING));
       const int base = quirk ? 2 : 0;   // quirk: 0 = start, 1 = inside the first-class run
       if (quirk) { add((d.flags & PF_START_ACCEPTING) != 0); add(true); }
+      // '$' (dfa.mojo:2019-2024: the LAST accepting position of the greedy walk must be the end of the text,
+      // i.e. the walk reaches the end alive and in an accepting state): no state accepts on the way, the
+      // accepting flags become the end-of-text flags the OnePass tables use
+      const bool dollar = (d.flags & PF_END_ANCHOR) != 0;
       for (size_t q = 0; q < T.size(); ++q) {
-        const int id = add(acc[q] != 0);
+        const int id = add(!dollar && acc[q] != 0);
         for (int c = 0; c < 256; ++c) N[id][c] = T[q][c] < 0 ? -1 : T[q][c] + base;
+        if (dollar) E.push_back(acc[q] != 0);
       }
       if (quirk)
         for (int c = 0; c < 256; ++c) {

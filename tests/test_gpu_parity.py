@@ -1420,6 +1420,58 @@ def test_stepper_on_fixed_pitch_batches(pat, n, pitch, var):
         assert [tuple(int(x) for x in r) for r in sp_h[pre_h[i]:pre_h[i + 1]]] == O.findall(pat, t), (pat, i)
 
 
+@pytest.mark.parametrize("pat", [b"^abc$", b"xyz$", b"a$", b"^hello$", b"^a$", b"^ab?c$", b"(foo|bar)$", b"^(foo|bar)x$", b"[a-z]+$",
+                                 b"^[a-z]*$", b"hello$"])
+def test_end_anchored_dfa_plans_on_the_anchored_automaton(pat):
+    """'$' on the DFA route (dfa.mojo:2019-2024: the last accepting position of the greedy walk must be the
+    end of the text): match_first / is_match -- and search / findall / count of '^...$' plans, which only
+    try position 0 -- run the anchored automaton with end-of-text flags on the streaming kernel.  Plans
+    where the _try_match_simd shortcut or the pure-literal return comes first keep the literal restatement;
+    every pattern here is checked against it and the oracle either way."""
+    _need_gpu()
+    rx = M.compile_regex(pat)
+    d = rx.describe()
+    rng = np.random.default_rng(zlib.crc32(pat))
+    al = b"abcxyzfor helo" + bytes(c for c in pat if chr(c).isalnum())
+    texts = _random_texts(rng, 200, 12, al) + _random_texts(rng, 40, 300, al) + [
+        b"", b"abc", b"abcabc", b"xabc", b"abcx", b"xyz", b"xxyz", b"xyzx", b"a", b"aa", b"ba", b"ab", b"hello", b"hello!", b"ac",
+        b"foo", b"bar", b"foox", b"barx", b"xfoo", b"q" * 200 + b"xyz", b"q" * 127 + b"a", b"abc" + b"\n", b"z" * 500]
+    lib = M.load_library()
+    batch = M.DeviceBatch.from_texts(texts)
+    fs, fe = rx.match_first(texts)
+    k_first = lib.mrx_last_kernel_name()
+    im = rx.is_match(texts)
+    try:
+        ss, se = rx.match_next(texts)
+        k_search = lib.mrx_last_kernel_name()
+        lists = rx.findall_lists(texts)
+        cnt = rx.count(batch).cpu().numpy()
+        searchable = True
+    except M.UnsupportedPattern:
+        searchable = False
+    with generic_kernels():
+        gfs, gfe = rx.match_first(texts)
+        gim = rx.is_match(texts)
+        assert np.array_equal(fs, gfs) and np.array_equal(fe, gfe) and np.array_equal(np.asarray(im), np.asarray(gim)), pat
+        if searchable:
+            gss, gse = rx.match_next(texts)
+            assert np.array_equal(ss, gss) and np.array_equal(se, gse), pat
+            assert rx.findall_lists(texts) == lists and (rx.count(batch).cpu().numpy() == cnt).all(), pat
+    orx = O.compile_regex(pat)
+    for i, t in enumerate(texts):
+        w = O.match_first(pat, t)
+        assert (int(fs[i]), int(fe[i])) == (w if w else (-1, -1)), (pat, "match_first", t)
+        assert bool(im[i]) == bool(orx.is_match(t, 0)), (pat, "is_match", t)
+        if searchable:
+            w = O.search(pat, t)
+            assert (int(ss[i]), int(se[i])) == (w if w else (-1, -1)), (pat, "search", t)
+            assert lists[i] == O.findall(pat, t), (pat, "findall", t)
+    if "engine_type=DFA" in d and "pure_literal=0" in d and "has_matcher=0" in d:
+        assert "device.first_stream=yes" in d and k_first == b"k_stream_first", (d, k_first)
+        if "start_anchor=1" in d and searchable:
+            assert k_search == b"k_stream_first", k_search
+
+
 @pytest.mark.parametrize("pat", [b"^[a-z]+\\d+", b"^\\d+", b"^[a-z]+[0-9]+x", b"^(foo|bar)", b"^a+b", b"^[a-z]*[0-9]*", b"^hello"])
 def test_start_anchored_search_uses_the_anchored_automaton(pat):
     """'^'-anchored DFA plans: match_next only tries position 0, so search runs the anchored automaton
