@@ -262,7 +262,12 @@ __host__ __device__ inline size_t wstep_table_bytes(int nstates) { return (size_
 // positions and without any data-dependent loop -- the lanes of a wavefront stay in step.
 __host__ __device__ inline size_t bstep_table_bytes(int npos) { return 2048 + (size_t)((npos + 7) / 8) * 2048 + 256; }
 
-template <int MODE, int ROUTE, int BITS = 0>
+// EMPTY = 1 (plain route of a table plan whose start state accepts and that has no first-byte matcher:
+// DFAEngine.match_all's last loop, dfa.mojo:2118-2130; LazyDFA.match_all without a filter, pikevm.mojo:805-817):
+// every position is tried and every try matches -- the longest walk from it, or the empty match when no walk
+// starts there -- and the search resumes at the match end, or one byte on after an empty match; the position
+// behind the last byte is tried as well.
+template <int MODE, int ROUTE, int BITS = 0, int EMPTY = 0>
 __global__ __launch_bounds__(64 * kWsWaves) void k_wstep(DevPlan p, const uint8_t* __restrict__ blob, Layout lay,
                                                          int64_t n, int32_t* __restrict__ counts,
                                                          const int64_t* __restrict__ prefix,
@@ -275,6 +280,7 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_wstep(DevPlan p, const uint8_
   // "looking for a start".  Entry = next | ACC | START, or DEAD.  (Built from the plan's class
   // tables, so a step costs one dependent LDS read instead of three.)
   static_assert(!(BITS && ROUTE), "the bitset form has the plain route only");
+  static_assert(!EMPTY || (!BITS && !ROUTE), "empty matches: plain route of a table plan");
   uint16_t* tab = (uint16_t*)lds;
   const int ns = p.nstates, idle = ns;
   // BITS: mask[256] | follow8[nch][256] | first-byte filter[256]
@@ -458,26 +464,31 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_wstep(DevPlan p, const uint8_
         const bool alive = act && inside && e != kWsDead;
         const bool stop = act && !alive;                     // dead entry, or the text has ended
         const bool ends = stop && state != idle;             // a walk stops here
-        const bool matched = ends && last >= 0;              // matches are never empty on these plans
+        // EMPTY: a walk always leaves a match (its start accepts); an idle step on a byte that starts no walk
+        // and the idle step behind the last byte leave the empty match at `pos`
+        const bool empty_here = EMPTY && act && state == idle && (inside ? !(e & kWsStart) : true);
+        const bool matched = (ends && last >= 0) || empty_here;   // (without EMPTY matches are never empty)
+        const int m_s = empty_here ? pos : start, m_e = empty_here ? pos : last;
         if (MODE == STEP_EMIT) {
           if (matched) {
-            if (wo < span_cap) { spans[2 * wo] = start - mis; spans[2 * wo + 1] = last - mis; }
+            if (wo < span_cap) { spans[2 * wo] = m_s - mis; spans[2 * wo + 1] = m_e - mis; }
             ++wo;
           }
         }
         if (MODE == STEP_SLOTS) {   // spans = slot rows [n][kStepSlots][2]
           if (matched) {
-            if (wo < slot_cap) *(int2*)(spans + 2 * (slot0 + wo)) = make_int2(start - mis, last - mis);
+            if (wo < slot_cap) *(int2*)(spans + 2 * (slot0 + wo)) = make_int2(m_s - mis, m_e - mis);
             ++wo;
           }
         }
-        if (MODE == STEP_SEARCH) { rs = matched ? start - mis : rs; re = matched ? last - mis : re; }
+        if (MODE == STEP_SEARCH) { rs = matched ? m_s - mis : rs; re = matched ? m_e - mis : re; }
         fin = fin || (stop && state == idle) || (MODE == STEP_SEARCH && matched);
         k += matched ? 1 : 0;
-        const int after = matched ? last : start + 1;        // where the search resumes after a walk
+        // where the search resumes after a walk (EMPTY: one byte on when the walk only left the empty match)
+        const int after = EMPTY ? (last > start ? last : start + 1) : (matched ? last : start + 1);
         const bool begins = alive && (e & kWsStart);
         start = begins ? pos : start;
-        last = begins ? -1 : last;
+        last = begins ? (EMPTY ? pos : -1) : last;
         const int nxt = pos + 1;
         last = (alive && (e & kWsAcc)) ? nxt : last;
         pos = alive ? nxt : (ends ? after : pos);
@@ -503,6 +514,11 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_wstep(DevPlan p, const uint8_
       if (__all(fin)) break;
     }
 #undef MRX_WS_LOAD
+    if (EMPTY && live && !skipped && t.len == 0) {   // the empty text: one try, at 0, and it matches
+      k = 1; rs = re = 0;
+      if (MODE == STEP_EMIT && !(counts && counts[i] <= slot_cap) && wo < span_cap) { spans[2 * wo] = 0; spans[2 * wo + 1] = 0; }
+      if (MODE == STEP_SLOTS) *(int2*)(spans + 2 * slot0) = make_int2(0, 0);
+    }
     if (live && !skipped) {
       if (MODE == STEP_COUNT || MODE == STEP_SLOTS) counts[i] = k;
       if (MODE == STEP_SEARCH) { out_s[i] = rs; out_e[i] = re; }
@@ -3390,6 +3406,7 @@ int grid_for(int64_t n, int block) {
 #define MRX_WSTEP_LAUNCH(MODE, ...)                                                        \
   do {                                                                                     \
     if (wstep_bits) hipLaunchKernelGGL((k_wstep<MODE, 0, 1>), __VA_ARGS__);                \
+    else if (wstep_empty) hipLaunchKernelGGL((k_wstep<MODE, 0, 0, 1>), __VA_ARGS__);       \
     else if (use_req_route) hipLaunchKernelGGL((k_wstep<MODE, 1>), __VA_ARGS__);         \
     else hipLaunchKernelGGL((k_wstep<MODE, 0>), __VA_ARGS__);                              \
   } while (0)
@@ -4009,9 +4026,11 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
   // match end visits -- the plain walk even on plans whose findall takes the required-byte route
   const bool use_req_route = (p.flags & PF_STEP_REQ) && !match_next_sequence;
   const bool wstep_bits = (p.flags & PF_BSTEP) != 0;   // bitset NFA on the lane-per-text stepper
+  // plans with empty matches: count, then emit (nearly every text has more matches than a slot row holds)
+  const bool wstep_empty = (p.flags & PF_STEP_EMPTY) != 0 && !match_next_sequence && g_force_generic < 2;
   bool step_ok = g_force_generic < 2 &&
                  (match_next_sequence ? ((p.flags & PF_STEP_SEARCH) && !(p.flags & PF_PREFILTER))
-                                      : (p.flags & (PF_STEPPABLE | PF_STEP_REQ)) != 0);
+                                      : (p.flags & (PF_STEPPABLE | PF_STEP_REQ | PF_STEP_EMPTY)) != 0);
   bool fused = false;      // streaming path: scan, CSR offsets and spans in one launch (ST_FUSED)
   bool dyn = false;        // streaming path: ragged CSR batch on k_stream_dyn (256-text tasks)
   unsigned long long* d_ctrl = nullptr;   // its ticket word, error word and descriptors
@@ -4113,12 +4132,12 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
       tm.stop();
       }
     } else {
-      if (step_ok && !wstep_bits)
+      if (step_ok && !wstep_bits && !wstep_empty)
         if (int rc = req_wave_pays(lay, n, use_req_route, s, &req_wave, (p.flags & PF_STEP_BIG) ? nullptr : &step_split,
                                    (p.flags & PF_STEP_BIG) != 0))
           return rc;
       lay2.split = step_split;
-      if (step_ok && (wstep_bits || (!req_wave && step_split == 0 && !use_req_route && union_pass_for_table_plan(p, false)))) {
+      if (step_ok && !wstep_empty && (wstep_bits || (!req_wave && step_split == 0 && !use_req_route && union_pass_for_table_plan(p, false)))) {
         // union automaton first: texts in which no walk from any start reaches MATCH are not walked at all
         // (mode 0: a wavefront stops as soon as each of its texts has shown one match end, so on texts full
         // of matches the pass costs next to nothing; cutting tails -- mode 1 -- would scan everything)
@@ -4127,7 +4146,7 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
       // big tables: only the wavefront kernel has their form; many short texts stay on the literal restatement
       if ((p.flags & PF_STEP_BIG) && !req_wave) step_ok = false;
       ScanTimer tm(s);
-      if (step_ok && span_cap > 0) {
+      if (step_ok && span_cap > 0 && !wstep_empty) {
         if (req_wave) {
           // long texts: rows of len / 4 + 32 slots (twice the bytes of the batch) -- the second walk
           // is then only for texts with a match every 4 bytes
@@ -4173,7 +4192,7 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
                            p, H_BLOB(h), lay_pre, n, d_counts, (const int64_t*)nullptr, (int32_t*)nullptr,
                            (int64_t)0);
       }
-      g_last_kernel = req_wave ? "k_req_wave" : step_ok ? (wstep_bits ? "k_bstep_count" : step_split > 0 ? "k_step_count+k_req_wave" : "k_step_count")
+      g_last_kernel = req_wave ? "k_req_wave" : step_ok ? (wstep_bits ? "k_bstep_count" : wstep_empty ? "k_estep_count" : step_split > 0 ? "k_step_count+k_req_wave" : "k_step_count")
                                                         : "k_findall_count";
       HIP_TRY(hipGetLastError());
       tm.stop();
@@ -4226,7 +4245,10 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
     if (stream_ok) {
       // spans were written by k_decode above
     } else {
-      if (step_ok) {
+      if (step_ok && wstep_empty) {   // second walk, every text: spans straight to their CSR place
+        MRX_WSTEP_LAUNCH(STEP_EMIT, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_lds(h->hp.dev), s, p, H_BLOB(h),
+                         lay2, n, (int32_t*)nullptr, d_prefix, d_spans, span_cap, (int32_t*)nullptr, (int32_t*)nullptr);
+      } else if (step_ok) {
         if (lay2.wide_slots)
           hipLaunchKernelGGL(k_slots_gather_wide, dim3(grid_for(n * 64, kBlock)), dim3(kBlock), 0, s, lay2, n, d_counts,
                              d_prefix, d_slots, d_spans, span_cap);
@@ -4852,6 +4874,7 @@ static int run_count_any(const mrx_handle* h, const Layout& lay, int64_t n, int3
   } else {
     const bool use_req_route = (h->hp.dev.flags & PF_STEP_REQ) != 0;
     const bool wstep_bits = (h->hp.dev.flags & PF_BSTEP) != 0;
+    const bool wstep_empty = (h->hp.dev.flags & PF_STEP_EMPTY) != 0 && g_force_generic < 2;
     bool req_wave = false;
     int split = 0;
     if (g_force_generic < 2 && !wstep_bits && (h->hp.dev.flags & (PF_STEPPABLE | PF_STEP_REQ)))
@@ -4867,11 +4890,11 @@ static int run_count_any(const mrx_handle* h, const Layout& lay, int64_t n, int3
     if (req_wave) {
       MRX_REQWAVE_LAUNCH(STEP_COUNT, h, lay, n, counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0, s);
       g_last_kernel = "k_req_wave";
-    } else if (g_force_generic < 2 && !big_lane && (h->hp.dev.flags & (PF_STEPPABLE | PF_STEP_REQ))) {
+    } else if (g_force_generic < 2 && !big_lane && (h->hp.dev.flags & (PF_STEPPABLE | PF_STEP_REQ | PF_STEP_EMPTY))) {
       MRX_WSTEP_LAUNCH(STEP_COUNT, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_lds(h->hp.dev), s, h->hp.dev,
                          H_BLOB(h), lay2, n, counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0,
                          (int32_t*)nullptr, (int32_t*)nullptr);
-      g_last_kernel = wstep_bits ? "k_bstep_count" : "k_step_count";
+      g_last_kernel = wstep_bits ? "k_bstep_count" : wstep_empty ? "k_estep_count" : "k_step_count";
       if (split > 0) {
         MRX_REQWAVE_LAUNCH(STEP_COUNT, h, lay2, n, counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0, s);
         g_last_kernel = "k_step_count+k_req_wave";

@@ -774,6 +774,15 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
     else if (d.kind == PLAN_DFA && (d.flags & PF_HAS_MATCHER) && !first[d.required_byte]) d.flags |= PF_STEP_REQ;
   }
 
+  // Empty matches (dfa.mojo:2118-2130 / pikevm.mojo:805-817: "while pos <= len: try at pos; every try
+  // matches; resume at the end, or one byte on after an empty match"): the start state accepts and no
+  // first-byte matcher or filter picks the candidates.  findall / count only -- match_next is one try at 0.
+  if ((d.kind == PLAN_DFA || d.kind == PLAN_LAZY) && hp.why_no_search.empty() && (d.flags & PF_START_ACCEPTING) &&
+      !(d.flags & (PF_START_ANCHOR | PF_END_ANCHOR | PF_PURE_LITERAL | PF_EXACT_LITERAL | PF_PREFILTER | PF_HAS_MATCHER |
+                   PF_START_DEAD | PF_BITSET | PF_SCAN_ELIGIBLE | PF_BT_SEARCH)) &&
+      d.required_byte < 0 && d.nstates <= 96)
+    d.flags |= PF_STEP_EMPTY;
+
   // The same plain route for a LazyDFA that is walked as a bitset NFA (pikevm.mojo:754-817 over the state
   // sets of pikevm.mojo:497-648): one 64-bit word of live positions per lane, no determinised table.
   if (d.kind == PLAN_LAZY && (d.flags & PF_BITSET) && hp.bitset.nw == 1 && hp.why_no_search.empty() &&
@@ -1013,7 +1022,7 @@ std::string describe_plan(const HostPlan& hp) {
     << (d.off_stg_pair >= 0 ? " pair_table=1" : "") << "\n";
   o << "device.steppable=" << ((d.flags & PF_STEPPABLE) ? "yes" : (d.flags & PF_STEP_REQ) ? "required-byte route" : "no")
     << " step_search=" << ((d.flags & PF_STEP_SEARCH) ? 1 : 0) << ((d.flags & PF_STEP_BIG) ? " big_table=1" : "")
-    << ((d.flags & PF_BSTEP) ? " bitset=1" : "") << "\n";
+    << ((d.flags & PF_BSTEP) ? " bitset=1" : "") << ((d.flags & PF_STEP_EMPTY) ? " empty_matches=1" : "") << "\n";
   o << "device.first_stream=" << (d.fa_bytes ? "yes" : ("no: " + hp.first_stream_why_not))
     << " fa_nstates=" << d.fa_nstates << " fa_kind=" << d.fa_kind << (hp.first_onepass ? " onepass=yes" : "")
     << (d.off_fa_run >= 0 ? " class_run=1" : "") << "\n";

@@ -44,6 +44,9 @@ enum PlanFlags : uint32_t {
   PF_BT_FIRST = 1u << 17,       // match_first / is_match: NFAMatcher falls through to NFAEngine.match_first
                                 // (matcher.mojo:380) -- the backtracking matcher, run as its flat program
   PF_BT_SEARCH = 1u << 18,      // match_next / match_all: NFAEngine.match_next / match_all (matcher.mojo:419, 431)
+  PF_STEP_EMPTY = 1u << 19,     // findall / count of a table plan whose start state accepts and that has no
+                                // first-byte matcher (every position yields a match, possibly empty): the
+                                // windowed stepper's plain route in its EMPTY form (k_wstep<., 0, 0, 1>)
   PF_STREAM_SEARCH = 1u << 11   // search / sub / captures may use the streaming kernel too (findall and
                                 // count may whenever PF_STREAMABLE is set): not with a memchr prefilter,
                                 // which only match_next consults (matcher.mojo:784-796)

@@ -1420,6 +1420,50 @@ def test_stepper_on_fixed_pitch_batches(pat, n, pitch, var):
         assert [tuple(int(x) for x in r) for r in sp_h[pre_h[i]:pre_h[i + 1]]] == O.findall(pat, t), (pat, i)
 
 
+@pytest.mark.parametrize("pat", [b"z*", b"x*", b"(abc)*", b"a+b*", b"", b"a**", b"http?", b"ca*t", b"(?:abc)?", b"cat|(dog){0,2}\\d?",
+                                 b"1{2}.{3}|hello|xy|(?:abc)?", b"(ab|cd)*", b"(?:a|b)*c?", b"x?y?", b"(foo)?(bar)?"])
+def test_empty_match_plans_on_the_stepper(pat):
+    """Plans whose start state accepts and that have no first-byte matcher (dfa.mojo:2118-2130,
+    pikevm.mojo:805-817): every position yields a match, possibly empty; findall / count run the windowed
+    stepper's EMPTY form (count, then emit) -- against the literal restatement on every text and the oracle."""
+    _need_gpu()
+    rx = M.compile_regex(pat)
+    d = rx.describe()
+    rng = np.random.default_rng(zlib.crc32(pat) + 3)
+    al = b"abcxyzt ht p1dogcafoobar" + bytes(c for c in pat if chr(c).isalnum()) * 2
+    texts = _random_texts(rng, 250, 40, al) + _random_texts(rng, 30, 700, al) + [
+        b"", b"a", b"aa", b"aab", b"abcabc", b"abx", b"xyz", b"zzz", b"http", b"htt", b"ct", b"caaat", b"cat", b"dogdog1", b"11abc",
+        b"hello", b"q" * 129, b"z" * 128, b"z" * 127 + b"q", b"ab" * 100, b"foobar", b"barfoo"]
+    lib = M.load_library()
+    batch = M.DeviceBatch.from_texts(texts)
+    try:
+        lists = rx.findall_lists(texts)
+    except M.UnsupportedPattern:
+        pytest.skip("search not supported for this plan")
+    used = lib.mrx_last_kernel_name()
+    cnt = rx.count(batch).cpu().numpy()
+    used_cnt = lib.mrx_last_kernel_name()
+    with generic_kernels():
+        assert rx.findall_lists(texts) == lists, pat
+        assert (rx.count(batch).cpu().numpy() == cnt).all(), pat
+    assert [len(x) for x in lists] == [int(c) for c in cnt]
+    for i in range(0, len(texts), 3):
+        assert lists[i] == O.findall(pat, texts[i]), (pat, texts[i])
+    for t, got in zip(texts[-22:], lists[-22:]):
+        assert got == O.findall(pat, t), (pat, t)
+    if "empty_matches=1" in d:
+        assert used == b"k_estep_count" and used_cnt == b"k_estep_count", (used, used_cnt)
+    # fixed pitch, and the C ABI's capacity protocol on a batch where nearly every byte is a match
+    if "empty_matches=1" in d:
+        L = 96
+        rows = [t[:L].ljust(L, b"q") for t in texts[:128]]
+        sb = M.DeviceBatch.strided(torch.tensor(list(b"".join(rows)), dtype=torch.uint8, device="cuda"), L, length=L)
+        pre, sp, tot = rx._dev_findall(sb)
+        pre_h, sp_h = pre.cpu().numpy(), sp.cpu().numpy()
+        for i in range(0, 128, 5):
+            assert [tuple(int(x) for x in r) for r in sp_h[pre_h[i]:pre_h[i + 1]]] == O.findall(pat, rows[i]), (pat, rows[i])
+
+
 @pytest.mark.parametrize("pat", [b"^abc$", b"xyz$", b"a$", b"^hello$", b"^a$", b"^ab?c$", b"(foo|bar)$", b"^(foo|bar)x$", b"[a-z]+$",
                                  b"^[a-z]*$", b"hello$"])
 def test_end_anchored_dfa_plans_on_the_anchored_automaton(pat):

@@ -24,6 +24,8 @@ CASES = [
     (b"(\\d{3})(\\d{3})(\\d{4})", "is_match"),
     (b"^[a-z]+", "findall"), (b"^[a-z]+", "count"), (b"^hello", "findall"), (b"^\\d+x", "count"),
     (b"hello.*world", "search"), (b"[a-z]+@example\\.com", "search"), (b"\\d+@example\\.com", "search"),
+    (b"hello.*", "findall"), (b".*@example\\.com", "count"),
+    (b"(abc)*", "count"), (b"(abc)*", "findall"), (b"(?:ab|cd)*x?", "count"), (b"^abc$", "search"), (b"^hello$", "findall"),
 ]
 
 
