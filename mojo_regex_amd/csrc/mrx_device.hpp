@@ -114,7 +114,24 @@ __device__ inline int bt_match_at(const Ctx& c, const Text& t, int start, BtCaps
   int top_ip = 0, top_depth = 0, top_pos = 0, top_cnt = 0;
   bool have_top = false;
   int gstart[kBtDepth];
+  int lcount[kBtDepth];   // LOOP: repetitions matched so far, per nesting depth
   int ip = 0, pos = start, depth = 0, sp = 0;
+  // ALT / LOOP leave a mark on the choice stack (cnt = kBtAltMark / kBtLoopMark): popping it on a failure means
+  // "branch A failed: try B" / "this repetition failed: the loop is over"
+  constexpr int kBtAltMark = -0x40000000, kBtLoopMark = -0x40000001;
+  auto push_entry = [&](int e_ip, int e_depth, int e_pos, int e_cnt) {
+    if (have_top) { ch_ip[sp] = (uint8_t)top_ip; ch_depth[sp] = (uint8_t)top_depth; ch_pos[sp] = top_pos; ch_cnt[sp] = top_cnt; ++sp; }
+    top_ip = e_ip; top_depth = e_depth; top_pos = e_pos; top_cnt = e_cnt; have_top = true;
+  };
+  // drop every entry made deeper than `d` (a group / branch / repetition has returned: no way back in)
+  auto cut_above = [&](int d) {
+    if (have_top && top_depth > d) have_top = false;
+    if (!have_top) while (sp > 0 && ch_depth[sp - 1] > d) --sp;
+  };
+  // the newest entry (a mark the caller knows is there) is dropped
+  auto pop_mark = [&]() {
+    if (have_top) have_top = false; else if (sp > 0) --sp;
+  };
   const int far100 = (mfm && req >= 0) ? req + 100 : 0x7FFFFFFF;   // match_first_mode cut-offs
   const int far50 = (mfm && req >= 0) ? req + 50 : 0x7FFFFFFF;
   bool failing = false;
@@ -125,6 +142,18 @@ __device__ inline int bt_match_at(const Ctx& c, const Text& t, int start, BtCaps
         if (!have_top) { --sp; top_ip = ch_ip[sp]; top_depth = ch_depth[sp]; top_pos = ch_pos[sp]; top_cnt = ch_cnt[sp]; }
         have_top = false;   // popped
         const BtItem it = c.bt_items[top_ip];
+        if (top_cnt == kBtAltMark) {   // branch A failed: branch B from the same position
+          pos = top_pos; depth = top_depth + 1; ip = it.min;
+          resumed = true;
+          break;
+        }
+        if (top_cnt == kBtLoopMark) {   // this repetition failed: the loop ends with what it has
+          depth = top_depth;
+          if (lcount[depth < kBtDepth ? depth : kBtDepth - 1] < it.min) continue;   // too few: the group fails
+          pos = top_pos; ip = it.max;
+          resumed = true;
+          break;
+        }
         const int cnt = top_cnt - 1;
         if (cnt < it.min) continue;
         if (top_pos + cnt > far100) continue;   // "new_pos > required_start_pos + 100": the choice is given up
@@ -144,11 +173,60 @@ __device__ inline int bt_match_at(const Ctx& c, const Text& t, int start, BtCaps
     if (it.kind == BT_START) { if (pos != 0) failing = true; else ++ip; continue; }
     if (it.kind == BT_END) { if (pos != n) failing = true; else ++ip; continue; }
     if (it.kind == BT_OPEN) { gstart[depth < kBtDepth ? depth : kBtDepth - 1] = pos; ++depth; ++ip; continue; }
+    if (it.kind == BT_FAIL) { failing = true; continue; }
+    if (it.kind == BT_ALT) {
+      if (sp + (have_top ? 1 : 0) >= kBtChoices) return -1;
+      push_entry(ip, depth, pos, kBtAltMark);
+      ++depth; ++ip;
+      continue;
+    }
+    if (it.kind == BT_ALT_END) {   // branch A matched: its choices and the mark go, B is skipped
+      --depth;
+      cut_above(depth);
+      pop_mark();
+      ip = it.max;
+      continue;
+    }
+    if (it.kind == BT_ALT_CLOSE) { --depth; cut_above(depth); ++ip; continue; }
+    if (it.kind == BT_LOOP || it.kind == BT_LOOP_END) {
+      int lp = ip;   // the LOOP item
+      if (it.kind == BT_LOOP_END) {   // a repetition matched: its choices and its mark go
+        --depth;
+        cut_above(depth);
+        pop_mark();
+        lp = it.min;
+        const int dd = depth < kBtDepth ? depth : kBtDepth - 1;
+        ++lcount[dd];
+        const BtItem li = c.bt_items[lp];
+        if (mfm && req >= 0 && pos > req + 100) {   // nfa.mojo:1143-1144: the loop stops here, before the span is recorded
+          if (lcount[dd] >= li.min) ip = li.max; else failing = true;
+          continue;
+        }
+        if ((li.flags & BTF_CAPTURING) && li.gid >= 0 && li.gid < 10) { caps.s[li.gid] = gstart[dd]; caps.e[li.gid] = pos; }
+      } else {
+        const int dd = depth < kBtDepth ? depth : kBtDepth - 1;
+        gstart[dd] = pos; lcount[dd] = 0;
+      }
+      const BtItem li = c.bt_items[lp];
+      const BtItem le = c.bt_items[li.max - 1];          // its LOOP_END carries max
+      const int dd = depth < kBtDepth ? depth : kBtDepth - 1;
+      const int maxr = le.max == -1 ? n - gstart[dd] : le.max;
+      if (lcount[dd] < maxr && pos <= n) {               // one more repetition
+        if (sp + (have_top ? 1 : 0) >= kBtChoices) return -1;
+        push_entry(lp, depth, pos, kBtLoopMark);
+        ++depth;
+        ip = lp + 1;
+      } else if (lcount[dd] >= li.min) {
+        ip = li.max;
+      } else {
+        failing = true;
+      }
+      continue;
+    }
     if (it.kind == BT_CLOSE) {
       --depth;
       // the group's sequence has returned: no way back in
-      if (have_top && top_depth > depth) have_top = false;
-      if (!have_top) while (sp > 0 && ch_depth[sp - 1] > depth) --sp;
+      cut_above(depth);
       if ((it.flags & BTF_CAPTURING) && it.gid >= 0 && it.gid < 10) { caps.s[it.gid] = gstart[depth]; caps.e[it.gid] = pos; }
       ++ip;
       continue;
@@ -168,8 +246,7 @@ __device__ inline int bt_match_at(const Ctx& c, const Text& t, int start, BtCaps
         if (pos + cnt > far100) { failing = true; continue; }
         if (cnt > it.min) {
           if (sp + (have_top ? 1 : 0) >= kBtChoices) return -1;   // (the host refuses programs that could get here)
-          if (have_top) { ch_ip[sp] = (uint8_t)top_ip; ch_depth[sp] = (uint8_t)top_depth; ch_pos[sp] = top_pos; ch_cnt[sp] = top_cnt; ++sp; }
-          top_ip = ip; top_depth = depth; top_pos = pos; top_cnt = cnt; have_top = true;
+          push_entry(ip, depth, pos, cnt);
         }
       }
       pos += cnt;
@@ -711,6 +788,10 @@ __device__ inline void sub_text(const Ctx& c, const Text& t, const uint8_t* repl
     BtCaps caps;
     while (pos <= t.len) {
       if (!bt_match_next_with_groups(c, t, pos, ms, me, caps)) break;
+      // NFAEngine's literal prefilter backs up to literal_pos - len(pattern) without looking at `start`
+      // (nfa.mojo:531-533): it can hand back a match that lies in front of `pos`.  Upstream the loop of
+      // CompiledRegex.sub then never advances; here the replacing stops (no result to agree with).
+      if ((me == ms ? me + 1 : me) <= pos) break;
       if (ms > pos) out.bytes(t.ptr + pos, ms - pos);
       for (int k = 0; k < ntpl; ++k) {   // _apply_template_groups, matcher.mojo:1624-1646
         const ReplSeg sg = tpl[k];
@@ -758,6 +839,7 @@ __device__ inline void sub_text(const Ctx& c, const Text& t, const uint8_t* repl
   int ms, me;
   while (pos <= t.len) {
     if (!hybrid_match_next(c, t, pos, ms, me)) break;
+    if ((me == ms ? me + 1 : me) <= pos) break;   // (as above: a match in front of pos; upstream does not terminate)
     if (ms > pos) out.bytes(t.ptr + pos, ms - pos);
     if (use_groups) apply_tpl(ms);
     else out.bytes(repl, repl_len);

@@ -138,7 +138,20 @@ void build_bitset(const Program& p, BitsetNfa& out);
 // choices and short runs) and the cached "SIMD" matchers of long runs (nfa.mojo:1446-1647), and
 // they differ (\s: the nibble tables also hold NUL and ")*+,-"; [a-z0-9]-style classes in long
 // runs are searched as plain strings).
-enum BtKind : uint8_t { BT_LEAF = 0, BT_OPEN = 1, BT_CLOSE = 2, BT_START = 3, BT_END = 4 };
+//   ALT / ALT_END / ALT_CLOSE: `A|B` (NFAEngine._match_or, nfa.mojo:1019-1055: the left branch's first local
+//          success is returned, else the right branch's; neither is re-entered afterwards).  ALT marks the
+//          choice stack (min = first item of B, max = first item behind the alternation), ALT_END closes A
+//          (drops A's choices and the mark, jumps to max), ALT_CLOSE closes B.
+//   LOOP / LOOP_END: a quantified group that is the LAST child of its sequence
+//          (_match_group_with_quantifier, nfa.mojo:1105-1156): the body is matched greedily up to max times,
+//          each repetition's first local success is kept, the first failing repetition ends the loop, at
+//          least min repetitions are required; every repetition records the span from the group's FIRST
+//          start.  (A quantified group elsewhere in a sequence goes through _match_with_backtracking, which
+//          asks ASTNode.is_match_char of the group node -- false -- so it matches zero times when min == 0
+//          and not at all otherwise: nothing is emitted, or FAIL.)
+//   FAIL:  never matches.
+enum BtKind : uint8_t { BT_LEAF = 0, BT_OPEN = 1, BT_CLOSE = 2, BT_START = 3, BT_END = 4,
+                        BT_ALT = 5, BT_ALT_END = 6, BT_ALT_CLOSE = 7, BT_LOOP = 8, BT_LOOP_END = 9, BT_FAIL = 10 };
 enum BtFlags : uint8_t {
   BTF_LAST = 1,        // leaf: last child of its sequence
   BTF_ZERO_OK = 2,     // \d, \w: zero repetitions on a non-matching byte / at the end when min == 0

@@ -464,7 +464,9 @@ struct BtBuilder {
   const Ast& a;
   BtProg& out;
   int depth = 0;
+  int choices = 0;   // items that can leave an entry on the choice stack (kBtChoices = 32 on the device)
   void fail(const std::string& why) { if (out.why_not.empty()) out.why_not = why; }
+  void push_fail() { BtItem f{}; f.kind = BT_FAIL; out.items.push_back(f); }
   void set(std::array<uint8_t, 32>& t, int c, bool v) { if (v) t[c >> 3] |= (uint8_t)(1u << (c & 7)); }
   void leaf(const Node& n, bool last) {
     BtItem it{};
@@ -472,6 +474,7 @@ struct BtBuilder {
     it.min = n.min; it.max = n.max;
     if (last) it.flags |= BTF_LAST;
     if (n.min != 1 || n.max != 1) it.flags |= BTF_QUANT;
+    if ((it.flags & BTF_QUANT) && !last && ++choices > 30) { fail("more than 30 open choices"); return; }
     if (n.type == N_DIGIT || n.type == N_WORD) it.flags |= BTF_ZERO_OK;
     if (n.type == N_SPACE || n.type == N_DIGIT || n.type == N_WORD || n.type == N_RANGE) it.flags |= BTF_SIMD_TYPE;
     const std::string_view v = a.value(n);
@@ -529,7 +532,35 @@ struct BtBuilder {
         break;
       }
       case N_GROUP: {
-        if (n.min != 1 || n.max != 1) { fail("quantified group (nfa.mojo:1105-1156)"); return; }
+        if ((n.min != 1 || n.max != 1) && !last) {
+          // _match_sequence -> _match_with_backtracking(group node): _try_match_count asks is_match_char of
+          // the GROUP node, which is false for every byte -- zero repetitions or nothing (nfa.mojo:1231-1349)
+          if (n.min != 0) push_fail();
+          if (n.capturing && n.group_id > out.ngroups) out.ngroups = n.group_id;
+          break;
+        }
+        if (n.min != 1 || n.max != 1) {   // last child: the greedy loop of _match_group_with_quantifier
+          if (++depth > 16) { fail("groups nested deeper than 16"); return; }
+          if (depth > out.max_depth) out.max_depth = depth;
+          if (++choices > 30) { fail("more than 30 open choices"); return; }
+          BtItem lp{};
+          lp.kind = BT_LOOP;
+          lp.gid = (int8_t)(n.group_id >= 0 ? (n.group_id > 127 ? 127 : n.group_id) : 0);
+          if (n.capturing) lp.flags |= BTF_CAPTURING;
+          lp.min = n.min;
+          const size_t at = out.items.size();
+          out.items.push_back(lp);
+          seq(n);
+          BtItem le{};
+          le.kind = BT_LOOP_END;
+          le.min = (int32_t)at;
+          le.max = n.max;            // -1: as many as there are bytes left (n - i)
+          out.items.push_back(le);
+          out.items[at].max = (int32_t)out.items.size();   // first item behind the loop
+          if (n.capturing && n.group_id > out.ngroups) out.ngroups = n.group_id;
+          --depth;
+          break;
+        }
         if (++depth > 16) { fail("groups nested deeper than 16"); return; }
         if (depth > out.max_depth) out.max_depth = depth;
         BtItem o{};
@@ -546,7 +577,33 @@ struct BtBuilder {
         --depth;
         break;
       }
-      case N_OR: fail("alternation (nfa.mojo:1019-1055)"); break;
+      case N_OR: {
+        if ((n.min != 1 || n.max != 1) && !last) { if (n.min != 0) push_fail(); break; }   // as a quantified group
+        if (a.nkids(n) < 2) { push_fail(); break; }                                         // nfa.mojo:1030-1031
+        if (++depth > 16) { fail("groups nested deeper than 16"); return; }
+        if (depth > out.max_depth) out.max_depth = depth;
+        if (++choices > 30) { fail("more than 30 open choices"); return; }
+        BtItem alt{};
+        alt.kind = BT_ALT;
+        const size_t at = out.items.size();
+        out.items.push_back(alt);
+        node(a.child(n, 0), true);   // _match_node of the branch itself: a quantified branch is "last"
+        BtItem ae{};
+        ae.kind = BT_ALT_END;
+        const size_t at_end = out.items.size();
+        out.items.push_back(ae);
+        out.items[at].min = (int32_t)out.items.size();   // first item of B
+        node(a.child(n, 1), true);
+        BtItem ac{};
+        ac.kind = BT_ALT_CLOSE;
+        out.items.push_back(ac);
+        out.items[at].max = out.items[at_end].max = (int32_t)out.items.size();   // behind the alternation
+        --depth;
+        break;
+      }
+      case N_RE:   // _match_re, nfa.mojo:1351-1373: the first child only
+        if (a.nkids(n) > 0) node(a.child(n, 0), true);
+        break;
       default: fail("node type outside the flat form"); break;
     }
   }

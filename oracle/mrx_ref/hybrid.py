@@ -30,6 +30,12 @@ class UnsupportedByOracle(Exception):
     """The reference would run an engine that is out of this repo's scope."""
 
 
+class ReferenceDoesNotTerminate(Exception):
+    """CompiledRegex.sub's loop (matcher.mojo:1747-1822) got a match that does not move `pos` forward:
+    NFAEngine's literal prefilter backs up to literal_pos - len(pattern) without looking at `start`
+    (nfa.mojo:441-447, 531-533), so the same match can come back for ever.  There is no result to restate."""
+
+
 def _is_simple_pattern_skip_prefilter(pattern: bytes) -> bool:
     """matcher.mojo:447-532."""
     n = len(pattern)
@@ -533,6 +539,8 @@ def _sub_impl(compiled: CompiledRegex, repl: bytes, text: bytes, count: int = 0)
                 if m is None:
                     break
                 ms, me = m
+                if (me + 1 if me == ms else me) <= pos:
+                    raise ReferenceDoesNotTerminate(text)
                 if ms > pos:
                     result += text[pos:ms]
                 result += _apply_template_fixed(template, repl, text, ms, offs, widths, ng)
@@ -555,6 +563,8 @@ def _sub_impl(compiled: CompiledRegex, repl: bytes, text: bytes, count: int = 0)
                 if m is None:
                     break
                 ms, me = m
+                if (me + 1 if me == ms else me) <= pos:
+                    raise ReferenceDoesNotTerminate(text)
                 if ms > pos:
                     result += text[pos:ms]
                 group_idx = [-1] * 10
@@ -583,6 +593,8 @@ def _sub_impl(compiled: CompiledRegex, repl: bytes, text: bytes, count: int = 0)
             if m is None:
                 break
             ms, me = m
+            if (me + 1 if me == ms else me) <= pos:
+                raise ReferenceDoesNotTerminate(text)
             if ms > pos:
                 result += text[pos:ms]
             result += repl

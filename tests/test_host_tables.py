@@ -102,15 +102,19 @@ def test_out_of_scope_patterns_fail_loudly_without_a_gpu():
     rx = M.CompiledRegex("^aaaa.*a$")   # '$' program that is not one-pass: the backtracking matcher's flat program
     d = rx.describe()
     assert "support.match_first=yes" in d and "device.backtrack=yes" in d
-    d = M.CompiledRegex("^(a|b)*a.*a$").describe()   # ... unless the pattern is outside the flat form: refused
-    assert "support.match_first=reference routes" in d and "device.backtrack=no: quantified group" in d
+    d = M.CompiledRegex("^(a|b)*a.*a$").describe()   # alternation / quantified groups: flat program since round 2
+    assert "support.match_first=yes" in d and "device.backtrack=yes" in d
+    d = M.CompiledRegex("^" + "(" * 17 + "a" + ")" * 17 + ".*a$").describe()   # outside the flat form: refused
+    assert "support.match_first=reference routes" in d and "device.backtrack=no: groups nested deeper than 16" in d
+    d = M.CompiledRegex("^" + "".join(c + "*" for c in "abcdefghijklmnopqrstuvwxyzABCDEFG") + ".*a$").describe()
+    assert "device.backtrack=no: more than 30 open choices" in d
     d = M.CompiledRegex("^[a-z]+[0-9]+$").describe()   # one-pass: match_first on the OnePass tables
     assert "support.match_first=yes" in d and "onepass=yes" in d
     assert "support.search=LazyDFA search with '$'" in d
     rx = M.CompiledRegex("hello.world")   # literal-prefiltered backtracker search: flat program
     assert "support.search=yes" in rx.describe() and "literal_opt=1" in rx.describe()
-    rx = M.CompiledRegex("hello(a|b)*world")
-    assert "support.search=reference routes" in rx.describe()
+    rx = M.CompiledRegex("hello(a|b)*world")   # the quantified group is not the last child: zero repetitions upstream
+    assert "support.search=yes" in rx.describe() and "device.backtrack=yes" in rx.describe()
     with pytest.raises(M.RegexSyntaxError, match=r"Missing closing '\]'"):
         M.CompiledRegex("[abc")
     with pytest.raises(M.RegexSyntaxError, match="Unescaped closing parenthesis"):
