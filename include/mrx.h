@@ -173,7 +173,7 @@ int mrx_count_strided_dev(const mrx_handle* h, const uint8_t* d_data, int64_t st
  * (src/regex/nfa.mojo:1057-1103): groups 1..g, then group 0 (whole match).
  * d_spans[(i*(g+1) + k)*2 + {0,1}]; -1 when text i has no match.
  * Fixed-width (\d{N}) groups run on the streaming kernel; other group structures on the flat-program
- * backtracker (no alternation, no quantified groups -- refused with that reason otherwise). */
+ * backtracker (refused only beyond its limits: 16 nesting levels, 30 open choices). */
 int mrx_captures_dev(const mrx_handle* h, const uint8_t* d_data,
                      const int64_t* d_offsets, int64_t n, int32_t* d_spans,
                      void* stream);
