@@ -1783,6 +1783,10 @@ def test_backtracker_routed_operations_match_oracle(pat):
     texts += [b"q" * 127 + b"hello", b"q" * 120 + b"hello world", b"z" * 300 + b"@example.com", b"p" * 400 + b"\n" + b"hello w" + b"r" * 200,
               b"hello", b"world", b"@example.com", b"k" * 500 + b"hello" + b"m" * 300 + b"world", b"w" * 255 + b"x", b"ing",
               b"sing" * 70, b"hell" * 40 + b"o", b"\n" * 10 + b"hello.*", b"aaaa" + b"b" * 200 + b"a"]
+    if "literal_opt=0" in d and pat.startswith(b".*"):
+        # no literal to prefilter with: every start backtracks through '.*' (quadratic upstream, in the oracle's
+        # Python and on one GPU lane alike) -- short texts only
+        texts = [t for t in texts if len(t) <= 100]
     supported_search = "support.search=yes" in d
     supported_first = "support.match_first=yes" in d
     assert supported_search or supported_first, d
