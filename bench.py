@@ -337,6 +337,15 @@ def main():
         torch.cuda.synchronize()
     launches = ctypes.c_int64(0)
     scan_ms = lib.mrx_timing_scan_ms(ctypes.byref(launches))
+    # the same kernel as the timed region runs it: steps back to back on the --streams streams, so with two
+    # streams a scan shares the device with the other stream's decode (and at times its scan) and its own
+    # duration stretches -- this is the figure a rocprofv3 --kernel-trace --stats of this command shows
+    lib.mrx_timing_reset()
+    for _ in range(max(10, min(args.steps, 40))):
+        step()
+    torch.cuda.synchronize()
+    launches2 = ctypes.c_int64(0)
+    scan_ms_pipelined = lib.mrx_timing_scan_ms(ctypes.byref(launches2))
     lib.mrx_timing_enable(0)
     kernel = lib.mrx_last_kernel_name().decode()
     # algorithmic bytes per launch (DESIGN.md "Measurement"): every input byte once,
@@ -387,6 +396,11 @@ def main():
                          "traffic": (measured_traffic(n, L) or (None, None))[0],
                          "traffic_source": (measured_traffic(n, L) or (None, None))[1],
                          "kernel_ms": round(scan_ms, 4), "launches_timed": int(launches.value),
+                         # kernel_ms: each launch alone on the device (a synchronisation between the timed steps) --
+                         # what `achieved` is priced with.  kernel_ms_pipelined: its duration in the steady state of
+                         # the timed region (with --streams 2 it overlaps the other stream's kernels and stretches;
+                         # rocprofv3 --kernel-trace --stats of this command shows this one; --streams 1: the same)
+                         "kernel_ms_pipelined": round(scan_ms_pipelined, 4), "streams": nstreams,
                          # real HBM traffic rate of the kernel next to what a plain float4 copy reaches
                          # on this part (6.29 TB/s measured, MI355X_MICROARCH.md) -- informational
                          "traffic_GBps": (round(measured_traffic(n, L)[0] / (scan_ms * 1e-3) / 1e9, 1)

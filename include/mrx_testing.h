@@ -37,6 +37,10 @@ void mrx_debug_fused_findall(int mode);
 /* Ragged (CSR) batches of streamable plans with a reset byte are scanned by k_stream_dyn -- 256-text tasks,
  * a lane takes the next text when its own ends -- from 16384 texts up; 1 = always, 2 = never, 0 = by size. */
 void mrx_debug_dynamic_texts(int mode);
+/* 1: findall of a fixed-pitch batch of 2^18 texts and more runs as two halves on two streams (the decode of the
+ * first under the scan of the second); 0 (default: the split measured slower) = one batch, three launches on the
+ * caller's stream.  Results are the same. */
+void mrx_debug_split_findall(int on);
 /* sub assembled from findall spans: lanes that share one text in k_subs_wave (16, 32 or 64; texts whose
  * frame or output exceed the group's LDS tiles go to k_subs_emit); 0 = k_subs_emit for every text,
  * anything else = chosen from the average text length. */

@@ -2200,7 +2200,9 @@ __global__ __launch_bounds__(kBlock) void k_decode(int64_t n, const int32_t* __r
                                                    int64_t* __restrict__ prefix,
                                                    int32_t* __restrict__ spans, int64_t span_cap,
                                                    int fixed_len, int64_t* __restrict__ total_out,
-                                                   const int32_t* __restrict__ vbase = nullptr) {
+                                                   const int32_t* __restrict__ vbase = nullptr,
+                                                   const int64_t* __restrict__ base = nullptr) {
+  // base: spans of the texts in front of this launch's (the second half of a split findall, see findall_split)
   static_assert(!(PACK16 && VBASE), "text-relative positions of a long text do not fit 16 bits");
   static_assert(!(DYN && VBASE), "pieces are not handed out dynamically");
   using Slot = typename std::conditional<PACK16, uint32_t, int2>::type;
@@ -2221,7 +2223,7 @@ __global__ __launch_bounds__(kBlock) void k_decode(int64_t n, const int32_t* __r
     // CSR offsets of my 64 texts: exclusive scan of their counts on top of the wavefront's base
     // wave_base is exclusive within its k_scan_local tile of kScanTile wavefronts; the tiles before
     // it (at most a few dozen sums) are added here instead of by two more scan launches
-    int64_t pre0 = wave_base[w];
+    int64_t pre0 = wave_base[w] + (base ? *base : 0);
     {
       const int64_t tiles_before = w / kScanTile;
       int64_t part = 0;
@@ -3980,6 +3982,103 @@ int findall_pieces(const mrx_handle* h, const Pieces& pc, int64_t n, int64_t* d_
   return MRX_OK;
 }
 
+// findall of a large fixed-pitch batch in two halves on two streams, so that the record decode of the first
+// half runs under the scan of the second (the scan is bound by instruction issue as much as by HBM, the decode
+// by memory latency: side by side they take less than one after the other):
+//   caller's stream:  scan(A) | scan(B), sums(B) ............ | decode(B, base = spans of A)
+//   side stream:                sums(A), decode(A) ...........^ (joined before decode(B))
+// Results are those of the one-batch form: decode(B) adds A's total to its CSR offsets.
+// OFF by default -- measured on the headline workload (one box, bench.py): 0.354 ms per step against 0.336 ms for
+// the one-batch form; each half-size scan takes 0.150 ms where the whole one takes 0.243 (half the wavefronts
+// per launch: the ramp-up and the tail of a launch weigh twice), which is more than the overlap returns.  What
+// does pay is overlapping WHOLE calls on two caller streams (bench.py --streams 2: 0.287 ms on the same box).
+// MRX_FINDALL_SPLIT=1 / mrx_debug_split_findall(1): on.
+std::atomic<int> g_split_findall{[] { const char* e = getenv("MRX_FINDALL_SPLIT"); return e ? atoi(e) : 0; }()};
+constexpr int64_t kSplitMinTexts = 1 << 18;
+struct SideStream {
+  hipStream_t side = nullptr;
+  hipEvent_t scanned = nullptr, decoded = nullptr;
+};
+thread_local std::map<int, SideStream> g_side;
+static int side_stream(SideStream** out) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  SideStream& ss = g_side[dev];
+  if (!ss.side) {
+    HIP_TRY(hipStreamCreateWithFlags(&ss.side, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&ss.scanned, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&ss.decoded, hipEventDisableTiming));
+  }
+  *out = &ss;
+  return MRX_OK;
+}
+static int findall_split(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d_counts, int64_t* d_prefix,
+                         int32_t* d_spans, int64_t span_cap, int64_t* d_total, int64_t rec_row, bool rec32, bool pack16,
+                         hipStream_t s) {
+  const DevPlan& p = h->hp.dev;
+  SideStream* ss = nullptr;
+  if (int rc = side_stream(&ss)) return rc;
+  const int64_t nA = (n / 2) & ~int64_t(63), nB = n - nA;
+  const int64_t nwA = nA / 64, nwB = (nB + 63) / 64;
+  const int64_t ntA = (nwA + kScanTile - 1) / kScanTile, ntB = (nwB + kScanTile - 1) / kScanTile;
+  EvRec* d_recs = nullptr;
+  int32_t *d_nrA = nullptr, *d_nrB = nullptr;
+  int64_t *d_wbA = nullptr, *d_wbB = nullptr, *d_tsA = nullptr, *d_tsB = nullptr, *d_totA = nullptr;
+  HIP_TRY(scratch_alloc((void**)&d_recs, sizeof(EvRec) * (size_t)rec_row * n, s));
+  HIP_TRY(scratch_alloc((void**)&d_nrA, sizeof(int32_t) * 2 * nwA, s));
+  HIP_TRY(scratch_alloc((void**)&d_nrB, sizeof(int32_t) * 2 * nwB, s));
+  HIP_TRY(scratch_alloc((void**)&d_wbA, sizeof(int64_t) * (nwA + 1), s));
+  HIP_TRY(scratch_alloc((void**)&d_wbB, sizeof(int64_t) * (nwB + 1), s));
+  HIP_TRY(scratch_alloc((void**)&d_tsA, sizeof(int64_t) * ntA, s));
+  HIP_TRY(scratch_alloc((void**)&d_tsB, sizeof(int64_t) * ntB, s));
+  HIP_TRY(scratch_alloc((void**)&d_totA, sizeof(int64_t), s));
+  Layout layB = lay;
+  layB.data = lay.data + nA * lay.stride;
+  if (lay.lens) layB.lens = lay.lens + nA;
+  EvRec* d_recsB = d_recs + (size_t)rec_row * nA;
+#define MRX_DECODE_HALF(STREAM, N, NRECS, RECS, COUNTS, WBASE, TSUM, PREFIX, TOTAL, BASE)                                   \
+  do {                                                                                                                     \
+    const dim3 dg_((unsigned)grid_for((N), kBlock) * (pack16 ? 2 : 1)), db_(kBlock);                                        \
+    if (pack16 && rec32)                                                                                                   \
+      hipLaunchKernelGGL((k_decode<true, false, true>), dg_, db_, 0, STREAM, (N), NRECS, RECS, rec_row, (const int64_t*)nullptr, \
+                         COUNTS, WBASE, TSUM, PREFIX, d_spans, span_cap, p.st_fixed_len, TOTAL, (const int32_t*)nullptr, BASE); \
+    else if (pack16)                                                                                                       \
+      hipLaunchKernelGGL(k_decode<true>, dg_, db_, 0, STREAM, (N), NRECS, RECS, rec_row, (const int64_t*)nullptr,            \
+                         COUNTS, WBASE, TSUM, PREFIX, d_spans, span_cap, p.st_fixed_len, TOTAL, (const int32_t*)nullptr, BASE); \
+    else                                                                                                                   \
+      hipLaunchKernelGGL(k_decode<false>, dg_, db_, 0, STREAM, (N), NRECS, RECS, rec_row, (const int64_t*)nullptr,           \
+                         COUNTS, WBASE, TSUM, PREFIX, d_spans, span_cap, p.st_fixed_len, TOTAL, (const int32_t*)nullptr, BASE); \
+  } while (0)
+  {
+    ScanTimer tm(s);
+    launch_stream<ST_RECORDS>(h, lay, nA, d_counts, d_nrA, d_recs, rec_row, nullptr, nullptr, s, nullptr, nullptr, rec32);
+    HIP_TRY(hipGetLastError());
+    tm.stop();
+  }
+  HIP_TRY(hipEventRecord(ss->scanned, s));
+  HIP_TRY(hipStreamWaitEvent(ss->side, ss->scanned, 0));
+  hipLaunchKernelGGL(k_scan_local<int32_t>, dim3((unsigned)ntA), dim3(kScanBlock), 0, ss->side, d_nrA + nwA, nwA, d_wbA, d_tsA);
+  MRX_DECODE_HALF(ss->side, nA, d_nrA, d_recs, d_counts, d_wbA, d_tsA, d_prefix, d_totA, (const int64_t*)nullptr);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(ss->decoded, ss->side));
+  {
+    ScanTimer tm(s);
+    launch_stream<ST_RECORDS>(h, layB, nB, d_counts + nA, d_nrB, d_recsB, rec_row, nullptr, nullptr, s, nullptr, nullptr, rec32);
+    HIP_TRY(hipGetLastError());
+    tm.stop();
+  }
+  hipLaunchKernelGGL(k_scan_local<int32_t>, dim3((unsigned)ntB), dim3(kScanBlock), 0, s, d_nrB + nwB, nwB, d_wbB, d_tsB);
+  HIP_TRY(hipStreamWaitEvent(s, ss->decoded, 0));
+  MRX_DECODE_HALF(s, nB, d_nrB, d_recsB, d_counts + nA, d_wbB, d_tsB, d_prefix + nA, d_total, (const int64_t*)d_totA);
+#undef MRX_DECODE_HALF
+  HIP_TRY(hipGetLastError());
+  g_last_kernel = "k_stream_findall";
+  HIP_TRY(scratch_free(d_recs, s)); HIP_TRY(scratch_free(d_nrA, s)); HIP_TRY(scratch_free(d_nrB, s));
+  HIP_TRY(scratch_free(d_wbA, s)); HIP_TRY(scratch_free(d_wbB, s)); HIP_TRY(scratch_free(d_tsA, s));
+  HIP_TRY(scratch_free(d_tsB, s)); HIP_TRY(scratch_free(d_totA, s));
+  return MRX_OK;
+}
+
 int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_prefix,
                 int32_t* d_spans, int64_t span_cap, int64_t* total, void* stream, bool match_next_sequence = false,
                 int64_t known_total = -1, int64_t known_max = -1) {
@@ -4032,6 +4131,7 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
                  (match_next_sequence ? ((p.flags & PF_STEP_SEARCH) && !(p.flags & PF_PREFILTER))
                                       : (p.flags & (PF_STEPPABLE | PF_STEP_REQ | PF_STEP_EMPTY)) != 0);
   bool fused = false;      // streaming path: scan, CSR offsets and spans in one launch (ST_FUSED)
+  bool split_done = false; // streaming path: two halves on two streams (findall_split)
   bool dyn = false;        // streaming path: ragged CSR batch on k_stream_dyn (256-text tasks)
   unsigned long long* d_ctrl = nullptr;   // its ticket word, error word and descriptors
   int32_t* d_blimit = nullptr;            // bitset NFA: per-text limits of the first pass
@@ -4121,6 +4221,10 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
         g_last_kernel = "k_stream_findall_dyn";
         HIP_TRY(hipGetLastError());
         tm.stop();
+      } else if (g_split_findall && !lay.offsets && strided_fast(lay) && span_cap > 0 && n >= kSplitMinTexts) {
+        split_done = true;
+        if (int rc = findall_split(h, lay, n, d_counts, d_prefix, d_spans, span_cap, d_total, rec_row, rec32, max_text <= 65535, s))
+          return rc;
       } else {
       HIP_TRY(scratch_alloc((void**)&d_recs, sizeof(EvRec) * nrec, s));
       HIP_TRY(scratch_alloc((void**)&d_nrecs, sizeof(int32_t) * 2 * nw, s));  // records | matches per wavefront
@@ -4198,8 +4302,8 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
       tm.stop();
     }
   }
-  if (by_pieces || fused) {
-    // done over the pieces above / by the one launch
+  if (by_pieces || fused || split_done) {
+    // done over the pieces above / by the one launch / in two halves (findall_split)
   } else if (stream_ok) {
     // prefix sums over the wavefronts' totals only (n/64 values); k_decode derives the per-text
     // offsets from its 64 counts and writes them along with the spans
@@ -5108,6 +5212,7 @@ void mrx_debug_force_generic(int on) { g_force_generic = on < 0 ? 0 : on > 2 ? 2
 void mrx_debug_long_text_kernels(int mode) { g_long_text_mode = mode < 0 ? 0 : mode > 2 ? 0 : mode; }
 void mrx_debug_fused_findall(int mode) { g_fused = mode < 0 ? 0 : mode > 2 ? 0 : mode; }
 void mrx_debug_dynamic_texts(int mode) { g_dyn_mode = mode < 0 ? 0 : mode > 2 ? 0 : mode; }
+void mrx_debug_split_findall(int on) { g_split_findall = on ? 1 : 0; }
 void mrx_debug_subs_group(int g) { g_subs_group = (g == 0 || g == 16 || g == 32 || g == 64 || g == 256) ? g : -1; }
 void mrx_release_scratch(void) { scratch_release_all(); }
 size_t mrx_debug_scratch_bytes(void) { return scratch_bytes_reserved(); }

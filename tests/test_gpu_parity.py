@@ -1821,6 +1821,31 @@ def test_backtracker_routed_operations_match_oracle(pat):
         assert [len(x) for x in lists] == [int(c) for c in cnt]
 
 
+@pytest.mark.parametrize("pat", [b"[a-z]+\\d+", b"(\\d{3})(\\d{3})(\\d{4})", b"hello"])
+def test_split_findall_equals_one_batch(pat):
+    """mrx_debug_split_findall(1): a fixed-pitch batch of 2^18 texts and more as two halves on two streams (decode of
+    the first half under the scan of the second; off by default, it measured slower) -- same CSR as the one-batch form."""
+    _need_gpu()
+    lib = M.load_library()
+    n, L = (1 << 18) + 77, 64
+    g = torch.Generator(device="cuda")
+    g.manual_seed(zlib.crc32(pat))
+    al = torch.tensor(list(b"abcxyz0123456789 helo-"), dtype=torch.uint8, device="cuda")
+    data = al[torch.randint(0, al.numel(), (n, L), generator=g, device="cuda")]
+    lens = torch.randint(0, L + 1, (n,), generator=g, device="cuda", dtype=torch.int32)
+    rx = M.compile_regex(pat)
+    for batch in (M.DeviceBatch.strided(data.reshape(-1), L, length=L), M.DeviceBatch.strided(data.reshape(-1), L, lens=lens)):
+        pre0, sp0, tot0 = rx._dev_findall(batch)
+        lib.mrx_debug_split_findall(1)
+        try:
+            pre1, sp1, tot1 = rx._dev_findall(batch)
+            pre2, sp2, tot2 = rx._dev_findall(batch)   # back to back: the side stream and its events are reused
+        finally:
+            lib.mrx_debug_split_findall(0)
+        assert tot0 == tot1 == tot2 and tot0 > 0
+        assert torch.equal(pre0, pre1) and torch.equal(sp0[:tot0], sp1[:tot0]) and torch.equal(sp0[:tot0], sp2[:tot0])
+
+
 @contextlib.contextmanager
 def subs_group(lanes):
     """Lanes per text in k_subs_wave (16 / 32 / 64), 0 = k_subs_emit for every text, -1 = by average length."""
