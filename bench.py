@@ -337,17 +337,20 @@ def main():
         torch.cuda.synchronize()
     launches = ctypes.c_int64(0)
     scan_ms = lib.mrx_timing_scan_ms(ctypes.byref(launches))
-    # the same kernel as the timed region runs it: steps back to back on the --streams streams, so with two
-    # streams a scan shares the device with the other stream's decode (and at times its scan) and its own
-    # duration stretches -- this is the figure a rocprofv3 --kernel-trace --stats of this command shows
-    lib.mrx_timing_reset()
-    for _ in range(max(10, min(args.steps, 40))):
-        step()
-    torch.cuda.synchronize()
-    launches2 = ctypes.c_int64(0)
-    scan_ms_pipelined = lib.mrx_timing_scan_ms(ctypes.byref(launches2))
     lib.mrx_timing_enable(0)
     kernel = lib.mrx_last_kernel_name().decode()
+    # the same K steps strictly one after the other on ONE stream (the round-1 method), next to the headline
+    serial_ms = None
+    if nstreams > 1:
+        with torch.cuda.stream(streams[0]):
+            for _ in range(3):
+                rx.findall_async(batch, outs[0])
+            torch.cuda.synchronize()
+            a0 = time.perf_counter()
+            for _ in range(args.steps):
+                rx.findall_async(batch, outs[0])
+            torch.cuda.synchronize()
+            serial_ms = (time.perf_counter() - a0) / args.steps * 1e3
     # algorithmic bytes per launch (DESIGN.md "Measurement"): every input byte once,
     # + 8 B per span written to its slot + 4 B per text for the count
     alg_bytes = float(n) * L + 8.0 * total + 4.0 * n
@@ -396,11 +399,12 @@ def main():
                          "traffic": (measured_traffic(n, L) or (None, None))[0],
                          "traffic_source": (measured_traffic(n, L) or (None, None))[1],
                          "kernel_ms": round(scan_ms, 4), "launches_timed": int(launches.value),
-                         # kernel_ms: each launch alone on the device (a synchronisation between the timed steps) --
-                         # what `achieved` is priced with.  kernel_ms_pipelined: its duration in the steady state of
-                         # the timed region (with --streams 2 it overlaps the other stream's kernels and stretches;
-                         # rocprofv3 --kernel-trace --stats of this command shows this one; --streams 1: the same)
-                         "kernel_ms_pipelined": round(scan_ms_pipelined, 4), "streams": nstreams,
+                         # kernel_ms: each launch alone on the device (a synchronisation between the timed launches),
+                         # which is what `achieved` is priced with.  In the timed region of a --streams 2 run the
+                         # scans of the two streams run side by side, so a kernel trace of this command shows about
+                         # twice this duration per launch (two kernels share the device); profiles/
+                         # rNN_kernel_stats_streams1.csv is the trace of --streams 1, where the two agree.
+                         "kernel_timing": "isolated launches",
                          # real HBM traffic rate of the kernel next to what a plain float4 copy reaches
                          # on this part (6.29 TB/s measured, MI355X_MICROARCH.md) -- informational
                          "traffic_GBps": (round(measured_traffic(n, L)[0] / (scan_ms * 1e-3) / 1e9, 1)
@@ -408,6 +412,11 @@ def main():
                          "copy_GBps_measured_on_part": 6290.0,
                          "algorithmic_bytes_per_launch": int(alg_bytes)},
         }
+        if serial_ms is not None:
+            line["serial_one_stream"] = {"ms_per_step": round(serial_ms, 4),
+                                         "value": round(float(n) * L / (serial_ms * 1e-3) / 1e9, 3), "unit": "GB/s",
+                                         "hbm_frac_of_peak_whole_step": round(float(n) * L / (serial_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                         "note": "rank 0, the same K steps one after the other on one stream (round 1's method)"}
         if other is not None:
             line["other_ops"] = other
         if gather_info is not None:
