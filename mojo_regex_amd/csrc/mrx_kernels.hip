@@ -3993,7 +3993,13 @@ int findall_pieces(const mrx_handle* h, const Pieces& pc, int64_t n, int64_t* d_
 // per launch: the ramp-up and the tail of a launch weigh twice), which is more than the overlap returns.  What
 // does pay is overlapping WHOLE calls on two caller streams (bench.py --streams 2: 0.287 ms on the same box).
 // MRX_FINDALL_SPLIT=1 / mrx_debug_split_findall(1): on.
-std::atomic<int> g_split_findall{[] { const char* e = getenv("MRX_FINDALL_SPLIT"); return e ? atoi(e) : 0; }()};
+// (a named function, not a lambda: hipcc gave two namespace-scope lambdas of this shape ONE body -- the second
+// variable was initialised by the first one's getenv -- see env_int's other user, g_subs_group)
+static int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+std::atomic<int> g_split_findall{env_int("MRX_FINDALL_SPLIT", 0)};
 constexpr int64_t kSplitMinTexts = 1 << 18;
 struct SideStream {
   hipStream_t side = nullptr;
@@ -4400,7 +4406,7 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
 
 namespace {
 // mrx_debug_subs_group(): lanes per text in k_subs_wave (16 / 32 / 64), 0 = k_subs_emit only, -1 = by text length
-std::atomic<int> g_subs_group{[] { const char* e = getenv("MRX_SUBS_G"); return e ? atoi(e) : -1; }()};
+std::atomic<int> g_subs_group{env_int("MRX_SUBS_G", -1)};
 // regex.sub for streamable plans: streaming findall -> sizes -> prefix sums -> emit (see k_subs_*)
 int sub_from_spans(const mrx_handle* h, const Layout& lay, int64_t n, const std::vector<uint16_t>& rmap,
                    int64_t count, int64_t* out_off, uint8_t* out, int64_t out_cap, int64_t* total_bytes,

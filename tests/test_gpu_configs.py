@@ -304,3 +304,33 @@ def test_config4_program_on_the_bitset_nfa_kernel_at_full_size():
         assert have == want, i
         w = o.match_next(t, 0)
         assert (int(s1[i]), int(e1[i])) == (w if w else (-1, -1)), i
+
+
+@pytest.mark.gpu
+def test_default_routes_in_a_fresh_process():
+    """The switches of include/mrx_testing.h at their start-up values: a fresh interpreter (no test has touched
+    them) must take the kernels DESIGN.md names -- round 2 shipped for a while with `sub` on round 1's kernel
+    because two namespace-scope initialisers of the library had been given one body by the compiler."""
+    import os
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, torch; sys.path.insert(0, %r)\n"
+        "import mojo_regex_amd as M\n"
+        "from mojo_regex_amd import workloads as W\n"
+        "lib = M.load_library()\n"
+        "d = W.make_c2_batch(4096, 1024)\n"
+        "b = M.DeviceBatch.strided(d.reshape(-1), 1024, length=1024)\n"
+        "rx = M.compile_regex(b'[a-z]+\\\\d+')\n"
+        "rx.sub_dev(b'#', b, 0, out_cap=4096 * 2048); print('sub', lib.mrx_last_kernel_name().decode())\n"
+        "rx._dev_findall(b); print('findall', lib.mrx_last_kernel_name().decode())\n"
+        "rx.count(b); print('count', lib.mrx_last_kernel_name().decode())\n"
+        "rx.match_next(b); print('search', lib.mrx_last_kernel_name().decode())\n"
+        "rx.is_match(b); print('is_match', lib.mrx_last_kernel_name().decode())\n" % ROOT)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("MRX_")}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = dict(line.split() for line in r.stdout.strip().splitlines() if len(line.split()) == 2)
+    assert got == {"sub": "k_subs_wave", "findall": "k_stream_findall", "count": "k_stream_count", "search": "k_stream_search",
+                   "is_match": "k_is_match_byte"}, got
