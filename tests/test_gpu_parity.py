@@ -1622,6 +1622,42 @@ def test_fused_findall_back_to_back_calls_reuse_their_scratch():
         assert torch.equal(pre, p0) and torch.equal(sp[:t0], s0[:t0])
 
 
+def test_scratch_arena_survives_failed_calls():
+    """Calls that fail after they have taken scratch (a CSR batch whose offsets[n] is negative, a span buffer
+    that is too small) give their scratch back: the arena of the (thread, stream) does not grow over the
+    good calls that follow."""
+    _need_gpu()
+    import ctypes as C
+    lib = M.load_library()
+    rx = M.compile_regex(b"[a-z]+\\d+")
+    texts = _random_texts(np.random.default_rng(11), 4000, 200, b"abcxyz0123456789 ")
+    batch = M.DeviceBatch.from_texts(texts)
+    p0, s0, t0 = rx._dev_findall(batch)
+    for _ in range(3):
+        rx._dev_findall(batch)
+    torch.cuda.synchronize()
+    size0 = lib.mrx_debug_scratch_bytes()
+    bad_off = batch.offsets.clone()
+    bad_off[-1] = -5
+    prefix = torch.empty(batch.n + 1, dtype=torch.int64, device="cuda")
+    spans = torch.empty((max(t0, 64), 2), dtype=torch.int32, device="cuda")
+    total = C.c_int64(0)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for it in range(100):
+        if it % 5 == 0:
+            rc = lib.mrx_findall_dev(rx._h, C.c_void_p(batch.data.data_ptr()), C.c_void_p(bad_off.data_ptr()), batch.n,
+                                     C.c_void_p(prefix.data_ptr()), C.c_void_p(spans.data_ptr()), spans.shape[0], C.byref(total), stream)
+            assert rc != 0, "negative offsets[n] must be refused"
+            rc = lib.mrx_findall_dev(rx._h, C.c_void_p(batch.data.data_ptr()), C.c_void_p(batch.offsets.data_ptr()), batch.n,
+                                     C.c_void_p(prefix.data_ptr()), C.c_void_p(spans.data_ptr()), 8, C.byref(total), stream)
+            assert rc != 0 and total.value == t0, "a span buffer of 8 entries is too small: MRX_E_CAPACITY with the needed size"
+        p1, s1, t1 = rx._dev_findall(batch)
+        assert t1 == t0
+    torch.cuda.synchronize()
+    assert torch.equal(p1, p0) and torch.equal(s1[:t0], s0[:t0])
+    assert lib.mrx_debug_scratch_bytes() == size0, (lib.mrx_debug_scratch_bytes(), size0)
+
+
 AT_PATTERNS = [b"hello", b"[a-z]+\\d+", b"\\d+", b"[0-9]*", b"[a-z]*[0-9]+", b"^abc", b"^[a-z]+", b"a$", b"^abc$", b".*", b"",
                b"(x|y|foo|bar)+", b"(\\d{3})(\\d{3})(\\d{4})", b"hello world this is long", b"\\w+@\\w+\\.com", b"\\d{3}-\\d{4}",
                b"(foo|foobar)x", b"\\d+(\\.\\d+)?", b"[a-c]+[x-z]?", b"^[a-z]+[0-9]+$", b"^\\d+$", b"(a|b)*c", b"^(a|b)*c",
