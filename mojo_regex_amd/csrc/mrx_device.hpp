@@ -84,11 +84,54 @@ __device__ inline int find_literal(const uint8_t* needle, int nlen, const Text& 
 }
 
 // ---- NFAEngine's backtracking matcher on its flat program (BtProg, mrx_engines.hpp) ---------------
-struct BtCaps {   // spans of the capture groups 0..9 of one attempt; -1 = the group did not close
+// Spans of the capture groups 0..9 of one attempt; -1 = the group did not close.  Read and written through
+// select chains over constant indices only, so the twenty values stay in registers (an array indexed by a run-time
+// group id lives in scratch memory: a 'clear' per attempt and a write per group cost microseconds there).
+struct BtCaps {
   int s[10], e[10];
   __device__ __forceinline__ void clear() {
 #pragma unroll
     for (int g = 0; g < 10; ++g) s[g] = e[g] = -1;
+  }
+  __device__ __forceinline__ void set(int g, int a, int b) {
+#pragma unroll
+    for (int k = 0; k < 10; ++k) { s[k] = k == g ? a : s[k]; e[k] = k == g ? b : e[k]; }
+  }
+  __device__ __forceinline__ int gs(int g) const {
+    int v = -1;
+#pragma unroll
+    for (int k = 0; k < 10; ++k) v = k == g ? s[k] : v;
+    return v;
+  }
+  __device__ __forceinline__ int ge(int g) const {
+    int v = -1;
+#pragma unroll
+    for (int k = 0; k < 10; ++k) v = k == g ? e[k] : v;
+    return v;
+  }
+};
+// One int per nesting level (group starts, loop counters): the first six levels in registers, deeper ones in a
+// per-lane array (scratch) that patterns of ordinary depth never touch.
+struct BtLevels {
+  static constexpr int kReg = 6;
+  int r[kReg];
+  int deep[17];
+  __device__ __forceinline__ void set(int d, int v) {
+    if (d < kReg) {
+#pragma unroll
+      for (int k = 0; k < kReg; ++k) r[k] = k == d ? v : r[k];
+    } else {
+      deep[d < 17 ? d : 16] = v;
+    }
+  }
+  __device__ __forceinline__ int get(int d) const {
+    if (d < kReg) {
+      int v = 0;
+#pragma unroll
+      for (int k = 0; k < kReg; ++k) v = k == d ? r[k] : v;
+      return v;
+    }
+    return deep[d < 17 ? d : 16];
   }
 };
 __device__ __forceinline__ bool bt_in(const Ctx& c, int tbl, int which, int byte) {
@@ -113,8 +156,8 @@ __device__ inline int bt_match_at(const Ctx& c, const Text& t, int start, BtCaps
   int ch_pos[kBtChoices], ch_cnt[kBtChoices];
   int top_ip = 0, top_depth = 0, top_pos = 0, top_cnt = 0;
   bool have_top = false;
-  int gstart[kBtDepth];
-  int lcount[kBtDepth];   // LOOP: repetitions matched so far, per nesting depth
+  BtLevels gstart;        // OPEN / LOOP: where the group began, per nesting depth
+  BtLevels lcount;        // LOOP: repetitions matched so far, per nesting depth
   int ip = 0, pos = start, depth = 0, sp = 0;
   // ALT / LOOP leave a mark on the choice stack (cnt = kBtAltMark / kBtLoopMark): popping it on a failure means
   // "branch A failed: try B" / "this repetition failed: the loop is over"
@@ -149,7 +192,7 @@ __device__ inline int bt_match_at(const Ctx& c, const Text& t, int start, BtCaps
         }
         if (top_cnt == kBtLoopMark) {   // this repetition failed: the loop ends with what it has
           depth = top_depth;
-          if (lcount[depth < kBtDepth ? depth : kBtDepth - 1] < it.min) continue;   // too few: the group fails
+          if (lcount.get(depth) < it.min) continue;   // too few: the group fails
           pos = top_pos; ip = it.max;
           resumed = true;
           break;
@@ -172,7 +215,7 @@ __device__ inline int bt_match_at(const Ctx& c, const Text& t, int start, BtCaps
     const BtItem it = c.bt_items[ip];
     if (it.kind == BT_START) { if (pos != 0) failing = true; else ++ip; continue; }
     if (it.kind == BT_END) { if (pos != n) failing = true; else ++ip; continue; }
-    if (it.kind == BT_OPEN) { gstart[depth < kBtDepth ? depth : kBtDepth - 1] = pos; ++depth; ++ip; continue; }
+    if (it.kind == BT_OPEN) { gstart.set(depth, pos); ++depth; ++ip; continue; }
     if (it.kind == BT_FAIL) { failing = true; continue; }
     if (it.kind == BT_ALT) {
       if (sp + (have_top ? 1 : 0) >= kBtChoices) return -1;
@@ -195,28 +238,27 @@ __device__ inline int bt_match_at(const Ctx& c, const Text& t, int start, BtCaps
         cut_above(depth);
         pop_mark();
         lp = it.min;
-        const int dd = depth < kBtDepth ? depth : kBtDepth - 1;
-        ++lcount[dd];
+        const int reps = lcount.get(depth) + 1;
+        lcount.set(depth, reps);
         const BtItem li = c.bt_items[lp];
         if (mfm && req >= 0 && pos > req + 100) {   // nfa.mojo:1143-1144: the loop stops here, before the span is recorded
-          if (lcount[dd] >= li.min) ip = li.max; else failing = true;
+          if (reps >= li.min) ip = li.max; else failing = true;
           continue;
         }
-        if ((li.flags & BTF_CAPTURING) && li.gid >= 0 && li.gid < 10) { caps.s[li.gid] = gstart[dd]; caps.e[li.gid] = pos; }
+        if ((li.flags & BTF_CAPTURING) && li.gid >= 0 && li.gid < 10) caps.set(li.gid, gstart.get(depth), pos);
       } else {
-        const int dd = depth < kBtDepth ? depth : kBtDepth - 1;
-        gstart[dd] = pos; lcount[dd] = 0;
+        gstart.set(depth, pos); lcount.set(depth, 0);
       }
       const BtItem li = c.bt_items[lp];
       const BtItem le = c.bt_items[li.max - 1];          // its LOOP_END carries max
-      const int dd = depth < kBtDepth ? depth : kBtDepth - 1;
-      const int maxr = le.max == -1 ? n - gstart[dd] : le.max;
-      if (lcount[dd] < maxr && pos <= n) {               // one more repetition
+      const int maxr = le.max == -1 ? n - gstart.get(depth) : le.max;
+      const int reps_now = lcount.get(depth);
+      if (reps_now < maxr && pos <= n) {               // one more repetition
         if (sp + (have_top ? 1 : 0) >= kBtChoices) return -1;
         push_entry(lp, depth, pos, kBtLoopMark);
         ++depth;
         ip = lp + 1;
-      } else if (lcount[dd] >= li.min) {
+      } else if (reps_now >= li.min) {
         ip = li.max;
       } else {
         failing = true;
@@ -227,7 +269,7 @@ __device__ inline int bt_match_at(const Ctx& c, const Text& t, int start, BtCaps
       --depth;
       // the group's sequence has returned: no way back in
       cut_above(depth);
-      if ((it.flags & BTF_CAPTURING) && it.gid >= 0 && it.gid < 10) { caps.s[it.gid] = gstart[depth]; caps.e[it.gid] = pos; }
+      if ((it.flags & BTF_CAPTURING) && it.gid >= 0 && it.gid < 10) caps.set(it.gid, gstart.get(depth), pos);
       ++ip;
       continue;
     }
@@ -556,15 +598,23 @@ __device__ inline bool lazy_run(const Ctx& c, const Text& t, int start, int& ms,
   return true;
 }
 
+// BT (here and in the callers below): the kernel instantiation that carries the backtracking matcher's
+// interpreter.  Plans without a backtracker route run the BT = false instantiations, which are a third of the
+// registers (80 against 256 VGPRs and 3.6 KB of scratch: with the interpreter inlined the compiler keeps one
+// wavefront per SIMD resident, whatever the plan at hand needs).
+template <bool BT>
 __device__ inline bool engine_match_first(const Ctx& c, const Text& t, int start, int& ms, int& me) {
-  if (flag(c, PF_BT_FIRST)) return bt_engine_match_first(c, t, start, ms, me);   // NFAMatcher -> NFAEngine, matcher.mojo:380
+  if constexpr (BT)
+    if (flag(c, PF_BT_FIRST)) return bt_engine_match_first(c, t, start, ms, me);   // NFAMatcher -> NFAEngine, matcher.mojo:380
   if (c.p.kind == PLAN_LAZY) return lazy_run(c, t, start, ms, me);
   if (flag(c, PF_START_ANCHOR) && start > 0) return false;   // dfa.mojo:1866-1867
   return try_match_at(c, t, start, true, ms, me);
 }
 
+template <bool BT>
 __device__ inline bool engine_match_next(const Ctx& c, const Text& t, int start, int& ms, int& me) {
-  if (flag(c, PF_BT_SEARCH)) return bt_engine_match_next(c, t, start, ms, me);   // matcher.mojo:419
+  if constexpr (BT)
+    if (flag(c, PF_BT_SEARCH)) return bt_engine_match_next(c, t, start, ms, me);   // matcher.mojo:419
   if (c.p.kind == PLAN_LAZY) {
     if (flag(c, PF_HAS_MATCHER)) {  // first-byte filter
       int pos = start;
@@ -616,15 +666,17 @@ __device__ inline bool engine_match_next(const Ctx& c, const Text& t, int start,
 }
 
 // HybridMatcher.match_first, matcher.mojo:733-753
+template <bool BT>
 __device__ inline bool hybrid_match_first(const Ctx& c, const Text& t, int start, int& ms, int& me) {
   if (c.p.kind == PLAN_ANY) {
     if (start <= t.len) { ms = start; me = t.len; return true; }
     return false;
   }
-  return engine_match_first(c, t, start, ms, me);
+  return engine_match_first<BT>(c, t, start, ms, me);
 }
 
 // HybridMatcher.match_next, matcher.mojo:755-802
+template <bool BT>
 __device__ inline bool hybrid_match_next(const Ctx& c, const Text& t, int start, int& ms, int& me) {
   if (c.p.kind == PLAN_ANY) {
     if (start <= t.len) { ms = start; me = t.len; return true; }
@@ -645,16 +697,18 @@ __device__ inline bool hybrid_match_next(const Ctx& c, const Text& t, int start,
     if (t.pre_first != kPreUnknown && start <= t.pre_first) cand = t.pre_first;
     else cand = find_literal(c.pre, c.p.pre_len, t, start);
     if (cand < 0) return false;
-    return engine_match_next(c, t, cand, ms, me);
+    return engine_match_next<BT>(c, t, cand, ms, me);
   }
-  return engine_match_next(c, t, start, ms, me);
+  return engine_match_next<BT>(c, t, start, ms, me);
 }
 
 // DFAEngine.is_match through HybridMatcher.is_match, matcher.mojo:721-731, dfa.mojo:1815-1849
+template <bool BT>
 __device__ inline bool hybrid_is_match(const Ctx& c, const Text& t, int start) {
   int ms, me;
   if (c.p.kind == PLAN_ANY) return start <= t.len;
-  if (flag(c, PF_BT_FIRST)) return bt_engine_match_first(c, t, start, ms, me);
+  if constexpr (BT)
+    if (flag(c, PF_BT_FIRST)) return bt_engine_match_first(c, t, start, ms, me);
   if (c.p.kind == PLAN_LAZY) return lazy_run(c, t, start, ms, me);
   if (flag(c, PF_START_ANCHOR) && start > 0) return false;
   if (flag(c, PF_HAS_MATCHER) && c.p.nstates > 0) {
@@ -666,7 +720,7 @@ __device__ inline bool hybrid_is_match(const Ctx& c, const Text& t, int start) {
 }
 
 // HybridMatcher.match_all: calls emit(start, end) for every match, in order.
-template <class Emit>
+template <bool BT, class Emit>
 __device__ inline void for_each_match(const Ctx& c, const Text& t, Emit&& emit) {
   int ms, me;
   if (c.p.kind == PLAN_ANY) { emit(0, t.len); return; }
@@ -694,7 +748,7 @@ __device__ inline void for_each_match(const Ctx& c, const Text& t, Emit&& emit) 
       if (hit < 0) break;
       int start = hit;
       while (start > 0 && c.first[t.at(start - 1)]) --start;
-      if (engine_match_first(c, t, start, ms, me) && me > hit) {
+      if (engine_match_first<BT>(c, t, start, ms, me) && me > hit) {
         emit(ms, me);
         pos = me;
         if (pos <= hit) pos = hit + 1;
@@ -704,7 +758,8 @@ __device__ inline void for_each_match(const Ctx& c, const Text& t, Emit&& emit) 
     }
     return;
   }
-  if (flag(c, PF_BT_SEARCH)) { bt_engine_match_all(c, t, emit); return; }   // matcher.mojo:431
+  if constexpr (BT)
+    if (flag(c, PF_BT_SEARCH)) { bt_engine_match_all(c, t, emit); return; }   // matcher.mojo:431
   if (c.p.kind == PLAN_LAZY) {
     int pos = 0;
     if (flag(c, PF_HAS_MATCHER)) {
@@ -725,7 +780,7 @@ __device__ inline void for_each_match(const Ctx& c, const Text& t, Emit&& emit) 
   }
   // DFAEngine.match_all
   if (flag(c, PF_START_ANCHOR) || flag(c, PF_END_ANCHOR)) {
-    if (engine_match_next(c, t, 0, ms, me)) emit(ms, me);
+    if (engine_match_next<BT>(c, t, 0, ms, me)) emit(ms, me);
     return;
   }
   int pos = 0;
@@ -777,12 +832,12 @@ __device__ inline void for_each_match(const Ctx& c, const Text& t, Emit&& emit) 
 // replacement template (only read when use_groups).
 // use_groups: 0 = literal replacement, 1 = fixed-width group form, 2 = general groups
 // (NFAEngine.match_next_with_groups, matcher.mojo:1781-1822)
-template <class Sink>
+template <bool BT, class Sink>
 __device__ inline void sub_text(const Ctx& c, const Text& t, const uint8_t* repl, int repl_len,
                                 int use_groups, const ReplSeg* tpl, int ntpl, long long count,
                                 Sink& out) {
   if (t.len == 0) return;
-  if (use_groups == 2) {
+  if constexpr (BT) if (use_groups == 2) {
     int pos = 0, ms, me;
     long long reps = 0;
     BtCaps caps;
@@ -796,8 +851,8 @@ __device__ inline void sub_text(const Ctx& c, const Text& t, const uint8_t* repl
       for (int k = 0; k < ntpl; ++k) {   // _apply_template_groups, matcher.mojo:1624-1646
         const ReplSeg sg = tpl[k];
         if (sg.group_ref > 0) {
-          if (sg.group_ref <= 9 && caps.s[sg.group_ref] >= 0)
-            out.bytes(t.ptr + caps.s[sg.group_ref], caps.e[sg.group_ref] - caps.s[sg.group_ref]);
+          const int cs = sg.group_ref <= 9 ? caps.gs(sg.group_ref) : -1;
+          if (cs >= 0) out.bytes(t.ptr + cs, caps.ge(sg.group_ref) - cs);
         } else {
           out.bytes(repl + sg.start, sg.length);
         }
@@ -838,7 +893,7 @@ __device__ inline void sub_text(const Ctx& c, const Text& t, const uint8_t* repl
   long long reps = 0;
   int ms, me;
   while (pos <= t.len) {
-    if (!hybrid_match_next(c, t, pos, ms, me)) break;
+    if (!hybrid_match_next<BT>(c, t, pos, ms, me)) break;
     if ((me == ms ? me + 1 : me) <= pos) break;   // (as above: a match in front of pos; upstream does not terminate)
     if (ms > pos) out.bytes(t.ptr + pos, ms - pos);
     if (use_groups) apply_tpl(ms);

@@ -130,7 +130,8 @@ __device__ __forceinline__ void mrx_stg_span(int32_t* p, int a, int b) {
 
 enum { OP_MATCH_FIRST = 0, OP_SEARCH = 1, OP_IS_MATCH = 2, OP_CAPTURES = 3 };
 
-template <int OP>
+// BT: the instantiation that carries the backtracking matcher (see engine_match_first in mrx_device.hpp)
+template <int OP, bool BT = false>
 __global__ __launch_bounds__(kBlock) void k_match(DevPlan p, const uint8_t* __restrict__ blob,
                                                   Layout lay, int64_t n, int32_t* __restrict__ out_s,
                                                   int32_t* __restrict__ out_e,
@@ -143,21 +144,21 @@ __global__ __launch_bounds__(kBlock) void k_match(DevPlan p, const uint8_t* __re
     int ms = -1, me = -1;
     if (OP == OP_MATCH_FIRST) {
       // regex.match_first, matcher.mojo:1396-1415: keep only matches starting at 0
-      if (!(hybrid_match_first(c, t, 0, ms, me) && ms == 0)) ms = me = -1;
+      if (!(hybrid_match_first<BT>(c, t, 0, ms, me) && ms == 0)) ms = me = -1;
       out_s[i] = ms; out_e[i] = me;
     } else if (OP == OP_SEARCH) {
-      if (!hybrid_match_next(c, t, 0, ms, me)) ms = me = -1;
+      if (!hybrid_match_next<BT>(c, t, 0, ms, me)) ms = me = -1;
       out_s[i] = ms; out_e[i] = me;
     } else if (OP == OP_IS_MATCH) {
-      out_flag[i] = hybrid_is_match(c, t, 0) ? 1 : 0;
+      out_flag[i] = hybrid_is_match<BT>(c, t, 0) ? 1 : 0;
     } else {
-      if (p.fixed_total < 0) {
+      if constexpr (BT) if (p.fixed_total < 0) {
         // general groups: NFAEngine.match_next_with_groups (nfa.mojo:500-574) on the flat program
         const int g = p.bt_ngroups;
         int32_t* o = out_s + i * (int64_t)(g + 1) * 2;
         BtCaps caps;
         if (bt_match_next_with_groups(c, t, 0, ms, me, caps)) {
-          for (int k = 1; k <= g; ++k) { o[(k - 1) * 2] = caps.s[k]; o[(k - 1) * 2 + 1] = caps.e[k]; }
+          for (int k = 1; k <= g; ++k) { o[(k - 1) * 2] = caps.gs(k); o[(k - 1) * 2 + 1] = caps.ge(k); }
           o[g * 2] = ms; o[g * 2 + 1] = me;
         } else {
           for (int k = 0; k < (g + 1) * 2; ++k) o[k] = -1;
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(kBlock) void k_match(DevPlan p, const uint8_t* __re
       // search + fixed-width groups in NFAEngine._match_group order (nfa.mojo:1057-1103)
       const int g = p.fixed_ngroups;
       int32_t* o = out_s + i * (int64_t)(g + 1) * 2;
-      if (hybrid_match_next(c, t, 0, ms, me)) {
+      if (hybrid_match_next<BT>(c, t, 0, ms, me)) {
         for (int k = 1; k <= g; ++k) {
           o[(k - 1) * 2] = ms + p.fixed_off[k];
           o[(k - 1) * 2 + 1] = ms + p.fixed_off[k] + p.fixed_w[k];
@@ -1039,7 +1040,7 @@ __global__ __launch_bounds__(kBlock) void k_slots_gather_wide(Layout lay, int64_
 }
 
 
-template <int MODE>
+template <int MODE, bool BT = false>
 __global__ __launch_bounds__(kBlock) void k_findall(DevPlan p, const uint8_t* __restrict__ blob,
                                                     Layout lay, int64_t n,
                                                     int32_t* __restrict__ counts,
@@ -1052,11 +1053,11 @@ __global__ __launch_bounds__(kBlock) void k_findall(DevPlan p, const uint8_t* __
     const Text t = lay.text(i);
     if (MODE == FA_COUNT) {
       int k = 0;
-      for_each_match(c, t, [&](int, int) { ++k; });
+      for_each_match<BT>(c, t, [&](int, int) { ++k; });
       counts[i] = k;
     } else {
       int64_t w = prefix[i];
-      for_each_match(c, t, [&](int s, int e) {
+      for_each_match<BT>(c, t, [&](int s, int e) {
         if (w < span_cap) { spans[2 * w] = s; spans[2 * w + 1] = e; }
         ++w;
       });
@@ -3120,7 +3121,7 @@ __global__ __launch_bounds__(kBlock) void k_subs_wave(int64_t n, const uint8_t* 
 
 enum { SUB_SIZE = 0, SUB_EMIT = 1 };
 
-template <int MODE>
+template <int MODE, bool BT = false>
 __global__ __launch_bounds__(kBlock) void k_sub(DevPlan p, const uint8_t* __restrict__ blob,
                                                 Layout lay, int64_t n,
                                                 const uint8_t* __restrict__ repl, int repl_len,
@@ -3136,11 +3137,11 @@ __global__ __launch_bounds__(kBlock) void k_sub(DevPlan p, const uint8_t* __rest
     const Text t = lay.text(i);
     if (MODE == SUB_SIZE) {
       SizeSink s;
-      sub_text(c, t, repl, repl_len, use_groups, tpl, ntpl, count, s);
+      sub_text<BT>(c, t, repl, repl_len, use_groups, tpl, ntpl, count, s);
       sizes[i] = s.n;
     } else {
       WriteSink s{out, out_off[i], out_cap};
-      sub_text(c, t, repl, repl_len, use_groups, tpl, ntpl, count, s);
+      sub_text<BT>(c, t, repl, repl_len, use_groups, tpl, ntpl, count, s);
     }
   }
 }
@@ -3567,6 +3568,10 @@ int check_lds(const mrx_handle* h) {
   return MRX_OK;
 }
 
+// plans with a backtracker route take the kernel instantiations that carry its interpreter (k_match<., true> ...)
+static bool plan_uses_backtracker(const mrx_handle* h) {
+  return (h->hp.dev.flags & (PF_BT_FIRST | PF_BT_SEARCH)) != 0 && h->hp.dev.bt_nitems > 0;
+}
 // NFAEngine's literal prefilter (nfa.mojo:86-143, 391-498, 169-340) in front of the lane-per-text kernels:
 // every backtracker-routed search starts with String.find(literal) -- and, on the '.*' fast paths, with a
 // look for a newline and String.rfind(literal) -- over the WHOLE text, per lane and byte by byte in the
@@ -3643,8 +3648,8 @@ int run_match(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d_s, i
       g_last_kernel = "k_bstep_search";
     } else
     if (big && !wave) {   // many short texts: the literal restatement, one lane per text
-      hipLaunchKernelGGL(k_match<OP>, dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s, h->hp.dev,
-                         H_BLOB(h), lay, n, d_s, d_e, d_flag);
+      hipLaunchKernelGGL((k_match<OP, false>), dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s, h->hp.dev,
+                         H_BLOB(h), lay, n, d_s, d_e, d_flag);   // (a stepper plan: no backtracker route)
       g_last_kernel = "k_match";
     } else if (big) {
       hipLaunchKernelGGL((k_req_wave<STEP_SEARCH, 0, 1>), dim3(reqwave_grid(n)), dim3(64 * kRqWaves),
@@ -3676,8 +3681,12 @@ int run_match(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d_s, i
     Layout layp = lay;
     if ((OP == OP_SEARCH && (h->hp.dev.flags & PF_BT_SEARCH)) || (OP == OP_CAPTURES && h->hp.fixed_total < 0))
       if (int rc = bt_prepass(h, lay, n, s, &layp)) return rc;
-    hipLaunchKernelGGL(k_match<OP>, dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s, h->hp.dev,
-                       H_BLOB(h), layp, n, d_s, d_e, d_flag);
+    if (plan_uses_backtracker(h) || (OP == OP_CAPTURES && h->hp.fixed_total < 0))
+      hipLaunchKernelGGL((k_match<OP, true>), dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s, h->hp.dev,
+                         H_BLOB(h), layp, n, d_s, d_e, d_flag);
+    else
+      hipLaunchKernelGGL((k_match<OP, false>), dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s, h->hp.dev,
+                         H_BLOB(h), layp, n, d_s, d_e, d_flag);
     g_last_kernel = "k_match";
   }
   HIP_TRY(hipGetLastError());
@@ -4298,9 +4307,12 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
       } else {
         if (p.flags & PF_BT_SEARCH)
           if (int rc = bt_prepass(h, lay, n, s, &lay_pre)) return rc;
-        hipLaunchKernelGGL(k_findall<FA_COUNT>, dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s,
-                           p, H_BLOB(h), lay_pre, n, d_counts, (const int64_t*)nullptr, (int32_t*)nullptr,
-                           (int64_t)0);
+        if (plan_uses_backtracker(h))
+          hipLaunchKernelGGL((k_findall<FA_COUNT, true>), dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s,
+                             p, H_BLOB(h), lay_pre, n, d_counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0);
+        else
+          hipLaunchKernelGGL((k_findall<FA_COUNT, false>), dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s,
+                             p, H_BLOB(h), lay_pre, n, d_counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0);
       }
       g_last_kernel = req_wave ? "k_req_wave" : step_ok ? (wstep_bits ? "k_bstep_count" : wstep_empty ? "k_estep_count" : step_split > 0 ? "k_step_count+k_req_wave" : "k_step_count")
                                                         : "k_findall_count";
@@ -4375,8 +4387,12 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
         if (step_split > 0) MRX_REQWAVE_LAUNCH(STEP_EMIT, h, lay2, n, d_counts, d_prefix, d_spans, span_cap, s);
         }
       } else
-        hipLaunchKernelGGL(k_findall<FA_EMIT>, dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s, p,
-                           H_BLOB(h), lay_pre, n, (int32_t*)nullptr, d_prefix, d_spans, span_cap);
+        if (plan_uses_backtracker(h))
+          hipLaunchKernelGGL((k_findall<FA_EMIT, true>), dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s, p,
+                             H_BLOB(h), lay_pre, n, (int32_t*)nullptr, d_prefix, d_spans, span_cap);
+        else
+          hipLaunchKernelGGL((k_findall<FA_EMIT, false>), dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s, p,
+                             H_BLOB(h), lay_pre, n, (int32_t*)nullptr, d_prefix, d_spans, span_cap);
     }
     HIP_TRY(hipGetLastError());
   }
@@ -5013,9 +5029,12 @@ static int run_count_any(const mrx_handle* h, const Layout& lay, int64_t n, int3
       Layout layp = lay;
       if (h->hp.dev.flags & PF_BT_SEARCH)
         if (int rc = bt_prepass(h, lay, n, s, &layp)) return rc;
-      hipLaunchKernelGGL(k_findall<FA_COUNT>, dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s,
-                         h->hp.dev, H_BLOB(h), layp, n, counts, (const int64_t*)nullptr, (int32_t*)nullptr,
-                         (int64_t)0);
+      if (plan_uses_backtracker(h))
+        hipLaunchKernelGGL((k_findall<FA_COUNT, true>), dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s,
+                           h->hp.dev, H_BLOB(h), layp, n, counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0);
+      else
+        hipLaunchKernelGGL((k_findall<FA_COUNT, false>), dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s,
+                           h->hp.dev, H_BLOB(h), layp, n, counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0);
       g_last_kernel = "k_findall_count";
     }
   }
@@ -5097,16 +5116,21 @@ int mrx_sub_dev(const mrx_handle* h, const char* repl, size_t repl_len, int64_t 
   if (!tpl.empty())
     HIP_TRY(hipMemcpyAsync(d_tpl, tpl.data(), sizeof(ReplSeg) * tpl.size(), hipMemcpyHostToDevice, s));
   Layout lay{d, off, 0, nullptr, 0};
+  const bool sub_bt = plan_uses_backtracker(h) || general_groups;
   if ((h->hp.dev.flags & PF_BT_SEARCH) || general_groups) {
     const Layout plain = lay;
     if (int rc = bt_prepass(h, plain, n, s, &lay)) return rc;
   }
   if (n > 0) {
     ScanTimer tm(s);
-    hipLaunchKernelGGL(k_sub<SUB_SIZE>, dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s,
-                       h->hp.dev, H_BLOB(h), lay, n, d_repl, (int)r.size(), general_groups ? 2 : groups ? 1 : 0, d_tpl,
-                       (int)tpl.size(), (long long)count, d_sizes, (const int64_t*)nullptr,
-                       (uint8_t*)nullptr, (int64_t)0);
+    if (sub_bt)
+      hipLaunchKernelGGL((k_sub<SUB_SIZE, true>), dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s,
+                         h->hp.dev, H_BLOB(h), lay, n, d_repl, (int)r.size(), general_groups ? 2 : groups ? 1 : 0, d_tpl,
+                         (int)tpl.size(), (long long)count, d_sizes, (const int64_t*)nullptr, (uint8_t*)nullptr, (int64_t)0);
+    else
+      hipLaunchKernelGGL((k_sub<SUB_SIZE, false>), dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s,
+                         h->hp.dev, H_BLOB(h), lay, n, d_repl, (int)r.size(), general_groups ? 2 : groups ? 1 : 0, d_tpl,
+                         (int)tpl.size(), (long long)count, d_sizes, (const int64_t*)nullptr, (uint8_t*)nullptr, (int64_t)0);
     g_last_kernel = "k_sub_size";
     HIP_TRY(hipGetLastError());
     tm.stop();
@@ -5120,9 +5144,14 @@ int mrx_sub_dev(const mrx_handle* h, const char* repl, size_t repl_len, int64_t 
   if (tot > out_cap) {
     rc = fail(MRX_E_CAPACITY, "output buffer too small: need " + std::to_string(tot));
   } else if (n > 0 && tot > 0) {
-    hipLaunchKernelGGL(k_sub<SUB_EMIT>, dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s,
-                       h->hp.dev, H_BLOB(h), lay, n, d_repl, (int)r.size(), general_groups ? 2 : groups ? 1 : 0, d_tpl,
-                       (int)tpl.size(), (long long)count, (int64_t*)nullptr, out_off, out, out_cap);
+    if (sub_bt)
+      hipLaunchKernelGGL((k_sub<SUB_EMIT, true>), dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s,
+                         h->hp.dev, H_BLOB(h), lay, n, d_repl, (int)r.size(), general_groups ? 2 : groups ? 1 : 0, d_tpl,
+                         (int)tpl.size(), (long long)count, (int64_t*)nullptr, out_off, out, out_cap);
+    else
+      hipLaunchKernelGGL((k_sub<SUB_EMIT, false>), dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s,
+                         h->hp.dev, H_BLOB(h), lay, n, d_repl, (int)r.size(), general_groups ? 2 : groups ? 1 : 0, d_tpl,
+                         (int)tpl.size(), (long long)count, (int64_t*)nullptr, out_off, out, out_cap);
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(scratch_free(d_repl, s));
