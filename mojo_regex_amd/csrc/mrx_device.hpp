@@ -84,55 +84,24 @@ __device__ inline int find_literal(const uint8_t* needle, int nlen, const Text& 
 }
 
 // ---- NFAEngine's backtracking matcher on its flat program (BtProg, mrx_engines.hpp) ---------------
-// Spans of the capture groups 0..9 of one attempt; -1 = the group did not close.  Read and written through
-// select chains over constant indices only, so the twenty values stay in registers (an array indexed by a run-time
-// group id lives in scratch memory: a 'clear' per attempt and a write per group cost microseconds there).
+// Spans of the capture groups 0..9 of one attempt; -1 = the group did not close.  (Plain per-lane arrays: keeping
+// the twenty values in registers through select chains was measured 15 % slower on the group-swapping sub of the
+// reference's benchmark list -- the interpreter is short of registers as it is.)
 struct BtCaps {
   int s[10], e[10];
   __device__ __forceinline__ void clear() {
 #pragma unroll
     for (int g = 0; g < 10; ++g) s[g] = e[g] = -1;
   }
-  __device__ __forceinline__ void set(int g, int a, int b) {
-#pragma unroll
-    for (int k = 0; k < 10; ++k) { s[k] = k == g ? a : s[k]; e[k] = k == g ? b : e[k]; }
-  }
-  __device__ __forceinline__ int gs(int g) const {
-    int v = -1;
-#pragma unroll
-    for (int k = 0; k < 10; ++k) v = k == g ? s[k] : v;
-    return v;
-  }
-  __device__ __forceinline__ int ge(int g) const {
-    int v = -1;
-#pragma unroll
-    for (int k = 0; k < 10; ++k) v = k == g ? e[k] : v;
-    return v;
-  }
+  __device__ __forceinline__ void set(int g, int a, int b) { s[g] = a; e[g] = b; }
+  __device__ __forceinline__ int gs(int g) const { return s[g]; }
+  __device__ __forceinline__ int ge(int g) const { return e[g]; }
 };
-// One int per nesting level (group starts, loop counters): the first six levels in registers, deeper ones in a
-// per-lane array (scratch) that patterns of ordinary depth never touch.
+// One int per nesting level (group starts, loop counters)
 struct BtLevels {
-  static constexpr int kReg = 6;
-  int r[kReg];
-  int deep[17];
-  __device__ __forceinline__ void set(int d, int v) {
-    if (d < kReg) {
-#pragma unroll
-      for (int k = 0; k < kReg; ++k) r[k] = k == d ? v : r[k];
-    } else {
-      deep[d < 17 ? d : 16] = v;
-    }
-  }
-  __device__ __forceinline__ int get(int d) const {
-    if (d < kReg) {
-      int v = 0;
-#pragma unroll
-      for (int k = 0; k < kReg; ++k) v = k == d ? r[k] : v;
-      return v;
-    }
-    return deep[d < 17 ? d : 16];
-  }
+  int v[17];
+  __device__ __forceinline__ void set(int d, int x) { v[d < 17 ? d : 16] = x; }
+  __device__ __forceinline__ int get(int d) const { return v[d < 17 ? d : 16]; }
 };
 __device__ __forceinline__ bool bt_in(const Ctx& c, int tbl, int which, int byte) {
   return (c.bt_tbl[(tbl * 3 + which) * 32 + (byte >> 3)] >> (byte & 7)) & 1;
