@@ -116,6 +116,10 @@ __device__ inline int bt_run(const Ctx& c, const Text& t, int tbl, int which, in
 // nfa.mojo:657-1443 on the flat program.  Returns the end of the match or -1; caps receives the groups
 // that closed (the last closing of a group wins, as the reference's append-only list read back to front).
 constexpr int kBtChoices = 32, kBtDepth = 17;
+// STACK = false: the plan is a deterministic chain (DevPlan::bt_flags bit 5, see mrx_plan.cpp): no ALT / LOOP items,
+// and a shorter count of a quantified leaf can never rescue the sequence behind it, so a failure is final -- the
+// choice stack, its arrays and its retry loop are compiled out.
+template <bool STACK>
 __device__ inline int bt_match_at(const Ctx& c, const Text& t, int start, BtCaps& caps, bool mfm, int req) {
   const int n = t.len, nitems = c.p.bt_nitems;
   // choice stack: the newest entry lives in registers (top_*), the rest in per-lane arrays -- a greedy leaf
@@ -149,6 +153,7 @@ __device__ inline int bt_match_at(const Ctx& c, const Text& t, int start, BtCaps
   bool failing = false;
   while (true) {
     if (failing) {   // back to the innermost open choice with a smaller count left (nfa.mojo:1276-1309)
+      if constexpr (!STACK) return -1;
       bool resumed = false;
       while (have_top || sp > 0) {
         if (!have_top) { --sp; top_ip = ch_ip[sp]; top_depth = ch_depth[sp]; top_pos = ch_pos[sp]; top_cnt = ch_cnt[sp]; }
@@ -186,6 +191,9 @@ __device__ inline int bt_match_at(const Ctx& c, const Text& t, int start, BtCaps
     if (it.kind == BT_END) { if (pos != n) failing = true; else ++ip; continue; }
     if (it.kind == BT_OPEN) { gstart.set(depth, pos); ++depth; ++ip; continue; }
     if (it.kind == BT_FAIL) { failing = true; continue; }
+    if constexpr (!STACK)
+      if (it.kind == BT_ALT || it.kind == BT_ALT_END || it.kind == BT_ALT_CLOSE || it.kind == BT_LOOP || it.kind == BT_LOOP_END)
+        return -1;   // (never in a chain program)
     if (it.kind == BT_ALT) {
       if (sp + (have_top ? 1 : 0) >= kBtChoices) return -1;
       push_entry(ip, depth, pos, kBtAltMark);
@@ -255,7 +263,7 @@ __device__ inline int bt_match_at(const Ctx& c, const Text& t, int start, BtCaps
         cnt = r < maxc ? r : maxc;
         if (cnt < it.min) { failing = true; continue; }
         if (pos + cnt > far100) { failing = true; continue; }
-        if (cnt > it.min) {
+        if constexpr (STACK) if (cnt > it.min) {
           if (sp + (have_top ? 1 : 0) >= kBtChoices) return -1;   // (the host refuses programs that could get here)
           push_entry(ip, depth, pos, cnt);
         }
@@ -297,6 +305,7 @@ __device__ inline bool bt_contains_literal(const Ctx& c, const Text& t, int star
   return pos >= 0 && pos + c.p.bt_lit_len <= end;
 }
 // NFAEngine.match_next_with_groups, nfa.mojo:500-574
+template <bool STACK>
 __device__ inline bool bt_match_next_with_groups(const Ctx& c, const Text& t, int start, int& ms, int& me, BtCaps& caps) {
   int search_pos = start;
   if (c.p.bt_flags & 1) {   // literal prefilter
@@ -307,7 +316,7 @@ __device__ inline bool bt_match_next_with_groups(const Ctx& c, const Text& t, in
       if (c.p.bt_lit_len > 0 && !(c.p.bt_flags & 2)) try_pos = lp - c.p.bt_pattern_len > 0 ? lp - c.p.bt_pattern_len : 0;
       while (try_pos <= lp) {
         caps.clear();
-        const int end = bt_match_at(c, t, try_pos, caps, false, -1);
+        const int end = bt_match_at<STACK>(c, t, try_pos, caps, false, -1);
         if (end >= 0 && bt_contains_literal(c, t, try_pos, end)) { ms = try_pos; me = end; return true; }
         ++try_pos;
       }
@@ -317,7 +326,7 @@ __device__ inline bool bt_match_next_with_groups(const Ctx& c, const Text& t, in
   }
   while (search_pos <= t.len) {
     caps.clear();
-    const int end = bt_match_at(c, t, search_pos, caps, false, -1);
+    const int end = bt_match_at<STACK>(c, t, search_pos, caps, false, -1);
     if (end >= 0) { ms = search_pos; me = end; return true; }
     ++search_pos;
   }
@@ -325,9 +334,10 @@ __device__ inline bool bt_match_next_with_groups(const Ctx& c, const Text& t, in
 }
 
 // NFAEngine.match_first, nfa.mojo:342-389 (match_first_mode, required_start_pos = start)
+template <bool STACK>
 __device__ inline bool bt_engine_match_first(const Ctx& c, const Text& t, int start, int& ms, int& me) {
   BtCaps caps;
-  const int end = bt_match_at(c, t, start, caps, true, start);
+  const int end = bt_match_at<STACK>(c, t, start, caps, true, start);
   if (end < 0) return false;
   ms = start; me = end;
   return true;
@@ -350,6 +360,7 @@ __device__ inline int bt_rfind_literal(const Ctx& c, const Text& t) {
   return -1;
 }
 // NFAEngine.match_next, nfa.mojo:391-498.  starts_dotstar / ends_dotstar: DevPlan::bt_flags bits 2 / 3.
+template <bool STACK>
 __device__ inline bool bt_engine_match_next(const Ctx& c, const Text& t, int start, int& ms, int& me) {
   const bool lit_opt = (c.p.bt_flags & 1) != 0, prefix_lit = (c.p.bt_flags & 2) != 0;
   if ((c.p.bt_flags & 4) && lit_opt && !bt_has_newline(t)) {   // .* prefix with a literal behind it
@@ -371,7 +382,7 @@ __device__ inline bool bt_engine_match_next(const Ctx& c, const Text& t, int sta
       int try_pos = lp;
       if (c.p.bt_lit_len > 0 && !prefix_lit) try_pos = lp - c.p.bt_pattern_len > 0 ? lp - c.p.bt_pattern_len : 0;
       while (try_pos <= lp) {
-        const int end = bt_match_at(c, t, try_pos, caps, false, -1);
+        const int end = bt_match_at<STACK>(c, t, try_pos, caps, false, -1);
         if (end >= 0 && bt_contains_literal(c, t, try_pos, end)) { ms = try_pos; me = end; return true; }
         ++try_pos;
       }
@@ -380,14 +391,14 @@ __device__ inline bool bt_engine_match_next(const Ctx& c, const Text& t, int sta
     return false;
   }
   while (search_pos <= t.len) {
-    const int end = bt_match_at(c, t, search_pos, caps, false, -1);
+    const int end = bt_match_at<STACK>(c, t, search_pos, caps, false, -1);
     if (end >= 0) { ms = search_pos; me = end; return true; }
     ++search_pos;
   }
   return false;
 }
 // NFAEngine.match_all, nfa.mojo:169-340
-template <class Emit>
+template <bool STACK, class Emit>
 __device__ inline void bt_engine_match_all(const Ctx& c, const Text& t, Emit&& emit) {
   const bool lit_opt = (c.p.bt_flags & 1) != 0, prefix_lit = (c.p.bt_flags & 2) != 0;
   int current_pos = 0;
@@ -414,7 +425,7 @@ __device__ inline void bt_engine_match_all(const Ctx& c, const Text& t, Emit&& e
       const int max_positions = lp - try_pos + 1 < 5 ? lp - try_pos + 1 : 5;
       int tried = 0;
       while (try_pos <= lp && try_pos <= t.len && tried < max_positions) {
-        const int end = bt_match_at(c, t, try_pos, caps, false, -1);
+        const int end = bt_match_at<STACK>(c, t, try_pos, caps, false, -1);
         if (end >= 0 && bt_contains_literal(c, t, try_pos, end)) {
           emit(try_pos, end);
           current_pos = end == try_pos ? try_pos + 1 : end;
@@ -429,7 +440,7 @@ __device__ inline void bt_engine_match_all(const Ctx& c, const Text& t, Emit&& e
     return;
   }
   while (current_pos <= t.len) {
-    const int end = bt_match_at(c, t, current_pos, caps, false, -1);
+    const int end = bt_match_at<STACK>(c, t, current_pos, caps, false, -1);
     if (end >= 0) {
       emit(current_pos, end);
       current_pos = end == current_pos ? current_pos + 1 : end;
@@ -571,19 +582,19 @@ __device__ inline bool lazy_run(const Ctx& c, const Text& t, int start, int& ms,
 // interpreter.  Plans without a backtracker route run the BT = false instantiations, which are a third of the
 // registers (80 against 256 VGPRs and 3.6 KB of scratch: with the interpreter inlined the compiler keeps one
 // wavefront per SIMD resident, whatever the plan at hand needs).
-template <bool BT>
+template <int BT>
 __device__ inline bool engine_match_first(const Ctx& c, const Text& t, int start, int& ms, int& me) {
   if constexpr (BT)
-    if (flag(c, PF_BT_FIRST)) return bt_engine_match_first(c, t, start, ms, me);   // NFAMatcher -> NFAEngine, matcher.mojo:380
+    if (flag(c, PF_BT_FIRST)) return bt_engine_match_first<BT == 1>(c, t, start, ms, me);   // NFAMatcher -> NFAEngine, matcher.mojo:380
   if (c.p.kind == PLAN_LAZY) return lazy_run(c, t, start, ms, me);
   if (flag(c, PF_START_ANCHOR) && start > 0) return false;   // dfa.mojo:1866-1867
   return try_match_at(c, t, start, true, ms, me);
 }
 
-template <bool BT>
+template <int BT>
 __device__ inline bool engine_match_next(const Ctx& c, const Text& t, int start, int& ms, int& me) {
   if constexpr (BT)
-    if (flag(c, PF_BT_SEARCH)) return bt_engine_match_next(c, t, start, ms, me);   // matcher.mojo:419
+    if (flag(c, PF_BT_SEARCH)) return bt_engine_match_next<BT == 1>(c, t, start, ms, me);   // matcher.mojo:419
   if (c.p.kind == PLAN_LAZY) {
     if (flag(c, PF_HAS_MATCHER)) {  // first-byte filter
       int pos = start;
@@ -635,7 +646,7 @@ __device__ inline bool engine_match_next(const Ctx& c, const Text& t, int start,
 }
 
 // HybridMatcher.match_first, matcher.mojo:733-753
-template <bool BT>
+template <int BT>
 __device__ inline bool hybrid_match_first(const Ctx& c, const Text& t, int start, int& ms, int& me) {
   if (c.p.kind == PLAN_ANY) {
     if (start <= t.len) { ms = start; me = t.len; return true; }
@@ -645,7 +656,7 @@ __device__ inline bool hybrid_match_first(const Ctx& c, const Text& t, int start
 }
 
 // HybridMatcher.match_next, matcher.mojo:755-802
-template <bool BT>
+template <int BT>
 __device__ inline bool hybrid_match_next(const Ctx& c, const Text& t, int start, int& ms, int& me) {
   if (c.p.kind == PLAN_ANY) {
     if (start <= t.len) { ms = start; me = t.len; return true; }
@@ -672,12 +683,12 @@ __device__ inline bool hybrid_match_next(const Ctx& c, const Text& t, int start,
 }
 
 // DFAEngine.is_match through HybridMatcher.is_match, matcher.mojo:721-731, dfa.mojo:1815-1849
-template <bool BT>
+template <int BT>
 __device__ inline bool hybrid_is_match(const Ctx& c, const Text& t, int start) {
   int ms, me;
   if (c.p.kind == PLAN_ANY) return start <= t.len;
   if constexpr (BT)
-    if (flag(c, PF_BT_FIRST)) return bt_engine_match_first(c, t, start, ms, me);
+    if (flag(c, PF_BT_FIRST)) return bt_engine_match_first<BT == 1>(c, t, start, ms, me);
   if (c.p.kind == PLAN_LAZY) return lazy_run(c, t, start, ms, me);
   if (flag(c, PF_START_ANCHOR) && start > 0) return false;
   if (flag(c, PF_HAS_MATCHER) && c.p.nstates > 0) {
@@ -689,7 +700,7 @@ __device__ inline bool hybrid_is_match(const Ctx& c, const Text& t, int start) {
 }
 
 // HybridMatcher.match_all: calls emit(start, end) for every match, in order.
-template <bool BT, class Emit>
+template <int BT, class Emit>
 __device__ inline void for_each_match(const Ctx& c, const Text& t, Emit&& emit) {
   int ms, me;
   if (c.p.kind == PLAN_ANY) { emit(0, t.len); return; }
@@ -728,7 +739,7 @@ __device__ inline void for_each_match(const Ctx& c, const Text& t, Emit&& emit) 
     return;
   }
   if constexpr (BT)
-    if (flag(c, PF_BT_SEARCH)) { bt_engine_match_all(c, t, emit); return; }   // matcher.mojo:431
+    if (flag(c, PF_BT_SEARCH)) { bt_engine_match_all<BT == 1>(c, t, emit); return; }   // matcher.mojo:431
   if (c.p.kind == PLAN_LAZY) {
     int pos = 0;
     if (flag(c, PF_HAS_MATCHER)) {
@@ -801,7 +812,7 @@ __device__ inline void for_each_match(const Ctx& c, const Text& t, Emit&& emit) 
 // replacement template (only read when use_groups).
 // use_groups: 0 = literal replacement, 1 = fixed-width group form, 2 = general groups
 // (NFAEngine.match_next_with_groups, matcher.mojo:1781-1822)
-template <bool BT, class Sink>
+template <int BT, class Sink>
 __device__ inline void sub_text(const Ctx& c, const Text& t, const uint8_t* repl, int repl_len,
                                 int use_groups, const ReplSeg* tpl, int ntpl, long long count,
                                 Sink& out) {
@@ -811,7 +822,7 @@ __device__ inline void sub_text(const Ctx& c, const Text& t, const uint8_t* repl
     long long reps = 0;
     BtCaps caps;
     while (pos <= t.len) {
-      if (!bt_match_next_with_groups(c, t, pos, ms, me, caps)) break;
+      if (!bt_match_next_with_groups<BT == 1>(c, t, pos, ms, me, caps)) break;
       // NFAEngine's literal prefilter backs up to literal_pos - len(pattern) without looking at `start`
       // (nfa.mojo:531-533): it can hand back a match that lies in front of `pos`.  Upstream the loop of
       // CompiledRegex.sub then never advances; here the replacing stops (no result to agree with).

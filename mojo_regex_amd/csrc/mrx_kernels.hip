@@ -131,7 +131,7 @@ __device__ __forceinline__ void mrx_stg_span(int32_t* p, int a, int b) {
 enum { OP_MATCH_FIRST = 0, OP_SEARCH = 1, OP_IS_MATCH = 2, OP_CAPTURES = 3 };
 
 // BT: the instantiation that carries the backtracking matcher (see engine_match_first in mrx_device.hpp)
-template <int OP, bool BT = false>
+template <int OP, int BT = 0>
 __global__ __launch_bounds__(kBlock) void k_match(DevPlan p, const uint8_t* __restrict__ blob,
                                                   Layout lay, int64_t n, int32_t* __restrict__ out_s,
                                                   int32_t* __restrict__ out_e,
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(kBlock) void k_match(DevPlan p, const uint8_t* __re
         const int g = p.bt_ngroups;
         int32_t* o = out_s + i * (int64_t)(g + 1) * 2;
         BtCaps caps;
-        if (bt_match_next_with_groups(c, t, 0, ms, me, caps)) {
+        if (bt_match_next_with_groups<BT == 1>(c, t, 0, ms, me, caps)) {
           for (int k = 1; k <= g; ++k) { o[(k - 1) * 2] = caps.gs(k); o[(k - 1) * 2 + 1] = caps.ge(k); }
           o[g * 2] = ms; o[g * 2 + 1] = me;
         } else {
@@ -1040,7 +1040,7 @@ __global__ __launch_bounds__(kBlock) void k_slots_gather_wide(Layout lay, int64_
 }
 
 
-template <int MODE, bool BT = false>
+template <int MODE, int BT = 0>
 __global__ __launch_bounds__(kBlock) void k_findall(DevPlan p, const uint8_t* __restrict__ blob,
                                                     Layout lay, int64_t n,
                                                     int32_t* __restrict__ counts,
@@ -3121,7 +3121,7 @@ __global__ __launch_bounds__(kBlock) void k_subs_wave(int64_t n, const uint8_t* 
 
 enum { SUB_SIZE = 0, SUB_EMIT = 1 };
 
-template <int MODE, bool BT = false>
+template <int MODE, int BT = 0>
 __global__ __launch_bounds__(kBlock) void k_sub(DevPlan p, const uint8_t* __restrict__ blob,
                                                 Layout lay, int64_t n,
                                                 const uint8_t* __restrict__ repl, int repl_len,
@@ -3572,6 +3572,18 @@ int check_lds(const mrx_handle* h) {
 static bool plan_uses_backtracker(const mrx_handle* h) {
   return (h->hp.dev.flags & (PF_BT_FIRST | PF_BT_SEARCH)) != 0 && h->hp.dev.bt_nitems > 0;
 }
+// ... 2: the lean instantiation for deterministic chains (DevPlan::bt_flags bit 5: no choice stack), 1: the full one
+static int bt_kernel_kind(const mrx_handle* h, bool wanted) {
+  static const bool full_only = getenv("MRX_BT_FULL") && getenv("MRX_BT_FULL")[0] == '1';   // A/B: chains on the full interpreter
+  if (!wanted) return 0;
+  return ((h->hp.dev.bt_flags & 32) && !full_only) ? 2 : 1;
+}
+#define MRX_BT_DISPATCH(KIND, LAUNCH)        \
+  do {                                       \
+    if ((KIND) == 2) { LAUNCH(2); }          \
+    else if ((KIND) == 1) { LAUNCH(1); }     \
+    else { LAUNCH(0); }                      \
+  } while (0)
 // NFAEngine's literal prefilter (nfa.mojo:86-143, 391-498, 169-340) in front of the lane-per-text kernels:
 // every backtracker-routed search starts with String.find(literal) -- and, on the '.*' fast paths, with a
 // look for a newline and String.rfind(literal) -- over the WHOLE text, per lane and byte by byte in the
@@ -3648,7 +3660,7 @@ int run_match(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d_s, i
       g_last_kernel = "k_bstep_search";
     } else
     if (big && !wave) {   // many short texts: the literal restatement, one lane per text
-      hipLaunchKernelGGL((k_match<OP, false>), dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s, h->hp.dev,
+      hipLaunchKernelGGL((k_match<OP, 0>), dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s, h->hp.dev,
                          H_BLOB(h), lay, n, d_s, d_e, d_flag);   // (a stepper plan: no backtracker route)
       g_last_kernel = "k_match";
     } else if (big) {
@@ -3681,12 +3693,10 @@ int run_match(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d_s, i
     Layout layp = lay;
     if ((OP == OP_SEARCH && (h->hp.dev.flags & PF_BT_SEARCH)) || (OP == OP_CAPTURES && h->hp.fixed_total < 0))
       if (int rc = bt_prepass(h, lay, n, s, &layp)) return rc;
-    if (plan_uses_backtracker(h) || (OP == OP_CAPTURES && h->hp.fixed_total < 0))
-      hipLaunchKernelGGL((k_match<OP, true>), dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s, h->hp.dev,
-                         H_BLOB(h), layp, n, d_s, d_e, d_flag);
-    else
-      hipLaunchKernelGGL((k_match<OP, false>), dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s, h->hp.dev,
-                         H_BLOB(h), layp, n, d_s, d_e, d_flag);
+#define MRX_L(B) hipLaunchKernelGGL((k_match<OP, B>), dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s, h->hp.dev, \
+                                   H_BLOB(h), layp, n, d_s, d_e, d_flag)
+    MRX_BT_DISPATCH(bt_kernel_kind(h, plan_uses_backtracker(h) || (OP == OP_CAPTURES && h->hp.fixed_total < 0)), MRX_L);
+#undef MRX_L
     g_last_kernel = "k_match";
   }
   HIP_TRY(hipGetLastError());
@@ -4307,12 +4317,10 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
       } else {
         if (p.flags & PF_BT_SEARCH)
           if (int rc = bt_prepass(h, lay, n, s, &lay_pre)) return rc;
-        if (plan_uses_backtracker(h))
-          hipLaunchKernelGGL((k_findall<FA_COUNT, true>), dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s,
-                             p, H_BLOB(h), lay_pre, n, d_counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0);
-        else
-          hipLaunchKernelGGL((k_findall<FA_COUNT, false>), dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s,
-                             p, H_BLOB(h), lay_pre, n, d_counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0);
+#define MRX_L(B) hipLaunchKernelGGL((k_findall<FA_COUNT, B>), dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s, \
+                                   p, H_BLOB(h), lay_pre, n, d_counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0)
+        MRX_BT_DISPATCH(bt_kernel_kind(h, plan_uses_backtracker(h)), MRX_L);
+#undef MRX_L
       }
       g_last_kernel = req_wave ? "k_req_wave" : step_ok ? (wstep_bits ? "k_bstep_count" : wstep_empty ? "k_estep_count" : step_split > 0 ? "k_step_count+k_req_wave" : "k_step_count")
                                                         : "k_findall_count";
@@ -4387,12 +4395,10 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
         if (step_split > 0) MRX_REQWAVE_LAUNCH(STEP_EMIT, h, lay2, n, d_counts, d_prefix, d_spans, span_cap, s);
         }
       } else
-        if (plan_uses_backtracker(h))
-          hipLaunchKernelGGL((k_findall<FA_EMIT, true>), dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s, p,
-                             H_BLOB(h), lay_pre, n, (int32_t*)nullptr, d_prefix, d_spans, span_cap);
-        else
-          hipLaunchKernelGGL((k_findall<FA_EMIT, false>), dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s, p,
-                             H_BLOB(h), lay_pre, n, (int32_t*)nullptr, d_prefix, d_spans, span_cap);
+#define MRX_L(B) hipLaunchKernelGGL((k_findall<FA_EMIT, B>), dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s, p, \
+                                   H_BLOB(h), lay_pre, n, (int32_t*)nullptr, d_prefix, d_spans, span_cap)
+        MRX_BT_DISPATCH(bt_kernel_kind(h, plan_uses_backtracker(h)), MRX_L);
+#undef MRX_L
     }
     HIP_TRY(hipGetLastError());
   }
@@ -5029,12 +5035,10 @@ static int run_count_any(const mrx_handle* h, const Layout& lay, int64_t n, int3
       Layout layp = lay;
       if (h->hp.dev.flags & PF_BT_SEARCH)
         if (int rc = bt_prepass(h, lay, n, s, &layp)) return rc;
-      if (plan_uses_backtracker(h))
-        hipLaunchKernelGGL((k_findall<FA_COUNT, true>), dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s,
-                           h->hp.dev, H_BLOB(h), layp, n, counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0);
-      else
-        hipLaunchKernelGGL((k_findall<FA_COUNT, false>), dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s,
-                           h->hp.dev, H_BLOB(h), layp, n, counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0);
+#define MRX_L(B) hipLaunchKernelGGL((k_findall<FA_COUNT, B>), dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s, \
+                                   h->hp.dev, H_BLOB(h), layp, n, counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0)
+      MRX_BT_DISPATCH(bt_kernel_kind(h, plan_uses_backtracker(h)), MRX_L);
+#undef MRX_L
       g_last_kernel = "k_findall_count";
     }
   }
@@ -5123,14 +5127,11 @@ int mrx_sub_dev(const mrx_handle* h, const char* repl, size_t repl_len, int64_t 
   }
   if (n > 0) {
     ScanTimer tm(s);
-    if (sub_bt)
-      hipLaunchKernelGGL((k_sub<SUB_SIZE, true>), dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s,
-                         h->hp.dev, H_BLOB(h), lay, n, d_repl, (int)r.size(), general_groups ? 2 : groups ? 1 : 0, d_tpl,
-                         (int)tpl.size(), (long long)count, d_sizes, (const int64_t*)nullptr, (uint8_t*)nullptr, (int64_t)0);
-    else
-      hipLaunchKernelGGL((k_sub<SUB_SIZE, false>), dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s,
-                         h->hp.dev, H_BLOB(h), lay, n, d_repl, (int)r.size(), general_groups ? 2 : groups ? 1 : 0, d_tpl,
-                         (int)tpl.size(), (long long)count, d_sizes, (const int64_t*)nullptr, (uint8_t*)nullptr, (int64_t)0);
+#define MRX_L(B) hipLaunchKernelGGL((k_sub<SUB_SIZE, B>), dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s,                     \
+                                   h->hp.dev, H_BLOB(h), lay, n, d_repl, (int)r.size(), general_groups ? 2 : groups ? 1 : 0, d_tpl, \
+                                   (int)tpl.size(), (long long)count, d_sizes, (const int64_t*)nullptr, (uint8_t*)nullptr, (int64_t)0)
+    MRX_BT_DISPATCH(bt_kernel_kind(h, sub_bt), MRX_L);
+#undef MRX_L
     g_last_kernel = "k_sub_size";
     HIP_TRY(hipGetLastError());
     tm.stop();
@@ -5144,14 +5145,11 @@ int mrx_sub_dev(const mrx_handle* h, const char* repl, size_t repl_len, int64_t 
   if (tot > out_cap) {
     rc = fail(MRX_E_CAPACITY, "output buffer too small: need " + std::to_string(tot));
   } else if (n > 0 && tot > 0) {
-    if (sub_bt)
-      hipLaunchKernelGGL((k_sub<SUB_EMIT, true>), dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s,
-                         h->hp.dev, H_BLOB(h), lay, n, d_repl, (int)r.size(), general_groups ? 2 : groups ? 1 : 0, d_tpl,
-                         (int)tpl.size(), (long long)count, (int64_t*)nullptr, out_off, out, out_cap);
-    else
-      hipLaunchKernelGGL((k_sub<SUB_EMIT, false>), dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s,
-                         h->hp.dev, H_BLOB(h), lay, n, d_repl, (int)r.size(), general_groups ? 2 : groups ? 1 : 0, d_tpl,
-                         (int)tpl.size(), (long long)count, (int64_t*)nullptr, out_off, out, out_cap);
+#define MRX_L(B) hipLaunchKernelGGL((k_sub<SUB_EMIT, B>), dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s,                     \
+                                   h->hp.dev, H_BLOB(h), lay, n, d_repl, (int)r.size(), general_groups ? 2 : groups ? 1 : 0, d_tpl, \
+                                   (int)tpl.size(), (long long)count, (int64_t*)nullptr, out_off, out, out_cap)
+    MRX_BT_DISPATCH(bt_kernel_kind(h, sub_bt), MRX_L);
+#undef MRX_L
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(scratch_free(d_repl, s));

@@ -514,6 +514,35 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
     if (hp.nfa_starts_dotstar) d.bt_flags |= 4;
     if (hp.nfa_ends_dotstar) d.bt_flags |= 8;
     if (!hp.nfa_literal.empty() && pattern.compare(0, hp.nfa_literal.size(), hp.nfa_literal) == 0) d.bt_flags |= 2;
+    // bit 5: a deterministic chain.  No ALT / LOOP / FAIL items, and behind every quantified leaf that can leave a
+    // choice (not the last child of its sequence) comes -- past group boundaries -- an anchor, or a leaf that must
+    // consume a byte (min >= 1) none of whose three membership tables shares a byte with the quantified leaf's
+    // is_match_char table: the leaf behind then fails on every byte the quantified leaf could give back, so a
+    // shorter count never rescues the sequence and the first failure is final (k_match<., 2> etc. run without
+    // the choice stack).
+    {
+      bool chain = true;
+      const auto& items = hp.bt.items;
+      const auto& tbls = hp.bt.tables;
+      for (size_t i = 0; i < items.size() && chain; ++i) {
+        const BtItem& it = items[i];
+        if (it.kind >= BT_ALT) { chain = false; break; }
+        if (it.kind != BT_LEAF || !(it.flags & BTF_QUANT) || (it.flags & BTF_LAST)) continue;
+        if (it.min == it.max) continue;   // a fixed count leaves no choice
+        size_t j = i + 1;
+        while (j < items.size() && (items[j].kind == BT_OPEN || items[j].kind == BT_CLOSE)) ++j;
+        if (j >= items.size()) { chain = false; break; }   // (cannot happen: a non-last leaf has a sibling behind it)
+        const BtItem& nx = items[j];
+        if (nx.kind == BT_START || nx.kind == BT_END) continue;
+        if (nx.kind != BT_LEAF || nx.min < 1) { chain = false; break; }
+        for (int b = 0; b < 32 && chain; ++b) {
+          const uint8_t mine = tbls[it.tbl * 3 + 1][b];
+          const uint8_t theirs = tbls[nx.tbl * 3 + 0][b] | tbls[nx.tbl * 3 + 1][b] | tbls[nx.tbl * 3 + 2][b];
+          if (mine & theirs) chain = false;
+        }
+      }
+      if (chain) d.bt_flags |= 32;
+    }
     align(hp.blob, 8);
   }
 
@@ -1028,7 +1057,7 @@ std::string describe_plan(const HostPlan& hp) {
     << (d.off_fa_run >= 0 ? " class_run=1" : "") << "\n";
   o << "device.backtrack=" << (hp.bt.ok ? "yes" : ("no: " + (hp.bt.why_not.empty() ? std::string("'.*' shortcut") : hp.bt.why_not)));
   if (hp.bt.ok) o << " items=" << d.bt_nitems << " groups=" << d.bt_ngroups << " literal_opt=" << (d.bt_flags & 1)
-                  << " prefix_literal=" << ((d.bt_flags >> 1) & 1);
+                  << " prefix_literal=" << ((d.bt_flags >> 1) & 1) << " chain=" << ((d.bt_flags >> 5) & 1);
   o << "\n";
   if (d.flags & PF_BITSET)
     o << "device.bitset=yes positions=" << d.bs_npos << " words=" << d.bs_nw << " byte_classes=" << d.bs_ncls << "\n";
