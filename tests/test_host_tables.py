@@ -161,3 +161,18 @@ def test_synchronising_bytes_and_long_text_plan_flags():
     assert line(b"abab", "device.streamable").startswith("device.streamable=yes")
     assert "big_table=1" in line(B.NANPA_PATTERN, "device.steppable")          # 154 states > 96
     assert "big_table" not in line(b"\\w+\\d{2}", "device.steppable")
+
+
+def test_backtracker_chain_classification():
+    """DevPlan::bt_flags bit 5 (`chain=1` in mrx_describe): the flat program needs no choice stack -- no ALT / LOOP
+    items, and no quantified leaf whose shorter counts could rescue what follows it."""
+    def chain(p):
+        d = M.CompiledRegex(p).describe()
+        line = [x for x in d.split("\n") if x.startswith("device.backtrack=yes")]
+        assert line, (p, d)
+        return "chain=1" in line[0]
+    for p in ("(\\w+) (\\w+)", "(\\d+)-(\\d+)", "hello.*", "x(.*)y", "(\\w+)@(\\w+)\\.com", "([a-z]+)(\\d*)x", "\\d+-\\d+x.*"):
+        assert chain(p), p
+    # '.*' / '\\w+' in front of something they can also match; alternation; a looping group
+    for p in ("hello.*world", ".*@example\\.com", "(a|b)(c)", "(ab)+(c)", "\\w+ing.*", "\\w+s \\w+x.*"):
+        assert not chain(p), p
