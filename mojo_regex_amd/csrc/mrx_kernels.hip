@@ -2170,10 +2170,7 @@ __global__ __launch_bounds__(kBlock) void k_fused_init(unsigned long long* __res
 #define MRX_DECODE_TILE 2048
 #endif
 constexpr int kDecodeTile = MRX_DECODE_TILE;  // spans per LDS tile and wavefront (16 KiB): one pass for typical wavefronts
-#ifndef MRX_DECODE_DIRECT
-#define MRX_DECODE_DIRECT (3 * kDecodeTile)
-#endif
-constexpr int kDecodeDirect = MRX_DECODE_DIRECT;  // above this many spans per wavefront: one direct pass
+// (above 3 x TILE spans per wavefront k_decode makes one pass with direct stores: kDecodeDirect inside the kernel)
 #ifndef MRX_DECODE_BATCH
 #define MRX_DECODE_BATCH 8
 #endif
@@ -2191,7 +2188,11 @@ constexpr int kScanTile = kScanBlock * kScanItems;
 // the texts' entries).
 // DYN: the records of k_stream_dyn -- a stream per task of kDynTexts texts, records name their text by its
 // index in the task (meta >> 24) and count its matches so far in 24 bits.
-template <bool PACK16, bool VBASE = false, bool REC32 = false, bool DYN = false>
+// TILE: spans per LDS tile and wavefront.  2048 keeps five workgroups per CU; batches of texts of 768 bytes and more
+// (16-bit positions) take 3072 -- config 4's wavefronts hold 2 600 spans and needed two passes over their records
+// (findall 0.505 -> 0.452 ms), config 2 is unchanged, 256-byte texts (config 3) lose 3 % to the lower occupancy and
+// keep 2048.
+template <bool PACK16, bool VBASE = false, bool REC32 = false, bool DYN = false, int TILE = kDecodeTile>
 __global__ __launch_bounds__(kBlock) void k_decode(int64_t n, const int32_t* __restrict__ wave_nrecs,
                                                    const EvRec* __restrict__ recs, int64_t rec_row,
                                                    const int64_t* __restrict__ offsets,
@@ -2207,7 +2208,8 @@ __global__ __launch_bounds__(kBlock) void k_decode(int64_t n, const int32_t* __r
   static_assert(!(PACK16 && VBASE), "text-relative positions of a long text do not fit 16 bits");
   static_assert(!(DYN && VBASE), "pieces are not handed out dynamically");
   using Slot = typename std::conditional<PACK16, uint32_t, int2>::type;
-  __shared__ Slot tile_all[kBlock / 64][kDecodeTile];
+  __shared__ Slot tile_all[kBlock / 64][TILE];
+  constexpr int kDecodeTile = TILE, kDecodeDirect = 3 * TILE;   // (shadow the file-scope defaults)
   __shared__ int rel_all[DYN ? kBlock / 64 : 1][DYN ? kDynTexts : 1];   // DYN: spans of the task's texts before each text
   constexpr int kTexts = DYN ? kDynTexts : 64;
   constexpr uint32_t kBefore = DYN ? kDynBeforeMask : kRecBeforeMask;
@@ -4353,7 +4355,11 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
         hipLaunchKernelGGL((k_decode<false, false, false, true>), dg, db, 0, s, n, d_nrecs, d_recs, rec_row, lay.offsets, d_counts,
                            d_wbase, d_tsum, d_prefix, d_spans, span_cap, p.st_fixed_len, d_total);
     } else
-    if (pack16 && rec32)
+    if (pack16 && rec32 && max_text >= 768)
+      hipLaunchKernelGGL((k_decode<true, false, true, false, 3072>), dim3(grid_for(n, kBlock) * 2), dim3(kBlock), 0, s, n, d_nrecs, d_recs,
+                         rec_row, lay.offsets, d_counts, d_wbase, d_tsum, d_prefix, d_spans, span_cap, p.st_fixed_len,
+                         d_total);
+    else if (pack16 && rec32)
       hipLaunchKernelGGL((k_decode<true, false, true>), dim3(grid_for(n, kBlock) * 2), dim3(kBlock), 0, s, n, d_nrecs, d_recs,
                          rec_row, lay.offsets, d_counts, d_wbase, d_tsum, d_prefix, d_spans, span_cap, p.st_fixed_len,
                          d_total);
