@@ -2188,6 +2188,9 @@ constexpr int kScanTile = kScanBlock * kScanItems;
 // the texts' entries).
 // DYN: the records of k_stream_dyn -- a stream per task of kDynTexts texts, records name their text by its
 // index in the task (meta >> 24) and count its matches so far in 24 bits.
+#ifndef MRX_DYN_DECODE_TILE
+#define MRX_DYN_DECODE_TILE 2048   // k_stream_dyn's 256-text tasks (A/B: tools/variants.sh)
+#endif
 // TILE: spans per LDS tile and wavefront.  2048 keeps five workgroups per CU; batches of texts of 768 bytes and more
 // (16-bit positions) take 3072 -- config 4's wavefronts hold 2 600 spans and needed two passes over their records
 // (findall 0.505 -> 0.452 ms), config 2 is unchanged, 256-byte texts (config 3) lose 3 % to the lower occupancy and
@@ -4346,7 +4349,7 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
     if (dyn) {
       const dim3 dg((unsigned)grid_for(nw * 64, kBlock) * 2), db(kBlock);
       if (pack16 && rec32)
-        hipLaunchKernelGGL((k_decode<true, false, true, true>), dg, db, 0, s, n, d_nrecs, d_recs, rec_row, lay.offsets, d_counts,
+        hipLaunchKernelGGL((k_decode<true, false, true, true, MRX_DYN_DECODE_TILE>), dg, db, 0, s, n, d_nrecs, d_recs, rec_row, lay.offsets, d_counts,
                            d_wbase, d_tsum, d_prefix, d_spans, span_cap, p.st_fixed_len, d_total);
       else if (pack16)
         hipLaunchKernelGGL((k_decode<true, false, false, true>), dg, db, 0, s, n, d_nrecs, d_recs, rec_row, lay.offsets, d_counts,
