@@ -26,8 +26,9 @@ const char* mrx_last_kernel_name(void);
 /* Testing aid: route every call to the generic lane-per-text kernels (the streaming kernel is
  * then never used) so that the two implementations can be compared on the same batch. */
 void mrx_debug_force_generic(int on);
-/* Testing aid: the kernels that put one wavefront (instead of one lane) on a text are chosen by the
- * batch's average text length; 1 = always use them, 2 = never, 0 = by length. */
+/* Testing aid: the treatments of long texts (pieces cut at synchronising bytes, a wavefront per text) are chosen by
+ * the batch's average text length; 1 = always use them (pieces of 200 bytes where the plan has synchronising bytes),
+ * 2 = never, 3 = as 1 but stepper plans take the wavefront-per-text kernel instead of pieces, 0 = by length. */
 void mrx_debug_long_text_kernels(int mode);
 /* findall of streamable plans runs as three launches (scan -> prefix sums -> decode; the default, and
  * the faster form as measured) or as ONE (scan, CSR offsets by decoupled look-back and spans fused);

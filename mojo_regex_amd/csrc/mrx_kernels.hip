@@ -2480,7 +2480,10 @@ __global__ __launch_bounds__(kBlock) void k_virt_check(Layout lay, int64_t n, co
 __global__ __launch_bounds__(kBlock) void k_virt_fill(Layout lay, int64_t n, const int64_t* __restrict__ vfirst,
                                                       int64_t nv, int C, const int32_t* __restrict__ back,
                                                       int64_t* __restrict__ vstart, int32_t* __restrict__ vlen,
-                                                      uint32_t* __restrict__ vskip, int32_t* __restrict__ vbase) {
+                                                      uint32_t* __restrict__ vskip, int32_t* __restrict__ vbase,
+                                                      int disjoint) {
+  // disjoint (stepper plans): a piece ends where the next one begins -- at that piece's synchronising byte --
+  // instead of running on to its cut with the overlap's events masked out (streaming plans)
   for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += (int64_t)gridDim.x * blockDim.x) {
     const int64_t t = virt_text_of(vfirst, n, v);
     const int64_t v0 = vfirst[t];
@@ -2498,14 +2501,28 @@ __global__ __launch_bounds__(kBlock) void k_virt_fill(Layout lay, int64_t n, con
       // my piece runs to the next cut that has a synchronising byte, or to the end of the text
       int j = k + 1;
       while (j < cpt && back[v0 + j] == -1) ++j;
-      const int e = j == cpt ? tx.len : j * C;
+      const int e = j == cpt ? tx.len : (disjoint ? j * C - back[v0 + j] : j * C);
       st = abs0 + c - b; ln = e - (int)c + b; base = (int)c - b;
-      sk = (uint32_t)b | (e == tx.len ? 0x80000000u : 0u);
+      sk = disjoint ? 0u : ((uint32_t)b | (e == tx.len ? 0x80000000u : 0u));
     }
     vstart[v] = st; vlen[v] = ln; vskip[v] = sk; vbase[v] = base;
   }
 }
 
+// spans of piece v are piece-relative: make them text-relative (stepper plans, whose kernels know nothing of pieces)
+__global__ __launch_bounds__(kBlock) void k_virt_add_base(int64_t nv, const int64_t* __restrict__ vprefix,
+                                                          const int32_t* __restrict__ vbase, int32_t* __restrict__ spans,
+                                                          int64_t span_cap) {
+  // one wavefront per piece: its spans are contiguous
+  const int lane = threadIdx.x & 63;
+  for (int64_t v = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; v < nv; v += ((int64_t)gridDim.x * blockDim.x) >> 6) {
+    const int b = vbase[v];
+    if (b == 0) continue;
+    int64_t a = vprefix[v], e = vprefix[v + 1];
+    if (e > span_cap) e = span_cap;
+    for (int64_t k = a + lane; k < e; k += 64) { spans[2 * k] += b; spans[2 * k + 1] += b; }
+  }
+}
 // per-text entries of the per-piece prefix sums / counts
 __global__ __launch_bounds__(kBlock) void k_virt_prefix(int64_t n, const int64_t* __restrict__ vfirst,
                                                         const int64_t* __restrict__ vprefix,
@@ -3261,7 +3278,8 @@ thread_local bool t_prefilter_done = false;
 // the two implementations; never set in production)
 // (process-wide switches of include/mrx_testing.h; relaxed atomics: set while no call is in flight)
 std::atomic<int> g_pair_tables{1};      // MRX_NO_PAIR_TABLES=1 in the environment: measure the one-byte class table
-std::atomic<int> g_long_text_mode{0};   // mrx_debug_long_text_kernels(): 0 by average length, 1 always, 2 never
+std::atomic<int> g_long_text_mode{0};   // mrx_debug_long_text_kernels(): 0 by average length, 1 always, 2 never,
+                                        // 3 = as 1 but stepper plans on the wavefront-per-text kernel instead of pieces
 std::atomic<int> g_force_generic{0};   // 0 best kernel, 1 no streaming kernel, 2 literal restatement (mrx_device.hpp) only
 
 int fail(int code, const std::string& msg) {
@@ -3466,7 +3484,7 @@ int req_wave_pays(const Layout& lay, int64_t n, bool req_route, hipStream_t s, b
                   bool big = false) {
   *out = false;
   if (split) *split = 0;
-  if (g_long_text_mode) { *out = g_long_text_mode == 1; return MRX_OK; }
+  if (g_long_text_mode) { *out = g_long_text_mode == 1 || g_long_text_mode == 3; return MRX_OK; }
   if (n <= 0) return MRX_OK;
   int64_t total = 0, max_len = 0;
   if (lay.offsets) {
@@ -3871,10 +3889,10 @@ int csr_stats(const Layout& lay, int64_t n, hipStream_t s, int64_t* total, int64
 }
 // known_total / known_max: csr_stats() of the batch when the caller has them already (< 0: not)
 int pieces_prepare(const mrx_handle* h, const Layout& lay, int64_t n, hipStream_t s, Pieces* pc,
-                   int64_t known_total = -1, int64_t known_max = -1) {
+                   int64_t known_total = -1, int64_t known_max = -1, bool disjoint = false) {
   const DevPlan& p = h->hp.dev;
   pc->on = false;
-  if (p.st_nsync <= 0 || g_long_text_mode == 2 || n <= 0) return MRX_OK;
+  if (p.st_nsync <= 0 || g_long_text_mode == 2 || (g_long_text_mode == 3 && disjoint) || n <= 0) return MRX_OK;
   // pays when one lane per text leaves the device mostly idle, or for outliers of a ragged batch; a
   // fixed-length batch of many texts is decided before anything is launched
   const bool env_pieces = getenv("MRX_PIECE_C") != nullptr;   // measurement
@@ -3897,7 +3915,7 @@ int pieces_prepare(const mrx_handle* h, const Layout& lay, int64_t n, hipStream_
     C = env_c;
     if (max_len <= C) return MRX_OK;
   } else
-  if (g_long_text_mode == 1) {
+  if (g_long_text_mode == 1 || g_long_text_mode == 3) {
     C = 200;   // tests: cut even short texts, at positions that are not multiples of 16
     if (max_len <= C) return MRX_OK;
   } else {
@@ -3905,6 +3923,11 @@ int pieces_prepare(const mrx_handle* h, const Layout& lay, int64_t n, hipStream_
     // batches that fill the device with one lane per text are cut only for the sake of texts far
     // longer than the rest (ragged batches: one lane would still be walking long after the others)
     const int64_t avg = total / n;
+    // stepper plans (disjoint pieces): measured on the reference's benchmark texts against the wavefront-per-text
+    // kernel -- pieces win on 11-74 KB texts of the plain route (dense candidates: flexible_phone 1.57 -> 0.84 ms,
+    // multi_format_phone 2.42 -> 1.57, alternation_quantifiers 2.84 -> 1.87) and lose below that and on every
+    // required-byte plan (sparse candidates are the wavefront kernel's best case)
+    if (disjoint && avg < 10000) return MRX_OK;
     if (n > 131072 && !(max_len >= 32768 && max_len >= 8 * avg && (lay.offsets || lay.lens))) return MRX_OK;
     const int64_t want = (total + 262143) / 262144;   // about 2^18 pieces
     C = (int)((want + 255) / 256 * 256);
@@ -3945,9 +3968,10 @@ int pieces_prepare(const mrx_handle* h, const Layout& lay, int64_t n, hipStream_
   hipLaunchKernelGGL(k_virt_check, dim3(grid_for(pc->nv, kBlock)), dim3(kBlock), 0, s, lay, n, pc->vfirst, pc->nv, C, sync,
                      pc->back);
   hipLaunchKernelGGL(k_virt_fill, dim3(grid_for(pc->nv, kBlock)), dim3(kBlock), 0, s, lay, n, pc->vfirst, pc->nv, C,
-                     pc->back, pc->vstart, pc->vlen, pc->vskip, pc->vbase);
+                     pc->back, pc->vstart, pc->vlen, pc->vskip, pc->vbase, disjoint ? 1 : 0);
   HIP_TRY(hipGetLastError());
   pc->lay = Layout{lay.data, pc->vstart, 0, nullptr, 0};
+  if (disjoint) pc->lay.vlen = pc->vlen;   // a view: the stepper's kernels read the pieces through Layout::text()
   pc->on = true;
   return MRX_OK;
 }
@@ -4109,6 +4133,11 @@ static int findall_split(const mrx_handle* h, const Layout& lay, int64_t n, int3
   return MRX_OK;
 }
 
+// Long texts on the stepper's routes (findall / count of plans that do not stream): cut at bytes on which every
+// walk dies and none begins (DevPlan::off_st_sync of such plans, mrx_plan.cpp), the disjoint pieces searched as
+// texts of their own with one lane each -- where the wavefront-per-text kernel pays for its busiest lane and for the
+// walks it repeats.  The recursion runs with t_in_pieces set: the batch of pieces is a view, not a CSR batch.
+thread_local bool t_in_pieces = false;
 int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_prefix,
                 int32_t* d_spans, int64_t span_cap, int64_t* total, void* stream, bool match_next_sequence = false,
                 int64_t known_total = -1, int64_t known_max = -1) {
@@ -4266,7 +4295,41 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
       tm.stop();
       }
     } else {
-      if (step_ok && !wstep_bits && !wstep_empty)
+      if (step_ok && !wstep_bits && !wstep_empty && !t_in_pieces && !(p.flags & PF_STEP_BIG) && p.st_nsync > 0 &&
+          !(p.flags & PF_STREAMABLE) && span_cap > 0 && (!use_req_route || g_long_text_mode == 1)) {
+        Pieces spc;
+        if (int rc = pieces_prepare(h, lay, n, s, &spc, -1, -1, /*disjoint=*/true)) return rc;
+        if (spc.on) {
+          int64_t* d_vprefix = nullptr;
+          HIP_TRY(scratch_alloc((void**)&d_vprefix, sizeof(int64_t) * (spc.nv + 1), s));
+          t_in_pieces = true;
+          const int rc = run_findall(h, spc.lay, spc.nv, d_vprefix, d_spans, span_cap, nullptr, s, match_next_sequence);
+          t_in_pieces = false;
+          if (rc != MRX_OK) return rc;
+          const std::string inner = g_last_kernel;
+          hipLaunchKernelGGL(k_virt_prefix, dim3(grid_for(n + 1, kBlock)), dim3(kBlock), 0, s, n, spc.vfirst, d_vprefix, d_prefix);
+          hipLaunchKernelGGL(k_virt_add_base, dim3(grid_for(spc.nv * 64, kBlock)), dim3(kBlock), 0, s, spc.nv, d_vprefix, spc.vbase,
+                             d_spans, span_cap);
+          HIP_TRY(hipGetLastError());
+          static thread_local std::string piece_name;
+          piece_name = inner + "_pieces";
+          g_last_kernel = piece_name.c_str();
+          int rc2 = MRX_OK;
+          if (total) {
+            int64_t tot = 0;
+            HIP_TRY(hipMemcpyAsync(&tot, d_vprefix + spc.nv, sizeof tot, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            *total = tot;
+            if (tot > span_cap) rc2 = fail(MRX_E_CAPACITY, "span buffer too small: need " + std::to_string(tot));
+          }
+          HIP_TRY(scratch_free(d_vprefix, s));
+          if (int rc3 = pieces_release(&spc, s)) return rc3;
+          HIP_TRY(scratch_free(d_counts, s));
+          HIP_TRY(scratch_free(d_total, s));
+          return rc2;
+        }
+      }
+      if (step_ok && !wstep_bits && !wstep_empty && !t_in_pieces)
         if (int rc = req_wave_pays(lay, n, use_req_route, s, &req_wave, (p.flags & PF_STEP_BIG) ? nullptr : &step_split,
                                    (p.flags & PF_STEP_BIG) != 0))
           return rc;
@@ -4474,7 +4537,7 @@ int sub_from_spans(const mrx_handle* h, const Layout& lay, int64_t n, const std:
     // lanes per text in k_subs_wave by average text length (1 KiB texts: 32 lanes 1.41 ms, 64 lanes 1.56 ms);
     // 0 = k_subs_emit alone: long replacement templates (one lane writes a replacement), forced, or texts
     // beyond the workgroup form's tiles, which take k_subs_emit<kBlock>
-    const bool long_texts = (g_long_text_mode == 1 || avg0 > 6144) && g_long_text_mode != 2;
+    const bool long_texts = (g_long_text_mode == 1 || g_long_text_mode == 3 || avg0 > 6144) && g_long_text_mode != 2;
     const int force_g = g_subs_group;
     G = force_g >= 0 ? force_g : (avg0 > 2048 ? 256 : avg0 > 1024 ? 64 : avg0 > 224 ? 32 : 16);
     if (R > 1024 || long_texts) G = 0;
@@ -4507,7 +4570,7 @@ int sub_from_spans(const mrx_handle* h, const Layout& lay, int64_t n, const std:
     if (tot > out_cap) {
       rc = fail(MRX_E_CAPACITY, "output buffer too small: need " + std::to_string(tot));
     } else if (tot > 0) {
-      if (G == 0 && (g_long_text_mode == 1 || in_bytes / n >= 4096) && g_long_text_mode != 2) {   // long texts: a workgroup per text
+      if (G == 0 && (g_long_text_mode == 1 || g_long_text_mode == 3 || in_bytes / n >= 4096) && g_long_text_mode != 2) {   // long texts: a workgroup per text
         hipLaunchKernelGGL(k_subs_emit<kBlock>, dim3((unsigned)(n < 4096 ? n : 4096)), dim3(kBlock),
                            (size_t)(2 * R + 16), s, n, lay.data, lay.offsets, d_prefix, d_spans, d_cum, (long long)count, R,
                            d_rmap, out_off, out, 0, (const int32_t*)nullptr);
@@ -4743,7 +4806,7 @@ static int run_first_any(const mrx_handle* h, const Layout& lay, int64_t n, int3
   hipStream_t s = (hipStream_t)st;
   // a single class run on long texts of a fixed-pitch batch: a wavefront per text (k_first_run)
   if (p.off_fa_run >= 0 && !lay.offsets && !lay.vlen && g_long_text_mode != 2 &&
-      (g_long_text_mode == 1 || ((lay.lens ? lay.stride : (int64_t)lay.len) >= 2048 && n <= 131072))) {
+      (g_long_text_mode == 1 || g_long_text_mode == 3 || ((lay.lens ? lay.stride : (int64_t)lay.len) >= 2048 && n <= 131072))) {
     ScanTimer tm(s);
     hipLaunchKernelGGL(k_first_run, dim3(grid_for(n * 64, kBlock)), dim3(kBlock), 0, s, p, H_BLOB(h), lay, n, ds, de);
     g_last_kernel = "k_first_run";
@@ -5018,7 +5081,26 @@ static int run_count_any(const mrx_handle* h, const Layout& lay, int64_t n, int3
     const bool wstep_empty = (h->hp.dev.flags & PF_STEP_EMPTY) != 0 && g_force_generic < 2;
     bool req_wave = false;
     int split = 0;
-    if (g_force_generic < 2 && !wstep_bits && (h->hp.dev.flags & (PF_STEPPABLE | PF_STEP_REQ)))
+    if (g_force_generic < 2 && !wstep_bits && !t_in_pieces && (h->hp.dev.flags & (PF_STEPPABLE | PF_STEP_REQ)) &&
+        !(h->hp.dev.flags & (PF_STEP_BIG | PF_STREAMABLE)) && h->hp.dev.st_nsync > 0 &&
+        (!use_req_route || g_long_text_mode == 1)) {
+      // long texts: disjoint pieces between synchronising bytes, one lane each (see run_findall)
+      Pieces spc;
+      if (int rc = pieces_prepare(h, lay, n, s, &spc, -1, -1, /*disjoint=*/true)) return rc;
+      if (spc.on) {
+        int32_t* d_vcounts = nullptr;
+        HIP_TRY(scratch_alloc((void**)&d_vcounts, sizeof(int32_t) * spc.nv, s));
+        t_in_pieces = true;
+        const int rc = run_count_any(h, spc.lay, spc.nv, d_vcounts, st);
+        t_in_pieces = false;
+        if (rc != MRX_OK) return rc;
+        hipLaunchKernelGGL(k_virt_sum, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, n, spc.vfirst, d_vcounts, counts);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(scratch_free(d_vcounts, s));
+        return pieces_release(&spc, s);
+      }
+    }
+    if (g_force_generic < 2 && !wstep_bits && !t_in_pieces && (h->hp.dev.flags & (PF_STEPPABLE | PF_STEP_REQ)))
       if (int rc = req_wave_pays(lay, n, use_req_route, s, &req_wave, (h->hp.dev.flags & PF_STEP_BIG) ? nullptr : &split,
                                  (h->hp.dev.flags & PF_STEP_BIG) != 0))
         return rc;
@@ -5251,7 +5333,7 @@ double mrx_timing_scan_ms(int64_t* launches) {
 }
 const char* mrx_last_kernel_name(void) { return g_last_kernel; }
 void mrx_debug_force_generic(int on) { g_force_generic = on < 0 ? 0 : on > 2 ? 2 : on; }
-void mrx_debug_long_text_kernels(int mode) { g_long_text_mode = mode < 0 ? 0 : mode > 2 ? 0 : mode; }
+void mrx_debug_long_text_kernels(int mode) { g_long_text_mode = mode < 0 ? 0 : mode > 3 ? 0 : mode; }
 void mrx_debug_fused_findall(int mode) { g_fused = mode < 0 ? 0 : mode > 2 ? 0 : mode; }
 void mrx_debug_dynamic_texts(int mode) { g_dyn_mode = mode < 0 ? 0 : mode > 2 ? 0 : mode; }
 void mrx_debug_split_findall(int on) { g_split_findall = on ? 1 : 0; }

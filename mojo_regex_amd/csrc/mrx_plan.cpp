@@ -801,6 +801,26 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
     // findall with a rare required byte (_match_all_required_byte, matcher.mojo:864-898): memchr for
     // the byte, back up over first-class bytes, anchored walk from there, keep it if it passes the hit
     else if (d.kind == PLAN_DFA && (d.flags & PF_HAS_MATCHER) && !first[d.required_byte]) d.flags |= PF_STEP_REQ;
+    // Bytes at which a long text may be cut for these routes (findall / count of a plan that does not stream):
+    // no state has a transition on the byte -- every walk dies there and none begins -- and the required-byte
+    // route neither stops at it nor backs up over it.  No match contains such a byte, so the pieces between
+    // them are searched as texts of their own (k_virt_* with disjoint pieces, see findall of stepper plans).
+    if (!(d.flags & (PF_STREAMABLE | PF_STEP_BIG)) && (d.flags & (PF_STEPPABLE | PF_STEP_REQ)) && d.st_nsync == 0) {
+      std::array<uint8_t, 256> sync{};
+      int nsync = 0;
+      for (int c = 0; c < 256; ++c) {
+        bool dead = true;
+        for (size_t q = 0; q < T.size() && dead; ++q) dead = T[q][c] < 0;
+        sync[c] = dead && !first[c] && c != d.required_byte;
+        nsync += sync[c];
+      }
+      if (nsync) {
+        d.st_nsync = nsync;
+        d.off_st_sync = (int)hp.blob.size();
+        put(hp.blob, sync.data(), 256);
+        align(hp.blob, 16);
+      }
+    }
   }
 
   // Empty matches (dfa.mojo:2118-2130 / pikevm.mojo:805-817: "while pos <= len: try at pos; every try

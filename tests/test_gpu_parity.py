@@ -198,7 +198,8 @@ def no_streaming_kernels():
 
 @contextlib.contextmanager
 def long_text_kernels(mode):
-    """1 = always the wavefront-per-text kernels, 2 = never (default: by average text length)."""
+    """1 = always the long-text treatments (pieces where the plan has synchronising bytes, else a wavefront per text),
+    2 = never, 3 = as 1 but stepper plans on the wavefront-per-text kernel (default: by average text length)."""
     lib = M.load_library()
     lib.mrx_debug_long_text_kernels(mode)
     try:
@@ -1315,7 +1316,7 @@ def test_required_byte_route_one_wavefront_per_text(pat):
         b"7" * 5000 + b"-1234 " + b"5" * 3000 + b"-" + b"8" * 4000,          # back-up over runs longer than the window
         b"ab" * 2000 + b"@" + b"cd" * 3000 + b".com " + b"x@y.com" * 300,     # walks longer than the window
         (b"call 555-123-4567 or 12:30 or a@b.com, 1.5 and cx9y bar5x " * 200)])
-    with long_text_kernels(1):
+    with long_text_kernels(3):
         got = rx.findall_lists(texts)
         assert lib.mrx_last_kernel_name() == b"k_req_wave"
     with long_text_kernels(2):
@@ -1328,7 +1329,7 @@ def test_required_byte_route_one_wavefront_per_text(pat):
     # device-resident batches: CSR and fixed pitch (aligned and not), count
     data, offsets = M.api.pack_texts(texts)
     b = M.DeviceBatch(torch.from_numpy(data).cuda(), torch.from_numpy(offsets).cuda())
-    with long_text_kernels(1):
+    with long_text_kernels(3):
         cnt = rx.count(b).cpu().numpy()
         assert lib.mrx_last_kernel_name() == b"k_req_wave"
     assert cnt.tolist() == [len(g) for g in got]
@@ -1338,8 +1339,12 @@ def test_required_byte_route_one_wavefront_per_text(pat):
         lens = rng.integers(0, pitch + 1, size=n).astype(np.int32)
         sb = M.DeviceBatch.strided(torch.from_numpy(arr).cuda().reshape(-1), pitch, length=pitch,
                                    lens=torch.from_numpy(lens).cuda())
-        pre, sp, tot = rx._dev_findall(sb)           # by average length: 4 KiB rows take the wavefront kernel
-        assert lib.mrx_last_kernel_name() == b"k_req_wave"
+        pre, sp, tot = rx._dev_findall(sb)           # by average length: 4 KiB rows are cut into pieces, or take the wavefront kernel
+        assert lib.mrx_last_kernel_name() in (b"k_req_wave", b"k_step_count_pieces"), lib.mrx_last_kernel_name()
+        with long_text_kernels(3):
+            pre3, sp3, tot3 = rx._dev_findall(sb)
+            assert lib.mrx_last_kernel_name() == b"k_req_wave"
+        assert tot == tot3 and torch.equal(pre, pre3) and torch.equal(sp[:tot], sp3[:tot3])
         with long_text_kernels(2):
             pre2, sp2, tot2 = rx._dev_findall(sb)
         assert tot == tot2 and torch.equal(pre, pre2) and torch.equal(sp[:tot], sp2[:tot2])
@@ -1369,7 +1374,7 @@ def test_stepper_one_wavefront_per_text(pat):
         b"", b"8", b"foo", b"5" * 9000 + b"-" + b"6" * 3000, b"AB" * 4000 + b"12345 " + b"hello123ab" * 500,
         b"foo" * 700, b"a@b " * 600, b"x1.5" * 500, b"x1 " * 900,   # a match every 3-4 bytes: more than a wide slot row holds
         (b"(555) 123-4567 8005551234 555-123-4567 2125551234 foobar x1.5 ABC1234 world456cd a@b " * 150)])
-    with no_streaming_kernels(), long_text_kernels(1):
+    with no_streaming_kernels(), long_text_kernels(3):
         got = rx.findall_lists(texts)
         k1 = lib.mrx_last_kernel_name()
         ss, se = rx.match_next(texts)
@@ -1880,6 +1885,50 @@ def test_split_findall_equals_one_batch(pat):
             lib.mrx_debug_split_findall(0)
         assert tot0 == tot1 == tot2 and tot0 > 0
         assert torch.equal(pre0, pre1) and torch.equal(sp0[:tot0], sp1[:tot0]) and torch.equal(sp0[:tot0], sp2[:tot0])
+
+
+@pytest.mark.parametrize("pat", [b"\\d+(\\.\\d+)?", b"[A-Z]{2,4}[0-9]{3,5}", b"\\d{3}-\\d{3}-\\d{4}", b"[0-9]+\\.[0-9]+", b"[a-z]+@[a-z]+",
+                                 b"(foo|foobar)x", b"[0-9]+:[0-9]+", b"\\(?\\d{3}\\)?[\\s.-]?\\d{3}[\\s.-]?\\d{4}"])
+def test_stepper_plans_in_disjoint_pieces(pat):
+    """findall / count of plans that do not stream, long texts cut at bytes on which every walk dies and none begins
+    (pieces of 200 bytes under mrx_debug_long_text_kernels(1)): against one lane per whole text and the oracle --
+    matches next to the cuts, texts without any synchronising byte for longer than the look-back, the last piece of
+    the batch, CSR and fixed pitch."""
+    _need_gpu()
+    rx = M.compile_regex(pat)
+    d = rx.describe()
+    if "device.streamable=yes" in d or "sync_bytes=0 " in d:
+        pytest.skip("streams, or has no synchronising byte")
+    lib = M.load_library()
+    rng = np.random.default_rng(zlib.crc32(pat) + 9)
+    al = b"abcfoxAZ0123456789.-@: ()" + bytes(c for c in pat if chr(c).isalnum())
+    texts = _random_texts(rng, 60, 2500, al) + _random_texts(rng, 40, 150, al) + [
+        b"", b"12", b"ABC1234", b"7" * 1000, b"A" * 700 + b"1234", b"555-123-4567 " * 90, b"3.14 " * 300 + b"2.", b"x" * 199 + b"12:30" * 50,
+        b"a@b " * 260, b"foobarx" * 120, b"12345.6789" * 77 + b" 1.5"]
+    batch = M.DeviceBatch.from_texts(texts)
+    with long_text_kernels(2):
+        want = rx.findall_lists(texts)
+        wcnt = rx.count(batch).cpu().numpy()
+    with long_text_kernels(1):
+        got = rx.findall_lists(texts)
+        used = lib.mrx_last_kernel_name()
+        cnt = rx.count(batch).cpu().numpy()
+    assert used.endswith(b"_pieces"), used
+    assert (cnt == wcnt).all()
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert g == w, (pat, i, len(texts[i]), g[:4], w[:4])
+    for i in list(range(0, len(texts), 9)) + list(range(len(texts) - 11, len(texts))):
+        assert got[i] == O.findall(pat, texts[i]), (pat, i)
+    # fixed pitch, default thresholds: texts of 12 KiB of a plain-route plan take the pieces on their own
+    L = 12288
+    rows = [(t * (L // max(len(t), 1) + 1))[:L] for t in texts[:24] if len(t) >= 8]
+    sb = M.DeviceBatch.strided(torch.tensor(list(b"".join(rows)), dtype=torch.uint8, device="cuda"), L, length=L)
+    pre, sp, tot = rx._dev_findall(sb)
+    if "required-byte route" not in d:
+        assert lib.mrx_last_kernel_name().endswith(b"_pieces"), lib.mrx_last_kernel_name()
+    pre_h, sp_h = pre.cpu().numpy(), sp.cpu().numpy()
+    for i in range(0, len(rows), 5):
+        assert [tuple(int(x) for x in r) for r in sp_h[pre_h[i]:pre_h[i + 1]]] == O.findall(pat, rows[i]), (pat, i)
 
 
 @contextlib.contextmanager
