@@ -2509,6 +2509,24 @@ __global__ __launch_bounds__(kBlock) void k_virt_fill(Layout lay, int64_t n, con
   }
 }
 
+// How many of the first `nbytes` bytes of a batch can begin a walk of a stepper plan (start state has a transition on
+// the byte, and the first-byte filter lets it through): the plain route's candidates.  Dense candidates are where the
+// wavefront-per-text kernel loses to one lane per piece; sparse ones where it wins.
+__global__ __launch_bounds__(kBlock) void k_candidate_density(DevPlan p, const uint8_t* __restrict__ blob,
+                                                              const uint8_t* __restrict__ data, int64_t nbytes,
+                                                              unsigned int* __restrict__ hits) {
+  __shared__ uint8_t starts[256];
+  const uint8_t* cls = blob + p.off_cls;
+  const uint8_t* first = blob + p.off_first;
+  const uint16_t* tr = (const uint16_t*)(blob + p.off_trans);
+  const bool filt = (p.flags & PF_HAS_MATCHER) != 0;
+  for (int b = threadIdx.x; b < 256; b += blockDim.x) starts[b] = (tr[cls[b]] != 0xFFFFu && (!filt || first[b])) ? 1 : 0;
+  __syncthreads();
+  unsigned int k = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nbytes; i += (int64_t)gridDim.x * blockDim.x) k += starts[data[i]];
+  for (int off = 32; off > 0; off >>= 1) k += __shfl_xor(k, off);
+  if ((threadIdx.x & 63) == 0 && k) atomicAdd(hits, k);
+}
 // spans of piece v are piece-relative: make them text-relative (stepper plans, whose kernels know nothing of pieces)
 __global__ __launch_bounds__(kBlock) void k_virt_add_base(int64_t nv, const int64_t* __restrict__ vprefix,
                                                           const int32_t* __restrict__ vbase, int32_t* __restrict__ spans,
@@ -4138,6 +4156,33 @@ static int findall_split(const mrx_handle* h, const Layout& lay, int64_t n, int3
 // texts of their own with one lane each -- where the wavefront-per-text kernel pays for its busiest lane and for the
 // walks it repeats.  The recursion runs with t_in_pieces set: the batch of pieces is a view, not a CSR batch.
 thread_local bool t_in_pieces = false;
+// plain-route stepper plan on long texts: pieces (true) or the wavefront kernel (false)?  Decided by the share of
+// bytes that can begin a walk in the first MiB of the batch (one small kernel, one 4-byte read-back): measured on the
+// reference's list, dense candidates (phone numbers everywhere: 30 %) are where one lane per piece wins (1.57 -> 0.84
+// ms), sparse ones (a number every few hundred bytes: 1-2 %) where the wavefront kernel does (0.52 against 1.0 ms).
+static int dense_candidates(const mrx_handle* h, const Layout& lay, int64_t n, hipStream_t s, bool* dense) {
+  *dense = true;
+  if (g_long_text_mode == 1) return MRX_OK;
+  int64_t bytes = 0;
+  if (lay.offsets) {
+    HIP_TRY(hipMemcpyAsync(&bytes, lay.offsets + n, sizeof bytes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+  } else {
+    bytes = n * lay.stride;
+  }
+  if (bytes > (1 << 20)) bytes = 1 << 20;
+  if (bytes <= 0) return MRX_OK;
+  unsigned int* d_hits = nullptr;
+  unsigned int hits = 0;
+  HIP_TRY(scratch_alloc((void**)&d_hits, sizeof(unsigned int), s));
+  HIP_TRY(hipMemsetAsync(d_hits, 0, sizeof(unsigned int), s));
+  hipLaunchKernelGGL(k_candidate_density, dim3(256), dim3(kBlock), 0, s, h->hp.dev, H_BLOB(h), lay.data, bytes, d_hits);
+  HIP_TRY(hipMemcpyAsync(&hits, d_hits, sizeof hits, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  HIP_TRY(scratch_free(d_hits, s));
+  *dense = (double)hits >= 0.08 * (double)bytes;
+  return MRX_OK;
+}
 int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_prefix,
                 int32_t* d_spans, int64_t span_cap, int64_t* total, void* stream, bool match_next_sequence = false,
                 int64_t known_total = -1, int64_t known_max = -1) {
@@ -4299,6 +4344,12 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
           !(p.flags & PF_STREAMABLE) && span_cap > 0 && (!use_req_route || g_long_text_mode == 1)) {
         Pieces spc;
         if (int rc = pieces_prepare(h, lay, n, s, &spc, -1, -1, /*disjoint=*/true)) return rc;
+        if (spc.on) {
+          bool dense = true;
+          if (int rc = dense_candidates(h, lay, n, s, &dense)) return rc;
+          if (!dense)
+            if (int rc = pieces_release(&spc, s)) return rc;
+        }
         if (spc.on) {
           int64_t* d_vprefix = nullptr;
           HIP_TRY(scratch_alloc((void**)&d_vprefix, sizeof(int64_t) * (spc.nv + 1), s));
@@ -5087,6 +5138,12 @@ static int run_count_any(const mrx_handle* h, const Layout& lay, int64_t n, int3
       // long texts: disjoint pieces between synchronising bytes, one lane each (see run_findall)
       Pieces spc;
       if (int rc = pieces_prepare(h, lay, n, s, &spc, -1, -1, /*disjoint=*/true)) return rc;
+      if (spc.on) {
+        bool dense = true;
+        if (int rc = dense_candidates(h, lay, n, s, &dense)) return rc;
+        if (!dense)
+          if (int rc = pieces_release(&spc, s)) return rc;
+      }
       if (spc.on) {
         int32_t* d_vcounts = nullptr;
         HIP_TRY(scratch_alloc((void**)&d_vcounts, sizeof(int32_t) * spc.nv, s));
