@@ -46,6 +46,10 @@ void mrx_debug_split_findall(int on);
  * frame or output exceed the group's LDS tiles go to k_subs_emit); 0 = k_subs_emit for every text,
  * anything else = chosen from the average text length. */
 void mrx_debug_subs_group(int lanes);
+/* The backtracking matcher's literal pass (k_litscan): 0 = one lane per text, 1 = always in pieces (208 bytes, so
+ * that short test texts are cut, at positions that are not multiples of 16), anything else = in 2 KiB pieces
+ * when the batch has few texts.  Results are the same. */
+void mrx_debug_litscan_pieces(int mode);
 /* Bytes of device memory the calling thread's scratch arenas hold (see mrx_release_scratch). */
 size_t mrx_debug_scratch_bytes(void);
 

@@ -110,6 +110,7 @@ def load_library():
         "mrx_debug_dynamic_texts": (None, [C.c_int]),
         "mrx_debug_subs_group": (None, [C.c_int]),
         "mrx_debug_split_findall": (None, [C.c_int]),
+        "mrx_debug_litscan_pieces": (None, [C.c_int]),
         "mrx_release_scratch": (None, []),
         "mrx_debug_scratch_bytes": (C.c_size_t, []),
         "mrx_version": (C.c_char_p, []),
@@ -138,7 +139,7 @@ TESTING_SYMBOLS = [
     "mrx_timing_reset", "mrx_timing_enable", "mrx_timing_scan_ms", "mrx_last_kernel_name",
     "mrx_debug_force_generic", "mrx_debug_long_text_kernels", "mrx_debug_scratch_bytes",
     "mrx_debug_fused_findall", "mrx_debug_dynamic_texts", "mrx_debug_subs_group",
-    "mrx_debug_split_findall",
+    "mrx_debug_split_findall", "mrx_debug_litscan_pieces",
 ]
 
 

@@ -707,10 +707,23 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_bscan(DevPlan p, const uint8_
 // stops when each of its texts has its answer.  starts[i] = position of the occurrence, -1 = none.
 // FULL: no early exit; pre[i] = {first occurrence or -1, last occurrence << 1 | "a newline in the text"} --
 // what NFAEngine's '.*' fast paths look at (nfa.mojo:577-585, 403-430), once per text instead of once per lane.
-template <bool FULL>
+// PIECES: a lane takes C bytes of a text (plus the lit_len - 1 before them) instead of a whole text -- few long
+// texts would leave most lanes without work -- and the pieces' answers meet in acc[text] = {first, last, newline}
+// (minimum / maximum / or; k_litscan_join writes pre[] from them).  vfirst[t] = first piece of text t, vfirst[n]
+// = their number, read here so that the host does not have to wait for it.
+__device__ __forceinline__ int64_t litscan_text_of(const int64_t* __restrict__ vfirst, int64_t n, int64_t v) {
+  int64_t lo = 0, hi = n;
+  while (hi - lo > 1) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (vfirst[mid] <= v) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+template <bool FULL, bool PIECES = false>
 __global__ __launch_bounds__(64 * kWsWaves) void k_litscan(const uint8_t* __restrict__ lit, int lit_len, const uint8_t* __restrict__ blob,
                                                            Layout lay, int64_t n, int32_t* __restrict__ starts,
-                                                           int2* __restrict__ pre) {
+                                                           int2* __restrict__ pre, const int64_t* __restrict__ vfirst = nullptr,
+                                                           int C = 0, int4* __restrict__ acc = nullptr) {
   constexpr int CH = 128, kRowPitch = CH + 16, LPR = CH / 16, RPI = 64 / LPR, NL = 64 / RPI;
   __shared__ __align__(16) uint8_t tiles[kWsWaves][64 * kRowPitch];
   __shared__ uint32_t maskt[256];
@@ -724,11 +737,22 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_litscan(const uint8_t* __rest
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint8_t* tile = tiles[wave];
   const int seg = lane % LPR, rsub = lane / LPR;
-  const int64_t nw = (n + 63) >> 6;
+  const int64_t nitems = PIECES ? vfirst[n] : n;
+  const int64_t nw = (nitems + 63) >> 6;
   for (int64_t w = (int64_t)blockIdx.x * kWsWaves + wave; w < nw; w += (int64_t)gridDim.x * kWsWaves) {
     const int64_t i = (w << 6) + lane;
-    const bool live = i < n;
-    const Text t = live ? lay.text(i) : Text(blob, 0);
+    const bool live = i < nitems;
+    Text t = live && !PIECES ? lay.text(i) : Text(blob, 0);
+    int64_t owner = 0;
+    int piece_at = 0;
+    if (PIECES && live) {
+      owner = litscan_text_of(vfirst, n, i);
+      const int k = (int)(i - vfirst[owner]);
+      const Text whole = lay.text(owner);
+      piece_at = k ? k * C - (lit_len - 1) : 0;   // C >= lit_len
+      const int64_t stop = (int64_t)(k + 1) * C;
+      t = Text(whole.ptr + piece_at, (int)(stop < whole.len ? stop : whole.len) - piece_at);
+    }
     const uintptr_t addr = t.len > 0 ? (uintptr_t)t.ptr : (uintptr_t)blob;
     const int mis = t.len > 0 ? (int)(addr & 15) : 0;
     const uintptr_t rb = addr & ~(uintptr_t)15;
@@ -786,11 +810,34 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_litscan(const uint8_t* __rest
     }
 #undef MRX_LS_LOAD
     const int first_pos = found_at >= 0 ? found_at - mis - (lit_len - 1) : -1;
+    if (PIECES) {
+      if (live && first_pos >= 0) {
+        atomicMin((unsigned int*)&acc[owner].x, (unsigned int)(first_pos + piece_at));
+        atomicMax(&acc[owner].y, last_at - mis - (lit_len - 1) + piece_at);
+      }
+      if (live && nl) atomicOr(&acc[owner].z, 1);
+      continue;
+    }
     if (live && starts) starts[i] = first_pos;
     if (live && pre) {
       const int last_pos = last_at >= 0 ? last_at - mis - (lit_len - 1) : -1;
       pre[i] = make_int2(first_pos, FULL ? (int)(((uint32_t)last_pos << 1) | nl) : 0);
     }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_litscan_pieces(Layout lay, int64_t n, int C, int32_t* __restrict__ cnt,
+                                                           int4* __restrict__ acc) {
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+    const int len = lay.text(t).len;
+    cnt[t] = len <= C ? 1 : (len + C - 1) / C;
+    acc[t] = make_int4(-1, -1, 0, 0);
+  }
+}
+__global__ __launch_bounds__(kBlock) void k_litscan_join(int64_t n, const int4* __restrict__ acc, int2* __restrict__ pre) {
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+    const int4 a = acc[t];
+    pre[t] = make_int2(a.x, (int)(((uint32_t)a.y << 1) | (uint32_t)a.z));
   }
 }
 
@@ -3299,6 +3346,7 @@ std::atomic<int> g_pair_tables{1};      // MRX_NO_PAIR_TABLES=1 in the environme
 std::atomic<int> g_long_text_mode{0};   // mrx_debug_long_text_kernels(): 0 by average length, 1 always, 2 never,
                                         // 3 = as 1 but stepper plans on the wavefront-per-text kernel instead of pieces
 std::atomic<int> g_force_generic{0};   // 0 best kernel, 1 no streaming kernel, 2 literal restatement (mrx_device.hpp) only
+std::atomic<int> g_litscan_pieces{2};   // mrx_debug_litscan_pieces(): 0 one lane per text, 1 always 208-byte pieces, 2 by batch shape
 
 int fail(int code, const std::string& msg) {
   g_err = msg;
@@ -3645,7 +3693,32 @@ int bt_prepass(const mrx_handle* h, const Layout& lay, int64_t n, hipStream_t s,
   const int64_t nw = (n + 63) / 64;
   int64_t g = (nw + kWsWaves - 1) / kWsWaves;
   if (g > grid_cap()) g = grid_cap();
-  if (p.bt_flags & (4 | 8))
+  // few texts: one lane per text cannot fill the device, and long ones (4549 texts of 59 KB: 71 wavefronts) take
+  // as long as one lane needs for its text.  Then the pass runs over 2 KiB pieces instead; their number stays on
+  // the device.  (The early exit of the first-occurrence-only form is worth more than that, so only FULL.)
+  const int64_t one_len = !lay.offsets && !lay.lens ? (int64_t)lay.len : -1;   // CSR / ragged: unknown here
+  const bool in_pieces = (p.bt_flags & (4 | 8)) && g_litscan_pieces != 0 &&
+                         (g_litscan_pieces == 1 || (n <= 32768 && (one_len < 0 || one_len > 4096)));
+  if (in_pieces) {
+    const int C = g_litscan_pieces == 1 ? 208 : 2048;   // tests: cuts that are not multiples of 16
+    int32_t* d_cnt = nullptr;
+    int64_t* d_vfirst = nullptr;
+    int4* d_acc = nullptr;
+    int64_t* d_tot = nullptr;
+    HIP_TRY(scratch_alloc((void**)&d_tot, sizeof(int64_t), s));
+    HIP_TRY(scratch_alloc((void**)&d_cnt, sizeof(int32_t) * n, s));
+    HIP_TRY(scratch_alloc((void**)&d_vfirst, sizeof(int64_t) * (n + 1), s));
+    HIP_TRY(scratch_alloc((void**)&d_acc, sizeof(int4) * n, s));
+    hipLaunchKernelGGL(k_litscan_pieces, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, lay, n, C, d_cnt, d_acc);
+    if (int rc = device_scan<int32_t>(d_cnt, n, d_vfirst, d_tot, s)) return rc;
+    hipLaunchKernelGGL((k_litscan<true, true>), dim3((unsigned)grid_cap()), dim3(64 * kWsWaves), 0, s, H_BLOB(h) + p.off_bt_lit,
+                       p.bt_lit_len, H_BLOB(h), lay, n, (int32_t*)nullptr, (int2*)nullptr, d_vfirst, C, d_acc);
+    hipLaunchKernelGGL(k_litscan_join, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, n, d_acc, d_pre);
+    HIP_TRY(scratch_free(d_cnt, s));
+    HIP_TRY(scratch_free(d_vfirst, s));
+    HIP_TRY(scratch_free(d_acc, s));
+    HIP_TRY(scratch_free(d_tot, s));
+  } else if (p.bt_flags & (4 | 8))
     hipLaunchKernelGGL(k_litscan<true>, dim3((unsigned)g), dim3(64 * kWsWaves), 0, s, H_BLOB(h) + p.off_bt_lit, p.bt_lit_len,
                        H_BLOB(h), lay, n, (int32_t*)nullptr, d_pre);
   else
@@ -5395,6 +5468,7 @@ void mrx_debug_fused_findall(int mode) { g_fused = mode < 0 ? 0 : mode > 2 ? 0 :
 void mrx_debug_dynamic_texts(int mode) { g_dyn_mode = mode < 0 ? 0 : mode > 2 ? 0 : mode; }
 void mrx_debug_split_findall(int on) { g_split_findall = on ? 1 : 0; }
 void mrx_debug_subs_group(int g) { g_subs_group = (g == 0 || g == 16 || g == 32 || g == 64 || g == 256) ? g : -1; }
+void mrx_debug_litscan_pieces(int mode) { g_litscan_pieces = (mode == 0 || mode == 1) ? mode : 2; }
 void mrx_release_scratch(void) { scratch_release_all(); }
 size_t mrx_debug_scratch_bytes(void) { return scratch_bytes_reserved(); }
 

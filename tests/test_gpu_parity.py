@@ -1860,6 +1860,48 @@ def test_backtracker_routed_operations_match_oracle(pat):
             assert (rx.count(batch).cpu().numpy() == cnt).all()
         assert (np.asarray(ss2) == np.asarray(ss)).all() and (np.asarray(se2) == np.asarray(se)).all()
         assert [len(x) for x in lists] == [int(c) for c in cnt]
+        for mode in (0, 1):   # the literal pass one lane per text / in 208-byte pieces (by default: 2 KiB pieces here)
+            with litscan_pieces(mode):
+                ss3, se3 = rx.match_next(texts)
+                assert rx.findall_lists(texts) == lists and rx.sub(b"<>", texts) == subs, (pat, mode)
+                assert (rx.count(batch).cpu().numpy() == cnt).all()
+            assert (np.asarray(ss3) == np.asarray(ss)).all() and (np.asarray(se3) == np.asarray(se)).all(), (pat, mode)
+
+
+@pytest.mark.parametrize("pat", [b"hello.*", b".*@example\\.com", b"hello.*world", b".*world"])
+def test_literal_pass_in_pieces_on_long_texts(pat):
+    """Few long texts: the backtracking matcher's literal pass (first / last occurrence, newline flag) cut into
+    2 KiB pieces whose answers meet per text -- occurrences across the cuts, only in the first or last piece, none --
+    against one lane per text and the oracle."""
+    _need_gpu()
+    rx = M.compile_regex(pat)
+    rng = np.random.default_rng(zlib.crc32(pat) + 5)
+    texts = []
+    for i in range(40):
+        L = int(rng.integers(3000, 30000))
+        t = bytearray(rng.choice(np.frombuffer(b"abcdefg xyz.@", dtype=np.uint8), size=L).tobytes())
+        if i % 4 != 3:
+            for word in (b"hello", b"world", b"@example.com"):
+                for _ in range(int(rng.integers(0, 3))):
+                    at = int(rng.integers(0, L - 16))
+                    if i % 4 == 1:
+                        at = min(L - 16, (at // 2048) * 2048 + 2048 - int(rng.integers(0, len(word) + 1)))   # on a cut
+                    t[at:at + len(word)] = word
+        if i % 5 == 0:
+            t[int(rng.integers(0, L))] = 10
+        texts.append(bytes(t))
+    texts += [b"hello world" + b"q" * 5000, b"q" * 5000 + b"hello world", b"q" * 2044 + b"hello" + b"q" * 2043 + b"world",
+              b"u@example.com" + b"\n" * 4000, b"q" * 6000]
+    ss, se = rx.match_next(texts)
+    lists = rx.findall_lists(texts)
+    with litscan_pieces(0):
+        ss0, se0 = rx.match_next(texts)
+        assert rx.findall_lists(texts) == lists
+    assert (np.asarray(ss0) == np.asarray(ss)).all() and (np.asarray(se0) == np.asarray(se)).all()
+    for i, t in enumerate(texts):
+        w = O.search(pat, t)
+        assert (int(ss[i]), int(se[i])) == (w if w else (-1, -1)), (pat, i)
+        assert lists[i] == O.findall(pat, t), (pat, i)
 
 
 @pytest.mark.parametrize("pat", [b"[a-z]+\\d+", b"(\\d{3})(\\d{3})(\\d{4})", b"hello"])
@@ -1940,6 +1982,17 @@ def subs_group(lanes):
         yield
     finally:
         lib.mrx_debug_subs_group(-1)
+
+
+@contextlib.contextmanager
+def litscan_pieces(mode):
+    """The backtracking matcher's literal pass: 0 = one lane per text, 1 = always in 208-byte pieces."""
+    lib = M.load_library()
+    lib.mrx_debug_litscan_pieces(mode)
+    try:
+        yield
+    finally:
+        lib.mrx_debug_litscan_pieces(2)
 
 
 @contextlib.contextmanager
