@@ -37,4 +37,5 @@ from .hybrid import (  # noqa: E402,F401
     split,
     sub,
     UnsupportedByOracle,
+    ReferenceDoesNotTerminate,
 )

@@ -15,7 +15,9 @@ import os
 MODE = int(os.environ.get("MRX_LONG_TEXT_MODE", "0"))
 M.load_library().mrx_debug_long_text_kernels(MODE)
 bad = 0; checked = 0
-for seed in range(30000, 30012):
+# MRX_FUZZ_SEEDS=first:count picks other generator seeds (default 30000:12, the set profiles/rNN_fuzz.txt quotes)
+SEED0, NSEEDS = (int(x) for x in os.environ.get("MRX_FUZZ_SEEDS", "30000:12").split(":"))
+for seed in range(SEED0, SEED0 + NSEEDS):
     rng = np.random.default_rng(seed)
     texts = rtexts(rng, 30, 60, b"abcxyz019 -@.") + rtexts(rng, 12, 220, b"abcfoobarhellocatdog0123456789 xyz@.-") + [b"", b"a", b"foobar", b"hello", b"abc123", b"cat dog", b"http://id.no", b"q"*150+b"1"]
     if MODE:
