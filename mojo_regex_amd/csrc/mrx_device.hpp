@@ -832,7 +832,11 @@ __device__ inline void sub_text(const Ctx& c, const Text& t, const uint8_t* repl
         const ReplSeg sg = tpl[k];
         if (sg.group_ref > 0) {
           const int cs = sg.group_ref <= 9 ? caps.gs(sg.group_ref) : -1;
-          if (cs >= 0) out.bytes(t.ptr + cs, caps.ge(sg.group_ref) - cs);
+          // a repeated group at the end of the text can carry a span that ends one byte behind it ('^(\\d)+' on
+          // "..1": _match_group_with_quantifier's span arithmetic); Match.get_match_text (matching.mojo:39-46)
+          // reads that byte unchecked upstream.  Here, as in the oracle, the group's text ends with the text.
+          const int ce = caps.ge(sg.group_ref) < t.len ? caps.ge(sg.group_ref) : t.len;
+          if (cs >= 0 && ce > cs) out.bytes(t.ptr + cs, ce - cs);
         } else {
           out.bytes(repl + sg.start, sg.length);
         }
@@ -852,9 +856,12 @@ __device__ inline void sub_text(const Ctx& c, const Text& t, const uint8_t* repl
   auto apply_tpl = [&](int match_start) {  // _apply_template_fixed, matcher.mojo:1592-1621
     for (int k = 0; k < ntpl; ++k) {
       const ReplSeg s = tpl[k];
-      if (s.group_ref > 0 && s.group_ref <= c.p.fixed_ngroups)
-        out.bytes(t.ptr + match_start + c.p.fixed_off[s.group_ref], c.p.fixed_w[s.group_ref]);
-      else
+      if (s.group_ref > 0 && s.group_ref <= c.p.fixed_ngroups) {
+        // upstream reads the window unchecked; here (and in the oracle) it ends with the text -- see k_subs_reach
+        const int gs = match_start + c.p.fixed_off[s.group_ref];
+        const int gw = gs + c.p.fixed_w[s.group_ref] <= t.len ? c.p.fixed_w[s.group_ref] : t.len - gs;
+        if (gw > 0) out.bytes(t.ptr + gs, gw);
+      } else
         out.bytes(repl + s.start, s.length);
     }
   };

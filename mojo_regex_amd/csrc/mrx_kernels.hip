@@ -4626,9 +4626,26 @@ namespace {
 // mrx_debug_subs_group(): lanes per text in k_subs_wave (16 / 32 / 64), 0 = k_subs_emit only, -1 = by text length
 std::atomic<int> g_subs_group{env_int("MRX_SUBS_G", -1)};
 // regex.sub for streamable plans: streaming findall -> sizes -> prefix sums -> emit (see k_subs_*)
+// A replacement that copies a fixed-width group copies text[match start + offset ...] whatever the match looked like
+// (_apply_template_fixed, matcher.mojo:1592-1621; the widths come from the pattern text, quantifiers ignored:
+// 'x(\\d)?' has its group at offset 1 even when the match is "x").  A match close to the end of its text can thus
+// reach behind the text -- upstream reads those bytes unchecked; the oracle's slice and sub_text() stop at the end of
+// the text, so the replacement is shorter than R bytes there.  The spans route has one R for every match: it
+// looks at the LAST match of each text (the one that reaches furthest) and hands the call back
+// (kSubsRetryGeneric) when any reaches behind its text.
+constexpr int kSubsRetryGeneric = 1 << 20;
+__global__ __launch_bounds__(kBlock) void k_subs_reach(int64_t n, const int64_t* __restrict__ offsets,
+                                                       const int64_t* __restrict__ prefix, const int32_t* __restrict__ spans,
+                                                       int64_t span_cap, int reach, int32_t* __restrict__ over) {
+  if (prefix[n] > span_cap) return;   // the spans are incomplete: the caller repeats the findall
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t a = prefix[i], b = prefix[i + 1];
+    if (b > a && (int64_t)spans[2 * (b - 1)] + reach > offsets[i + 1] - offsets[i]) *over = 1;
+  }
+}
 int sub_from_spans(const mrx_handle* h, const Layout& lay, int64_t n, const std::vector<uint16_t>& rmap,
                    int64_t count, int64_t* out_off, uint8_t* out, int64_t out_cap, int64_t* total_bytes,
-                   hipStream_t s) {
+                   hipStream_t s, int group_reach = 0) {
   // Two host synchronisations per call: the batch's byte count and longest text (sizes the span buffer
   // and, handed on, spares findall its own look), and the two totals -- matches and output bytes -- behind
   // findall, sizes and prefix sums, all enqueued without waiting.
@@ -4642,6 +4659,10 @@ int sub_from_spans(const mrx_handle* h, const Layout& lay, int64_t n, const std:
   int32_t* d_cum = nullptr;
   int64_t *d_sizes = nullptr, *d_total = nullptr;
   int32_t* d_left = nullptr;
+  int32_t* d_over = nullptr;
+  int32_t over = 0;
+  HIP_TRY(scratch_alloc((void**)&d_over, sizeof(int32_t), s));
+  if (group_reach > 0) HIP_TRY(hipMemsetAsync(d_over, 0, sizeof(int32_t), s));
   HIP_TRY(scratch_alloc((void**)&d_prefix, sizeof(int64_t) * (n + 1), s));
   HIP_TRY(scratch_alloc((void**)&d_rmap, sizeof(uint16_t) * (R + 8), s));
   HIP_TRY(scratch_alloc((void**)&d_sizes, sizeof(int64_t) * n, s));
@@ -4680,6 +4701,11 @@ int sub_from_spans(const mrx_handle* h, const Layout& lay, int64_t n, const std:
     HIP_TRY(hipGetLastError());
     rc = device_scan<int64_t>(d_sizes, n, out_off, d_total, s);
     if (rc != MRX_OK) return rc;
+    if (group_reach > 0) {
+      hipLaunchKernelGGL(k_subs_reach, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, n, lay.offsets, d_prefix, d_spans, cap,
+                         group_reach, d_over);
+      HIP_TRY(hipMemcpyAsync(&over, d_over, sizeof over, hipMemcpyDeviceToHost, s));
+    }
     HIP_TRY(hipMemcpyAsync(&nm, d_prefix + n, sizeof nm, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(&tot, d_total, sizeof tot, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -4689,7 +4715,9 @@ int sub_from_spans(const mrx_handle* h, const Layout& lay, int64_t n, const std:
     HIP_TRY(scratch_free(d_cum, s));
     cap = nm;   // more matches than one per eight bytes: once more with room for all of them
   }
-  {
+  if (over) {
+    rc = kSubsRetryGeneric;
+  } else {
     if (total_bytes) *total_bytes = tot;
     if (tot > out_cap) {
       rc = fail(MRX_E_CAPACITY, "output buffer too small: need " + std::to_string(tot));
@@ -4736,6 +4764,7 @@ int sub_from_spans(const mrx_handle* h, const Layout& lay, int64_t n, const std:
   HIP_TRY(scratch_free(d_sizes, s));
   HIP_TRY(scratch_free(d_total, s));
   HIP_TRY(scratch_free(d_left, s));
+  HIP_TRY(scratch_free(d_over, s));
   return rc;
 }
 }  // namespace
@@ -5312,23 +5341,31 @@ int mrx_sub_dev(const mrx_handle* h, const char* repl, size_t repl_len, int64_t 
   const bool spans_ok = !(sfl & PF_EXACT_LITERAL) &&
                         ((!g_force_generic && (sfl & PF_STREAM_SEARCH)) ||
                          (g_force_generic < 2 && (sfl & PF_STEP_SEARCH) && !(sfl & PF_PREFILTER)));
-  if (spans_ok && !general_groups && n > 0 && off) {
+  // (group templates of "concat" patterns that are not purely groups: texts of exactly fixed_total bytes take the
+  // whole-text shortcut, which only sub_text() has)
+  const bool shortcut_differs = groups && h->hp.fixed_concat && !h->hp.fixed_pure;
+  if (spans_ok && !general_groups && !shortcut_differs && n > 0 && off) {
     // replacement as a fixed-length byte map
     std::vector<uint16_t> rmap;
+    int group_reach = 0;   // how far behind a match's start the template reads
     if (groups) {
       for (const ReplSeg& sg : tpl) {
-        if (sg.group_ref > 0 && sg.group_ref <= h->hp.fixed_ngroups)
+        if (sg.group_ref > 0 && sg.group_ref <= h->hp.fixed_ngroups) {
           for (int j = 0; j < h->hp.fixed_w[sg.group_ref]; ++j)
             rmap.push_back((uint16_t)(0x8000 | (h->hp.fixed_off[sg.group_ref] + j)));
+          group_reach = std::max(group_reach, h->hp.fixed_off[sg.group_ref] + h->hp.fixed_w[sg.group_ref]);
+        }
         else
           for (int j = 0; j < sg.length; ++j) rmap.push_back((uint8_t)r[sg.start + j]);
       }
     } else {
       for (unsigned char ch : r) rmap.push_back(ch);
     }
-    if (rmap.size() <= 4096 && h->hp.fixed_total < 0x7FFF)
-      return sub_from_spans(h, Layout{d, off, 0, nullptr, 0}, n, rmap, count, out_off, out, out_cap,
-                            total_bytes, s);
+    if (rmap.size() <= 4096 && h->hp.fixed_total < 0x7FFF) {
+      const int rc = sub_from_spans(h, Layout{d, off, 0, nullptr, 0}, n, rmap, count, out_off, out, out_cap,
+                                    total_bytes, s, group_reach);
+      if (rc != kSubsRetryGeneric) return rc;   // else: a group reaches behind its text, the lane-per-text form cuts it
+    }
   }
   uint8_t* d_repl = nullptr;
   ReplSeg* d_tpl = nullptr;

@@ -250,6 +250,27 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
       }
       if (ok && ng > 0) {
         hp.fixed_total = total; hp.fixed_ngroups = ng; hp.fixed_concat = !lits;
+        // nothing but (\d{N}) / (\d) groups, end to end: only then is the whole-text shortcut of
+        // _sub_impl_with_repl (matcher.mojo:1726-1744: a text of exactly this many bytes is rewritten iff it is
+        // all digits, no engine asked) the same as matching.  Literals behind the last group are not counted
+        // upstream ('(\\d)*a' has fixed_total 1 and "concat"), so such patterns take the shortcut on texts they
+        // would match differently.
+        {
+          size_t i = 0;
+          bool pure = !lits;
+          while (pure && i < pattern.size()) {
+            if (pattern.compare(i, 3, "(\\d") != 0) { pure = false; break; }
+            i += 3;
+            if (i < pattern.size() && pattern[i] == '{') {
+              const size_t close = pattern.find('}', i);
+              if (close == std::string::npos) { pure = false; break; }
+              i = close + 1;
+            }
+            if (i >= pattern.size() || pattern[i] != ')') { pure = false; break; }
+            ++i;
+          }
+          hp.fixed_pure = pure;
+        }
         std::memcpy(hp.fixed_off, off, sizeof off);
         std::memcpy(hp.fixed_w, w, sizeof w);
       }

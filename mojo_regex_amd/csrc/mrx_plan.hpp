@@ -138,6 +138,7 @@ struct HostPlan {
   // fixed-width group form
   int fixed_total = -1, fixed_ngroups = 0;
   bool fixed_concat = false;
+  bool fixed_pure = false;   // the pattern is nothing but (\d{N}) groups (see build_plan)
   int fixed_off[10] = {0}, fixed_w[10] = {0};
   // device payload
   DevPlan dev{};

@@ -16,6 +16,7 @@ MODE = int(os.environ.get("MRX_LONG_TEXT_MODE", "0"))
 M.load_library().mrx_debug_long_text_kernels(MODE)
 bad = 0; checked = 0
 # MRX_FUZZ_SEEDS=first:count picks other generator seeds (default 30000:12, the set profiles/rNN_fuzz.txt quotes)
+GROUPS = os.environ.get("MRX_FUZZ_GROUPS", "0") == "1"
 SEED0, NSEEDS = (int(x) for x in os.environ.get("MRX_FUZZ_SEEDS", "30000:12").split(":"))
 for seed in range(SEED0, SEED0 + NSEEDS):
     rng = np.random.default_rng(seed)
@@ -26,6 +27,40 @@ for seed in range(SEED0, SEED0 + NSEEDS):
         pb = p.encode()
         try: rx = M.compile_regex(pb)
         except M.RegexSyntaxError: continue
+        # MRX_FUZZ_GROUPS=1: capture groups instead -- sub with \\1 / \\2 and the group spans of the first match
+        # (the backtracking matcher's flat program, or the fixed-width form) against the oracle
+        if GROUPS:
+            if rx.num_groups < 1: continue
+            repl = b"<\\1>" if rx.num_groups == 1 else b"<\\2|\\1>"
+            orx = O.compile_regex(pb)
+            try: got = rx.sub(repl, texts, 0)
+            except M.UnsupportedPattern: got = None
+            if got is not None:
+                for t, g in zip(texts, got):
+                    try: w = orx.sub(repl, t, 0)
+                    except (UnsupportedByOracle, O.ReferenceDoesNotTerminate): continue
+                    checked += 1
+                    if g != w:
+                        bad += 1
+                        if bad < 10: print("MISMATCH group sub", repr(p), t, g, w)
+            try: caps = rx.captures(texts)
+            except M.UnsupportedPattern: caps = None
+            if caps is not None and orx.fixed_total_width < 0:
+                ng = rx.num_groups
+                bt = getattr(getattr(orx.matcher, "nfa_matcher", None), "backtrack", None)
+                for t, c in zip(texts, caps if bt is not None else []):
+                    try: m, groups = bt.match_next_with_groups(t, 0)
+                    except (UnsupportedByOracle, O.ReferenceDoesNotTerminate): continue
+                    want = [(-1, -1)] * (ng + 1)
+                    if m is not None:
+                        for gid, gs, ge in groups:
+                            if 1 <= gid <= ng: want[gid - 1] = (gs, ge)
+                        want[ng] = m
+                    checked += 1
+                    if [tuple(int(x) for x in r) for r in c] != want:
+                        bad += 1
+                        if bad < 10: print("MISMATCH captures", repr(p), t, [tuple(int(x) for x in r) for r in c], want)
+            continue
         for op in ("findall", "search", "match_first"):
             try:
                 if op == "findall": got = rx.findall_lists(texts)

@@ -284,6 +284,33 @@ def test_sub_matches_oracle(pat, repl, count):
         assert g == O.sub(pat, repl, t, count), (pat, repl, t, count)
 
 
+@pytest.mark.parametrize("pat", [b"x(\\d)?", b"(\\d)?", b"(\\d)*", b"^(\\d)+", b"(\\d)+", b"ab(\\d)?(\\d)?", b"(\\d)(\\d)?x?",
+                                 b"(\\d{3})(\\d{3})(\\d{4})", b"ab(\\d)*", b"(\\d{2})-(\\d)?", b"(\\d)*a", b"(\\d)(\\d)x", b"(\\d{2})+"])
+def test_fixed_width_group_windows_end_with_the_text(pat):
+    """CompiledRegex._try_precompute_fixed_sub takes the group widths from the pattern text, quantifiers ignored
+    (matcher.mojo:1002-1035), and _apply_template_fixed copies text[match start + offset ...] unchecked
+    (matcher.mojo:1592-1621): near the end of a text the window reaches behind it.  The oracle's slice ends with the
+    text, and so do the product's two forms -- the spans route notices (k_subs_reach) and hands such a batch to the
+    lane-per-text kernel.  Batches with and without such a match, CSR neighbours whose first byte would show."""
+    _need_gpu()
+    rx = M.compile_regex(pat)
+    orx = O.compile_regex(pat)
+    assert orx.fixed_total_width >= 0
+    rng = np.random.default_rng(zlib.crc32(pat))
+    reaching = _random_texts(rng, 120, 40, b"abx0123456789 ") + [b"x", b"abx", b"ab", b"ab1", b"12x", b"1", b"", b"a1x", b"zz9",
+                                                                  b"6502530000", b"650253000", b"call 6502530000", b"a", b"7", b"77", b"7a", b"12", b"1x", b"123", b"12x"]
+    inside = [t + b" ." for t in reaching if t]   # every match has the whole window in front of the text's end
+    for texts in (reaching, inside):
+        for repl in (b"<\\1>", b"[\\2\\1]", b"#"):
+            for count in (0, 1):
+                got = rx.sub(repl, texts, count)
+                for t, g in zip(texts, got):
+                    try:
+                        assert g == orx.sub(repl, t, count), (pat, repl, count, t)
+                    except O.ReferenceDoesNotTerminate:
+                        pass
+
+
 def test_captures_fixed_width_groups():
     _need_gpu()
     pat = b"(\\d{3})(\\d{3})(\\d{4})"
@@ -1760,7 +1787,7 @@ def test_general_capture_groups_match_the_backtracking_oracle(pat, repl):
     texts = _random_texts(rng, 160, 60, al) + _random_texts(rng, 20, 300, al)
     texts += [b"hello world", b"42 and 99", b"abc 123 def 456", b"john@example.com mary@test.com", b"ab12x cdx", b"foo  bar",
               b"aabbc bc abc", b"  17  ", b"k9-zz-top", b"2024-12 19-1", b"xaayxbby", b"a.b@c.d e@f", b"3.14 2.718", b"",
-              b"hello world said Hello World", b"Ada Lovelace and Alan Turing"]
+              b"hello world said Hello World", b"Ada Lovelace and Alan Turing", b"z9", b"1", b"77"]
     for count in (0, 1):
         got = rx.sub(repl, texts, count)
         for i, t in enumerate(texts):
