@@ -2627,7 +2627,7 @@ __global__ __launch_bounds__(kBlock) void k_virt_first(int64_t n, const int64_t*
 // unchanged on a view of the batch: text i = [offsets[i] + start_i, len_i - start_i).
 __global__ __launch_bounds__(kBlock) void k_view_build(Layout lay, int64_t n, int32_t start, const int32_t* __restrict__ starts,
                                                        int64_t* __restrict__ vstart, int32_t* __restrict__ vlen,
-                                                       uint32_t* __restrict__ vskip) {
+                                                       uint32_t* __restrict__ vskip, int beyond_neg) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += (int64_t)gridDim.x * blockDim.x) {
     if (i == n) {   // an end offset for the kernels that size things by the batch's byte count
       vstart[n] = lay.offsets ? lay.offsets[n] : n * lay.stride;
@@ -2639,13 +2639,17 @@ __global__ __launch_bounds__(kBlock) void k_view_build(Layout lay, int64_t n, in
     const int s0 = starts ? starts[i] : start;
     const int sc = s0 < 0 ? 0 : s0 > len ? len : s0;
     vstart[i] = a + sc;
-    vlen[i] = len - sc;
+    // beyond_neg (the backtracking matcher's match_first): a start behind the end is a view of NEGATIVE length --
+    // position 0 of it lies s0 - len bytes behind the text's end, where no byte matches and '$' does not hold
+    // either (nfa.mojo:998-1006 compares with the length), which is what bt_match_at() makes of it
+    vlen[i] = beyond_neg && s0 > len ? len - s0 : len - sc;
     vskip[i] = 0x80000000u;   // k_stream_findall VIRT: a whole text (nothing skipped, may end a match at its end)
   }
 }
 // results of the view -> results of the text.  rule bits: 1 = None for start > 0 ('^' on the DFA /
 // OnePass route), 2 = match_first at start > len is the empty match (start, start), 4 = is_match at
-// start > len is true, 8 = is_match operation (out_flag), else spans
+// start > len is true, 8 = is_match operation (out_flag), else spans, 16 = start > len was answered by the
+// kernel itself (k_view_build's beyond_neg)
 __global__ __launch_bounds__(kBlock) void k_view_fix(Layout lay, int64_t n, int32_t start, const int32_t* __restrict__ starts,
                                                      int rules, int32_t* __restrict__ out_s, int32_t* __restrict__ out_e,
                                                      uint8_t* __restrict__ out_flag) {
@@ -2653,7 +2657,7 @@ __global__ __launch_bounds__(kBlock) void k_view_fix(Layout lay, int64_t n, int3
     const int len = lay.text(i).len;
     const int s0 = starts ? starts[i] : start;
     const bool none = s0 < 0 || ((rules & 1) && s0 > 0);
-    const bool beyond = s0 > len;
+    const bool beyond = s0 > len && !(rules & 16);
     if (rules & 8) {
       if (none) out_flag[i] = 0;
       else if (beyond) out_flag[i] = (rules & 4) ? 1 : 0;
@@ -4897,7 +4901,7 @@ static int run_search_any(const mrx_handle* h, const Layout& lay, int64_t n, int
       hipLaunchKernelGGL(k_litscan<false>, dim3((unsigned)g), dim3(64 * kWsWaves), 0, s, H_BLOB(h) + p.off_pre, p.pre_len, H_BLOB(h), lay, n,
                          d_cand, (int2*)nullptr);
     }
-    hipLaunchKernelGGL(k_view_build, dim3(grid_for(n + 1, kBlock)), dim3(kBlock), 0, s, lay, n, 0, d_cand, vstart, vlen, vskip);
+    hipLaunchKernelGGL(k_view_build, dim3(grid_for(n + 1, kBlock)), dim3(kBlock), 0, s, lay, n, 0, d_cand, vstart, vlen, vskip, 0);
     HIP_TRY(hipGetLastError());
     Layout view{lay.data, vstart, 0, nullptr, 0};
     view.vlen = vlen;
@@ -5075,7 +5079,11 @@ static int run_at(int op, const mrx_handle* h, const Layout& lay, int64_t n, int
   HIP_TRY(scratch_alloc((void**)&vstart, sizeof(int64_t) * (n + 1), s));
   HIP_TRY(scratch_alloc((void**)&vlen, sizeof(int32_t) * n, s));
   HIP_TRY(scratch_alloc((void**)&vskip, sizeof(uint32_t) * n, s));
-  hipLaunchKernelGGL(k_view_build, dim3(grid_for(n + 1, kBlock)), dim3(kBlock), 0, s, lay, n, start, d_starts, vstart, vlen, vskip);
+  // NFAEngine.match_first (is_match = bool of it) at start > len: the program decides -- zero repetitions and
+  // groups pass, bytes and '$' do not ('[^0-9]{0,2}$' at len + 1: None; 'x?' there: the empty match)
+  const bool bt_first = op != AT_SEARCH && (h->hp.dev.flags & PF_BT_FIRST) && plan_uses_backtracker(h);
+  hipLaunchKernelGGL(k_view_build, dim3(grid_for(n + 1, kBlock)), dim3(kBlock), 0, s, lay, n, start, d_starts, vstart, vlen, vskip,
+                     bt_first ? 1 : 0);
   Layout view{lay.data, vstart, 0, nullptr, 0};
   view.vlen = vlen;
   view.vskip = vskip;
@@ -5085,7 +5093,7 @@ static int run_at(int op, const mrx_handle* h, const Layout& lay, int64_t n, int
   // OnePassNFA.match_first (onepass.mojo:445) answer None at start > 0; the LazyDFA does not (quirk A.6 #9)
   const bool caret = p.kind == PLAN_DFA ? (p.flags & PF_START_ANCHOR) != 0
                                          : (hp.first_onepass && hp.onepass.has_start_anchor && op != AT_SEARCH);
-  int rules = caret ? 1 : 0;
+  int rules = (caret ? 1 : 0) | (bt_first ? 16 : 0);
   // start > len.  match_first: DFAEngine None (dfa.mojo:1922-1923), ".*" None (matcher.mojo:741-745); LazyDFA
   // ._run_lazy and OnePassNFA.match_first run no step and report the empty match (start, start) when the
   // start state accepts (pikevm.mojo:820-867, onepass.mojo:447-488).  match_next: None on every route.

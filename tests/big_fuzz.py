@@ -15,6 +15,89 @@ import os
 MODE = int(os.environ.get("MRX_LONG_TEXT_MODE", "0"))
 M.load_library().mrx_debug_long_text_kernels(MODE)
 bad = 0; checked = 0
+EXTRA = os.environ.get("MRX_FUZZ_EXTRA", "0") == "1"
+
+
+def _cmp(what, p, t, got, want_fn):
+    global bad, checked
+    try: w = want_fn()
+    except (UnsupportedByOracle, O.ReferenceDoesNotTerminate): return
+    checked += 1
+    if got != w:
+        bad += 1
+        if bad < 15: print("MISMATCH", what, repr(p), t, got, w, flush=True)
+
+
+def _span(a, b):
+    return (int(a), int(b)) if a >= 0 else None
+
+
+def extra_checks(rx, pb, p, texts, rng):
+    """MRX_FUZZ_EXTRA=1: what the default mode leaves out -- texts of arbitrary bytes, fixed-pitch batches (with per-text
+    lengths and padding that could match; one common length, with and without padding), the `start` argument,
+    sub with a count, is_match and count."""
+    import torch
+    orx = O.compile_regex(pb)
+    binary = [bytes(rng.integers(0, 256, size=int(k), dtype=np.uint8).tolist()) for k in rng.integers(0, 70, size=16)]
+    binary += [bytes(rng.choice(np.frombuffer(b"ab01 \x00\xff\x80\n\t.-", dtype=np.uint8), size=int(k)).tolist()) for k in rng.integers(0, 50, size=12)]
+    def ops_on(tag, tx, batch):
+        # batch: None = host lists (CSR), else a DeviceBatch holding the same texts
+        for op in ("findall", "search", "match_first", "is_match", "count"):
+            try:
+                if op == "findall":
+                    if batch is None: got = rx.findall_lists(tx)
+                    else:
+                        pre, sp, tot = rx._dev_findall(batch)
+                        pre = pre.cpu().numpy(); sp = sp[:tot].cpu().numpy()
+                        got = [[(int(a), int(b)) for a, b in sp[pre[i]:pre[i + 1]]] for i in range(len(tx))]
+                    for t, g in zip(tx, got): _cmp(tag + " findall", p, t, g, lambda: O.findall(pb, t))
+                elif op == "count":
+                    b2 = batch if batch is not None else M.DeviceBatch.from_texts(tx)
+                    got = rx.count(b2).cpu().numpy()
+                    for t, g in zip(tx, got): _cmp(tag + " count", p, t, int(g), lambda: len(O.findall(pb, t)))
+                elif op == "is_match":
+                    got = rx.is_match(tx if batch is None else batch)
+                    got = got.cpu().numpy() if batch is not None else got
+                    for t, g in zip(tx, got): _cmp(tag + " is_match", p, t, bool(g), lambda: bool(orx.is_match(t, 0)))
+                else:
+                    fn = rx.match_next if op == "search" else rx.match_first
+                    s, e = fn(tx if batch is None else batch)
+                    if batch is not None: s, e = s.cpu().numpy(), e.cpu().numpy()
+                    for t, a, b in zip(tx, s, e): _cmp(tag + " " + op, p, t, _span(a, b), lambda: getattr(O, op)(pb, t))
+            except M.UnsupportedPattern:
+                continue
+    ops_on("binary", binary, None)
+    # fixed pitch with per-text lengths; the padding holds bytes of the same alphabet
+    short = [t for t in texts if len(t) <= 96][:40]
+    P = 96
+    al = np.frombuffer(b"abcxyz019 -@.foobarhello", dtype=np.uint8)
+    rows = rng.choice(al, size=(len(short), P))
+    for i, t in enumerate(short): rows[i, :len(t)] = np.frombuffer(t, dtype=np.uint8)
+    data = torch.from_numpy(rows.reshape(-1).copy()).cuda()
+    lens = torch.tensor([len(t) for t in short], dtype=torch.int32, device="cuda")
+    ops_on("pitch+lens", short, M.DeviceBatch.strided(data, P, lens=lens))
+    # one common length: rows used whole (the headline layout), and with padding behind them
+    whole = [bytes(r.tolist()) for r in rows]
+    ops_on("pitch=len", whole, M.DeviceBatch.strided(data, P, length=P))
+    cut = [w[:80] for w in whole]
+    ops_on("pitch>len", cut, M.DeviceBatch.strided(data, P, length=80))
+    # the `start` argument
+    sub_t = texts[:40]
+    starts = np.array([int(rng.integers(0, len(t) + 2)) for t in sub_t], dtype=np.int32)
+    for op, meth, ofn in (("match_first", rx.match_first_at, orx.match_first), ("search", rx.match_next_at, orx.match_next)):
+        try: s, e = meth(sub_t, starts)
+        except M.UnsupportedPattern: continue
+        for t, st, a, b in zip(sub_t, starts, s, e): _cmp("start " + op + " @%d" % st, p, t, _span(a, b), lambda: ofn(t, int(st)))
+    try:
+        f = rx.is_match_at(sub_t, starts)
+        for t, st, g in zip(sub_t, starts, f): _cmp("start is_match @%d" % st, p, t, bool(g), lambda: bool(orx.is_match(t, int(st))))
+    except M.UnsupportedPattern:
+        pass
+    # sub with a count
+    for cnt in (1, 2):
+        try: got = rx.sub(b"#", sub_t, cnt)
+        except M.UnsupportedPattern: break
+        for t, g in zip(sub_t, got): _cmp("sub count=%d" % cnt, p, t, g, lambda: O.sub(pb, b"#", t, cnt))
 # MRX_FUZZ_SEEDS=first:count picks other generator seeds (default 30000:12, the set profiles/rNN_fuzz.txt quotes)
 GROUPS = os.environ.get("MRX_FUZZ_GROUPS", "0") == "1"
 SEED0, NSEEDS = (int(x) for x in os.environ.get("MRX_FUZZ_SEEDS", "30000:12").split(":"))
@@ -60,6 +143,9 @@ for seed in range(SEED0, SEED0 + NSEEDS):
                     if [tuple(int(x) for x in r) for r in c] != want:
                         bad += 1
                         if bad < 10: print("MISMATCH captures", repr(p), t, [tuple(int(x) for x in r) for r in c], want)
+            continue
+        if EXTRA:
+            extra_checks(rx, pb, p, texts, rng)
             continue
         for op in ("findall", "search", "match_first"):
             try:

@@ -1693,7 +1693,9 @@ def test_scratch_arena_survives_failed_calls():
 AT_PATTERNS = [b"hello", b"[a-z]+\\d+", b"\\d+", b"[0-9]*", b"[a-z]*[0-9]+", b"^abc", b"^[a-z]+", b"a$", b"^abc$", b".*", b"",
                b"(x|y|foo|bar)+", b"(\\d{3})(\\d{3})(\\d{4})", b"hello world this is long", b"\\w+@\\w+\\.com", b"\\d{3}-\\d{4}",
                b"(foo|foobar)x", b"\\d+(\\.\\d+)?", b"[a-c]+[x-z]?", b"^[a-z]+[0-9]+$", b"^\\d+$", b"(a|b)*c", b"^(a|b)*c",
-               b"abab", b"[^0-9]+", b"x*", b"hello.*", b".*@b\\.com", b"^aaaa.*a$"]
+               b"abab", b"[^0-9]+", b"x*", b"hello.*", b".*@b\\.com", b"^aaaa.*a$",
+               # match_first on the backtracking matcher: a start behind the end is the program's to answer
+               b"xy|[^0-9]{0,2}$", b"ab|x?", b"(a|b)?$", b"a*(b|c)*", b"ab|[a-z]*$"]
 
 
 @pytest.mark.parametrize("pat", AT_PATTERNS)
