@@ -28,6 +28,44 @@ def _cmp(what, p, t, got, want_fn):
         if bad < 15: print("MISMATCH", what, repr(p), t, got, w, flush=True)
 
 
+NFA = os.environ.get("MRX_FUZZ_NFA", "0") == "1"
+
+
+def nfa_checks(pb, p, texts):
+    """MRX_FUZZ_NFA=1: every pattern on the NFA route (lazydfa_semantics: PikeVM program, LazyDFA tables) and on the
+    bitset-NFA kernels (bitset_nfa), whatever the reference's router would pick, against the oracle's forced-NFA
+    matcher; split through the module-level API."""
+    from mrx_ref.hybrid import CompiledRegex as OracleRegex
+    try: o = OracleRegex(pb, force_nfa=True)
+    except Exception: return
+    for forced in (False, True):
+        try: rx = M.compile_regex(pb, lazydfa_semantics=True, bitset_nfa=forced)
+        except (M.RegexSyntaxError, M.UnsupportedPattern): continue
+        if forced and "device.bitset=yes" not in rx.describe(): continue
+        tag = "bitset" if forced else "nfa"
+        try:
+            got = rx.findall_lists(texts)
+            for t, g in zip(texts, got): _cmp(tag + " findall", p, t, g, lambda: o.match_all(t))
+        except M.UnsupportedPattern: pass
+        try:
+            s_, e_ = rx.match_next(texts)
+            for t, a, b in zip(texts, s_, e_): _cmp(tag + " search", p, t, _span(a, b), lambda: o.match_next(t, 0))
+        except M.UnsupportedPattern: pass
+        try:
+            s_, e_ = rx.match_first(texts)
+            def first(t):
+                w = o.match_first(t, 0)
+                return w if (w and w[0] == 0) else None
+            for t, a, b in zip(texts, s_, e_): _cmp(tag + " match_first", p, t, _span(a, b), lambda: first(t))
+        except M.UnsupportedPattern: pass
+    try:
+        for ms in (0, 2):
+            got = M.split(pb, texts[:30], ms)
+            for t, g in zip(texts[:30], got): _cmp("split %d" % ms, p, t, g, lambda: O.split(pb, t, ms))
+    except M.UnsupportedPattern:
+        pass
+
+
 def _span(a, b):
     return (int(a), int(b)) if a >= 0 else None
 
@@ -106,7 +144,10 @@ for seed in range(SEED0, SEED0 + NSEEDS):
     texts = rtexts(rng, 30, 60, b"abcxyz019 -@.") + rtexts(rng, 12, 220, b"abcfoobarhellocatdog0123456789 xyz@.-") + [b"", b"a", b"foobar", b"hello", b"abc123", b"cat dog", b"http://id.no", b"q"*150+b"1"]
     if MODE:
         texts += rtexts(rng, 6, 2600, b"abcfoobarhellocatdog0123456789 xyz@.-") + [b"ab" * 700 + b"12 " + b"7" * 1300 + b"-5 x@y.z"]
-    for p in patterns(seed, 300):
+    if MODE and NFA:   # the oracle's PikeVM in Python: 50 ms per call on a 2600-byte text
+        texts = texts[:-7] + rtexts(rng, 3, 900, b"abcfoobarhellocatdog0123456789 xyz@.-") + [b"ab" * 300 + b"12 " + b"7" * 500 + b"-5 x@y.z"]
+    for ip, p in enumerate(patterns(seed, 300)):
+        if ip % 50 == 49: print("  seed", seed, "pattern", ip + 1, "checked", checked, flush=True)
         pb = p.encode()
         try: rx = M.compile_regex(pb)
         except M.RegexSyntaxError: continue
@@ -146,6 +187,9 @@ for seed in range(SEED0, SEED0 + NSEEDS):
             continue
         if EXTRA:
             extra_checks(rx, pb, p, texts, rng)
+            continue
+        if NFA:
+            nfa_checks(pb, p, texts)
             continue
         for op in ("findall", "search", "match_first"):
             try:
