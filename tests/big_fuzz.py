@@ -14,6 +14,11 @@ import os
 # pieces) on every plan that has them, with texts long enough to span several blocks / pieces
 MODE = int(os.environ.get("MRX_LONG_TEXT_MODE", "0"))
 M.load_library().mrx_debug_long_text_kernels(MODE)
+# MRX_FUZZ_DEBUG="mrx_debug_dynamic_texts:1,mrx_debug_subs_group:16": switches of include/mrx_testing.h to run under
+for item in filter(None, os.environ.get("MRX_FUZZ_DEBUG", "").split(",")):
+    name, val = item.split(":")
+    getattr(M.load_library(), name)(int(val))
+    print("switch", name, val, flush=True)
 bad = 0; checked = 0
 EXTRA = os.environ.get("MRX_FUZZ_EXTRA", "0") == "1"
 
