@@ -5369,6 +5369,8 @@ int mrx_sub_dev(const mrx_handle* h, const char* repl, size_t repl_len, int64_t 
     } else {
       for (unsigned char ch : r) rmap.push_back(ch);
     }
+    // (nothing but (\d{N}) groups: every match is fixed_total bytes long and holds all its windows)
+    if (h->hp.fixed_pure) group_reach = 0;
     if (rmap.size() <= 4096 && h->hp.fixed_total < 0x7FFF) {
       const int rc = sub_from_spans(h, Layout{d, off, 0, nullptr, 0}, n, rmap, count, out_off, out, out_cap,
                                     total_bytes, s, group_reach);
