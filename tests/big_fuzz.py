@@ -1,5 +1,6 @@
-import sys, zlib
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/oracle'); sys.path.insert(0,'/root/repo/tests')
+import os, sys, zlib
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [_ROOT, os.path.join(_ROOT, 'oracle'), os.path.join(_ROOT, 'tests')]
 import numpy as np
 import mojo_regex_amd as M
 import mrx_ref as O
