@@ -142,6 +142,11 @@ def extra_checks(rx, pb, p, texts, rng):
         try: got = rx.sub(b"#", sub_t, cnt)
         except M.UnsupportedPattern: break
         for t, g in zip(sub_t, got): _cmp("sub count=%d" % cnt, p, t, g, lambda: O.sub(pb, b"#", t, cnt))
+    # replacement forms: empty, backslashes that are not group references, a missing group, longer than 1 KiB
+    for repl in (b"", b"\\", b"a\\0b\\", b"<\\7>", b"=" * 1100):
+        try: got = rx.sub(repl, sub_t, 0)
+        except M.UnsupportedPattern: continue
+        for t, g in zip(sub_t, got): _cmp("sub repl=%r" % repl[:8], p, t, g, lambda: O.sub(pb, repl, t, 0))
 # MRX_FUZZ_SEEDS=first:count picks other generator seeds (default 30000:12, the set profiles/rNN_fuzz.txt quotes)
 GROUPS = os.environ.get("MRX_FUZZ_GROUPS", "0") == "1"
 SEED0, NSEEDS = (int(x) for x in os.environ.get("MRX_FUZZ_SEEDS", "30000:12").split(":"))
@@ -163,16 +168,16 @@ for seed in range(SEED0, SEED0 + NSEEDS):
             if rx.num_groups < 1: continue
             repl = b"<\\1>" if rx.num_groups == 1 else b"<\\2|\\1>"
             orx = O.compile_regex(pb)
-            try: got = rx.sub(repl, texts, 0)
-            except M.UnsupportedPattern: got = None
-            if got is not None:
+            for cnt in (0, 1):
+                try: got = rx.sub(repl, texts, cnt)
+                except M.UnsupportedPattern: break
                 for t, g in zip(texts, got):
-                    try: w = orx.sub(repl, t, 0)
+                    try: w = orx.sub(repl, t, cnt)
                     except (UnsupportedByOracle, O.ReferenceDoesNotTerminate): continue
                     checked += 1
                     if g != w:
                         bad += 1
-                        if bad < 10: print("MISMATCH group sub", repr(p), t, g, w)
+                        if bad < 10: print("MISMATCH group sub count=%d" % cnt, repr(p), t, g, w)
             try: caps = rx.captures(texts)
             except M.UnsupportedPattern: caps = None
             if caps is not None and orx.fixed_total_width < 0:
