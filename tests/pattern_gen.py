@@ -62,3 +62,64 @@ def patterns(seed: int, n: int):
             seen.add(p)
             out.append(p)
     return out
+
+
+# ---- second generator: the shapes the first one rarely reaches ---------------------------------------------------
+# literal-led and literal-tailed '.*' patterns (NFAEngine's prefilter and fast paths), alternations of words,
+# escaped specials, the upper-case predefined classes, larger counted repetitions, phone / date / e-mail style
+# concatenations, anchors inside alternations.
+ATOMS2 = ["\\d", "\\w", "\\s", "\\D", "\\W", "\\S", "[a-z]", "[A-Z]", "[0-9]", "[a-zA-Z0-9._%+-]", "[\\s.-]", "[^ ]", "[^@]",
+          "\\.", "\\(", "\\)", "\\[", "\\+", "\\\\", "\\t", "\\n", "-", "@", ":", "/", " ", "a", "e", "o", "x", "0", "."]
+QUANTS2 = ["", "", "", "+", "*", "?", "{2}", "{3}", "{4}", "{2,4}", "{3,}", "{1,2}", "{5,10}", "{10}", "{0,1}"]
+WORDS2 = ["hello", "world", "foo", "bar", "foobar", "http", "https", "com", "org", "example", "user", "error", "id", "GET",
+          "a", "ab", "abc", "the", "cat", "42"]
+
+
+def _piece2(r):
+    k = r.random()
+    if k < 0.55:
+        return r.choice(ATOMS2) + r.choice(QUANTS2)
+    if k < 0.8:
+        return r.choice(WORDS2)
+    if k < 0.9:
+        inner = "|".join(r.choice(WORDS2) if r.random() < 0.6 else _piece2(r) + _piece2(r) for _ in range(r.choice([2, 2, 3, 4])))
+        return r.choice(["(", "(?:"]) + inner + ")" + r.choice(QUANTS2)
+    return "(" + "".join(_piece2(r) for _ in range(r.choice([1, 2, 3]))) + ")" + r.choice(["", "", "?", "+", "*", "{2}"])
+
+
+def gen_pattern2(r: random.Random) -> str:
+    style = r.random()
+    body = "".join(_piece2(r) for _ in range(r.choice([1, 2, 2, 3, 3, 4, 5])))
+    if style < 0.15:
+        p = r.choice(WORDS2) + r.choice([".*", ".+", ".*", "\\s*"]) + body
+    elif style < 0.3:
+        p = body + r.choice([".*", ".+"]) + r.choice(WORDS2)
+    elif style < 0.4:
+        p = ".*" + body
+    elif style < 0.5:
+        p = "|".join(r.choice(WORDS2) for _ in range(r.choice([2, 3, 5, 8])))
+    elif style < 0.6:
+        p = body + "|" + "".join(_piece2(r) for _ in range(r.choice([1, 2])))
+    else:
+        p = body
+    k = r.random()
+    if k < 0.1:
+        p = "^" + p
+    elif k < 0.2:
+        p = p + "$"
+    elif k < 0.27:
+        p = "^" + p + "$"
+    elif k < 0.3:
+        p = p.replace("|", "$|^", 1) if "|" in p else "^" + p
+    return p
+
+
+def patterns2(seed: int, n: int):
+    r = random.Random(seed)
+    seen, out = set(), []
+    while len(out) < n:
+        p = gen_pattern2(r)
+        if p not in seen and len(p) <= 70:
+            seen.add(p)
+            out.append(p)
+    return out
