@@ -4,7 +4,7 @@ everything mrx_describe() prints (syntax errors, routing, DFA tables, matcher se
 import mojo_regex_amd as M
 from mrx_ref import RegexSyntaxError as OracleSyntaxError
 from mrx_ref.describe import describe
-from pattern_gen import patterns
+from pattern_gen import patterns, patterns2
 
 N_PATTERNS = 3000
 
@@ -42,3 +42,10 @@ def test_generated_patterns_compile_to_the_same_tables():
     assert not bad, bad[:10]
     # the generator must actually exercise all three outcomes
     assert kinds["DFA"] > 300 and kinds["NFA"] > 300 and kinds["SYNTAX"] > 20, kinds
+
+
+def test_second_generator_compiles_to_the_same_tables():
+    """tests/pattern_gen.py's second generator ('.*' with literals, word alternations, escaped specials, \\D \\W \\S,
+    larger counts, anchors inside alternations): the shapes the first one rarely reaches."""
+    bad = [p for p in patterns2(20260502, 1500) if _oracle(p.encode()) != _product(p.encode())]
+    assert not bad, bad[:10]
