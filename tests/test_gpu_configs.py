@@ -334,3 +334,47 @@ def test_default_routes_in_a_fresh_process():
     got = dict(line.split() for line in r.stdout.strip().splitlines() if len(line.split()) == 2)
     assert got == {"sub": "k_subs_wave", "findall": "k_stream_findall", "count": "k_stream_count", "search": "k_stream_search",
                    "is_match": "k_is_match_byte"}, got
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pat", [b"[a-z]+\\d+", b"[0-9]{2,4}", b"ab", b"(\\d{3})(\\d{3})(\\d{4})"])
+def test_batches_beyond_4_gib(pat):
+    """Byte offsets past 2^32 in both layouts: a 64 MiB block (65536 texts x 1 KiB of config 2's mix; for the phone
+    pattern config 4's) tiled 80 times = 5 GiB.  count / findall / search of the whole batch are the block's answers,
+    tile after tile (fixed pitch and CSR with int64 offsets)."""
+    _need_gpu()
+    import torch
+    from mojo_regex_amd.workloads import make_c2_batch
+    T, nb, L = 80, 65536, 1024
+    blk = (make_phone_batch(nb, L, device="cuda") if pat.startswith(b"(") else make_c2_batch(nb, L, seed=7, device="cuda")).reshape(nb, L)
+    data = blk.repeat(T, 1).reshape(-1)
+    n = nb * T
+    assert data.numel() > (1 << 32)
+    rx = M.compile_regex(pat)
+    small = M.DeviceBatch.strided(blk.reshape(-1), L, length=L)
+    c0 = rx.count(small)
+    p0, s0, t0 = rx._dev_findall(small)
+    ss0, se0 = rx.match_next(small)
+    assert t0 > 1000
+    for big in (M.DeviceBatch.strided(data, L, length=L),
+                M.DeviceBatch(data, torch.arange(0, (n + 1) * L, L, dtype=torch.int64, device="cuda"))):
+        c = rx.count(big)
+        assert torch.equal(c.reshape(T, nb), c0.expand(T, nb))
+        p, s, tot = rx._dev_findall(big)
+        assert tot == t0 * T
+        assert torch.equal(s[:t0], s0[:t0]) and torch.equal(s[tot - t0:tot], s0[:t0])
+        assert torch.equal(p[-(nb + 1):] - p[-(nb + 1)], p0)
+        assert torch.equal(p[nb * 41:nb * 42 + 1] - p[nb * 41], p0)   # the tile that straddles 2^32 bytes and its neighbours
+        ss, se = rx.match_next(big)
+        assert torch.equal(ss.reshape(T, nb), ss0.expand(T, nb)) and torch.equal(se.reshape(T, nb), se0.expand(T, nb))
+        del c, p, s, ss, se
+    # regex.sub: the output passes 2^32 bytes as well (a replacement longer than most matches)
+    repl = b"<\\3\\2\\1>" if pat.startswith(b"(") else b"<=====>"
+    o0, d0 = rx.sub_dev(repl, small)
+    o, d = rx.sub_dev(repl, big, out_cap=int(d0.numel()) * T + 64)
+    assert d.numel() == d0.numel() * T   # (past 2^32 bytes for all but the first pattern, whose matches are long)
+    assert torch.equal(o[-(nb + 1):] - o[-(nb + 1)], o0)
+    assert torch.equal(d[:d0.numel()], d0) and torch.equal(d[-d0.numel():], d0)
+    k = min(T - 1, (1 << 32) // d0.numel())   # the tile in which the output passes 2^32 bytes, if it does
+    mid = int(o[nb * k])
+    assert mid == k * d0.numel() and torch.equal(d[mid:mid + d0.numel()], d0)
