@@ -1100,6 +1100,8 @@ std::string describe_plan(const HostPlan& hp) {
   if (hp.bt.ok) o << " items=" << d.bt_nitems << " groups=" << d.bt_ngroups << " literal_opt=" << (d.bt_flags & 1)
                   << " prefix_literal=" << ((d.bt_flags >> 1) & 1) << " chain=" << ((d.bt_flags >> 5) & 1);
   o << "\n";
+  if (hp.fixed_total >= 0)   // group templates of regex.sub: see HostPlan::fixed_pure
+    o << "device.sub_groups=fixed pure=" << (hp.fixed_pure ? 1 : 0) << "\n";
   if (d.flags & PF_BITSET)
     o << "device.bitset=yes positions=" << d.bs_npos << " words=" << d.bs_nw << " byte_classes=" << d.bs_ncls << "\n";
   return o.str();

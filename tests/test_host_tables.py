@@ -176,3 +176,18 @@ def test_backtracker_chain_classification():
     # '.*' / '\\w+' in front of something they can also match; alternation; a looping group
     for p in ("hello.*world", ".*@example\\.com", "(a|b)(c)", "(ab)+(c)", "\\w+ing.*", "\\w+s \\w+x.*"):
         assert not chain(p), p
+
+
+def test_fixed_width_group_patterns_that_are_nothing_but_groups():
+    """HostPlan::fixed_pure (`device.sub_groups=fixed pure=1`): the pattern is (\\d{N}) / (\\d) groups end to end -- only
+    then does every match hold all its group windows and equal the whole-text shortcut of regex.sub
+    (matcher.mojo:1726-1744), so only then does a group template stay on the spans route unchecked."""
+    def pure(p):
+        line = [x for x in M.CompiledRegex(p).describe().split("\n") if x.startswith("device.sub_groups=")]
+        return line[0].endswith("pure=1") if line else None
+    for p in ("(\\d{3})(\\d{3})(\\d{4})", "(\\d)", "(\\d)(\\d{2})", "(\\d{10})"):
+        assert pure(p) is True, p
+    for p in ("(\\d)*", "(\\d)+", "(\\d)?", "(\\d)*a", "(\\d{4})-(\\d{2})-(\\d{2})", "^(\\d)+", "x(\\d)?", "(\\d{2})+", "(\\d)x"):
+        assert pure(p) is False, p
+    for p in ("(\\w+) (\\w+)", "[a-z]+(\\d)*", "hello"):
+        assert pure(p) is None, p
