@@ -505,7 +505,13 @@ class CompiledRegex:
 
 
 def _apply_template_fixed(template, repl, text, match_start, offs, widths, ng) -> bytes:
-    """matcher.mojo:1592-1621."""
+    """matcher.mojo:1592-1621.
+
+    Upstream copies ``text_ptr[gs : gs + width]`` unchecked; the widths come from the pattern text with
+    quantifiers ignored (matcher.mojo:1002-1035), so near the end of a text the window can reach behind it
+    ('x(\\d)?' matching "x" at the very end) and upstream reads whatever follows the string.  There is no
+    defined result to restate for those bytes: the slice below ends with the text, and that is what the
+    product is held to (tests/test_gpu_parity.py::test_fixed_width_group_windows_end_with_the_text)."""
     out = b""
     for (gref, s, ln) in template:
         if gref > 0 and gref <= ng:
@@ -575,6 +581,8 @@ def _sub_impl(compiled: CompiledRegex, repl: bytes, text: bytes, count: int = 0)
                     if gref > 0:
                         idx = group_idx[gref] if gref <= 9 else -1
                         if idx >= 0:
+                            # Match.get_match_text (matching.mojo:39-46) reads [start, end) unchecked; a span that
+                            # ends behind the text is cut at its end here, as in _apply_template_fixed
                             result += text[groups[idx][1]:groups[idx][2]]
                     else:
                         result += repl[s_:s_ + ln]
