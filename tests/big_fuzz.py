@@ -162,7 +162,7 @@ for seed in range(SEED0, SEED0 + NSEEDS):
     if MODE and (NFA or GEN2 or GROUPS):   # the oracle's PikeVM / backtracker in Python: 50 ms and more per call on a 2600-byte text
         texts = texts[:-7] + rtexts(rng, 3, 900, b"abcfoobarhellocatdog0123456789 xyz@.-") + [b"ab" * 300 + b"12 " + b"7" * 500 + b"-5 x@y.z"]
     for ip, p in enumerate((patterns2 if GEN2 else patterns)(seed, 300)):
-        if ip % 50 == 49: print("  seed", seed, "pattern", ip + 1, "checked", checked, flush=True)
+        if ip % 10 == 9: print("  seed", seed, "pattern", ip + 1, "checked", checked, flush=True)
         pb = p.encode()
         try: rx = M.compile_regex(pb)
         except M.RegexSyntaxError: continue
