@@ -57,8 +57,9 @@ typedef struct mrx_handle mrx_handle;
 enum {
   MRX_OK = 0,
   MRX_E_SYNTAX = 1,       /* the reference's parser raises on this pattern          */
-  MRX_E_UNSUPPORTED = 2,  /* reference routes this pattern/op to an engine outside  */
-                          /* the hot path (backtracking NFA, OnePass): see message  */
+  MRX_E_UNSUPPORTED = 2,  /* refused, never approximated: backtracker programs beyond */
+                          /* the flat form's limits, `$` on the LazyDFA search, ... */
+                          /* mrx_last_error() carries the reason                    */
   MRX_E_NO_DEVICE = 3,    /* no HIP device / HIP runtime error                      */
   MRX_E_CAPACITY = 4,     /* output buffer too small; *total holds the need         */
   MRX_E_ARGUMENT = 5
@@ -88,8 +89,9 @@ const char* mrx_stats(const mrx_handle* h);
 /* Text dump of the compiled tables (states, transitions, flags, kernel plan).
  * Returns the number of bytes needed (excluding NUL); writes at most cap. */
 size_t mrx_describe(const mrx_handle* h, char* buf, size_t cap);
-/* number of capture groups usable by mrx_captures_* / group references in
- * mrx_sub_* (fixed-width form, matcher.mojo:1002-1035); 0 if none */
+/* number of capture groups usable by mrx_captures_* / group references in mrx_sub_*:
+ * the fixed-width (\d{N}) form (matcher.mojo:1002-1035) or the general groups of
+ * NFAEngine.match_next_with_groups (nfa.mojo:500-574), in _match_group order; 0 if none */
 int mrx_num_groups(const mrx_handle* h);
 
 /* ---- device-resident batches (the measured path) --------------------------- */

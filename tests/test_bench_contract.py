@@ -21,8 +21,11 @@ def test_bench_prints_one_contract_line():
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["unit"] == "GB/s" and d["dtype"] == "u8" and d["data"] == "synthetic" and d["vs_baseline"] is None
-    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup_requested"] == 1 and d["scaling"] == "weak"
-    assert d["warmup"] == 1 + d["config"]["settle_steps"]   # every untimed step is counted
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["untimed_steps"] == 1 + d["config"]["settle_steps"]   # every untimed step is counted
+    # `value` is the strictly serial figure; the overlapped one is an extra object
+    assert d["config"]["streams"] == 1 and d["two_streams_overlapped"]["ms_per_step"] > 0
+    assert abs(d["value"] - 8192 * 1024 / (d["ms_per_step"] * 1e-3) / 1e9) < 0.02 * d["value"]
     assert "workload" in d["config"] and "model" not in d["config"]
     rf = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
