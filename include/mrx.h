@@ -77,8 +77,16 @@ int mrx_compile(const char* pattern, size_t pattern_len, mrx_handle** out);
  * MRX_COMPILE_BITSET_NFA: patterns the reference routes to LazyDFA (pikevm.mojo:664-987)
  * normally run on its eagerly determinised table; with this option -- and always when that
  * table would exceed 4096 states -- the walk runs on the bitset NFA instead (state = bit
- * mask of live PikeVM positions, up to 256).  Results are identical; only the kernel differs. */
-enum { MRX_COMPILE_LAZYDFA_SEMANTICS = 1, MRX_COMPILE_BITSET_NFA = 2 };
+ * mask of live PikeVM positions, up to 256).  Results are identical; only the kernel differs.
+ *
+ * MRX_COMPILE_NFA_ENGINE: the handle is the reference's NFAEngine used directly as the Engine
+ * (engine.mojo:4-37, nfa.mojo:66-143) -- what `regex.nfa.match_first / findall`
+ * (nfa.mojo:1733-1769) and the reference's tests/test_nfa.mojo drive -- instead of the
+ * HybridMatcher router: greedy backtracking, first alternative wins, NFAEngine's literal
+ * prefilter and `.*` fast paths, none of HybridMatcher's shortcuts.  Served by the flat program
+ * of the backtracking matcher; MRX_E_UNSUPPORTED at the first matching call when the pattern
+ * exceeds that form (16 nesting levels, 30 open choices, 240 items). */
+enum { MRX_COMPILE_LAZYDFA_SEMANTICS = 1, MRX_COMPILE_BITSET_NFA = 2, MRX_COMPILE_NFA_ENGINE = 4 };
 int mrx_compile_ex(const char* pattern, size_t pattern_len, uint32_t options, mrx_handle** out);
 void mrx_free(mrx_handle* h);
 const char* mrx_last_error(void);

@@ -228,17 +228,21 @@ std::vector<ReplSeg> parse_repl_template(const std::string& r) {  // matcher.moj
   return segs;
 }
 
-void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool force_bitset) {
+void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool force_bitset, bool nfa_engine) {
   hp = HostPlan();
   hp.force_nfa = force_nfa;
   hp.force_bitset = force_bitset;
+  hp.nfa_engine = nfa_engine;
   hp.pattern = pattern;
-  hp.wildcard_any = (pattern == ".*");  // matcher.mojo:435-444, 573-591
+  // nfa_engine: the Engine is NFAEngine itself (engine.mojo:4-37, nfa.mojo:66-143), as regex.nfa's module
+  // functions build it (nfa.mojo:1733-1769): no HybridMatcher in front, so none of its shortcuts ('.*',
+  // exact literal, memchr prefilter, required byte, fixed-width groups), no DFA, LazyDFA or OnePass.
+  hp.wildcard_any = (pattern == ".*") && !nfa_engine;  // matcher.mojo:435-444, 573-591
 
   // fixed-width capture groups, CompiledRegex._try_precompute_fixed_sub (:1002-1035)
   {
     std::vector<int> segs;
-    if (detect_fixed_width(pattern, segs)) {
+    if (!nfa_engine && detect_fixed_width(pattern, segs)) {
       int ng = 0, total = 0;
       bool lits = false, ok = true;
       int off[10] = {0}, w[10] = {0};
@@ -282,7 +286,7 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
     parse(pattern, ast);  // may throw SyntaxError
     hp.complexity = classify(ast);
     hp.use_pure_dfa = should_use_pure_dfa(ast);
-    const bool analyze = !skip_prefilter(pattern) && !hp.use_pure_dfa;
+    const bool analyze = !skip_prefilter(pattern) && !hp.use_pure_dfa && !nfa_engine;
     if (analyze) {  // matcher.mojo:609-654
       LiteralSet ls = extract_literals(ast);
       const bool anchors = ast_has_anchors(ast, ast.root);
@@ -325,7 +329,7 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
       // NFAMatcher.__init__, matcher.mojo:310-313: OnePass only for programs with '$'
       if (hp.lazy.supported && hp.program.has_end_anchor()) build_onepass(hp.program, hp.onepass);
     }
-    if (hp.complexity == CX_SIMPLE && !force_nfa) {  // matcher.mojo:664-675
+    if (hp.complexity == CX_SIMPLE && !force_nfa && !nfa_engine) {  // matcher.mojo:664-675
       try {
         compile_dfa_pattern(ast, hp.dfa);
         hp.use_dfa = true;
@@ -339,6 +343,7 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
 
   // get_engine_type / get_stats, matcher.mojo:900-918, 1139-1163
   hp.engine_type = hp.use_dfa ? "DFA" : "NFA";
+  if (nfa_engine) hp.engine_type = "NFAEngine";
   if (hp.exact_literal && !hp.literal_has_anchors) hp.engine_type += "+ExactLiteral";
   else if (hp.has_prefilter && !hp.literal_has_anchors) hp.engine_type += "+Prefilter";
   static const char* cxn[] = {"SIMPLE", "MEDIUM", "COMPLEX"};
@@ -353,7 +358,13 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
   const bool lazy_ok = hp.lazy.supported && !too_large;
   const bool nfa_end = hp.program.has_end_anchor();
   bool bt_first = false, bt_search = false;   // operations the reference sends to NFAEngine's backtracking matcher
-  if (!hp.wildcard_any && !hp.use_dfa) {
+  if (nfa_engine) {
+    // NFAEngine.match_first / match_next / match_all (nfa.mojo:169-498) and nothing else
+    if (hp.bt.ok) bt_first = bt_search = true;
+    else
+      hp.why_no_match_first = hp.why_no_search =
+          "NFAEngine selected as the engine; its flat-program form does not cover: " + hp.bt.why_not;
+  } else if (!hp.wildcard_any && !hp.use_dfa) {
     // NFAMatcher.match_first, matcher.mojo:361-380
     if (lazy_ok && nfa_end && hp.onepass.ok)
       hp.first_onepass = true;  // matcher.mojo:378-379
@@ -1023,6 +1034,7 @@ std::string describe_plan(const HostPlan& hp) {
   o << "complexity=" << cxn[hp.complexity] << "\n";
   if (hp.force_nfa) o << "option.lazydfa_semantics=1\n";
   if (hp.force_bitset) o << "option.bitset_nfa=1\n";
+  if (hp.nfa_engine) o << "option.nfa_engine=1\n";
   o << "use_dfa=" << hp.use_dfa << " wildcard_any=" << hp.wildcard_any
     << " use_pure_dfa=" << hp.use_pure_dfa << "\n";
   o << "exact_literal=" << hp.exact_literal << " literal_has_anchors=" << hp.literal_has_anchors

@@ -27,6 +27,13 @@ class OracleBackend:
     def split(self, p, t, maxsplit=0):
         return hybrid.split(p, t, maxsplit)
 
+    # regex.nfa's module functions: NFAEngine driven directly (tests/test_nfa.mojo)
+    def nfa_match_first(self, p, t):
+        return hybrid.nfa_match_first(p, t)
+
+    def nfa_findall(self, p, t):
+        return hybrid.nfa_findall(p, t)
+
     def obj_match_first(self, p, t, start=0):
         return hybrid.compile_regex(p).match_first(t, start)
 

@@ -130,6 +130,27 @@ class NFAEngineFlags:
         self.starts_with_dotstar = swd
 
 
+def nfa_engine(pattern: bytes) -> BacktrackNFA:
+    """NFAEngine(pattern) on its own (nfa.mojo:86-143), as regex.nfa's module functions and the
+    reference's tests/test_nfa.mojo use it: no hybrid router, no LazyDFA, no OnePass in front."""
+    try:
+        own_ast = parse(pattern)
+    except Exception:
+        own_ast = None
+    return BacktrackNFA(pattern, own_ast, NFAEngineFlags(pattern))
+
+
+def nfa_findall(pattern: bytes, text: bytes):
+    """regex.nfa.findall, nfa.mojo:1733-1747."""
+    return nfa_engine(pattern).match_all(text)
+
+
+def nfa_match_first(pattern: bytes, text: bytes):
+    """regex.nfa.match_first, nfa.mojo:1750-1769: NFAEngine.match_first(text, 0), kept only at 0."""
+    r = nfa_engine(pattern).match_first(text, 0)
+    return r if (r is not None and r[0] == 0) else None
+
+
 class NFAMatcher:
     """matcher.mojo:273-431."""
 

@@ -27,9 +27,11 @@ import sys
 REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_vectors.json")
 
-# files whose tests exercise the hot path through the hybrid/DFA/comptime API.
-# tests/test_nfa.mojo is left out on purpose: it imports regex.nfa (the
-# backtracking interpreter), which is not the path this repo covers.
+# files whose tests exercise the hot path through the hybrid/DFA/comptime API, plus
+# tests/test_nfa.mojo: its `match_first` / `findall` are regex.nfa's (NFAEngine driven
+# directly, nfa.mojo:1733-1769), recorded under the distinct ops `nfa_match_first` /
+# `nfa_findall` -- they pin the backtracking matcher (oracle/mrx_ref/backtrack.py and
+# the product's flat program), whatever the hybrid router would do with the pattern.
 FILES = [
     "tests/test_matcher.mojo",
     "tests/test_dfa.mojo",
@@ -37,6 +39,7 @@ FILES = [
     "tests/test_predefined_classes.mojo",
     "tests/test_split.mojo",
     "tests/test_simd.mojo",
+    "tests/test_nfa.mojo",
 ]
 
 
@@ -433,6 +436,8 @@ def run_file(rec: Recorder, relpath: str, stats: dict):
         rec.test = name
         fn = tree.body[0]
         env = make_env(rec)
+        if relpath.endswith("test_nfa.mojo"):
+            env.update(rec.api("nfa_"))   # `from regex.nfa import match_first, findall`
         if relpath.endswith("test_comptime_regex.mojo"):
             for op in ("search", "match_first", "findall"):
                 env[op] = Comptime(rec, op)

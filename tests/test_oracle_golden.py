@@ -2,10 +2,11 @@
 
 tests/golden/reference_vectors.json holds the vectors transcribed from the
 reference's tests/test_*.mojo (file:line per vector).  This is what pins the
-oracle: every vector must pass -- the DFA / LazyDFA / OnePass routes and, since
-round 2, the vectors the reference routes to its backtracking matcher
-(oracle/mrx_ref/backtrack.py; 15 matching vectors and the regex.sub vectors with
-group references).
+oracle: every vector must pass -- the DFA / LazyDFA / OnePass routes, the vectors the
+hybrid router sends to the backtracking matcher, and (round 3) the 104 vectors of the
+reference's tests/test_nfa.mojo, which drive NFAEngine directly (`nfa_match_first`,
+`nfa_findall`: regex.nfa's module functions, nfa.mojo:1733-1769) and pin
+oracle/mrx_ref/backtrack.py.
 """
 import collections
 
@@ -18,9 +19,11 @@ VECS = load_vectors()
 
 
 def test_fixture_is_large_enough():
-    assert len(VECS) >= 450
+    assert len(VECS) >= 580
     files = {v["file"] for v in VECS}
     assert "tests/test_matcher.mojo" in files and "tests/test_dfa.mojo" in files
+    ops = collections.Counter(v["op"] for v in VECS)
+    assert ops["nfa_match_first"] >= 94 and ops["nfa_findall"] >= 10   # tests/test_nfa.mojo
 
 
 def test_oracle_passes_every_in_scope_reference_vector(oracle_backend):
@@ -133,9 +136,27 @@ def test_onepass_routing_and_rejections():
     # backed off inside _match_with_backtracking: the reference's own answer, whatever re.match says.
     r = H.compile_regex(b"^aaaa.*a$")
     assert r.matcher.nfa_matcher.onepass is None
-    assert H.match_first(b"^aaaa.*a$", b"aaaaa") == r.matcher.nfa_matcher.backtrack.match_first(b"aaaaa", 0)
+    # traced by hand: `.*` is a quantified leaf followed by siblings -> _match_with_backtracking
+    # (nfa.mojo:1236-1311) gives back one byte at a time: count 1 -> 0, then `a` and `$` match at 4
+    assert H.match_first(b"^aaaa.*a$", b"aaaaa") == (0, 5)
+    assert H.match_first(b"^aaaa.*a$", b"aaaab") is None
     with pytest.raises(UnsupportedByOracle):               # search with '$' stays LazyDFA (history dependent)
         H.search(b"^[a-z]+$", b"abc")
+
+
+def test_hand_traced_backtracker_quirks(oracle_backend):
+    """tests/golden/backtrack_quirk_vectors.json: NFAEngine quirks the reference's own tests do not reach,
+    traced by hand through nfa.mojo (each vector cites the lines that decide it)."""
+    import json
+    import os
+    doc = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "backtrack_quirk_vectors.json")))
+    assert len(doc["vectors"]) >= 20
+    for v in doc["vectors"]:
+        got = getattr(oracle_backend, v["op"])(v["pattern"].encode("latin-1"), v["text"].encode("latin-1"))
+        if v["op"] == "nfa_findall":
+            assert [list(x) for x in got] == v["want"], (v, got)
+        else:
+            assert (list(got) if got is not None else None) == v["want"], (v, got)
 
 
 def test_optimizer_vectors_pin_classifier_and_literal_helpers():

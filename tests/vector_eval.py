@@ -33,13 +33,15 @@ def evaluate(backend, v):
     pat = b(v["pattern"]) if v.get("pattern") is not None else None
     start = v.get("start", 0)
     kind_result = None
-    if op in ("match_first", "search", "ct_match_first", "ct_search",
+    if op in ("match_first", "search", "ct_match_first", "ct_search", "nfa_match_first",
               "obj_match_first", "obj_match_next", "dfa_match_first", "dfa_match_next"):
         kind_result = "opt"
         if op == "match_first":
             r = backend.match_first(pat, text)
         elif op == "search":
             r = backend.search(pat, text)
+        elif op == "nfa_match_first":
+            r = backend.nfa_match_first(pat, text)
         elif op == "ct_match_first":
             r = backend.ct_match_first(pat, text)
         elif op == "ct_search":
@@ -52,10 +54,12 @@ def evaluate(backend, v):
             r = backend.dfa_match_first(v["engine"], text, start)
         else:
             r = backend.dfa_match_next(v["engine"], text, start)
-    elif op in ("findall", "ct_findall", "obj_match_all", "dfa_match_all"):
+    elif op in ("findall", "ct_findall", "obj_match_all", "dfa_match_all", "nfa_findall"):
         kind_result = "list"
         if op == "findall":
             r = backend.findall(pat, text)
+        elif op == "nfa_findall":
+            r = backend.nfa_findall(pat, text)
         elif op == "ct_findall":
             r = backend.ct_findall(pat, text)
         elif op == "obj_match_all":
