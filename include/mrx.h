@@ -85,8 +85,15 @@ int mrx_compile(const char* pattern, size_t pattern_len, mrx_handle** out);
  * HybridMatcher router: greedy backtracking, first alternative wins, NFAEngine's literal
  * prefilter and `.*` fast paths, none of HybridMatcher's shortcuts.  Served by the flat program
  * of the backtracking matcher; MRX_E_UNSUPPORTED at the first matching call when the pattern
- * exceeds that form (16 nesting levels, 30 open choices, 240 items). */
-enum { MRX_COMPILE_LAZYDFA_SEMANTICS = 1, MRX_COMPILE_BITSET_NFA = 2, MRX_COMPILE_NFA_ENGINE = 4 };
+ * exceeds that form (16 nesting levels, 30 open choices, 240 items).
+ *
+ * MRX_COMPILE_DFA_ENGINE: likewise, the DFAEngine that compile_dfa_pattern(parse(pattern))
+ * returns (dfa.mojo:2385-2496), as the comptime API (comptime_regex.mojo:59-87, 176-233) and
+ * the reference's tests/test_dfa.mojo use it: no classifier, no exact-literal / prefilter /
+ * required-byte shortcut in front.  MRX_E_UNSUPPORTED at compile time, with the dispatcher's
+ * message, when no shape compiler takes the pattern. */
+enum { MRX_COMPILE_LAZYDFA_SEMANTICS = 1, MRX_COMPILE_BITSET_NFA = 2, MRX_COMPILE_NFA_ENGINE = 4,
+       MRX_COMPILE_DFA_ENGINE = 8 };
 int mrx_compile_ex(const char* pattern, size_t pattern_len, uint32_t options, mrx_handle** out);
 void mrx_free(mrx_handle* h);
 const char* mrx_last_error(void);

@@ -263,19 +263,20 @@ class CompiledRegex:
     """Compile once, match many batches (reference: matcher.mojo:929-1163)."""
 
     def __init__(self, pattern, lazydfa_semantics: bool = False, bitset_nfa: bool = False,
-                 nfa_engine: bool = False):
+                 nfa_engine: bool = False, dfa_engine: bool = False):
         """lazydfa_semantics: MRX_COMPILE_LAZYDFA_SEMANTICS (include/mrx.h) -- NOT the
         reference's result for SIMPLE patterns; off by default.
         bitset_nfa: MRX_COMPILE_BITSET_NFA -- same results, LazyDFA walks run on the bitset NFA.
         nfa_engine: MRX_COMPILE_NFA_ENGINE -- NFAEngine itself as the Engine (regex.nfa, nfa.mojo:66-143,
-        1733-1769), no hybrid router in front."""
+        1733-1769), no hybrid router in front.
+        dfa_engine: MRX_COMPILE_DFA_ENGINE -- compile_dfa_pattern's DFAEngine as the Engine (comptime API)."""
         self._lib = load_library()
         self.pattern = _b(pattern)
         self.lazydfa_semantics = bool(lazydfa_semantics)
         h = C.c_void_p()
         _check(self._lib.mrx_compile_ex(self.pattern, len(self.pattern),
                                         (1 if lazydfa_semantics else 0) | (2 if bitset_nfa else 0)
-                                        | (4 if nfa_engine else 0),
+                                        | (4 if nfa_engine else 0) | (8 if dfa_engine else 0),
                                         C.byref(h)))
         self._h = h
 
@@ -571,11 +572,11 @@ _CACHE = {}
 
 
 def compile_regex(pattern, lazydfa_semantics: bool = False, bitset_nfa: bool = False,
-                  nfa_engine: bool = False) -> CompiledRegex:
-    key = (_b(pattern), bool(lazydfa_semantics), bool(bitset_nfa), bool(nfa_engine))
+                  nfa_engine: bool = False, dfa_engine: bool = False) -> CompiledRegex:
+    key = (_b(pattern), bool(lazydfa_semantics), bool(bitset_nfa), bool(nfa_engine), bool(dfa_engine))
     c = _CACHE.get(key)
     if c is None:
-        c = CompiledRegex(key[0], lazydfa_semantics, bitset_nfa, nfa_engine)
+        c = CompiledRegex(key[0], lazydfa_semantics, bitset_nfa, nfa_engine, dfa_engine)
         _CACHE[key] = c
     return c
 

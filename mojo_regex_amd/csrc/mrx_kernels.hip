@@ -4810,13 +4810,19 @@ int mrx_compile_ex(const char* pattern, size_t pattern_len, uint32_t options, mr
   if (const char* e = getenv("MRX_FUSED")) g_fused = atoi(e) < 0 ? 0 : atoi(e) > 2 ? 2 : atoi(e);
   if (const char* e = getenv("MRX_FUSED_BPC")) g_fused_bpc = atoi(e);
   if (!out || (!pattern && pattern_len)) return fail(MRX_E_ARGUMENT, "null argument");
-  if (options & ~(uint32_t)(MRX_COMPILE_LAZYDFA_SEMANTICS | MRX_COMPILE_BITSET_NFA | MRX_COMPILE_NFA_ENGINE))
+  if (options & ~(uint32_t)(MRX_COMPILE_LAZYDFA_SEMANTICS | MRX_COMPILE_BITSET_NFA | MRX_COMPILE_NFA_ENGINE |
+                             MRX_COMPILE_DFA_ENGINE))
     return fail(MRX_E_ARGUMENT, "unknown compile option");
+  if ((options & MRX_COMPILE_NFA_ENGINE) && (options & (MRX_COMPILE_DFA_ENGINE | MRX_COMPILE_LAZYDFA_SEMANTICS)))
+    return fail(MRX_E_ARGUMENT, "MRX_COMPILE_NFA_ENGINE excludes the other engine options");
+  if ((options & MRX_COMPILE_DFA_ENGINE) && (options & MRX_COMPILE_LAZYDFA_SEMANTICS))
+    return fail(MRX_E_ARGUMENT, "MRX_COMPILE_DFA_ENGINE excludes MRX_COMPILE_LAZYDFA_SEMANTICS");
   *out = nullptr;
   mrx_handle* h = new mrx_handle();
   try {
     build_plan(std::string(pattern, pattern_len), h->hp, (options & MRX_COMPILE_LAZYDFA_SEMANTICS) != 0,
-               (options & MRX_COMPILE_BITSET_NFA) != 0, (options & MRX_COMPILE_NFA_ENGINE) != 0);
+               (options & MRX_COMPILE_BITSET_NFA) != 0, (options & MRX_COMPILE_NFA_ENGINE) != 0,
+               (options & MRX_COMPILE_DFA_ENGINE) != 0);
   } catch (const SyntaxError& e) {
     delete h;
     return fail(MRX_E_SYNTAX, e.what());

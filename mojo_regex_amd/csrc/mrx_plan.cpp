@@ -228,21 +228,25 @@ std::vector<ReplSeg> parse_repl_template(const std::string& r) {  // matcher.moj
   return segs;
 }
 
-void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool force_bitset, bool nfa_engine) {
+void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool force_bitset, bool nfa_engine,
+                bool dfa_engine) {
   hp = HostPlan();
   hp.force_nfa = force_nfa;
   hp.force_bitset = force_bitset;
   hp.nfa_engine = nfa_engine;
+  hp.dfa_engine = dfa_engine;
   hp.pattern = pattern;
   // nfa_engine: the Engine is NFAEngine itself (engine.mojo:4-37, nfa.mojo:66-143), as regex.nfa's module
   // functions build it (nfa.mojo:1733-1769): no HybridMatcher in front, so none of its shortcuts ('.*',
   // exact literal, memchr prefilter, required byte, fixed-width groups), no DFA, LazyDFA or OnePass.
-  hp.wildcard_any = (pattern == ".*") && !nfa_engine;  // matcher.mojo:435-444, 573-591
+  // dfa_engine: the Engine is the DFAEngine that compile_dfa_pattern(parse(pattern)) returns, as the comptime
+  // API (comptime_regex.mojo:59-87, 176-233) and the reference's tests/test_dfa.mojo use it: again no router.
+  hp.wildcard_any = (pattern == ".*") && !nfa_engine && !dfa_engine;  // matcher.mojo:435-444, 573-591
 
   // fixed-width capture groups, CompiledRegex._try_precompute_fixed_sub (:1002-1035)
   {
     std::vector<int> segs;
-    if (!nfa_engine && detect_fixed_width(pattern, segs)) {
+    if (!nfa_engine && !dfa_engine && detect_fixed_width(pattern, segs)) {
       int ng = 0, total = 0;
       bool lits = false, ok = true;
       int off[10] = {0}, w[10] = {0};
@@ -286,7 +290,7 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
     parse(pattern, ast);  // may throw SyntaxError
     hp.complexity = classify(ast);
     hp.use_pure_dfa = should_use_pure_dfa(ast);
-    const bool analyze = !skip_prefilter(pattern) && !hp.use_pure_dfa && !nfa_engine;
+    const bool analyze = !skip_prefilter(pattern) && !hp.use_pure_dfa && !nfa_engine && !dfa_engine;
     if (analyze) {  // matcher.mojo:609-654
       LiteralSet ls = extract_literals(ast);
       const bool anchors = ast_has_anchors(ast, ast.root);
@@ -329,6 +333,10 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
       // NFAMatcher.__init__, matcher.mojo:310-313: OnePass only for programs with '$'
       if (hp.lazy.supported && hp.program.has_end_anchor()) build_onepass(hp.program, hp.onepass);
     }
+    if (dfa_engine) {   // whatever the classifier says; a pattern no shape compiler takes has no DFAEngine
+      compile_dfa_pattern(ast, hp.dfa);   // DfaCompileError -> MRX_E_UNSUPPORTED with its message
+      hp.use_dfa = true;
+    } else
     if (hp.complexity == CX_SIMPLE && !force_nfa && !nfa_engine) {  // matcher.mojo:664-675
       try {
         compile_dfa_pattern(ast, hp.dfa);
@@ -337,13 +345,14 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
         hp.use_dfa = false;
       }
     }
-    if (hp.use_dfa && !hp.literal_has_anchors && hp.dfa.has_matcher)
+    if (hp.use_dfa && !dfa_engine && !hp.literal_has_anchors && hp.dfa.has_matcher)
       hp.required_byte = rare_required_byte(ast, hp.dfa.matcher.lookup);
   }
 
   // get_engine_type / get_stats, matcher.mojo:900-918, 1139-1163
   hp.engine_type = hp.use_dfa ? "DFA" : "NFA";
   if (nfa_engine) hp.engine_type = "NFAEngine";
+  if (dfa_engine) hp.engine_type = "DFAEngine";
   if (hp.exact_literal && !hp.literal_has_anchors) hp.engine_type += "+ExactLiteral";
   else if (hp.has_prefilter && !hp.literal_has_anchors) hp.engine_type += "+Prefilter";
   static const char* cxn[] = {"SIMPLE", "MEDIUM", "COMPLEX"};
@@ -1035,6 +1044,7 @@ std::string describe_plan(const HostPlan& hp) {
   if (hp.force_nfa) o << "option.lazydfa_semantics=1\n";
   if (hp.force_bitset) o << "option.bitset_nfa=1\n";
   if (hp.nfa_engine) o << "option.nfa_engine=1\n";
+  if (hp.dfa_engine) o << "option.dfa_engine=1\n";
   o << "use_dfa=" << hp.use_dfa << " wildcard_any=" << hp.wildcard_any
     << " use_pure_dfa=" << hp.use_pure_dfa << "\n";
   o << "exact_literal=" << hp.exact_literal << " literal_has_anchors=" << hp.literal_has_anchors

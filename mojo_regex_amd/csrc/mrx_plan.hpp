@@ -133,6 +133,7 @@ struct HostPlan {
   bool first_onepass = false;  // match_first runs the OnePass tables (NFA-routed '$' pattern)
   bool force_bitset = false;  // MRX_COMPILE_BITSET_NFA
   bool nfa_engine = false;    // MRX_COMPILE_NFA_ENGINE
+  bool dfa_engine = false;    // MRX_COMPILE_DFA_ENGINE
   bool nfa_has_literal_opt = false, nfa_starts_dotstar = false, nfa_ends_dotstar = false;
   // per-operation support: empty string = supported, else the reason
   std::string why_no_match_first, why_no_search;
@@ -153,8 +154,9 @@ struct HostPlan {
 // NFAMatcher / LazyDFA path -- the "LazyDFA semantics" switch of SURVEY.md 8(c).
 // force_bitset: LazyDFA-routed patterns walk the bitset NFA even when the determinised table fits.
 // nfa_engine: the Engine is NFAEngine itself (nfa.mojo:66-143), no hybrid router in front.
+// dfa_engine: the Engine is compile_dfa_pattern's DFAEngine (dfa.mojo:2385-2496), no hybrid router in front.
 void build_plan(const std::string& pattern, HostPlan& out, bool force_nfa = false,
-                bool force_bitset = false, bool nfa_engine = false);
+                bool force_bitset = false, bool nfa_engine = false, bool dfa_engine = false);
 std::string describe_plan(const HostPlan& p);
 
 // replacement template (matcher.mojo:1436-1482)

@@ -84,48 +84,56 @@ class ProductBackend:
     def stats(self, p):
         return self._rx(p).get_stats()
 
-    # comptime API == runtime API whenever the runtime route is the DFA
-    def _ct_ok(self, p):
-        if "use_dfa=1" not in self._rx(p).describe():
-            raise Unsupported("comptime route differs from the runtime route")
+    # comptime API (comptime_regex.mojo:59-87, 176-233): the DFAEngine of compile_dfa_pattern when that
+    # compiles (MRX_COMPILE_DFA_ENGINE), the runtime API when it raises
+    def _ct_rx(self, p):
+        try:
+            return M.compile_regex(p, dfa_engine=True)
+        except M.UnsupportedPattern:
+            return self._rx(p)
 
     def ct_search(self, p, t):
-        self._ct_ok(p)
-        return self.search(p, t)
+        return self._one(self._ct_rx(p).match_next([t]))
 
     def ct_match_first(self, p, t):
-        self._ct_ok(p)
-        return self.match_first(p, t)
+        return self._one(self._ct_rx(p).match_first([t]))
 
     def ct_findall(self, p, t):
-        self._ct_ok(p)
-        return self.findall(p, t)
+        return self._ct_rx(p).findall_lists([t])[0]
 
-    def _dfa_pat(self, build):
-        if build["kind"] == "literal" and build["literal"].isalnum():
+    def _dfa_rx(self, build):
+        """DFAEngine built directly (tests/test_dfa.mojo) = MRX_COMPILE_DFA_ENGINE on the pattern whose
+        shape compiler makes the same call."""
+        if build["kind"] == "literal":
             # DFAEngine.compile_pattern(literal, anchors) is what compile_dfa_pattern builds for ^literal$
-            # (dfa.mojo:2385-2410): reach it through the pattern
+            # (dfa.mojo:2385-2410)
+            if build["literal"] and not build["literal"].isalnum():
+                raise Unsupported("direct DFAEngine construction is not an ABI entry point")
             p = (("^" if build.get("start_anchor") else "") + build["literal"] +
                  ("$" if build.get("end_anchor") else "")).encode()
-            self._ct_ok(p)
-            if "pure_literal=1" not in self._rx(p).describe():
+            rx = M.compile_regex(p, dfa_engine=True)
+            d = rx.describe()
+            if "dfa.shape=literal\n" not in d or ("dfa.literal=%s\n" % build["literal"].encode().hex()) not in d:
                 raise Unsupported("literal does not take the DFA literal route")
-            return p
-        if build["kind"] != "pattern":
-            raise Unsupported("direct DFAEngine construction is not an ABI entry point")
-        p = build["pattern"].encode()
-        self._ct_ok(p)
-        return p
+            return rx
+        if build["kind"] == "char_class":
+            # compile_character_class(chars, min, max) is what the single-class compiler calls for [chars]{min,max}
+            # (dfa.mojo:375-496 via :2420-2440)
+            q = {(1, -1): "+", (0, -1): "*", (0, 1): "?", (1, 1): ""}.get((build["min"], build["max"]))
+            if q is None or not build["char_class"].isalnum():
+                raise Unsupported("direct DFAEngine construction is not an ABI entry point")
+            return M.compile_regex(("[" + build["char_class"] + "]" + q).encode(), dfa_engine=True)
+        return M.compile_regex(build["pattern"].encode(), dfa_engine=True)
 
     def dfa_match_first(self, build, t, start=0):
         # DFAEngine.match_first(text, start) == the engine-level operation of the ABI
-        return self._one(self._rx(self._dfa_pat(build)).match_first_at([t], start))
+        return self._one(self._dfa_rx(build).match_first_at([t], start))
 
     def dfa_match_next(self, build, t, start=0):
-        return self._one(self._rx(self._dfa_pat(build)).match_next_at([t], start))
+        return self._one(self._dfa_rx(build).match_next_at([t], start))
 
     def dfa_match_all(self, build, t):
-        return self.findall(self._dfa_pat(build), t)
+        return self._dfa_rx(build).findall_lists([t])[0]
 
 
 def _vector_key(v):
