@@ -183,8 +183,11 @@ def main():
                          "the scan of the next, as a caller feeding batches continuously runs) is reported as the "
                          "extra object `two_streams_overlapped`, never as `value`")
     ap.add_argument("--gather", action="store_true",
-                    help="N > 1: also time scan + results exchange (SURVEY.md 8(e): all-gatherv of the "
-                         "spans to every rank); reported as an extra object, never as `value`")
+                    help="N > 1: time scan + results exchange (SURVEY.md 8(e): all-gatherv of the spans to every "
+                         "rank) even with --no-extras; reported as an extra object, never as `value`")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="N > 1: skip the extra legs (results exchange on the headline batch, config 3's per-GPU share)")
+    ap.add_argument("--c3-texts", type=int, default=1 << 23, help="texts per GPU of the config-3 leg (256 B each)")
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -305,30 +308,107 @@ def main():
             step()
         torch.cuda.synchronize()
 
-    # ---- optional: scan + results exchange (results stay sharded in the headline) -----
+    # ---- scan + results exchange (results stay sharded in the headline) -----------------------------
+    # the one optional exchange step, "results only".  With the nccl backend it runs behind the
+    # C ABI (include/mrx_comm.h: RCCL called by the library, all-gather of the sizes, then the spans into
+    # prefix-sum offsets; padded form, nothing is read back inside the timed loop); gloo (shared-GPU rehearsal)
+    # takes the torch.distributed path.  On by default for N > 1 (MRX_BENCH_EXTRAS=0 or --no-extras turns the
+    # extra legs off); extra objects, never `value`.  A leg that raises is reported as {"error": ...} and the
+    # headline line is still printed (the legs are symmetric: every rank raises or none does).
     gather_info = None
-    if args.gather and world > 1:
-        # (no try/except: a rank that left the exchange alone would leave the others blocked in it)
-        gsteps = max(3, min(args.steps, 10))
+    config3_info = None
+    extras = world > 1 and not args.no_extras and os.environ.get("MRX_BENCH_EXTRAS", "1") != "0"
+
+    def exchange_leg(rx_, batch_, out_, n_, comm):
+        """Times K steps of findall and of findall + exchange on this batch; returns the extra object."""
         gdev = dev if backend == "nccl" else None
-        def gstep():
-            rx.findall_async(batch, out)
-            tot = int(prefix[n].item())          # the exchange needs the per-rank totals
-            return D.gather_spans(world, prefix, spans, tot)
-        gp, gs = gstep()
+        gsteps = max(3, min(args.steps, 10))
+        pre_, sp_ = out_
+        rx_.findall_async(batch_, out_)
+        tot = torch.tensor([int(pre_[n_].item())], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+        import torch.distributed as tdist
+        tdist.all_reduce(tot, op=tdist.ReduceOp.MAX)
+        cap = int(tot.item()) + 1024          # padded form: slots every rank ships (the largest rank's spans)
+        n_all = torch.tensor([n_], dtype=torch.int64, device=tot.device)
+        tdist.all_reduce(n_all, op=tdist.ReduceOp.SUM)
+        n_glob = int(n_all.item())
+        if cap > sp_.shape[0]:
+            raise RuntimeError("span buffer smaller than the exchange capacity")
+        gout = None
+        if comm is not None:
+            gout = (torch.empty(n_glob + 1, dtype=torch.int64, device=dev),
+                    torch.empty((world * cap, 2), dtype=torch.int32, device=dev),
+                    torch.zeros(1, dtype=torch.int32, device=dev))
+
+        def scan_only():
+            rx_.findall_async(batch_, out_)
+
+        def scan_gather():
+            rx_.findall_async(batch_, out_)
+            if comm is not None:
+                return comm.gather_spans(pre_, sp_, n_global=n_glob, cap_spans_per_rank=cap, out=gout)
+            return D.gather_spans(world, pre_, sp_, int(pre_[n_].item()))
+
+        res = {}
+        for name, fn in (("scan_only", scan_only), ("scan_plus_gather", scan_gather)):
+            for _ in range(2):
+                r = fn()
+            torch.cuda.synchronize()
+            D.barrier(world, gdev)
+            g0 = time.perf_counter()
+            for _ in range(gsteps):
+                r = fn()
+            torch.cuda.synchronize()
+            D.barrier(world, gdev)
+            gel = time.perf_counter() - g0
+            ga = D.combine(world, gel, {"bytes": float(batch_.nbytes_text) * gsteps}, device=dev if backend == "nccl" else "cpu")
+            res[name] = {"ms_per_step": round(ga["elapsed_s"] / gsteps * 1e3, 4),
+                         "GBps_whole_job": round(ga["bytes"] / ga["elapsed_s"] / 1e9, 3)}
+        if comm is not None:
+            status = int(r[2].item())
+            total_spans = int(r[0][n_glob].item())
+            res["exchange"] = {"form": "padded, no host read-back (mrx_allgatherv_spans over RCCL)", "status": status,
+                               "span_slots_per_rank": cap, "global_texts": n_glob, "global_spans": total_spans,
+                               "gathered_span_bytes_per_rank": total_spans * 8}
+        else:
+            res["exchange"] = {"form": "torch.distributed (%s)" % backend, "global_texts": int(r[0].shape[0]) - 1,
+                               "global_spans": int(r[1].shape[0]), "gathered_span_bytes_per_rank": int(r[1].shape[0]) * 8}
+        res["steps"] = gsteps
+        res["backend"] = backend
+        return res
+
+    if extras or (args.gather and world > 1):
+        comm = None
+        try:
+            if backend == "nccl":
+                comm = D.Comm.create(world, rank)
+            batch.nbytes_text = n * L
+            gather_info = exchange_leg(rx, batch, out, n, comm)
+            gather_info["workload"] = "config 2 (the headline batch)"
+        except Exception as e:   # noqa: BLE001 -- reported, the headline must still be printed
+            gather_info = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        # config 3 in its defining form: `\\d+` findall over 64M x 256 B sharded over 8 GPUs = 8M x 256 B per GPU
+        # (BASELINE.json configs[2]); the per-GPU share is fixed, so this is a weak-scaling figure as well
+        if extras:
+            try:
+                from mojo_regex_amd.workloads import make_digits_batch
+                n3, L3 = args.c3_texts, 256
+                b3_t = make_digits_batch(n3, L3, seed=20260103 + rank, device=dev)
+                b3 = M.DeviceBatch.strided(b3_t.reshape(-1), L3, length=L3)
+                b3.nbytes_text = n3 * L3
+                rx3 = M.compile_regex(b"\\d+")
+                out3 = (torch.empty(n3 + 1, dtype=torch.int64, device=dev),
+                        torch.empty((n3 * 6, 2), dtype=torch.int32, device=dev))
+                config3_info = exchange_leg(rx3, b3, out3, n3, comm)
+                config3_info["workload"] = "findall \\d+ over %d x %d B texts per GPU (config 3's per-GPU share)" % (n3, L3)
+                del b3, b3_t, out3
+            except Exception as e:   # noqa: BLE001
+                config3_info = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        if comm is not None:
+            comm.close()
+        for _ in range(2):   # put the arena back into the headline batch's shape for the legs below
+            step()
         torch.cuda.synchronize()
-        D.barrier(world, gdev)
-        g0 = time.perf_counter()
-        for _ in range(gsteps):
-            gp, gs = gstep()
-        torch.cuda.synchronize()
-        D.barrier(world, gdev)
-        gel = time.perf_counter() - g0
-        gagg = D.combine(world, gel, {"bytes": float(n) * L * gsteps}, device=dev if backend == "nccl" else "cpu")
-        gather_info = {"ms_per_step": round(gagg["elapsed_s"] / gsteps * 1e3, 4),
-                       "GBps_scan_plus_gather": round(gagg["bytes"] / gagg["elapsed_s"] / 1e9, 3),
-                       "gathered_span_bytes_per_rank": int(gs.shape[0]) * 8,
-                       "global_texts": int(gp.shape[0]) - 1, "steps": gsteps, "backend": backend}
 
     # ---- roofline of the dominant kernel: HIP events on its own launch stream -------
     lib.mrx_timing_enable(1)
@@ -432,6 +512,8 @@ def main():
             line["other_ops"] = other
         if gather_info is not None:
             line["scan_plus_gather"] = gather_info
+        if config3_info is not None:
+            line["config3"] = config3_info
         if strong_info is not None:
             line["strong"] = strong_info
         if world == 1 and not args.no_cpu_baseline:

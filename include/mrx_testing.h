@@ -50,6 +50,15 @@ void mrx_debug_subs_group(int lanes);
  * that short test texts are cut, at positions that are not multiples of 16), anything else = in 2 KiB pieces
  * when the batch has few texts.  Results are the same. */
 void mrx_debug_litscan_pieces(int mode);
+/* include/mrx_comm.h, padded form of mrx_allgatherv_spans: its two device steps on buffers the caller fills as
+ * ncclAllGather would have, so that the multi-rank arithmetic can be checked on one GPU.
+ * shift: out[i] = prefix[i + 1] + (spans of the ranks before `rank`) for i < n_local, 0 up to pad_to.
+ * compact: meta_all[r] = {texts, spans} of rank r; stage_prefix[r][P], stage_spans[r][cap][2] -> global CSR. */
+int mrx_testing_comm_shift(const int64_t* d_prefix, int64_t n_local, const int64_t* d_meta_all, int rank,
+                           int64_t* d_out, int64_t pad_to, void* stream);
+int mrx_testing_comm_compact(const int64_t* d_meta_all, int nranks, const int64_t* d_stage_prefix, int64_t P,
+                             const int32_t* d_stage_spans, int64_t cap, int64_t* d_gprefix, int64_t gprefix_cap,
+                             int32_t* d_gspans, int64_t gspans_cap, int32_t* d_status, void* stream);
 /* Bytes of device memory the calling thread's scratch arenas hold (see mrx_release_scratch). */
 size_t mrx_debug_scratch_bytes(void);
 

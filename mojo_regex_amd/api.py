@@ -114,6 +114,20 @@ def load_library():
         "mrx_release_scratch": (None, []),
         "mrx_debug_scratch_bytes": (C.c_size_t, []),
         "mrx_version": (C.c_char_p, []),
+        # include/mrx_comm.h: results exchange between ranks (RCCL, opened on first use)
+        "mrx_comm_unique_id": (C.c_int, [C.c_void_p]),
+        "mrx_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(H)]),
+        "mrx_comm_free": (None, [H]),
+        "mrx_comm_rank": (C.c_int, [H]),
+        "mrx_comm_size": (C.c_int, [H]),
+        "mrx_allgather_fixed": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+        "mrx_allgatherv_rows": (C.c_int, [H, C.c_void_p, C.c_int64, C.c_size_t, C.c_void_p, C.c_int64,
+                                          C.POINTER(C.c_int64), C.c_void_p]),
+        "mrx_allgatherv_spans": (C.c_int, [H, i64p, C.c_int64, i32p, C.c_int64, C.c_int64, i64p, C.c_int64, i32p,
+                                           C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), i32p, C.c_void_p]),
+        "mrx_testing_comm_shift": (C.c_int, [i64p, C.c_int64, i64p, C.c_int, i64p, C.c_int64, C.c_void_p]),
+        "mrx_testing_comm_compact": (C.c_int, [i64p, C.c_int, i64p, C.c_int64, i32p, C.c_int64, i64p, C.c_int64,
+                                               i32p, C.c_int64, i32p, C.c_void_p]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch
@@ -139,7 +153,11 @@ TESTING_SYMBOLS = [
     "mrx_timing_reset", "mrx_timing_enable", "mrx_timing_scan_ms", "mrx_last_kernel_name",
     "mrx_debug_force_generic", "mrx_debug_long_text_kernels", "mrx_debug_scratch_bytes",
     "mrx_debug_fused_findall", "mrx_debug_dynamic_texts", "mrx_debug_subs_group",
-    "mrx_debug_split_findall", "mrx_debug_litscan_pieces",
+    "mrx_debug_split_findall", "mrx_debug_litscan_pieces", "mrx_testing_comm_shift", "mrx_testing_comm_compact",
+]
+COMM_SYMBOLS = [
+    "mrx_comm_unique_id", "mrx_comm_init", "mrx_comm_free", "mrx_comm_rank", "mrx_comm_size",
+    "mrx_allgather_fixed", "mrx_allgatherv_rows", "mrx_allgatherv_spans",
 ]
 
 

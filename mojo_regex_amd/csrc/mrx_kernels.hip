@@ -1436,6 +1436,8 @@ __global__ __launch_bounds__(64 * kStreamWaves, (MODE == ST_FUSED ? MRX_FUSED_WA
   constexpr int NL = 64 / RPI;            // load instructions per chunk (= CH / 16)
   __shared__ __align__(16) uint8_t tiles[kStreamWaves][64 * kRowPitch];
   __shared__ __align__(16) uint16_t col_lds[256];
+  __shared__ __align__(16) uint16_t col32_lds[AUTO == 5 ? 256 : 2];   // code columns (DevPlan::off_stcol32)
+  static_assert(AUTO != 5 || MODE != ST_FIRST, "the anchored automaton has no code-column form");
   // pmask[x]: the first x bytes of a 16-byte group set.  Texts that end (or, in a frame, begin) inside
   // a group: when the automaton has a reset byte (DevPlan::st_reset_byte -- every state goes idle, no
   // walk starts, accepting states emit), the bytes outside the text are replaced by it and the group
@@ -1466,10 +1468,13 @@ __global__ __launch_bounds__(64 * kStreamWaves, (MODE == ST_FUSED ? MRX_FUSED_WA
     blk_ticket[0] = (1ull << 32) | (uint32_t)__hip_atomic_fetch_add(fz.ctrl, (unsigned long long)kStreamWaves, __ATOMIC_RELAXED,
                                                                     __HIP_MEMORY_SCOPE_AGENT);
   }
-  const bool use_fill = MODE != ST_FIRST && p.st_reset_byte >= 0 && !(MODE == ST_COUNT && (AUTO == 2 || AUTO == 3));
+  const bool use_fill = AUTO == 5 || (MODE != ST_FIRST && p.st_reset_byte >= 0 && !(MODE == ST_COUNT && (AUTO == 2 || AUTO == 3)));
   const uint32_t fillw = (uint32_t)(p.st_reset_byte & 0xFF) * 0x01010101u;
   extern __shared__ __align__(16) uint8_t stg_lds[];  // AUTO == 2: cls | trans | accept
-  if (AUTO == 1) {
+  if (AUTO == 5) {
+    const uint16_t* src = (const uint16_t*)(blob + p.off_stcol32);
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) col32_lds[i] = src[i];
+  } else if (AUTO == 1) {
     const uint16_t* src = (const uint16_t*)(blob + (MODE == ST_FIRST ? p.off_fa_col : p.off_stcol));
     for (int i = threadIdx.x; i < 256; i += blockDim.x) col_lds[i] = src[i];
   } else if (AUTO == 3) {
@@ -1598,7 +1603,8 @@ __global__ __launch_bounds__(64 * kStreamWaves, (MODE == ST_FUSED ? MRX_FUSED_WA
     } while (0)
     uint64_t skip_rows = 0;  // ST_FIRST: rows (= lanes) whose walk has ended
 
-    uint32_t q4 = 0;  // 4 * state
+    uint32_t q4 = 0;  // 4 * state (AUTO == 5: bit offset of the state's field, low two bits = its code)
+    uint32_t q_codes = 0;   // AUTO == 5: the code word of the previous group (its top field = the state before this group)
     int start = 0;
     int cnt = 0;
     int wrec = 0;  // records written by this wavefront so far (wave uniform)
@@ -1734,6 +1740,21 @@ __global__ __launch_bounds__(64 * kStreamWaves, (MODE == ST_FUSED ? MRX_FUSED_WA
               F = __builtin_amdgcn_alignbit(e, F, 2);
             }
           }
+        } else if (AUTO == 5) {
+          // code columns: one shift per byte (the count is taken modulo 32, so the fields above the state's
+          // own need no masking), the state's 2-bit code recorded per byte, events from two code words
+          uint32_t cv[16];
+#pragma unroll
+          for (int k = 0; k < 16; ++k)
+            cv[k] = col32_lds[(words[k >> 2] >> ((k & 3) * 8)) & 0xFFu];
+#pragma unroll
+          for (int k = 0; k < 16; ++k) {
+            q4 = cv[k] >> (q4 & 31u);
+            F = __builtin_amdgcn_alignbit(q4, F, 2);
+          }
+          const uint32_t qn = F, qp = __builtin_amdgcn_alignbit(qn, q_codes, 30);   // codes after / before each byte
+          q_codes = qn;
+          F = (qp & ~qn & 0xAAAAAAAAu) | (qn & ~qp & 0x55555555u);   // EMIT: accepting -> not; NEWSTART: not first -> first
         } else if (full) {
           uint32_t cv[16];
 #pragma unroll
@@ -1828,7 +1849,8 @@ __global__ __launch_bounds__(64 * kStreamWaves, (MODE == ST_FUSED ? MRX_FUSED_WA
     // end of text: a walk that is in an accepting state ends at len
     {
       const bool tail = MODE != ST_FIRST && live && (!VIRT || (vsk >> 31)) &&
-                        (AUTO == 4 ? acc_lds[q4 >> (2 * p.st_cshift)] != 0
+                        (AUTO == 5 ? ((p.st_acc32 >> (q4 & 31u)) & 1u) != 0
+                         : AUTO == 4 ? acc_lds[q4 >> (2 * p.st_cshift)] != 0
                          : AUTO == 2 ? acc_lds[q4 >> p.st_cshift] != 0
                                    : ((accmask >> (q4 >> (AUTO == 3 ? 3 : 2))) & 1u) != 0);
       if (RECS) {
@@ -2253,7 +2275,9 @@ __global__ __launch_bounds__(kBlock) void k_decode(int64_t n, const int32_t* __r
                                                    int32_t* __restrict__ spans, int64_t span_cap,
                                                    int fixed_len, int64_t* __restrict__ total_out,
                                                    const int32_t* __restrict__ vbase = nullptr,
-                                                   const int64_t* __restrict__ base = nullptr) {
+                                                   const int64_t* __restrict__ base = nullptr, int reverse = 0) {
+  // reverse: wavefronts take the 64-text groups last first -- the records the scan wrote last are the ones still
+  // in L2 / Infinity Cache when this kernel starts
   // base: spans of the texts in front of this launch's (the second half of a split findall, see findall_split)
   static_assert(!(PACK16 && VBASE), "text-relative positions of a long text do not fit 16 bits");
   static_assert(!(DYN && VBASE), "pieces are not handed out dynamically");
@@ -2269,8 +2293,9 @@ __global__ __launch_bounds__(kBlock) void k_decode(int64_t n, const int32_t* __r
   int* rel_lds = rel_all[DYN ? (threadIdx.x >> 6) : 0];
   const int64_t nw = (n + kTexts - 1) / kTexts;
   const int waves_per_block = blockDim.x >> 6;
-  for (int64_t w = (int64_t)blockIdx.x * waves_per_block + (threadIdx.x >> 6); w < nw;
-       w += (int64_t)gridDim.x * waves_per_block) {
+  for (int64_t w0 = (int64_t)blockIdx.x * waves_per_block + (threadIdx.x >> 6); w0 < nw;
+       w0 += (int64_t)gridDim.x * waves_per_block) {
+    const int64_t w = reverse ? nw - 1 - w0 : w0;
     const int64_t first = w * kTexts;
     const int64_t i = first + lane;
     // CSR offsets of my 64 texts: exclusive scan of their counts on top of the wavefront's base
@@ -3357,6 +3382,10 @@ int fail(int code, const std::string& msg) {
   return code;
 }
 
+}  // namespace
+namespace mrx { int internal_fail(int code, const std::string& msg) { return fail(code, msg); } }   // mrx_internal.hpp
+namespace {
+
 #define HIP_TRY(expr)                                                                  \
   do {                                                                                 \
     hipError_t e_ = (expr);                                                            \
@@ -3860,6 +3889,12 @@ bool strided_fast(const Layout& lay) {
          lay.stride * 64 < (int64_t(1) << 31);
 }
 
+// code columns (DevPlan::off_stcol32) on fixed-pitch batches; MRX_NO_CODE_COLUMNS=1 keeps the 4-bit columns (A/B runs)
+static bool code_columns_on() {
+  static const bool on = [] { const char* e = getenv("MRX_NO_CODE_COLUMNS"); return !(e && e[0] == '1'); }();
+  return on;
+}
+
 template <int MODE>
 void launch_stream(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d_counts, int32_t* d_nrecs,
                    EvRec* d_recs, int64_t rec_row, int32_t* d_s, int32_t* d_e, hipStream_t s,
@@ -3910,6 +3945,7 @@ void launch_stream(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d
     if (pairs) { if constexpr (MODE != ST_FIRST) MRX_LAUNCH(4, 0); }
     else if (table) MRX_LAUNCH(2, 0);
     else if (wide) MRX_LAUNCH(3, 0);
+    else if (MODE != ST_FIRST && p.off_stcol32 >= 0 && code_columns_on()) { if constexpr (MODE != ST_FIRST) MRX_LAUNCH(5, 0); }
     else MRX_LAUNCH(1, 0);
   }
 #undef MRX_LAUNCH
@@ -4552,7 +4588,7 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
     if (pack16 && rec32 && max_text >= 768)
       hipLaunchKernelGGL((k_decode<true, false, true, false, 3072>), dim3(grid_for(n, kBlock) * 2), dim3(kBlock), 0, s, n, d_nrecs, d_recs,
                          rec_row, lay.offsets, d_counts, d_wbase, d_tsum, d_prefix, d_spans, span_cap, p.st_fixed_len,
-                         d_total);
+                         d_total, (const int32_t*)nullptr, (const int64_t*)nullptr, env_int("MRX_DECODE_REVERSE", 0));
     else if (pack16 && rec32)
       hipLaunchKernelGGL((k_decode<true, false, true>), dim3(grid_for(n, kBlock) * 2), dim3(kBlock), 0, s, n, d_nrecs, d_recs,
                          rec_row, lay.offsets, d_counts, d_wbase, d_tsum, d_prefix, d_spans, span_cap, p.st_fixed_len,

@@ -589,6 +589,8 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
 
   // ---- streaming automaton (findall only) -----------------------------------------
   d.off_stcol = -1;
+  d.off_stcol32 = -1;
+  d.st_acc32 = 0;
   d.off_st_sync = -1;
   d.off_stg_pair = -1;
   d.st_nsync = 0;
@@ -706,6 +708,40 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
       align(hp.blob, 4);
       d.off_stcol = (int)hp.blob.size();
       put(hp.blob, cols.data(), 512);
+      // code columns (see DevPlan::off_stcol32): the events must be functions of the states' 2-bit codes
+      if (d.st_reset_byte >= 0 && !live_acc[0]) {
+        int first[4] = {0, 0, 0, 0};
+        for (int q = 0; q < nlive; ++q)
+          for (int c = 0; c < 256; ++c)
+            if (E[q][c] & 1) first[E[q][c] >> 2] = 1;
+        bool ok = first[0] == 0;
+        for (int q = 0; q < nlive && ok; ++q)
+          for (int c = 0; c < 256 && ok; ++c) {
+            const int nx = E[q][c] >> 2, em = (E[q][c] >> 1) & 1, ns = E[q][c] & 1;
+            ok = nx < nlive && em == ((live_acc[q] && !live_acc[nx]) ? 1 : 0) && ns == ((first[nx] && !first[q]) ? 1 : 0);
+          }
+        int off[4] = {0, 0, 0, 0}, cur = 0;
+        for (int q = 0; q < nlive && ok; ++q) {
+          const int code = (live_acc[q] ? 2 : 0) | first[q];
+          int o = cur;
+          while ((o & 3) != code) ++o;
+          off[q] = o;
+          cur = o + 5;
+          // u16 entries (idle + two states): a u32 table was measured to add a fifth to the LDS bank conflicts
+          // (bank = byte mod 32 instead of byte / 2 mod 32), which cost the count kernel 8 %
+          ok = cur <= 16;
+        }
+        if (ok) {
+          std::vector<uint16_t> c16(256, 0);
+          for (int c = 0; c < 256; ++c)
+            for (int q = 0; q < nlive; ++q) c16[c] |= (uint16_t)(off[E[q][c] >> 2] << off[q]);
+          for (int q = 0; q < nlive; ++q)
+            if (live_acc[q]) d.st_acc32 |= 1u << off[q];
+          align(hp.blob, 4);
+          d.off_stcol32 = (int)hp.blob.size();
+          put(hp.blob, c16.data(), 512);
+        }
+      }
     } else if (nlive <= 8) {
       // wide byte-column form: 8 states x 8-bit fields in a u64 column,
       // field(q) = next << 3 | EMIT << 1 | NEWSTART, so "field & 0x38" is the next shift amount
@@ -1110,7 +1146,7 @@ std::string describe_plan(const HostPlan& hp) {
   o << "device.streamable=" << ((d.flags & PF_STREAMABLE) ? "yes" : ("no: " + hp.streamable_why_not))
     << " st_nstates=" << d.st_nstates << " st_kind=" << d.st_kind
     << (((d.flags & PF_STREAMABLE) && !(d.flags & PF_STREAM_SEARCH)) ? " findall_only=1" : "")
-    << " sync_bytes=" << d.st_nsync << " reset_byte=" << d.st_reset_byte
+    << " sync_bytes=" << d.st_nsync << " reset_byte=" << d.st_reset_byte << " code_columns=" << (d.off_stcol32 >= 0 ? 1 : 0)
     << (d.off_stg_pair >= 0 ? " pair_table=1" : "") << "\n";
   o << "device.steppable=" << ((d.flags & PF_STEPPABLE) ? "yes" : (d.flags & PF_STEP_REQ) ? "required-byte route" : "no")
     << " step_search=" << ((d.flags & PF_STEP_SEARCH) ? 1 : 0) << ((d.flags & PF_STEP_BIG) ? " big_table=1" : "")

@@ -73,6 +73,16 @@ struct DevPlan {
   int32_t st_fixed_len;   // > 0: every match is [end - st_fixed_len, end) (exact-literal KMP automaton)
   int32_t off_stcol;      // kind 1: u16 column table [256] (4 states x 4 bit); kind 3: u64 [256] (8 x 8 bit)
   uint32_t st_accept_mask;
+  // kind 1, "code columns" (off_stcol32 >= 0; round 3): u16 column table [256] (idle + at most two states).  State q owns the 5-bit field at
+  // bit offset st_code_off(q) (the idle state at 0); the field holds the bit offset of the next state's field,
+  // so one step is `s = col[byte] >> s` (the hardware takes the shift count modulo 32).  Offsets are chosen
+  // with offset mod 4 = the state's 2-bit CODE: bit 1 = "accepting", bit 0 = "a walk's first state(s)", and the
+  // plan qualifies only if for every transition EMIT == acc(old) && !acc(new) and NEWSTART == first(new) &&
+  // !first(old) -- so the kernel records the low two bits of s per byte (`alignbit`) and derives the event word
+  // of a 16-byte group from that code word and the one before it with two instructions.  st_acc32: bit o set
+  // when the state whose field sits at offset o accepts (the end-of-text rule).
+  int32_t off_stcol32;
+  uint32_t st_acc32;
   // kind 2: cls[256] u8, trans[st_nstates][1 << st_cshift] u16 = (next << st_cshift) << 2 | EMIT << 1 | NEWSTART,
   // accept[st_nstates] u8
   int32_t off_stg_cls, off_stg_trans, off_stg_acc, st_cshift, stg_bytes;

@@ -6,6 +6,11 @@ gather_fixed() (match_first / search / captures: fixed bytes per text, plain
 all-gather) and gather_spans() (findall: per-rank totals first, then an
 all-gatherv into prefix-sum offsets).  torch.distributed backend "nccl" (= RCCL
 over xGMI) on GPUs, "gloo" in the CPU tests.
+
+On GPUs the exchange itself runs behind the C ABI (include/mrx_comm.h, csrc/mrx_comm.hip:
+RCCL called directly, the same entry points a Mojo host binds): `Comm` below wraps it; the
+torch.distributed process group only carries the 128-byte communicator id and the barriers.
+The torch-only implementations further down remain for gloo (CPU tests, shared-GPU rehearsal).
 """
 from __future__ import annotations
 
@@ -62,7 +67,110 @@ def combine(world: int, elapsed_s: float, units: Dict[str, float], device="cpu")
     return out
 
 
-# ---- results exchange (optional) -----------------------------------
+# ---- results exchange behind the C ABI (include/mrx_comm.h) --------------------------
+class Comm:
+    """mrx_comm: an RCCL communicator owned by libmrx_hip.so.  Comm.create(world, rank) is collective:
+    rank 0 makes the id (mrx_comm_unique_id) and the process group broadcasts its 128 bytes."""
+
+    def __init__(self, handle, world: int, rank: int):
+        self._h, self.world, self.rank = handle, world, rank
+
+    @classmethod
+    def create(cls, world: int, rank: int):
+        import ctypes as C
+        import torch
+        from .api import load_library, _check
+        lib = load_library()
+        ident = (C.c_uint8 * 128)()
+        if rank == 0:
+            _check(lib.mrx_comm_unique_id(ident))
+        if world > 1:
+            import torch.distributed as dist
+            t = torch.tensor(list(ident), dtype=torch.uint8)
+            if dist.get_backend() == "nccl":
+                t = t.cuda()
+            dist.broadcast(t, src=0)
+            ident = (C.c_uint8 * 128)(*t.cpu().tolist())
+        h = C.c_void_p()
+        _check(lib.mrx_comm_init(ident, world, rank, C.byref(h)))
+        return cls(h, world, rank)
+
+    def close(self):
+        if self._h:
+            from .api import load_library
+            load_library().mrx_comm_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def gather_fixed(self, local):
+        """Equal shards: [world * n_local, ...] in rank order (one ncclAllGather, no host synchronisation)."""
+        import torch
+        from .api import load_library, _check
+        local = local.contiguous()
+        out = torch.empty((self.world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        _check(load_library().mrx_allgather_fixed(self._h, local.data_ptr(), out.data_ptr(),
+                                                  local.numel() * local.element_size(),
+                                                  torch.cuda.current_stream().cuda_stream))
+        return out
+
+    def gather_rows(self, local, rows_cap: int):
+        """Ragged shards of fixed-width rows (exact form: one 8-byte-per-rank read-back)."""
+        import ctypes as C
+        import torch
+        from .api import load_library, _check
+        local = local.contiguous()
+        row_bytes = local.element_size()
+        for d in local.shape[1:]:
+            row_bytes *= int(d)
+        out = torch.empty((rows_cap,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        total = C.c_int64(0)
+        _check(load_library().mrx_allgatherv_rows(self._h, local.data_ptr(), local.shape[0], row_bytes, out.data_ptr(),
+                                                  rows_cap, C.byref(total), torch.cuda.current_stream().cuda_stream))
+        return out[: total.value]
+
+    def gather_spans(self, prefix, spans, n_global: int, cap_spans_per_rank: int = 0, out=None):
+        """findall CSR of all ranks on every rank.  cap_spans_per_rank = 0: exact form (sizes read back once);
+        > 0: padded form, nothing is read back -- returns (gprefix[n_global + 1], gspans[world * cap], status)
+        with the span total in gprefix[n_global] and int32 status on the device (0 = ok)."""
+        import ctypes as C
+        import torch
+        from .api import load_library, _check
+        lib = load_library()
+        n_local = int(prefix.shape[0]) - 1
+        dev = prefix.device
+        stream = torch.cuda.current_stream().cuda_stream
+        if cap_spans_per_rank > 0:
+            if out is None:
+                out = (torch.empty(n_global + 1, dtype=torch.int64, device=dev),
+                       torch.empty((self.world * cap_spans_per_rank, 2), dtype=torch.int32, device=dev),
+                       torch.zeros(1, dtype=torch.int32, device=dev))
+            gp, gs, st = out
+            assert spans.shape[0] >= cap_spans_per_rank, "the local span buffer must hold cap_spans_per_rank slots"
+            _check(lib.mrx_allgatherv_spans(self._h, prefix.data_ptr(), n_local, spans.data_ptr(), cap_spans_per_rank,
+                                            n_global, gp.data_ptr(), gp.shape[0], gs.data_ptr(), gs.shape[0], None, None,
+                                            st.data_ptr(), stream))
+            return gp, gs, st
+        # exact: capacities are known only after the sizes are back, so gather into generous buffers once
+        if out is None:
+            tot_local = int(prefix[n_local].item())
+            t = torch.tensor([tot_local], dtype=torch.int64, device=dev)
+            allt = self.gather_fixed(t)
+            out = (torch.empty(n_global + 1, dtype=torch.int64, device=dev),
+                   torch.empty((max(1, int(allt.sum().item())), 2), dtype=torch.int32, device=dev))
+        gp, gs = out[0], out[1]
+        N, T = C.c_int64(0), C.c_int64(0)
+        _check(lib.mrx_allgatherv_spans(self._h, prefix.data_ptr(), n_local, spans.data_ptr(), 0, n_global,
+                                        gp.data_ptr(), gp.shape[0], gs.data_ptr(), gs.shape[0], C.byref(N), C.byref(T),
+                                        None, stream))
+        return gp[: N.value + 1], gs[: T.value]
+
+
+# ---- results exchange over torch.distributed (gloo rehearsal; SURVEY.md 8(e)) -----------
 def _all_gather_sizes(world: int, values: List[int], device) -> List[List[int]]:
     """values of every rank, [world][len(values)] (one small fixed-size all-gather)."""
     import torch

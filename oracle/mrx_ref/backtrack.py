@@ -177,6 +177,68 @@ def _match_char_in_range(range_pattern: bytes, ch: int) -> bool:
     return ch in range_pattern
 
 
+def range_first_test(ast: Node, ch: int) -> bool:
+    """The membership test _match_range makes on the byte at str_i (nfa.mojo:930-995): by range kind."""
+    kind = range_kind(ast)
+    found = False
+    if kind == RK_ALNUM:
+        found = _is_lower(ch) or _is_upper(ch) or _is_digit(ch)
+    elif kind == RK_LOWER:
+        found = _is_lower(ch)
+    elif kind == RK_UPPER:
+        found = _is_upper(ch)
+    elif kind == RK_DIGITS:
+        found = _is_digit(ch)
+    elif kind == RK_ALPHA:
+        found = _is_lower(ch) or _is_upper(ch)
+    elif kind == RK_COMPLEX_ALNUM:
+        if _is_lower(ch) or _is_upper(ch) or _is_digit(ch):
+            found = True
+        else:
+            v = ast.get_value()
+            if v:
+                found = ch in v[1:len(v) - 1]
+    else:
+        v = ast.get_value()
+        if v:
+            found = _is_char_in_range_by_code(ch, v)
+    return found == ast.positive_logic
+
+
+def simd_predicate(ast: Node):
+    """The byte predicate of _apply_quantifier_simd's loop for this leaf (nfa.mojo:1446-1647), None when that
+    function falls off its end (`return (False, str_i)`)."""
+    t = ast.type
+    if t == DIGIT:
+        return _is_digit
+    if t == SPACE:
+        return whitespace_matcher_contains
+    if t == WORD:
+        return _is_word
+    v = ast.get_value()
+    if t == RANGE and v:
+        kind = range_kind(ast)
+        if kind == RK_ALNUM:
+            pred = lambda c: _is_lower(c) or _is_upper(c) or _is_digit(c)   # noqa: E731
+        elif kind == RK_LOWER:
+            pred = _is_lower
+        elif kind == RK_UPPER:
+            pred = _is_upper
+        elif kind == RK_DIGITS:
+            pred = _is_digit
+        elif kind == RK_ALPHA:
+            pred = lambda c: _is_lower(c) or _is_upper(c)   # noqa: E731
+        elif kind == RK_COMPLEX_ALNUM:
+            inner = v[1:len(v) - 1]
+            pred = lambda c: _is_lower(c) or _is_upper(c) or _is_digit(c) or c in inner   # noqa: E731
+        else:
+            # RK_OTHER: _create_range_matcher returns None for every bracket pattern
+            # (nfa.mojo:587-640), so the scalar fallback runs (:1620-1645)
+            pred = lambda c: _match_char_in_range(v, c)   # noqa: E731
+        return pred if ast.positive_logic else (lambda c: not pred(c))
+    return None
+
+
 class BacktrackNFA:
     """NFAEngine (nfa.mojo:66-1731).  `flags` carries the constructor's routing facts
     (literal_prefix, has_literal_optimization, starts/ends_with_dotstar; nfa.mojo:86-143)."""
@@ -419,31 +481,7 @@ class BacktrackNFA:
         """nfa.mojo:930-995."""
         if i >= len(s):
             return (False, i)
-        ch = s[i]
-        kind = range_kind(ast)
-        found = False
-        if kind == RK_ALNUM:
-            found = _is_lower(ch) or _is_upper(ch) or _is_digit(ch)
-        elif kind == RK_LOWER:
-            found = _is_lower(ch)
-        elif kind == RK_UPPER:
-            found = _is_upper(ch)
-        elif kind == RK_DIGITS:
-            found = _is_digit(ch)
-        elif kind == RK_ALPHA:
-            found = _is_lower(ch) or _is_upper(ch)
-        elif kind == RK_COMPLEX_ALNUM:
-            if _is_lower(ch) or _is_upper(ch) or _is_digit(ch):
-                found = True
-            else:
-                v = ast.get_value()
-                if v:
-                    found = ch in v[1:len(v) - 1]
-        else:
-            v = ast.get_value()
-            if v:
-                found = _is_char_in_range_by_code(ch, v)
-        if found == ast.positive_logic:
+        if range_first_test(ast, s[i]):
             return self._apply_quantifier(ast, s, i, 1, mfm, req)
         return (False, i)
 
@@ -579,34 +617,7 @@ class BacktrackNFA:
 
     def _apply_quantifier_simd(self, ast, s, i, min_matches, max_matches):
         """nfa.mojo:1446-1647."""
-        t = ast.type
-        if t == DIGIT:
-            return _run(_is_digit, s, i, min_matches, max_matches)
-        if t == SPACE:
-            return _run(whitespace_matcher_contains, s, i, min_matches, max_matches)
-        if t == WORD:
-            return _run(_is_word, s, i, min_matches, max_matches)
-        v = ast.get_value()
-        if t == RANGE and v:
-            pos_logic = ast.positive_logic
-            kind = range_kind(ast)
-
-            def by(pred):
-                return _run(pred if pos_logic else (lambda c: not pred(c)), s, i, min_matches, max_matches)
-            if kind == RK_ALNUM:
-                return by(lambda c: _is_lower(c) or _is_upper(c) or _is_digit(c))
-            if kind == RK_LOWER:
-                return by(_is_lower)
-            if kind == RK_UPPER:
-                return by(_is_upper)
-            if kind == RK_DIGITS:
-                return by(_is_digit)
-            if kind == RK_ALPHA:
-                return by(lambda c: _is_lower(c) or _is_upper(c))
-            if kind == RK_COMPLEX_ALNUM:
-                inner = v[1:len(v) - 1]
-                return by(lambda c: _is_lower(c) or _is_upper(c) or _is_digit(c) or c in inner)
-            # RK_OTHER: _create_range_matcher returns None for every bracket pattern
-            # (nfa.mojo:587-640), so the scalar fallback runs (:1620-1645)
-            return by(lambda c: _match_char_in_range(v, c))
-        return (False, i)
+        pred = simd_predicate(ast)
+        if pred is None:
+            return (False, i)
+        return _run(pred, s, i, min_matches, max_matches)

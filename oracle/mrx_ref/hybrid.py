@@ -13,6 +13,8 @@ whose results depend on the transition cache's history (pikevm.mojo:697-700).
 """
 from __future__ import annotations
 
+import os
+
 from typing import List, Optional, Tuple
 
 from .frontend import parse, Node, RE, GROUP, ELEMENT, START, END
@@ -130,6 +132,20 @@ class NFAEngineFlags:
         self.starts_with_dotstar = swd
 
 
+# The backtracking matcher's C twin (oracle/c/mrx_backtrack.c through cbacktrack.py): same results, affordable
+# on kilobyte texts.  Off by default -- the Python restatement is what the reference's vectors pin;
+# tests/big_fuzz.py switches it on for long texts (MRX_ORACLE_C_BACKTRACK=1 does the same).
+USE_C_BACKTRACK = os.environ.get("MRX_ORACLE_C_BACKTRACK") == "1"
+
+
+def _make_backtrack(pattern: bytes, ast, flags):
+    bt = BacktrackNFA(pattern, ast, flags)
+    if USE_C_BACKTRACK:
+        from .cbacktrack import CBacktrack
+        return CBacktrack(bt)
+    return bt
+
+
 def nfa_engine(pattern: bytes) -> BacktrackNFA:
     """NFAEngine(pattern) on its own (nfa.mojo:86-143), as regex.nfa's module functions and the
     reference's tests/test_nfa.mojo use it: no hybrid router, no LazyDFA, no OnePass in front."""
@@ -137,7 +153,7 @@ def nfa_engine(pattern: bytes) -> BacktrackNFA:
         own_ast = parse(pattern)
     except Exception:
         own_ast = None
-    return BacktrackNFA(pattern, own_ast, NFAEngineFlags(pattern))
+    return _make_backtrack(pattern, own_ast, NFAEngineFlags(pattern))
 
 
 def nfa_findall(pattern: bytes, text: bytes):
@@ -160,7 +176,7 @@ class NFAMatcher:
             own_ast = parse(pattern)
         except Exception:
             own_ast = None
-        self.backtrack = BacktrackNFA(pattern, own_ast, self.engine)   # NFAMatcher.engine's matching half
+        self.backtrack = _make_backtrack(pattern, own_ast, self.engine)   # NFAMatcher.engine's matching half
         vm = PikeVMEngine(compile_ast(ast))
         self.program = vm.program
         self.onepass = None   # OnePassNFA, only for '$' programs that compile one-pass (:310-313)

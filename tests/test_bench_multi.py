@@ -37,8 +37,8 @@ def test_more_ranks_than_gpus_is_an_error_not_a_smaller_run():
 
 @pytest.mark.gpu
 def test_two_ranks_self_launched_with_results_exchange():
-    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--gather", "--texts", "16384", "--steps", "3",
-                        "--warmup", "1", "--settle", "2"], capture_output=True, text=True, timeout=900,
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--texts", "16384", "--steps", "3",
+                        "--warmup", "1", "--settle", "2", "--c3-texts", "32768"], capture_output=True, text=True, timeout=900,
                        env=_env(MRX_BENCH_SHARE_GPU="1"))
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -46,8 +46,14 @@ def test_two_ranks_self_launched_with_results_exchange():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 3
     assert d["config"]["texts_per_gpu"] == 16384
+    # the exchange legs run by default for N > 1 (gloo here: two ranks share the GPU, RCCL refuses that)
     g = d["scan_plus_gather"]
-    assert "error" not in g and g["global_texts"] == 2 * 16384 and g["ms_per_step"] > 0
+    assert "error" not in g, g
+    assert g["exchange"]["global_texts"] == 2 * 16384 and g["scan_plus_gather"]["ms_per_step"] > 0
+    assert g["scan_only"]["ms_per_step"] > 0 and g["exchange"]["global_spans"] > 0
+    c3 = d["config3"]
+    assert "error" not in c3, c3
+    assert c3["exchange"]["global_texts"] == 2 * 32768 and c3["scan_plus_gather"]["GBps_whole_job"] > 0
     s = d["strong"]
     assert s["total_texts"] == 16384 and s["texts_per_gpu"] == 8192 and s["value"] > 0
     assert "cpu_baseline" not in d   # rank 0 at N = 1 only

@@ -78,6 +78,11 @@ def test_library_exports_every_header_symbol():
     assert sorted(api.TESTING_SYMBOLS) == hooks
     for name in hooks:
         assert hasattr(lib, name), name
+    hdr = open(os.path.join(ROOT, "include", "mrx_comm.h")).read()
+    comm = sorted(set(re.findall(r"\b(mrx_[a-z_]+)\s*\(", hdr)))
+    assert sorted(api.COMM_SYMBOLS) == comm
+    for name in comm:
+        assert hasattr(lib, name), name
     assert b"gfx950" in lib.mrx_version()
 
 

@@ -65,3 +65,63 @@ def test_c_oracle_on_reference_vector_texts():
         assert [tuple(int(x) for x in r) for r in spans] == O.findall(pat, text)
         done += 1
     assert done > 150
+
+
+# ---- the backtracking matcher's C twin (oracle/c/mrx_backtrack.c) against backtrack.py ----------------------------
+def _both(pat):
+    from mrx_ref import hybrid as H
+    from mrx_ref.cbacktrack import CBacktrack
+    py = H.nfa_engine(pat)
+    assert py.__class__.__name__ == "BacktrackNFA"
+    return py, CBacktrack(py)
+
+
+def _same(py, c, text, starts=(0,)):
+    assert c.match_all(text) == py.match_all(text), ("match_all", py.pattern, text)
+    for st in starts:
+        assert c.match_first(text, st) == py.match_first(text, st), ("match_first", py.pattern, text, st)
+        assert c.match_next(text, st) == py.match_next(text, st), ("match_next", py.pattern, text, st)
+        assert c.match_next_with_groups(text, st) == py.match_next_with_groups(text, st), ("groups", py.pattern, text, st)
+
+
+def test_c_backtracker_on_the_reference_nfa_vectors_and_quirks():
+    import json
+    import os
+    done = 0
+    for v in load_vectors():
+        if not v["op"].startswith("nfa_"):
+            continue
+        py, c = _both(v["pattern"].encode())
+        _same(py, c, v["text"].encode())
+        done += 1
+    assert done >= 104
+    doc = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "backtrack_quirk_vectors.json")))
+    for v in doc["vectors"]:
+        py, c = _both(v["pattern"].encode("latin-1"))
+        _same(py, c, v["text"].encode("latin-1"))
+
+
+def test_c_backtracker_equals_python_on_generated_patterns():
+    import random
+    from pattern_gen import patterns, patterns2
+    from mrx_ref import RegexSyntaxError
+    rng = np.random.default_rng(77)
+    alphabets = [np.frombuffer(a, dtype=np.uint8) for a in (b"abcxyz0189 -.@\n", b"abfoo bar 12hello", bytes(range(256)))]
+    r = random.Random(5)
+    done = 0
+    for pat in patterns(31, 220) + patterns2(32, 220):
+        try:
+            py, c = _both(pat.encode())
+        except RegexSyntaxError:
+            continue
+        if py.regex is None:
+            continue
+        for al in alphabets:
+            for _ in range(4):
+                t = bytes(rng.choice(al, size=int(rng.integers(0, 70))).tolist())
+                _same(py, c, t, starts=(0, r.randrange(0, len(t) + 2)))
+        # one long text: runs past the 50 / 100-byte cut-offs of match_first mode and the > 8 SIMD switch
+        t = bytes(rng.choice(alphabets[0], size=400).tolist())
+        _same(py, c, t)
+        done += 1
+    assert done > 350
