@@ -206,6 +206,13 @@ int mrx_sub_dev(const mrx_handle* h, const char* repl, size_t repl_len, int64_t 
                 int64_t* d_out_offsets, uint8_t* d_out_data, int64_t out_cap,
                 int64_t* total_bytes, void* stream);
 
+/* Same, texts at a fixed pitch (round 3; every other operation already had this form).  Rows without padding
+ * (len == stride, d_lens == NULL) take every fast path of mrx_sub_dev; padded rows run on the lane-per-text kernels. */
+int mrx_sub_strided_dev(const mrx_handle* h, const char* repl, size_t repl_len, int64_t count,
+                        const uint8_t* d_data, int64_t stride, const int32_t* d_lens, int32_t len, int64_t n,
+                        int64_t* d_out_offsets, uint8_t* d_out_data, int64_t out_cap,
+                        int64_t* total_bytes, void* stream);
+
 /* ---- host-buffer convenience wrappers (copy in, run, copy out) -------------- */
 int mrx_match_first_batch(const mrx_handle* h, const uint8_t* data,
                           const int64_t* offsets, int64_t n, int32_t* start,

@@ -50,6 +50,10 @@ void mrx_debug_subs_group(int lanes);
  * that short test texts are cut, at positions that are not multiples of 16), anything else = in 2 KiB pieces
  * when the batch has few texts.  Results are the same. */
 void mrx_debug_litscan_pieces(int mode);
+/* Stepper plans with a multi-walk table (several walks side by side in one pass, k_mwalk; `multiwalk=yes` in
+ * mrx_describe) use it for findall / count / search; 2 = never (the windowed stepper's restart-per-position loop
+ * instead), anything else = where the plan has one.  Results are the same. */
+void mrx_debug_multiwalk(int mode);
 /* include/mrx_comm.h, padded form of mrx_allgatherv_spans: its two device steps on buffers the caller fills as
  * ncclAllGather would have, so that the multi-rank arithmetic can be checked on one GPU.
  * shift: out[i] = prefix[i + 1] + (spans of the ranks before `rank`) for i < n_local, 0 up to pad_to.

@@ -92,6 +92,8 @@ def load_library():
         "mrx_captures_dev": (C.c_int, [H, u8p, i64p, C.c_int64, i32p, C.c_void_p]),
         "mrx_sub_dev": (C.c_int, [H, C.c_char_p, C.c_size_t, C.c_int64, u8p, i64p, C.c_int64, i64p,
                                   u8p, C.c_int64, C.POINTER(C.c_int64), C.c_void_p]),
+        "mrx_sub_strided_dev": (C.c_int, [H, C.c_char_p, C.c_size_t, C.c_int64, u8p, C.c_int64, i32p, C.c_int32,
+                                          C.c_int64, i64p, u8p, C.c_int64, C.POINTER(C.c_int64), C.c_void_p]),
         "mrx_match_first_batch": (C.c_int, [H, u8p, i64p, C.c_int64, i32p, i32p]),
         "mrx_search_batch": (C.c_int, [H, u8p, i64p, C.c_int64, i32p, i32p]),
         "mrx_is_match_batch": (C.c_int, [H, u8p, i64p, C.c_int64, u8p]),
@@ -111,6 +113,7 @@ def load_library():
         "mrx_debug_subs_group": (None, [C.c_int]),
         "mrx_debug_split_findall": (None, [C.c_int]),
         "mrx_debug_litscan_pieces": (None, [C.c_int]),
+        "mrx_debug_multiwalk": (None, [C.c_int]),
         "mrx_release_scratch": (None, []),
         "mrx_debug_scratch_bytes": (C.c_size_t, []),
         "mrx_version": (C.c_char_p, []),
@@ -146,14 +149,14 @@ EXPORTED_SYMBOLS = [
     "mrx_captures_strided_dev", "mrx_captures_dev",
     "mrx_match_first_at_dev", "mrx_search_at_dev", "mrx_is_match_at_dev", "mrx_match_first_at_strided_dev",
     "mrx_search_at_strided_dev", "mrx_is_match_at_strided_dev",
-    "mrx_sub_dev", "mrx_match_first_batch", "mrx_search_batch", "mrx_is_match_batch",
+    "mrx_sub_dev", "mrx_sub_strided_dev", "mrx_match_first_batch", "mrx_search_batch", "mrx_is_match_batch",
     "mrx_findall_batch", "mrx_captures_batch", "mrx_sub_batch", "mrx_version", "mrx_release_scratch",
 ]
 TESTING_SYMBOLS = [
     "mrx_timing_reset", "mrx_timing_enable", "mrx_timing_scan_ms", "mrx_last_kernel_name",
     "mrx_debug_force_generic", "mrx_debug_long_text_kernels", "mrx_debug_scratch_bytes",
     "mrx_debug_fused_findall", "mrx_debug_dynamic_texts", "mrx_debug_subs_group",
-    "mrx_debug_split_findall", "mrx_debug_litscan_pieces", "mrx_testing_comm_shift", "mrx_testing_comm_compact",
+    "mrx_debug_split_findall", "mrx_debug_litscan_pieces", "mrx_debug_multiwalk", "mrx_testing_comm_shift", "mrx_testing_comm_compact",
 ]
 COMM_SYMBOLS = [
     "mrx_comm_unique_id", "mrx_comm_init", "mrx_comm_free", "mrx_comm_rank", "mrx_comm_size",
@@ -490,18 +493,24 @@ class CompiledRegex:
         return out
 
     def sub_dev(self, repl, batch: "DeviceBatch", count: int = 0, out_cap: Optional[int] = None):
-        """regex.sub on a device-resident CSR batch: (out_offsets int64[n+1], out_data uint8[total])."""
+        """regex.sub on a device-resident batch (CSR, or fixed pitch: mrx_sub_strided_dev):
+        (out_offsets int64[n+1], out_data uint8[total])."""
         import torch
         repl = _b(repl)
         dev = batch.data.device
-        off = batch.csr_offsets()
+        off = batch.csr_offsets() if batch.offsets is not None else None
         cap = int(out_cap) if out_cap else int(batch.data.numel()) * 2 + 16 * batch.n + 64
         out_off = torch.empty(batch.n + 1, dtype=torch.int64, device=dev)
         while True:
             out = torch.empty(cap, dtype=torch.uint8, device=dev)
             total = C.c_int64(0)
-            rc = self._lib.mrx_sub_dev(self._h, repl, len(repl), count, _ptr(batch.data), _ptr(off), batch.n,
-                                       _ptr(out_off), _ptr(out), cap, C.byref(total), self._stream_ptr())
+            if off is None:
+                rc = self._lib.mrx_sub_strided_dev(self._h, repl, len(repl), count, _ptr(batch.data), batch.stride,
+                                                   _ptr(batch.lens), batch.length, batch.n, _ptr(out_off), _ptr(out),
+                                                   cap, C.byref(total), self._stream_ptr())
+            else:
+                rc = self._lib.mrx_sub_dev(self._h, repl, len(repl), count, _ptr(batch.data), _ptr(off), batch.n,
+                                           _ptr(out_off), _ptr(out), cap, C.byref(total), self._stream_ptr())
             if rc == MRX_E_CAPACITY:
                 cap = int(total.value)
                 continue

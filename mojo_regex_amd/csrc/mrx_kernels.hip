@@ -527,6 +527,132 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_wstep(DevPlan p, const uint8_
   }
 }
 
+// ---- several walks in one pass (PF_MWALK, DevPlan::off_mw_*; host side: build_multiwalk() in mrx_plan.cpp) ------
+// The stepper above re-scans: a walk that fails at byte q after starting at p sends the lane back to p + 1, and a
+// match that ends before the byte that killed its walk sends it back to the match end.  Here the walks the
+// reference would start one after the other run side by side -- up to four per text, oldest first, the whole list
+// folded into ONE table state (a "configuration": has the oldest walk accepted + the DFA states of the live walks in
+// age order) -- so every byte is looked at once, every lane steps in lockstep and nothing ever moves backwards.
+// Per byte: class lookup, one dependent read of tab[configuration][class], and a few selects that move the walks'
+// START registers as the entry says (a walk that leaves the list lets the younger ones move up, a walk that begins
+// on the byte takes the first free slot); `last` = the position behind the oldest walk's latest accepting state.
+// EMIT (entry bit 0) reports [start of slot 0, last) BEFORE the registers move.  At the end of the text the oldest
+// walk reports if it has accepted (entry bit 10 of the last step).  Same modes and arguments as k_wstep, so the
+// host swaps the kernel and nothing else (slot rows, second walk for overflowing texts, search, count).
+__host__ __device__ inline size_t mwalk_table_bytes(const DevPlan& p) { return (size_t)p.mw_bytes; }
+
+template <int MODE>
+__global__ __launch_bounds__(64 * kWsWaves) void k_mwalk(DevPlan p, const uint8_t* __restrict__ blob, Layout lay,
+                                                         int64_t n, int32_t* __restrict__ counts,
+                                                         const int64_t* __restrict__ prefix,
+                                                         int32_t* __restrict__ spans, int64_t span_cap,
+                                                         int32_t* __restrict__ out_s, int32_t* __restrict__ out_e) {
+  constexpr int CH = 128, kRowPitch = CH + 16, LPR = CH / 16, RPI = 64 / LPR, NL = 64 / RPI;
+  __shared__ __align__(16) uint8_t tiles[kWsWaves][64 * kRowPitch];
+  extern __shared__ __align__(16) uint8_t lds[];
+  {
+    const uint32_t* src = (const uint32_t*)(blob + p.off_mw_cls);   // cls[256] | tab[...], contiguous and 16-byte aligned
+    uint32_t* dst = (uint32_t*)lds;
+    for (int e = threadIdx.x; e < (p.mw_bytes >> 2); e += blockDim.x) dst[e] = src[e];
+  }
+  __syncthreads();
+  const uint8_t* clsT = lds;
+  const uint32_t* tab = (const uint32_t*)(lds + 256);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint8_t* tile = tiles[wave];
+  const int seg = lane % LPR, rsub = lane / LPR;
+  const int64_t nw = (n + 63) >> 6;
+  for (int64_t w = (int64_t)blockIdx.x * kWsWaves + wave; w < nw; w += (int64_t)gridDim.x * kWsWaves) {
+    const int64_t i = (w << 6) + lane;
+    const bool live = i < n;
+    const Text t = live ? lay.text(i) : Text(blob, 0);
+    const uintptr_t addr = t.len > 0 ? (uintptr_t)t.ptr : (uintptr_t)blob;   // empty rows park on the blob
+    const int mis = t.len > 0 ? (int)(addr & 15) : 0;
+    const uintptr_t rb = addr & ~(uintptr_t)15;
+    const int end = mis + t.len;   // frame coordinates: the text is [mis, end)
+    __builtin_amdgcn_wave_barrier();
+    *(uint4*)(tile + lane * kRowPitch + CH) = make_uint4((uint32_t)rb, (uint32_t)((uint64_t)rb >> 32), (uint32_t)end, 0u);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    int max_end = end;
+    for (int off = 32; off > 0; off >>= 1) max_end = max(max_end, __shfl_xor(max_end, off));
+
+    const bool skipped = lay.split > 0 && t.len >= lay.split;   // k_req_wave's text
+    bool fin = !live || t.len == 0 || skipped;
+    int64_t wo = (MODE == STEP_EMIT && live) ? prefix[i] : 0;
+    int slot_cap = kStepSlots;
+    int64_t slot0 = i * kStepSlots;
+    if ((MODE == STEP_EMIT || MODE == STEP_SLOTS) && lay.wide_slots && live) slot0 = lay.slot_row(i, &slot_cap);
+    if (MODE == STEP_EMIT && counts) {   // after STEP_SLOTS: only texts that overflowed their slots
+      if (live && counts[i] <= slot_cap) fin = true;
+      if (__all(fin)) continue;
+    }
+    if (MODE == STEP_SLOTS) wo = 0;
+    uint32_t e = 0;            // the last entry taken: bits 16.. = row of the current configuration
+    int s0 = 0, s1 = 0, s2 = 0, s3 = 0, last = 0, k = 0, rs = -1, re = -1;
+    auto report = [&](int a, int b) {
+      if (MODE == STEP_EMIT) {
+        if (wo < span_cap) { spans[2 * wo] = a; spans[2 * wo + 1] = b; }
+        ++wo;
+      }
+      if (MODE == STEP_SLOTS) {
+        if (wo < slot_cap) *(int2*)(spans + 2 * (slot0 + wo)) = make_int2(a, b);
+        ++wo;
+      }
+      if (MODE == STEP_SEARCH) { rs = a; re = b; fin = true; }
+      ++k;
+    };
+    const uint8_t* myrow = tile + lane * kRowPitch;
+    uint4 v[NL];
+#define MRX_MW_LOAD(CB)                                                                   \
+    do {                                                                                  \
+      _Pragma("unroll") for (int j_ = 0; j_ < NL; ++j_) {                                  \
+        const uint4 rs_ = *(const uint4*)(tile + (RPI * j_ + rsub) * kRowPitch + CH);      \
+        uint32_t fo_ = (uint32_t)(CB) + seg * 16;                                          \
+        if (fo_ >= rs_.z) fo_ = 0;                                                         \
+        v[j_] = mrx_ldg((const uint4*)((const uint8_t*)(((uint64_t)rs_.y << 32) | rs_.x) + fo_)); \
+      }                                                                                    \
+    } while (0)
+    if (max_end > 0) MRX_MW_LOAD(0);
+    for (int wb = 0; wb < max_end; wb += CH) {
+#pragma unroll
+      for (int j = 0; j < NL; ++j) *(uint4*)(tile + (RPI * j + rsub) * kRowPitch + seg * 16) = v[j];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (wb + CH < max_end) MRX_MW_LOAD(wb + CH);   // next window, in flight while this one is stepped
+#pragma unroll 8
+      for (int it = 0; it < CH; ++it) {
+        const int f = wb + it;                        // frame position, the same for every lane
+        const bool act = !fin && f >= mis && f < end;
+        const uint32_t cl = clsT[myrow[it]];
+        const uint32_t en = tab[(e >> 16) + cl];
+        const int pr = f - mis;                       // text position of this byte
+        if (act && (en & 1u)) report(s0, last);      // the oldest walk ended behind its last accepting position
+        if (act) {
+          const uint32_t c0 = (en >> 2) & 7u, c1 = (en >> 5) & 3u, c2 = (en >> 7) & 3u, c3 = (en >> 9) & 1u;
+          const int n0 = c0 == 0u ? s0 : c0 == 1u ? s1 : c0 == 2u ? s2 : c0 == 3u ? s3 : pr;
+          const int n1 = c1 == 0u ? s1 : c1 == 1u ? s2 : c1 == 2u ? s3 : pr;
+          const int n2 = c2 == 0u ? s2 : c2 == 1u ? s3 : pr;
+          const int n3 = c3 == 0u ? s3 : pr;
+          s0 = n0; s1 = n1; s2 = n2; s3 = n3;
+          last = (en & 2u) ? pr + 1 : last;
+          e = en;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (__all(fin || wb + CH >= end)) break;
+    }
+#undef MRX_MW_LOAD
+    if (!fin && ((e >> 10) & 1u)) report(s0, last);   // end of the text: the oldest walk has accepted
+    if (live && !skipped) {
+      if (MODE == STEP_COUNT || MODE == STEP_SLOTS) counts[i] = k;
+      if (MODE == STEP_SEARCH) { out_s[i] = rs; out_e[i] = re; }
+    }
+  }
+}
+
 // ---- bitset NFA, first pass: the union automaton -------------------------------------------------
 // PF_BSTEP plans.  The restart-per-position search of the reference (LazyDFA.match_next / match_all,
 // pikevm.mojo:754-817) walks the bytes of a failing region once per start position.  What it can find
@@ -3528,16 +3654,26 @@ int grid_for(int64_t n, int block) {
 
 // k_wstep for findall / count: plain route or required-byte route (a bool `use_req_route` in scope)
 // (and a DevPlan `p` or handle `h` whose flags say whether the bitset form runs: `wstep_bits`)
+// (and a bool `wstep_mwalk`: the plan's multi-walk form, k_mwalk, takes the plain route's place)
 #define MRX_WSTEP_LAUNCH(MODE, ...)                                                        \
   do {                                                                                     \
-    if (wstep_bits) hipLaunchKernelGGL((k_wstep<MODE, 0, 1>), __VA_ARGS__);                \
+    if (wstep_mwalk) hipLaunchKernelGGL((k_mwalk<MODE>), __VA_ARGS__);                     \
+    else if (wstep_bits) hipLaunchKernelGGL((k_wstep<MODE, 0, 1>), __VA_ARGS__);           \
     else if (wstep_empty) hipLaunchKernelGGL((k_wstep<MODE, 0, 0, 1>), __VA_ARGS__);       \
     else if (use_req_route) hipLaunchKernelGGL((k_wstep<MODE, 1>), __VA_ARGS__);         \
     else hipLaunchKernelGGL((k_wstep<MODE, 0>), __VA_ARGS__);                              \
   } while (0)
 // dynamic LDS of k_wstep for this plan
-size_t wstep_lds(const DevPlan& p) {
+size_t wstep_lds(const DevPlan& p, bool mwalk = false) {
+  if (mwalk) return mwalk_table_bytes(p);
   return (p.flags & PF_BSTEP) ? bstep_table_bytes(p.bs_npos) : wstep_table_bytes(p.nstates);
+}
+// PF_MWALK plans: several walks in one pass (k_mwalk) instead of the stepper's restart-per-position loop.
+// mrx_debug_multiwalk(2) / MRX_NO_MWALK=1: never (A/B runs, and the parity tests compare the two text by text).
+std::atomic<int> g_mwalk_mode{0};
+bool mwalk_on(const DevPlan& p) {
+  static const bool off = getenv("MRX_NO_MWALK") && getenv("MRX_NO_MWALK")[0] == '1';
+  return (p.flags & PF_MWALK) && !off && g_mwalk_mode != 2 && g_force_generic == 0;   // (level 1 = the stepper and nothing newer)
 }
 // Table plans of the stepper's plain route get the same first pass when their state sets fit 32 bits and the
 // per-class follow tables fit LDS next to the text tiles (MRX_NO_UNION_PASS=1: off, for measurement).
@@ -3806,6 +3942,18 @@ int run_match(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d_s, i
       HIP_TRY(scratch_free(d_limit, s));
       g_last_kernel = "k_bstep_search";
     } else
+    if (!wave && !big && mwalk_on(h->hp.dev)) {   // several walks in one pass; the few very long texts keep their kernel
+      hipLaunchKernelGGL((k_mwalk<STEP_SEARCH>), dim3(wstep_grid(n)), dim3(64 * kWsWaves), mwalk_table_bytes(h->hp.dev), s,
+                         h->hp.dev, H_BLOB(h), lay2, n, (int32_t*)nullptr, (const int64_t*)nullptr, (int32_t*)nullptr,
+                         (int64_t)0, d_s, d_e);
+      g_last_kernel = "k_mwalk_search";
+      if (split > 0) {
+        hipLaunchKernelGGL((k_req_wave<STEP_SEARCH, 0>), dim3(reqwave_grid(n)), dim3(64 * kRqWaves),
+                           reqwave_table_bytes(h->hp.dev.nstates), s, h->hp.dev, H_BLOB(h), lay2, n, (int32_t*)nullptr,
+                           (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0, d_s, d_e);
+        g_last_kernel = "k_mwalk_search+k_req_wave_search";
+      }
+    } else
     if (big && !wave) {   // many short texts: the literal restatement, one lane per text
       hipLaunchKernelGGL((k_match<OP, 0>), dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s, h->hp.dev,
                          H_BLOB(h), lay, n, d_s, d_e, d_flag);   // (a stepper plan: no backtracker route)
@@ -3945,7 +4093,9 @@ void launch_stream(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d
     if (pairs) { if constexpr (MODE != ST_FIRST) MRX_LAUNCH(4, 0); }
     else if (table) MRX_LAUNCH(2, 0);
     else if (wide) MRX_LAUNCH(3, 0);
-    else if (MODE != ST_FIRST && p.off_stcol32 >= 0 && code_columns_on()) { if constexpr (MODE != ST_FIRST) MRX_LAUNCH(5, 0); }
+    // (records / search / fused: -16 % VALU instructions, findall step -1 %, search +6 %; the count kernel measured 4 %
+    // slower in this form -- profiles/r03_scan_forms.md -- and keeps the 4-bit columns)
+    else if (MODE != ST_FIRST && MODE != ST_COUNT && p.off_stcol32 >= 0 && code_columns_on()) { if constexpr (MODE != ST_FIRST && MODE != ST_COUNT) MRX_LAUNCH(5, 0); }
     else MRX_LAUNCH(1, 0);
   }
 #undef MRX_LAUNCH
@@ -4344,9 +4494,14 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
   const bool wstep_bits = (p.flags & PF_BSTEP) != 0;   // bitset NFA on the lane-per-text stepper
   // plans with empty matches: count, then emit (nearly every text has more matches than a slot row holds)
   const bool wstep_empty = (p.flags & PF_STEP_EMPTY) != 0 && !match_next_sequence && g_force_generic < 2;
+  // several walks in one pass instead of the restart-per-position loop (plain route; sub's match_next sequence is
+  // the same list of matches, but a memchr-prefiltered match_next is not the plain search)
+  const bool wstep_mwalk = mwalk_on(p) && !use_req_route && !wstep_bits && !wstep_empty &&
+                           !(match_next_sequence && (p.flags & PF_PREFILTER));
   bool step_ok = g_force_generic < 2 &&
-                 (match_next_sequence ? ((p.flags & PF_STEP_SEARCH) && !(p.flags & PF_PREFILTER))
-                                      : (p.flags & (PF_STEPPABLE | PF_STEP_REQ | PF_STEP_EMPTY)) != 0);
+                 (wstep_mwalk ||
+                  (match_next_sequence ? ((p.flags & PF_STEP_SEARCH) && !(p.flags & PF_PREFILTER))
+                                       : (p.flags & (PF_STEPPABLE | PF_STEP_REQ | PF_STEP_EMPTY)) != 0));
   bool fused = false;      // streaming path: scan, CSR offsets and spans in one launch (ST_FUSED)
   bool split_done = false; // streaming path: two halves on two streams (findall_split)
   bool dyn = false;        // streaming path: ragged CSR batch on k_stream_dyn (256-text tasks)
@@ -4498,14 +4653,14 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
                                    (p.flags & PF_STEP_BIG) != 0))
           return rc;
       lay2.split = step_split;
-      if (step_ok && !wstep_empty && (wstep_bits || (!req_wave && step_split == 0 && !use_req_route && union_pass_for_table_plan(p, false)))) {
+      if (step_ok && !wstep_empty && !wstep_mwalk && (wstep_bits || (!req_wave && step_split == 0 && !use_req_route && union_pass_for_table_plan(p, false)))) {
         // union automaton first: texts in which no walk from any start reaches MATCH are not walked at all
         // (mode 0: a wavefront stops as soon as each of its texts has shown one match end, so on texts full
         // of matches the pass costs next to nothing; cutting tails -- mode 1 -- would scan everything)
         if (int rc = bscan_limits(h, lay, n, 0, s, &lay2, &d_blimit)) return rc;
       }
       // big tables: only the wavefront kernel has their form; many short texts stay on the literal restatement
-      if ((p.flags & PF_STEP_BIG) && !req_wave) step_ok = false;
+      if ((p.flags & PF_STEP_BIG) && !req_wave && !wstep_mwalk) step_ok = false;
       ScanTimer tm(s);
       if (step_ok && span_cap > 0 && !wstep_empty) {
         if (req_wave) {
@@ -4532,7 +4687,7 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
           MRX_REQWAVE_LAUNCH(STEP_SLOTS, h, lay2, n, d_counts, (const int64_t*)nullptr, d_slots, (int64_t)0, s);
         else
         {
-        MRX_WSTEP_LAUNCH(STEP_SLOTS, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_lds(h->hp.dev), s, p,
+        MRX_WSTEP_LAUNCH(STEP_SLOTS, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_lds(h->hp.dev, wstep_mwalk), s, p,
                            H_BLOB(h), lay2, n, d_counts, (const int64_t*)nullptr, d_slots, (int64_t)0,
                            (int32_t*)nullptr, (int32_t*)nullptr);
         if (step_split > 0)
@@ -4541,7 +4696,7 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
       } else if (step_ok && req_wave)
         MRX_REQWAVE_LAUNCH(STEP_COUNT, h, lay, n, d_counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0, s);
       else if (step_ok) {
-        MRX_WSTEP_LAUNCH(STEP_COUNT, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_lds(h->hp.dev), s, p,
+        MRX_WSTEP_LAUNCH(STEP_COUNT, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_lds(h->hp.dev, wstep_mwalk), s, p,
                            H_BLOB(h), lay2, n, d_counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0,
                            (int32_t*)nullptr, (int32_t*)nullptr);
         if (step_split > 0)
@@ -4554,7 +4709,7 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
         MRX_BT_DISPATCH(bt_kernel_kind(h, plan_uses_backtracker(h)), MRX_L);
 #undef MRX_L
       }
-      g_last_kernel = req_wave ? "k_req_wave" : step_ok ? (wstep_bits ? "k_bstep_count" : wstep_empty ? "k_estep_count" : step_split > 0 ? "k_step_count+k_req_wave" : "k_step_count")
+      g_last_kernel = req_wave ? "k_req_wave" : step_ok ? (wstep_mwalk ? (step_split > 0 ? "k_mwalk+k_req_wave" : "k_mwalk") : wstep_bits ? "k_bstep_count" : wstep_empty ? "k_estep_count" : step_split > 0 ? "k_step_count+k_req_wave" : "k_step_count")
                                                         : "k_findall_count";
       HIP_TRY(hipGetLastError());
       tm.stop();
@@ -4612,7 +4767,7 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
       // spans were written by k_decode above
     } else {
       if (step_ok && wstep_empty) {   // second walk, every text: spans straight to their CSR place
-        MRX_WSTEP_LAUNCH(STEP_EMIT, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_lds(h->hp.dev), s, p, H_BLOB(h),
+        MRX_WSTEP_LAUNCH(STEP_EMIT, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_lds(h->hp.dev, wstep_mwalk), s, p, H_BLOB(h),
                          lay2, n, (int32_t*)nullptr, d_prefix, d_spans, span_cap, (int32_t*)nullptr, (int32_t*)nullptr);
       } else if (step_ok) {
         if (lay2.wide_slots)
@@ -4625,7 +4780,7 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
         if (req_wave)
           MRX_REQWAVE_LAUNCH(STEP_EMIT, h, lay2, n, d_counts, d_prefix, d_spans, span_cap, s);
         else {
-        MRX_WSTEP_LAUNCH(STEP_EMIT, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_lds(h->hp.dev), s, p, H_BLOB(h),
+        MRX_WSTEP_LAUNCH(STEP_EMIT, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_lds(h->hp.dev, wstep_mwalk), s, p, H_BLOB(h),
                            lay2, n, d_counts, d_prefix, d_spans, span_cap, (int32_t*)nullptr,
                            (int32_t*)nullptr);
         if (step_split > 0) MRX_REQWAVE_LAUNCH(STEP_EMIT, h, lay2, n, d_counts, d_prefix, d_spans, span_cap, s);
@@ -5282,6 +5437,7 @@ static int run_count_any(const mrx_handle* h, const Layout& lay, int64_t n, int3
     const bool use_req_route = (h->hp.dev.flags & PF_STEP_REQ) != 0;
     const bool wstep_bits = (h->hp.dev.flags & PF_BSTEP) != 0;
     const bool wstep_empty = (h->hp.dev.flags & PF_STEP_EMPTY) != 0 && g_force_generic < 2;
+    const bool wstep_mwalk = mwalk_on(h->hp.dev) && !use_req_route && !wstep_bits && !wstep_empty;
     bool req_wave = false;
     int split = 0;
     if (g_force_generic < 2 && !wstep_bits && !t_in_pieces && (h->hp.dev.flags & (PF_STEPPABLE | PF_STEP_REQ)) &&
@@ -5316,17 +5472,17 @@ static int run_count_any(const mrx_handle* h, const Layout& lay, int64_t n, int3
     Layout lay2 = lay;
     lay2.split = split;
     int32_t* d_blimit = nullptr;
-    if (g_force_generic < 2 && (wstep_bits || (!req_wave && split == 0 && !use_req_route && union_pass_for_table_plan(h->hp.dev, false))))
+    if (g_force_generic < 2 && !wstep_mwalk && (wstep_bits || (!req_wave && split == 0 && !use_req_route && union_pass_for_table_plan(h->hp.dev, false))))
       if (int rc = bscan_limits(h, lay, n, 0, s, &lay2, &d_blimit)) return rc;   // union automaton first
-    const bool big_lane = (h->hp.dev.flags & PF_STEP_BIG) && !req_wave;   // -> literal restatement
+    const bool big_lane = (h->hp.dev.flags & PF_STEP_BIG) && !req_wave && !wstep_mwalk;   // -> literal restatement
     if (req_wave) {
       MRX_REQWAVE_LAUNCH(STEP_COUNT, h, lay, n, counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0, s);
       g_last_kernel = "k_req_wave";
-    } else if (g_force_generic < 2 && !big_lane && (h->hp.dev.flags & (PF_STEPPABLE | PF_STEP_REQ | PF_STEP_EMPTY))) {
-      MRX_WSTEP_LAUNCH(STEP_COUNT, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_lds(h->hp.dev), s, h->hp.dev,
+    } else if (g_force_generic < 2 && !big_lane && ((h->hp.dev.flags & (PF_STEPPABLE | PF_STEP_REQ | PF_STEP_EMPTY)) || wstep_mwalk)) {
+      MRX_WSTEP_LAUNCH(STEP_COUNT, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_lds(h->hp.dev, wstep_mwalk), s, h->hp.dev,
                          H_BLOB(h), lay2, n, counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0,
                          (int32_t*)nullptr, (int32_t*)nullptr);
-      g_last_kernel = wstep_bits ? "k_bstep_count" : wstep_empty ? "k_estep_count" : "k_step_count";
+      g_last_kernel = wstep_mwalk ? "k_mwalk" : wstep_bits ? "k_bstep_count" : wstep_empty ? "k_estep_count" : "k_step_count";
       if (split > 0) {
         MRX_REQWAVE_LAUNCH(STEP_COUNT, h, lay2, n, counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0, s);
         g_last_kernel = "k_step_count+k_req_wave";
@@ -5358,9 +5514,42 @@ int mrx_count_strided_dev(const mrx_handle* h, const uint8_t* d, int64_t stride,
   return run_count_any(h, Layout{d, nullptr, stride, lens, len}, n, counts, st);
 }
 
+}  // extern "C"
+namespace {
+__global__ __launch_bounds__(kBlock) void k_pitch_offsets(int64_t n, int64_t stride, int64_t* __restrict__ off) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += (int64_t)gridDim.x * blockDim.x) off[i] = i * stride;
+}
+}  // namespace
+static int sub_any(const mrx_handle* h, const char* repl, size_t repl_len, int64_t count, const Layout& lay_in,
+                   int64_t n, int64_t* out_off, uint8_t* out, int64_t out_cap, int64_t* total_bytes, void* st);
+extern "C" {
 int mrx_sub_dev(const mrx_handle* h, const char* repl, size_t repl_len, int64_t count,
                 const uint8_t* d, const int64_t* off, int64_t n, int64_t* out_off, uint8_t* out,
                 int64_t out_cap, int64_t* total_bytes, void* st) {
+  return sub_any(h, repl, repl_len, count, Layout{d, off, 0, nullptr, 0}, n, out_off, out, out_cap, total_bytes, st);
+}
+// Texts at a fixed pitch.  Rows without padding (len == stride, no per-text lengths) are a CSR batch whose offsets
+// are i * stride: they are written once on the device and the call takes every fast path of mrx_sub_dev; padded
+// rows run on the lane-per-text kernels (the spans route assembles its output from CSR offsets).
+int mrx_sub_strided_dev(const mrx_handle* h, const char* repl, size_t repl_len, int64_t count,
+                        const uint8_t* d, int64_t stride, const int32_t* d_lens, int32_t len, int64_t n,
+                        int64_t* out_off, uint8_t* out, int64_t out_cap, int64_t* total_bytes, void* st) {
+  if (stride <= 0 || len < 0 || len > stride) return fail(MRX_E_ARGUMENT, "bad pitch / length");
+  if (!d_lens && (int64_t)len == stride && n > 0) {
+    ScratchScope scope_((hipStream_t)st);
+    int64_t* d_off = nullptr;
+    HIP_TRY(scratch_alloc((void**)&d_off, sizeof(int64_t) * (n + 1), (hipStream_t)st));
+    hipLaunchKernelGGL(k_pitch_offsets, dim3(grid_for(n + 1, kBlock)), dim3(kBlock), 0, (hipStream_t)st, n, stride, d_off);
+    HIP_TRY(hipGetLastError());
+    return sub_any(h, repl, repl_len, count, Layout{d, d_off, 0, nullptr, 0}, n, out_off, out, out_cap, total_bytes, st);
+  }
+  return sub_any(h, repl, repl_len, count, Layout{d, nullptr, stride, d_lens, len}, n, out_off, out, out_cap, total_bytes, st);
+}
+}  // extern "C"
+static int sub_any(const mrx_handle* h, const char* repl, size_t repl_len, int64_t count, const Layout& lay_in,
+                   int64_t n, int64_t* out_off, uint8_t* out, int64_t out_cap, int64_t* total_bytes, void* st) {
+  const uint8_t* d = lay_in.data;
+  const int64_t* off = lay_in.offsets;
   ScratchScope scratch_scope_((hipStream_t)st);
   if (!h) return fail(MRX_E_ARGUMENT, "null handle");
   if (n < 0) return fail(MRX_E_ARGUMENT, "negative batch size");
@@ -5429,7 +5618,7 @@ int mrx_sub_dev(const mrx_handle* h, const char* repl, size_t repl_len, int64_t 
   if (!r.empty()) HIP_TRY(hipMemcpyAsync(d_repl, r.data(), r.size(), hipMemcpyHostToDevice, s));
   if (!tpl.empty())
     HIP_TRY(hipMemcpyAsync(d_tpl, tpl.data(), sizeof(ReplSeg) * tpl.size(), hipMemcpyHostToDevice, s));
-  Layout lay{d, off, 0, nullptr, 0};
+  Layout lay = lay_in;
   const bool sub_bt = plan_uses_backtracker(h) || general_groups;
   if ((h->hp.dev.flags & PF_BT_SEARCH) || general_groups) {
     const Layout plain = lay;
@@ -5469,6 +5658,7 @@ int mrx_sub_dev(const mrx_handle* h, const char* repl, size_t repl_len, int64_t 
   return rc;
 }
 
+extern "C" {
 // ---- host-buffer wrappers -----------------------------------------------------------
 
 int mrx_match_first_batch(const mrx_handle* h, const uint8_t* data, const int64_t* off, int64_t n,
@@ -5558,6 +5748,7 @@ void mrx_debug_dynamic_texts(int mode) { g_dyn_mode = mode < 0 ? 0 : mode > 2 ? 
 void mrx_debug_split_findall(int on) { g_split_findall = on ? 1 : 0; }
 void mrx_debug_subs_group(int g) { g_subs_group = (g == 0 || g == 16 || g == 32 || g == 64 || g == 256) ? g : -1; }
 void mrx_debug_litscan_pieces(int mode) { g_litscan_pieces = (mode == 0 || mode == 1) ? mode : 2; }
+void mrx_debug_multiwalk(int mode) { g_mwalk_mode = mode == 2 ? 2 : 0; }
 void mrx_release_scratch(void) { scratch_release_all(); }
 size_t mrx_debug_scratch_bytes(void) { return scratch_bytes_reserved(); }
 

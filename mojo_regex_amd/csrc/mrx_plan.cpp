@@ -191,6 +191,117 @@ std::vector<std::array<uint16_t, 256>> stream_entries(const SearchAutomaton& s,
   return E;
 }
 
+// ---- several walks in one pass ("multi-walk" automaton, DevPlan::off_mw_*) ---------------------------------------
+// What check_streamable() rejects still has a one-pass form when the walks that the reference starts one after the
+// other (findall's `pos + 1` / `pos = end` loop, dfa.mojo:2096-2130, pikevm.mojo:755-817) are run SIDE BY SIDE: the
+// list of walks begun at candidate bytes since the last reported match, oldest first.  Per byte every walk takes
+// its table step; a dead walk leaves the list; a walk begins on the byte if it may (first-byte filter) -- unless a
+// live walk is already in that state (same future, the older one wins: leftmost); two walks in one state merge the
+// same way.  When the OLDEST walk accepts, every younger one began inside its match and is dropped (the reference
+// resumes at the match end); when the oldest walk dies after having accepted the match [its start, its last
+// accepting position) is reported and the next-oldest walk -- begun at or behind that position, by construction --
+// takes over; when it dies without having accepted, likewise without a report (the reference's `pos + 1`).
+// Not covered, and left to the stepper: a younger walk that accepts while an older one is still undecided (its
+// match would have to be remembered until the older walk is settled), more than four walks at a time, tables
+// beyond the LDS budget.
+struct MultiWalk {
+  std::array<uint8_t, 256> cls{};
+  int ncls = 0, cshift = 0, ncfg = 0;
+  std::vector<uint32_t> tab;   // [ncfg][1 << cshift]
+};
+
+bool build_multiwalk(const SearchAutomaton& s, MultiWalk& mw, std::string& why) {
+  constexpr int K = 4;
+  if (s.acc[0]) { why = "start state accepts (empty matches)"; return false; }
+  // byte classes: identical columns over all states and the same "may start a walk"
+  std::vector<int> rep;
+  {
+    std::map<std::vector<int>, int> seen;
+    for (int c = 0; c < 256; ++c) {
+      std::vector<int> col(s.n + 1);
+      for (int q = 0; q < s.n; ++q) col[q] = s.next[q][c];
+      col[s.n] = s.allowed[c];
+      auto it = seen.find(col);
+      if (it == seen.end()) { it = seen.emplace(col, (int)rep.size()).first; rep.push_back(c); }
+      mw.cls[c] = (uint8_t)it->second;
+    }
+  }
+  mw.ncls = (int)rep.size();
+  mw.cshift = 0;
+  while ((1 << mw.cshift) < mw.ncls) ++mw.cshift;
+  const int ncp = 1 << mw.cshift;
+  using Key = std::pair<int, std::vector<int>>;   // (oldest has accepted, states oldest first)
+  std::map<Key, int> ids;
+  std::vector<Key> cfgs;
+  auto id_of = [&](const Key& k) {
+    auto it = ids.find(k);
+    if (it == ids.end()) { it = ids.emplace(k, (int)cfgs.size()).first; cfgs.push_back(k); }
+    return it->second;
+  };
+  id_of({0, {}});
+  std::vector<std::array<uint32_t, 64>> rows;   // per config, per class (ncls <= 64 checked below)
+  if (mw.ncls > 64) { why = "multi-walk: more than 64 byte classes"; return false; }
+  for (size_t ci = 0; ci < cfgs.size(); ++ci) {
+    if ((int64_t)cfgs.size() * ncp > 8192) { why = "multi-walk: configuration table beyond the LDS budget"; return false; }
+    const Key cur = cfgs[ci];   // (copy: cfgs grows)
+    std::array<uint32_t, 64> row{};
+    for (int k = 0; k < mw.ncls; ++k) {
+      const int c = rep[k];
+      const int n_old = (int)cur.second.size();
+      // advance; provenance = old slot index, or -1 for the walk that begins on this byte
+      std::vector<std::pair<int, int>> lst;   // (state, provenance)
+      bool emit = false;
+      int A = cur.first;
+      for (int i = 0; i < n_old; ++i) {
+        const int t = s.next[cur.second[i]][c];
+        if (t < 0) {
+          if (i == 0) { emit = A != 0; A = 0; }
+          continue;
+        }
+        if (t == 0) { why = "transition back into the start state"; return false; }
+        lst.push_back({t, i});
+      }
+      if (n_old > 0 && (lst.empty() || lst[0].second != 0)) A = 0;   // the walk the flag belonged to is gone
+      const int b = s.allowed[c] ? s.next[0][c] : -1;
+      if (b == 0) { why = "transition back into the start state"; return false; }
+      if (b > 0) lst.push_back({b, -1});
+      // merge: the older walk in a state wins
+      std::vector<std::pair<int, int>> m;
+      for (const auto& x : lst) {
+        bool dup = false;
+        for (const auto& y : m) dup = dup || y.first == x.first;
+        if (!dup) m.push_back(x);
+      }
+      bool acc_now = false;
+      if (!m.empty() && s.acc[m[0].first]) { acc_now = true; A = 1; m.resize(1); }   // younger walks lie inside the match
+      for (size_t j = 1; j < m.size(); ++j)
+        if (s.acc[m[j].first]) { why = "a later start accepts while the earlier walk is still undecided"; return false; }
+      if ((int)m.size() > K) { why = "multi-walk: more than four walks at a time"; return false; }
+      Key nk{m.empty() ? 0 : A, {}};
+      for (const auto& x : m) nk.second.push_back(x.first);
+      const int nid = id_of(nk);
+      uint32_t e = ((uint32_t)nid << mw.cshift) << 16;
+      if (emit) e |= 1u;
+      if (acc_now) e |= 2u;
+      if (nk.first) e |= 1u << 10;
+      static const int shift[4] = {2, 5, 7, 9};
+      for (int j = 0; j < (int)m.size(); ++j) {
+        const int code = m[j].second < 0 ? K - j : m[j].second - j;   // provenance >= j: walks only ever leave the list
+        e |= (uint32_t)code << shift[j];
+      }
+      if ((((uint64_t)nid << mw.cshift) >> 16) != 0) { why = "multi-walk: configuration table beyond the LDS budget"; return false; }
+      row[k] = e;
+    }
+    rows.push_back(row);
+  }
+  mw.ncfg = (int)cfgs.size();
+  if ((int64_t)mw.ncfg * ncp > 8192) { why = "multi-walk: configuration table beyond the LDS budget"; return false; }
+  mw.tab.assign((size_t)mw.ncfg * ncp, 0);
+  for (int ci = 0; ci < mw.ncfg; ++ci)
+    for (int k = 0; k < mw.ncls; ++k) mw.tab[(size_t)ci * ncp + k] = rows[ci][k];
+  return true;
+}
+
 void put(std::vector<uint8_t>& blob, const void* p, size_t n) {
   const uint8_t* b = (const uint8_t*)p;
   blob.insert(blob.end(), b, b + n);
@@ -591,6 +702,8 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
   d.off_stcol = -1;
   d.off_stcol32 = -1;
   d.st_acc32 = 0;
+  d.off_mw_cls = d.off_mw_tab = -1;
+  d.mw_ncfg = d.mw_cshift = d.mw_bytes = 0;
   d.off_st_sync = -1;
   d.off_stg_pair = -1;
   d.st_nsync = 0;
@@ -843,6 +956,25 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
       if (!(d.flags & PF_STREAMABLE)) d.st_fixed_len = 0;
     } else if (!why.empty()) {
       hp.streamable_why_not = why;
+      // several walks side by side (k_mwalk) where one walk does not do; plain route only (no required byte)
+      if (d.required_byte < 0 && !(d.flags & (PF_PURE_LITERAL | PF_EXACT_LITERAL | PF_SCAN_ELIGIBLE))) {
+        MultiWalk mw;
+        std::string mwhy;
+        if (build_multiwalk(sa, mw, mwhy)) {
+          align(hp.blob, 16);
+          d.off_mw_cls = (int)hp.blob.size();
+          put(hp.blob, mw.cls.data(), 256);
+          d.off_mw_tab = (int)hp.blob.size();
+          put(hp.blob, mw.tab.data(), mw.tab.size() * 4);
+          d.mw_ncfg = mw.ncfg;
+          d.mw_cshift = mw.cshift;
+          d.mw_bytes = 256 + (int)mw.tab.size() * 4;
+          d.flags |= PF_MWALK;
+          align(hp.blob, 16);
+        } else {
+          hp.mwalk_why_not = mwhy;
+        }
+      }
     } else {
       // number the states actually reachable
       std::vector<int> remap(sa.n, -1);
@@ -1147,6 +1279,8 @@ std::string describe_plan(const HostPlan& hp) {
     << " st_nstates=" << d.st_nstates << " st_kind=" << d.st_kind
     << (((d.flags & PF_STREAMABLE) && !(d.flags & PF_STREAM_SEARCH)) ? " findall_only=1" : "")
     << " sync_bytes=" << d.st_nsync << " reset_byte=" << d.st_reset_byte << " code_columns=" << (d.off_stcol32 >= 0 ? 1 : 0)
+    << " multiwalk=" << ((d.flags & PF_MWALK) ? "yes" : hp.mwalk_why_not.empty() ? "no" : "no: " + hp.mwalk_why_not)
+    << " mw_configs=" << d.mw_ncfg
     << (d.off_stg_pair >= 0 ? " pair_table=1" : "") << "\n";
   o << "device.steppable=" << ((d.flags & PF_STEPPABLE) ? "yes" : (d.flags & PF_STEP_REQ) ? "required-byte route" : "no")
     << " step_search=" << ((d.flags & PF_STEP_SEARCH) ? 1 : 0) << ((d.flags & PF_STEP_BIG) ? " big_table=1" : "")

@@ -47,6 +47,10 @@ enum PlanFlags : uint32_t {
   PF_STEP_EMPTY = 1u << 19,     // findall / count of a table plan whose start state accepts and that has no
                                 // first-byte matcher (every position yields a match, possibly empty): the
                                 // windowed stepper's plain route in its EMPTY form (k_wstep<., 0, 0, 1>)
+  PF_MWALK = 1u << 20,          // findall / count / search of a plain-route table plan in ONE left-to-right pass over
+                                // several simultaneous walks (DevPlan::off_mw_*; k_mwalk): what the single-walk proof
+                                // of the streaming kernel rejects ("accepting state continues into a non-accepting
+                                // one", "a later start survives ...") without the stepper's re-scans
   PF_STREAM_SEARCH = 1u << 11   // search / sub / captures may use the streaming kernel too (findall and
                                 // count may whenever PF_STREAMABLE is set): not with a memchr prefilter,
                                 // which only match_next consults (matcher.mojo:784-796)
@@ -90,6 +94,15 @@ struct DevPlan {
   // per dependent lookup: (row offset of the state after both bytes) << 4 | flags of byte 1 << 2 | flags
   // of byte 0, indexed by row offset + (class of byte 0 << st_cshift | class of byte 1); -1: none
   int32_t off_stg_pair;
+  // multi-walk automaton (PF_MWALK; mw_ncfg == 0: none).  The restart-per-position search as ONE pass: the walks
+  // begun at every candidate byte since the last match run side by side, oldest first.  A configuration is
+  // (the oldest walk has accepted, the DFA states of the live walks in age order); cls[256] u8 gives the byte's
+  // class, tab[config][1 << mw_cshift] u32 the step: bits 16.. = row offset of the next configuration, bit 0 =
+  // EMIT (the oldest walk ended behind its last accepting position: the match is [start of slot 0, that position)),
+  // bit 1 = the oldest walk accepts behind this byte, bit 10 = "the oldest walk has accepted" in the new
+  // configuration (the end-of-text rule), bits 2-4 / 5-6 / 7-8 / 9 = where the start register of walk slot
+  // 0 / 1 / 2 / 3 comes from: v <= 3 - j: old slot j + v, v == 4 - j: this byte (a walk begins here).
+  int32_t off_mw_cls, off_mw_tab, mw_ncfg, mw_cshift, mw_bytes;
   // synchronising bytes of the search automaton: sync[b] != 0 when byte b takes EVERY state to the
   // same state with the same start (idle, or a new start at b) -- after such a byte the walk does not
   // depend on what came before, so a long text can be cut there (st_nsync = how many, 0 = no table)
@@ -156,6 +169,7 @@ struct HostPlan {
   DevPlan dev{};
   std::vector<uint8_t> blob;
   std::string streamable_why_not;
+  std::string mwalk_why_not;
   std::string first_stream_why_not;
 };
 

@@ -166,7 +166,7 @@ for seed in range(SEED0, SEED0 + NSEEDS):
                                                                                        b"error: id 42\nhello\tworld", b"https://example.org/a.b", b"foobar foo bar", b"2024-01-15 10:30"]
     if MODE:
         texts += rtexts(rng, 6, 2600, b"abcfoobarhellocatdog0123456789 xyz@.-") + [b"ab" * 700 + b"12 " + b"7" * 1300 + b"-5 x@y.z"]
-    if MODE and NFA:   # the oracle's PikeVM in Python: 50 ms and more per call on a 2600-byte text
+    if MODE and (NFA or (GEN2 and not GROUPS)):   # the oracle's PikeVM / LazyDFA in Python: 50 ms and more per call on a 2600-byte text
         texts = texts[:-7] + rtexts(rng, 3, 900, b"abcfoobarhellocatdog0123456789 xyz@.-") + [b"ab" * 300 + b"12 " + b"7" * 500 + b"-5 x@y.z"]
     for ip, p in enumerate((patterns2 if GEN2 else patterns)(seed, 300)):
         if ip % 10 == 9: print("  seed", seed, "pattern", ip + 1, "checked", checked, flush=True)

@@ -245,6 +245,18 @@ def no_streaming_kernels():
 
 
 @contextlib.contextmanager
+def multiwalk(mode):
+    """2 = stepper plans never take their multi-walk form (k_mwalk: several walks side by side in one pass), 0 = where
+    the plan has one (the default)."""
+    lib = M.load_library()
+    lib.mrx_debug_multiwalk(mode)
+    try:
+        yield
+    finally:
+        lib.mrx_debug_multiwalk(0)
+
+
+@contextlib.contextmanager
 def long_text_kernels(mode):
     """1 = always the long-text treatments (pieces where the plan has synchronising bytes, else a wavefront per text),
     2 = never, 3 = as 1 but stepper plans on the wavefront-per-text kernel (default: by average text length)."""
@@ -1206,6 +1218,48 @@ def test_generated_patterns_stepper_equals_literal_restatement(seed):
     assert nstep > 150, (nstep, nreq)
 
 
+@pytest.mark.parametrize("seed", [41, 42, 43])
+def test_generated_patterns_multiwalk_equals_stepper_and_oracle(seed):
+    """k_mwalk (several walks side by side, one pass) against the windowed stepper's restart-per-position loop on
+    every generated pattern that has the multi-walk table: findall (slot rows and the second walk), count and
+    search, ragged CSR texts that overlap the pattern's own pieces; the oracle on a sample."""
+    _need_gpu()
+    from pattern_gen import patterns, patterns2
+    lib = M.load_library()
+    rng = np.random.default_rng(seed)
+    base = b"abcxyz019 -@.fobrhelcatdg"
+    nmw = 0
+    for p in patterns(seed, 260) + patterns2(seed, 140):
+        pb = p.encode()
+        try:
+            rx = M.compile_regex(pb)
+        except (M.RegexSyntaxError, M.UnsupportedPattern):
+            continue
+        if "multiwalk=yes" not in rx.describe():
+            continue
+        nmw += 1
+        al = base + bytes(c for c in pb if chr(c).isalnum() or c in b" -@.") * 2
+        texts = _random_texts(rng, 90, 70, al) + _random_texts(rng, 12, 700, al) + [b"", pb[:1], bytes(al[:3]) * 40]
+        for j in range(0, len(texts), 5):   # long runs of one byte: walks that overlap themselves
+            k = len(texts[j])
+            texts[j] = (bytes([al[int(rng.integers(0, len(al)))]]) * (k // 2) + texts[j])[:k]
+        with long_text_kernels(2):
+            got = rx.findall_lists(texts)
+            assert lib.mrx_last_kernel_name() == b"k_mwalk", (p, lib.mrx_last_kernel_name())
+            gs, ge = rx.match_next(texts)
+            gc = rx.count(M.DeviceBatch.from_texts(texts)).cpu().numpy()
+            with multiwalk(2):
+                want = rx.findall_lists(texts)
+                assert lib.mrx_last_kernel_name() != b"k_mwalk"
+                ws, we = rx.match_next(texts)
+        assert got == want, (p, [(t, g, w) for t, g, w in zip(texts, got, want) if g != w][:3])
+        assert np.array_equal(gs, ws) and np.array_equal(ge, we), p
+        assert [int(x) for x in gc] == [len(g) for g in got], p
+        for j in range(0, len(texts), 13):
+            assert got[j] == O.findall(pb, texts[j]), (p, texts[j])
+    assert nmw > 60, nmw
+
+
 @pytest.mark.parametrize("pat,repl", [(b"\\w+\\d{2}", b"<W>"), (b"\\d+(\\.\\d+)?", b"N"), (b"(foo|foobar)", b""),
                                       (b"[a-z]+(-[a-z]+)*", b"_"),
                                       # required-byte plans: sub walks match_next, not the findall route
@@ -1470,11 +1524,13 @@ def test_stepper_one_wavefront_per_text(pat):
     assert sum(len(g) for g in got) >= 1
 
 
+@pytest.mark.parametrize("mw", [2, 0])
 @pytest.mark.parametrize("pat", [b"\\d+(\\.\\d+)?", b"\\w+\\d{2}", b"[a-z]+@[a-z]+", b"(foo|foobar)"])
 @pytest.mark.parametrize("n,pitch,var", [(130, 256, True), (70, 50, True), (64, 1024, False), (3, 7, True),
                                          (40, 2304, True), (33, 2051, False)])   # >= 2 KiB: slot rows sized by the text
-def test_stepper_on_fixed_pitch_batches(pat, n, pitch, var):
-    """k_wstep's frame form on fixed-pitch batches (aligned and not, with and without lens)."""
+def test_stepper_on_fixed_pitch_batches(pat, n, pitch, var, mw):
+    """k_wstep's frame form (mw = 2) and k_mwalk's (mw = 0, plans that have the multi-walk table) on fixed-pitch
+    batches (aligned and not, with and without lens)."""
     _need_gpu()
     rng = np.random.default_rng(n * 31 + pitch + zlib.crc32(pat))
     al = np.frombuffer(b"abcfoxr0123456789.-@ " + bytes(c for c in pat if chr(c).isalnum()) * 2, dtype=np.uint8)
@@ -1485,10 +1541,13 @@ def test_stepper_on_fixed_pitch_batches(pat, n, pitch, var):
     d = torch.from_numpy(arr).cuda().reshape(-1)
     batch = M.DeviceBatch.strided(d, pitch, length=pitch, lens=torch.from_numpy(lens).cuda() if var else None)
     lib = M.load_library()
-    with long_text_kernels(2):   # this test is about the lane-per-text stepper
+    has_mw = mw == 0 and "multiwalk=yes" in rx.describe()
+    with long_text_kernels(2), multiwalk(mw):   # this test is about the lane-per-text kernels
         pre, sp, tot = rx._dev_findall(batch)
-        assert lib.mrx_last_kernel_name() == b"k_step_count"
+        assert lib.mrx_last_kernel_name() == (b"k_mwalk" if has_mw else b"k_step_count")
         ss, se = rx.match_next(batch)
+        if has_mw and b"@" not in pat:
+            assert lib.mrx_last_kernel_name() == b"k_mwalk_search"
         cnt = rx.count(batch)
     with generic_kernels():
         gpre, gsp, gtot = rx._dev_findall(batch)
@@ -2138,3 +2197,28 @@ def test_dynamic_text_assignment_equals_static(pat, lens_kind):
         for i in range(0, n, max(1, n // 40)):
             have = [tuple(int(x) for x in r) for r in sp[pre[i]:pre[i + 1]]]
             assert have == O.findall(pat, texts[i]), (pat, lens_kind, n, i)
+
+
+@pytest.mark.parametrize("pat,repl", [(b"[a-z]+\\d+", b"#"), (b"(\\d{3})(\\d{3})(\\d{4})", b"\\1-\\2-\\3"), (b"\\d+(\\.\\d+)?", b"N"),
+                                      (b"(\\w+) (\\w+)", b"\\2 \\1")])
+def test_sub_on_fixed_pitch_batches(pat, repl):
+    """mrx_sub_strided_dev (matcher.mojo:1857-1917 over a fixed-pitch batch): rows without padding take the CSR
+    fast paths through offsets written on the device, padded rows the lane-per-text kernels; both equal mrx_sub_dev
+    on the same texts and the oracle."""
+    _need_gpu()
+    rng = np.random.default_rng(zlib.crc32(pat))
+    al = np.frombuffer(b"abcxy 0123456789.-", dtype=np.uint8)
+    rx = M.compile_regex(pat)
+    for n, pitch, var in ((200, 64, False), (100, 96, True), (70, 50, True), (33, 1024, False)):
+        arr = rng.choice(al, size=(n, pitch)).astype(np.uint8)
+        lens = rng.integers(0, pitch + 1, size=n).astype(np.int32) if var else None
+        texts = [arr[i, : (lens[i] if var else pitch)].tobytes() for i in range(n)]
+        d = torch.from_numpy(arr).cuda().reshape(-1)
+        sb = M.DeviceBatch.strided(d, pitch, length=pitch, lens=torch.from_numpy(lens).cuda() if var else None)
+        for count in (0, 2):
+            so, sd = rx.sub_dev(repl, sb, count)
+            co, cd = rx.sub_dev(repl, M.DeviceBatch.from_texts(texts), count)
+            assert torch.equal(so, co) and torch.equal(sd, cd), (pat, n, pitch, var, count)
+            so_h, sd_h = so.cpu().numpy(), sd.cpu().numpy().tobytes()
+            for i in range(0, n, 7):
+                assert sd_h[so_h[i]:so_h[i + 1]] == O.sub(pat, repl, texts[i], count), (pat, texts[i])
