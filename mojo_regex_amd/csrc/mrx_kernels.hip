@@ -230,7 +230,8 @@ enum { FA_COUNT = 0, FA_EMIT = 1 };
 // STEP_SLOTS: count, and park the first kStepSlots spans of every text in a per-text slot row, so
 // that findall usually needs ONE walk over the batch (k_slots_gather moves the rows to their CSR
 // place); STEP_EMIT then only re-walks the texts that have more matches than slots.
-enum { STEP_COUNT = 0, STEP_EMIT = 1, STEP_SEARCH = 2, STEP_SLOTS = 3 };
+// STEP_ANY (k_mwalk only): counts[i] = 1 when text i holds a match, else 0; a text is left at its first match.
+enum { STEP_COUNT = 0, STEP_EMIT = 1, STEP_SEARCH = 2, STEP_SLOTS = 3, STEP_ANY = 4 };
 constexpr int kStepSlots = 32;
 
 // Windowed stepper for PF_STEPPABLE plans.  Same results as for_each_match() / hybrid_match_next()
@@ -360,10 +361,15 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_wstep(DevPlan p, const uint8_
     int64_t wo = (MODE == STEP_EMIT && live) ? prefix[i] : 0;
     int slot_cap = kStepSlots;           // my slot row (wide rows: sized by the text, Layout::slot_row)
     int64_t slot0 = i * kStepSlots;
-    if ((MODE == STEP_EMIT || MODE == STEP_SLOTS) && lay.wide_slots && live) slot0 = lay.slot_row(i, &slot_cap);
-    if (MODE == STEP_EMIT && counts) {   // after STEP_SLOTS: only texts that overflowed their slots
-      if (live && counts[i] <= slot_cap) fin = true;
-      if (__all(fin)) continue;
+    if ((MODE == STEP_EMIT || MODE == STEP_SLOTS) && lay.wide_slots == 1 && live) slot0 = lay.slot_row(i, &slot_cap);
+    if ((MODE == STEP_EMIT || MODE == STEP_SEARCH) && counts) {
+      // EMIT after STEP_SLOTS: only texts that overflowed their slots.  wide_slots == 2 (the two-pass findall of these
+      // plans; search behind a STEP_ANY pass): counts come from a first pass -- texts without a match are not scanned again
+      if (live && (lay.wide_slots == 2 ? counts[i] == 0 : counts[i] <= slot_cap)) fin = true;
+      if (__all(fin)) {
+        if (MODE == STEP_SEARCH && live && !skipped) { out_s[i] = -1; out_e[i] = -1; }
+        continue;
+      }
     }
     if (MODE == STEP_SLOTS) wo = 0;
     const uint8_t* myrow = tile + lane * kRowPitch;
@@ -541,7 +547,8 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_wstep(DevPlan p, const uint8_
 // host swaps the kernel and nothing else (slot rows, second walk for overflowing texts, search, count).
 __host__ __device__ inline size_t mwalk_table_bytes(const DevPlan& p) { return (size_t)p.mw_bytes; }
 
-template <int MODE>
+// KW: walk slots the plan needs (DevPlan::mw_k <= 2: two start registers and three selects per byte instead of ten)
+template <int MODE, int KW = 4>
 __global__ __launch_bounds__(64 * kWsWaves) void k_mwalk(DevPlan p, const uint8_t* __restrict__ blob, Layout lay,
                                                          int64_t n, int32_t* __restrict__ counts,
                                                          const int64_t* __restrict__ prefix,
@@ -583,10 +590,15 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_mwalk(DevPlan p, const uint8_
     int64_t wo = (MODE == STEP_EMIT && live) ? prefix[i] : 0;
     int slot_cap = kStepSlots;
     int64_t slot0 = i * kStepSlots;
-    if ((MODE == STEP_EMIT || MODE == STEP_SLOTS) && lay.wide_slots && live) slot0 = lay.slot_row(i, &slot_cap);
-    if (MODE == STEP_EMIT && counts) {   // after STEP_SLOTS: only texts that overflowed their slots
-      if (live && counts[i] <= slot_cap) fin = true;
-      if (__all(fin)) continue;
+    if ((MODE == STEP_EMIT || MODE == STEP_SLOTS) && lay.wide_slots == 1 && live) slot0 = lay.slot_row(i, &slot_cap);
+    if ((MODE == STEP_EMIT || MODE == STEP_SEARCH) && counts) {
+      // EMIT after STEP_SLOTS: only texts that overflowed their slots.  wide_slots == 2 (the two-pass findall of these
+      // plans; search behind a STEP_ANY pass): counts come from a first pass -- texts without a match are not scanned again
+      if (live && (lay.wide_slots == 2 ? counts[i] == 0 : counts[i] <= slot_cap)) fin = true;
+      if (__all(fin)) {
+        if (MODE == STEP_SEARCH && live && !skipped) { out_s[i] = -1; out_e[i] = -1; }
+        continue;
+      }
     }
     if (MODE == STEP_SLOTS) wo = 0;
     uint32_t e = 0;            // the last entry taken: bits 16.. = row of the current configuration
@@ -601,6 +613,7 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_mwalk(DevPlan p, const uint8_
         ++wo;
       }
       if (MODE == STEP_SEARCH) { rs = a; re = b; fin = true; }
+      if (MODE == STEP_ANY) fin = true;
       ++k;
     };
     const uint8_t* myrow = tile + lane * kRowPitch;
@@ -629,17 +642,33 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_mwalk(DevPlan p, const uint8_
         const uint32_t cl = clsT[myrow[it]];
         const uint32_t en = tab[(e >> 16) + cl];
         const int pr = f - mis;                       // text position of this byte
-        if (act && (en & 1u)) report(s0, last);      // the oldest walk ended behind its last accepting position
-        if (act) {
-          const uint32_t c0 = (en >> 2) & 7u, c1 = (en >> 5) & 3u, c2 = (en >> 7) & 3u, c3 = (en >> 9) & 1u;
-          const int n0 = c0 == 0u ? s0 : c0 == 1u ? s1 : c0 == 2u ? s2 : c0 == 3u ? s3 : pr;
-          const int n1 = c1 == 0u ? s1 : c1 == 1u ? s2 : c1 == 2u ? s3 : pr;
-          const int n2 = c2 == 0u ? s2 : c2 == 1u ? s3 : pr;
-          const int n3 = c3 == 0u ? s3 : pr;
-          s0 = n0; s1 = n1; s2 = n2; s3 = n3;
-          last = (en & 2u) ? pr + 1 : last;
-          e = en;
+        if (act && (en & 1u)) report(s0, last);      // the oldest walk ended behind its last accepting position (rare branch)
+        // the start registers move as the entry says; plain selects, no branches (code 0 = stays; a lane that is
+        // not stepping takes code 0 everywhere)
+        const uint32_t ea = act ? en : 0u;
+        const uint32_t c0 = (ea >> 2) & 7u, c1 = (ea >> 5) & 3u;
+        int n0 = s0, n1 = s1;
+        n0 = c0 == 1u ? s1 : n0;
+        n0 = c0 == 4u ? pr : n0;
+        n1 = c1 == 3u ? pr : n1;
+        if (KW > 2) {
+          const uint32_t c2 = (ea >> 7) & 3u;
+          int n2 = s2;
+          n0 = c0 == 2u ? s2 : n0;
+          n1 = c1 == 1u ? s2 : n1;
+          n2 = c2 == 2u ? pr : n2;
+          if (KW > 3) {
+            const uint32_t c3 = (ea >> 9) & 1u;
+            n0 = c0 == 3u ? s3 : n0;
+            n1 = c1 == 2u ? s3 : n1;
+            n2 = c2 == 1u ? s3 : n2;
+            s3 = c3 == 1u ? pr : s3;
+          }
+          s2 = n2;
         }
+        s0 = n0; s1 = n1;
+        last = (ea & 2u) ? pr + 1 : last;
+        e = act ? en : e;
       }
       __builtin_amdgcn_wave_barrier();
       if (__all(fin || wb + CH >= end)) break;
@@ -647,7 +676,7 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_mwalk(DevPlan p, const uint8_
 #undef MRX_MW_LOAD
     if (!fin && ((e >> 10) & 1u)) report(s0, last);   // end of the text: the oldest walk has accepted
     if (live && !skipped) {
-      if (MODE == STEP_COUNT || MODE == STEP_SLOTS) counts[i] = k;
+      if (MODE == STEP_COUNT || MODE == STEP_SLOTS || MODE == STEP_ANY) counts[i] = k;
       if (MODE == STEP_SEARCH) { out_s[i] = rs; out_e[i] = re; }
     }
   }
@@ -2409,6 +2438,7 @@ __global__ __launch_bounds__(kBlock) void k_decode(int64_t n, const int32_t* __r
   static_assert(!(DYN && VBASE), "pieces are not handed out dynamically");
   using Slot = typename std::conditional<PACK16, uint32_t, int2>::type;
   __shared__ Slot tile_all[kBlock / 64][TILE];
+  __shared__ int dense_upto[kBlock / 64][64];   // dense path: spans of each of the wavefront's texts expanded so far
   constexpr int kDecodeTile = TILE, kDecodeDirect = 3 * TILE;   // (shadow the file-scope defaults)
   __shared__ int rel_all[DYN ? kBlock / 64 : 1][DYN ? kDynTexts : 1];   // DYN: spans of the task's texts before each text
   constexpr int kTexts = DYN ? kDynTexts : 64;
@@ -2475,9 +2505,17 @@ __global__ __launch_bounds__(kBlock) void k_decode(int64_t n, const int32_t* __r
                                          : offsets ? rec_region_start(offsets[first], w) : first * rec_row);
     const int my_vb = (VBASE && i < n) ? vbase[i] : 0;
     if (total_spans > kDecodeDirect) {
-      // dense matches: the tile passes would re-read the stream total_spans / kDecodeTile
-      // times.  One pass with direct 8-byte stores instead; every text's spans are written
-      // in increasing order, so L2 merges them into full lines.
+      // dense matches: the tile passes would re-read the stream total_spans / kDecodeTile times.  One pass instead.
+      // Round 3: the spans of a batch of records no longer leave as per-lane 8-byte stores scattered over the 64 texts'
+      // regions (config 5: 262 K partly written lines in flight across the device, more than L2 holds, so most of
+      // them reached HBM as read-modify-writes: 1.65 TB/s).  The LDS tile becomes 64 ROW WINDOWS, one per text of the
+      // wavefront, kRowCap spans each: a record's spans go to their text's row at (index within the text - spans of
+      // that text already written) -- the index is in the record (matches of the text before it) -- and after every
+      // batch each row's new spans, which are contiguous in the output, leave with one coalesced store instruction
+      // per row.  A span that falls behind its row's window (one text far denser than a batch's average) is stored
+      // directly, as before.
+      constexpr int kRowCap = (DYN || !PACK16) ? 0 : kDecodeTile / 64;   // (16-bit positions only: 48 spans of 4 bytes)
+      int done_t = 0;                       // lane t: spans of text t written so far
       for (int j = 0; j < total_recs; j += 64 * kDecodeBatch) {
         EvRec rr[kDecodeBatch];
 #pragma unroll
@@ -2489,12 +2527,21 @@ __global__ __launch_bounds__(kBlock) void k_decode(int64_t n, const int32_t* __r
             rr[u].F = q_.x; rr[u].start = (int32_t)q_.y; rr[u].pos_base = (int32_t)q_.z; rr[u].meta = q_.w;
           }
         }
+        if (kRowCap > 0) {
+          dense_upto[threadIdx.x >> 6][lane] = done_t;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
 #pragma unroll
         for (int u = 0; u < kDecodeBatch; ++u) {
           EvRec r = rr[u];
-          const int rel_t = DYN ? rel_lds[r.meta >> kTextShift] : __shfl(my_rel, (int)(r.meta >> 26));
+          const int txt = DYN ? 0 : (int)(r.meta >> 26);
+          const int rel_t = DYN ? rel_lds[r.meta >> kTextShift] : __shfl(my_rel, txt);
           if (VBASE) { const int vb = __shfl(my_vb, (int)(r.meta >> 26)); r.start += vb; r.pos_base += vb; }
-          int64_t dst = pre0 + rel_t + (int)(r.meta & kBefore);
+          const int done_r = kRowCap > 0 ? __shfl(done_t, txt) : 0;   // spans of my record's text already written
+          int within = (int)(r.meta & kBefore);                       // index of my record's first span within its text
+          int64_t dst = pre0 + rel_t + within;
           uint32_t Fw = r.F;
           int pb = REC32 ? (int)((uint32_t)r.pos_base >> 16) - 16 : r.pos_base;
           int rstart = REC32 ? (int)((uint32_t)r.pos_base & 0xFFFFu) : r.start;
@@ -2507,8 +2554,13 @@ __global__ __launch_bounds__(kBlock) void k_decode(int64_t n, const int32_t* __r
               const uint32_t nsb = ns & ((1u << (2 * kk)) - 1u);
               int st = nsb ? pb + ((31 - __builtin_clz(nsb)) >> 1) : rstart;
               if (fixed_len > 0) st = pb + kk - fixed_len;
-              if (dst < span_cap) *(int2*)(spans + 2 * dst) = make_int2(st, pb + kk);
-              ++dst;
+              const int slot = within - done_r;
+              if (kRowCap > 0 && slot < kRowCap) {
+                if constexpr (PACK16) tile[txt * (kRowCap > 0 ? kRowCap : 1) + slot] = ((uint32_t)st << 16) | (uint32_t)(pb + kk);
+              } else if (dst < span_cap) {
+                *(int2*)(spans + 2 * dst) = make_int2(st, pb + kk);
+              }
+              ++dst; ++within;
               em &= em - 1;
             }
             if (REC32) {
@@ -2517,6 +2569,29 @@ __global__ __launch_bounds__(kBlock) void k_decode(int64_t n, const int32_t* __r
               Fw = (uint32_t)r.start;
             }
           }
+          if (kRowCap > 0 && (r.F | (REC32 ? (uint32_t)r.start : 0u)) != 0u) atomicMax(&dense_upto[threadIdx.x >> 6][txt], within);
+        }
+        if constexpr (PACK16 && !DYN) {
+          // every record up to here is expanded: row t holds the spans [done_t, upto_t) of text t (those beyond the
+          // window went out directly); one coalesced store per row
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          const int upto_t = dense_upto[threadIdx.x >> 6][lane];
+          const int64_t row_dst = pre0 + my_rel + done_t;
+          int row_n = upto_t - done_t;
+          if (row_n > kRowCap) row_n = kRowCap;
+          for (int r_ = 0; r_ < 64; ++r_) {
+            const int n_r = __shfl(row_n, r_);
+            if (n_r <= 0) continue;          // (wave uniform)
+            const int64_t d_r = __shfl(row_dst, r_);
+            if (lane < n_r && d_r + lane < span_cap) {
+              const uint32_t v = (uint32_t)tile[r_ * (kRowCap > 0 ? kRowCap : 1) + lane];
+              mrx_stg_span(spans + 2 * (d_r + lane), (int)(v >> 16), (int)(v & 0xFFFFu));
+            }
+          }
+          done_t = upto_t;
+          __builtin_amdgcn_wave_barrier();
         }
       }
       continue;
@@ -3657,7 +3732,9 @@ int grid_for(int64_t n, int block) {
 // (and a bool `wstep_mwalk`: the plan's multi-walk form, k_mwalk, takes the plain route's place)
 #define MRX_WSTEP_LAUNCH(MODE, ...)                                                        \
   do {                                                                                     \
-    if (wstep_mwalk) hipLaunchKernelGGL((k_mwalk<MODE>), __VA_ARGS__);                     \
+    if (wstep_mwalk && wstep_mwalk_k <= 2) hipLaunchKernelGGL((k_mwalk<MODE, 2>), __VA_ARGS__); \
+    else if (wstep_mwalk && wstep_mwalk_k == 3) hipLaunchKernelGGL((k_mwalk<MODE, 3>), __VA_ARGS__); \
+    else if (wstep_mwalk) hipLaunchKernelGGL((k_mwalk<MODE, 4>), __VA_ARGS__);             \
     else if (wstep_bits) hipLaunchKernelGGL((k_wstep<MODE, 0, 1>), __VA_ARGS__);           \
     else if (wstep_empty) hipLaunchKernelGGL((k_wstep<MODE, 0, 0, 1>), __VA_ARGS__);       \
     else if (use_req_route) hipLaunchKernelGGL((k_wstep<MODE, 1>), __VA_ARGS__);         \
@@ -3716,7 +3793,7 @@ int bscan_limits(const mrx_handle* h, const Layout& lay, int64_t n, int mode, hi
 // alternative is the literal restatement (50 GB/s), so the wavefront form takes every batch of texts of
 // half a KiB and more
 int req_wave_pays(const Layout& lay, int64_t n, bool req_route, hipStream_t s, bool* out, int* split = nullptr,
-                  bool big = false) {
+                  bool big = false, bool mwalk = false) {
   *out = false;
   if (split) *split = 0;
   if (g_long_text_mode) { *out = g_long_text_mode == 1 || g_long_text_mode == 3; return MRX_OK; }
@@ -3743,6 +3820,10 @@ int req_wave_pays(const Layout& lay, int64_t n, bool req_route, hipStream_t s, b
   // only pays while one lane per text would leave most of the device idle.
   *out = req_route ? (avg >= 2048 || (avg >= 512 && n <= 32768)) : (avg >= 1024 && n <= 65536);
   if (big && avg >= 512) *out = true;
+  // plans with a multi-walk table: a lane scans its text once whatever the text holds, so from 32 Ki texts on one
+  // lane per text beats the wavefront kernel's per-candidate walks (measured on the reference's list:
+  // range_quantifiers 474 -> 853 GB/s, dual_quantifiers 218 -> 156: profiles/r03_multiwalk.md)
+  if (mwalk && !req_route && !big && n >= 32768) *out = false;
   // a ragged batch with a few texts far longer than the rest: those go to the wavefront kernel, the
   // others keep one lane each
   if (!*out && split && max_len >= 32768 && max_len >= 8 * avg) *split = 16384;
@@ -3930,7 +4011,7 @@ int run_match(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d_s, i
     const bool bits = (h->hp.dev.flags & PF_BSTEP) != 0;     // bitset NFA: the lane-per-text stepper only
     int split = 0;
     if (!bits)
-      if (int rc = req_wave_pays(lay, n, false, s, &wave, big ? nullptr : &split)) return rc;   // (not the `big` rule: search stops at the first match)
+      if (int rc = req_wave_pays(lay, n, false, s, &wave, big ? nullptr : &split, false, mwalk_on(h->hp.dev))) return rc;   // (not the `big` rule: search stops at the first match)
     Layout lay2 = lay;
     lay2.split = split;
     if (bits) {   // union automaton first: texts without any match end are not searched at all
@@ -3943,9 +4024,17 @@ int run_match(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d_s, i
       g_last_kernel = "k_bstep_search";
     } else
     if (!wave && !big && mwalk_on(h->hp.dev)) {   // several walks in one pass; the few very long texts keep their kernel
-      hipLaunchKernelGGL((k_mwalk<STEP_SEARCH>), dim3(wstep_grid(n)), dim3(64 * kWsWaves), mwalk_table_bytes(h->hp.dev), s,
-                         h->hp.dev, H_BLOB(h), lay2, n, (int32_t*)nullptr, (const int64_t*)nullptr, (int32_t*)nullptr,
-                         (int64_t)0, d_s, d_e);
+      // (measured, profiles/r03_multiwalk.md: an "is there a match" pass in front -- STEP_ANY, no start registers,
+      // 3 TB/s -- doubles the rate on texts without a match and halves it where the first match lies deep in
+      // the text; one pass at 0.9-1.3 TB/s whatever the text holds is the default)
+#define MRX_MW_SEARCH(KW)                                                                                                  \
+      hipLaunchKernelGGL((k_mwalk<STEP_SEARCH, KW>), dim3(wstep_grid(n)), dim3(64 * kWsWaves), mwalk_table_bytes(h->hp.dev), s, \
+                         h->hp.dev, H_BLOB(h), lay2, n, (int32_t*)nullptr, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0, \
+                         d_s, d_e)
+      if (h->hp.dev.mw_k <= 2) MRX_MW_SEARCH(2);
+      else if (h->hp.dev.mw_k == 3) MRX_MW_SEARCH(3);
+      else MRX_MW_SEARCH(4);
+#undef MRX_MW_SEARCH
       g_last_kernel = "k_mwalk_search";
       if (split > 0) {
         hipLaunchKernelGGL((k_req_wave<STEP_SEARCH, 0>), dim3(reqwave_grid(n)), dim3(64 * kRqWaves),
@@ -4498,6 +4587,7 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
   // the same list of matches, but a memchr-prefiltered match_next is not the plain search)
   const bool wstep_mwalk = mwalk_on(p) && !use_req_route && !wstep_bits && !wstep_empty &&
                            !(match_next_sequence && (p.flags & PF_PREFILTER));
+  const int wstep_mwalk_k = p.mw_k;
   bool step_ok = g_force_generic < 2 &&
                  (wstep_mwalk ||
                   (match_next_sequence ? ((p.flags & PF_STEP_SEARCH) && !(p.flags & PF_PREFILTER))
@@ -4510,6 +4600,7 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
   bool rec32 = false;      // streaming path: one record per two groups (positions fit 16 bits)
   int64_t max_text = int64_t(1) << 40;   // longest text of the batch, where known
   bool req_wave = false;   // the stepper's route on the wavefront-per-text kernel
+  bool mwalk_two_pass = false;   // multi-walk plan: count pass + emit pass instead of slot rows
   int step_split = 0;      // > 0: lane kernel for texts below this length AND wavefront kernel for the rest
   Layout lay2 = lay;       // lay + that split
   EvRec* d_recs = nullptr;
@@ -4612,7 +4703,7 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
           !(p.flags & PF_STREAMABLE) && span_cap > 0 && (!use_req_route || g_long_text_mode == 1)) {
         Pieces spc;
         if (int rc = pieces_prepare(h, lay, n, s, &spc, -1, -1, /*disjoint=*/true)) return rc;
-        if (spc.on) {
+        if (spc.on && !wstep_mwalk) {   // (a multi-walk plan scans every piece once, dense candidates or not)
           bool dense = true;
           if (int rc = dense_candidates(h, lay, n, s, &dense)) return rc;
           if (!dense)
@@ -4650,7 +4741,7 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
       }
       if (step_ok && !wstep_bits && !wstep_empty && !t_in_pieces)
         if (int rc = req_wave_pays(lay, n, use_req_route, s, &req_wave, (p.flags & PF_STEP_BIG) ? nullptr : &step_split,
-                                   (p.flags & PF_STEP_BIG) != 0))
+                                   (p.flags & PF_STEP_BIG) != 0, wstep_mwalk))
           return rc;
       lay2.split = step_split;
       if (step_ok && !wstep_empty && !wstep_mwalk && (wstep_bits || (!req_wave && step_split == 0 && !use_req_route && union_pass_for_table_plan(p, false)))) {
@@ -4662,7 +4753,10 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
       // big tables: only the wavefront kernel has their form; many short texts stay on the literal restatement
       if ((p.flags & PF_STEP_BIG) && !req_wave && !wstep_mwalk) step_ok = false;
       ScanTimer tm(s);
-      if (step_ok && span_cap > 0 && !wstep_empty) {
+      // multi-walk plans: count, prefix sums, emit -- two one-pass scans whatever the match density (the count pass
+      // keeps no start registers and runs at 3 TB/s; slot rows + a second walk for overflowing texts would be three)
+      mwalk_two_pass = wstep_mwalk && !req_wave && step_split == 0;
+      if (step_ok && span_cap > 0 && !wstep_empty && !mwalk_two_pass) {
         if (req_wave) {
           // long texts: rows of len / 4 + 32 slots (twice the bytes of the batch) -- the second walk
           // is then only for texts with a match every 4 bytes
@@ -4741,7 +4835,7 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
                            d_wbase, d_tsum, d_prefix, d_spans, span_cap, p.st_fixed_len, d_total);
     } else
     if (pack16 && rec32 && max_text >= 768)
-      hipLaunchKernelGGL((k_decode<true, false, true, false, 3072>), dim3(grid_for(n, kBlock) * 2), dim3(kBlock), 0, s, n, d_nrecs, d_recs,
+      hipLaunchKernelGGL((k_decode<true, false, true, false, 3072>), dim3(env_int("MRX_DECODE_GRID", 0) > 0 ? env_int("MRX_DECODE_GRID", 0) : grid_for(n, kBlock) * 2), dim3(kBlock), 0, s, n, d_nrecs, d_recs,
                          rec_row, lay.offsets, d_counts, d_wbase, d_tsum, d_prefix, d_spans, span_cap, p.st_fixed_len,
                          d_total, (const int32_t*)nullptr, (const int64_t*)nullptr, env_int("MRX_DECODE_REVERSE", 0));
     else if (pack16 && rec32)
@@ -4766,7 +4860,12 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
     if (stream_ok) {
       // spans were written by k_decode above
     } else {
-      if (step_ok && wstep_empty) {   // second walk, every text: spans straight to their CSR place
+      if (step_ok && mwalk_two_pass) {   // second scan, texts that hold a match: spans straight to their CSR place
+        Layout lay_e = lay2;
+        lay_e.wide_slots = 2;
+        MRX_WSTEP_LAUNCH(STEP_EMIT, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_lds(h->hp.dev, wstep_mwalk), s, p, H_BLOB(h),
+                         lay_e, n, d_counts, d_prefix, d_spans, span_cap, (int32_t*)nullptr, (int32_t*)nullptr);
+      } else if (step_ok && wstep_empty) {   // second walk, every text: spans straight to their CSR place
         MRX_WSTEP_LAUNCH(STEP_EMIT, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_lds(h->hp.dev, wstep_mwalk), s, p, H_BLOB(h),
                          lay2, n, (int32_t*)nullptr, d_prefix, d_spans, span_cap, (int32_t*)nullptr, (int32_t*)nullptr);
       } else if (step_ok) {
@@ -5438,6 +5537,7 @@ static int run_count_any(const mrx_handle* h, const Layout& lay, int64_t n, int3
     const bool wstep_bits = (h->hp.dev.flags & PF_BSTEP) != 0;
     const bool wstep_empty = (h->hp.dev.flags & PF_STEP_EMPTY) != 0 && g_force_generic < 2;
     const bool wstep_mwalk = mwalk_on(h->hp.dev) && !use_req_route && !wstep_bits && !wstep_empty;
+    const int wstep_mwalk_k = h->hp.dev.mw_k;
     bool req_wave = false;
     int split = 0;
     if (g_force_generic < 2 && !wstep_bits && !t_in_pieces && (h->hp.dev.flags & (PF_STEPPABLE | PF_STEP_REQ)) &&
@@ -5467,7 +5567,7 @@ static int run_count_any(const mrx_handle* h, const Layout& lay, int64_t n, int3
     }
     if (g_force_generic < 2 && !wstep_bits && !t_in_pieces && (h->hp.dev.flags & (PF_STEPPABLE | PF_STEP_REQ)))
       if (int rc = req_wave_pays(lay, n, use_req_route, s, &req_wave, (h->hp.dev.flags & PF_STEP_BIG) ? nullptr : &split,
-                                 (h->hp.dev.flags & PF_STEP_BIG) != 0))
+                                 (h->hp.dev.flags & PF_STEP_BIG) != 0, wstep_mwalk))
         return rc;
     Layout lay2 = lay;
     lay2.split = split;

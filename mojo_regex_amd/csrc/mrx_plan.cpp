@@ -206,7 +206,7 @@ std::vector<std::array<uint16_t, 256>> stream_entries(const SearchAutomaton& s,
 // beyond the LDS budget.
 struct MultiWalk {
   std::array<uint8_t, 256> cls{};
-  int ncls = 0, cshift = 0, ncfg = 0;
+  int ncls = 0, cshift = 0, ncfg = 0, kmax = 0;
   std::vector<uint32_t> tab;   // [ncfg][1 << cshift]
 };
 
@@ -277,6 +277,7 @@ bool build_multiwalk(const SearchAutomaton& s, MultiWalk& mw, std::string& why) 
       for (size_t j = 1; j < m.size(); ++j)
         if (s.acc[m[j].first]) { why = "a later start accepts while the earlier walk is still undecided"; return false; }
       if ((int)m.size() > K) { why = "multi-walk: more than four walks at a time"; return false; }
+      mw.kmax = std::max(mw.kmax, (int)m.size());
       Key nk{m.empty() ? 0 : A, {}};
       for (const auto& x : m) nk.second.push_back(x.first);
       const int nid = id_of(nk);
@@ -703,7 +704,7 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
   d.off_stcol32 = -1;
   d.st_acc32 = 0;
   d.off_mw_cls = d.off_mw_tab = -1;
-  d.mw_ncfg = d.mw_cshift = d.mw_bytes = 0;
+  d.mw_ncfg = d.mw_cshift = d.mw_bytes = d.mw_k = 0;
   d.off_st_sync = -1;
   d.off_stg_pair = -1;
   d.st_nsync = 0;
@@ -968,6 +969,7 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
           put(hp.blob, mw.tab.data(), mw.tab.size() * 4);
           d.mw_ncfg = mw.ncfg;
           d.mw_cshift = mw.cshift;
+          d.mw_k = mw.kmax;
           d.mw_bytes = 256 + (int)mw.tab.size() * 4;
           d.flags |= PF_MWALK;
           align(hp.blob, 16);
@@ -1280,7 +1282,7 @@ std::string describe_plan(const HostPlan& hp) {
     << (((d.flags & PF_STREAMABLE) && !(d.flags & PF_STREAM_SEARCH)) ? " findall_only=1" : "")
     << " sync_bytes=" << d.st_nsync << " reset_byte=" << d.st_reset_byte << " code_columns=" << (d.off_stcol32 >= 0 ? 1 : 0)
     << " multiwalk=" << ((d.flags & PF_MWALK) ? "yes" : hp.mwalk_why_not.empty() ? "no" : "no: " + hp.mwalk_why_not)
-    << " mw_configs=" << d.mw_ncfg
+    << " mw_configs=" << d.mw_ncfg << " mw_walks=" << d.mw_k
     << (d.off_stg_pair >= 0 ? " pair_table=1" : "") << "\n";
   o << "device.steppable=" << ((d.flags & PF_STEPPABLE) ? "yes" : (d.flags & PF_STEP_REQ) ? "required-byte route" : "no")
     << " step_search=" << ((d.flags & PF_STEP_SEARCH) ? 1 : 0) << ((d.flags & PF_STEP_BIG) ? " big_table=1" : "")

@@ -102,7 +102,7 @@ struct DevPlan {
   // bit 1 = the oldest walk accepts behind this byte, bit 10 = "the oldest walk has accepted" in the new
   // configuration (the end-of-text rule), bits 2-4 / 5-6 / 7-8 / 9 = where the start register of walk slot
   // 0 / 1 / 2 / 3 comes from: v <= 3 - j: old slot j + v, v == 4 - j: this byte (a walk begins here).
-  int32_t off_mw_cls, off_mw_tab, mw_ncfg, mw_cshift, mw_bytes;
+  int32_t off_mw_cls, off_mw_tab, mw_ncfg, mw_cshift, mw_bytes, mw_k;   // mw_k: the most walks any configuration holds
   // synchronising bytes of the search automaton: sync[b] != 0 when byte b takes EVERY state to the
   // same state with the same start (idle, or a new start at b) -- after such a byte the walk does not
   // depend on what came before, so a long text can be cut there (st_nsync = how many, 0 = no table)
