@@ -3748,9 +3748,17 @@ size_t wstep_lds(const DevPlan& p, bool mwalk = false) {
 // PF_MWALK plans: several walks in one pass (k_mwalk) instead of the stepper's restart-per-position loop.
 // mrx_debug_multiwalk(2) / MRX_NO_MWALK=1: never (A/B runs, and the parity tests compare the two text by text).
 std::atomic<int> g_mwalk_mode{0};
-bool mwalk_on(const DevPlan& p) {
+bool mwalk_enabled() {
   static const bool off = getenv("MRX_NO_MWALK") && getenv("MRX_NO_MWALK")[0] == '1';
-  return (p.flags & PF_MWALK) && !off && g_mwalk_mode != 2 && g_force_generic == 0;   // (level 1 = the stepper and nothing newer)
+  return !off && g_mwalk_mode != 2 && g_force_generic == 0;   // (level 1 = the stepper and nothing newer)
+}
+bool mwalk_on(const DevPlan& p) { return (p.flags & PF_MWALK) && mwalk_enabled(); }
+// the plan as k_mwalk sees it on the required-byte route: its table in the place of the plain route's
+DevPlan mwalk_req_plan(const DevPlan& p) {
+  DevPlan q = p;
+  q.off_mw_cls = p.off_mwr_cls; q.off_mw_tab = p.off_mwr_cls + 256;
+  q.mw_ncfg = p.mwr_ncfg; q.mw_cshift = p.mwr_cshift; q.mw_bytes = p.mwr_bytes; q.mw_k = p.mwr_k;
+  return q;
 }
 // Table plans of the stepper's plain route get the same first pass when their state sets fit 32 bits and the
 // per-class follow tables fit LDS next to the text tiles (MRX_NO_UNION_PASS=1: off, for measurement).
@@ -3823,7 +3831,7 @@ int req_wave_pays(const Layout& lay, int64_t n, bool req_route, hipStream_t s, b
   // plans with a multi-walk table: a lane scans its text once whatever the text holds, so from 32 Ki texts on one
   // lane per text beats the wavefront kernel's per-candidate walks (measured on the reference's list:
   // range_quantifiers 474 -> 853 GB/s, dual_quantifiers 218 -> 156: profiles/r03_multiwalk.md)
-  if (mwalk && !req_route && !big && n >= 32768) *out = false;
+  if (mwalk && !big && n >= 32768) *out = false;
   // a ragged batch with a few texts far longer than the rest: those go to the wavefront kernel, the
   // others keep one lane each
   if (!*out && split && max_len >= 32768 && max_len >= 8 * avg) *split = 16384;
@@ -4585,9 +4593,11 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
   const bool wstep_empty = (p.flags & PF_STEP_EMPTY) != 0 && !match_next_sequence && g_force_generic < 2;
   // several walks in one pass instead of the restart-per-position loop (plain route; sub's match_next sequence is
   // the same list of matches, but a memchr-prefiltered match_next is not the plain search)
-  const bool wstep_mwalk = mwalk_on(p) && !use_req_route && !wstep_bits && !wstep_empty &&
+  const bool mwalk_req = use_req_route && (p.flags & PF_MWALK_REQ) && mwalk_enabled();
+  const bool wstep_mwalk = (mwalk_req || (mwalk_on(p) && !use_req_route)) && !wstep_bits && !wstep_empty &&
                            !(match_next_sequence && (p.flags & PF_PREFILTER));
-  const int wstep_mwalk_k = p.mw_k;
+  const DevPlan pk = mwalk_req ? mwalk_req_plan(p) : p;   // what the lane kernels are launched with
+  const int wstep_mwalk_k = pk.mw_k;
   bool step_ok = g_force_generic < 2 &&
                  (wstep_mwalk ||
                   (match_next_sequence ? ((p.flags & PF_STEP_SEARCH) && !(p.flags & PF_PREFILTER))
@@ -4781,7 +4791,7 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
           MRX_REQWAVE_LAUNCH(STEP_SLOTS, h, lay2, n, d_counts, (const int64_t*)nullptr, d_slots, (int64_t)0, s);
         else
         {
-        MRX_WSTEP_LAUNCH(STEP_SLOTS, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_lds(h->hp.dev, wstep_mwalk), s, p,
+        MRX_WSTEP_LAUNCH(STEP_SLOTS, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_lds(pk, wstep_mwalk), s, pk,
                            H_BLOB(h), lay2, n, d_counts, (const int64_t*)nullptr, d_slots, (int64_t)0,
                            (int32_t*)nullptr, (int32_t*)nullptr);
         if (step_split > 0)
@@ -4790,7 +4800,7 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
       } else if (step_ok && req_wave)
         MRX_REQWAVE_LAUNCH(STEP_COUNT, h, lay, n, d_counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0, s);
       else if (step_ok) {
-        MRX_WSTEP_LAUNCH(STEP_COUNT, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_lds(h->hp.dev, wstep_mwalk), s, p,
+        MRX_WSTEP_LAUNCH(STEP_COUNT, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_lds(pk, wstep_mwalk), s, pk,
                            H_BLOB(h), lay2, n, d_counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0,
                            (int32_t*)nullptr, (int32_t*)nullptr);
         if (step_split > 0)
@@ -4863,10 +4873,10 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
       if (step_ok && mwalk_two_pass) {   // second scan, texts that hold a match: spans straight to their CSR place
         Layout lay_e = lay2;
         lay_e.wide_slots = 2;
-        MRX_WSTEP_LAUNCH(STEP_EMIT, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_lds(h->hp.dev, wstep_mwalk), s, p, H_BLOB(h),
+        MRX_WSTEP_LAUNCH(STEP_EMIT, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_lds(pk, wstep_mwalk), s, pk, H_BLOB(h),
                          lay_e, n, d_counts, d_prefix, d_spans, span_cap, (int32_t*)nullptr, (int32_t*)nullptr);
       } else if (step_ok && wstep_empty) {   // second walk, every text: spans straight to their CSR place
-        MRX_WSTEP_LAUNCH(STEP_EMIT, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_lds(h->hp.dev, wstep_mwalk), s, p, H_BLOB(h),
+        MRX_WSTEP_LAUNCH(STEP_EMIT, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_lds(pk, wstep_mwalk), s, pk, H_BLOB(h),
                          lay2, n, (int32_t*)nullptr, d_prefix, d_spans, span_cap, (int32_t*)nullptr, (int32_t*)nullptr);
       } else if (step_ok) {
         if (lay2.wide_slots)
@@ -4879,7 +4889,7 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
         if (req_wave)
           MRX_REQWAVE_LAUNCH(STEP_EMIT, h, lay2, n, d_counts, d_prefix, d_spans, span_cap, s);
         else {
-        MRX_WSTEP_LAUNCH(STEP_EMIT, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_lds(h->hp.dev, wstep_mwalk), s, p, H_BLOB(h),
+        MRX_WSTEP_LAUNCH(STEP_EMIT, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_lds(pk, wstep_mwalk), s, pk, H_BLOB(h),
                            lay2, n, d_counts, d_prefix, d_spans, span_cap, (int32_t*)nullptr,
                            (int32_t*)nullptr);
         if (step_split > 0) MRX_REQWAVE_LAUNCH(STEP_EMIT, h, lay2, n, d_counts, d_prefix, d_spans, span_cap, s);
@@ -5536,8 +5546,10 @@ static int run_count_any(const mrx_handle* h, const Layout& lay, int64_t n, int3
     const bool use_req_route = (h->hp.dev.flags & PF_STEP_REQ) != 0;
     const bool wstep_bits = (h->hp.dev.flags & PF_BSTEP) != 0;
     const bool wstep_empty = (h->hp.dev.flags & PF_STEP_EMPTY) != 0 && g_force_generic < 2;
-    const bool wstep_mwalk = mwalk_on(h->hp.dev) && !use_req_route && !wstep_bits && !wstep_empty;
-    const int wstep_mwalk_k = h->hp.dev.mw_k;
+    const bool mwalk_req = use_req_route && (h->hp.dev.flags & PF_MWALK_REQ) && mwalk_enabled();
+    const bool wstep_mwalk = (mwalk_req || (mwalk_on(h->hp.dev) && !use_req_route)) && !wstep_bits && !wstep_empty;
+    const DevPlan pk = mwalk_req ? mwalk_req_plan(h->hp.dev) : h->hp.dev;
+    const int wstep_mwalk_k = pk.mw_k;
     bool req_wave = false;
     int split = 0;
     if (g_force_generic < 2 && !wstep_bits && !t_in_pieces && (h->hp.dev.flags & (PF_STEPPABLE | PF_STEP_REQ)) &&
@@ -5579,7 +5591,7 @@ static int run_count_any(const mrx_handle* h, const Layout& lay, int64_t n, int3
       MRX_REQWAVE_LAUNCH(STEP_COUNT, h, lay, n, counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0, s);
       g_last_kernel = "k_req_wave";
     } else if (g_force_generic < 2 && !big_lane && ((h->hp.dev.flags & (PF_STEPPABLE | PF_STEP_REQ | PF_STEP_EMPTY)) || wstep_mwalk)) {
-      MRX_WSTEP_LAUNCH(STEP_COUNT, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_lds(h->hp.dev, wstep_mwalk), s, h->hp.dev,
+      MRX_WSTEP_LAUNCH(STEP_COUNT, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_lds(pk, wstep_mwalk), s, pk,
                          H_BLOB(h), lay2, n, counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0,
                          (int32_t*)nullptr, (int32_t*)nullptr);
       g_last_kernel = wstep_mwalk ? "k_mwalk" : wstep_bits ? "k_bstep_count" : wstep_empty ? "k_estep_count" : "k_step_count";

@@ -303,6 +303,126 @@ bool build_multiwalk(const SearchAutomaton& s, MultiWalk& mw, std::string& why) 
   return true;
 }
 
+// The required-byte route (HybridMatcher._match_all_required_byte, matcher.mojo:864-898) in the same table form:
+//   pos = 0; while pos < len: hit = next required byte at or behind pos; start = hit backed up over first-class
+//   bytes; m = DFAEngine.match_first(text, start); if m and m.end > hit: report, pos = m.end; else pos = hit + 1
+// The walks that can ever be asked for begin where a run of first-class bytes begins (or on a required byte that
+// follows none), so ONE speculative walk accompanies every run (the last slot of the list); the required byte that
+// ends the run ACTIVATES it (it joins the list of pending walks, oldest first, keeping its start register -- a
+// change of role, not of place), any other byte behind the run discards it.  Only what a walk accepts from its
+// hit on counts (m.end > hit).  Among the pending walks the rules are those of build_multiwalk(): the oldest one
+// that has accepted behind its hit makes every younger pending walk void the moment it accepts (their hits lie
+// inside its match, the reference's `pos = m.end` skips them) and reports when it dies; a pending walk that dies
+// without having accepted behind its hit just leaves (`pos = hit + 1`).  The quirk that a start may lie inside the
+// previous match (the back-up is not bounded by pos) needs nothing: the speculative walk began there anyway.
+// Left to the stepper: a younger pending walk that accepts while an older one is undecided, more than four slots.
+bool build_reqwalk(const SearchAutomaton& s, int needle, const std::array<uint8_t, 256>& first, MultiWalk& mw,
+                   std::string& why) {
+  constexpr int K = 4;
+  if (s.acc[0]) { why = "start state accepts"; return false; }
+  if (needle < 0 || first[needle]) { why = "required byte inside the first class"; return false; }
+  std::vector<int> rep;
+  {
+    std::map<std::vector<int>, int> seen;
+    for (int c = 0; c < 256; ++c) {
+      std::vector<int> col(s.n + 2);
+      for (int q = 0; q < s.n; ++q) col[q] = s.next[q][c];
+      col[s.n] = first[c];
+      col[s.n + 1] = c == needle;
+      auto it = seen.find(col);
+      if (it == seen.end()) { it = seen.emplace(col, (int)rep.size()).first; rep.push_back(c); }
+      mw.cls[c] = (uint8_t)it->second;
+    }
+  }
+  mw.ncls = (int)rep.size();
+  if (mw.ncls > 64) { why = "multi-walk: more than 64 byte classes"; return false; }
+  mw.cshift = 0;
+  while ((1 << mw.cshift) < mw.ncls) ++mw.cshift;
+  const int ncp = 1 << mw.cshift;
+  // (A: the oldest pending walk has accepted behind its hit; P: the previous byte was a first-class byte;
+  //  pending walks oldest first; the run's speculative walk, -1 = none / dead)
+  struct Cfg { int A, P; std::vector<int> act; int spec; };
+  auto key = [](const Cfg& c) { std::vector<int> k{c.A, c.P, c.spec}; k.insert(k.end(), c.act.begin(), c.act.end()); return k; };
+  std::map<std::vector<int>, int> ids;
+  std::vector<Cfg> cfgs;
+  auto id_of = [&](const Cfg& c) {
+    auto k = key(c);
+    auto it = ids.find(k);
+    if (it == ids.end()) { it = ids.emplace(k, (int)cfgs.size()).first; cfgs.push_back(c); }
+    return it->second;
+  };
+  id_of(Cfg{0, 0, {}, -1});
+  std::vector<std::array<uint32_t, 64>> rows;
+  for (size_t ci = 0; ci < cfgs.size(); ++ci) {
+    if ((int64_t)cfgs.size() * ncp > 8192) { why = "multi-walk: configuration table beyond the LDS budget"; return false; }
+    const Cfg cur = cfgs[ci];
+    std::array<uint32_t, 64> row{};
+    const int n_act = (int)cur.act.size();
+    const int spec_slot = n_act;   // old slot of the speculative walk
+    for (int k = 0; k < mw.ncls; ++k) {
+      const int b = rep[k];
+      const bool isF = first[b] != 0, isN = b == needle;
+      std::vector<std::pair<int, int>> lst;   // pending walks: (state, provenance: old slot, -1 = begins on this byte)
+      bool emit = false;
+      int A = cur.A;
+      for (int i = 0; i < n_act; ++i) {
+        const int t = s.next[cur.act[i]][b];
+        if (t < 0) {
+          if (i == 0) { emit = A != 0; A = 0; }
+          continue;
+        }
+        if (t == 0) { why = "transition back into the start state"; return false; }
+        lst.push_back({t, i});
+      }
+      if (n_act > 0 && (lst.empty() || lst[0].second != 0)) A = 0;
+      const int spec_t = cur.spec >= 0 ? s.next[cur.spec][b] : -1;
+      const int fresh = s.next[0][b];   // a walk that begins on this byte
+      if (spec_t == 0 || fresh == 0) { why = "transition back into the start state"; return false; }
+      int nspec = -1, nspec_prov = 0, nP = 0;
+      if (isF) {
+        nP = 1;
+        if (!cur.P) { nspec = fresh; nspec_prov = -1; }
+        else { nspec = spec_t; nspec_prov = spec_slot; }
+      } else if (isN) {
+        if (cur.P) { if (spec_t >= 0) lst.push_back({spec_t, spec_slot}); }
+        else if (fresh >= 0) lst.push_back({fresh, -1});   // no run in front of the hit: the walk begins on it
+      }
+      std::vector<std::pair<int, int>> m;
+      for (const auto& x : lst) {
+        bool dup = false;
+        for (const auto& y : m) dup = dup || y.first == x.first;
+        if (!dup) m.push_back(x);
+      }
+      bool acc_now = false;
+      if (!m.empty() && s.acc[m[0].first]) { acc_now = true; A = 1; m.resize(1); }
+      for (size_t j = 1; j < m.size(); ++j)
+        if (s.acc[m[j].first]) { why = "a later hit's walk accepts while an earlier one is still undecided"; return false; }
+      const int total = (int)m.size() + (nspec >= 0 ? 1 : 0);
+      if (total > K) { why = "multi-walk: more than four walks at a time"; return false; }
+      mw.kmax = std::max(mw.kmax, total);
+      Cfg nc{m.empty() ? 0 : A, nP, {}, nspec};
+      for (const auto& x : m) nc.act.push_back(x.first);
+      const int nid = id_of(nc);
+      if ((((uint64_t)nid << mw.cshift) >> 16) != 0) { why = "multi-walk: configuration table beyond the LDS budget"; return false; }
+      uint32_t e = ((uint32_t)nid << mw.cshift) << 16;
+      if (emit) e |= 1u;
+      if (acc_now) e |= 2u;
+      if (nc.A) e |= 1u << 10;
+      static const int shift[4] = {2, 5, 7, 9};
+      int j = 0;
+      for (; j < (int)m.size(); ++j) e |= (uint32_t)(m[j].second < 0 ? K - j : m[j].second - j) << shift[j];
+      if (nspec >= 0) e |= (uint32_t)(nspec_prov < 0 ? K - j : nspec_prov - j) << shift[j];
+      row[k] = e;
+    }
+    rows.push_back(row);
+  }
+  mw.ncfg = (int)cfgs.size();
+  mw.tab.assign((size_t)mw.ncfg * ncp, 0);
+  for (int ci = 0; ci < mw.ncfg; ++ci)
+    for (int k = 0; k < mw.ncls; ++k) mw.tab[(size_t)ci * ncp + k] = rows[ci][k];
+  return true;
+}
+
 void put(std::vector<uint8_t>& blob, const void* p, size_t n) {
   const uint8_t* b = (const uint8_t*)p;
   blob.insert(blob.end(), b, b + n);
@@ -705,6 +825,8 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
   d.st_acc32 = 0;
   d.off_mw_cls = d.off_mw_tab = -1;
   d.mw_ncfg = d.mw_cshift = d.mw_bytes = d.mw_k = 0;
+  d.off_mwr_cls = -1;
+  d.mwr_ncfg = d.mwr_cshift = d.mwr_bytes = d.mwr_k = 0;
   d.off_st_sync = -1;
   d.off_stg_pair = -1;
   d.st_nsync = 0;
@@ -909,7 +1031,38 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
   else if (d.flags & PF_BT_SEARCH) hp.streamable_why_not = "backtracking matcher route (NFAEngine.match_all)";
   else if (d.flags & PF_BITSET) hp.streamable_why_not = "bitset NFA walk (no determinised table)";
   else if (d.flags & (PF_START_ANCHOR | PF_END_ANCHOR)) hp.streamable_why_not = "anchored";
-  else if (d.required_byte >= 0) hp.streamable_why_not = "required-byte findall path";
+  else if (d.required_byte >= 0) {
+    hp.streamable_why_not = "required-byte findall path";
+    // one-pass forms on k_mwalk: the plain search (match_next never takes the required-byte route) and findall's
+    // required-byte route itself
+    if (hp.why_no_search.empty() && d.kind == PLAN_DFA && (d.flags & PF_HAS_MATCHER) && !first[d.required_byte] &&
+        !(d.flags & (PF_PURE_LITERAL | PF_EXACT_LITERAL | PF_SCAN_ELIGIBLE | PF_START_ACCEPTING))) {
+      SearchAutomaton sa;
+      sa.n = d.nstates;
+      sa.next = T;
+      sa.acc = acc;
+      sa.allowed = first;
+      auto store = [&](const MultiWalk& mw, int32_t& off_cls, int32_t& ncfg, int32_t& cshift, int32_t& bytes, int32_t& kk) {
+        align(hp.blob, 16);
+        off_cls = (int)hp.blob.size();
+        put(hp.blob, mw.cls.data(), 256);
+        put(hp.blob, mw.tab.data(), mw.tab.size() * 4);
+        ncfg = mw.ncfg; cshift = mw.cshift; bytes = 256 + (int)mw.tab.size() * 4; kk = mw.kmax;
+        align(hp.blob, 16);
+      };
+      MultiWalk plain, req;
+      std::string w1, w2;
+      if (build_multiwalk(sa, plain, w1)) {
+        store(plain, d.off_mw_cls, d.mw_ncfg, d.mw_cshift, d.mw_bytes, d.mw_k);
+        d.off_mw_tab = d.off_mw_cls + 256;
+        d.flags |= PF_MWALK;
+      } else hp.mwalk_why_not = w1;
+      if (build_reqwalk(sa, d.required_byte, first, req, w2)) {
+        store(req, d.off_mwr_cls, d.mwr_ncfg, d.mwr_cshift, d.mwr_bytes, d.mwr_k);
+        d.flags |= PF_MWALK_REQ;
+      } else hp.mwalk_req_why_not = w2;
+    }
+  }
   else if (!hp.why_no_search.empty()) hp.streamable_why_not = hp.why_no_search;
   else {
     SearchAutomaton sa;
@@ -1283,6 +1436,8 @@ std::string describe_plan(const HostPlan& hp) {
     << " sync_bytes=" << d.st_nsync << " reset_byte=" << d.st_reset_byte << " code_columns=" << (d.off_stcol32 >= 0 ? 1 : 0)
     << " multiwalk=" << ((d.flags & PF_MWALK) ? "yes" : hp.mwalk_why_not.empty() ? "no" : "no: " + hp.mwalk_why_not)
     << " mw_configs=" << d.mw_ncfg << " mw_walks=" << d.mw_k
+    << " multiwalk_req=" << ((d.flags & PF_MWALK_REQ) ? "yes" : hp.mwalk_req_why_not.empty() ? "no" : "no: " + hp.mwalk_req_why_not)
+    << " mwr_configs=" << d.mwr_ncfg << " mwr_walks=" << d.mwr_k
     << (d.off_stg_pair >= 0 ? " pair_table=1" : "") << "\n";
   o << "device.steppable=" << ((d.flags & PF_STEPPABLE) ? "yes" : (d.flags & PF_STEP_REQ) ? "required-byte route" : "no")
     << " step_search=" << ((d.flags & PF_STEP_SEARCH) ? 1 : 0) << ((d.flags & PF_STEP_BIG) ? " big_table=1" : "")

@@ -51,6 +51,8 @@ enum PlanFlags : uint32_t {
                                 // several simultaneous walks (DevPlan::off_mw_*; k_mwalk): what the single-walk proof
                                 // of the streaming kernel rejects ("accepting state continues into a non-accepting
                                 // one", "a later start survives ...") without the stepper's re-scans
+  PF_MWALK_REQ = 1u << 21,      // findall / count of a required-byte plan (PF_STEP_REQ: HybridMatcher._match_all_required_byte,
+                                // matcher.mojo:864-898) in one pass on the same kernel (DevPlan::off_mwr_*)
   PF_STREAM_SEARCH = 1u << 11   // search / sub / captures may use the streaming kernel too (findall and
                                 // count may whenever PF_STREAMABLE is set): not with a memchr prefilter,
                                 // which only match_next consults (matcher.mojo:784-796)
@@ -103,6 +105,9 @@ struct DevPlan {
   // configuration (the end-of-text rule), bits 2-4 / 5-6 / 7-8 / 9 = where the start register of walk slot
   // 0 / 1 / 2 / 3 comes from: v <= 3 - j: old slot j + v, v == 4 - j: this byte (a walk begins here).
   int32_t off_mw_cls, off_mw_tab, mw_ncfg, mw_cshift, mw_bytes, mw_k;   // mw_k: the most walks any configuration holds
+  // the same table form for the required-byte route (PF_MWALK_REQ): walks begin where a run of first-class bytes
+  // begins, count from the required byte that ends their run ("hits"), report only behind it; see build_reqwalk()
+  int32_t off_mwr_cls, mwr_ncfg, mwr_cshift, mwr_bytes, mwr_k;
   // synchronising bytes of the search automaton: sync[b] != 0 when byte b takes EVERY state to the
   // same state with the same start (idle, or a new start at b) -- after such a byte the walk does not
   // depend on what came before, so a long text can be cut there (st_nsync = how many, 0 = no table)
@@ -169,7 +174,7 @@ struct HostPlan {
   DevPlan dev{};
   std::vector<uint8_t> blob;
   std::string streamable_why_not;
-  std::string mwalk_why_not;
+  std::string mwalk_why_not, mwalk_req_why_not;
   std::string first_stream_why_not;
 };
 

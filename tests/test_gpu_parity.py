@@ -11,6 +11,7 @@ Bit-exact is the bar: every start/end offset, every count, every replaced byte.
 import collections
 import json
 import os
+import re
 import zlib
 
 import numpy as np
@@ -1228,16 +1229,21 @@ def test_generated_patterns_multiwalk_equals_stepper_and_oracle(seed):
     lib = M.load_library()
     rng = np.random.default_rng(seed)
     base = b"abcxyz019 -@.fobrhelcatdg"
-    nmw = 0
-    for p in patterns(seed, 260) + patterns2(seed, 140):
+    nmw = nreq = 0
+    # (required-byte plans: findall / count take the route's own table, search the plain one)
+    extra = ["[a-z]+@[a-z]+\\.com", "\\d{3}-\\d{4}", "[0-9]+\\.[0-9]+", "[a-z0-9._%+-]+@[a-z0-9.-]+\\.[a-z]{2,}", "\\d{3}-\\d{3}-\\d{4}",
+             "[a-c]+:[0-9]+", "\\w+@\\w+", "[89]00\\d{6}"]
+    for p in patterns(seed, 260) + patterns2(seed, 140) + extra:
         pb = p.encode()
         try:
             rx = M.compile_regex(pb)
         except (M.RegexSyntaxError, M.UnsupportedPattern):
             continue
-        if "multiwalk=yes" not in rx.describe():
+        dsc = rx.describe()
+        if "multiwalk=yes" not in dsc and "multiwalk_req=yes" not in dsc:
             continue
         nmw += 1
+        nreq += "multiwalk_req=yes" in dsc
         al = base + bytes(c for c in pb if chr(c).isalnum() or c in b" -@.") * 2
         texts = _random_texts(rng, 90, 70, al) + _random_texts(rng, 12, 700, al) + [b"", pb[:1], bytes(al[:3]) * 40]
         for j in range(0, len(texts), 5):   # long runs of one byte: walks that overlap themselves
@@ -1245,19 +1251,31 @@ def test_generated_patterns_multiwalk_equals_stepper_and_oracle(seed):
             texts[j] = (bytes([al[int(rng.integers(0, len(al)))]]) * (k // 2) + texts[j])[:k]
         with long_text_kernels(2):
             got = rx.findall_lists(texts)
-            assert lib.mrx_last_kernel_name() == b"k_mwalk", (p, lib.mrx_last_kernel_name())
+            if "multiwalk_req=yes" in dsc or "required-byte route" not in dsc:
+                assert lib.mrx_last_kernel_name() == b"k_mwalk", (p, lib.mrx_last_kernel_name())
             gs, ge = rx.match_next(texts)
             gc = rx.count(M.DeviceBatch.from_texts(texts)).cpu().numpy()
             with multiwalk(2):
                 want = rx.findall_lists(texts)
                 assert lib.mrx_last_kernel_name() != b"k_mwalk"
                 ws, we = rx.match_next(texts)
+        texts_h = texts   # (texts with the required byte doubled / hits inside matches / hits without a run in front)
+        if "multiwalk_req=yes" in dsc:
+            rb = int(re.search(r"required_byte=(-?\d+)", dsc).group(1))
+            more = [bytes([rb]) * 3 + t[:40] + bytes([rb]) + t[40:80] + bytes([rb, rb]) + t[80:] for t in texts[:40]]
+            with long_text_kernels(2):
+                g2 = rx.findall_lists(more)
+                with multiwalk(2):
+                    w2 = rx.findall_lists(more)
+            assert g2 == w2, (p, [(t, a, b) for t, a, b in zip(more, g2, w2) if a != b][:2])
+            for j in range(0, len(more), 7):
+                assert g2[j] == O.findall(pb, more[j]), (p, more[j])
         assert got == want, (p, [(t, g, w) for t, g, w in zip(texts, got, want) if g != w][:3])
         assert np.array_equal(gs, ws) and np.array_equal(ge, we), p
         assert [int(x) for x in gc] == [len(g) for g in got], p
         for j in range(0, len(texts), 13):
             assert got[j] == O.findall(pb, texts[j]), (p, texts[j])
-    assert nmw > 40, nmw
+    assert nmw > 40 and nreq >= 5, (nmw, nreq)
 
 
 @pytest.mark.parametrize("pat,repl", [(b"\\w+\\d{2}", b"<W>"), (b"\\d+(\\.\\d+)?", b"N"), (b"(foo|foobar)", b""),
@@ -1450,8 +1468,11 @@ def test_required_byte_route_one_wavefront_per_text(pat):
         assert lib.mrx_last_kernel_name() == b"k_req_wave"
     with long_text_kernels(2):
         want = rx.findall_lists(texts)
-        assert lib.mrx_last_kernel_name() == b"k_step_count"
-    assert got == want
+        assert lib.mrx_last_kernel_name() in (b"k_step_count", b"k_mwalk")   # (k_mwalk: the route's one-pass table)
+        with multiwalk(2):
+            want2 = rx.findall_lists(texts)
+            assert lib.mrx_last_kernel_name() == b"k_step_count"
+    assert got == want == want2
     for i in list(range(0, 60, 5)) + list(range(60, len(texts))):
         assert got[i] == O.findall(pat, texts[i]), (pat, i)
     assert max(len(g) for g in got) > 32          # more matches than slots: the emit pass ran
@@ -2222,3 +2243,36 @@ def test_sub_on_fixed_pitch_batches(pat, repl):
             so_h, sd_h = so.cpu().numpy(), sd.cpu().numpy().tobytes()
             for i in range(0, n, 7):
                 assert sd_h[so_h[i]:so_h[i + 1]] == O.sub(pat, repl, texts[i], count), (pat, texts[i])
+
+
+@pytest.mark.parametrize("pat", [b"(x|y|foo|bar)+", b"[a-z]+\\d+", b"\\d+"])
+def test_dense_matches_decode_in_row_windows(pat):
+    """k_decode's dense path (a wavefront's 64 texts hold more spans than three LDS tiles): row windows per text,
+    one coalesced store per row and batch, spans behind a row's window stored directly -- a match every one to three
+    bytes, texts of very different density in one wavefront (one text far denser than the batch's average), fixed
+    pitch and CSR, against the generic kernels on every text and the oracle on a sample."""
+    _need_gpu()
+    rng = np.random.default_rng(zlib.crc32(pat) + 3)
+    dense = {b"(x|y|foo|bar)+": b"xyxyfoobarxy ", b"[a-z]+\\d+": b"a1b2c3 d4", b"\\d+": b"1 2 3 45 6 "}[pat]
+    n, L = 192, 4096
+    arr = np.empty((n, L), dtype=np.uint8)
+    for i in range(n):
+        al = np.frombuffer(dense if i % 3 else dense + b" " * 40, dtype=np.uint8)   # every third text is sparse
+        arr[i] = rng.choice(al, size=L)
+    arr[5] = np.frombuffer((b"x1" * (L // 2))[:L], dtype=np.uint8) if pat != b"\\d+" else np.frombuffer((b"1 " * (L // 2))[:L], dtype=np.uint8)
+    rx = M.compile_regex(pat)
+    d = torch.from_numpy(arr).cuda().reshape(-1)
+    lens = rng.integers(L // 2, L + 1, size=n).astype(np.int32)
+    batches = [M.DeviceBatch.strided(d, L, length=L),
+               M.DeviceBatch.strided(d, L, length=L, lens=torch.from_numpy(lens).cuda()),
+               M.DeviceBatch.from_texts([arr[i, : lens[i]].tobytes() for i in range(n)])]
+    for bi, b in enumerate(batches):
+        pre, sp, tot = rx._dev_findall(b)
+        with generic_kernels():
+            gpre, gsp, gtot = rx._dev_findall(b)
+        assert tot == gtot and tot > 3 * 3072 * (n // 64), (pat, bi, tot)
+        assert torch.equal(pre, gpre) and torch.equal(sp[:tot], gsp[:tot]), (pat, bi)
+    pre_h, sp_h = pre.cpu().numpy(), sp.cpu().numpy()
+    for i in (0, 3, 5, 64, 191):
+        t = arr[i, : lens[i]].tobytes()
+        assert [tuple(int(x) for x in r) for r in sp_h[pre_h[i]:pre_h[i + 1]]] == O.findall(pat, t), (pat, i)
