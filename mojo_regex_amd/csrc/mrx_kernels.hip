@@ -58,6 +58,13 @@ struct Layout {  // where text i lives
   // per text: first occurrence of the backtracking matcher's literal, last occurrence << 1 | has-newline
   // (k_litscan in front of the lane-per-text kernels, see bt_prepass()); nullptr = not computed
   const int2* pre = nullptr;
+  // marks of the positions at which a match begins (k_backscan -> k_wstep<., 0, 0, 0, 1>): one bit per text byte,
+  // text i's words from bm_row(i) on; bm_cnt[i] = how many marks text i has
+  const uint32_t* bm = nullptr;
+  const int32_t* bm_cnt = nullptr;
+  __host__ __device__ __forceinline__ int64_t bm_row(int64_t i) const {
+    return offsets ? (offsets[i] >> 5) + 2 * i : i * ((stride >> 5) + 2);
+  }
   // first slot of text i's row and the row's capacity (wide rows)
   __device__ __forceinline__ int64_t slot_row(int64_t i, int* cap) const {
     if (offsets) {
@@ -269,7 +276,13 @@ __host__ __device__ inline size_t bstep_table_bytes(int npos) { return 2048 + (s
 // every position is tried and every try matches -- the longest walk from it, or the empty match when no walk
 // starts there -- and the search resumes at the match end, or one byte on after an empty match; the position
 // behind the last byte is tried as well.
-template <int MODE, int ROUTE, int BITS = 0, int EMPTY = 0>
+// BM = 1 (plain route of a table plan with a backward table, PF_BACKSET): the positions at which a match begins are
+// marked (Layout::bm, written by k_backscan), so a lane that is looking for a start jumps to the next mark -- up to 32
+// bytes per step -- and every walk it begins succeeds.
+// CLSIDX = 1 (with BM, tables of more than 96 states -- PF_STEP_BIG): the table stays class indexed, cls[256] |
+// tr[(nstates + 1) x ncls] (last row = "a walk begins": the start state's transitions; which bytes may begin one is
+// in the marks already), two dependent LDS reads per step instead of one -- affordable now that no walk fails.
+template <int MODE, int ROUTE, int BITS = 0, int EMPTY = 0, int BM = 0, int CLSIDX = 0>
 __global__ __launch_bounds__(64 * kWsWaves) void k_wstep(DevPlan p, const uint8_t* __restrict__ blob, Layout lay,
                                                          int64_t n, int32_t* __restrict__ counts,
                                                          const int64_t* __restrict__ prefix,
@@ -283,7 +296,11 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_wstep(DevPlan p, const uint8_
   // tables, so a step costs one dependent LDS read instead of three.)
   static_assert(!(BITS && ROUTE), "the bitset form has the plain route only");
   static_assert(!EMPTY || (!BITS && !ROUTE), "empty matches: plain route of a table plan");
+  static_assert(!BM || (!BITS && !ROUTE && !EMPTY), "marks: plain route of a table plan");
+  static_assert(!CLSIDX || BM, "the class-indexed table needs the marks (no first-byte filter in it)");
   uint16_t* tab = (uint16_t*)lds;
+  const uint8_t* clsT = lds;                       // CLSIDX: cls[256] | tr[(ns + 1) x ncls]
+  uint16_t* trc = (uint16_t*)(lds + 256);
   const int ns = p.nstates, idle = ns;
   // BITS: mask[256] | follow8[nch][256] | first-byte filter[256]
   uint64_t* bmask = (uint64_t*)lds;
@@ -307,6 +324,17 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_wstep(DevPlan p, const uint8_
       for (int k = 0; k < 8; ++k)
         if (((v >> k) & 1) && 8 * j + k < p.bs_npos) u |= g_fol[8 * j + k];
       bfol[e] = u;
+    }
+  } else if (CLSIDX) {
+    const uint8_t* g_cls = blob + p.off_cls;
+    const uint16_t* g_tr = (const uint16_t*)(blob + p.off_trans);
+    for (int e = threadIdx.x; e < 256; e += blockDim.x) lds[e] = g_cls[e];
+    for (int e = threadIdx.x; e < (ns + 1) * p.ncls; e += blockDim.x) {
+      const int q = e / p.ncls, c = e - q * p.ncls;
+      const uint32_t t = g_tr[(q < ns ? q : 0) * p.ncls + c];
+      uint32_t v = t == 0xFFFFu ? (q < ns ? kWsDead : (uint32_t)idle) : ((t & 0x7FFFu) | ((t & 0x8000u) ? kWsAcc : 0u));
+      if (q == ns && t != 0xFFFFu) v |= kWsStart;
+      trc[e] = (uint16_t)v;
     }
   } else
   {
@@ -358,6 +386,13 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_wstep(DevPlan p, const uint8_
     uint64_t bset = 0;   // BITS: live positions of the current walk (0 = looking for a start)
     const bool skipped = lay.split > 0 && t.len >= lay.split;   // k_req_wave's text
     bool fin = !live || t.len == 0 || skipped;
+    const uint32_t* mybm = nullptr;      // BM: my text's marks
+    int bm_idx = -1;
+    uint32_t bm_word = 0;
+    if (BM && live) {
+      mybm = lay.bm + lay.bm_row(i);
+      if (lay.bm_cnt[i] == 0) fin = true;   // no match begins anywhere in my text
+    }
     int64_t wo = (MODE == STEP_EMIT && live) ? prefix[i] : 0;
     int slot_cap = kStepSlots;           // my slot row (wide rows: sized by the text, Layout::slot_row)
     int64_t slot0 = i * kStepSlots;
@@ -432,7 +467,18 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_wstep(DevPlan p, const uint8_
           bset = alive ? nx : (stop ? 0ull : bset);   // (a lane that is not stepping keeps its walk)
           return;
         }
-        const uint32_t e = tab[(state << 8) + byte];
+        if (BM) {
+          if (act && state == idle && inside) {   // looking for a start: on to the next mark
+            const int tp = pos - mis;
+            if ((tp >> 5) != bm_idx) { bm_idx = tp >> 5; bm_word = mybm[bm_idx]; }
+            const uint32_t rest = bm_word >> (tp & 31);
+            if (!(rest & 1u)) {
+              pos += rest ? __builtin_ctz(rest) : 32 - (tp & 31);
+              return;
+            }
+          }
+        }
+        const uint32_t e = CLSIDX ? trc[state * p.ncls + clsT[byte]] : tab[(state << 8) + byte];
         if (ROUTE == 1) {
           const bool scanning = state == idle;
           // SCAN
@@ -679,6 +725,86 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_mwalk(DevPlan p, const uint8_
       if (MODE == STEP_COUNT || MODE == STEP_SLOTS || MODE == STEP_ANY) counts[i] = k;
       if (MODE == STEP_SEARCH) { out_s[i] = rs; out_e[i] = re; }
     }
+  }
+}
+
+// ---- where matches begin: the right-to-left pass (PF_BACKSET, DevPlan::off_bk_*; host side: build_backset()) ------
+// One lane per text, the text through the LDS tile window by window FROM ITS END, one class lookup and one table
+// lookup per byte, no registers but the set number: bit (position & 31) of word (position >> 5) of the text's row
+// of Layout::bm says whether the reference's walk from that position succeeds.  cnt[i] = marks of text i.
+__global__ __launch_bounds__(64 * kWsWaves) void k_backscan(DevPlan p, const uint8_t* __restrict__ blob, Layout lay,
+                                                            int64_t n, uint32_t* __restrict__ bm,
+                                                            int32_t* __restrict__ cnt) {
+  constexpr int CH = 128, kRowPitch = CH + 16, LPR = CH / 16, RPI = 64 / LPR, NL = 64 / RPI;
+  __shared__ __align__(16) uint8_t tiles[kWsWaves][64 * kRowPitch];
+  extern __shared__ __align__(16) uint8_t lds[];
+  {
+    const uint32_t* src = (const uint32_t*)(blob + p.off_bk_cls);
+    uint32_t* dst = (uint32_t*)lds;
+    for (int e = threadIdx.x; e < ((p.bk_bytes + 3) >> 2); e += blockDim.x) dst[e] = src[e];
+  }
+  __syncthreads();
+  const uint8_t* clsT = lds;
+  const uint16_t* tab = (const uint16_t*)(lds + 256);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint8_t* tile = tiles[wave];
+  const int seg = lane % LPR, rsub = lane / LPR;
+  const int64_t nw = (n + 63) >> 6;
+  for (int64_t w = (int64_t)blockIdx.x * kWsWaves + wave; w < nw; w += (int64_t)gridDim.x * kWsWaves) {
+    const int64_t i = (w << 6) + lane;
+    const bool live = i < n;
+    const Text t = live ? lay.text(i) : Text(blob, 0);
+    const uintptr_t addr = t.len > 0 ? (uintptr_t)t.ptr : (uintptr_t)blob;
+    const int mis = t.len > 0 ? (int)(addr & 15) : 0;
+    const uintptr_t rb = addr & ~(uintptr_t)15;
+    const int end = mis + t.len;
+    __builtin_amdgcn_wave_barrier();
+    *(uint4*)(tile + lane * kRowPitch + CH) = make_uint4((uint32_t)rb, (uint32_t)((uint64_t)rb >> 32), (uint32_t)end, 0u);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    int max_end = end;
+    for (int off = 32; off > 0; off >>= 1) max_end = max(max_end, __shfl_xor(max_end, off));
+    const uint8_t* myrow = tile + lane * kRowPitch;
+    uint32_t* myout = bm + (live ? lay.bm_row(i) : 0);
+    uint32_t st = (uint32_t)p.bk_start << p.bk_cshift, word = 0;
+    int marks = 0;
+    uint4 v[NL];
+#define MRX_BK_LOAD(CB)                                                                   \
+    do {                                                                                  \
+      _Pragma("unroll") for (int j_ = 0; j_ < NL; ++j_) {                                  \
+        const uint4 rs_ = *(const uint4*)(tile + (RPI * j_ + rsub) * kRowPitch + CH);      \
+        uint32_t fo_ = (uint32_t)(CB) + seg * 16;                                          \
+        if (fo_ >= rs_.z) fo_ = 0;                                                         \
+        v[j_] = mrx_ldg((const uint4*)((const uint8_t*)(((uint64_t)rs_.y << 32) | rs_.x) + fo_)); \
+      }                                                                                    \
+    } while (0)
+    const int wb_last = max_end > 0 ? ((max_end - 1) / CH) * CH : -CH;
+    if (wb_last >= 0) MRX_BK_LOAD(wb_last);
+    for (int wb = wb_last; wb >= 0; wb -= CH) {
+#pragma unroll
+      for (int j = 0; j < NL; ++j) *(uint4*)(tile + (RPI * j + rsub) * kRowPitch + seg * 16) = v[j];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (wb - CH >= 0) MRX_BK_LOAD(wb - CH);   // the window in front, in flight while this one is stepped
+#pragma unroll 8
+      for (int it = CH - 1; it >= 0; --it) {
+        const int f = wb + it;
+        const bool act = live && f >= mis && f < end;
+        const uint32_t en = tab[st + clsT[myrow[it]]];
+        const int pr = f - mis;
+        if (act) {
+          st = (uint32_t)(en >> 1) << p.bk_cshift;
+          word |= (uint32_t)(en & 1u) << (pr & 31);
+          marks += (int)(en & 1u);
+          if ((pr & 31) == 0) { myout[pr >> 5] = word; word = 0; }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+#undef MRX_BK_LOAD
+    if (live) cnt[i] = marks;
   }
 }
 
@@ -3735,14 +3861,17 @@ int grid_for(int64_t n, int block) {
     if (wstep_mwalk && wstep_mwalk_k <= 2) hipLaunchKernelGGL((k_mwalk<MODE, 2>), __VA_ARGS__); \
     else if (wstep_mwalk && wstep_mwalk_k == 3) hipLaunchKernelGGL((k_mwalk<MODE, 3>), __VA_ARGS__); \
     else if (wstep_mwalk) hipLaunchKernelGGL((k_mwalk<MODE, 4>), __VA_ARGS__);             \
+    else if (wstep_bm && wstep_bm_big) hipLaunchKernelGGL((k_wstep<MODE, 0, 0, 0, 1, 1>), __VA_ARGS__); \
+    else if (wstep_bm) hipLaunchKernelGGL((k_wstep<MODE, 0, 0, 0, 1>), __VA_ARGS__);       \
     else if (wstep_bits) hipLaunchKernelGGL((k_wstep<MODE, 0, 1>), __VA_ARGS__);           \
     else if (wstep_empty) hipLaunchKernelGGL((k_wstep<MODE, 0, 0, 1>), __VA_ARGS__);       \
     else if (use_req_route) hipLaunchKernelGGL((k_wstep<MODE, 1>), __VA_ARGS__);         \
     else hipLaunchKernelGGL((k_wstep<MODE, 0>), __VA_ARGS__);                              \
   } while (0)
 // dynamic LDS of k_wstep for this plan
-size_t wstep_lds(const DevPlan& p, bool mwalk = false) {
+size_t wstep_lds(const DevPlan& p, bool mwalk = false, bool bm_big = false) {
   if (mwalk) return mwalk_table_bytes(p);
+  if (bm_big) return 256 + (size_t)(p.nstates + 1) * p.ncls * 2 + 16;
   return (p.flags & PF_BSTEP) ? bstep_table_bytes(p.bs_npos) : wstep_table_bytes(p.nstates);
 }
 // PF_MWALK plans: several walks in one pass (k_mwalk) instead of the stepper's restart-per-position loop.
@@ -3753,6 +3882,12 @@ bool mwalk_enabled() {
   return !off && g_mwalk_mode != 2 && g_force_generic == 0;   // (level 1 = the stepper and nothing newer)
 }
 bool mwalk_on(const DevPlan& p) { return (p.flags & PF_MWALK) && mwalk_enabled(); }
+// PF_BACKSET plans: mark where matches begin (k_backscan), then the stepper only starts walks that succeed.
+// MRX_NO_BACKSET=1 / mrx_debug_multiwalk(2): off.
+bool backset_on(const DevPlan& p) {
+  static const bool off = getenv("MRX_NO_BACKSET") && getenv("MRX_NO_BACKSET")[0] == '1';
+  return (p.flags & PF_BACKSET) && !off && g_mwalk_mode != 2 && g_force_generic == 0;
+}
 // the plan as k_mwalk sees it on the required-byte route: its table in the place of the plain route's
 DevPlan mwalk_req_plan(const DevPlan& p) {
   DevPlan q = p;
@@ -3771,6 +3906,44 @@ bool union_pass_for_table_plan(const DevPlan& p, bool search) {
 }
 // Bitset NFA, first pass (k_bscan): on return *out is `lay` with every text cut to what the second pass
 // has to look at (mode 0 search, 1 count / findall); *d_limit is scratch the caller frees.
+// Right-to-left pass of a PF_BACKSET plan: on return *out is `lay` with the marks (bm, bm_cnt) attached (scratch of
+// the calling scope).  A CSR batch's byte count is read back once to size the bitmap.
+int backscan_marks(const mrx_handle* h, const Layout& lay, int64_t n, hipStream_t s, Layout* out) {
+  const DevPlan& p = h->hp.dev;
+  int64_t words;
+  if (lay.offsets) {
+    // rows are placed by the texts' byte offsets (Layout::bm_row), which never decrease: where the last text ends
+    int64_t total = 0;
+    if (lay.vlen) {   // views / pieces: offsets[n] need not exist
+      int32_t last_len = 0;
+      HIP_TRY(hipMemcpyAsync(&total, lay.offsets + (n - 1), sizeof total, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipMemcpyAsync(&last_len, lay.vlen + (n - 1), sizeof last_len, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      total += last_len;
+    } else {
+      HIP_TRY(hipMemcpyAsync(&total, lay.offsets + n, sizeof total, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+    }
+    words = (total >> 5) + 2 * n + 4;
+  } else {
+    words = n * ((lay.stride >> 5) + 2) + 4;
+  }
+  uint32_t* d_bm = nullptr;
+  int32_t* d_cnt = nullptr;
+  HIP_TRY(scratch_alloc((void**)&d_bm, sizeof(uint32_t) * (size_t)words, s));
+  HIP_TRY(scratch_alloc((void**)&d_cnt, sizeof(int32_t) * (n > 0 ? n : 1), s));
+  const int64_t nw = (n + 63) / 64;
+  int64_t g = (nw + kWsWaves - 1) / kWsWaves;
+  if (g < 1) g = 1;
+  if (g > grid_cap()) g = grid_cap();
+  hipLaunchKernelGGL(k_backscan, dim3((unsigned)g), dim3(64 * kWsWaves), (size_t)p.bk_bytes + 16, s, p, H_BLOB(h), lay, n, d_bm, d_cnt);
+  HIP_TRY(hipGetLastError());
+  *out = lay;
+  out->bm = d_bm;
+  out->bm_cnt = d_cnt;
+  return MRX_OK;
+}
+
 int bscan_limits(const mrx_handle* h, const Layout& lay, int64_t n, int mode, hipStream_t s, Layout* out,
                  int32_t** d_limit) {
   const DevPlan& p = h->hp.dev;
@@ -3801,7 +3974,7 @@ int bscan_limits(const mrx_handle* h, const Layout& lay, int64_t n, int mode, hi
 // alternative is the literal restatement (50 GB/s), so the wavefront form takes every batch of texts of
 // half a KiB and more
 int req_wave_pays(const Layout& lay, int64_t n, bool req_route, hipStream_t s, bool* out, int* split = nullptr,
-                  bool big = false, bool mwalk = false) {
+                  bool big = false, bool mwalk = false, bool marks_big = false) {
   *out = false;
   if (split) *split = 0;
   if (g_long_text_mode) { *out = g_long_text_mode == 1 || g_long_text_mode == 3; return MRX_OK; }
@@ -3831,7 +4004,9 @@ int req_wave_pays(const Layout& lay, int64_t n, bool req_route, hipStream_t s, b
   // plans with a multi-walk table: a lane scans its text once whatever the text holds, so from 32 Ki texts on one
   // lane per text beats the wavefront kernel's per-candidate walks (measured on the reference's list:
   // range_quantifiers 474 -> 853 GB/s, dual_quantifiers 218 -> 156: profiles/r03_multiwalk.md)
-  if (mwalk && !big && n >= 32768) *out = false;
+  if (mwalk && !req_route && !big && n >= 32768) *out = false;   // (required-byte route: sparse hits stay the wavefront kernel's best case)
+  // big tables with a backward table: marks + one lane per text (class-indexed walk) once the batch has the lanes
+  if (marks_big && big && !req_route && n >= 32768) *out = false;
   // a ragged batch with a few texts far longer than the rest: those go to the wavefront kernel, the
   // others keep one lane each
   if (!*out && split && max_len >= 32768 && max_len >= 8 * avg) *split = 16384;
@@ -4267,7 +4442,7 @@ int csr_stats(const Layout& lay, int64_t n, hipStream_t s, int64_t* total, int64
 }
 // known_total / known_max: csr_stats() of the batch when the caller has them already (< 0: not)
 int pieces_prepare(const mrx_handle* h, const Layout& lay, int64_t n, hipStream_t s, Pieces* pc,
-                   int64_t known_total = -1, int64_t known_max = -1, bool disjoint = false) {
+                   int64_t known_total = -1, int64_t known_max = -1, bool disjoint = false, bool mwalk = false) {
   const DevPlan& p = h->hp.dev;
   pc->on = false;
   if (p.st_nsync <= 0 || g_long_text_mode == 2 || (g_long_text_mode == 3 && disjoint) || n <= 0) return MRX_OK;
@@ -4305,7 +4480,9 @@ int pieces_prepare(const mrx_handle* h, const Layout& lay, int64_t n, hipStream_
     // kernel -- pieces win on 11-74 KB texts of the plain route (dense candidates: flexible_phone 1.57 -> 0.84 ms,
     // multi_format_phone 2.42 -> 1.57, alternation_quantifiers 2.84 -> 1.87) and lose below that and on every
     // required-byte plan (sparse candidates are the wavefront kernel's best case)
-    if (disjoint && avg < 10000) return MRX_OK;
+    // (multi-walk plans: a piece is scanned once whatever it holds, so pieces pay as soon as one lane per text
+    // leaves the device short of lanes)
+    if (disjoint && avg < (mwalk ? 2048 : 10000)) return MRX_OK;
     if (n > 131072 && !(max_len >= 32768 && max_len >= 8 * avg && (lay.offsets || lay.lens))) return MRX_OK;
     const int64_t want = (total + 262143) / 262144;   // about 2^18 pieces
     C = (int)((want + 255) / 256 * 256);
@@ -4611,6 +4788,8 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
   int64_t max_text = int64_t(1) << 40;   // longest text of the batch, where known
   bool req_wave = false;   // the stepper's route on the wavefront-per-text kernel
   bool mwalk_two_pass = false;   // multi-walk plan: count pass + emit pass instead of slot rows
+  bool wstep_bm = false;         // stepper behind the right-to-left pass that marks where matches begin (PF_BACKSET)
+  bool wstep_bm_big = false;     // ... with its table class indexed (more than 96 states)
   int step_split = 0;      // > 0: lane kernel for texts below this length AND wavefront kernel for the rest
   Layout lay2 = lay;       // lay + that split
   EvRec* d_recs = nullptr;
@@ -4710,9 +4889,9 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
       }
     } else {
       if (step_ok && !wstep_bits && !wstep_empty && !t_in_pieces && !(p.flags & PF_STEP_BIG) && p.st_nsync > 0 &&
-          !(p.flags & PF_STREAMABLE) && span_cap > 0 && (!use_req_route || g_long_text_mode == 1)) {
+          !(p.flags & PF_STREAMABLE) && span_cap > 0 && (!use_req_route || mwalk_req || g_long_text_mode == 1)) {
         Pieces spc;
-        if (int rc = pieces_prepare(h, lay, n, s, &spc, -1, -1, /*disjoint=*/true)) return rc;
+        if (int rc = pieces_prepare(h, lay, n, s, &spc, -1, -1, /*disjoint=*/true, wstep_mwalk)) return rc;
         if (spc.on && !wstep_mwalk) {   // (a multi-walk plan scans every piece once, dense candidates or not)
           bool dense = true;
           if (int rc = dense_candidates(h, lay, n, s, &dense)) return rc;
@@ -4751,17 +4930,25 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
       }
       if (step_ok && !wstep_bits && !wstep_empty && !t_in_pieces)
         if (int rc = req_wave_pays(lay, n, use_req_route, s, &req_wave, (p.flags & PF_STEP_BIG) ? nullptr : &step_split,
-                                   (p.flags & PF_STEP_BIG) != 0, wstep_mwalk))
+                                   (p.flags & PF_STEP_BIG) != 0, wstep_mwalk, backset_on(p) && !wstep_mwalk))
           return rc;
       lay2.split = step_split;
-      if (step_ok && !wstep_empty && !wstep_mwalk && (wstep_bits || (!req_wave && step_split == 0 && !use_req_route && union_pass_for_table_plan(p, false)))) {
+      wstep_bm = step_ok && backset_on(p) && !wstep_mwalk && !wstep_bits && !wstep_empty && !use_req_route && !req_wave &&
+                 step_split == 0;
+      wstep_bm_big = wstep_bm && (p.flags & PF_STEP_BIG) != 0;
+      if (wstep_bm) {
+        const int32_t split_keep = lay2.split;
+        if (int rc = backscan_marks(h, lay, n, s, &lay2)) return rc;
+        lay2.split = split_keep;
+      }
+      if (step_ok && !wstep_empty && !wstep_mwalk && !wstep_bm && (wstep_bits || (!req_wave && step_split == 0 && !use_req_route && union_pass_for_table_plan(p, false)))) {
         // union automaton first: texts in which no walk from any start reaches MATCH are not walked at all
         // (mode 0: a wavefront stops as soon as each of its texts has shown one match end, so on texts full
         // of matches the pass costs next to nothing; cutting tails -- mode 1 -- would scan everything)
         if (int rc = bscan_limits(h, lay, n, 0, s, &lay2, &d_blimit)) return rc;
       }
       // big tables: only the wavefront kernel has their form; many short texts stay on the literal restatement
-      if ((p.flags & PF_STEP_BIG) && !req_wave && !wstep_mwalk) step_ok = false;
+      if ((p.flags & PF_STEP_BIG) && !req_wave && !wstep_mwalk && !wstep_bm) step_ok = false;
       ScanTimer tm(s);
       // multi-walk plans: count, prefix sums, emit -- two one-pass scans whatever the match density (the count pass
       // keeps no start registers and runs at 3 TB/s; slot rows + a second walk for overflowing texts would be three)
@@ -4791,7 +4978,7 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
           MRX_REQWAVE_LAUNCH(STEP_SLOTS, h, lay2, n, d_counts, (const int64_t*)nullptr, d_slots, (int64_t)0, s);
         else
         {
-        MRX_WSTEP_LAUNCH(STEP_SLOTS, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_lds(pk, wstep_mwalk), s, pk,
+        MRX_WSTEP_LAUNCH(STEP_SLOTS, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_lds(pk, wstep_mwalk, wstep_bm_big), s, pk,
                            H_BLOB(h), lay2, n, d_counts, (const int64_t*)nullptr, d_slots, (int64_t)0,
                            (int32_t*)nullptr, (int32_t*)nullptr);
         if (step_split > 0)
@@ -4800,7 +4987,7 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
       } else if (step_ok && req_wave)
         MRX_REQWAVE_LAUNCH(STEP_COUNT, h, lay, n, d_counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0, s);
       else if (step_ok) {
-        MRX_WSTEP_LAUNCH(STEP_COUNT, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_lds(pk, wstep_mwalk), s, pk,
+        MRX_WSTEP_LAUNCH(STEP_COUNT, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_lds(pk, wstep_mwalk, wstep_bm_big), s, pk,
                            H_BLOB(h), lay2, n, d_counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0,
                            (int32_t*)nullptr, (int32_t*)nullptr);
         if (step_split > 0)
@@ -4813,7 +5000,7 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
         MRX_BT_DISPATCH(bt_kernel_kind(h, plan_uses_backtracker(h)), MRX_L);
 #undef MRX_L
       }
-      g_last_kernel = req_wave ? "k_req_wave" : step_ok ? (wstep_mwalk ? (step_split > 0 ? "k_mwalk+k_req_wave" : "k_mwalk") : wstep_bits ? "k_bstep_count" : wstep_empty ? "k_estep_count" : step_split > 0 ? "k_step_count+k_req_wave" : "k_step_count")
+      g_last_kernel = req_wave ? "k_req_wave" : step_ok ? (wstep_mwalk ? (step_split > 0 ? "k_mwalk+k_req_wave" : "k_mwalk") : wstep_bm ? "k_backscan+k_step_count" : wstep_bits ? "k_bstep_count" : wstep_empty ? "k_estep_count" : step_split > 0 ? "k_step_count+k_req_wave" : "k_step_count")
                                                         : "k_findall_count";
       HIP_TRY(hipGetLastError());
       tm.stop();
@@ -4873,10 +5060,10 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
       if (step_ok && mwalk_two_pass) {   // second scan, texts that hold a match: spans straight to their CSR place
         Layout lay_e = lay2;
         lay_e.wide_slots = 2;
-        MRX_WSTEP_LAUNCH(STEP_EMIT, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_lds(pk, wstep_mwalk), s, pk, H_BLOB(h),
+        MRX_WSTEP_LAUNCH(STEP_EMIT, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_lds(pk, wstep_mwalk, wstep_bm_big), s, pk, H_BLOB(h),
                          lay_e, n, d_counts, d_prefix, d_spans, span_cap, (int32_t*)nullptr, (int32_t*)nullptr);
       } else if (step_ok && wstep_empty) {   // second walk, every text: spans straight to their CSR place
-        MRX_WSTEP_LAUNCH(STEP_EMIT, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_lds(pk, wstep_mwalk), s, pk, H_BLOB(h),
+        MRX_WSTEP_LAUNCH(STEP_EMIT, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_lds(pk, wstep_mwalk, wstep_bm_big), s, pk, H_BLOB(h),
                          lay2, n, (int32_t*)nullptr, d_prefix, d_spans, span_cap, (int32_t*)nullptr, (int32_t*)nullptr);
       } else if (step_ok) {
         if (lay2.wide_slots)
@@ -4889,7 +5076,7 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
         if (req_wave)
           MRX_REQWAVE_LAUNCH(STEP_EMIT, h, lay2, n, d_counts, d_prefix, d_spans, span_cap, s);
         else {
-        MRX_WSTEP_LAUNCH(STEP_EMIT, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_lds(pk, wstep_mwalk), s, pk, H_BLOB(h),
+        MRX_WSTEP_LAUNCH(STEP_EMIT, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_lds(pk, wstep_mwalk, wstep_bm_big), s, pk, H_BLOB(h),
                            lay2, n, d_counts, d_prefix, d_spans, span_cap, (int32_t*)nullptr,
                            (int32_t*)nullptr);
         if (step_split > 0) MRX_REQWAVE_LAUNCH(STEP_EMIT, h, lay2, n, d_counts, d_prefix, d_spans, span_cap, s);
@@ -5554,11 +5741,11 @@ static int run_count_any(const mrx_handle* h, const Layout& lay, int64_t n, int3
     int split = 0;
     if (g_force_generic < 2 && !wstep_bits && !t_in_pieces && (h->hp.dev.flags & (PF_STEPPABLE | PF_STEP_REQ)) &&
         !(h->hp.dev.flags & (PF_STEP_BIG | PF_STREAMABLE)) && h->hp.dev.st_nsync > 0 &&
-        (!use_req_route || g_long_text_mode == 1)) {
+        (!use_req_route || mwalk_req || g_long_text_mode == 1)) {
       // long texts: disjoint pieces between synchronising bytes, one lane each (see run_findall)
       Pieces spc;
-      if (int rc = pieces_prepare(h, lay, n, s, &spc, -1, -1, /*disjoint=*/true)) return rc;
-      if (spc.on) {
+      if (int rc = pieces_prepare(h, lay, n, s, &spc, -1, -1, /*disjoint=*/true, wstep_mwalk)) return rc;
+      if (spc.on && !wstep_mwalk) {
         bool dense = true;
         if (int rc = dense_candidates(h, lay, n, s, &dense)) return rc;
         if (!dense)
@@ -5579,22 +5766,27 @@ static int run_count_any(const mrx_handle* h, const Layout& lay, int64_t n, int3
     }
     if (g_force_generic < 2 && !wstep_bits && !t_in_pieces && (h->hp.dev.flags & (PF_STEPPABLE | PF_STEP_REQ)))
       if (int rc = req_wave_pays(lay, n, use_req_route, s, &req_wave, (h->hp.dev.flags & PF_STEP_BIG) ? nullptr : &split,
-                                 (h->hp.dev.flags & PF_STEP_BIG) != 0, wstep_mwalk))
+                                 (h->hp.dev.flags & PF_STEP_BIG) != 0, wstep_mwalk, backset_on(h->hp.dev) && !wstep_mwalk))
         return rc;
     Layout lay2 = lay;
     lay2.split = split;
     int32_t* d_blimit = nullptr;
-    if (g_force_generic < 2 && !wstep_mwalk && (wstep_bits || (!req_wave && split == 0 && !use_req_route && union_pass_for_table_plan(h->hp.dev, false))))
+    const bool wstep_bm = backset_on(h->hp.dev) && !wstep_mwalk && !wstep_bits && !wstep_empty && !use_req_route && !req_wave &&
+                          split == 0 && (h->hp.dev.flags & PF_STEPPABLE);
+    const bool wstep_bm_big = wstep_bm && (h->hp.dev.flags & PF_STEP_BIG) != 0;
+    if (wstep_bm)
+      if (int rc = backscan_marks(h, lay, n, s, &lay2)) return rc;
+    if (g_force_generic < 2 && !wstep_mwalk && !wstep_bm && (wstep_bits || (!req_wave && split == 0 && !use_req_route && union_pass_for_table_plan(h->hp.dev, false))))
       if (int rc = bscan_limits(h, lay, n, 0, s, &lay2, &d_blimit)) return rc;   // union automaton first
-    const bool big_lane = (h->hp.dev.flags & PF_STEP_BIG) && !req_wave && !wstep_mwalk;   // -> literal restatement
+    const bool big_lane = (h->hp.dev.flags & PF_STEP_BIG) && !req_wave && !wstep_mwalk && !wstep_bm;   // -> literal restatement
     if (req_wave) {
       MRX_REQWAVE_LAUNCH(STEP_COUNT, h, lay, n, counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0, s);
       g_last_kernel = "k_req_wave";
     } else if (g_force_generic < 2 && !big_lane && ((h->hp.dev.flags & (PF_STEPPABLE | PF_STEP_REQ | PF_STEP_EMPTY)) || wstep_mwalk)) {
-      MRX_WSTEP_LAUNCH(STEP_COUNT, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_lds(pk, wstep_mwalk), s, pk,
+      MRX_WSTEP_LAUNCH(STEP_COUNT, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_lds(pk, wstep_mwalk, wstep_bm_big), s, pk,
                          H_BLOB(h), lay2, n, counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0,
                          (int32_t*)nullptr, (int32_t*)nullptr);
-      g_last_kernel = wstep_mwalk ? "k_mwalk" : wstep_bits ? "k_bstep_count" : wstep_empty ? "k_estep_count" : "k_step_count";
+      g_last_kernel = wstep_mwalk ? "k_mwalk" : wstep_bm ? "k_backscan+k_step_count" : wstep_bits ? "k_bstep_count" : wstep_empty ? "k_estep_count" : "k_step_count";
       if (split > 0) {
         MRX_REQWAVE_LAUNCH(STEP_COUNT, h, lay2, n, counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0, s);
         g_last_kernel = "k_step_count+k_req_wave";

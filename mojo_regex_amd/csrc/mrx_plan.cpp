@@ -303,6 +303,77 @@ bool build_multiwalk(const SearchAutomaton& s, MultiWalk& mw, std::string& why) 
   return true;
 }
 
+// ---- where do matches begin?  (backward table, DevPlan::off_bk_*) -----------------------------------------------------
+// The restart-per-position search spends its time on walks that fail.  Whether the walk from position s succeeds
+// does not depend on the search's history -- only on the text from s on -- so it can be known for EVERY s before the
+// search runs: scan the text right to left keeping B(s) = { q : some prefix of text[s:] leads q into an accepting
+// state }, B(len) = accepting states, B(s) = accepting states + { q : next[q][text[s]] in B(s + 1) }; the walk from
+// s succeeds iff text[s] may start a walk and next[start][text[s]] lies in B(s + 1).  The sets are numbered here
+// (subset construction over the reversed table), the device keeps a set number and one table lookup per byte.
+// With the marks the forward search starts a walk only where one succeeds: `pos + 1` restarts disappear, what is
+// left of the reference's loop is "next mark at or behind pos, longest walk from it, pos = its end".
+struct BackSet {
+  std::array<uint8_t, 256> cls{};
+  int ncls = 0, cshift = 0, nsub = 0, start = 0;
+  std::vector<uint16_t> tab;
+};
+
+bool build_backset(const SearchAutomaton& s, BackSet& bk, std::string& why) {
+  if (s.acc[0]) { why = "start state accepts (empty matches)"; return false; }
+  if (s.n > 256) { why = "backward table: more than 256 states"; return false; }
+  std::vector<int> rep;
+  {
+    std::map<std::vector<int>, int> seen;
+    for (int c = 0; c < 256; ++c) {
+      std::vector<int> col(s.n + 1);
+      for (int q = 0; q < s.n; ++q) col[q] = s.next[q][c];
+      col[s.n] = s.allowed[c];
+      auto it = seen.find(col);
+      if (it == seen.end()) { it = seen.emplace(col, (int)rep.size()).first; rep.push_back(c); }
+      bk.cls[c] = (uint8_t)it->second;
+    }
+  }
+  bk.ncls = (int)rep.size();
+  bk.cshift = 0;
+  while ((1 << bk.cshift) < bk.ncls) ++bk.cshift;
+  const int ncp = 1 << bk.cshift;
+  using Set = std::vector<uint8_t>;   // membership per DFA state
+  std::map<Set, int> ids;
+  std::vector<Set> sets;
+  auto id_of = [&](const Set& b) {
+    auto it = ids.find(b);
+    if (it == ids.end()) { it = ids.emplace(b, (int)sets.size()).first; sets.push_back(b); }
+    return it->second;
+  };
+  Set accs(s.n, 0);
+  for (int q = 0; q < s.n; ++q) accs[q] = s.acc[q] ? 1 : 0;
+  bk.start = id_of(accs);
+  std::vector<std::vector<uint16_t>> rows;
+  for (size_t si = 0; si < sets.size(); ++si) {
+    if ((int64_t)sets.size() * ncp > 16384 || sets.size() > 32000) { why = "backward table beyond the LDS budget"; return false; }
+    const Set cur = sets[si];
+    std::vector<uint16_t> row(ncp, 0);
+    for (int k = 0; k < bk.ncls; ++k) {
+      const int c = rep[k];
+      Set nb = accs;
+      for (int q = 0; q < s.n; ++q) {
+        const int t = s.next[q][c];
+        if (t >= 0 && cur[t]) nb[q] = 1;
+      }
+      const int t0 = s.allowed[c] ? s.next[0][c] : -1;
+      const int mark = (t0 >= 0 && cur[t0]) ? 1 : 0;
+      row[k] = (uint16_t)((id_of(nb) << 1) | mark);
+    }
+    rows.push_back(row);
+  }
+  bk.nsub = (int)sets.size();
+  if ((int64_t)bk.nsub * ncp > 16384) { why = "backward table beyond the LDS budget"; return false; }
+  bk.tab.assign((size_t)bk.nsub * ncp, 0);
+  for (int si = 0; si < bk.nsub; ++si)
+    for (int k = 0; k < ncp; ++k) bk.tab[(size_t)si * ncp + k] = rows[si][k];
+  return true;
+}
+
 // The required-byte route (HybridMatcher._match_all_required_byte, matcher.mojo:864-898) in the same table form:
 //   pos = 0; while pos < len: hit = next required byte at or behind pos; start = hit backed up over first-class
 //   bytes; m = DFAEngine.match_first(text, start); if m and m.end > hit: report, pos = m.end; else pos = hit + 1
@@ -827,6 +898,8 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
   d.mw_ncfg = d.mw_cshift = d.mw_bytes = d.mw_k = 0;
   d.off_mwr_cls = -1;
   d.mwr_ncfg = d.mwr_cshift = d.mwr_bytes = d.mwr_k = 0;
+  d.off_bk_cls = -1;
+  d.bk_nsub = d.bk_cshift = d.bk_bytes = d.bk_start = 0;
   d.off_st_sync = -1;
   d.off_stg_pair = -1;
   d.st_nsync = 0;
@@ -1052,6 +1125,20 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
       };
       MultiWalk plain, req;
       std::string w1, w2;
+      {   // marks for the plain route (search never takes the required-byte route, nor does sub's match_next loop)
+        BackSet bk;
+        std::string bwhy;
+        if (build_backset(sa, bk, bwhy)) {
+          align(hp.blob, 16);
+          d.off_bk_cls = (int)hp.blob.size();
+          put(hp.blob, bk.cls.data(), 256);
+          put(hp.blob, bk.tab.data(), bk.tab.size() * 2);
+          d.bk_nsub = bk.nsub; d.bk_cshift = bk.cshift; d.bk_start = bk.start;
+          d.bk_bytes = 256 + (int)bk.tab.size() * 2;
+          d.flags |= PF_BACKSET;
+          align(hp.blob, 16);
+        } else hp.backset_why_not = bwhy;
+      }
       if (build_multiwalk(sa, plain, w1)) {
         store(plain, d.off_mw_cls, d.mw_ncfg, d.mw_cshift, d.mw_bytes, d.mw_k);
         d.off_mw_tab = d.off_mw_cls + 256;
@@ -1112,6 +1199,22 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
       hp.streamable_why_not = why;
       // several walks side by side (k_mwalk) where one walk does not do; plain route only (no required byte)
       if (d.required_byte < 0 && !(d.flags & (PF_PURE_LITERAL | PF_EXACT_LITERAL | PF_SCAN_ELIGIBLE))) {
+        {   // marks of the positions where a match begins, for the stepper (whatever the multi-walk builder says)
+          BackSet bk;
+          std::string bwhy;
+          if (build_backset(sa, bk, bwhy)) {
+            align(hp.blob, 16);
+            d.off_bk_cls = (int)hp.blob.size();
+            put(hp.blob, bk.cls.data(), 256);
+            put(hp.blob, bk.tab.data(), bk.tab.size() * 2);
+            d.bk_nsub = bk.nsub; d.bk_cshift = bk.cshift; d.bk_start = bk.start;
+            d.bk_bytes = 256 + (int)bk.tab.size() * 2;
+            d.flags |= PF_BACKSET;
+            align(hp.blob, 16);
+          } else {
+            hp.backset_why_not = bwhy;
+          }
+        }
         MultiWalk mw;
         std::string mwhy;
         if (build_multiwalk(sa, mw, mwhy)) {
@@ -1438,6 +1541,8 @@ std::string describe_plan(const HostPlan& hp) {
     << " mw_configs=" << d.mw_ncfg << " mw_walks=" << d.mw_k
     << " multiwalk_req=" << ((d.flags & PF_MWALK_REQ) ? "yes" : hp.mwalk_req_why_not.empty() ? "no" : "no: " + hp.mwalk_req_why_not)
     << " mwr_configs=" << d.mwr_ncfg << " mwr_walks=" << d.mwr_k
+    << " backset=" << ((d.flags & PF_BACKSET) ? "yes" : hp.backset_why_not.empty() ? "no" : "no: " + hp.backset_why_not)
+    << " bk_sets=" << d.bk_nsub
     << (d.off_stg_pair >= 0 ? " pair_table=1" : "") << "\n";
   o << "device.steppable=" << ((d.flags & PF_STEPPABLE) ? "yes" : (d.flags & PF_STEP_REQ) ? "required-byte route" : "no")
     << " step_search=" << ((d.flags & PF_STEP_SEARCH) ? 1 : 0) << ((d.flags & PF_STEP_BIG) ? " big_table=1" : "")

@@ -53,6 +53,9 @@ enum PlanFlags : uint32_t {
                                 // one", "a later start survives ...") without the stepper's re-scans
   PF_MWALK_REQ = 1u << 21,      // findall / count of a required-byte plan (PF_STEP_REQ: HybridMatcher._match_all_required_byte,
                                 // matcher.mojo:864-898) in one pass on the same kernel (DevPlan::off_mwr_*)
+  PF_BACKSET = 1u << 22,        // plain-route stepper plan with a BACKWARD table (DevPlan::off_bk_*): a right-to-left pass
+                                // marks the positions at which a match begins, the stepper then only starts walks
+                                // that succeed (k_backscan + k_wstep<., 0, 0, 0, 1>)
   PF_STREAM_SEARCH = 1u << 11   // search / sub / captures may use the streaming kernel too (findall and
                                 // count may whenever PF_STREAMABLE is set): not with a memchr prefilter,
                                 // which only match_next consults (matcher.mojo:784-796)
@@ -108,6 +111,11 @@ struct DevPlan {
   // the same table form for the required-byte route (PF_MWALK_REQ): walks begin where a run of first-class bytes
   // begins, count from the required byte that ends their run ("hits"), report only behind it; see build_reqwalk()
   int32_t off_mwr_cls, mwr_ncfg, mwr_cshift, mwr_bytes, mwr_k;
+  // backward table (PF_BACKSET): cls[256] u8 | tab[bk_nsub][1 << bk_cshift] u16.  The state of the right-to-left scan
+  // behind position s is the SET of DFA states from which the text from s on leads to an accepting state (the
+  // sets are numbered on the host); entry = next set << 1 | "a match begins at this byte" (the start state's
+  // transition on the byte lands in the set, and the byte may start a walk); bk_start = the set at the text's end.
+  int32_t off_bk_cls, bk_nsub, bk_cshift, bk_bytes, bk_start;
   // synchronising bytes of the search automaton: sync[b] != 0 when byte b takes EVERY state to the
   // same state with the same start (idle, or a new start at b) -- after such a byte the walk does not
   // depend on what came before, so a long text can be cut there (st_nsync = how many, 0 = no table)
@@ -174,7 +182,7 @@ struct HostPlan {
   DevPlan dev{};
   std::vector<uint8_t> blob;
   std::string streamable_why_not;
-  std::string mwalk_why_not, mwalk_req_why_not;
+  std::string mwalk_why_not, mwalk_req_why_not, backset_why_not;
   std::string first_stream_why_not;
 };
 

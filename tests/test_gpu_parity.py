@@ -1229,7 +1229,7 @@ def test_generated_patterns_multiwalk_equals_stepper_and_oracle(seed):
     lib = M.load_library()
     rng = np.random.default_rng(seed)
     base = b"abcxyz019 -@.fobrhelcatdg"
-    nmw = nreq = 0
+    nmw = nreq = nback = 0
     # (required-byte plans: findall / count take the route's own table, search the plain one)
     extra = ["[a-z]+@[a-z]+\\.com", "\\d{3}-\\d{4}", "[0-9]+\\.[0-9]+", "[a-z0-9._%+-]+@[a-z0-9.-]+\\.[a-z]{2,}", "\\d{3}-\\d{3}-\\d{4}",
              "[a-c]+:[0-9]+", "\\w+@\\w+", "[89]00\\d{6}"]
@@ -1240,10 +1240,11 @@ def test_generated_patterns_multiwalk_equals_stepper_and_oracle(seed):
         except (M.RegexSyntaxError, M.UnsupportedPattern):
             continue
         dsc = rx.describe()
-        if "multiwalk=yes" not in dsc and "multiwalk_req=yes" not in dsc:
+        if "multiwalk=yes" not in dsc and "multiwalk_req=yes" not in dsc and "backset=yes" not in dsc:
             continue
         nmw += 1
         nreq += "multiwalk_req=yes" in dsc
+        nback += "backset=yes" in dsc and "multiwalk=yes" not in dsc
         al = base + bytes(c for c in pb if chr(c).isalnum() or c in b" -@.") * 2
         texts = _random_texts(rng, 90, 70, al) + _random_texts(rng, 12, 700, al) + [b"", pb[:1], bytes(al[:3]) * 40]
         for j in range(0, len(texts), 5):   # long runs of one byte: walks that overlap themselves
@@ -1251,13 +1252,16 @@ def test_generated_patterns_multiwalk_equals_stepper_and_oracle(seed):
             texts[j] = (bytes([al[int(rng.integers(0, len(al)))]]) * (k // 2) + texts[j])[:k]
         with long_text_kernels(2):
             got = rx.findall_lists(texts)
-            if "multiwalk_req=yes" in dsc or "required-byte route" not in dsc:
+            if "multiwalk=yes" not in dsc and "multiwalk_req=yes" not in dsc:   # marks of the match starts + the stepper
+                # (tables of more than 96 states: the marked stepper in its class-indexed form)
+                assert lib.mrx_last_kernel_name() in (b"k_backscan+k_step_count", b"k_req_wave"), (p, lib.mrx_last_kernel_name())
+            elif "multiwalk_req=yes" in dsc or "required-byte route" not in dsc:
                 assert lib.mrx_last_kernel_name() == b"k_mwalk", (p, lib.mrx_last_kernel_name())
             gs, ge = rx.match_next(texts)
             gc = rx.count(M.DeviceBatch.from_texts(texts)).cpu().numpy()
             with multiwalk(2):
                 want = rx.findall_lists(texts)
-                assert lib.mrx_last_kernel_name() != b"k_mwalk"
+                assert lib.mrx_last_kernel_name() not in (b"k_mwalk", b"k_backscan+k_step_count")
                 ws, we = rx.match_next(texts)
         texts_h = texts   # (texts with the required byte doubled / hits inside matches / hits without a run in front)
         if "multiwalk_req=yes" in dsc:
@@ -1275,7 +1279,7 @@ def test_generated_patterns_multiwalk_equals_stepper_and_oracle(seed):
         assert [int(x) for x in gc] == [len(g) for g in got], p
         for j in range(0, len(texts), 13):
             assert got[j] == O.findall(pb, texts[j]), (p, texts[j])
-    assert nmw > 40 and nreq >= 5, (nmw, nreq)
+    assert nmw > 60 and nreq >= 5 and nback >= 15, (nmw, nreq, nback)
 
 
 @pytest.mark.parametrize("pat,repl", [(b"\\w+\\d{2}", b"<W>"), (b"\\d+(\\.\\d+)?", b"N"), (b"(foo|foobar)", b""),
@@ -1490,7 +1494,7 @@ def test_required_byte_route_one_wavefront_per_text(pat):
         sb = M.DeviceBatch.strided(torch.from_numpy(arr).cuda().reshape(-1), pitch, length=pitch,
                                    lens=torch.from_numpy(lens).cuda())
         pre, sp, tot = rx._dev_findall(sb)           # by average length: 4 KiB rows are cut into pieces, or take the wavefront kernel
-        assert lib.mrx_last_kernel_name() in (b"k_req_wave", b"k_step_count_pieces"), lib.mrx_last_kernel_name()
+        assert lib.mrx_last_kernel_name() in (b"k_req_wave", b"k_step_count_pieces", b"k_mwalk_pieces"), lib.mrx_last_kernel_name()
         with long_text_kernels(3):
             pre3, sp3, tot3 = rx._dev_findall(sb)
             assert lib.mrx_last_kernel_name() == b"k_req_wave"
@@ -1565,7 +1569,8 @@ def test_stepper_on_fixed_pitch_batches(pat, n, pitch, var, mw):
     has_mw = mw == 0 and "multiwalk=yes" in rx.describe()
     with long_text_kernels(2), multiwalk(mw):   # this test is about the lane-per-text kernels
         pre, sp, tot = rx._dev_findall(batch)
-        assert lib.mrx_last_kernel_name() == (b"k_mwalk" if has_mw else b"k_step_count")
+        has_bk = mw == 0 and not has_mw and "backset=yes" in rx.describe() and "required-byte route" not in rx.describe()
+        assert lib.mrx_last_kernel_name() == (b"k_mwalk" if has_mw else b"k_backscan+k_step_count" if has_bk else b"k_step_count")
         ss, se = rx.match_next(batch)
         if has_mw and b"@" not in pat:
             assert lib.mrx_last_kernel_name() == b"k_mwalk_search"

@@ -14,7 +14,7 @@ batches = {"noise": (torch.randint(0, 95, (n, L), generator=g, device="cuda") + 
            "config2_mix": make_c2_batch(n, L, device="cuda"), "phone": make_phone_batch(n, L, device="cuda")}
 lib = M.load_library()
 pats = [b"\\w+\\d{2}", b"\\d+(\\.\\d+)?", b"(foo|foobar)x", b"[a-z]{2}-9*", b"(?:xy){4}@{2}", b"[a-z]+@[a-z]+\\.com", b"\\d{3}-\\d{4}",
-        b"[0-9]+\\.[0-9]+", b"\\d{3}-\\d{3}-\\d{4}"]
+        b"[0-9]+\\.[0-9]+", b"\\d{3}-\\d{3}-\\d{4}", b"[A-Z]{10,20}[0-9]{15,25}", b"foo|[a-z]{3}\\d|[ab]", b"xy[a-z]+\\d{2,}|[0-9a-f]|hello"]
 def timed(fn, reps=3):
     fn(); torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -25,7 +25,7 @@ for name, d in batches.items():
     batch = M.DeviceBatch.strided(d.reshape(-1), L, length=L)
     for pat in pats:
         rx = M.compile_regex(pat)
-        if "multiwalk=yes" not in rx.describe() and "multiwalk_req=yes" not in rx.describe():
+        if "multiwalk=yes" not in rx.describe() and "multiwalk_req=yes" not in rx.describe() and "backset=yes" not in rx.describe():
             print(json.dumps({"batch": name, "pattern": pat.decode(), "multiwalk": False})); continue
         row = {"batch": name, "pattern": pat.decode()}
         for mode, tag in ((0, "mwalk"), (2, "stepper")):
