@@ -58,12 +58,14 @@ struct Layout {  // where text i lives
   // per text: first occurrence of the backtracking matcher's literal, last occurrence << 1 | has-newline
   // (k_litscan in front of the lane-per-text kernels, see bt_prepass()); nullptr = not computed
   const int2* pre = nullptr;
-  // marks of the positions at which a match begins (k_backscan -> k_wstep<., 0, 0, 0, 1>): one bit per text byte,
-  // text i's words from bm_row(i) on; bm_cnt[i] = how many marks text i has
+  // marks of the positions at which a match begins (k_backscan -> k_wstep<., 0, 0, 0, 1>): one bit per byte of the
+  // text's FRAME (the 16-byte blocks that hold it: bit f = frame position f, the text begins at f = address & 15),
+  // text i's words from bm_row(i) on -- a multiple of four, so that the four words of a 128-byte window are one
+  // aligned 16-byte load; bm_cnt[i] = how many marks text i has
   const uint32_t* bm = nullptr;
   const int32_t* bm_cnt = nullptr;
   __host__ __device__ __forceinline__ int64_t bm_row(int64_t i) const {
-    return offsets ? (offsets[i] >> 5) + 2 * i : i * ((stride >> 5) + 2);
+    return 4 * (offsets ? (offsets[i] >> 7) + 2 * i : i * ((stride >> 7) + 2));
   }
   // first slot of text i's row and the row's capacity (wide rows)
   __device__ __forceinline__ int64_t slot_row(int64_t i, int* cap) const {
@@ -386,9 +388,11 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_wstep(DevPlan p, const uint8_
     uint64_t bset = 0;   // BITS: live positions of the current walk (0 = looking for a start)
     const bool skipped = lay.split > 0 && t.len >= lay.split;   // k_req_wave's text
     bool fin = !live || t.len == 0 || skipped;
-    const uint32_t* mybm = nullptr;      // BM: my text's marks
+    const uint32_t* mybm = nullptr;      // BM: my text's marks (frame coordinates)
     int bm_idx = -1;
     uint32_t bm_word = 0;
+    uint4 bm_win = make_uint4(0, 0, 0, 0);   // the four words of the current window
+    int bm_wb = -(1 << 30);
     if (BM && live) {
       mybm = lay.bm + lay.bm_row(i);
       if (lay.bm_cnt[i] == 0) fin = true;   // no match begins anywhere in my text
@@ -427,6 +431,10 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_wstep(DevPlan p, const uint8_
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       if (wb + CH < max_end) MRX_WS_LOAD(wb + CH);   // next window, in flight while this one is stepped
+      if (BM) {   // this window's marks: one aligned 16-byte load per lane
+        if (!fin && wb < end) bm_win = *(const uint4*)(mybm + (wb >> 5));
+        bm_wb = wb;
+      }
       // One step of the search for this lane, given the byte at `pos` (ignored when act is false
       // or the text has ended).  Branch-free apart from the span store.
       auto step = [&](bool act, uint32_t byte) {
@@ -469,11 +477,18 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_wstep(DevPlan p, const uint8_
         }
         if (BM) {
           if (act && state == idle && inside) {   // looking for a start: on to the next mark
-            const int tp = pos - mis;
-            if ((tp >> 5) != bm_idx) { bm_idx = tp >> 5; bm_word = mybm[bm_idx]; }
-            const uint32_t rest = bm_word >> (tp & 31);
+            uint32_t wv;
+            const int rel = pos - bm_wb;
+            if (rel >= 0 && rel < CH) {   // the window's marks are in registers
+              const int j = rel >> 5;
+              wv = j == 0 ? bm_win.x : j == 1 ? bm_win.y : j == 2 ? bm_win.z : bm_win.w;
+            } else {
+              if ((pos >> 5) != bm_idx) { bm_idx = pos >> 5; bm_word = mybm[bm_idx]; }
+              wv = bm_word;
+            }
+            const uint32_t rest = wv >> (pos & 31);
             if (!(rest & 1u)) {
-              pos += rest ? __builtin_ctz(rest) : 32 - (tp & 31);
+              pos += rest ? __builtin_ctz(rest) : 32 - (pos & 31);
               return;
             }
           }
@@ -793,12 +808,14 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_backscan(DevPlan p, const uin
         const int f = wb + it;
         const bool act = live && f >= mis && f < end;
         const uint32_t en = tab[st + clsT[myrow[it]]];
-        const int pr = f - mis;
         if (act) {
           st = (uint32_t)(en >> 1) << p.bk_cshift;
-          word |= (uint32_t)(en & 1u) << (pr & 31);
+          word |= (uint32_t)(en & 1u) << (f & 31);
           marks += (int)(en & 1u);
-          if ((pr & 31) == 0) { myout[pr >> 5] = word; word = 0; }
+        }
+        if ((f & 31) == 0) {   // (the same step for every lane)
+          if (live && f < end && f + 32 > mis) myout[f >> 5] = word;
+          word = 0;
         }
       }
       __builtin_amdgcn_wave_barrier();
@@ -3924,9 +3941,9 @@ int backscan_marks(const mrx_handle* h, const Layout& lay, int64_t n, hipStream_
       HIP_TRY(hipMemcpyAsync(&total, lay.offsets + n, sizeof total, hipMemcpyDeviceToHost, s));
       HIP_TRY(hipStreamSynchronize(s));
     }
-    words = (total >> 5) + 2 * n + 4;
+    words = 4 * ((total >> 7) + 2 * n + 2);
   } else {
-    words = n * ((lay.stride >> 5) + 2) + 4;
+    words = 4 * (n * ((lay.stride >> 7) + 2) + 2);
   }
   uint32_t* d_bm = nullptr;
   int32_t* d_cnt = nullptr;
@@ -4889,7 +4906,7 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
       }
     } else {
       if (step_ok && !wstep_bits && !wstep_empty && !t_in_pieces && !(p.flags & PF_STEP_BIG) && p.st_nsync > 0 &&
-          !(p.flags & PF_STREAMABLE) && span_cap > 0 && (!use_req_route || mwalk_req || g_long_text_mode == 1)) {
+          !(p.flags & PF_STREAMABLE) && span_cap > 0 && (!use_req_route || g_long_text_mode == 1)) {
         Pieces spc;
         if (int rc = pieces_prepare(h, lay, n, s, &spc, -1, -1, /*disjoint=*/true, wstep_mwalk)) return rc;
         if (spc.on && !wstep_mwalk) {   // (a multi-walk plan scans every piece once, dense candidates or not)
@@ -5741,7 +5758,7 @@ static int run_count_any(const mrx_handle* h, const Layout& lay, int64_t n, int3
     int split = 0;
     if (g_force_generic < 2 && !wstep_bits && !t_in_pieces && (h->hp.dev.flags & (PF_STEPPABLE | PF_STEP_REQ)) &&
         !(h->hp.dev.flags & (PF_STEP_BIG | PF_STREAMABLE)) && h->hp.dev.st_nsync > 0 &&
-        (!use_req_route || mwalk_req || g_long_text_mode == 1)) {
+        (!use_req_route || g_long_text_mode == 1)) {
       // long texts: disjoint pieces between synchronising bytes, one lane each (see run_findall)
       Pieces spc;
       if (int rc = pieces_prepare(h, lay, n, s, &spc, -1, -1, /*disjoint=*/true, wstep_mwalk)) return rc;
