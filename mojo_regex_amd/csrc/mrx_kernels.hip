@@ -618,10 +618,22 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_mwalk(DevPlan p, const uint8_
   constexpr int CH = 128, kRowPitch = CH + 16, LPR = CH / 16, RPI = 64 / LPR, NL = 64 / RPI;
   __shared__ __align__(16) uint8_t tiles[kWsWaves][64 * kRowPitch];
   extern __shared__ __align__(16) uint8_t lds[];
+  // PRE: the tables as LDS ADDRESSES -- cls4[byte] = 4 x class (at most 64 classes: it stays a byte), and an entry's
+  // bits 16.. = LDS byte address of the next configuration's row instead of its index -- so that a byte's entry is at
+  // (entry >> 16) + cls4[byte]: one add (the compiler folds the shift into its operand select) instead of shift,
+  // shift, add3.  Needs the table to end below 64 KiB of LDS.
+  typedef __attribute__((address_space(3))) const uint8_t lds_cu8;
+  typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
+  const uint32_t lds_base = (uint32_t)(uintptr_t)lds;   // (the low half of a flat LDS address is the LDS offset)
+  const bool pre = p.mw_cshift <= 6 && lds_base + (uint32_t)p.mw_bytes <= 65536u;
   {
     const uint32_t* src = (const uint32_t*)(blob + p.off_mw_cls);   // cls[256] | tab[...], contiguous and 16-byte aligned
     uint32_t* dst = (uint32_t*)lds;
-    for (int e = threadIdx.x; e < (p.mw_bytes >> 2); e += blockDim.x) dst[e] = src[e];
+    for (int e = threadIdx.x; e < (p.mw_bytes >> 2); e += blockDim.x) {
+      uint32_t w = src[e];
+      if (pre) w = e < 64 ? (w << 2) & 0xFCFCFCFCu : (w & 0xFFFFu) | ((((w >> 16) << 2) + lds_base + 256u) << 16);
+      dst[e] = w;
+    }
   }
   __syncthreads();
   const uint8_t* clsT = lds;
@@ -662,7 +674,7 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_mwalk(DevPlan p, const uint8_
       }
     }
     if (MODE == STEP_SLOTS) wo = 0;
-    uint32_t e = 0;            // the last entry taken: bits 16.. = row of the current configuration
+    uint32_t e = pre ? (lds_base + 256u) << 16 : 0u;   // the last entry taken: bits 16.. = row of the current configuration
     int s0 = 0, s1 = 0, s2 = 0, s3 = 0, last = 0, k = 0, rs = -1, re = -1;
     auto report = [&](int a, int b) {
       if (MODE == STEP_EMIT) {
@@ -696,41 +708,64 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_mwalk(DevPlan p, const uint8_
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       if (wb + CH < max_end) MRX_MW_LOAD(wb + CH);   // next window, in flight while this one is stepped
-#pragma unroll 8
-      for (int it = 0; it < CH; ++it) {
-        const int f = wb + it;                        // frame position, the same for every lane
-        const bool act = !fin && f >= mis && f < end;
-        const uint32_t cl = clsT[myrow[it]];
-        const uint32_t en = tab[(e >> 16) + cl];
-        const int pr = f - mis;                       // text position of this byte
-        if (act && (en & 1u)) report(s0, last);      // the oldest walk ended behind its last accepting position (rare branch)
-        // the start registers move as the entry says; plain selects, no branches (code 0 = stays; a lane that is
-        // not stepping takes code 0 everywhere)
-        const uint32_t ea = act ? en : 0u;
-        const uint32_t c0 = (ea >> 2) & 7u, c1 = (ea >> 5) & 3u;
-        int n0 = s0, n1 = s1;
-        n0 = c0 == 1u ? s1 : n0;
-        n0 = c0 == 4u ? pr : n0;
-        n1 = c1 == 3u ? pr : n1;
-        if (KW > 2) {
-          const uint32_t c2 = (ea >> 7) & 3u;
-          int n2 = s2;
-          n0 = c0 == 2u ? s2 : n0;
-          n1 = c1 == 1u ? s2 : n1;
-          n2 = c2 == 2u ? pr : n2;
-          if (KW > 3) {
-            const uint32_t c3 = (ea >> 9) & 1u;
-            n0 = c0 == 3u ? s3 : n0;
-            n1 = c1 == 2u ? s3 : n1;
-            n2 = c2 == 1u ? s3 : n2;
-            s3 = c3 == 1u ? pr : s3;
-          }
-          s2 = n2;
+      // One byte.  ACT: is this lane stepping (a wavefront whose 64 texts all cover the 16-byte group, none of them
+      // finished, steps without the test -- FULL); PRE_: the tables hold LDS addresses (above)
+#define MRX_MW_BYTE(BYTE_, F_, FULL_, PRE_)                                                                          \
+      do {                                                                                                           \
+        const int f = (F_);                           /* frame position, the same for every lane */                  \
+        const bool act = (FULL_) || (!fin && f >= mis && f < end);                                                   \
+        uint32_t en;                                                                                                 \
+        if (PRE_) en = *(lds_cu32*)(uintptr_t)((e >> 16) + *(lds_cu8*)(uintptr_t)(lds_base + (BYTE_)));               \
+        else en = tab[(e >> 16) + clsT[(BYTE_)]];                                                                    \
+        const int pr = f - mis;                       /* text position of this byte */                               \
+        if (act && (en & 1u)) report(s0, last);      /* the oldest walk ended behind its last accepting position (rare branch) */ \
+        /* the start registers move as the entry says; plain selects, no branches (code 0 = stays; a lane that is    \
+           not stepping takes code 0 everywhere) */                                                                  \
+        const uint32_t ea = act ? en : 0u;                                                                           \
+        if (MODE != STEP_COUNT && MODE != STEP_ANY) {                                                                \
+        const uint32_t c0 = (ea >> 2) & 7u, c1 = (ea >> 5) & 3u;                                                     \
+        int n0 = s0, n1 = s1;                                                                                        \
+        n0 = c0 == 1u ? s1 : n0;                                                                                     \
+        n0 = c0 == 4u ? pr : n0;                                                                                     \
+        n1 = c1 == 3u ? pr : n1;                                                                                     \
+        if (KW > 2) {                                                                                                \
+          const uint32_t c2 = (ea >> 7) & 3u;                                                                        \
+          int n2 = s2;                                                                                               \
+          n0 = c0 == 2u ? s2 : n0;                                                                                   \
+          n1 = c1 == 1u ? s2 : n1;                                                                                   \
+          n2 = c2 == 2u ? pr : n2;                                                                                   \
+          if (KW > 3) {                                                                                              \
+            const uint32_t c3 = (ea >> 9) & 1u;                                                                      \
+            n0 = c0 == 3u ? s3 : n0;                                                                                 \
+            n1 = c1 == 2u ? s3 : n1;                                                                                 \
+            n2 = c2 == 1u ? s3 : n2;                                                                                 \
+            s3 = c3 == 1u ? pr : s3;                                                                                 \
+          }                                                                                                          \
+          s2 = n2;                                                                                                   \
+        }                                                                                                            \
+        s0 = n0; s1 = n1;                                                                                            \
+        last = (ea & 2u) ? pr + 1 : last;                                                                            \
+        }                                                                                                            \
+        e = act ? en : e;                                                                                            \
+      } while (0)
+      for (int g = 0; g < CH / 16; ++g) {
+        const int f0 = wb + g * 16;
+        const uint4 wv = *(const uint4*)(myrow + g * 16);
+        const uint32_t words[4] = {wv.x, wv.y, wv.z, wv.w};
+        // (search modes: a lane that has its answer stops stepping -- `fin` changes inside a group)
+        const bool all_full = pre && MODE != STEP_SEARCH && MODE != STEP_ANY && __all(!fin && f0 >= mis && f0 + 16 <= end);
+        if (all_full) {
+#pragma unroll
+          for (int q = 0; q < 16; ++q) MRX_MW_BYTE((words[q >> 2] >> ((q & 3) * 8)) & 0xFFu, f0 + q, true, true);
+        } else if (pre) {
+#pragma unroll
+          for (int q = 0; q < 16; ++q) MRX_MW_BYTE((words[q >> 2] >> ((q & 3) * 8)) & 0xFFu, f0 + q, false, true);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 16; ++q) MRX_MW_BYTE((words[q >> 2] >> ((q & 3) * 8)) & 0xFFu, f0 + q, false, false);
         }
-        s0 = n0; s1 = n1;
-        last = (ea & 2u) ? pr + 1 : last;
-        e = act ? en : e;
       }
+#undef MRX_MW_BYTE
       __builtin_amdgcn_wave_barrier();
       if (__all(fin || wb + CH >= end)) break;
     }
@@ -842,8 +877,13 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_backscan(DevPlan p, const uin
 // lockstep) and writes for every text the length the second pass (k_wstep<., 0, 1>) has to look at:
 // mode 0 (search) the whole text if it has a match end, else 0; mode 1 (count / findall) the last match
 // end, 0 if none.  W32: at most 32 positions -- 32-bit sets.
+// 32-bit sets: the follow tables are indexed by chunks of up to 11 positions instead of 8 (2048 entries each) --
+// 11 positions need one lookup per byte instead of two, 22 two instead of three
+__host__ __device__ inline int bscan_nch32(int npos) { return (npos + 10) / 11; }
+__host__ __device__ inline int bscan_cb32(int npos) { const int c = bscan_nch32(npos); return c ? (npos + c - 1) / c : 8; }
 __host__ __device__ inline size_t bscan_table_bytes(int npos) {
-  return npos <= 32 ? (size_t)2048 + (size_t)((npos + 7) / 8) * 1024 : (size_t)4096 + (size_t)((npos + 7) / 8) * 2048;
+  return npos <= 32 ? (size_t)2048 + (size_t)bscan_nch32(npos) * ((size_t)4 << bscan_cb32(npos))
+                    : (size_t)4096 + (size_t)((npos + 7) / 8) * 2048;
 }
 // DFA = 1: the same pass for a table plan of the stepper's plain route (PF_STEPPABLE, at most 32 states):
 // U is the set of DFA STATES some walk is in.  A state's successor depends on the byte, so the follow
@@ -853,10 +893,21 @@ __host__ __device__ inline size_t bscan_table_bytes(int npos) {
 __host__ __device__ inline size_t bscan_dfa_table_bytes(int nstates, int ncls) {
   return (size_t)2048 + (size_t)ncls * ((nstates + 7) / 8) * 1024;
 }
-template <int W32, int DFA = 0>
+// NCH: follow-table lookups per byte where the launch site knows them (no branch per lookup); CHB: bytes of a text per
+// tile row -- 64 halves the tile, so that five workgroups instead of three share a CU's LDS (the pass waits on LDS
+// round trips: a byte's set depends on the lookup of the byte before)
+template <int W32, int DFA = 0, int NCH = 0, int CHB = 128>
 __global__ __launch_bounds__(64 * kWsWaves) void k_bscan(DevPlan p, const uint8_t* __restrict__ blob, Layout lay,
-                                                         int64_t n, int mode, int32_t* __restrict__ limit) {
-  constexpr int CH = 128, kRowPitch = CH + 16, LPR = CH / 16, RPI = 64 / LPR, NL = 64 / RPI;
+                                                         int64_t n, int mode, int32_t* __restrict__ limit,
+                                                         int32_t* __restrict__ out2 = nullptr,
+                                                         const int64_t* __restrict__ prefix = nullptr,
+                                                         int64_t span_cap = 0) {
+  // Modes 2-4 (programs whose matches all have one length L, DevPlan::bs_fixed_len): the restart-per-position loop
+  // takes a match end e iff e - L does not lie inside the match taken before, so this pass IS the findall --
+  // 2: limit[i] = number of matches; 3: their spans at prefix[i] (limit[i] = count of mode 2: texts without a
+  // match are skipped); 4: search, limit[i] / out2[i] = start / end of the first match, -1 without one; 5: as 2, and
+  // the spans into the text's slot row (L >= 4: a row of len / 4 + 32 slots holds them all).
+  constexpr int CH = CHB, kRowPitch = CH + 16, LPR = CH / 16, RPI = 64 / LPR, NL = 64 / RPI;
   static_assert(!DFA || W32, "the state-set form is 32 bits wide");
   using Set = typename std::conditional<W32 != 0, uint32_t, uint64_t>::type;
   struct Ent { Set mask, sm; };   // positions that consume the byte (DFA: offset of the class's follow tables); what a walk starting on it adds
@@ -864,7 +915,9 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_bscan(DevPlan p, const uint8_
   extern __shared__ __align__(16) uint8_t lds[];
   Ent* tbl = (Ent*)lds;
   Set* fol = (Set*)(tbl + 256);
-  const int nch = DFA ? (p.nstates + 7) >> 3 : (p.bs_npos + 7) >> 3;
+  const int nch = NCH ? NCH : DFA ? (p.nstates + 7) >> 3 : W32 ? bscan_nch32(p.bs_npos) : (p.bs_npos + 7) >> 3;
+  const int cb = (W32 && !DFA) ? bscan_cb32(p.bs_npos) : 8;   // positions per follow-table chunk
+  const uint32_t cmask = (1u << cb) - 1u;
   Set bmatch = (Set)p.bs_match[0];
   if (DFA) {
     const uint8_t* g_cls = blob + p.off_cls;
@@ -911,11 +964,11 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_bscan(DevPlan p, const uint8_
       t.sm = (Set)((!filt || g_first[e]) ? (p.bs_start[0] & m) : 0ull);
       tbl[e] = t;
     }
-    for (int e = threadIdx.x; e < nch * 256; e += blockDim.x) {
-      const int j = e >> 8, v = e & 255;
+    for (int e = threadIdx.x; e < (nch << cb); e += blockDim.x) {
+      const int j = e >> cb, v = e & (int)cmask;
       uint64_t u = 0;
-      for (int k = 0; k < 8; ++k)
-        if (((v >> k) & 1) && 8 * j + k < p.bs_npos) u |= g_fol[8 * j + k];
+      for (int k = 0; k < cb; ++k)
+        if (((v >> k) & 1) && cb * j + k < p.bs_npos) u |= g_fol[cb * j + k];
       fol[e] = (Set)u;
     }
   }
@@ -927,11 +980,22 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_bscan(DevPlan p, const uint8_
   for (int64_t w = (int64_t)blockIdx.x * kWsWaves + wave; w < nw; w += (int64_t)gridDim.x * kWsWaves) {
     const int64_t i = (w << 6) + lane;
     const bool live = i < n;
-    const Text t = live ? lay.text(i) : Text(blob, 0);
+    Text t = live ? lay.text(i) : Text(blob, 0);
+    if (mode == 3 && live && limit[i] == 0) t = Text(blob, 0);   // emit pass: nothing to find here
+    if (mode == 3 && __all(t.len == 0)) continue;
     const uintptr_t addr = t.len > 0 ? (uintptr_t)t.ptr : (uintptr_t)blob;   // empty rows park on the blob
     const int mis = t.len > 0 ? (int)(addr & 15) : 0;
     const uintptr_t rb = addr & ~(uintptr_t)15;
     const int end = mis + t.len;   // frame coordinates: the text is [mis, end)
+    const int L = p.bs_fixed_len;
+    int taken_end = mis, nmatch = 0, first_s = -1;   // modes 2-4: end of the match taken last (frame), matches so far
+    int64_t span_at = (mode == 3 && live && t.len > 0) ? prefix[i] : 0;
+    int64_t span_room = span_cap;
+    if (mode == 5) {   // spans into the text's slot row (out2 = the rows, Layout::slot_row), gathered behind the prefix sums
+      int cap = 0;
+      span_at = live ? lay.slot_row(i, &cap) : 0;
+      span_room = span_at + cap;
+    }
     __builtin_amdgcn_wave_barrier();
     *(uint4*)(tile + lane * kRowPitch + CH) = make_uint4((uint32_t)rb, (uint32_t)((uint64_t)rb >> 32), (uint32_t)end, 0u);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -966,34 +1030,59 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_bscan(DevPlan p, const uint8_
         const uint4 wv = *(const uint4*)(myrow + g * 16);
         const uint32_t words[4] = {wv.x, wv.y, wv.z, wv.w};
         uint32_t hits = 0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-          const uint32_t b = (words[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
-          const Ent e = tbl[b];
-          const Set x = DFA ? U : ((U & e.mask) | e.sm);
-          Set nx = DFA ? e.sm : (Set)0;
-          if (DFA) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              if (j < nch) nx |= fol[(int)e.mask + (j << 8) + (int)((x >> (8 * j)) & 0xFFu)];   // (wave uniform)
-          } else if (W32) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              if (j < nch) nx |= fol[(j << 8) + (int)((x >> (8 * j)) & 0xFFu)];   // (wave uniform)
-          } else {
-            for (int j = 0; j < nch; ++j) nx |= fol[(j << 8) + (int)((x >> (8 * j)) & 0xFFu)];
-          }
-          const int f = wb + g * 16 + k;
-          const bool inside = f >= mis && f < end;
-          U = inside ? nx : (Set)0;
-          hits |= (inside && (nx & bmatch)) ? (1u << k) : 0u;
+        // (a wavefront whose 64 texts all cover the whole group -- every group of a fixed-pitch batch of full rows --
+        // steps without the per-byte frame test)
+        const bool all_full = __all(wb + g * 16 >= mis && wb + g * 16 + 16 <= end);
+#define MRX_BS_STEP16(FULL)                                                                                       \
+        _Pragma("unroll") for (int k = 0; k < 16; ++k) {                                                          \
+          const uint32_t b = (words[k >> 2] >> ((k & 3) * 8)) & 0xFFu;                                            \
+          const Ent e = tbl[b];                                                                                   \
+          const Set x = DFA ? U : ((U & e.mask) | e.sm);                                                          \
+          Set nx = DFA ? e.sm : (Set)0;                                                                           \
+          if (DFA) {                                                                                              \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                         \
+              if (j < nch) nx |= fol[(int)e.mask + (j << 8) + (int)((x >> (8 * j)) & 0xFFu)];   /* (wave uniform) */ \
+          } else if (W32) {                                                                                       \
+            _Pragma("unroll") for (int j = 0; j < 3; ++j)                                                         \
+              if (j < nch) nx |= fol[(j << cb) + (int)((x >> (cb * j)) & cmask)];   /* (wave uniform) */          \
+          } else {                                                                                                \
+            for (int j = 0; j < nch; ++j) nx |= fol[(j << 8) + (int)((x >> (8 * j)) & 0xFFu)];                    \
+          }                                                                                                       \
+          if (FULL) {                                                                                             \
+            U = nx;                                                                                               \
+            hits |= (nx & bmatch) ? (1u << k) : 0u;                                                               \
+          } else {                                                                                                \
+            const int f = wb + g * 16 + k;                                                                        \
+            const bool inside = f >= mis && f < end;                                                              \
+            U = inside ? nx : (Set)0;                                                                             \
+            hits |= (inside && (nx & bmatch)) ? (1u << k) : 0u;                                                   \
+          }                                                                                                       \
         }
+        if (all_full) { MRX_BS_STEP16(true) } else { MRX_BS_STEP16(false) }
+#undef MRX_BS_STEP16
+        if (mode >= 2) {
+          while (hits) {   // match ends of this group, left to right
+            const int e = wb + g * 16 + __builtin_ctz(hits) + 1;
+            hits &= hits - 1;
+            if (e - L < taken_end) continue;   // begins inside the match taken before it
+            if ((mode == 3 || mode == 5) && span_at + nmatch < span_room) *(int2*)(out2 + 2 * (span_at + nmatch)) = make_int2(e - L - mis, e - mis);
+            if (mode == 4 && !found) first_s = e - L - mis;
+            taken_end = e;
+            ++nmatch;
+            found = true;
+          }
+        } else
         if (hits) { last_end = wb + g * 16 + (32 - __builtin_clz(hits)); found = true; }
       }
       __builtin_amdgcn_wave_barrier();
-      if (mode == 0 && __all(found || wb + CH >= end)) break;   // search: every text has its answer
+      if ((mode == 0 || mode == 4) && __all(found || wb + CH >= end)) break;   // search: every text has its answer
     }
 #undef MRX_BS_LOAD
+    if (mode == 4) {
+      if (live) { limit[i] = first_s; out2[i] = first_s >= 0 ? first_s + L : -1; }
+    } else if (mode == 2 || mode == 5) {
+      if (live) limit[i] = nmatch;
+    } else if (mode < 2)
     if (live) limit[i] = mode == 0 ? (found ? t.len : 0) : (found ? last_end - mis : 0);
   }
 }
@@ -3699,6 +3788,9 @@ struct mrx_handle {
   std::atomic<uint8_t*> d_blobs[kMaxDevices];
   std::mutex mu;   // serialises the first upload per device
   std::string describe_cache;
+  // sub: matches per KiB of input the last batch held (0 = nothing seen yet): sizes the span buffer of the next
+  // call so that a dense batch (more than one match per eight bytes) does not scan twice every time
+  mutable std::atomic<int64_t> sub_matches_per_kib{0};
   mrx_handle() { for (auto& b : d_blobs) b.store(nullptr, std::memory_order_relaxed); }
 };
 
@@ -3972,8 +4064,14 @@ int bscan_limits(const mrx_handle* h, const Layout& lay, int64_t n, int mode, hi
   if (!(p.flags & PF_BSTEP))   // a table plan: sets of DFA states
     hipLaunchKernelGGL((k_bscan<1, 1>), dim3((unsigned)g), dim3(64 * kWsWaves), bscan_dfa_table_bytes(p.nstates, p.ncls), s, p,
                        H_BLOB(h), lay, n, mode, *d_limit);
+  else if (p.bs_npos <= 11)
+    hipLaunchKernelGGL((k_bscan<1, 0, 1>), dim3((unsigned)g), dim3(64 * kWsWaves), bscan_table_bytes(p.bs_npos), s, p, H_BLOB(h),
+                       lay, n, mode, *d_limit);
+  else if (p.bs_npos <= 22)
+    hipLaunchKernelGGL((k_bscan<1, 0, 2>), dim3((unsigned)g), dim3(64 * kWsWaves), bscan_table_bytes(p.bs_npos), s, p, H_BLOB(h),
+                       lay, n, mode, *d_limit);
   else if (p.bs_npos <= 32)
-    hipLaunchKernelGGL((k_bscan<1>), dim3((unsigned)g), dim3(64 * kWsWaves), bscan_table_bytes(p.bs_npos), s, p, H_BLOB(h),
+    hipLaunchKernelGGL((k_bscan<1, 0, 3>), dim3((unsigned)g), dim3(64 * kWsWaves), bscan_table_bytes(p.bs_npos), s, p, H_BLOB(h),
                        lay, n, mode, *d_limit);
   else
     hipLaunchKernelGGL((k_bscan<0>), dim3((unsigned)g), dim3(64 * kWsWaves), bscan_table_bytes(p.bs_npos), s, p, H_BLOB(h),
@@ -3981,6 +4079,39 @@ int bscan_limits(const mrx_handle* h, const Layout& lay, int64_t n, int mode, hi
   HIP_TRY(hipGetLastError());
   *out = lay;
   if (lay.offsets) out->vlen = *d_limit; else out->lens = *d_limit;
+  return MRX_OK;
+}
+
+// Bitset program whose matches all have one length: the union pass answers count (mode 2), findall's emit (3:
+// counts = mode 2's, prefix = their prefix sums) and search (4: a = start, b = end) by itself.
+bool bits_fixed_on(const DevPlan& p) {
+  return (p.flags & PF_BSTEP) && p.bs_fixed_len > 0 && p.bs_nw == 1 && g_force_generic == 0 && mwalk_enabled();
+}
+int bscan_fixed(const mrx_handle* h, const Layout& lay, int64_t n, int mode, hipStream_t s, int32_t* a, int32_t* b,
+                const int64_t* prefix, int64_t span_cap) {
+  const DevPlan& p = h->hp.dev;
+  const int64_t nw = (n + 63) / 64;
+  int64_t g = (nw + kWsWaves - 1) / kWsWaves;
+  if (g < 1) g = 1;
+  if (g > grid_cap()) g = grid_cap();
+  static const int ch = getenv("MRX_BSCAN_CH") ? atoi(getenv("MRX_BSCAN_CH")) : 64;
+#define MRX_BSF(NCH_)                                                                                                       \
+  do {                                                                                                                      \
+    if (ch == 64 && mode != 5)   /* (the slot-row form measured better on the 128-byte tile: 0.95 against 1.07 ms) */       \
+      hipLaunchKernelGGL((k_bscan<1, 0, NCH_, 64>), dim3((unsigned)g), dim3(64 * kWsWaves), bscan_table_bytes(p.bs_npos), s, p, \
+                         H_BLOB(h), lay, n, mode, a, b, prefix, span_cap);                                                  \
+    else                                                                                                                    \
+      hipLaunchKernelGGL((k_bscan<1, 0, NCH_>), dim3((unsigned)g), dim3(64 * kWsWaves), bscan_table_bytes(p.bs_npos), s, p,   \
+                         H_BLOB(h), lay, n, mode, a, b, prefix, span_cap);                                                  \
+  } while (0)
+  if (p.bs_npos <= 11) MRX_BSF(1);
+  else if (p.bs_npos <= 22) MRX_BSF(2);
+  else if (p.bs_npos <= 32) MRX_BSF(3);
+#undef MRX_BSF
+  else
+    hipLaunchKernelGGL((k_bscan<0>), dim3((unsigned)g), dim3(64 * kWsWaves), bscan_table_bytes(p.bs_npos), s, p, H_BLOB(h),
+                       lay, n, mode, a, b, prefix, span_cap);
+  HIP_TRY(hipGetLastError());
   return MRX_OK;
 }
 
@@ -4214,6 +4345,10 @@ int run_match(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d_s, i
       if (int rc = req_wave_pays(lay, n, false, s, &wave, big ? nullptr : &split, false, mwalk_on(h->hp.dev))) return rc;   // (not the `big` rule: search stops at the first match)
     Layout lay2 = lay;
     lay2.split = split;
+    if (bits && bits_fixed_on(h->hp.dev)) {   // one match length: the first match end of the union pass is the answer
+      if (int rc = bscan_fixed(h, lay, n, 4, s, d_s, d_e, nullptr, 0)) return rc;
+      g_last_kernel = "k_bscan_fixed_search";
+    } else
     if (bits) {   // union automaton first: texts without any match end are not searched at all
       int32_t* d_limit = nullptr;
       if (int rc = bscan_limits(h, lay, n, 0, s, &lay2, &d_limit)) return rc;
@@ -4796,6 +4931,9 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
                  (wstep_mwalk ||
                   (match_next_sequence ? ((p.flags & PF_STEP_SEARCH) && !(p.flags & PF_PREFILTER))
                                        : (p.flags & (PF_STEPPABLE | PF_STEP_REQ | PF_STEP_EMPTY)) != 0));
+  // bitset program whose matches all have one length: the union pass counts and emits by itself (k_bscan modes 2, 3)
+  const bool bits_fixed = step_ok && wstep_bits && bits_fixed_on(p) && !(match_next_sequence && (p.flags & PF_PREFILTER));
+  bool bits_fixed_slots = false;   // ... with the spans in slot rows (one pass)
   bool fused = false;      // streaming path: scan, CSR offsets and spans in one launch (ST_FUSED)
   bool split_done = false; // streaming path: two halves on two streams (findall_split)
   bool dyn = false;        // streaming path: ragged CSR batch on k_stream_dyn (256-text tasks)
@@ -4958,7 +5096,7 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
         if (int rc = backscan_marks(h, lay, n, s, &lay2)) return rc;
         lay2.split = split_keep;
       }
-      if (step_ok && !wstep_empty && !wstep_mwalk && !wstep_bm && (wstep_bits || (!req_wave && step_split == 0 && !use_req_route && union_pass_for_table_plan(p, false)))) {
+      if (step_ok && !bits_fixed && !wstep_empty && !wstep_mwalk && !wstep_bm && (wstep_bits || (!req_wave && step_split == 0 && !use_req_route && union_pass_for_table_plan(p, false)))) {
         // union automaton first: texts in which no walk from any start reaches MATCH are not walked at all
         // (mode 0: a wavefront stops as soon as each of its texts has shown one match end, so on texts full
         // of matches the pass costs next to nothing; cutting tails -- mode 1 -- would scan everything)
@@ -4970,7 +5108,23 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
       // multi-walk plans: count, prefix sums, emit -- two one-pass scans whatever the match density (the count pass
       // keeps no start registers and runs at 3 TB/s; slot rows + a second walk for overflowing texts would be three)
       mwalk_two_pass = wstep_mwalk && !req_wave && step_split == 0;
-      if (step_ok && span_cap > 0 && !wstep_empty && !mwalk_two_pass) {
+      if (bits_fixed) {
+        // matches of at least four bytes: one pass, spans into slot rows of len / 4 + 32 (they cannot overflow),
+        // gathered behind the prefix sums; shorter ones: count, prefix sums, the pass once more to emit
+        bits_fixed_slots = p.bs_fixed_len >= 4 && span_cap > 0 && !lay.vlen;
+        if (bits_fixed_slots) {
+          int64_t bytes = 0;
+          if (lay.offsets) {
+            HIP_TRY(hipMemcpyAsync(&bytes, lay.offsets + n, sizeof bytes, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+          } else {
+            bytes = n * (lay.lens ? lay.stride : (int64_t)lay.len);
+          }
+          lay2.wide_slots = 1;
+          HIP_TRY(scratch_alloc((void**)&d_slots, sizeof(int32_t) * 2 * (size_t)(bytes / 4 + 32 * n + 64), s));
+        }
+        if (int rc = bscan_fixed(h, lay, n, bits_fixed_slots ? 5 : 2, s, d_counts, d_slots, nullptr, 0)) return rc;
+      } else if (step_ok && span_cap > 0 && !wstep_empty && !mwalk_two_pass) {
         if (req_wave) {
           // long texts: rows of len / 4 + 32 slots (twice the bytes of the batch) -- the second walk
           // is then only for texts with a match every 4 bytes
@@ -5017,7 +5171,7 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
         MRX_BT_DISPATCH(bt_kernel_kind(h, plan_uses_backtracker(h)), MRX_L);
 #undef MRX_L
       }
-      g_last_kernel = req_wave ? "k_req_wave" : step_ok ? (wstep_mwalk ? (step_split > 0 ? "k_mwalk+k_req_wave" : "k_mwalk") : wstep_bm ? "k_backscan+k_step_count" : wstep_bits ? "k_bstep_count" : wstep_empty ? "k_estep_count" : step_split > 0 ? "k_step_count+k_req_wave" : "k_step_count")
+      g_last_kernel = bits_fixed ? "k_bscan_fixed" : req_wave ? "k_req_wave" : step_ok ? (wstep_mwalk ? (step_split > 0 ? "k_mwalk+k_req_wave" : "k_mwalk") : wstep_bm ? "k_backscan+k_step_count" : wstep_bits ? "k_bstep_count" : wstep_empty ? "k_estep_count" : step_split > 0 ? "k_step_count+k_req_wave" : "k_step_count")
                                                         : "k_findall_count";
       HIP_TRY(hipGetLastError());
       tm.stop();
@@ -5074,7 +5228,12 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
     if (stream_ok) {
       // spans were written by k_decode above
     } else {
-      if (step_ok && mwalk_two_pass) {   // second scan, texts that hold a match: spans straight to their CSR place
+      if (bits_fixed && bits_fixed_slots) {
+        hipLaunchKernelGGL(k_slots_gather_wide, dim3(grid_for(n * 64, kBlock)), dim3(kBlock), 0, s, lay2, n, d_counts,
+                           d_prefix, d_slots, d_spans, span_cap);
+      } else if (bits_fixed) {   // the union pass once more, texts that hold a match: spans straight to their CSR place
+        if (int rc = bscan_fixed(h, lay, n, 3, s, d_counts, d_spans, d_prefix, span_cap)) return rc;
+      } else if (step_ok && mwalk_two_pass) {   // second scan, texts that hold a match: spans straight to their CSR place
         Layout lay_e = lay2;
         lay_e.wide_slots = 2;
         MRX_WSTEP_LAUNCH(STEP_EMIT, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_lds(pk, wstep_mwalk, wstep_bm_big), s, pk, H_BLOB(h),
@@ -5178,6 +5337,10 @@ int sub_from_spans(const mrx_handle* h, const Layout& lay, int64_t n, const std:
   HIP_TRY(scratch_alloc((void**)&d_left, sizeof(int32_t), s));
   if (R) HIP_TRY(hipMemcpyAsync(d_rmap, rmap.data(), sizeof(uint16_t) * R, hipMemcpyHostToDevice, s));
   int64_t cap = in_bytes / 8 + n + 64, nm = 0, tot = 0;
+  if (const int64_t seen = h->sub_matches_per_kib.load(std::memory_order_relaxed); seen > 128) {
+    const int64_t by_hint = (in_bytes >> 10) * (seen + seen / 8 + 1) + n + 64;   // the last batch's density + 1/8
+    if (by_hint > cap) cap = by_hint < in_bytes + n + 64 ? by_hint : in_bytes + n + 64;
+  }
   int rc = MRX_OK;
   bool cum_later = false;
   int G = 0;
@@ -5217,6 +5380,7 @@ int sub_from_spans(const mrx_handle* h, const Layout& lay, int64_t n, const std:
     HIP_TRY(hipMemcpyAsync(&nm, d_prefix + n, sizeof nm, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(&tot, d_total, sizeof tot, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    h->sub_matches_per_kib.store(in_bytes >= 1024 ? nm / (in_bytes >> 10) : 0, std::memory_order_relaxed);
     if (nm <= cap) break;
     if (attempt == 1) return fail(MRX_E_NO_DEVICE, "sub: match count changed between two passes");
     HIP_TRY(scratch_free(d_spans, s));
@@ -5793,10 +5957,14 @@ static int run_count_any(const mrx_handle* h, const Layout& lay, int64_t n, int3
     const bool wstep_bm_big = wstep_bm && (h->hp.dev.flags & PF_STEP_BIG) != 0;
     if (wstep_bm)
       if (int rc = backscan_marks(h, lay, n, s, &lay2)) return rc;
-    if (g_force_generic < 2 && !wstep_mwalk && !wstep_bm && (wstep_bits || (!req_wave && split == 0 && !use_req_route && union_pass_for_table_plan(h->hp.dev, false))))
+    const bool bits_fixed = wstep_bits && bits_fixed_on(h->hp.dev);
+    if (g_force_generic < 2 && !bits_fixed && !wstep_mwalk && !wstep_bm && (wstep_bits || (!req_wave && split == 0 && !use_req_route && union_pass_for_table_plan(h->hp.dev, false))))
       if (int rc = bscan_limits(h, lay, n, 0, s, &lay2, &d_blimit)) return rc;   // union automaton first
     const bool big_lane = (h->hp.dev.flags & PF_STEP_BIG) && !req_wave && !wstep_mwalk && !wstep_bm;   // -> literal restatement
-    if (req_wave) {
+    if (bits_fixed) {
+      if (int rc = bscan_fixed(h, lay, n, 2, s, counts, nullptr, nullptr, 0)) return rc;
+      g_last_kernel = "k_bscan_fixed";
+    } else if (req_wave) {
       MRX_REQWAVE_LAUNCH(STEP_COUNT, h, lay, n, counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0, s);
       g_last_kernel = "k_req_wave";
     } else if (g_force_generic < 2 && !big_lane && ((h->hp.dev.flags & (PF_STEPPABLE | PF_STEP_REQ | PF_STEP_EMPTY)) || wstep_mwalk)) {

@@ -837,6 +837,34 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
     for (const auto& m : masks) put(hp.blob, m.data(), 8 * b.nw);
     d.off_bs_follow = (int)hp.blob.size();
     for (const auto& f : b.follow) put(hp.blob, f.data(), 8 * b.nw);
+    // Do all matches have one length?  Layer the positions by the number of bytes consumed before them: a start
+    // position is at depth 0, every follower of a position at depth k at k + 1; one position at two depths (any
+    // loop, any optional part) or MATCH at two depths means no.  With one length L the restart-per-position loop
+    // (pikevm.mojo:755-867 under matcher.mojo:1341-1354) takes a match end e iff e - L is not inside the match
+    // taken before it, which the union pass can decide as it goes (k_bscan modes 2-4).
+    d.bs_fixed_len = 0;
+    if (b.nw == 1) {
+      std::vector<int> depth(b.npos, -1);
+      std::vector<int> queue;
+      bool fixed = (b.start[0] & b.match[0]) == 0;
+      for (int q = 0; q < b.npos; ++q)
+        if ((b.start[0] >> q) & 1) { depth[q] = 0; queue.push_back(q); }
+      int L = -1;
+      for (size_t qi = 0; qi < queue.size() && fixed; ++qi) {
+        const int q = queue[qi];
+        if ((b.match[0] >> q) & 1) {
+          if (L >= 0 && L != depth[q]) fixed = false;
+          L = depth[q];
+          continue;   // MATCH consumes nothing
+        }
+        for (int r = 0; r < b.npos && fixed; ++r)
+          if ((b.follow[q][0] >> r) & 1) {
+            if (depth[r] < 0) { depth[r] = depth[q] + 1; queue.push_back(r); }
+            else if (depth[r] != depth[q] + 1) fixed = false;
+          }
+      }
+      if (fixed && L >= 1 && L < 32768) d.bs_fixed_len = L;
+    }
   }
   if (d.nstates >= 0x7FFF) {
     hp.why_no_match_first = hp.why_no_search = "more than 32766 DFA states";
@@ -1557,7 +1585,7 @@ std::string describe_plan(const HostPlan& hp) {
   if (hp.fixed_total >= 0)   // group templates of regex.sub: see HostPlan::fixed_pure
     o << "device.sub_groups=fixed pure=" << (hp.fixed_pure ? 1 : 0) << "\n";
   if (d.flags & PF_BITSET)
-    o << "device.bitset=yes positions=" << d.bs_npos << " words=" << d.bs_nw << " byte_classes=" << d.bs_ncls << "\n";
+    o << "device.bitset=yes positions=" << d.bs_npos << " words=" << d.bs_nw << " byte_classes=" << d.bs_ncls << " fixed_len=" << d.bs_fixed_len << "\n";
   return o.str();
 }
 

@@ -138,6 +138,7 @@ struct DevPlan {
   // bitset NFA (PF_BITSET): cls[256] u8, byte masks u64[bs_ncls][bs_nw], follow u64[bs_npos][bs_nw]
   int32_t bs_nw, bs_npos, bs_ncls, off_bs_cls, off_bs_mask, off_bs_follow;
   uint64_t bs_start[4], bs_match[4];
+  int32_t bs_fixed_len, bs_pad_;   // > 0: every match of the program has this length (k_bscan modes 2-4 need no second pass)
   // the backtracking matcher as a flat program (BtProg, mrx_engines.hpp; bt_nitems == 0: none): BtItem
   // [bt_nitems], membership bitmaps u8[32] x 3 per leaf, and NFAEngine's literal prefilter facts
   // (nfa.mojo:86-143): bt_flags bit 0 = has_literal_optimization, 1 = is_prefix_literal, 2 = starts_with_dotstar,

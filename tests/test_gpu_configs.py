@@ -262,8 +262,8 @@ def test_record_forms_at_the_16_bit_position_boundary(L):
 
 def test_config4_program_on_the_bitset_nfa_kernel_at_full_size():
     """BASELINE config 4, "(\\d{3})(\\d{3})(\\d{4}) capture-group NFA fallback, 1M strings, 1 GPU (bitset-NFA
-    kernel)": the pattern's PikeVM program (pikevm.mojo:124-333; 11 positions) walked as a bitset NFA by
-    k_wstep<., 0, 1> -- no determinised table -- over 2^20 x 1 KiB texts.  search, count and findall must
+    kernel)": the pattern's PikeVM program (pikevm.mojo:124-333; 11 positions) as a bitset NFA (k_bscan, and
+    k_wstep<., 0, 1> for the walks) -- no determinised table -- over 2^20 x 1 KiB texts.  search, count and findall must
     equal the LazyDFA table kernels' answers on every text (the same function of the text computed two
     ways) and the oracle's NFAMatcher (PikeVM / LazyDFA restatement) on a sample."""
     _need_gpu()
@@ -279,19 +279,27 @@ def test_config4_program_on_the_bitset_nfa_kernel_at_full_size():
     assert "device.bitset=yes positions=11 words=1" in desc and "bitset=1" in desc, desc
     tab = M.compile_regex(pat, lazydfa_semantics=True)
     assert "device.bitset" not in tab.describe()
-    s1, e1 = nfa.match_next(batch)
-    assert lib.mrx_last_kernel_name() == b"k_bstep_search"
-    s2, e2 = tab.match_next(batch)
-    assert lib.mrx_last_kernel_name() != b"k_bstep_search"
-    assert torch.equal(s1, s2) and torch.equal(e1, e2)
-    c1 = nfa.count(batch)
-    assert lib.mrx_last_kernel_name() == b"k_bstep_count"
-    c2 = tab.count(batch)
-    assert torch.equal(c1, c2)
-    p1, sp1, t1 = nfa._dev_findall(batch)
-    assert lib.mrx_last_kernel_name() == b"k_bstep_count"
-    p2, sp2, t2 = tab._dev_findall(batch)
-    assert t1 == t2 and torch.equal(p1, p2) and torch.equal(sp1[:t1], sp2[:t2])
+    # round 3: every match of this program is 10 bytes long, so the union pass takes the match ends by itself
+    # (k_bscan modes 2-4); mrx_debug_multiwalk(2) brings the walk per start back -- both against the table kernels
+    assert "fixed_len=10" in desc, desc
+    for walks in (False, True):
+        lib.mrx_debug_multiwalk(2 if walks else 0)
+        try:
+            s1, e1 = nfa.match_next(batch)
+            assert lib.mrx_last_kernel_name() == (b"k_bstep_search" if walks else b"k_bscan_fixed_search")
+            c1 = nfa.count(batch)
+            assert lib.mrx_last_kernel_name() == (b"k_bstep_count" if walks else b"k_bscan_fixed")
+            p1, sp1, t1 = nfa._dev_findall(batch)
+            assert lib.mrx_last_kernel_name() == (b"k_bstep_count" if walks else b"k_bscan_fixed")
+        finally:
+            lib.mrx_debug_multiwalk(0)
+        s2, e2 = tab.match_next(batch)
+        assert lib.mrx_last_kernel_name() not in (b"k_bstep_search", b"k_bscan_fixed_search")
+        assert torch.equal(s1, s2) and torch.equal(e1, e2)
+        c2 = tab.count(batch)
+        assert torch.equal(c1, c2)
+        p2, sp2, t2 = tab._dev_findall(batch)
+        assert t1 == t2 and torch.equal(p1, p2) and torch.equal(sp1[:t1], sp2[:t2])
     # oracle sample (NFAMatcher: PikeVM program + LazyDFA, the route the option selects)
     o = OracleRegex(pat, force_nfa=True)
     idx = np.linspace(0, n - 1, 48).astype(np.int64)

@@ -587,6 +587,67 @@ def test_bitset_nfa_matches_oracle(case):
         assert tab.findall_lists(texts) == got_all
 
 
+@pytest.mark.parametrize("pat,lazy,width", [
+    (b"(\\d{3})(\\d{3})(\\d{4})", True, 10),      # config 4's program
+    (b"(a|b)x", False, 2),
+    (b"([a-f]|x)[0-9][0-9]", False, 3),
+    (b"(a|b)(c|d)[0-9a-f][0-9a-f](x|y)", True, 5),
+    (b"(ab)+c", False, 0),                        # a loop: several lengths
+    (b"(foo|ba)z", False, 0),                     # branches of different lengths
+])
+@pytest.mark.parametrize("csr", [False, True])
+def test_bitset_programs_of_one_match_length_need_no_second_pass(pat, lazy, width, csr):
+    """When every match of a bitset program has the same length, the union pass (k_bscan) takes a match end iff the match
+    does not begin inside the one taken before -- count, findall and search without any walk per start.  Equal to the
+    walks (mrx_debug_multiwalk(2)) on every text and to the oracle on a sample; programs of several lengths keep the
+    walks."""
+    _need_gpu()
+    from mrx_ref.hybrid import CompiledRegex as OracleRegex
+    rx = M.compile_regex(pat, lazydfa_semantics=lazy, bitset_nfa=True)
+    d = rx.describe()
+    assert "device.bitset=yes" in d and ("fixed_len=%d\n" % width) in d, d
+    rng = np.random.default_rng(zlib.crc32(pat) + csr)
+    al = np.frombuffer(b"ab0123456789fxz -" + bytes(c for c in pat if chr(c).isalnum()) * 3, dtype=np.uint8)
+    n, pitch = 700, 272
+    arr = rng.choice(al, size=(n, pitch)).astype(np.uint8)
+    arr[::3] = rng.choice(np.frombuffer(b"0123456789abfoz", dtype=np.uint8), size=arr[::3].shape)   # matches back to back
+    lens = rng.integers(0, pitch + 1, size=n).astype(np.int32)
+    lens[:8] = [0, 1, pitch, max(width, 1), max(width - 1, 0), 16, 17, 128]
+    texts = [arr[i, :lens[i]].tobytes() for i in range(n)]
+    if csr:
+        batch = M.DeviceBatch.from_texts(texts)
+    else:
+        batch = M.DeviceBatch.strided(torch.from_numpy(arr).cuda().reshape(-1), pitch, length=pitch, lens=torch.from_numpy(lens).cuda())
+    lib = M.load_library()
+
+    def run():
+        prefix, spans, total = rx._dev_findall(batch)
+        k1 = lib.mrx_last_kernel_name()
+        cnt = rx.count(batch)
+        k2 = lib.mrx_last_kernel_name()
+        s, e = rx.match_next(batch)
+        k3 = lib.mrx_last_kernel_name()
+        return (prefix.cpu().numpy(), spans[:total].cpu().numpy(), cnt.cpu().numpy(), s.cpu().numpy(), e.cpu().numpy()), (k1, k2, k3)
+
+    got, names = run()
+    if width:
+        assert names == (b"k_bscan_fixed", b"k_bscan_fixed", b"k_bscan_fixed_search"), names
+    else:
+        assert b"k_bscan_fixed" not in names and b"k_bscan_fixed_search" not in names, names
+    with multiwalk(2):
+        want, names2 = run()
+        assert names2 == (b"k_bstep_count", b"k_bstep_count", b"k_bstep_search"), names2
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b), pat
+    assert np.array_equal(np.diff(got[0]), got[2])
+    o = OracleRegex(pat, force_nfa=lazy)
+    for i in range(0, n, 7):
+        have = [tuple(int(x) for x in r) for r in got[1][got[0][i]:got[0][i + 1]]]
+        assert have == o.match_all(texts[i]), (pat, i)
+        w = o.match_next(texts[i], 0)
+        assert (int(got[3][i]), int(got[4][i])) == (w if w else (-1, -1)), (pat, i)
+
+
 FIRST_PATTERNS = STREAM_PATTERNS + [b"[a-z]*[0-9]*", b"^abc", b"a*", b"\\w+@\\w+\\.com", b"[a-c]+x[0-9]+y",
                                     b"\\d{3}-\\d{4}", b"hello world this is long", b"^[a-z]+\\d*", b"x?y?z?",
                                     b"[a-z]+\\s+[a-z]+\\s+[0-9]+"]
