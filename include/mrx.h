@@ -164,7 +164,8 @@ int mrx_is_match_at_strided_dev(const mrx_handle* h, const uint8_t* d_data, int6
 /* regex.findall(pattern, text), matcher.mojo:1341-1354.
  * d_counts_prefix[n+1]: exclusive prefix sum of matches per text (CSR);
  * d_spans[2*k], d_spans[2*k+1] = start, end of match k (text-relative), in text
- * order then match order.  span_cap = capacity of d_spans in spans.
+ * order then match order.  span_cap = capacity of d_spans in spans.  d_spans must be 8-byte aligned (a span is
+ * stored as one 8-byte word; hipMalloc and every framework allocator give far more).
  * Synchronises the stream once to return *total; MRX_E_CAPACITY if
  * *total > span_cap (nothing is ever written to d_spans beyond capacity).
  * total == NULL: nothing is read back and the call returns without synchronising;

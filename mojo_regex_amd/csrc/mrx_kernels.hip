@@ -228,7 +228,7 @@ __global__ void k_first_to_counts(int64_t n, const int32_t* __restrict__ start, 
 __global__ void k_first_to_spans(int64_t n, const int32_t* __restrict__ start, const int32_t* __restrict__ end,
                                  const int64_t* __restrict__ prefix, int32_t* __restrict__ spans, int64_t span_cap) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    if (start[i] >= 0 && prefix[i] < span_cap) { spans[2 * prefix[i]] = start[i]; spans[2 * prefix[i] + 1] = end[i]; }
+    if (start[i] >= 0 && prefix[i] < span_cap) *(int2*)(spans + 2 * prefix[i]) = make_int2(start[i], end[i]);
 }
 __global__ void k_span_to_flag(int64_t n, const int32_t* __restrict__ start, uint8_t* __restrict__ flag) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -393,6 +393,7 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_wstep(DevPlan p, const uint8_
     uint32_t bm_word = 0;
     uint4 bm_win = make_uint4(0, 0, 0, 0);   // the four words of the current window
     int bm_wb = -(1 << 30);
+    bool bm_none = false;
     if (BM && live) {
       mybm = lay.bm + lay.bm_row(i);
       if (lay.bm_cnt[i] == 0) fin = true;   // no match begins anywhere in my text
@@ -411,6 +412,8 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_wstep(DevPlan p, const uint8_
       }
     }
     if (MODE == STEP_SLOTS) wo = 0;
+    // (no match begins in any of the 64 texts: nothing to load.  Not a `continue`: that costs this loop 40 registers)
+    if (BM && __all(fin)) max_end = 0;
     const uint8_t* myrow = tile + lane * kRowPitch;
     const uint8_t* frame = (const uint8_t*)rb;   // frame position f is frame[f] in global memory
     uint4 v[NL];
@@ -434,6 +437,7 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_wstep(DevPlan p, const uint8_
       if (BM) {   // this window's marks: one aligned 16-byte load per lane
         if (!fin && wb < end) bm_win = *(const uint4*)(mybm + (wb >> 5));
         bm_wb = wb;
+        bm_none = (bm_win.x | bm_win.y | bm_win.z | bm_win.w) == 0;
       }
       // One step of the search for this lane, given the byte at `pos` (ignored when act is false
       // or the text has ended).  Branch-free apart from the span store.
@@ -452,7 +456,7 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_wstep(DevPlan p, const uint8_
           const bool matched = ends && last >= 0;
           if (MODE == STEP_EMIT) {
             if (matched) {
-              if (wo < span_cap) { spans[2 * wo] = start - mis; spans[2 * wo + 1] = last - mis; }
+              if (wo < span_cap) *(int2*)(spans + 2 * wo) = make_int2(start - mis, last - mis);
               ++wo;
             }
           }
@@ -480,6 +484,7 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_wstep(DevPlan p, const uint8_
             uint32_t wv;
             const int rel = pos - bm_wb;
             if (rel >= 0 && rel < CH) {   // the window's marks are in registers
+              if (bm_none) { pos = bm_wb + CH; return; }   // none in the whole window: out of it in one step
               const int j = rel >> 5;
               wv = j == 0 ? bm_win.x : j == 1 ? bm_win.y : j == 2 ? bm_win.z : bm_win.w;
             } else {
@@ -506,7 +511,7 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_wstep(DevPlan p, const uint8_
           const bool matched = ends && last > hit;           // must end past the required byte
           if (MODE == STEP_EMIT) {
             if (matched) {
-              if (wo < span_cap) { spans[2 * wo] = start - mis; spans[2 * wo + 1] = last - mis; }
+              if (wo < span_cap) *(int2*)(spans + 2 * wo) = make_int2(start - mis, last - mis);
               ++wo;
             }
           }
@@ -539,7 +544,7 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_wstep(DevPlan p, const uint8_
         const int m_s = empty_here ? pos : start, m_e = empty_here ? pos : last;
         if (MODE == STEP_EMIT) {
           if (matched) {
-            if (wo < span_cap) { spans[2 * wo] = m_s - mis; spans[2 * wo + 1] = m_e - mis; }
+            if (wo < span_cap) *(int2*)(spans + 2 * wo) = make_int2(m_s - mis, m_e - mis);
             ++wo;
           }
         }
@@ -566,10 +571,15 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_wstep(DevPlan p, const uint8_
         // fast phase: 32 steps on the tile without any cross-lane vote; lanes that are ahead of the
         // window, behind it or finished run the same instructions as no-ops
 #pragma unroll 1
-        for (int it = 0; it < 32; ++it) {
-          const int rel = pos - wb;
-          const bool act = !fin && rel >= 0 && (rel < CH || pos >= end);
-          step(act, (uint32_t)myrow[rel & (CH - 1)]);
+        for (int blk = 0; blk < 4; ++blk) {
+#pragma unroll 1
+          for (int it = 0; it < 8; ++it) {
+            const int rel = pos - wb;
+            const bool act = !fin && rel >= 0 && (rel < CH || pos >= end);
+            step(act, (uint32_t)myrow[rel & (CH - 1)]);
+          }
+          // (marks: a lane without a mark in the window leaves it in one step -- do not idle through the other steps)
+          if (BM && !__any(!fin && pos >= wb && (pos < wb + CH || pos >= end))) break;
         }
         // a restart moved some lane behind the window: it reads those bytes from memory
         while (__any(!fin && pos < wb)) {
@@ -678,7 +688,7 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_mwalk(DevPlan p, const uint8_
     int s0 = 0, s1 = 0, s2 = 0, s3 = 0, last = 0, k = 0, rs = -1, re = -1;
     auto report = [&](int a, int b) {
       if (MODE == STEP_EMIT) {
-        if (wo < span_cap) { spans[2 * wo] = a; spans[2 * wo + 1] = b; }
+        if (wo < span_cap) *(int2*)(spans + 2 * wo) = make_int2(a, b);
         ++wo;
       }
       if (MODE == STEP_SLOTS) {
@@ -713,7 +723,9 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_mwalk(DevPlan p, const uint8_
 #define MRX_MW_BYTE(BYTE_, F_, FULL_, PRE_)                                                                          \
       do {                                                                                                           \
         const int f = (F_);                           /* frame position, the same for every lane */                  \
-        const bool act = (FULL_) || (!fin && f >= mis && f < end);                                                   \
+        /* FULL_ = 2 (search): a lane that has its answer keeps stepping on whatever its row holds -- its registers   \
+           are dead, only the report is guarded */                                                                   \
+        const bool act = (FULL_) == 2 ? !fin : ((FULL_) || (!fin && f >= mis && f < end));                           \
         uint32_t en;                                                                                                 \
         if (PRE_) en = *(lds_cu32*)(uintptr_t)((e >> 16) + *(lds_cu8*)(uintptr_t)(lds_base + (BYTE_)));               \
         else en = tab[(e >> 16) + clsT[(BYTE_)]];                                                                    \
@@ -721,7 +733,7 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_mwalk(DevPlan p, const uint8_
         if (act && (en & 1u)) report(s0, last);      /* the oldest walk ended behind its last accepting position (rare branch) */ \
         /* the start registers move as the entry says; plain selects, no branches (code 0 = stays; a lane that is    \
            not stepping takes code 0 everywhere) */                                                                  \
-        const uint32_t ea = act ? en : 0u;                                                                           \
+        const uint32_t ea = ((FULL_) == 2 || act) ? en : 0u;                                                         \
         if (MODE != STEP_COUNT && MODE != STEP_ANY) {                                                                \
         const uint32_t c0 = (ea >> 2) & 7u, c1 = (ea >> 5) & 3u;                                                     \
         int n0 = s0, n1 = s1;                                                                                        \
@@ -746,23 +758,26 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_mwalk(DevPlan p, const uint8_
         s0 = n0; s1 = n1;                                                                                            \
         last = (ea & 2u) ? pr + 1 : last;                                                                            \
         }                                                                                                            \
-        e = act ? en : e;                                                                                            \
+        e = ((FULL_) == 2 || act) ? en : e;                                                                          \
       } while (0)
       for (int g = 0; g < CH / 16; ++g) {
         const int f0 = wb + g * 16;
         const uint4 wv = *(const uint4*)(myrow + g * 16);
         const uint32_t words[4] = {wv.x, wv.y, wv.z, wv.w};
-        // (search modes: a lane that has its answer stops stepping -- `fin` changes inside a group)
-        const bool all_full = pre && MODE != STEP_SEARCH && MODE != STEP_ANY && __all(!fin && f0 >= mis && f0 + 16 <= end);
-        if (all_full) {
+        const bool covers = f0 >= mis && f0 + 16 <= end;
+        const bool all_full = pre && MODE != STEP_ANY && __all(MODE == STEP_SEARCH ? (fin || covers) : (!fin && covers));
+        if (all_full && MODE == STEP_SEARCH) {
 #pragma unroll
-          for (int q = 0; q < 16; ++q) MRX_MW_BYTE((words[q >> 2] >> ((q & 3) * 8)) & 0xFFu, f0 + q, true, true);
+          for (int q = 0; q < 16; ++q) MRX_MW_BYTE((words[q >> 2] >> ((q & 3) * 8)) & 0xFFu, f0 + q, 2, true);
+        } else if (all_full) {
+#pragma unroll
+          for (int q = 0; q < 16; ++q) MRX_MW_BYTE((words[q >> 2] >> ((q & 3) * 8)) & 0xFFu, f0 + q, 1, true);
         } else if (pre) {
 #pragma unroll
-          for (int q = 0; q < 16; ++q) MRX_MW_BYTE((words[q >> 2] >> ((q & 3) * 8)) & 0xFFu, f0 + q, false, true);
+          for (int q = 0; q < 16; ++q) MRX_MW_BYTE((words[q >> 2] >> ((q & 3) * 8)) & 0xFFu, f0 + q, 0, true);
         } else {
 #pragma unroll
-          for (int q = 0; q < 16; ++q) MRX_MW_BYTE((words[q >> 2] >> ((q & 3) * 8)) & 0xFFu, f0 + q, false, false);
+          for (int q = 0; q < 16; ++q) MRX_MW_BYTE((words[q >> 2] >> ((q & 3) * 8)) & 0xFFu, f0 + q, 0, false);
         }
       }
 #undef MRX_MW_BYTE
@@ -788,10 +803,29 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_backscan(DevPlan p, const uin
   constexpr int CH = 128, kRowPitch = CH + 16, LPR = CH / 16, RPI = 64 / LPR, NL = 64 / RPI;
   __shared__ __align__(16) uint8_t tiles[kWsWaves][64 * kRowPitch];
   extern __shared__ __align__(16) uint8_t lds[];
+  // PRE (as in k_mwalk): cls2[byte] = 2 x class and an entry = LDS byte address of the next set's row | mark -- rows
+  // begin on multiples of 2 << cshift bytes and the table on a multiple of 128, so (entry & ~1) | cls2[byte] is the
+  // address of the byte's entry: one v_and_or instead of shift, shift, add
+  typedef __attribute__((address_space(3))) const uint8_t lds_cu8;
+  typedef __attribute__((address_space(3))) const uint16_t lds_cu16;
+  const uint32_t lds_base = (uint32_t)(uintptr_t)lds;
+  const uint32_t tab_base = lds_base + 256u;
+  const bool pre = p.bk_cshift <= 6 && lds_base + (uint32_t)p.bk_bytes <= 65536u && (tab_base & 127u) == 0;
   {
     const uint32_t* src = (const uint32_t*)(blob + p.off_bk_cls);
     uint32_t* dst = (uint32_t*)lds;
-    for (int e = threadIdx.x; e < ((p.bk_bytes + 3) >> 2); e += blockDim.x) dst[e] = src[e];
+    const int sh = p.bk_cshift + 1;
+    for (int e = threadIdx.x; e < ((p.bk_bytes + 3) >> 2); e += blockDim.x) {
+      uint32_t w = src[e];
+      if (pre) {
+        if (e < 64) w = (w << 1) & 0xFEFEFEFEu;
+        else {
+          const uint32_t lo = w & 0xFFFFu, hi = w >> 16;
+          w = ((((lo >> 1) << sh) + tab_base) | (lo & 1u)) | (((((hi >> 1) << sh) + tab_base) | (hi & 1u)) << 16);
+        }
+      }
+      dst[e] = w;
+    }
   }
   __syncthreads();
   const uint8_t* clsT = lds;
@@ -817,7 +851,8 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_backscan(DevPlan p, const uin
     for (int off = 32; off > 0; off >>= 1) max_end = max(max_end, __shfl_xor(max_end, off));
     const uint8_t* myrow = tile + lane * kRowPitch;
     uint32_t* myout = bm + (live ? lay.bm_row(i) : 0);
-    uint32_t st = (uint32_t)p.bk_start << p.bk_cshift, word = 0;
+    // st: !pre: first entry of the current set's row; pre: the last entry taken (row address | mark)
+    uint32_t st = pre ? tab_base + (((uint32_t)p.bk_start << p.bk_cshift) << 1) : (uint32_t)p.bk_start << p.bk_cshift, word = 0;
     int marks = 0;
     uint4 v[NL];
 #define MRX_BK_LOAD(CB)                                                                   \
@@ -838,21 +873,44 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_backscan(DevPlan p, const uin
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       if (wb - CH >= 0) MRX_BK_LOAD(wb - CH);   // the window in front, in flight while this one is stepped
-#pragma unroll 8
-      for (int it = CH - 1; it >= 0; --it) {
-        const int f = wb + it;
-        const bool act = live && f >= mis && f < end;
-        const uint32_t en = tab[st + clsT[myrow[it]]];
-        if (act) {
-          st = (uint32_t)(en >> 1) << p.bk_cshift;
-          word |= (uint32_t)(en & 1u) << (f & 31);
-          marks += (int)(en & 1u);
+      uint4 mw = make_uint4(0, 0, 0, 0);
+#pragma unroll
+      for (int g = CH / 16 - 1; g >= 0; --g) {
+        const int f0 = wb + g * 16;
+        const uint4 wv = *(const uint4*)(myrow + g * 16);
+        const uint32_t words[4] = {wv.x, wv.y, wv.z, wv.w};
+        const bool all_full = pre && __all(live && f0 >= mis && f0 + 16 <= end);
+        if (all_full) {   // every lane's text covers the group: no frame test per byte
+#pragma unroll
+          for (int q = 15; q >= 0; --q) {
+            const uint32_t b = (words[q >> 2] >> ((q & 3) * 8)) & 0xFFu;
+            st = *(lds_cu16*)(uintptr_t)((st & 0xFFFEu) | *(lds_cu8*)(uintptr_t)(lds_base + b));
+            word |= (st & 1u) << ((g & 1) * 16 + q);
+          }
+        } else {
+#pragma unroll
+          for (int q = 15; q >= 0; --q) {
+            const int f = f0 + q;
+            const bool act = live && f >= mis && f < end;
+            const uint32_t b = (words[q >> 2] >> ((q & 3) * 8)) & 0xFFu;
+            uint32_t en;
+            if (pre) en = *(lds_cu16*)(uintptr_t)((st & 0xFFFEu) | *(lds_cu8*)(uintptr_t)(lds_base + b));
+            else en = tab[st + clsT[b]];
+            if (act) {
+              st = pre ? en : (uint32_t)(en >> 1) << p.bk_cshift;
+              word |= (uint32_t)(en & 1u) << (f & 31);
+            }
+          }
         }
-        if ((f & 31) == 0) {   // (the same step for every lane)
-          if (live && f < end && f + 32 > mis) myout[f >> 5] = word;
+        if ((g & 1) == 0) {   // a word of marks is complete (the same step for every lane)
+          marks += __popc(word);
+          if (g == 6) mw.w = word; else if (g == 4) mw.z = word; else if (g == 2) mw.y = word; else mw.x = word;
           word = 0;
         }
       }
+      // the window's four words in one 16-byte store (rows begin on multiples of four words): single words from 64
+      // lanes to 64 rows left the rows' lines partly written for the length of the pass
+      if (live && wb < end && wb + CH > mis) *(uint4*)(myout + (wb >> 5)) = mw;
       __builtin_amdgcn_wave_barrier();
     }
 #undef MRX_BK_LOAD
@@ -1492,7 +1550,7 @@ __global__ __launch_bounds__(kBlock) void k_findall(DevPlan p, const uint8_t* __
     } else {
       int64_t w = prefix[i];
       for_each_match<BT>(c, t, [&](int s, int e) {
-        if (w < span_cap) { spans[2 * w] = s; spans[2 * w + 1] = e; }
+        if (w < span_cap) *(int2*)(spans + 2 * w) = make_int2(s, e);
         ++w;
       });
     }
@@ -4878,6 +4936,7 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
   ScratchScope scratch_scope_((hipStream_t)stream);
   if (!h) return fail(MRX_E_ARGUMENT, "null handle");
   if (n < 0 || span_cap < 0) return fail(MRX_E_ARGUMENT, "negative size");
+  if ((uintptr_t)d_spans & 7) return fail(MRX_E_ARGUMENT, "d_spans must be 8-byte aligned");
   if (int rc = check_search_supported(h)) return rc;
   if (int rc = check_lds(h)) return rc;
   if (int rc = ensure_device(h)) return rc;

@@ -2,7 +2,8 @@
 """Stepper plans with a multi-walk table: k_mwalk (several walks side by side, one pass) against the windowed
 stepper's restart-per-position loop (mrx_debug_multiwalk(2)) -- count, findall and search on 2^20 x 1 KiB texts:
 printable noise, config 2's mix (letter runs: worst case for restarts) and config 4's phone texts."""
-import json, os, sys, time
+import json
+import os, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
@@ -25,6 +26,10 @@ for name, d in batches.items():
     batch = M.DeviceBatch.strided(d.reshape(-1), L, length=L)
     for pat in pats:
         rx = M.compile_regex(pat)
+        if os.environ.get("MRX_PROBE_ONLY") == "backset" and "backset=yes" not in rx.describe():
+            continue
+        if os.environ.get("MRX_PROBE_ONLY") == "backset" and "multiwalk=yes" in rx.describe():
+            continue
         if "multiwalk=yes" not in rx.describe() and "multiwalk_req=yes" not in rx.describe() and "backset=yes" not in rx.describe():
             print(json.dumps({"batch": name, "pattern": pat.decode(), "multiwalk": False})); continue
         row = {"batch": name, "pattern": pat.decode()}
