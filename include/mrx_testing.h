@@ -52,7 +52,9 @@ void mrx_debug_subs_group(int lanes);
 void mrx_debug_litscan_pieces(int mode);
 /* Stepper plans with a multi-walk table (several walks side by side in one pass, k_mwalk; `multiwalk=yes` in
  * mrx_describe) use it for findall / count / search; 2 = never (the windowed stepper's restart-per-position loop
- * instead), anything else = where the plan has one.  Results are the same. */
+ * instead; also no backward marks and no fixed-length form of the bitset union pass), 3 = the multi-walk kernel
+ * without its packed-start form (starts as 16-bit halves moved by byte permutes, texts below 64 KiB), anything else
+ * = where the plan has one.  Results are the same. */
 void mrx_debug_multiwalk(int mode);
 /* include/mrx_comm.h, padded form of mrx_allgatherv_spans: its two device steps on buffers the caller fills as
  * ncclAllGather would have, so that the multi-rank arithmetic can be checked on one GPU.

@@ -619,14 +619,43 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_wstep(DevPlan p, const uint8_
 __host__ __device__ inline size_t mwalk_table_bytes(const DevPlan& p) { return (size_t)p.mw_bytes; }
 
 // KW: walk slots the plan needs (DevPlan::mw_k <= 2: two start registers and three selects per byte instead of ten)
-template <int MODE, int KW = 4>
+// PK (texts below 64 KiB; modes that keep the registers): the starts as 16-bit halves of two registers and `last` in
+// a third, moved by byte permutes -- v_perm_b32 picks every byte of its result from two source registers, so
+// "slot 0 takes slot 2's start, slot 1 the current position" is ONE instruction with the right selector.  The
+// selectors come from a table indexed by the entry's nine code bits (accepting | slot codes): one 8- or 16-byte LDS
+// read and two (KW = 2) or four (KW = 4) permutes per byte instead of 7-24 compares and selects.
+//   KW = 2:  R01 = perm(prpr, R01, selR)                                       prpr = position in both halves
+//   KW = 4:  R01 = perm(prpr, perm(R23, R01, selA), selB),  R23 = perm(prpr, R23, selC)
+//   both:    L   = perm(prpr + 0x10001, L, selL)                               (low half = last)
+// perm(a, b, sel): result byte k = byte sel[k] of the eight bytes b (0-3) | a (4-7).
+template <int MODE, int KW = 4, int PK = 0>
 __global__ __launch_bounds__(64 * kWsWaves) void k_mwalk(DevPlan p, const uint8_t* __restrict__ blob, Layout lay,
                                                          int64_t n, int32_t* __restrict__ counts,
                                                          const int64_t* __restrict__ prefix,
                                                          int32_t* __restrict__ spans, int64_t span_cap,
                                                          int32_t* __restrict__ out_s, int32_t* __restrict__ out_e) {
   constexpr int CH = 128, kRowPitch = CH + 16, LPR = CH / 16, RPI = 64 / LPR, NL = 64 / RPI;
+  static_assert(!PK || ((KW == 2 || KW == 4) && MODE != STEP_COUNT && MODE != STEP_ANY), "packed starts: two or four slots, modes with registers");
   __shared__ __align__(16) uint8_t tiles[kWsWaves][64 * kRowPitch];
+  __shared__ __align__(16) uint32_t plut[PK ? 512 * (KW == 2 ? 2 : 4) : 4];   // PK: the permute selectors per code
+  if (PK) {
+    for (int c = threadIdx.x; c < 512; c += blockDim.x) {
+      const uint32_t a = c & 1, c0 = (c >> 1) & 7, c1 = (c >> 4) & 3, c2 = (c >> 6) & 3, c3 = (c >> 8) & 1;
+      auto half = [](uint32_t b) { return b | ((b + 1) << 8); };   // the two byte indices of the half that begins at byte b
+      const uint32_t selL = half(a ? 4 : 0) | (half(2) << 16);
+      if (KW == 2) {
+        const uint32_t n0 = c0 == 1 ? 2 : c0 == 4 ? 4 : 0, n1 = c1 == 3 ? 4 : 2;
+        plut[2 * c] = half(n0) | (half(n1) << 16);
+        plut[2 * c + 1] = selL;
+      } else {
+        const uint32_t a0 = c0 == 1 ? 2 : c0 == 2 ? 4 : c0 == 3 ? 6 : 0, a1 = c1 == 1 ? 4 : c1 == 2 ? 6 : 2;
+        plut[4 * c] = half(a0) | (half(a1) << 16);                                       // selA: among the old starts
+        plut[4 * c + 1] = half(c0 == 4 ? 4 : 0) | (half(c1 == 3 ? 4 : 2) << 16);          // selB: the position into slot 0 / 1
+        plut[4 * c + 2] = half(c2 == 1 ? 2 : c2 == 2 ? 4 : 0) | (half(c3 == 1 ? 4 : 2) << 16);   // selC: slots 2, 3
+        plut[4 * c + 3] = selL;
+      }
+    }
+  }
   extern __shared__ __align__(16) uint8_t lds[];
   // PRE: the tables as LDS ADDRESSES -- cls4[byte] = 4 x class (at most 64 classes: it stays a byte), and an entry's
   // bits 16.. = LDS byte address of the next configuration's row instead of its index -- so that a byte's entry is at
@@ -686,6 +715,7 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_mwalk(DevPlan p, const uint8_
     if (MODE == STEP_SLOTS) wo = 0;
     uint32_t e = pre ? (lds_base + 256u) << 16 : 0u;   // the last entry taken: bits 16.. = row of the current configuration
     int s0 = 0, s1 = 0, s2 = 0, s3 = 0, last = 0, k = 0, rs = -1, re = -1;
+    uint32_t R01 = 0, R23 = 0, Lr = 0;   // PK: starts of slots 0 | 1, 2 | 3, last (16-bit halves)
     auto report = [&](int a, int b) {
       if (MODE == STEP_EMIT) {
         if (wo < span_cap) *(int2*)(spans + 2 * wo) = make_int2(a, b);
@@ -730,10 +760,27 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_mwalk(DevPlan p, const uint8_
         if (PRE_) en = *(lds_cu32*)(uintptr_t)((e >> 16) + *(lds_cu8*)(uintptr_t)(lds_base + (BYTE_)));               \
         else en = tab[(e >> 16) + clsT[(BYTE_)]];                                                                    \
         const int pr = f - mis;                       /* text position of this byte */                               \
+        if (PK) { if (act && (en & 1u)) report((int)(R01 & 0xFFFFu), (int)(Lr & 0xFFFFu)); }                         \
+        else                                                                                                         \
         if (act && (en & 1u)) report(s0, last);      /* the oldest walk ended behind its last accepting position (rare branch) */ \
         /* the start registers move as the entry says; plain selects, no branches (code 0 = stays; a lane that is    \
            not stepping takes code 0 everywhere) */                                                                  \
         const uint32_t ea = ((FULL_) == 2 || act) ? en : 0u;                                                         \
+        if (PK) {                                                                                                    \
+          const uint32_t prpr = (uint32_t)pr * 0x10001u;                                                             \
+          const uint32_t* sel = plut + ((ea >> 1) & 0x1FFu) * (KW == 2 ? 2 : 4);                                     \
+          if (KW == 2) {                                                                                             \
+            const uint2 sv = *(const uint2*)sel;                                                                     \
+            R01 = __builtin_amdgcn_perm(prpr, R01, sv.x);                                                            \
+            Lr = __builtin_amdgcn_perm(prpr + 0x10001u, Lr, sv.y);                                                   \
+          } else {                                                                                                   \
+            const uint4 sv = *(const uint4*)sel;                                                                     \
+            const uint32_t t01 = __builtin_amdgcn_perm(R23, R01, sv.x);                                              \
+            R23 = __builtin_amdgcn_perm(prpr, R23, sv.z);                                                            \
+            R01 = __builtin_amdgcn_perm(prpr, t01, sv.y);                                                            \
+            Lr = __builtin_amdgcn_perm(prpr + 0x10001u, Lr, sv.w);                                                   \
+          }                                                                                                          \
+        } else                                                                                                       \
         if (MODE != STEP_COUNT && MODE != STEP_ANY) {                                                                \
         const uint32_t c0 = (ea >> 2) & 7u, c1 = (ea >> 5) & 3u;                                                     \
         int n0 = s0, n1 = s1;                                                                                        \
@@ -785,6 +832,8 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_mwalk(DevPlan p, const uint8_
       if (__all(fin || wb + CH >= end)) break;
     }
 #undef MRX_MW_LOAD
+    if (PK) { if (!fin && ((e >> 10) & 1u)) report((int)(R01 & 0xFFFFu), (int)(Lr & 0xFFFFu)); }
+    else
     if (!fin && ((e >> 10) & 1u)) report(s0, last);   // end of the text: the oldest walk has accepted
     if (live && !skipped) {
       if (MODE == STEP_COUNT || MODE == STEP_SLOTS || MODE == STEP_ANY) counts[i] = k;
@@ -4023,11 +4072,33 @@ int grid_for(int64_t n, int block) {
 // k_wstep for findall / count: plain route or required-byte route (a bool `use_req_route` in scope)
 // (and a DevPlan `p` or handle `h` whose flags say whether the bitset form runs: `wstep_bits`)
 // (and a bool `wstep_mwalk`: the plan's multi-walk form, k_mwalk, takes the plain route's place)
+// k_mwalk for a plan of `kw` walk slots; pk: every text is shorter than 64 KiB (the packed-start form, modes that
+// keep start registers)
+std::atomic<int> g_mwalk_pk{1};   // MRX_NO_MWALK_PK=1: never the packed form (A/B, and a parity test compares the two)
+bool mwalk_pk_ok(const Layout& lay, int64_t known_max) {
+  static const bool off = getenv("MRX_NO_MWALK_PK") && getenv("MRX_NO_MWALK_PK")[0] == '1';
+  if (off || !g_mwalk_pk || lay.vlen) return false;
+  const int64_t m = lay.offsets ? known_max : (lay.lens ? lay.stride : (int64_t)lay.len);
+  return m >= 0 && m <= 65535;
+}
+template <int MODE, class... Args>
+void mwalk_launch(int kw, bool pk, dim3 g, dim3 b, size_t lds_bytes, hipStream_t s, Args... args) {
+  if constexpr (MODE == STEP_COUNT || MODE == STEP_ANY) {
+    if (kw <= 2) hipLaunchKernelGGL((k_mwalk<MODE, 2>), g, b, lds_bytes, s, args...);
+    else if (kw == 3) hipLaunchKernelGGL((k_mwalk<MODE, 3>), g, b, lds_bytes, s, args...);
+    else hipLaunchKernelGGL((k_mwalk<MODE, 4>), g, b, lds_bytes, s, args...);
+  } else {
+    if (pk && kw <= 2) hipLaunchKernelGGL((k_mwalk<MODE, 2, 1>), g, b, lds_bytes, s, args...);
+    else if (pk) hipLaunchKernelGGL((k_mwalk<MODE, 4, 1>), g, b, lds_bytes, s, args...);
+    else if (kw <= 2) hipLaunchKernelGGL((k_mwalk<MODE, 2>), g, b, lds_bytes, s, args...);
+    else if (kw == 3) hipLaunchKernelGGL((k_mwalk<MODE, 3>), g, b, lds_bytes, s, args...);
+    else hipLaunchKernelGGL((k_mwalk<MODE, 4>), g, b, lds_bytes, s, args...);
+  }
+}
+thread_local int64_t t_csr_max_len = -1;   // longest text of the CSR batch req_wave_pays() last looked at (-1: not known)
 #define MRX_WSTEP_LAUNCH(MODE, ...)                                                        \
   do {                                                                                     \
-    if (wstep_mwalk && wstep_mwalk_k <= 2) hipLaunchKernelGGL((k_mwalk<MODE, 2>), __VA_ARGS__); \
-    else if (wstep_mwalk && wstep_mwalk_k == 3) hipLaunchKernelGGL((k_mwalk<MODE, 3>), __VA_ARGS__); \
-    else if (wstep_mwalk) hipLaunchKernelGGL((k_mwalk<MODE, 4>), __VA_ARGS__);             \
+    if (wstep_mwalk) mwalk_launch<MODE>(wstep_mwalk_k, wstep_mwalk_pk, __VA_ARGS__);         \
     else if (wstep_bm && wstep_bm_big) hipLaunchKernelGGL((k_wstep<MODE, 0, 0, 0, 1, 1>), __VA_ARGS__); \
     else if (wstep_bm) hipLaunchKernelGGL((k_wstep<MODE, 0, 0, 0, 1>), __VA_ARGS__);       \
     else if (wstep_bits) hipLaunchKernelGGL((k_wstep<MODE, 0, 1>), __VA_ARGS__);           \
@@ -4183,6 +4254,7 @@ int req_wave_pays(const Layout& lay, int64_t n, bool req_route, hipStream_t s, b
                   bool big = false, bool mwalk = false, bool marks_big = false) {
   *out = false;
   if (split) *split = 0;
+  t_csr_max_len = -1;
   if (g_long_text_mode) { *out = g_long_text_mode == 1 || g_long_text_mode == 3; return MRX_OK; }
   if (n <= 0) return MRX_OK;
   int64_t total = 0, max_len = 0;
@@ -4197,6 +4269,7 @@ int req_wave_pays(const Layout& lay, int64_t n, bool req_route, hipStream_t s, b
     HIP_TRY(hipStreamSynchronize(s));
     HIP_TRY(scratch_free(d_max, s));
     max_len = m;
+    if (!lay.vlen) t_csr_max_len = m;
   } else {
     total = n * (lay.lens ? lay.stride : (int64_t)lay.len);
   }
@@ -4420,14 +4493,9 @@ int run_match(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d_s, i
       // (measured, profiles/r03_multiwalk.md: an "is there a match" pass in front -- STEP_ANY, no start registers,
       // 3 TB/s -- doubles the rate on texts without a match and halves it where the first match lies deep in
       // the text; one pass at 0.9-1.3 TB/s whatever the text holds is the default)
-#define MRX_MW_SEARCH(KW)                                                                                                  \
-      hipLaunchKernelGGL((k_mwalk<STEP_SEARCH, KW>), dim3(wstep_grid(n)), dim3(64 * kWsWaves), mwalk_table_bytes(h->hp.dev), s, \
-                         h->hp.dev, H_BLOB(h), lay2, n, (int32_t*)nullptr, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0, \
-                         d_s, d_e)
-      if (h->hp.dev.mw_k <= 2) MRX_MW_SEARCH(2);
-      else if (h->hp.dev.mw_k == 3) MRX_MW_SEARCH(3);
-      else MRX_MW_SEARCH(4);
-#undef MRX_MW_SEARCH
+      mwalk_launch<STEP_SEARCH>(h->hp.dev.mw_k, mwalk_pk_ok(lay, t_csr_max_len), dim3(wstep_grid(n)), dim3(64 * kWsWaves),
+                                mwalk_table_bytes(h->hp.dev), s, h->hp.dev, H_BLOB(h), lay2, n, (int32_t*)nullptr,
+                                (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0, d_s, d_e);
       g_last_kernel = "k_mwalk_search";
       if (split > 0) {
         hipLaunchKernelGGL((k_req_wave<STEP_SEARCH, 0>), dim3(reqwave_grid(n)), dim3(64 * kRqWaves),
@@ -4986,6 +5054,7 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
                            !(match_next_sequence && (p.flags & PF_PREFILTER));
   const DevPlan pk = mwalk_req ? mwalk_req_plan(p) : p;   // what the lane kernels are launched with
   const int wstep_mwalk_k = pk.mw_k;
+  bool wstep_mwalk_pk = false;   // k_mwalk's packed-start form (every text below 64 KiB)
   bool step_ok = g_force_generic < 2 &&
                  (wstep_mwalk ||
                   (match_next_sequence ? ((p.flags & PF_STEP_SEARCH) && !(p.flags & PF_PREFILTER))
@@ -5142,10 +5211,12 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
           return rc2;
         }
       }
-      if (step_ok && !wstep_bits && !wstep_empty && !t_in_pieces)
+      if (step_ok && !wstep_bits && !wstep_empty && !t_in_pieces) {
         if (int rc = req_wave_pays(lay, n, use_req_route, s, &req_wave, (p.flags & PF_STEP_BIG) ? nullptr : &step_split,
                                    (p.flags & PF_STEP_BIG) != 0, wstep_mwalk, backset_on(p) && !wstep_mwalk))
           return rc;
+        wstep_mwalk_pk = wstep_mwalk && mwalk_pk_ok(lay, t_csr_max_len);
+      }
       lay2.split = step_split;
       wstep_bm = step_ok && backset_on(p) && !wstep_mwalk && !wstep_bits && !wstep_empty && !use_req_route && !req_wave &&
                  step_split == 0;
@@ -5977,6 +6048,7 @@ static int run_count_any(const mrx_handle* h, const Layout& lay, int64_t n, int3
     const bool wstep_mwalk = (mwalk_req || (mwalk_on(h->hp.dev) && !use_req_route)) && !wstep_bits && !wstep_empty;
     const DevPlan pk = mwalk_req ? mwalk_req_plan(h->hp.dev) : h->hp.dev;
     const int wstep_mwalk_k = pk.mw_k;
+    const bool wstep_mwalk_pk = false;   // (count keeps no start registers)
     bool req_wave = false;
     int split = 0;
     if (g_force_generic < 2 && !wstep_bits && !t_in_pieces && (h->hp.dev.flags & (PF_STEPPABLE | PF_STEP_REQ)) &&
@@ -6296,7 +6368,7 @@ void mrx_debug_dynamic_texts(int mode) { g_dyn_mode = mode < 0 ? 0 : mode > 2 ? 
 void mrx_debug_split_findall(int on) { g_split_findall = on ? 1 : 0; }
 void mrx_debug_subs_group(int g) { g_subs_group = (g == 0 || g == 16 || g == 32 || g == 64 || g == 256) ? g : -1; }
 void mrx_debug_litscan_pieces(int mode) { g_litscan_pieces = (mode == 0 || mode == 1) ? mode : 2; }
-void mrx_debug_multiwalk(int mode) { g_mwalk_mode = mode == 2 ? 2 : 0; }
+void mrx_debug_multiwalk(int mode) { g_mwalk_mode = mode == 2 ? 2 : 0; g_mwalk_pk = mode == 3 ? 0 : 1; }
 void mrx_release_scratch(void) { scratch_release_all(); }
 size_t mrx_debug_scratch_bytes(void) { return scratch_bytes_reserved(); }
 

@@ -247,8 +247,8 @@ def no_streaming_kernels():
 
 @contextlib.contextmanager
 def multiwalk(mode):
-    """2 = stepper plans never take their multi-walk form (k_mwalk: several walks side by side in one pass), 0 = where
-    the plan has one (the default)."""
+    """2 = stepper plans never take their multi-walk form (k_mwalk: several walks side by side in one pass), 3 = k_mwalk
+    without its packed-start form, 0 = where the plan has one (the default)."""
     lib = M.load_library()
     lib.mrx_debug_multiwalk(mode)
     try:
@@ -1610,27 +1610,34 @@ def test_stepper_one_wavefront_per_text(pat):
     assert sum(len(g) for g in got) >= 1
 
 
-@pytest.mark.parametrize("mw", [2, 0])
-@pytest.mark.parametrize("pat", [b"\\d+(\\.\\d+)?", b"\\w+\\d{2}", b"[a-z]+@[a-z]+", b"(foo|foobar)"])
+@pytest.mark.parametrize("mw", [2, 0, 3])
+@pytest.mark.parametrize("pat", [b"\\d+(\\.\\d+)?", b"\\w+\\d{2}", b"[a-z]+@[a-z]+", b"(foo|foobar)",
+                                 b"[A-Z]{10,20}[0-9]{15,25}", b"foo|[a-z]{3}\\d|[ab]", b"[0-9]+\\.[0-9]+", b"(?:xy){4}@{2}"])
 @pytest.mark.parametrize("n,pitch,var", [(130, 256, True), (70, 50, True), (64, 1024, False), (3, 7, True),
-                                         (40, 2304, True), (33, 2051, False)])   # >= 2 KiB: slot rows sized by the text
+                                         (40, 2304, True), (33, 2051, False),   # >= 2 KiB: slot rows sized by the text
+                                         (192, 512, False)])   # whole wavefronts of full rows: the kernels' paths without the per-byte frame test
 def test_stepper_on_fixed_pitch_batches(pat, n, pitch, var, mw):
     """k_wstep's frame form (mw = 2) and k_mwalk's (mw = 0, plans that have the multi-walk table) on fixed-pitch
     batches (aligned and not, with and without lens)."""
     _need_gpu()
     rng = np.random.default_rng(n * 31 + pitch + zlib.crc32(pat))
-    al = np.frombuffer(b"abcfoxr0123456789.-@ " + bytes(c for c in pat if chr(c).isalnum()) * 2, dtype=np.uint8)
+    al = np.frombuffer(b"abcfoxr0123456789.-@ xyAZ" + bytes(c for c in pat if chr(c).isalnum()) * 2, dtype=np.uint8)
     arr = rng.choice(al, size=(n, pitch)).astype(np.uint8)
+    if pitch >= 256:   # something for the counted repetitions to find
+        for i in range(0, n, 4):
+            k = int(rng.integers(0, pitch - 60))
+            arr[i, k:k + 14] = ord("Q"); arr[i, k + 14:k + 34] = ord("7")
+            arr[i, k + 40:k + 48] = np.frombuffer(b"xyxyxyxy", dtype=np.uint8); arr[i, k + 48:k + 50] = ord("@")
     lens = rng.integers(0, pitch + 1, size=n).astype(np.int32) if var else None
     rx = M.compile_regex(pat)
     assert "device.streamable=no" in rx.describe()
     d = torch.from_numpy(arr).cuda().reshape(-1)
     batch = M.DeviceBatch.strided(d, pitch, length=pitch, lens=torch.from_numpy(lens).cuda() if var else None)
     lib = M.load_library()
-    has_mw = mw == 0 and "multiwalk=yes" in rx.describe()
+    has_mw = mw != 2 and "multiwalk=yes" in rx.describe()
     with long_text_kernels(2), multiwalk(mw):   # this test is about the lane-per-text kernels
         pre, sp, tot = rx._dev_findall(batch)
-        has_bk = mw == 0 and not has_mw and "backset=yes" in rx.describe() and "required-byte route" not in rx.describe()
+        has_bk = mw != 2 and not has_mw and "backset=yes" in rx.describe() and "required-byte route" not in rx.describe()
         assert lib.mrx_last_kernel_name() == (b"k_mwalk" if has_mw else b"k_backscan+k_step_count" if has_bk else b"k_step_count")
         ss, se = rx.match_next(batch)
         if has_mw and b"@" not in pat:
