@@ -716,14 +716,14 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_mwalk(DevPlan p, const uint8_
     uint32_t e = pre ? (lds_base + 256u) << 16 : 0u;   // the last entry taken: bits 16.. = row of the current configuration
     int s0 = 0, s1 = 0, s2 = 0, s3 = 0, last = 0, k = 0, rs = -1, re = -1;
     uint32_t R01 = 0, R23 = 0, Lr = 0;   // PK: starts of slots 0 | 1, 2 | 3, last (16-bit halves)
+    // EMIT / SLOTS: the lane's output row and how many spans it may still take, as a pointer and a 32-bit count (the
+    // report branch is taken on nearly every byte step of a dense batch: 64-bit compares and adds in it cost 5 of 15)
+    int2* const orow = (int2*)spans + (MODE == STEP_SLOTS ? slot0 : wo);
+    const int64_t room64 = MODE == STEP_SLOTS ? (int64_t)slot_cap : span_cap - wo;
+    const int oroom = room64 < 0 ? 0 : room64 > 0x7FFFFFFF ? 0x7FFFFFFF : (int)room64;
     auto report = [&](int a, int b) {
-      if (MODE == STEP_EMIT) {
-        if (wo < span_cap) *(int2*)(spans + 2 * wo) = make_int2(a, b);
-        ++wo;
-      }
-      if (MODE == STEP_SLOTS) {
-        if (wo < slot_cap) *(int2*)(spans + 2 * (slot0 + wo)) = make_int2(a, b);
-        ++wo;
+      if (MODE == STEP_EMIT || MODE == STEP_SLOTS) {
+        if (k < oroom) orow[k] = make_int2(a, b);
       }
       if (MODE == STEP_SEARCH) { rs = a; re = b; fin = true; }
       if (MODE == STEP_ANY) fin = true;
@@ -811,9 +811,12 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_mwalk(DevPlan p, const uint8_
         const int f0 = wb + g * 16;
         const uint4 wv = *(const uint4*)(myrow + g * 16);
         const uint32_t words[4] = {wv.x, wv.y, wv.z, wv.w};
+        // (lanes that are finished -- a text without a match in the emit pass, a search that has its answer, an empty
+        // text -- do not keep the wavefront off the fast paths: they step on whatever their row holds, unreported)
         const bool covers = f0 >= mis && f0 + 16 <= end;
-        const bool all_full = pre && MODE != STEP_ANY && __all(MODE == STEP_SEARCH ? (fin || covers) : (!fin && covers));
-        if (all_full && MODE == STEP_SEARCH) {
+        // (the count pass keeps its loop lean: one fast form, no finished lanes in it)
+        const bool all_full = pre && MODE != STEP_ANY && __all(MODE == STEP_COUNT ? (!fin && covers) : (fin || covers));
+        if (all_full && MODE != STEP_COUNT && (MODE == STEP_SEARCH || __any(fin))) {
 #pragma unroll
           for (int q = 0; q < 16; ++q) MRX_MW_BYTE((words[q >> 2] >> ((q & 3) * 8)) & 0xFFu, f0 + q, 2, true);
         } else if (all_full) {
@@ -825,6 +828,13 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_mwalk(DevPlan p, const uint8_
         } else {
 #pragma unroll
           for (int q = 0; q < 16; ++q) MRX_MW_BYTE((words[q >> 2] >> ((q & 3) * 8)) & 0xFFu, f0 + q, 0, false);
+        }
+        if (MODE != STEP_COUNT && !all_full && !fin && f0 + 16 >= end) {
+          // the text ended in this group: its last report now (the oldest walk has accepted), then the lane rides along
+          if ((e >> 10) & 1u) {
+            if (PK) report((int)(R01 & 0xFFFFu), (int)(Lr & 0xFFFFu)); else report(s0, last);
+          }
+          fin = true;
         }
       }
 #undef MRX_MW_BYTE
