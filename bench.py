@@ -185,6 +185,10 @@ def main():
     ap.add_argument("--gather", action="store_true",
                     help="N > 1: time scan + results exchange (SURVEY.md 8(e): all-gatherv of the spans to every "
                          "rank) even with --no-extras; reported as an extra object, never as `value`")
+    ap.add_argument("--no-overlap-leg", action="store_true",
+                    help="skip the two-stream leg (`two_streams_overlapped`): a kernel trace of this command then holds "
+                         "serial launches only, and its average scan duration is the one `roofline.kernel_ms` reports "
+                         "(in the overlapped leg two scans share the device and each takes longer)")
     ap.add_argument("--no-extras", action="store_true",
                     help="N > 1: skip the extra legs (results exchange on the headline batch, config 3's per-GPU share)")
     ap.add_argument("--c3-texts", type=int, default=1 << 23, help="texts per GPU of the config-3 leg (256 B each)")
@@ -423,7 +427,7 @@ def main():
     # the same K steps round-robin on TWO streams (decode of step i under the scan of step i + 1), next to
     # the serial headline: an extra object, never `value`
     overlap_ms = None
-    if nstreams == 1 and rank == 0:
+    if nstreams == 1 and rank == 0 and not args.no_overlap_leg:
         s2 = [streams[0], torch.cuda.Stream(device=dev)]
         o2 = [outs[0], (torch.empty(n + 1, dtype=torch.int64, device=dev),
                         torch.empty((span_cap, 2), dtype=torch.int32, device=dev))]

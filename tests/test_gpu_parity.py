@@ -1340,6 +1340,23 @@ def test_generated_patterns_multiwalk_equals_stepper_and_oracle(seed):
         assert [int(x) for x in gc] == [len(g) for g in got], p
         for j in range(0, len(texts), 13):
             assert got[j] == O.findall(pb, texts[j]), (p, texts[j])
+        # whole wavefronts of full rows (fixed pitch, no lens): the kernels' paths without the per-byte frame test, the
+        # packed-start form (mrx_debug_multiwalk(3): without it), rows without a match beside rows full of them
+        blob = b"".join(texts) + bytes(al) * 8
+        rows = np.frombuffer((blob * (128 * 256 // len(blob) + 1))[:128 * 256], dtype=np.uint8).reshape(128, 256).copy()
+        rows[5::7] = ord("~")
+        fb = M.DeviceBatch.strided(torch.from_numpy(rows).cuda().reshape(-1), 256, length=256)
+        res = []
+        for mode in (0, 3, 2):
+            with long_text_kernels(2), multiwalk(mode):
+                pre_, sp_, tot_ = rx._dev_findall(fb)
+                s_, e_ = rx.match_next(fb)
+                c_ = rx.count(fb)
+            res.append((pre_.cpu().numpy(), sp_[:tot_].cpu().numpy(), s_.cpu().numpy(), e_.cpu().numpy(), c_.cpu().numpy()))
+        for other in res[1:]:
+            for a_, b_ in zip(res[0], other):
+                assert np.array_equal(a_, b_), p
+        assert np.array_equal(np.diff(res[0][0]), res[0][4]), p
     assert nmw > 60 and nreq >= 5 and nback >= 15, (nmw, nreq, nback)
 
 

@@ -7,7 +7,7 @@ O=$R/gpurun_out/r03
 mkdir -p $O
 cd $R
 python bench.py > $O/bench_line.json 2> $O/bench.err || exit 1
-(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/bench.py --no-cpu-baseline > $O/bench_line_under_rocprofv3.json 2> $O/prof.err) || exit 1
+(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/bench.py --no-cpu-baseline --no-overlap-leg > $O/bench_line_under_rocprofv3.json 2> $O/prof.err) || exit 1
 bash tools/pmc_pass.sh r03/pmc || exit 1
 python tools/bench_configs.py > $O/cfg.jsonl 2> $O/cfg.err || exit 1
 python tools/bench_configs.py sub >> $O/cfg.jsonl 2>> $O/cfg.err || exit 1
