@@ -52,6 +52,10 @@ struct Text {
   int pre_first = kPreUnknown, pre_last_nl = 0;
   mutable uint64_t win = 0;
   mutable int win_lo = 0x40000000;  // index of the window's first byte; invalid at start
+  // PF_LAZY_END plans: the LazyDFA's transition cache as this text's call has filled it so far -- bit s of lz_mid /
+  // lz_end = the transition of state s on the text's LAST byte value was first computed inside the text / while
+  // the last byte was consumed (walk_lazy_end)
+  mutable uint64_t lz_mid = 0, lz_end = 0;
   __device__ __forceinline__ Text(const uint8_t* p, int n) : ptr(p), len(n) {}
   __device__ __forceinline__ int at(int i) const {
     unsigned d = (unsigned)(i - win_lo);
@@ -466,6 +470,40 @@ __device__ inline int walk(const Ctx& c, const Text& t, int start) {
   return last;
 }
 
+// LazyDFA._run_lazy (pikevm.mojo:819-867) of a '$' program with the cache a freshly compiled pattern starts the
+// text's call with.  _compute_transition closes the target with '$' satisfied iff the byte it consumes is the last
+// of the text (pos + 1 == text_len, pikevm.mojo:869-942) and the result is cached for every later use of the same
+// (state, byte) -- within the call: the other walks of a findall, the match_next calls of a sub.  Only the value of
+// the text's last byte can ever be looked at "at the end", so the cache's memory is two state masks: pairs
+// (state, that byte) first computed inside the text take the plain row for good, pairs first computed on the last
+// byte take row nstates/2 + state for good -- including later uses INSIDE the text (a restarted search walks the
+// text again): upstream does exactly that.
+__device__ inline int walk_lazy_end(const Ctx& c, const Text& t, int start) {
+  int state = 0;
+  int pos = start;
+  int last = flag(c, PF_START_ACCEPTING) ? pos : -1;
+  const int ncls = c.p.ncls, ns = c.p.nstates >> 1;
+  const int last_byte = t.len > 0 ? t.at(t.len - 1) : -1;
+  while (pos < t.len) {
+    const int b = t.at(pos);
+    int row = state;
+    if (b == last_byte) {
+      const uint64_t bit = 1ull << state;
+      if (t.lz_end & bit) row = ns + state;
+      else if (!(t.lz_mid & bit)) {
+        if (pos + 1 == t.len) { t.lz_end |= bit; row = ns + state; }
+        else t.lz_mid |= bit;
+      }
+    }
+    const uint32_t e = c.trans[row * ncls + c.cls[b]];
+    if (e == 0xFFFFu) break;
+    state = e & 0x7FFF;
+    ++pos;
+    if (e & 0x8000u) last = pos;
+  }
+  return last;
+}
+
 __device__ inline int count_consecutive(const Ctx& c, const Text& t, int start) {
   int pos = start;
   while (pos < t.len && c.first[t.at(pos)]) ++pos;
@@ -558,6 +596,7 @@ __device__ __noinline__ int walk_bitset(const Ctx& c, const Text& t, int start) 
 }
 
 __device__ inline int lazy_walk(const Ctx& c, const Text& t, int start) {
+  if (flag(c, PF_LAZY_END)) return walk_lazy_end(c, t, start);
   if (!flag(c, PF_BITSET)) return walk(c, t, start);
   if (c.p.bs_nw == 1) return walk_bitset<1>(c, t, start);
   if (c.p.bs_nw == 2) return walk_bitset<2>(c, t, start);

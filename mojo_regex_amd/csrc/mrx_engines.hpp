@@ -88,6 +88,9 @@ struct LazyTables {
   std::vector<std::array<int32_t, 256>> trans;  // -1 dead
   std::vector<uint8_t> is_match;
   bool too_large = false;       // determinisation exceeded the state budget
+  // '$' programs: the transition as computed while the text's last byte is consumed ('$' holds in its closure)
+  bool has_end_variant = false;
+  std::vector<std::array<int32_t, 256>> trans_end;
 };
 void build_lazy(const Program& p, LazyTables& out, int max_dfa_states);
 

@@ -233,18 +233,30 @@ void build_lazy(const Program& p, LazyTables& out, int max_dfa_states) {
     ids[seen] = 0;
     sets.push_back(seen);
   }
-  for (size_t s = 0; s < sets.size(); ++s) {
+  // '$' programs: a transition computed while the LAST byte of the text is consumed closes with '$' satisfied
+  // (_compute_transition passes pos + 1 and text_len to _add_state, pikevm.mojo:869-942) and is cached like any
+  // other, so every (state, byte) has two possible targets; which one a text sees depends on where the pair first
+  // occurs in it (mrx_device.hpp: walk_lazy_end).  trans_end holds the "at the end" variant; the states reachable
+  // through either variant are explored with both.
+  const bool two = p.has_end_anchor();
+  out.has_end_variant = two;
+  auto new_row = [&]() {
     out.trans.emplace_back();
     out.trans.back().fill(-1);
+    if (two) { out.trans_end.emplace_back(); out.trans_end.back().fill(-1); }
+  };
+  for (size_t s = 0; s < sets.size(); ++s) {
+    new_row();
     out.is_match.push_back(cl.has_match(sets[s]) ? 1 : 0);
   }
   for (size_t s = 0; s < sets.size(); ++s) {
+    for (int variant = 0; variant < (two ? 2 : 1); ++variant)
     for (int ch = 0; ch < 256; ++ch) {
       std::vector<uint8_t> nxt(n, 0);
       int leaves = 0;
       const std::vector<uint8_t> cur = sets[s];
       for (int pc = 0; pc < n; ++pc)
-        if (cur[pc] && cl.steps(pc, ch)) cl.add(nxt, leaves, pc + 1, false, false);
+        if (cur[pc] && cl.steps(pc, ch)) cl.add(nxt, leaves, pc + 1, false, variant == 1);
       if (leaves == 0) continue;  // LAZY_DFA_DEAD
       auto it = ids.find(nxt);
       int id;
@@ -253,13 +265,12 @@ void build_lazy(const Program& p, LazyTables& out, int max_dfa_states) {
         if (id >= max_dfa_states) { out.too_large = true; return; }
         ids[nxt] = id;
         sets.push_back(nxt);
-        out.trans.emplace_back();
-        out.trans.back().fill(-1);
+        new_row();
         out.is_match.push_back(cl.has_match(nxt) ? 1 : 0);
       } else {
         id = it->second;
       }
-      out.trans[s][ch] = id;
+      (variant ? out.trans_end : out.trans)[s][ch] = id;
     }
   }
 }

@@ -669,6 +669,7 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
   const bool too_large = hp.lazy.too_large && !use_bitset;
   const bool lazy_ok = hp.lazy.supported && !too_large;
   const bool nfa_end = hp.program.has_end_anchor();
+  bool lazy_end = false;   // '$' program on the LazyDFA search, per-text transition cache (below)
   bool bt_first = false, bt_search = false;   // operations the reference sends to NFAEngine's backtracking matcher
   if (nfa_engine) {
     // NFAEngine.match_first / match_next / match_all (nfa.mojo:169-498) and nothing else
@@ -699,9 +700,17 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
                          "(literal prefilter or leading/trailing .* fast path); its flat-program form does "
                          "not cover: " + hp.bt.why_not;
     }
-    else if (nfa_end)
-      hp.why_no_search = "LazyDFA search with '$' depends on the transition cache history "
-                         "(pikevm.mojo:697-700); not reproducible";
+    else if (nfa_end) {
+      // Upstream the answer depends on what EARLIER calls left in the transition cache (pikevm.mojo:697-700).  A
+      // batch has no call order: every text is answered as a freshly compiled pattern would answer it (the cache
+      // empty when the text's call begins, carried through the call's walks as upstream) -- the generic kernels
+      // keep, per text, which (state, last byte) pairs were first computed where (walk_lazy_end, mrx_device.hpp).
+      // Needs the determinised states of both transition variants to fit one 64-bit mask.
+      if (!use_bitset && !too_large && hp.lazy.has_end_variant && hp.lazy.trans.size() <= 64) lazy_end = true;
+      hp.why_no_search = lazy_end ? "(internal: '$' on the LazyDFA search, cleared at the end of build_plan)"
+                                  : "LazyDFA search with '$': the per-text transition cache is tracked for at most 64 "
+                                    "determinised states (pikevm.mojo:697-700)";
+    }
     else if (too_large)
       hp.why_no_search = "LazyDFA determinisation exceeds the state budget and the program has more "
                          "than 256 positions";
@@ -767,6 +776,15 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
       for (int c = 0; c < 256; ++c) row[c] = z.trans[s][c];
       T.push_back(row);
       acc.push_back(z.is_match[s]);
+    }
+    if (lazy_end) {   // rows nstates/2 ..: the transitions as computed while the text's last byte is consumed
+      for (size_t s = 0; s < z.trans_end.size(); ++s) {
+        std::array<int, 256> row;
+        for (int c = 0; c < 256; ++c) row[c] = z.trans_end[s][c];
+        T.push_back(row);
+        acc.push_back(z.is_match[s]);
+      }
+      d.flags |= PF_LAZY_END;
     }
     if (use_bitset) {  // the table is not used; only "does the start set accept" survives
       std::array<int, 256> row; row.fill(-1); T.push_back(row);
@@ -1486,6 +1504,13 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
     hp.why_no_match_first = "OnePass table too large for the streaming kernel's LDS table";
   align(hp.blob, 16);
   d.blob_bytes = (int)hp.blob.size();
+  // '$' on the LazyDFA search: none of the derived tables above exists for it (they were refused with the search);
+  // the generic lane-per-text kernels serve it
+  if (lazy_end && (d.flags & PF_LAZY_END)) {
+    hp.why_no_search.clear();
+    if (hp.streamable_why_not.empty() || hp.streamable_why_not[0] == '(')
+      hp.streamable_why_not = "'$' on the LazyDFA search: per-text transition cache (generic kernels)";
+  }
 }
 
 std::string describe_plan(const HostPlan& hp) {
@@ -1559,6 +1584,7 @@ std::string describe_plan(const HostPlan& hp) {
     << " fixed_concat=" << hp.fixed_concat << "\n";
   o << "support.match_first=" << (hp.why_no_match_first.empty() ? "yes" : hp.why_no_match_first) << "\n";
   o << "support.search=" << (hp.why_no_search.empty() ? "yes" : hp.why_no_search) << "\n";
+  if (d.flags & PF_LAZY_END) o << "device.lazy_end_cache=yes states=" << d.nstates / 2 << "\n";
   o << "device.kind=" << d.kind << " nstates=" << d.nstates << " ncls=" << d.ncls
     << " flags=0x" << std::hex << d.flags << std::dec << " blob_bytes=" << d.blob_bytes << "\n";
   o << "device.streamable=" << ((d.flags & PF_STREAMABLE) ? "yes" : ("no: " + hp.streamable_why_not))

@@ -56,6 +56,8 @@ enum PlanFlags : uint32_t {
   PF_BACKSET = 1u << 22,        // plain-route stepper plan with a BACKWARD table (DevPlan::off_bk_*): a right-to-left pass
                                 // marks the positions at which a match begins, the stepper then only starts walks
                                 // that succeed (k_backscan + k_wstep<., 0, 0, 0, 1>)
+  PF_LAZY_END = 1u << 23,       // '$' program on the LazyDFA search: transition rows nstates/2.. are the "computed at the
+                                // text's end" variants, chosen per text as the lazy cache would have them (generic kernels only)
   PF_STREAM_SEARCH = 1u << 11   // search / sub / captures may use the streaming kernel too (findall and
                                 // count may whenever PF_STREAMABLE is set): not with a memchr prefilter,
                                 // which only match_next consults (matcher.mojo:784-796)

@@ -7,9 +7,16 @@ CompiledRegex (:929-1163), module functions search/findall/split/match_first
 (:1418-1917); NFAEngine's constructor flags (src/regex/nfa.mojo:86-143).
 
 The recursive backtracking interpreter (nfa.mojo:657-1769) is restated in
-backtrack.py; calls the reference routes to it are answered from there.  What is
-still refused (UnsupportedByOracle): LazyDFA search / findall of '$' programs,
-whose results depend on the transition cache's history (pikevm.mojo:697-700).
+backtrack.py; calls the reference routes to it are answered from there.
+
+LazyDFA search / findall / sub of '$' programs (matcher.mojo:401-431 reach the LazyDFA before the OnePass
+branch that was meant for them): upstream results depend on what the transition cache holds from EARLIER
+calls -- a transition first computed while the last byte of some text was consumed carries "'$' holds" to
+every later use, one first computed elsewhere never sees '$' (pikevm.mojo:697-700, 869-942).  A batch has
+no call order, so the contract restated here is: every text is answered as a freshly compiled pattern
+would answer it -- CompiledRegex empties the cache at the start of every public call (FRESH_LAZY_CACHE;
+False = the cache lives as long as the object, as upstream).  Within one call (the walks of one findall,
+the match_next calls of one sub) the cache carries over exactly as upstream.
 """
 from __future__ import annotations
 
@@ -26,6 +33,9 @@ from .onepass import compile_onepass
 from .backtrack import BacktrackNFA
 
 Span = Tuple[int, int]
+
+
+FRESH_LAZY_CACHE = True   # module docstring: '$' programs on the LazyDFA search
 
 
 class UnsupportedByOracle(Exception):
@@ -201,21 +211,18 @@ class NFAMatcher:
             return self.onepass.match_first(text, start)
         return self.backtrack.match_first(text, start)
 
+    def fresh_cache(self):
+        if self.lazy is not None and self.lazy.has_end_anchor:
+            self.lazy.reset()
+
     def match_next(self, text: bytes, start: int = 0):
         if self._use_lazy_dfa_for_search():
-            if self.lazy.has_end_anchor:
-                raise UnsupportedByOracle(
-                    "LazyDFA search with '$' depends on cache history "
-                    "(pikevm.mojo:697-700)")
-            return self.lazy.match_next(text, start)
+            return self.lazy.match_next(text, start)   # ('$' programs: see the module docstring)
         # (_use_onepass_for_search needs the LazyDFA branch above to have been taken: unreachable)
         return self.backtrack.match_next(text, start)
 
     def match_all(self, text: bytes):
         if self._use_lazy_dfa_for_search():
-            if self.lazy.has_end_anchor:
-                raise UnsupportedByOracle(
-                    "LazyDFA findall with '$' depends on cache history")
             return self.lazy.match_all(text)
         return self.backtrack.match_all(text)
 
@@ -470,6 +477,7 @@ class CompiledRegex:
             pattern = pattern.encode("latin-1")
         self.pattern = pattern
         self.matcher = HybridMatcher(pattern, force_nfa)
+        self._depth = 0
         self.fixed_total_width = -1
         self.fixed_num_groups = 0
         self.fixed_offsets = [0] * 10
@@ -502,16 +510,24 @@ class CompiledRegex:
         self.fixed_total_width = total
         self.fixed_concat = not has_lit
 
+    def _enter(self):
+        """Start of a public call: the LazyDFA of a '$' program forgets what earlier calls cached (module docstring)."""
+        if FRESH_LAZY_CACHE and self._depth == 0 and self.matcher.nfa_matcher is not None:
+            self.matcher.nfa_matcher.fresh_cache()
+
     def match_first(self, text: bytes, start: int = 0):
         return self.matcher.match_first(text, start)
 
     def match_next(self, text: bytes, start: int = 0):
+        self._enter()
         return self.matcher.match_next(text, start)
 
     def match_all(self, text: bytes):
+        self._enter()
         return self.matcher.match_all(text)
 
     def test(self, text: bytes) -> bool:
+        self._enter()
         return self.matcher.match_next(text, 0) is not None
 
     def is_match(self, text: bytes, start: int = 0) -> bool:
@@ -538,7 +554,12 @@ class CompiledRegex:
         return out
 
     def sub(self, repl: bytes, text: bytes, count: int = 0) -> bytes:
-        return _sub_impl(self, repl, text, count)
+        self._enter()
+        self._depth += 1   # (the match_next calls of this sub share one cache)
+        try:
+            return _sub_impl(self, repl, text, count)
+        finally:
+            self._depth -= 1
 
 
 def _apply_template_fixed(template, repl, text, match_start, offs, widths, ng) -> bytes:

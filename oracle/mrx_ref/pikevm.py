@@ -317,6 +317,11 @@ class LazyDFA:
         if vm.has_filter:
             self.lo_tbl, self.hi_tbl = build_nibble_tables(vm.first_byte_filter)
 
+    def reset(self):
+        """The cache as a freshly constructed LazyDFA has it (pikevm.mojo:702-717): no states but the start state."""
+        self.states = []
+        self.start_state_id = self._get_or_create_state_for_pos(0, 0)
+
     def _has_match_in_set(self, nfa_set) -> bool:
         prog = self.pikevm.program
         return any(nfa_set[pc] != 0 and prog.instructions[pc][0] == OP_MATCH

@@ -115,7 +115,11 @@ def test_out_of_scope_patterns_fail_loudly_without_a_gpu():
     assert "device.backtrack=no: more than 30 open choices" in d
     d = M.CompiledRegex("^[a-z]+[0-9]+$").describe()   # one-pass: match_first on the OnePass tables
     assert "support.match_first=yes" in d and "onepass=yes" in d
-    assert "support.search=LazyDFA search with '$'" in d
+    # its search runs on the LazyDFA upstream (matcher.mojo:401-431): served with a per-text transition cache (round 3)
+    assert "support.search=yes" in d and "device.lazy_end_cache=yes" in d
+    # ... as long as the states of both transition variants fit one 64-bit mask
+    d = M.CompiledRegex("(a|b)*a(a|b){5}$").describe()
+    assert "support.search=LazyDFA search with '$': the per-text transition cache is tracked for at most 64" in d, d
     rx = M.CompiledRegex("hello.world")   # literal-prefiltered backtracker search: flat program
     assert "support.search=yes" in rx.describe() and "literal_opt=1" in rx.describe()
     rx = M.CompiledRegex("hello(a|b)*world")   # the quantified group is not the last child: zero repetitions upstream

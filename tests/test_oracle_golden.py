@@ -140,8 +140,25 @@ def test_onepass_routing_and_rejections():
     # (nfa.mojo:1236-1311) gives back one byte at a time: count 1 -> 0, then `a` and `$` match at 4
     assert H.match_first(b"^aaaa.*a$", b"aaaaa") == (0, 5)
     assert H.match_first(b"^aaaa.*a$", b"aaaab") is None
-    with pytest.raises(UnsupportedByOracle):               # search with '$' stays LazyDFA (history dependent)
-        H.search(b"^[a-z]+$", b"abc")
+    # search with '$' stays on the LazyDFA (matcher.mojo:401-431), whose cached transitions carry "'$' held" or
+    # "'$' did not hold" from their FIRST computation (pikevm.mojo:869-942).  Restated with the cache empty at the
+    # start of every call (oracle/mrx_ref/hybrid.py, module docstring); traced by hand through _run_lazy:
+    #   "abc":    (S1, 'c') is first computed while the last byte is consumed -> closes with '$' -> match
+    #   "abcabc": (S1, 'c') is first computed at position 2, inside the text -> cached without '$' -> the walk from 0
+    #             ends without a match at 6, and so does every later start (the start closure passes '^' anywhere)
+    #   "abcabd": 'd' only occurs as the last byte -> match
+    assert H.search(b"^[a-z]+$", b"abc") == (0, 3)
+    assert H.search(b"^[a-z]+$", b"abcabc") is None
+    assert H.search(b"^[a-z]+$", b"abcabd") == (0, 6)
+    assert H.search(b"^[a-z]+$", b"abc") == (0, 3)        # (the call before left nothing behind)
+    H.FRESH_LAZY_CACHE = False                             # as upstream: the cache lives as long as the object
+    try:
+        H.clear_regex_cache()
+        assert H.search(b"^[a-z]+$", b"abcabc") is None
+        assert H.search(b"^[a-z]+$", b"abc") is None       # (S1, 'c') was cached without '$' by the call before
+    finally:
+        H.FRESH_LAZY_CACHE = True
+        H.clear_regex_cache()
 
 
 def test_hand_traced_backtracker_quirks(oracle_backend):
