@@ -58,7 +58,7 @@ enum {
   MRX_OK = 0,
   MRX_E_SYNTAX = 1,       /* the reference's parser raises on this pattern          */
   MRX_E_UNSUPPORTED = 2,  /* refused, never approximated: backtracker programs beyond */
-                          /* the flat form's limits, `$` on the LazyDFA search, ... */
+                          /* the flat form's limits, tables beyond their budgets ... */
                           /* mrx_last_error() carries the reason                    */
   MRX_E_NO_DEVICE = 3,    /* no HIP device / HIP runtime error                      */
   MRX_E_CAPACITY = 4,     /* output buffer too small; *total holds the need         */
