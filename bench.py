@@ -312,6 +312,110 @@ def main():
             step()
         torch.cuda.synchronize()
 
+    # ---- roofline of the dominant kernel: HIP events on its own launch stream -------
+    lib.mrx_timing_enable(1)
+    lib.mrx_timing_reset()
+    for _ in range(max(5, min(args.steps, 20))):
+        step()
+        torch.cuda.synchronize()
+    launches = ctypes.c_int64(0)
+    scan_ms = lib.mrx_timing_scan_ms(ctypes.byref(launches))
+    lib.mrx_timing_enable(0)
+    kernel = lib.mrx_last_kernel_name().decode()
+    # the same K steps round-robin on TWO streams (decode of step i under the scan of step i + 1), next to
+    # the serial headline: an extra object, never `value`
+    overlap_ms = None
+    if nstreams == 1 and rank == 0 and not args.no_overlap_leg:
+        s2 = [streams[0], torch.cuda.Stream(device=dev)]
+        o2 = [outs[0], (torch.empty(n + 1, dtype=torch.int64, device=dev),
+                        torch.empty((span_cap, 2), dtype=torch.int32, device=dev))]
+        def step2(i):
+            with torch.cuda.stream(s2[i & 1]):
+                rx.findall_async(batch, o2[i & 1])
+        for i in range(8):
+            step2(i)
+        torch.cuda.synchronize()
+        a0 = time.perf_counter()
+        for i in range(args.steps):
+            step2(i)
+        torch.cuda.synchronize()
+        overlap_ms = (time.perf_counter() - a0) / args.steps * 1e3
+        del o2
+    # algorithmic bytes per launch (DESIGN.md "Measurement"): every input byte once,
+    # + 8 B per span written to its slot + 4 B per text for the count
+    alg_bytes = float(n) * L + 8.0 * total + 4.0 * n
+    achieved = alg_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+
+    # ---- the other operations of the path on the same batch (rank 0's view; extra fields) -------
+    def _time(fn, reps=10):
+        fn()
+        torch.cuda.synchronize()
+        a = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - a) / reps
+
+    other = None
+    if rank == 0:
+        nb = float(n) * L
+        other = {"count_GBps": round(nb / _time(lambda: rx.count(batch)) / 1e9, 1),
+                 "search_GBps": round(nb / _time(lambda: rx.match_next(batch)) / 1e9, 1),
+                 "match_first_GBps_whole_batch": round(nb / _time(lambda: rx.match_first(batch)) / 1e9, 1),
+                 "note": "same batch, device resident, per rank; count = scan without records/decode"}
+
+    line = None
+    if rank == 0:
+        value = agg["bytes"] / agg["elapsed_s"] / 1e9
+        line = {
+            "metric": "GB/s input scanned + matches/sec, 1M x 1KiB batch, [a-z]+\\d+ DFA",
+            "value": round(value, 3), "unit": "GB/s",
+            "matches_per_s": round(agg["matches"] / agg["elapsed_s"], 1),
+            "n_gpus": world, "steps": args.steps,
+            # `warmup` = the W asked for; every untimed step before the timed region (the settle
+            # phase that precedes them included) is `untimed_steps`
+            "warmup": args.warmup, "untimed_steps": args.settle + args.warmup,
+            "ms_per_step": round(agg["elapsed_s"] / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "findall [a-z]+\\d+ over %d x %d B ASCII texts per GPU "
+                                   "(40/30/20/10 full/tokens/noise/adversarial)" % (n, L),
+                       "texts_per_gpu": n, "text_bytes": L, "pattern": PATTERN.decode(),
+                       "op": "findall", "matches_per_batch": int(total),
+                       "parallelism": "texts sharded, %d rank(s), no data-path collective" % world,
+                       "streams": nstreams, "settle_steps": args.settle},
+            "hbm_frac_of_peak_whole_step": round(value / world / HBM_PEAK_GBS, 4),
+            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": (measured_traffic(n, L) or (None, None))[0],
+                         "traffic_source": (measured_traffic(n, L) or (None, None))[1],
+                         "kernel_ms": round(scan_ms, 4), "launches_timed": int(launches.value),
+                         # kernel_ms: each launch alone on the device (a synchronisation between the timed launches),
+                         # which is what `achieved` is priced with.  In the timed region of a --streams 2 run the
+                         # scans of the two streams run side by side, so a kernel trace of this command shows about
+                         # twice this duration per launch (two kernels share the device); profiles/
+                         # rNN_kernel_stats_streams1.csv is the trace of --streams 1, where the two agree.
+                         "kernel_timing": "isolated launches",
+                         # real HBM traffic rate of the kernel next to what a plain float4 copy reaches
+                         # on this part (6.29 TB/s measured, MI355X_MICROARCH.md) -- informational
+                         "traffic_GBps": (round(measured_traffic(n, L)[0] / (scan_ms * 1e-3) / 1e9, 1)
+                                          if measured_traffic(n, L) and scan_ms > 0 else None),
+                         "copy_GBps_measured_on_part": 6290.0,
+                         "algorithmic_bytes_per_launch": int(alg_bytes)},
+        }
+        if overlap_ms is not None:
+            line["two_streams_overlapped"] = {
+                "ms_per_step": round(overlap_ms, 4),
+                "value": round(float(n) * L / (overlap_ms * 1e-3) / 1e9, 3), "unit": "GB/s",
+                "hbm_frac_of_peak_whole_step": round(float(n) * L / (overlap_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "note": "rank 0, the same K steps issued round-robin on two streams with separate outputs; "
+                        "round 2 printed this as `value`, round 1 and round 3 print the serial figure"}
+        if other is not None:
+            line["other_ops"] = other
+        if strong_info is not None:
+            line["strong"] = strong_info
+
     # ---- scan + results exchange (results stay sharded in the headline) -----------------------------
     # the one optional exchange step, "results only".  With the nccl backend it runs behind the
     # C ABI (include/mrx_comm.h: RCCL called by the library, all-gather of the sizes, then the spans into
@@ -381,7 +485,23 @@ def main():
         res["backend"] = backend
         return res
 
+    watchdog = None
     if extras or (args.gather and world > 1):
+        # The exchange legs are the one part of this file that no multi-GPU box has run yet.  If they hang (a rank
+        # that died, an RCCL rendezvous that never completes), the headline measured above must not be lost with
+        # them: after MRX_BENCH_EXTRAS_TIMEOUT seconds (default 300) rank 0 prints the line without the legs and
+        # every rank leaves.
+        import threading
+        limit = float(os.environ.get("MRX_BENCH_EXTRAS_TIMEOUT", "300"))
+
+        def _bail():
+            if rank == 0 and line is not None:
+                line["scan_plus_gather"] = {"error": "the extra legs did not finish within %.0f s (watchdog); headline unaffected" % limit}
+                print(json.dumps(line), flush=True)
+            os._exit(0)
+        watchdog = threading.Timer(limit, _bail)
+        watchdog.daemon = True
+        watchdog.start()
         comm = None
         try:
             if backend == "nccl":
@@ -410,116 +530,14 @@ def main():
                 config3_info = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
         if comm is not None:
             comm.close()
-        for _ in range(2):   # put the arena back into the headline batch's shape for the legs below
-            step()
-        torch.cuda.synchronize()
+        watchdog.cancel()
 
-    # ---- roofline of the dominant kernel: HIP events on its own launch stream -------
-    lib.mrx_timing_enable(1)
-    lib.mrx_timing_reset()
-    for _ in range(max(5, min(args.steps, 20))):
-        step()
-        torch.cuda.synchronize()
-    launches = ctypes.c_int64(0)
-    scan_ms = lib.mrx_timing_scan_ms(ctypes.byref(launches))
-    lib.mrx_timing_enable(0)
-    kernel = lib.mrx_last_kernel_name().decode()
-    # the same K steps round-robin on TWO streams (decode of step i under the scan of step i + 1), next to
-    # the serial headline: an extra object, never `value`
-    overlap_ms = None
-    if nstreams == 1 and rank == 0 and not args.no_overlap_leg:
-        s2 = [streams[0], torch.cuda.Stream(device=dev)]
-        o2 = [outs[0], (torch.empty(n + 1, dtype=torch.int64, device=dev),
-                        torch.empty((span_cap, 2), dtype=torch.int32, device=dev))]
-        def step2(i):
-            with torch.cuda.stream(s2[i & 1]):
-                rx.findall_async(batch, o2[i & 1])
-        for i in range(8):
-            step2(i)
-        torch.cuda.synchronize()
-        a0 = time.perf_counter()
-        for i in range(args.steps):
-            step2(i)
-        torch.cuda.synchronize()
-        overlap_ms = (time.perf_counter() - a0) / args.steps * 1e3
-        del o2
-    # algorithmic bytes per launch (DESIGN.md "Measurement"): every input byte once,
-    # + 8 B per span written to its slot + 4 B per text for the count
-    alg_bytes = float(n) * L + 8.0 * total + 4.0 * n
-    achieved = alg_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
-
-    # ---- the other operations of the path on the same batch (rank 0's view; extra fields) -------
-    def _time(fn, reps=10):
-        fn()
-        torch.cuda.synchronize()
-        a = time.perf_counter()
-        for _ in range(reps):
-            fn()
-        torch.cuda.synchronize()
-        return (time.perf_counter() - a) / reps
-
-    other = None
-    if rank == 0:
-        nb = float(n) * L
-        other = {"count_GBps": round(nb / _time(lambda: rx.count(batch)) / 1e9, 1),
-                 "search_GBps": round(nb / _time(lambda: rx.match_next(batch)) / 1e9, 1),
-                 "match_first_GBps_whole_batch": round(nb / _time(lambda: rx.match_first(batch)) / 1e9, 1),
-                 "note": "same batch, device resident, per rank; count = scan without records/decode"}
 
     if rank == 0:
-        value = agg["bytes"] / agg["elapsed_s"] / 1e9
-        line = {
-            "metric": "GB/s input scanned + matches/sec, 1M x 1KiB batch, [a-z]+\\d+ DFA",
-            "value": round(value, 3), "unit": "GB/s",
-            "matches_per_s": round(agg["matches"] / agg["elapsed_s"], 1),
-            "n_gpus": world, "steps": args.steps,
-            # `warmup` = the W asked for; every untimed step before the timed region (the settle
-            # phase that precedes them included) is `untimed_steps`
-            "warmup": args.warmup, "untimed_steps": args.settle + args.warmup,
-            "ms_per_step": round(agg["elapsed_s"] / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
-            "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "findall [a-z]+\\d+ over %d x %d B ASCII texts per GPU "
-                                   "(40/30/20/10 full/tokens/noise/adversarial)" % (n, L),
-                       "texts_per_gpu": n, "text_bytes": L, "pattern": PATTERN.decode(),
-                       "op": "findall", "matches_per_batch": int(total),
-                       "parallelism": "texts sharded, %d rank(s), no data-path collective" % world,
-                       "streams": nstreams, "settle_steps": args.settle},
-            "hbm_frac_of_peak_whole_step": round(value / world / HBM_PEAK_GBS, 4),
-            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": (measured_traffic(n, L) or (None, None))[0],
-                         "traffic_source": (measured_traffic(n, L) or (None, None))[1],
-                         "kernel_ms": round(scan_ms, 4), "launches_timed": int(launches.value),
-                         # kernel_ms: each launch alone on the device (a synchronisation between the timed launches),
-                         # which is what `achieved` is priced with.  In the timed region of a --streams 2 run the
-                         # scans of the two streams run side by side, so a kernel trace of this command shows about
-                         # twice this duration per launch (two kernels share the device); profiles/
-                         # rNN_kernel_stats_streams1.csv is the trace of --streams 1, where the two agree.
-                         "kernel_timing": "isolated launches",
-                         # real HBM traffic rate of the kernel next to what a plain float4 copy reaches
-                         # on this part (6.29 TB/s measured, MI355X_MICROARCH.md) -- informational
-                         "traffic_GBps": (round(measured_traffic(n, L)[0] / (scan_ms * 1e-3) / 1e9, 1)
-                                          if measured_traffic(n, L) and scan_ms > 0 else None),
-                         "copy_GBps_measured_on_part": 6290.0,
-                         "algorithmic_bytes_per_launch": int(alg_bytes)},
-        }
-        if overlap_ms is not None:
-            line["two_streams_overlapped"] = {
-                "ms_per_step": round(overlap_ms, 4),
-                "value": round(float(n) * L / (overlap_ms * 1e-3) / 1e9, 3), "unit": "GB/s",
-                "hbm_frac_of_peak_whole_step": round(float(n) * L / (overlap_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                "note": "rank 0, the same K steps issued round-robin on two streams with separate outputs; "
-                        "round 2 printed this as `value`, round 1 and round 3 print the serial figure"}
-        if other is not None:
-            line["other_ops"] = other
         if gather_info is not None:
             line["scan_plus_gather"] = gather_info
         if config3_info is not None:
             line["config3"] = config3_info
-        if strong_info is not None:
-            line["strong"] = strong_info
         if world == 1 and not args.no_cpu_baseline:
             m = min(args.cpu_sample, n)
             host = batch_t[:m].cpu().numpy()
