@@ -284,7 +284,12 @@ __host__ __device__ inline size_t bstep_table_bytes(int npos) { return 2048 + (s
 // CLSIDX = 1 (with BM, tables of more than 96 states -- PF_STEP_BIG): the table stays class indexed, cls[256] |
 // tr[(nstates + 1) x ncls] (last row = "a walk begins": the start state's transitions; which bytes may begin one is
 // in the marks already), two dependent LDS reads per step instead of one -- affordable now that no walk fails.
-template <int MODE, int ROUTE, int BITS = 0, int EMPTY = 0, int BM = 0, int CLSIDX = 0>
+// LZ = 1 (PF_LAZY_END: '$' program on the LazyDFA search): the plan's table holds every state twice --
+// rows nstates/2.. are the transitions as computed while the text's last byte is consumed -- and the lane keeps the
+// two state masks of walk_lazy_end() (mrx_device.hpp): which variant a (state, last-byte-value) pair was first
+// computed in decides the row for the rest of the text.  The idle row exists twice as well (its entry is the
+// start state's transition).
+template <int MODE, int ROUTE, int BITS = 0, int EMPTY = 0, int BM = 0, int CLSIDX = 0, int LZ = 0>
 __global__ __launch_bounds__(64 * kWsWaves) void k_wstep(DevPlan p, const uint8_t* __restrict__ blob, Layout lay,
                                                          int64_t n, int32_t* __restrict__ counts,
                                                          const int64_t* __restrict__ prefix,
@@ -300,6 +305,7 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_wstep(DevPlan p, const uint8_
   static_assert(!EMPTY || (!BITS && !ROUTE), "empty matches: plain route of a table plan");
   static_assert(!BM || (!BITS && !ROUTE && !EMPTY), "marks: plain route of a table plan");
   static_assert(!CLSIDX || BM, "the class-indexed table needs the marks (no first-byte filter in it)");
+  static_assert(!LZ || (!ROUTE && !BITS && !EMPTY && !BM), "per-text lazy cache: plain route of a table plan");
   uint16_t* tab = (uint16_t*)lds;
   const uint8_t* clsT = lds;                       // CLSIDX: cls[256] | tr[(ns + 1) x ncls]
   uint16_t* trc = (uint16_t*)(lds + 256);
@@ -360,6 +366,12 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_wstep(DevPlan p, const uint8_
       }
       tab[e] = (uint16_t)v;
     }
+    if (LZ)   // row ns + 1: looking for a start, the start state's transition in its "at the end" variant
+      for (int b = threadIdx.x; b < 256; b += blockDim.x) {
+        const uint32_t t = g_tr[(ns >> 1) * p.ncls + g_cls[b]];
+        tab[((ns + 1) << 8) + b] = (uint16_t)(((filt && !g_first[b]) || t == 0xFFFFu)
+                                                  ? (uint32_t)idle : ((t & 0x7FFFu) | ((t & 0x8000u) ? kWsAcc : 0u) | kWsStart));
+      }
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -388,6 +400,8 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_wstep(DevPlan p, const uint8_
     uint64_t bset = 0;   // BITS: live positions of the current walk (0 = looking for a start)
     const bool skipped = lay.split > 0 && t.len >= lay.split;   // k_req_wave's text
     bool fin = !live || t.len == 0 || skipped;
+    uint64_t lz_mid = 0, lz_end = 0;     // LZ: (state, last byte value) pairs first computed inside the text / on its last byte
+    const int lz_byte = (LZ && live && t.len > 0) ? (int)t.ptr[t.len - 1] : -1;
     const uint32_t* mybm = nullptr;      // BM: my text's marks (frame coordinates)
     int bm_idx = -1;
     uint32_t bm_word = 0;
@@ -498,7 +512,19 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_wstep(DevPlan p, const uint8_
             }
           }
         }
-        const uint32_t e = CLSIDX ? trc[state * p.ncls + clsT[byte]] : tab[(state << 8) + byte];
+        int row = state;
+        if (LZ && act && inside && (int)byte == lz_byte) {
+          // the transition of DFA state st0 on the text's last byte value: as the lazy cache has it by now
+          const int st0 = state == idle ? 0 : state;
+          const uint64_t bit = 1ull << st0;
+          bool at_end = (lz_end & bit) != 0;
+          if (!at_end && !(lz_mid & bit)) {   // first use: computed here, with '$' iff this is the last byte
+            at_end = pos + 1 == end;
+            if (at_end) lz_end |= bit; else lz_mid |= bit;
+          }
+          if (at_end) row = state == idle ? idle + 1 : (ns >> 1) + state;
+        }
+        const uint32_t e = CLSIDX ? trc[state * p.ncls + clsT[byte]] : tab[(row << 8) + byte];
         if (ROUTE == 1) {
           const bool scanning = state == idle;
           // SCAN
@@ -4114,13 +4140,14 @@ thread_local int64_t t_csr_max_len = -1;   // longest text of the CSR batch req_
     else if (wstep_bits) hipLaunchKernelGGL((k_wstep<MODE, 0, 1>), __VA_ARGS__);           \
     else if (wstep_empty) hipLaunchKernelGGL((k_wstep<MODE, 0, 0, 1>), __VA_ARGS__);       \
     else if (use_req_route) hipLaunchKernelGGL((k_wstep<MODE, 1>), __VA_ARGS__);         \
+    else if (wstep_lz) hipLaunchKernelGGL((k_wstep<MODE, 0, 0, 0, 0, 0, 1>), __VA_ARGS__); \
     else hipLaunchKernelGGL((k_wstep<MODE, 0>), __VA_ARGS__);                              \
   } while (0)
 // dynamic LDS of k_wstep for this plan
 size_t wstep_lds(const DevPlan& p, bool mwalk = false, bool bm_big = false) {
   if (mwalk) return mwalk_table_bytes(p);
   if (bm_big) return 256 + (size_t)(p.nstates + 1) * p.ncls * 2 + 16;
-  return (p.flags & PF_BSTEP) ? bstep_table_bytes(p.bs_npos) : wstep_table_bytes(p.nstates);
+  return (p.flags & PF_BSTEP) ? bstep_table_bytes(p.bs_npos) : wstep_table_bytes(p.nstates + ((p.flags & PF_LAZY_END) ? 1 : 0));
 }
 // PF_MWALK plans: several walks in one pass (k_mwalk) instead of the stepper's restart-per-position loop.
 // mrx_debug_multiwalk(2) / MRX_NO_MWALK=1: never (A/B runs, and the parity tests compare the two text by text).
@@ -4149,7 +4176,7 @@ DevPlan mwalk_req_plan(const DevPlan& p) {
 bool union_pass_for_table_plan(const DevPlan& p, bool search) {
   static const bool off = getenv("MRX_NO_UNION_PASS") && getenv("MRX_NO_UNION_PASS")[0] == '1';
   const bool plain = search ? (p.flags & PF_STEP_SEARCH) != 0 : ((p.flags & PF_STEPPABLE) && !(p.flags & PF_STEP_REQ));
-  return !off && plain && !(p.flags & (PF_BSTEP | PF_STEP_BIG)) && p.nstates <= 32 &&
+  return !off && plain && !(p.flags & (PF_BSTEP | PF_STEP_BIG | PF_LAZY_END)) && p.nstates <= 32 &&
          bscan_dfa_table_bytes(p.nstates, p.ncls) <= 26 * 1024;
 }
 // Bitset NFA, first pass (k_bscan): on return *out is `lay` with every text cut to what the second pass
@@ -4482,7 +4509,8 @@ int run_match(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d_s, i
     const bool big = (h->hp.dev.flags & PF_STEP_BIG) != 0;   // only the wavefront kernel has its table form
     const bool bits = (h->hp.dev.flags & PF_BSTEP) != 0;     // bitset NFA: the lane-per-text stepper only
     int split = 0;
-    if (!bits)
+    const bool lz = (h->hp.dev.flags & PF_LAZY_END) != 0;   // '$' on the LazyDFA search: one lane per text (the cache is the text's)
+    if (!bits && !lz)
       if (int rc = req_wave_pays(lay, n, false, s, &wave, big ? nullptr : &split, false, mwalk_on(h->hp.dev))) return rc;   // (not the `big` rule: search stops at the first match)
     Layout lay2 = lay;
     lay2.split = split;
@@ -4532,6 +4560,11 @@ int run_match(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d_s, i
     int32_t* d_limit = nullptr;
     if (split == 0 && union_pass_for_table_plan(h->hp.dev, true))   // texts in which no walk from any start reaches an accepting state are not searched
       if (int rc = bscan_limits(h, lay, n, 0, s, &lay2, &d_limit)) return rc;
+    if (lz)
+      hipLaunchKernelGGL((k_wstep<STEP_SEARCH, 0, 0, 0, 0, 0, 1>), dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_lds(h->hp.dev), s,
+                         h->hp.dev, H_BLOB(h), lay2, n, (int32_t*)nullptr, (const int64_t*)nullptr, (int32_t*)nullptr,
+                         (int64_t)0, d_s, d_e);
+    else
     hipLaunchKernelGGL((k_wstep<STEP_SEARCH, 0>), dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_lds(h->hp.dev), s, h->hp.dev,
                        H_BLOB(h), lay2, n, (int32_t*)nullptr, (const int64_t*)nullptr, (int32_t*)nullptr,
                        (int64_t)0, d_s, d_e);
@@ -5055,6 +5088,7 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
   // match end visits -- the plain walk even on plans whose findall takes the required-byte route
   const bool use_req_route = (p.flags & PF_STEP_REQ) && !match_next_sequence;
   const bool wstep_bits = (p.flags & PF_BSTEP) != 0;   // bitset NFA on the lane-per-text stepper
+  const bool wstep_lz = (p.flags & PF_LAZY_END) != 0;  // '$' on the LazyDFA search: lane per text only (the cache is the text's)
   // plans with empty matches: count, then emit (nearly every text has more matches than a slot row holds)
   const bool wstep_empty = (p.flags & PF_STEP_EMPTY) != 0 && !match_next_sequence && g_force_generic < 2;
   // several walks in one pass instead of the restart-per-position loop (plain route; sub's match_next sequence is
@@ -5221,7 +5255,7 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
           return rc2;
         }
       }
-      if (step_ok && !wstep_bits && !wstep_empty && !t_in_pieces) {
+      if (step_ok && !wstep_bits && !wstep_empty && !t_in_pieces && !wstep_lz) {
         if (int rc = req_wave_pays(lay, n, use_req_route, s, &req_wave, (p.flags & PF_STEP_BIG) ? nullptr : &step_split,
                                    (p.flags & PF_STEP_BIG) != 0, wstep_mwalk, backset_on(p) && !wstep_mwalk))
           return rc;
@@ -6053,6 +6087,7 @@ static int run_count_any(const mrx_handle* h, const Layout& lay, int64_t n, int3
   } else {
     const bool use_req_route = (h->hp.dev.flags & PF_STEP_REQ) != 0;
     const bool wstep_bits = (h->hp.dev.flags & PF_BSTEP) != 0;
+    const bool wstep_lz = (h->hp.dev.flags & PF_LAZY_END) != 0;
     const bool wstep_empty = (h->hp.dev.flags & PF_STEP_EMPTY) != 0 && g_force_generic < 2;
     const bool mwalk_req = use_req_route && (h->hp.dev.flags & PF_MWALK_REQ) && mwalk_enabled();
     const bool wstep_mwalk = (mwalk_req || (mwalk_on(h->hp.dev) && !use_req_route)) && !wstep_bits && !wstep_empty;
@@ -6086,7 +6121,7 @@ static int run_count_any(const mrx_handle* h, const Layout& lay, int64_t n, int3
         return pieces_release(&spc, s);
       }
     }
-    if (g_force_generic < 2 && !wstep_bits && !t_in_pieces && (h->hp.dev.flags & (PF_STEPPABLE | PF_STEP_REQ)))
+    if (g_force_generic < 2 && !wstep_bits && !wstep_lz && !t_in_pieces && (h->hp.dev.flags & (PF_STEPPABLE | PF_STEP_REQ)))
       if (int rc = req_wave_pays(lay, n, use_req_route, s, &req_wave, (h->hp.dev.flags & PF_STEP_BIG) ? nullptr : &split,
                                  (h->hp.dev.flags & PF_STEP_BIG) != 0, wstep_mwalk, backset_on(h->hp.dev) && !wstep_mwalk))
         return rc;

@@ -1303,6 +1303,12 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
   // LazyDFA (pikevm.mojo:754-817): optional skip to a first-class / first-byte candidate, table
   // walk, emit (start, last accept) and continue at the match end, or retry at start + 1.
   // Everything that takes another branch upstream keeps the literal restatement in mrx_device.hpp.
+  if (lazy_end && (d.flags & PF_LAZY_END) && d.nstates <= 94 &&
+      !(d.flags & (PF_EXACT_LITERAL | PF_PREFILTER | PF_START_ACCEPTING | PF_START_DEAD | PF_BITSET | PF_BT_SEARCH))) {
+    // '$' on the LazyDFA search: the windowed stepper's plain route in its LZ form (both variants of every state's
+    // row and of the idle row in one byte-indexed table); one lane per text only -- no pieces, no wavefront kernel
+    d.flags |= PF_STEP_SEARCH | PF_STEPPABLE;
+  } else
   if ((d.kind == PLAN_DFA || d.kind == PLAN_LAZY) && hp.why_no_search.empty() &&
       !(d.flags & (PF_START_ANCHOR | PF_END_ANCHOR | PF_PURE_LITERAL | PF_EXACT_LITERAL | PF_START_ACCEPTING |
                    PF_START_DEAD | PF_BITSET | PF_SCAN_ELIGIBLE | PF_BT_SEARCH)) &&

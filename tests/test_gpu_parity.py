@@ -437,7 +437,7 @@ def test_streaming_kernel_equals_generic_and_oracle(pat, n, pitch, var):
     texts = [arr[i, : (lens[i] if var else pitch)].tobytes() for i in range(n)]
     with generic_kernels():
         generic = rx.findall_lists(texts)
-        assert M.load_library().mrx_last_kernel_name() == b"k_findall_count"
+        assert M.load_library().mrx_last_kernel_name() in (b"k_step_count", b"k_findall_count")   # (stepper in its LZ form; start-accepting plans: generic)
     assert rx.findall_lists(texts) == generic   # CSR batch -> streaming kernel, ragged frame
     assert M.load_library().mrx_last_kernel_name() in STREAM_FINDALL
     assert int(prefix[-1]) == total == sum(len(x) for x in generic)
@@ -528,7 +528,7 @@ def test_full_size_c2_properties():
     # the generic kernel (count only) agrees text by text
     with generic_kernels():
         counts2 = rx.count(batch)
-        assert M.load_library().mrx_last_kernel_name() == b"k_findall_count"
+        assert M.load_library().mrx_last_kernel_name() in (b"k_step_count", b"k_findall_count")   # (stepper in its LZ form; start-accepting plans: generic)
     assert bool((counts2.to(torch.int64) == counts).all())
     counts3 = rx.count(batch)   # count-only mode of the streaming kernel (no records, no decode)
     assert M.load_library().mrx_last_kernel_name() == b"k_stream_count"
@@ -687,7 +687,7 @@ def test_end_anchor_on_the_lazydfa_search_with_a_per_text_cache(pat):
         assert int(cnt[i]) == len(got[i])
         nmatch += len(got[i])
     assert nmatch > 0
-    assert M.load_library().mrx_last_kernel_name() == b"k_findall_count"
+    assert M.load_library().mrx_last_kernel_name() in (b"k_step_count", b"k_findall_count")   # (stepper in its LZ form; start-accepting plans: generic)
 
 
 FIRST_PATTERNS = STREAM_PATTERNS + [b"[a-z]*[0-9]*", b"^abc", b"a*", b"\\w+@\\w+\\.com", b"[a-c]+x[0-9]+y",
