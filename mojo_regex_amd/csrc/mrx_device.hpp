@@ -175,9 +175,19 @@ __device__ inline int bt_match_at(const Ctx& c, const Text& t, int start, BtCaps
           resumed = true;
           break;
         }
-        const int cnt = top_cnt - 1;
+        int cnt = top_cnt - 1;
         if (cnt < it.min) continue;
         if (top_pos + cnt > far100) continue;   // "new_pos > required_start_pos + 100": the choice is given up
+        // The item behind the leaf is a plain one-byte leaf ('.*' in front of a literal): counts at which that byte
+        // does not match would each come straight back here (set pos, fetch the item, test, fail, pop) -- step over
+        // them in place.  (A one-byte leaf fails without side effects; the cut-off above only ever applies to the
+        // first count tried, the later ones are smaller.)
+        if (top_ip + 1 < nitems) {
+          const BtItem nx = c.bt_items[top_ip + 1];
+          if (nx.kind == BT_LEAF && nx.min == 1 && nx.max == 1)
+            while (cnt >= it.min && !(top_pos + cnt < n && bt_in(c, nx.tbl, 0, t.at(top_pos + cnt)))) --cnt;
+          if (cnt < it.min) continue;
+        }
         pos = top_pos + cnt;
         ip = top_ip + 1;
         depth = top_depth;
