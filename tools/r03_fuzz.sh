@@ -1,15 +1,19 @@
 #!/bin/bash
 # Round-3 fuzz campaign on the GPU box (tests/big_fuzz.py against the oracle); prints one summary line per mode.
-# usage (under gpurun): bash tools/r03_fuzz.sh > gpurun_out/r03_fuzz.txt
+# usage (under gpurun, two calls of at most 20 minutes): bash tools/r03_fuzz.sh 1|2 > gpurun_out/r03_fuzz_N.txt
 run() {  # label, time limit, env...
   local label="$1" limit="$2"; shift 2
   echo "# $label"
-  env "$@" timeout -k 10 "$limit" python tests/big_fuzz.py 2>&1 | grep -E "^seed|MISMATCH|Traceback|Error" | tail -3
+  env "$@" timeout -k 10 "$limit" python tests/big_fuzz.py 2>&1 | grep -E "^seed|MISMATCH|Traceback|Error" | tail -1
 }
-run "default kernel choice, seeds 51000:16" 280 MRX_FUZZ_SEEDS=51000:16
-run "MRX_FUZZ_NFA=1 (NFA route and bitset kernels forced), seeds 52000:12" 280 MRX_FUZZ_NFA=1 MRX_FUZZ_SEEDS=52000:12
-run "MRX_FUZZ_EXTRA=1 (arbitrary bytes, fixed-pitch layouts, start, count), seeds 53000:8" 280 MRX_FUZZ_EXTRA=1 MRX_FUZZ_SEEDS=53000:8
-run "MRX_LONG_TEXT_MODE=1 (pieces / wavefront-per-text forms), seeds 54000:3" 280 MRX_LONG_TEXT_MODE=1 MRX_FUZZ_SEEDS=54000:3
-run "MRX_FUZZ_GROUPS=1 (capture groups), seeds 55000:30" 200 MRX_FUZZ_GROUPS=1 MRX_FUZZ_SEEDS=55000:30
-run "MRX_FUZZ_GEN=2 (second generator), seeds 56000:8" 200 MRX_FUZZ_GEN=2 MRX_FUZZ_SEEDS=56000:8
-run "mrx_debug_multiwalk:2 (no multi-walk / marks / fixed-length forms), seeds 57000:6" 150 MRX_FUZZ_DEBUG=mrx_debug_multiwalk:2 MRX_FUZZ_SEEDS=57000:6
+if [ "${1:-1}" = "1" ]; then
+run "default kernel choice, seeds 71000:16" 290 MRX_FUZZ_SEEDS=71000:16
+run "MRX_FUZZ_NFA=1 (NFA route and bitset kernels forced), seeds 72000:12" 290 MRX_FUZZ_NFA=1 MRX_FUZZ_SEEDS=72000:12
+run "MRX_FUZZ_EXTRA=1 (arbitrary bytes, fixed-pitch layouts, start, count), seeds 73000:8" 290 MRX_FUZZ_EXTRA=1 MRX_FUZZ_SEEDS=73000:8
+else
+run "MRX_LONG_TEXT_MODE=1 (pieces / wavefront-per-text forms), seeds 74000:3" 290 MRX_LONG_TEXT_MODE=1 MRX_FUZZ_SEEDS=74000:3
+run "MRX_FUZZ_GROUPS=1 (capture groups), seeds 75000:30" 220 MRX_FUZZ_GROUPS=1 MRX_FUZZ_SEEDS=75000:30
+run "MRX_FUZZ_GEN=2 (second generator), seeds 76000:8" 220 MRX_FUZZ_GEN=2 MRX_FUZZ_SEEDS=76000:8
+run "mrx_debug_multiwalk:2 (no multi-walk / marks / fixed-length forms), seeds 77000:6" 160 MRX_FUZZ_DEBUG=mrx_debug_multiwalk:2 MRX_FUZZ_SEEDS=77000:6
+run "mrx_debug_multiwalk:3 (multi-walk without the packed starts), seeds 78000:4" 120 MRX_FUZZ_DEBUG=mrx_debug_multiwalk:3 MRX_FUZZ_SEEDS=78000:4
+fi
