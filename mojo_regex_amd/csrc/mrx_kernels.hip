@@ -1786,9 +1786,9 @@ __device__ __forceinline__ int64_t fused_lookback(unsigned long long* ctrl, int6
     const bool need = lane <= F;
     const bool ok = (d1 & kDescValid) != 0ull && (!need || (gs >> kGroupCountShift) == 64ull);
     if (!__all(ok)) {   // a scan in front of me has not reported yet
-      if (++spins > kLookbackSpinLimit) {
+      if (++spins > kLookbackSpinLimit) {   // gave up (never seen): no spans are stored, the totals are poisoned
         if (lane == 0) __hip_atomic_fetch_or(ctrl + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        break;
+        return -1;
       }
       __builtin_amdgcn_s_sleep(2);
       continue;
@@ -1905,10 +1905,12 @@ __device__ __forceinline__ void fused_finish(const FusedArgs& fz, const EvRec* _
     if (!(fz.debug & 1))
     fused_fill_tile<REC32, false>(wave_recs, wrec, my_rel, 0, 0, tile, tile_bytes, fz.spans, fz.span_cap, fixed_len, lane);
     base = (fz.debug & 2) ? 0 : fused_lookback(fz.ctrl, w, nw, lane);
-    if (!(fz.debug & 4))
+    if (!(fz.debug & 4) && base >= 0)
     fused_store_tile<REC32>(tile, total_spans, base, fz.spans, fz.span_cap, lane);
   } else {
     base = fused_lookback(fz.ctrl, w, nw, lane);
+    if (base < 0) {
+    } else
     if (total_spans > 3 * tile_cap) {
       fused_fill_tile<REC32, true>(wave_recs, wrec, my_rel, 0, base, tile, tile_bytes, fz.spans, fz.span_cap, fixed_len, lane);
     } else {
@@ -1920,6 +1922,10 @@ __device__ __forceinline__ void fused_finish(const FusedArgs& fz, const EvRec* _
     }
   }
   const int64_t my_text = (w << 6) + lane;
+  if (base < 0) {   // a consumer of the CSR must not take it for complete (the host reports the error word as well)
+    if (lane == 0) { fz.prefix[n] = -1; *fz.total_out = -1; }
+    return;
+  }
   if (my_text < n) fz.prefix[my_text] = base + my_rel;
   if (my_text == n - 1) { fz.prefix[n] = base + incl; *fz.total_out = base + incl; }
 }
@@ -5649,7 +5655,13 @@ int mrx_compile(const char* pattern, size_t pattern_len, mrx_handle** out) {
 
 int mrx_compile_ex(const char* pattern, size_t pattern_len, uint32_t options, mrx_handle** out) {
   if (const char* e = getenv("MRX_NO_PAIR_TABLES")) g_pair_tables = !(e[0] == '1');
-  if (const char* e = getenv("MRX_FUSED")) g_fused = atoi(e) < 0 ? 0 : atoi(e) > 2 ? 2 : atoi(e);
+  {   // MRX_FUSED is read once per process, so that it does not override a later mrx_debug_fused_findall()
+    static const bool once = [] {
+      if (const char* e = getenv("MRX_FUSED")) g_fused = atoi(e) < 0 ? 0 : atoi(e) > 2 ? 2 : atoi(e);
+      return true;
+    }();
+    (void)once;
+  }
   if (const char* e = getenv("MRX_FUSED_BPC")) g_fused_bpc = atoi(e);
   if (!out || (!pattern && pattern_len)) return fail(MRX_E_ARGUMENT, "null argument");
   if (options & ~(uint32_t)(MRX_COMPILE_LAZYDFA_SEMANTICS | MRX_COMPILE_BITSET_NFA | MRX_COMPILE_NFA_ENGINE |
