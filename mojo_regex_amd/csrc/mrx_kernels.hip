@@ -3299,8 +3299,31 @@ struct WriteSink {
   uint8_t* out;
   int64_t pos, cap;
   __device__ __forceinline__ void bytes(const uint8_t* src, int k) {
-    for (int j = 0; j < k; ++j)
-      if (pos + j < cap) out[pos + j] = src[j];
+    if (pos + k > cap || k < 24) {   // clipped at the buffer's end, or short: byte by byte
+      for (int j = 0; j < k; ++j)
+        if (pos + j < cap) out[pos + j] = src[j];
+      pos += k;
+      return;
+    }
+    // A long piece (the text between two matches): aligned 8-byte stores; the source word for each is put
+    // together from the two aligned words that hold its bytes (every word read holds at least one byte of the piece)
+    uint8_t* d = out + pos;
+    int j = 0;
+    while ((uintptr_t)(d + j) & 7) { d[j] = src[j]; ++j; }
+    const uintptr_t sa = (uintptr_t)(src + j);
+    const uint64_t* sp = (const uint64_t*)(sa & ~(uintptr_t)7);
+    const int sh = (int)(sa & 7) * 8;
+    if (sh) {
+      uint64_t lo = *sp;
+      for (; j + 8 <= k; j += 8) {
+        const uint64_t hi = *++sp;   // (holds the chunk's last sh / 8 bytes)
+        *(uint64_t*)(d + j) = (lo >> sh) | (hi << (64 - sh));
+        lo = hi;
+      }
+    } else {
+      for (; j + 8 <= k; j += 8) *(uint64_t*)(d + j) = *sp++;
+    }
+    for (; j < k; ++j) d[j] = src[j];
     pos += k;
   }
 };
