@@ -489,10 +489,10 @@ def main():
     if extras or (args.gather and world > 1):
         # The exchange legs are the one part of this file that no multi-GPU box has run yet.  If they hang (a rank
         # that died, an RCCL rendezvous that never completes), the headline measured above must not be lost with
-        # them: after MRX_BENCH_EXTRAS_TIMEOUT seconds (default 300) rank 0 prints the line without the legs and
+        # them: after MRX_BENCH_EXTRAS_TIMEOUT seconds (default 150) rank 0 prints the line without the legs and
         # every rank leaves.
         import threading
-        limit = float(os.environ.get("MRX_BENCH_EXTRAS_TIMEOUT", "300"))
+        limit = float(os.environ.get("MRX_BENCH_EXTRAS_TIMEOUT", "150"))
 
         def _bail():
             if rank == 0 and line is not None:
