@@ -56,6 +56,9 @@ void mrx_debug_litscan_pieces(int mode);
  * without its packed-start form (starts as 16-bit halves moved by byte permutes, texts below 64 KiB), anything else
  * = where the plan has one.  Results are the same. */
 void mrx_debug_multiwalk(int mode);
+/* Placement experiments (profiles/r03_scan_forms.md): the streaming findall's record stream begins `bytes` (a multiple
+ * of 16) behind the start of its scratch allocation.  Results are the same. */
+void mrx_debug_rec_skew(int64_t bytes);
 /* include/mrx_comm.h, padded form of mrx_allgatherv_spans: its two device steps on buffers the caller fills as
  * ncclAllGather would have, so that the multi-rank arithmetic can be checked on one GPU.
  * shift: out[i] = prefix[i + 1] + (spans of the ranks before `rank`) for i < n_local, 0 up to pad_to.

@@ -4630,6 +4630,7 @@ int run_match(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d_s, i
 // its own, and what the fusion saves (0.46 GB of record traffic, two launch boundaries) is less than what
 // the per-task hand-offs add.  MRX_FUSED=1 / mrx_debug_fused_findall(1): on for tasks of >= 32 KiB, 2: always.
 std::atomic<int> g_fused{0};
+std::atomic<int64_t> g_rec_skew{0};   // mrx_debug_rec_skew(): bytes (a multiple of 16) the record stream begins behind its allocation
 std::atomic<int> g_fused_bpc{0};      // MRX_FUSED_BPC: workgroups per CU (measurement)
 int64_t fused_grid_cap() {
   const int bpc = g_fused_bpc.load() > 0 ? g_fused_bpc.load() : 4;
@@ -5149,6 +5150,7 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
   int step_split = 0;      // > 0: lane kernel for texts below this length AND wavefront kernel for the rest
   Layout lay2 = lay;       // lay + that split
   EvRec* d_recs = nullptr;
+  EvRec* d_recs_alloc = nullptr;   // what d_recs was cut from when it is skewed (mrx_debug_rec_skew)
   int32_t* d_nrecs = nullptr;
   int64_t* d_wbase = nullptr;
   int32_t* d_slots = nullptr;
@@ -5234,7 +5236,9 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
         if (int rc = findall_split(h, lay, n, d_counts, d_prefix, d_spans, span_cap, d_total, rec_row, rec32, max_text <= 65535, s))
           return rc;
       } else {
-      HIP_TRY(scratch_alloc((void**)&d_recs, sizeof(EvRec) * nrec, s));
+      const int64_t skew = g_rec_skew.load(std::memory_order_relaxed);   // (mrx_debug_rec_skew: placement experiments)
+      HIP_TRY(scratch_alloc((void**)&d_recs_alloc, sizeof(EvRec) * nrec + (size_t)skew, s));
+      d_recs = (EvRec*)((uint8_t*)d_recs_alloc + skew);
       HIP_TRY(scratch_alloc((void**)&d_nrecs, sizeof(int32_t) * 2 * nw, s));  // records | matches per wavefront
       HIP_TRY(scratch_alloc((void**)&d_wbase, sizeof(int64_t) * (nw + 1), s));
       ScanTimer tm(s);
@@ -5482,7 +5486,8 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
   HIP_TRY(scratch_free(d_counts, s));
   HIP_TRY(scratch_free(d_total, s));
   if (d_ctrl) { HIP_TRY(scratch_free(d_ctrl, s)); HIP_TRY(scratch_free(d_ctrl, s)); }   // ctrl block and the argument copy
-  if (d_recs) HIP_TRY(scratch_free(d_recs, s));
+  if (d_recs_alloc) HIP_TRY(scratch_free(d_recs_alloc, s));
+  else if (d_recs) HIP_TRY(scratch_free(d_recs, s));
   if (d_nrecs) HIP_TRY(scratch_free(d_nrecs, s));
   if (d_wbase) HIP_TRY(scratch_free(d_wbase, s));
   if (d_slots) HIP_TRY(scratch_free(d_slots, s));
@@ -6443,6 +6448,7 @@ double mrx_timing_scan_ms(int64_t* launches) {
 const char* mrx_last_kernel_name(void) { return g_last_kernel; }
 void mrx_debug_force_generic(int on) { g_force_generic = on < 0 ? 0 : on > 2 ? 2 : on; }
 void mrx_debug_long_text_kernels(int mode) { g_long_text_mode = mode < 0 ? 0 : mode > 3 ? 0 : mode; }
+void mrx_debug_rec_skew(int64_t bytes) { g_rec_skew = bytes < 0 ? 0 : (bytes & ~int64_t(15)); }
 void mrx_debug_fused_findall(int mode) { g_fused = mode < 0 ? 0 : mode > 2 ? 0 : mode; }
 void mrx_debug_dynamic_texts(int mode) { g_dyn_mode = mode < 0 ? 0 : mode > 2 ? 0 : mode; }
 void mrx_debug_split_findall(int on) { g_split_findall = on ? 1 : 0; }
