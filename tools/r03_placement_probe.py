@@ -42,7 +42,20 @@ for trial in range(8):
     d = src.clone()
     keep.append((pad, d))
     b = M.DeviceBatch.strided(d.reshape(-1), L, length=L)
-    print(json.dumps({"trial": trial, "batch_ptr": hex(d.data_ptr()), "scan_ms": scan_ms(b, out)}), flush=True)
+    # the same pages under two other readers: the count kernel (no record stream) and a plain device copy
+    import time
+    def timed(fn, reps=20):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return round((time.perf_counter() - t0) / reps * 1e3, 4)
+    dst = torch.empty_like(src) if trial == 0 else dst
+    print(json.dumps({"trial": trial, "batch_ptr": hex(d.data_ptr()), "scan_ms": scan_ms(b, out),
+                      "count_ms": timed(lambda: rx.count(b)), "copy_ms": timed(lambda: dst.copy_(d))}), flush=True)
 
 # the same batch (the last one), the record stream skewed inside its scratch allocation
 b = M.DeviceBatch.strided(keep[-1][1].reshape(-1), L, length=L)
