@@ -175,6 +175,15 @@ int mrx_findall_dev(const mrx_handle* h, const uint8_t* d_data,
                     const int64_t* d_offsets, int64_t n,
                     int64_t* d_counts_prefix, int32_t* d_spans, int64_t span_cap,
                     int64_t* total, void* stream);
+/* Same for a caller that knows its offsets (it built them on the host, or holds an Arrow array's): end_offset =
+ * d_offsets[n], max_text_len = the longest text's length -- both may be upper bounds, neither may be too small
+ * (they size scratch the kernels index with the real offsets).  mrx_findall_dev has to read the two from the device
+ * -- one small kernel and one stream synchronisation before its scan can be enqueued -- which this entry point
+ * spares: with total == NULL the whole call is asynchronous. */
+int mrx_findall_known_dev(const mrx_handle* h, const uint8_t* d_data,
+                          const int64_t* d_offsets, int64_t n, int64_t end_offset, int64_t max_text_len,
+                          int64_t* d_counts_prefix, int32_t* d_spans, int64_t span_cap,
+                          int64_t* total, void* stream);
 /* Same, texts at a fixed pitch (see header comment).  d_lens may be NULL. */
 int mrx_findall_strided_dev(const mrx_handle* h, const uint8_t* d_data,
                             int64_t stride, const int32_t* d_lens, int32_t len,

@@ -84,6 +84,8 @@ def load_library():
                                                   u8p, C.c_void_p]),
         "mrx_findall_dev": (C.c_int, [H, u8p, i64p, C.c_int64, i64p, i32p, C.c_int64,
                                       C.POINTER(C.c_int64), C.c_void_p]),
+        "mrx_findall_known_dev": (C.c_int, [H, u8p, i64p, C.c_int64, C.c_int64, C.c_int64, i64p, i32p, C.c_int64,
+                                           C.POINTER(C.c_int64), C.c_void_p]),
         "mrx_findall_strided_dev": (C.c_int, [H, u8p, C.c_int64, i32p, C.c_int32, C.c_int64, i64p,
                                               i32p, C.c_int64, C.POINTER(C.c_int64), C.c_void_p]),
         "mrx_count_dev": (C.c_int, [H, u8p, i64p, C.c_int64, i32p, C.c_void_p]),
@@ -146,7 +148,7 @@ EXPORTED_SYMBOLS = [
     "mrx_compile", "mrx_compile_ex", "mrx_free", "mrx_last_error", "mrx_engine_type", "mrx_stats", "mrx_describe",
     "mrx_num_groups", "mrx_match_first_dev", "mrx_search_dev", "mrx_match_first_strided_dev",
     "mrx_search_strided_dev", "mrx_is_match_dev", "mrx_is_match_strided_dev",
-    "mrx_findall_dev", "mrx_findall_strided_dev", "mrx_count_dev", "mrx_count_strided_dev",
+    "mrx_findall_dev", "mrx_findall_known_dev", "mrx_findall_strided_dev", "mrx_count_dev", "mrx_count_strided_dev",
     "mrx_captures_strided_dev", "mrx_captures_dev",
     "mrx_match_first_at_dev", "mrx_search_at_dev", "mrx_is_match_at_dev", "mrx_match_first_at_strided_dev",
     "mrx_search_at_strided_dev", "mrx_is_match_at_strided_dev",
@@ -204,6 +206,10 @@ class DeviceBatch:
         if data.dtype != torch.uint8 or not data.is_contiguous():
             raise MrxError("batch data must be a contiguous uint8 tensor")
         self.data, self.offsets, self.stride, self.length, self.lens = data, offsets, stride, length, lens
+        # CSR batches whose offsets were built on the host: offsets[n] and the longest text, so that findall does not
+        # have to read them back from the device (mrx_findall_known_dev); None = not known
+        self.end_offset: Optional[int] = None
+        self.max_len: Optional[int] = None
         if offsets is not None:
             if offsets.dtype != torch.int64 or not offsets.is_contiguous() or offsets.device != data.device:
                 raise MrxError("offsets must be a contiguous int64 tensor on the data's device")
@@ -238,7 +244,10 @@ class DeviceBatch:
         import torch
         data, offsets = pack_texts(texts)
         d = torch.from_numpy(data).to(device) if data.size else torch.zeros(0, dtype=torch.uint8, device=device)
-        return cls(d, torch.from_numpy(offsets).to(device))
+        b = cls(d, torch.from_numpy(offsets).to(device))
+        b.end_offset = int(offsets[-1])
+        b.max_len = int(np.diff(offsets).max()) if len(offsets) > 1 else 0
+        return b
 
     @classmethod
     def from_arrow(cls, arr, device="cuda"):
@@ -264,7 +273,10 @@ class DeviceBatch:
         data = np.frombuffer(bufs[2], dtype=np.uint8, count=hi - lo, offset=lo) if hi > lo else np.zeros(0, np.uint8)
         offs -= lo
         d = torch.from_numpy(data.copy()).to(device) if data.size else torch.zeros(0, dtype=torch.uint8, device=device)
-        return cls(d, torch.from_numpy(offs).to(device))
+        b = cls(d, torch.from_numpy(offs).to(device))
+        b.end_offset = int(offs[-1])
+        b.max_len = int(np.diff(offs).max()) if n > 0 else 0
+        return b
 
     def csr_offsets(self):
         """CSR offsets for the generic kernels (built on device for strided batches)."""
@@ -540,7 +552,11 @@ class CompiledRegex:
         out = (counts_prefix int64[n+1], spans int32[cap, 2]) device tensors; the total
         is counts_prefix[n] once the stream has drained (check it against cap)."""
         prefix, spans = out
-        if batch.offsets is not None:
+        if batch.offsets is not None and batch.end_offset is not None:
+            rc = self._lib.mrx_findall_known_dev(self._h, _ptr(batch.data), _ptr(batch.offsets), batch.n,
+                                                 batch.end_offset, batch.max_len, _ptr(prefix), _ptr(spans),
+                                                 spans.shape[0], None, self._stream_ptr())
+        elif batch.offsets is not None:
             rc = self._lib.mrx_findall_dev(self._h, _ptr(batch.data), _ptr(batch.offsets), batch.n,
                                            _ptr(prefix), _ptr(spans), spans.shape[0], None,
                                            self._stream_ptr())
@@ -565,7 +581,11 @@ class CompiledRegex:
             span_cap = spans.shape[0]
         total = C.c_int64(0)
         while True:
-            if batch.offsets is not None:
+            if batch.offsets is not None and batch.end_offset is not None:
+                rc = self._lib.mrx_findall_known_dev(self._h, _ptr(batch.data), _ptr(batch.offsets), batch.n,
+                                                     batch.end_offset, batch.max_len, _ptr(prefix), _ptr(spans),
+                                                     span_cap, C.byref(total), self._stream_ptr())
+            elif batch.offsets is not None:
                 rc = self._lib.mrx_findall_dev(self._h, _ptr(batch.data), _ptr(batch.offsets), batch.n,
                                                _ptr(prefix), _ptr(spans), span_cap, C.byref(total),
                                                self._stream_ptr())

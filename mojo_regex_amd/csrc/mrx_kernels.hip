@@ -6076,6 +6076,11 @@ int mrx_findall_dev(const mrx_handle* h, const uint8_t* d, const int64_t* off, i
                     int64_t* prefix, int32_t* spans, int64_t cap, int64_t* total, void* st) {
   return run_findall(h, Layout{d, off, 0, nullptr, 0}, n, prefix, spans, cap, total, st);
 }
+int mrx_findall_known_dev(const mrx_handle* h, const uint8_t* d, const int64_t* off, int64_t n, int64_t end_offset,
+                          int64_t max_text_len, int64_t* prefix, int32_t* spans, int64_t cap, int64_t* total, void* st) {
+  if (end_offset < 0 || max_text_len < 0) return fail(MRX_E_ARGUMENT, "end_offset and max_text_len must not be negative");
+  return run_findall(h, Layout{d, off, 0, nullptr, 0}, n, prefix, spans, cap, total, st, false, end_offset, max_text_len);
+}
 int mrx_findall_strided_dev(const mrx_handle* h, const uint8_t* d, int64_t stride,
                             const int32_t* lens, int32_t len, int64_t n, int64_t* prefix,
                             int32_t* spans, int64_t cap, int64_t* total, void* st) {

@@ -690,6 +690,31 @@ def test_end_anchor_on_the_lazydfa_search_with_a_per_text_cache(pat):
     assert M.load_library().mrx_last_kernel_name() in (b"k_step_count", b"k_findall_count")   # (stepper in its LZ form; start-accepting plans: generic)
 
 
+@pytest.mark.parametrize("pat", [b"[a-z]+\\d+", b"\\w+\\d{2}", b"(x|y|foo|bar)+", b"[A-Z]{10,20}[0-9]{15,25}|ab"])
+def test_findall_with_offsets_known_on_the_host(pat):
+    """mrx_findall_known_dev: the caller passes offsets[n] and the longest text's length (exact, or upper bounds) and
+    the call needs no read-back before its scan -- same CSR as mrx_findall_dev."""
+    _need_gpu()
+    rng = np.random.default_rng(zlib.crc32(pat) + 11)
+    al = b"abcxyz0123456789 fooQRSTUVWXYZ" + bytes(c for c in pat if chr(c).isalnum())
+    texts = _random_texts(rng, 3000, 300, al) + _random_texts(rng, 8, 9000, al) + [b"", b"ab12"]
+    rx = M.compile_regex(pat)
+    plain = M.DeviceBatch.from_texts(texts)
+    exact_end, exact_max = plain.end_offset, plain.max_len
+    assert exact_end == sum(len(t) for t in texts) and exact_max == max(len(t) for t in texts)
+    plain.end_offset = plain.max_len = None            # mrx_findall_dev: reads both from the device
+    want = rx._dev_findall(plain)
+    for end, mx in ((exact_end, exact_max), (exact_end + 12345, exact_max * 3 + 7)):
+        b = M.DeviceBatch(plain.data, plain.offsets)
+        b.end_offset, b.max_len = end, mx
+        got = rx._dev_findall(b)
+        assert got[2] == want[2] and torch.equal(got[0], want[0]) and torch.equal(got[1][:got[2]], want[1][:want[2]]), (pat, end, mx)
+        pre = torch.empty_like(want[0]); sp = torch.empty_like(want[1])
+        rx.findall_async(b, (pre, sp))
+        torch.cuda.synchronize()
+        assert torch.equal(pre, want[0]) and torch.equal(sp[:want[2]], want[1][:want[2]])
+
+
 FIRST_PATTERNS = STREAM_PATTERNS + [b"[a-z]*[0-9]*", b"^abc", b"a*", b"\\w+@\\w+\\.com", b"[a-c]+x[0-9]+y",
                                     b"\\d{3}-\\d{4}", b"hello world this is long", b"^[a-z]+\\d*", b"x?y?z?",
                                     b"[a-z]+\\s+[a-z]+\\s+[0-9]+"]
