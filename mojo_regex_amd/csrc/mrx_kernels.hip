@@ -2482,6 +2482,10 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_dyn(
   __shared__ __align__(16) uint8_t tiles[kStreamWaves][64 * kRowPitch];
   __shared__ __align__(16) uint16_t col_lds[256];
   __shared__ __align__(16) uint4 pmask[17];   // pmask[x]: the first x bytes of a 16-byte group set
+  // the task's texts in the order they are handed out: LONGEST FIRST (by length class), so that what is left for the
+  // end of the task are short texts and the lanes finish close together
+  __shared__ uint16_t perm_all[kStreamWaves][kDynTexts];
+  __shared__ int hist_all[kStreamWaves][32];
   if (threadIdx.x < 17) {
     const int x = threadIdx.x;
     uint32_t w[4];
@@ -2524,10 +2528,11 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_dyn(
   for (int64_t task = (int64_t)blockIdx.x * kStreamWaves + wave; task < ntasks; task += (int64_t)gridDim.x * kStreamWaves) {
     const int64_t T0 = task * kDynTexts;
     const int64_t T1 = T0 + kDynTexts < n ? T0 + kDynTexts : n;
-    int64_t next = T0 + 64;                       // first text nobody has taken (wave uniform)
+    const int ntask = (int)(T1 - T0);
+    int next = 64;                                // position in the hand-out order of the first text nobody has taken (wave uniform)
     // what a lane knows about the text it is walking
     int64_t my_text = T0 + lane;
-    bool active = my_text < T1;
+    bool active = lane < ntask;
     int my_len = 0, mis = 0, flen = 0;           // flen: frame position behind the text's last byte
     // row descriptor of a text (byte offset o0, length len; t < 0: none) taken over at chunk `shift`
     auto describe = [&](int64_t t, int64_t o0, int len, int shift, int& len_o, int& mis_o, int& flen_o) {
@@ -2541,21 +2546,88 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_dyn(
       *(uint4*)(tile + lane * kRowPitch + CH) =
           make_uint4((uint32_t)rb, (uint32_t)((uint64_t)rb >> 32), len > 0 ? (uint32_t)flen_o : 0u, (uint32_t)shift);
     };
-    // where a text lies: lane l keeps the offsets (and view lengths) of text next + l, loaded one chunk ahead, so
-    // that a lane taking text next + rank gets them by a cross-lane read instead of a dependent global load
-    // in front of the next chunk's prefetch
-    auto load_window = [&](int64_t first, int64_t& w0, int64_t& w1, int& wl) {
-      const int64_t t = first + lane < T1 ? first + lane : T1 - 1;   // (clamped: entries at or past T1 are never handed out)
-      w0 = offsets[t];
-      w1 = vlen ? 0 : offsets[t + 1];
-      wl = vlen ? vlen[t] : 0;
+    // where the task's texts lie: lane l keeps offsets[T0 + 64 j + l] (and the view lengths) for every j, read once;
+    // a lane taking text ti gets them by cross-lane reads instead of a dependent global load in front of the next
+    // chunk's prefetch.  (off_of / len_of are cross-lane: every lane of the wavefront calls them together.)
+    constexpr int KJ = kDynTexts / 64;
+    int64_t offr[KJ + 1];
+    int lenr[KJ];
+#pragma unroll
+    for (int j = 0; j <= KJ; ++j) {
+      const int64_t t = T0 + 64 * j + lane < T1 ? T0 + 64 * j + lane : T1;   // (clamped: offsets[T1] exists, views excepted)
+      offr[j] = vlen ? offsets[t < T1 ? t : T1 - 1] : offsets[t];
+      if (j < KJ) lenr[j] = vlen ? vlen[t < T1 ? t : T1 - 1] : 0;
+    }
+    auto off_of = [&](int ti) -> int64_t {
+      int64_t v = __shfl(offr[0], ti & 63);
+#pragma unroll
+      for (int j = 1; j <= KJ; ++j) { const int64_t u = __shfl(offr[j], ti & 63); v = (ti >> 6) == j ? u : v; }
+      return v;
     };
-    int64_t win0, win1;
-    int winl;
-    load_window(T0, win0, win1, winl);
-    __builtin_amdgcn_wave_barrier();
-    describe(active ? my_text : -1, win0, vlen ? winl : (int)(win1 - win0), 0, my_len, mis, flen);
-    load_window(next, win0, win1, winl);
+    if (!vlen) {   // lengths from the offsets: the next text's offset is the neighbour lane's (lane 63: the next row's lane 0)
+#pragma unroll
+      for (int j = 0; j < KJ; ++j) {
+        const int64_t up = __shfl_down(offr[j], 1), wrap = __shfl(offr[j + 1], 0);
+        lenr[j] = (int)((lane == 63 ? wrap : up) - offr[j]);
+      }
+    }
+    auto len_of = [&](int ti) -> int {
+      int v = __shfl(lenr[0], ti & 63);
+#pragma unroll
+      for (int j = 1; j < KJ; ++j) { const int u = __shfl(lenr[j], ti & 63); v = (ti >> 6) == j ? u : v; }
+      return v;
+    };
+    // hand-out order: counting sort of the task's texts by length class (32 classes of the task's longest text),
+    // longest class first
+    uint16_t* perm = perm_all[wave];
+    int* hist = hist_all[wave];
+    {
+      int mylen[KJ], tmax = 0;
+#pragma unroll
+      for (int j = 0; j < KJ; ++j) {
+        const int ti = 64 * j + lane;
+        const int l = len_of(ti < ntask ? ti : 0);
+        mylen[j] = ti < ntask ? l : 0;
+        tmax = max(tmax, mylen[j]);
+      }
+      for (int off = 32; off > 0; off >>= 1) tmax = max(tmax, __shfl_xor(tmax, off));
+      const int sh = tmax >= 32 ? 32 - __builtin_clz((unsigned)tmax) - 5 : 0;   // tmax >> sh < 32
+      __builtin_amdgcn_wave_barrier();
+      if (lane < 32) hist[lane] = 0;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      int slot[KJ], cls[KJ];
+#pragma unroll
+      for (int j = 0; j < KJ; ++j) {
+        cls[j] = 31 - (mylen[j] >> sh);
+        slot[j] = 64 * j + lane < ntask ? atomicAdd(&hist[cls[j]], 1) : 0;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      int hv = lane < 32 ? hist[lane] : 0, incl = hv;
+#pragma unroll
+      for (int d = 1; d < 32; d <<= 1) { const int v = __shfl_up(incl, d); if (lane >= d) incl += v; }
+      __builtin_amdgcn_wave_barrier();
+      if (lane < 32) hist[lane] = incl - hv;   // first position of the class
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int j = 0; j < KJ; ++j)
+        if (64 * j + lane < ntask) perm[hist[cls[j]] + slot[j]] = (uint16_t)(64 * j + lane);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    {
+      const int ti = active ? (int)perm[lane] : 0;
+      const int64_t o0 = off_of(ti);
+      const int l0 = len_of(ti);
+      my_text = T0 + ti;
+      describe(active ? my_text : -1, o0, l0, 0, my_len, mis, flen);
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -2590,15 +2662,15 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_dyn(
       int n_len = 0, n_mis = 0, n_flen = 0;
       if (fm) {   // wave uniform
         const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0));
-        const int64_t c0 = __shfl(win0, rank), c1 = __shfl(win1, rank);   // (all lanes take part in the cross-lane reads)
-        const int cl = __shfl(winl, rank);
+        const int cpos = next + rank;                                   // my place in the hand-out order, if I take a text
+        const int cti = cpos < ntask ? (int)perm[cpos] : 0;
+        const int64_t c0 = off_of(cti);                                 // (all lanes take part in the cross-lane reads)
+        const int cl = len_of(cti);
         if (fin) {
-          const int64_t cand = next + rank;
-          n_text = cand < T1 ? cand : -1;
-          describe(n_text, c0, vlen ? cl : (int)(c1 - c0), cbase + CH, n_len, n_mis, n_flen);
+          n_text = cpos < ntask ? T0 + cti : -1;
+          describe(n_text, c0, cl, cbase + CH, n_len, n_mis, n_flen);
         }
         next += __builtin_popcountll(fm);
-        load_window(next, win0, win1, winl);   // in flight while this chunk is walked
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
