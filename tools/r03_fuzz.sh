@@ -7,9 +7,9 @@ run() {  # label, time limit, env...
   env "$@" timeout -k 10 "$limit" python tests/big_fuzz.py 2>&1 | grep -E "^seed|MISMATCH|Traceback|Error" | tail -1
 }
 if [ "${1:-1}" = "1" ]; then
-run "default kernel choice, seeds 71000:16" 290 MRX_FUZZ_SEEDS=71000:16
-run "MRX_FUZZ_NFA=1 (NFA route and bitset kernels forced), seeds 72000:12" 290 MRX_FUZZ_NFA=1 MRX_FUZZ_SEEDS=72000:12
-run "MRX_FUZZ_EXTRA=1 (arbitrary bytes, fixed-pitch layouts, start, count), seeds 73000:8" 290 MRX_FUZZ_EXTRA=1 MRX_FUZZ_SEEDS=73000:8
+run "default kernel choice, seeds ${S1:-71000}:16" 290 MRX_FUZZ_SEEDS=${S1:-71000}:16
+run "MRX_FUZZ_NFA=1 (NFA route and bitset kernels forced), seeds ${S2:-72000}:12" 290 MRX_FUZZ_NFA=1 MRX_FUZZ_SEEDS=${S2:-72000}:12
+run "MRX_FUZZ_EXTRA=1 (arbitrary bytes, fixed-pitch layouts, start, count), seeds ${S3:-73000}:8" 290 MRX_FUZZ_EXTRA=1 MRX_FUZZ_SEEDS=${S3:-73000}:8
 else
 run "MRX_LONG_TEXT_MODE=1 (pieces / wavefront-per-text forms), seeds 74000:3" 290 MRX_LONG_TEXT_MODE=1 MRX_FUZZ_SEEDS=74000:3
 run "MRX_FUZZ_GROUPS=1 (capture groups), seeds 75000:30" 220 MRX_FUZZ_GROUPS=1 MRX_FUZZ_SEEDS=75000:30
