@@ -4,7 +4,7 @@
 run() {  # label, time limit, env...
   local label="$1" limit="$2"; shift 2
   echo "# $label"
-  env "$@" timeout -k 10 "$limit" python tests/big_fuzz.py 2>&1 | grep -E "^seed|MISMATCH|Traceback|Error" | tail -1
+  env PYTHONUNBUFFERED=1 "$@" timeout -k 10 "$limit" python tests/big_fuzz.py 2>&1 | grep -E "^seed|MISMATCH|Traceback|Error" | tail -1
 }
 if [ "${1:-1}" = "1" ]; then
 run "default kernel choice, seeds ${S1:-71000}:16" 290 MRX_FUZZ_SEEDS=${S1:-71000}:16
