@@ -35,6 +35,17 @@ void mrx_debug_long_text_kernels(int mode);
  * same results either way.  0 = three launches, 1 = one launch when a 64-text task has at least
  * 32 KiB, 2 = one launch for short texts too.  Environment: MRX_FUSED=0|1|2 at compile time. */
 void mrx_debug_fused_findall(int mode);
+/* 1: findall of streamable plans over fixed-pitch texts of at most 1 KiB (16-byte aligned pitch, search automaton in
+ * byte or code columns) runs as ONE launch that keeps every text's event bits in registers and writes offsets and
+ * spans at their final place (k_stream_bits: no record stream, 1.27 GB of traffic instead of 1.74 GB on the headline
+ * batch).  0 (default) = scan -> prefix sums -> decode: the one launch measured 4 % slower on 1 KiB texts and 1.5-3 x
+ * slower on shorter ones (profiles/r04_stream_bits.md: its expansion costs as many VALU instructions as the scan).
+ * Same results.  Environment: MRX_STREAM_BITS=1. */
+void mrx_debug_stream_bits(int on);
+/* Measurement: k_stream_bits writes four device clock readings (10 ns ticks) per 64-text task into d_trace
+ * [4 * tasks]: task taken, texts walked and count published, count of all texts before known, spans written.
+ * NULL = off (default). */
+void mrx_debug_stream_bits_trace(int64_t* d_trace);
 /* Ragged (CSR) batches of streamable plans with a reset byte are scanned by k_stream_dyn -- 256-text tasks,
  * a lane takes the next text when its own ends -- from 16384 texts up; 1 = always, 2 = never, 0 = by size. */
 void mrx_debug_dynamic_texts(int mode);

@@ -29,6 +29,8 @@
 #include "../../include/mrx.h"
 #include "../../include/mrx_testing.h"
 #include "mrx_device.hpp"
+#include "mrx_internal.hpp"
+#include "mrx_lookback.hpp"
 
 using namespace mrx;
 
@@ -109,33 +111,6 @@ __device__ __forceinline__ Ctx stage_tables(const DevPlan& p, const uint8_t* __r
   c.bt_lit = lds + (p.off_bt_lit >= 0 ? p.off_bt_lit : 0);
   return c;
 }
-
-// The text stream is read exactly once: non-temporal loads keep it from displacing the event
-// records (written here, read back by k_decode) in L2 / Infinity Cache.  -DMRX_NT_LOADS=0 to compare.
-#ifndef MRX_NT_LOADS
-#define MRX_NT_LOADS 1
-#endif
-typedef unsigned int mrx_u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ uint4 mrx_ldg(const uint4* p) {
-#if MRX_NT_LOADS
-  const mrx_u32x4 v = __builtin_nontemporal_load((const mrx_u32x4*)p);
-  return make_uint4(v.x, v.y, v.z, v.w);
-#else
-  return *p;
-#endif
-}
-#define MRX_LDG(P) mrx_ldg(P)
-typedef int mrx_i32x2 __attribute__((ext_vector_type(2)));
-// result spans are written once and not read again by this library
-__device__ __forceinline__ void mrx_stg_span(int32_t* p, int a, int b) {
-#if MRX_NT_LOADS
-  mrx_i32x2 v; v.x = a; v.y = b;
-  __builtin_nontemporal_store(v, (mrx_i32x2*)p);
-#else
-  *(int2*)p = make_int2(a, b);
-#endif
-}
-
 
 enum { OP_MATCH_FIRST = 0, OP_SEARCH = 1, OP_IS_MATCH = 2, OP_CAPTURES = 3 };
 
@@ -1741,71 +1716,6 @@ struct FusedArgs {
   int64_t rec_cap;            // records a wavefront's region holds (>= the most one task can produce)
   int32_t debug;              // measurement only (MRX_FUSED_DEBUG): 1 no record expansion, 2 no look-back, 4 no span stores
 };
-constexpr unsigned long long kDescValid = 1ull << 62, kDescVal = (1ull << 62) - 1ull;
-// group word: bits 0..39 = spans of the group's tasks that have reported, bits 40..47 = how many have
-constexpr int kGroupCountShift = 40;
-constexpr unsigned long long kGroupSumMask = (1ull << kGroupCountShift) - 1ull;
-constexpr uint32_t kLookbackSpinLimit = 1u << 22;   // insurance only: a predecessor is always a running wavefront
-
-// The end of a task's scan: its span count goes out at once, as the task's own descriptor and added
-// to its group's word (64 consecutive tasks form a group; fire-and-forget atomic, one word per group).
-// Every word is one 8-byte relaxed agent-scope access whose value IS the flag, so no fence is involved.
-__device__ __forceinline__ void fused_publish(unsigned long long* ctrl, int64_t w, int64_t nw, uint32_t total, int lane) {
-  if (lane == 0) {
-    unsigned long long* desc = ctrl + 2;
-    __hip_atomic_store(desc + w, kDescValid | (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    (void)__hip_atomic_fetch_add(desc + nw + (w >> 6), (unsigned long long)total + (1ull << kGroupCountShift),
-                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-
-// Spans of all tasks before task w = (tasks of my group before me, one window of task descriptors)
-// + (whole groups before mine, windows of 64 group words, cut short at the nearest group whose first
-// task has already published the running total at the group's start).  Nothing here waits for another
-// wavefront's look-back -- only for scans, and this runs one task late, so as a rule nothing waits at all.
-__device__ __forceinline__ int64_t fused_lookback(unsigned long long* ctrl, int64_t w, int64_t nw, int lane) {
-  unsigned long long* desc = ctrl + 2;
-  unsigned long long* gsum = desc + nw;
-  unsigned long long* ginc = gsum + ((nw + 63) >> 6);
-  const int64_t G = w >> 6;
-  const int r = (int)(w & 63);
-  int64_t base = 0;
-  bool level1 = true;
-  uint32_t spins = 0;
-  for (int64_t g0 = G - 1;;) {
-    unsigned long long d1 = kDescValid;
-    if (level1 && lane < r) d1 = __hip_atomic_load(desc + (w - 1 - lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int64_t g = g0 - lane;
-    unsigned long long gs = 64ull << kGroupCountShift, gi = kDescValid;   // in front of group 0: nothing, total 0
-    if (g >= 0) {
-      gs = __hip_atomic_load(gsum + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      gi = __hip_atomic_load(ginc + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    const uint64_t inc_m = __ballot((gi & kDescValid) != 0ull);
-    const int F = inc_m ? __builtin_ctzll(inc_m) : 64;   // nearest group whose starting total is known
-    const bool need = lane <= F;
-    const bool ok = (d1 & kDescValid) != 0ull && (!need || (gs >> kGroupCountShift) == 64ull);
-    if (!__all(ok)) {   // a scan in front of me has not reported yet
-      if (++spins > kLookbackSpinLimit) {   // gave up (never seen): no spans are stored, the totals are poisoned
-        if (lane == 0) __hip_atomic_fetch_or(ctrl + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return -1;
-      }
-      __builtin_amdgcn_s_sleep(2);
-      continue;
-    }
-    int64_t v = (level1 && lane < r ? (int64_t)(d1 & kDescVal) : 0) + (need ? (int64_t)(gs & kGroupSumMask) : 0) +
-                (lane == F ? (int64_t)(gi & kDescVal) : 0);
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    base += v;
-    level1 = false;
-    if (F < 64) break;
-    g0 -= 64;
-  }
-  if (r == 0 && lane == 0)   // the running total at the start of my group, for the groups behind
-    __hip_atomic_store(ginc + G, kDescValid | (unsigned long long)base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return base;
-}
-
 // A wavefront's own records -> spans at their final CSR position.  lane = record here, so the per-match
 // work is spread evenly whatever the texts look like.  fused_fill_tile places the spans [tb, tb + tile)
 // of the wavefront's range in an LDS tile (the text tile, free once the scan is over) -- that needs my_rel
@@ -5274,6 +5184,21 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
       const size_t fz_nrec = (size_t)(64 * fz_per_text + 64) * (size_t)(fz_grid * kStreamWaves) * 2;   // two regions per wavefront
       const int64_t batch_bytes = lay.offsets ? csr_total : n * (lay.lens ? lay.stride : (int64_t)lay.len);
       fused = !dyn && g_fused && span_cap > 0 && fz_nrec <= 2 * nrec + (size_t(8) << 20) && (g_fused == 2 || batch_bytes >= nw * kFusedMinTaskBytes);
+      // texts of at most 1 KiB at a 16-byte aligned pitch, automaton in registers: one launch, no records at all
+      // (mrx_stream_bits.hip)
+      const bool bits = !dyn && !fused && !lay.offsets && span_cap > 0 && !g_split_findall &&
+                        stream_bits_eligible(p, lay.data, lay.stride, max_text, n);
+      if (bits) {
+        void* d_args = nullptr;
+        HIP_TRY(scratch_alloc((void**)&d_ctrl, sizeof(unsigned long long) * stream_bits_ctrl_words(n), s));
+        HIP_TRY(scratch_alloc(&d_args, stream_bits_args_bytes(), s));
+        if (int rc = stream_bits_init(n, max_text, d_prefix, d_spans, span_cap, d_total, d_ctrl, d_args, s)) return rc;
+        ScanTimer tm(s);
+        if (int rc = stream_bits_scan(p, H_BLOB(h), lay.data, lay.stride, lay.lens, lay.len, max_text, n, d_args, s)) return rc;
+        g_last_kernel = "k_stream_bits";
+        tm.stop();
+        fused = true;   // (offsets and spans are complete: nothing is left for the launches below)
+      } else
       if (fused) {
         // ticket | error | one descriptor per task | two words per group of 64 tasks; a 16-byte multiple
         const size_t ctrl_words = (size_t)((2 + nw + 2 * ((nw + 63) / 64) + 1) & ~int64_t(1));
@@ -6527,6 +6452,8 @@ void mrx_debug_force_generic(int on) { g_force_generic = on < 0 ? 0 : on > 2 ? 2
 void mrx_debug_long_text_kernels(int mode) { g_long_text_mode = mode < 0 ? 0 : mode > 3 ? 0 : mode; }
 void mrx_debug_rec_skew(int64_t bytes) { g_rec_skew = bytes < 0 ? 0 : (bytes & ~int64_t(15)); }
 void mrx_debug_fused_findall(int mode) { g_fused = mode < 0 ? 0 : mode > 2 ? 0 : mode; }
+void mrx_debug_stream_bits(int on) { mrx::stream_bits_set_mode(on); }
+void mrx_debug_stream_bits_trace(int64_t* d_trace) { mrx::stream_bits_set_trace(d_trace); }
 void mrx_debug_dynamic_texts(int mode) { g_dyn_mode = mode < 0 ? 0 : mode > 2 ? 0 : mode; }
 void mrx_debug_split_findall(int on) { g_split_findall = on ? 1 : 0; }
 void mrx_debug_subs_group(int g) { g_subs_group = (g == 0 || g == 16 || g == 32 || g == 64 || g == 256) ? g : -1; }

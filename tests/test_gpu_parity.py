@@ -207,7 +207,7 @@ ALPHABETS = {
 import contextlib
 
 # findall of a streamable plan: one launch (scan + CSR offsets + spans fused), or scan -> sums -> decode
-STREAM_FINDALL = (b"k_stream_findall_fused", b"k_stream_findall")
+STREAM_FINDALL = (b"k_stream_findall_fused", b"k_stream_findall", b"k_stream_bits")
 
 
 @contextlib.contextmanager
@@ -220,6 +220,18 @@ def fused_findall(mode=2):
         yield
     finally:
         lib.mrx_debug_fused_findall(0)
+
+
+@contextlib.contextmanager
+def stream_bits(on):
+    """findall of short fixed-pitch texts as ONE launch with the event bits in registers (k_stream_bits, opt-in)
+    or, 0 = the default, as scan -> prefix sums -> decode."""
+    lib = M.load_library()
+    lib.mrx_debug_stream_bits(1 if on else 0)
+    try:
+        yield
+    finally:
+        lib.mrx_debug_stream_bits(0)
 
 
 @contextlib.contextmanager
@@ -1895,10 +1907,11 @@ def test_fused_findall_equals_three_launch_form(pat, shape):
             lens[:: 7] = 0
             batch = M.DeviceBatch.from_texts([arr[i, : lens[i]].tobytes() for i in range(n)])
         with long_text_kernels(2):   # (the 4 KiB texts would otherwise be cut into pieces)
-            with fused_findall():
+            with fused_findall(), stream_bits(0):
                 p1, s1, t1 = rx._dev_findall(batch)
                 assert lib.mrx_last_kernel_name() == b"k_stream_findall_fused"
-            p3, s3, t3 = rx._dev_findall(batch)
+            with stream_bits(0):
+                p3, s3, t3 = rx._dev_findall(batch)
             assert lib.mrx_last_kernel_name() == b"k_stream_findall"
         assert t1 == t3 and torch.equal(p1, p3) and torch.equal(s1[:t1], s3[:t3]), (pat, shape, n, pitch)
         # a span buffer that is too small: what fits is written in order, the need is reported
@@ -1906,12 +1919,114 @@ def test_fused_findall_equals_three_launch_form(pat, shape):
             cap = t1 // 2
             pre = torch.empty(batch.n + 1, dtype=torch.int64, device="cuda")
             sp = torch.full((cap + 4, 2), -9, dtype=torch.int32, device="cuda")
-            with long_text_kernels(2), fused_findall():
+            with long_text_kernels(2), fused_findall(), stream_bits(0):
                 rx.findall_async(batch, (pre, sp[:cap]))
                 assert lib.mrx_last_kernel_name() == b"k_stream_findall_fused"
             torch.cuda.synchronize()
             assert int(pre[-1]) == t1 and torch.equal(pre, p1)
             assert torch.equal(sp[:cap], s1[:cap]) and bool((sp[cap:] == -9).all())
+
+
+STREAM_BITS_PATTERNS = [b"[a-z]+\\d+", b"\\d+", b"[0-9]+", b"hello", b"a", b"abab", b"[a-z]+", b"[a-c]+[0-9]+",
+                        b"[^0-9]+", b"[a-z]+[0-9]+[a-z]+"]
+
+
+@pytest.mark.parametrize("pat", STREAM_BITS_PATTERNS)
+@pytest.mark.parametrize("shape", ["strided", "strided_short", "strided_lens"])
+def test_stream_bits_equals_three_launch_form_and_oracle(pat, shape):
+    """k_stream_bits (round 4: one launch, every text's event bits in registers, tickets + look-back, spans written at
+    their final place; texts of at most 1 KiB at a 16-byte aligned pitch) against scan -> prefix sums -> decode on
+    the same batches, and against the oracle text by text (DFAEngine.match_all, dfa.mojo:2028-2130).  Sizes chosen so
+    that one to many tickets, a partial last task, a partial last 64-text group, empty texts, texts that end inside
+    a chunk, all three register-file sizes (256 / 512 / 1024 bytes), tiles of more spans than one window holds and
+    matches that run to the end of the text all occur."""
+    _need_gpu()
+    lib = M.load_library()
+    rx = M.compile_regex(pat)
+    if "device.streamable=yes" not in rx.describe():
+        pytest.skip("not a streamable plan")
+    rng = np.random.default_rng(zlib.crc32(pat) + len(shape))
+    al = np.frombuffer(b"abcxyz0189 -fobar5" + bytes(c for c in pat if chr(c).isalnum()) * 2, dtype=np.uint8)
+    took_bits = 0
+    for n, pitch in ((1, 16), (63, 48), (64 * 9 + 5, 208), (4099, 64), (300, 1024), (257, 256), (1000, 512), (130, 528),
+                     (64 * 4 * 7, 1024), (5000, 128), (3, 1024)):
+        arr = rng.choice(al, size=(n, pitch)).astype(np.uint8)
+        for i in range(0, n, 3):   # dense rows: a match every two or three bytes
+            body = np.frombuffer((b"a1 " * pitch)[:pitch], dtype=np.uint8)
+            arr[i] = body if i % 2 == 0 else np.frombuffer((b"x" * pitch), dtype=np.uint8)
+        if n > 200:   # a whole 64-text group of the densest rows there are: several tile windows
+            arr[64:128] = np.frombuffer((b"a1" * pitch)[:pitch], dtype=np.uint8)
+        for i in range(1, n, 5):   # a match that runs to the end of the row
+            arr[i, -3:] = np.frombuffer(b"a12", dtype=np.uint8)
+        data = torch.from_numpy(arr).cuda().reshape(-1)
+        if shape == "strided":
+            lens = np.full(n, pitch)
+            batch = M.DeviceBatch.strided(data, pitch, length=pitch)
+        elif shape == "strided_short":
+            L = max(0, pitch - 5)
+            lens = np.full(n, L)
+            batch = M.DeviceBatch.strided(data, pitch, length=L)
+        else:
+            lens = rng.integers(0, pitch + 1, size=n).astype(np.int32)
+            lens[:: 11] = 0
+            lens[1:: 11] = pitch
+            batch = M.DeviceBatch.strided(data, pitch, lens=torch.from_numpy(lens).cuda())
+        with stream_bits(1):
+            p1, s1, t1 = rx._dev_findall(batch)
+            k1 = lib.mrx_last_kernel_name()
+        p3, s3, t3 = rx._dev_findall(batch)
+        assert lib.mrx_last_kernel_name() != b"k_stream_bits"
+        assert t1 == t3 and torch.equal(p1, p3) and torch.equal(s1[:t1], s3[:t3]), (pat, shape, n, pitch, k1)
+        if k1 != b"k_stream_bits":
+            continue
+        took_bits += 1
+        pre, sp = p1.cpu().numpy(), s1.cpu().numpy()
+        for i in list(range(0, n, max(1, n // 40))) + [n - 1]:
+            want = O.findall(pat, arr[i, : lens[i]].tobytes())
+            have = [tuple(int(x) for x in r) for r in sp[pre[i]:pre[i + 1]]]
+            assert have == want, (pat, shape, n, pitch, i)
+        # a span buffer that is too small: what fits is written in order, the need is reported
+        if t1 > 8:
+            cap = t1 // 2
+            pre_t = torch.empty(batch.n + 1, dtype=torch.int64, device="cuda")
+            sp_t = torch.full((cap + 4, 2), -9, dtype=torch.int32, device="cuda")
+            with stream_bits(1):
+                rx.findall_async(batch, (pre_t, sp_t[:cap]))
+            assert lib.mrx_last_kernel_name() == b"k_stream_bits"
+            torch.cuda.synchronize()
+            assert int(pre_t[-1]) == t1 and torch.equal(pre_t, p1)
+            assert torch.equal(sp_t[:cap], s1[:cap]) and bool((sp_t[cap:] == -9).all())
+    if pat in (b"[a-z]+\\d+", b"\\d+"):   # (automata of more than four states keep the three-launch form: hello, abab ...)
+        assert took_bits > 0, "the headline plans must take the one-launch form"
+
+
+def test_stream_bits_back_to_back_calls_on_two_streams():
+    """Tickets and look-back words are zeroed per call and live in the per-stream scratch arena: many calls in a
+    row on two streams (their launches overlap on the device, so neither grid is resident as a whole -- tasks
+    are handed out by ticket) give the same answer, and the arena stops growing."""
+    _need_gpu()
+    lib = M.load_library()
+    rx = M.compile_regex(b"[a-z]+\\d+")
+    batch_t = make_c2_batch(1 << 15, 1024, seed=5, device="cuda")
+    batch = M.DeviceBatch.strided(batch_t.reshape(-1), 1024, length=1024)
+    p0, s0, t0 = rx._dev_findall(batch)
+    assert lib.mrx_last_kernel_name() == b"k_stream_findall"
+    size0 = None
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [(torch.empty_like(p0), torch.empty_like(s0)) for _ in streams]
+    with stream_bits(1):
+        for it in range(40):
+            k = it % 2
+            with torch.cuda.stream(streams[k]):
+                rx.findall_async(batch, outs[k])
+                assert lib.mrx_last_kernel_name() == b"k_stream_bits"
+            if it == 9:
+                torch.cuda.synchronize()
+                size0 = lib.mrx_debug_scratch_bytes()
+        torch.cuda.synchronize()
+    assert lib.mrx_debug_scratch_bytes() == size0
+    for pre, sp in outs:
+        assert torch.equal(pre, p0) and torch.equal(sp[:t0], s0[:t0])
 
 
 def test_fused_findall_back_to_back_calls_reuse_their_scratch():
@@ -1923,7 +2038,8 @@ def test_fused_findall_back_to_back_calls_reuse_their_scratch():
     rx = M.compile_regex(b"[a-z]+\\d+")
     batch_t = make_c2_batch(1 << 14, 1024, seed=5, device="cuda")
     batch = M.DeviceBatch.strided(batch_t.reshape(-1), 1024, length=1024)
-    p0, s0, t0 = rx._dev_findall(batch)
+    with stream_bits(0):
+        p0, s0, t0 = rx._dev_findall(batch)
     assert lib.mrx_last_kernel_name() == b"k_stream_findall"
     size0 = None
     streams = [torch.cuda.Stream(), torch.cuda.Stream()]
