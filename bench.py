@@ -427,14 +427,28 @@ def main():
     config3_info = None
     extras = world > 1 and not args.no_extras and os.environ.get("MRX_BENCH_EXTRAS", "1") != "0"
 
+    import threading as _threading
+    progress = {"leg": "none", "call": "none"}     # what the watchdog reports if the legs hang
+    _print_lock = _threading.Lock()
+    _printed = [False]
+
+    def _claim_print():
+        with _print_lock:
+            if _printed[0]:
+                return False
+            _printed[0] = True
+            return True
+
     def exchange_leg(rx_, batch_, out_, n_, comm):
         """Times K steps of findall and of findall + exchange on this batch; returns the extra object."""
         gdev = dev if backend == "nccl" else None
         gsteps = max(3, min(args.steps, 10))
         pre_, sp_ = out_
+        progress["call"] = "first findall of the leg"
         rx_.findall_async(batch_, out_)
         tot = torch.tensor([int(pre_[n_].item())], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
         import torch.distributed as tdist
+        progress["call"] = "torch.distributed all_reduce of the span totals (%s)" % backend
         tdist.all_reduce(tot, op=tdist.ReduceOp.MAX)
         cap = int(tot.item()) + 1024          # padded form: slots every rank ships (the largest rank's spans)
         n_all = torch.tensor([n_], dtype=torch.int64, device=tot.device)
@@ -458,15 +472,23 @@ def main():
             return D.gather_spans(world, pre_, sp_, int(pre_[n_].item()))
 
         res = {}
+        how = "mrx_allgatherv_spans over RCCL" if comm is not None else "torch.distributed gather (%s)" % backend
         for name, fn in (("scan_only", scan_only), ("scan_plus_gather", scan_gather)):
-            for _ in range(2):
+            what = "findall" if name == "scan_only" else "findall + " + how
+            for k_ in range(2):
+                progress["call"] = "%s, warm-up step %d" % (what, k_)
                 r = fn()
+            progress["call"] = "%s, device synchronisation after the warm-up" % what
             torch.cuda.synchronize()
+            progress["call"] = "%s, barrier before the timed steps" % what
             D.barrier(world, gdev)
             g0 = time.perf_counter()
-            for _ in range(gsteps):
+            for k_ in range(gsteps):
+                progress["call"] = "%s, timed step %d of %d" % (what, k_, gsteps)
                 r = fn()
+            progress["call"] = "%s, device synchronisation after the timed steps" % what
             torch.cuda.synchronize()
+            progress["call"] = "%s, barrier after the timed steps" % what
             D.barrier(world, gdev)
             gel = time.perf_counter() - g0
             ga = D.combine(world, gel, {"bytes": float(batch_.nbytes_text) * gsteps}, device=dev if backend == "nccl" else "cpu")
@@ -495,16 +517,22 @@ def main():
         limit = float(os.environ.get("MRX_BENCH_EXTRAS_TIMEOUT", "150"))
 
         def _bail():
-            if rank == 0 and line is not None:
-                line["scan_plus_gather"] = {"error": "the extra legs did not finish within %.0f s (watchdog); headline unaffected" % limit}
+            # exactly one line, whoever gets there first (this timer or the main thread below); the exit status says
+            # that the legs hung -- the diagnosis is in the error object: which leg, which call was in flight
+            if rank == 0 and line is not None and _claim_print():
+                where = "leg %r, in flight: %s" % (progress["leg"], progress["call"])
+                line[progress["leg"] if progress["leg"] in ("scan_plus_gather", "config3") else "scan_plus_gather"] = {
+                    "error": "the extra legs did not finish within %.0f s (watchdog); %s; headline unaffected" % (limit, where)}
                 print(json.dumps(line), flush=True)
-            os._exit(0)
+            os._exit(3)
         watchdog = threading.Timer(limit, _bail)
         watchdog.daemon = True
         watchdog.start()
         comm = None
         try:
+            progress["leg"] = "scan_plus_gather"
             if backend == "nccl":
+                progress["call"] = "Comm.create: mrx_comm_init (ncclCommInitRank, %d ranks)" % world
                 comm = D.Comm.create(world, rank)
             batch.nbytes_text = n * L
             gather_info = exchange_leg(rx, batch, out, n, comm)
@@ -516,6 +544,7 @@ def main():
         if extras:
             try:
                 from mojo_regex_amd.workloads import make_digits_batch
+                progress["leg"], progress["call"] = "config3", "building the batch"
                 n3, L3 = args.c3_texts, 256
                 b3_t = make_digits_batch(n3, L3, seed=20260103 + rank, device=dev)
                 b3 = M.DeviceBatch.strided(b3_t.reshape(-1), L3, length=L3)
@@ -529,6 +558,7 @@ def main():
             except Exception as e:   # noqa: BLE001
                 config3_info = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
         if comm is not None:
+            progress["call"] = "Comm.close: mrx_comm_free"
             comm.close()
         watchdog.cancel()
 
@@ -542,11 +572,20 @@ def main():
             m = min(args.cpu_sample, n)
             host = batch_t[:m].cpu().numpy()
             cb, counts = cpu_baseline(host, PATTERN)
-            # the sample doubles as a parity spot check of the measured path
-            gpu_counts = (prefix[1:m + 1] - prefix[:m]).cpu().numpy()
-            cb["parity_on_sample"] = bool((gpu_counts == counts).all())
+            # the sample doubles as a parity spot check of the measured path: counts, CSR offsets AND every span of
+            # the sample's texts against the oracle's (the oracle writes its spans where the device's offsets put them)
+            pre = prefix[:m + 1].cpu().numpy()
+            gpu_counts = pre[1:] - pre[:-1]
+            from mrx_ref.cfast import CDfa
+            import numpy as np
+            ocnt, ospans, _ = CDfa(PATTERN).findall_at_mt(host.reshape(-1), np.arange(0, (m + 1) * L, L, dtype=np.int64), pre,
+                                                          max(1, min(64, len(os.sched_getaffinity(0)))))
+            same_counts = bool((gpu_counts == counts).all()) and bool((ocnt == counts).all())
+            cb["parity_on_sample"] = same_counts and bool(np.array_equal(spans[:int(pre[-1])].cpu().numpy(), ospans))
+            cb["parity_checks"] = "counts, offsets and all %d spans of the sample's texts" % int(pre[-1])
             line["cpu_baseline"] = cb
-        print(json.dumps(line), flush=True)
+        if _claim_print():
+            print(json.dumps(line), flush=True)
 
     if world > 1:
         import torch.distributed as dist

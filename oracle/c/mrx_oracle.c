@@ -322,6 +322,25 @@ int64_t mrx_oracle_count_batch_mt(const mrx_dfa* d, const uint8_t* data, const i
   return total;
 }
 
+/* findall of the whole batch on `threads` host threads, the spans of text i written at spans + 2 * prefix[i]
+ * (room: prefix[i + 1] - prefix[i]; a text with more matches than that keeps what fits) and its true count at
+ * counts[i]: the full-size parity tests hand in the DEVICE's offsets, so that one pass gives both the counts to
+ * compare with them and the spans in the device's layout.  Same per-text function as above (match_all,
+ * dfa.mojo:2028-2130). */
+int64_t mrx_oracle_findall_at_mt(const mrx_dfa* d, const uint8_t* data, const int64_t* offsets, int64_t n,
+                                 const int64_t* prefix, int32_t* spans, int32_t* counts, int threads) {
+  int64_t total = 0;
+#pragma omp parallel for schedule(dynamic, 64) num_threads(threads) reduction(+ : total)
+  for (int64_t i = 0; i < n; ++i) {
+    const int64_t room = prefix[i + 1] - prefix[i];
+    const int64_t k = mrx_oracle_match_all(d, data + offsets[i], offsets[i + 1] - offsets[i],
+                                           spans + 2 * (prefix[i] - prefix[0]), room > 0 ? room : 0);
+    counts[i] = (int32_t)k;
+    total += k;
+  }
+  return total;
+}
+
 /* which: 0 = match_first (kept only if it starts at 0, matcher.mojo:1411-1415), 1 = search */
 void mrx_oracle_span_batch(const mrx_dfa* d, int which, const uint8_t* data, const int64_t* offsets,
                            int64_t n, int32_t* start, int32_t* end) {

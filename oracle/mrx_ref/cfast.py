@@ -71,6 +71,8 @@ def _bind(lib):
                                              C.c_void_p, C.c_int64]
     lib.mrx_oracle_count_batch_mt.restype = C.c_int64
     lib.mrx_oracle_count_batch_mt.argtypes = [P, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]
+    lib.mrx_oracle_findall_at_mt.restype = C.c_int64
+    lib.mrx_oracle_findall_at_mt.argtypes = [P, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     lib.mrx_oracle_span_batch.restype = None
     lib.mrx_oracle_span_batch.argtypes = [P, C.c_int, C.c_void_p, C.c_void_p, C.c_int64,
                                           C.c_void_p, C.c_void_p]
@@ -153,6 +155,21 @@ class CDfa:
         total = self._lib.mrx_oracle_count_batch_mt(C.byref(self._d), data.ctypes.data, offsets.ctypes.data,
                                                     n, counts.ctypes.data, int(threads))
         return counts, int(total)
+
+    def findall_at_mt(self, data: np.ndarray, offsets: np.ndarray, prefix: np.ndarray, threads: int):
+        """findall of every text on `threads` host threads, text i's spans written where `prefix` (int64[n + 1],
+        e.g. the device's CSR offsets; only differences and prefix[0] matter) puts them: (counts int32[n] -- the
+        true counts, whatever room prefix left --, spans int32[prefix[n] - prefix[0], 2], total)."""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        prefix = np.ascontiguousarray(prefix, dtype=np.int64)
+        n = len(offsets) - 1
+        assert len(prefix) == n + 1
+        counts = np.zeros(n, np.int32)
+        spans = np.full((max(int(prefix[-1] - prefix[0]), 1), 2), -7, np.int32)
+        total = self._lib.mrx_oracle_findall_at_mt(C.byref(self._d), data.ctypes.data, offsets.ctypes.data, n,
+                                                   prefix.ctypes.data, spans.ctypes.data, counts.ctypes.data, int(threads))
+        return counts, spans[: int(prefix[-1] - prefix[0])], int(total)
 
     def span_batch(self, which: str, data: np.ndarray, offsets: np.ndarray):
         data = np.ascontiguousarray(data, dtype=np.uint8)

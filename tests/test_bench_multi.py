@@ -62,13 +62,15 @@ def test_two_ranks_self_launched_with_results_exchange():
 @pytest.mark.gpu
 def test_a_hanging_exchange_leg_does_not_lose_the_headline():
     """The exchange legs are the only part of bench.py no multi-GPU box has run: past MRX_BENCH_EXTRAS_TIMEOUT the
-    watchdog prints the headline line without them and every rank leaves with status 0."""
+    watchdog prints the headline line without them -- exactly once, with the leg and the call that was in flight --
+    and every rank leaves with a NON-ZERO status: a hang is never reported to the driver as a clean run."""
     r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--texts", "16384", "--steps", "3",
                         "--warmup", "1", "--settle", "2", "--c3-texts", "32768"], capture_output=True, text=True, timeout=900,
                        env=_env(MRX_BENCH_SHARE_GPU="1", MRX_BENCH_EXTRAS_TIMEOUT="0.0001"))
-    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    assert r.returncode != 0, (r.stdout[-2000:], r.stderr[-4000:])
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["roofline"]["frac"] > 0
-    assert "watchdog" in d["scan_plus_gather"]["error"]
+    err = d["scan_plus_gather"]["error"]
+    assert "watchdog" in err and "leg 'scan_plus_gather'" in err and "in flight:" in err

@@ -1,6 +1,7 @@
-"""GPU parity at the sizes BASELINE.json quotes for configs 3, 4 and 5 (per-GPU
-share), through exact whole-batch checks where a closed form exists and through
-the oracle's C port on a sample plus size-independent properties otherwise."""
+"""GPU parity at the sizes BASELINE.json quotes for configs 2, 3, 4 and 5 (per-GPU share): EXACT over the whole batch
+-- every CSR offset and every span of every text -- against the closed form (config 3) or the oracle's C port run over
+the whole batch on the host's cores (configs 2, 4, 5; round 4), next to the size-independent properties."""
+import os
 import numpy as np
 import pytest
 
@@ -21,21 +22,52 @@ def _need_gpu():
         pytest.fail("gpu-marked test run without a GPU: the HIP path has no fallback")
 
 
-def _oracle_sample_check(pat, d, prefix, spans, idxs):
-    """Exact comparison with the C oracle on the rows idxs."""
+def _oracle_exact_check(pat, d, prefix, spans, slab_texts=1 << 18):
+    """Every offset and every span of the WHOLE batch against the oracle's C port (DFAEngine.match_all,
+    dfa.mojo:2028-2130 as oracle/c/mrx_oracle.c restates it), texts split over the host's cores, in slabs of
+    `slab_texts` texts to bound the temporaries: a single wrong offset anywhere in the batch fails.  The oracle
+    writes text i's spans where the DEVICE's offsets put them (and reports its own count per text), so one pass
+    compares counts, offsets and spans."""
     n, L = d.shape
-    rows = d[idxs].cpu().numpy()
-    cd = CDfa(pat)
-    offsets = np.arange(0, (len(idxs) + 1) * L, L, dtype=np.int64)
-    counts, osp, total = cd.findall_batch(rows.reshape(-1), offsets)
-    pre = prefix.cpu().numpy()
-    k = 0
-    for j, i in enumerate(idxs.tolist()):
-        a, b = int(pre[i]), int(pre[i + 1])
-        assert b - a == counts[j], (i, b - a, counts[j])
-        have = spans[a:b].cpu().numpy()
-        assert np.array_equal(have, osp[k:k + counts[j]]), i
-        k += counts[j]
+    cd = CDfa(pat, native=True)
+    try:
+        threads = len(os.sched_getaffinity(0))
+    except AttributeError:
+        threads = os.cpu_count() or 1
+    threads = max(1, min(threads, 128))
+    assert int(prefix[0].item()) == 0
+    checked = 0
+    for a in range(0, n, slab_texts):
+        b = min(n, a + slab_texts)
+        rows = d[a:b].cpu().numpy().reshape(-1)
+        offsets = np.arange(0, (b - a + 1) * L, L, dtype=np.int64)
+        pre = prefix[a:b + 1].cpu().numpy()
+        counts, osp, total = cd.findall_at_mt(rows, offsets, pre, threads)
+        dev_counts = (pre[1:] - pre[:-1])
+        bad = np.nonzero(dev_counts != counts)[0]
+        assert bad.size == 0, (pat, "count of text", a + int(bad[0]), int(dev_counts[bad[0]]), int(counts[bad[0]]))
+        have = spans[int(pre[0]):int(pre[-1])].cpu().numpy()
+        if not np.array_equal(have, osp):
+            k = int(np.nonzero((have != osp).any(axis=1))[0][0])
+            t = int(np.searchsorted(pre, pre[0] + k, side="right")) - 1
+            raise AssertionError((pat, "span", k, "of text", a + t, have[k].tolist(), osp[k].tolist()))
+        checked += total
+    assert checked == int(prefix[n].item())
+    return checked
+
+
+def test_config2_exact_over_the_whole_batch():
+    """BASELINE.json config 2 (`[a-z]+\\d+`, 2^20 x 1 KiB, SURVEY.md 8(d) mix -- the headline batch): every CSR
+    offset and every span of all 2^20 texts equals the oracle's (round 4; rounds 1-3 compared 256 texts)."""
+    _need_gpu()
+    from mojo_regex_amd.workloads import make_c2_batch
+    n, L = 1 << 20, 1024
+    pat = b"[a-z]+\\d+"
+    d = make_c2_batch(n, L, seed=20260102, device="cuda")
+    rx = M.compile_regex(pat)
+    prefix, spans, total = rx._dev_findall(M.DeviceBatch.strided(d.reshape(-1), L, length=L), span_cap=n * 32)
+    assert M.load_library().mrx_last_kernel_name() in STREAM_FINDALL
+    assert _oracle_exact_check(pat, d, prefix, spans) == total > n
 
 
 def test_config3_digit_runs_exact_at_per_gpu_size():
@@ -90,8 +122,7 @@ def test_config4_phone_groups_at_full_size():
         assert bool(((b >= 48) & (b <= 57)).all())
     same = owner[1:] == owner[:-1]
     assert bool((sp[1:, 0][same] >= sp[:-1, 1][same]).all())
-    idxs = torch.arange(0, n, n // 8192)
-    _oracle_sample_check(pat, d, prefix, spans, idxs)
+    assert _oracle_exact_check(pat, d, prefix, spans) == total   # every offset and span of all 2^20 texts
     # search == first findall span; captures at fixed offsets, a18 order (groups, then whole)
     s, e = rx.match_next(batch)
     first = torch.full((n,), -1, dtype=torch.int32, device="cuda")
@@ -154,7 +185,7 @@ def test_config5_alternation_at_full_size():
         nxy = int(((d[a:a + blk] == ord("x")) | (d[a:a + blk] == ord("y"))).sum().item())
         assert int(one.sum().item()) == nxy
         del sp, owner, ln, b0, b1, b2, foo, bar, same, one, three
-    _oracle_sample_check(pat, d, prefix, spans, torch.arange(0, n, n // 2048))
+    assert _oracle_exact_check(pat, d, prefix, spans, slab_texts=1 << 18) == total   # all 2^22 texts, 2.9 G spans
 
 
 def test_config5_lazydfa_semantics_switch():
