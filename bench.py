@@ -458,6 +458,8 @@ def main():
             raise RuntimeError("span buffer smaller than the exchange capacity")
         gout = None
         if comm is not None:
+            progress["call"] = "mrx_comm_reserve (staging of the padded exchange)"
+            comm.reserve_spans(n_glob, cap)
             gout = (torch.empty(n_glob + 1, dtype=torch.int64, device=dev),
                     torch.empty((world * cap, 2), dtype=torch.int32, device=dev),
                     torch.zeros(1, dtype=torch.int32, device=dev))

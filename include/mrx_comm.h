@@ -13,6 +13,17 @@
  * never calls them needs no RCCL).  One process per GPU; every call is collective over the
  * communicator and enqueues on `stream` of the calling rank's current device.
  *
+ * ONE STREAM PER COMMUNICATOR, CALLS SERIALISED: the size words and the staging of a communicator are single
+ * buffers reused by every call, so two exchanges of one communicator must not be in flight at the same time
+ * (enqueue them on one stream, or order the streams with events; use a second communicator for a second stream).
+ *
+ * ERRORS ARE COLLECTIVE: a rank whose own arguments are invalid, or whose output buffers are too small, still goes
+ * through the size exchange, and EVERY rank then returns the same code (MRX_E_ARGUMENT / MRX_E_CAPACITY; padded
+ * form: in *d_status) -- no rank is left waiting in a collective the others have abandoned.  Two things cannot be
+ * told to the others and must hold on every rank: the arguments that size the collectives themselves
+ * (cap_spans_per_rank, n_global, bytes_per_rank), and memory for the staging (mrx_comm_reserve at set-up rules
+ * an allocation failure inside a call out).
+ *
  * Host-language binding (Mojo): INTEGRATION.md, "Sharded batches".
  */
 #ifndef MRX_COMM_H
@@ -38,6 +49,12 @@ void mrx_comm_free(mrx_comm* c);
 int mrx_comm_rank(const mrx_comm* c);
 int mrx_comm_size(const mrx_comm* c);
 
+/* Staging of the padded form of mrx_allgatherv_spans for a job of n_global texts and cap_spans_per_rank span slots;
+ * mrx_comm_reserve(c, bytes) allocates it now.  A call that finds its staging too small grows it itself -- with a
+ * device synchronisation and an allocation inside the call; reserving at set-up keeps both out of the timed path. */
+size_t mrx_comm_spans_staging_bytes(const mrx_comm* c, int64_t n_global, int64_t cap_spans_per_rank);
+int mrx_comm_reserve(mrx_comm* c, size_t bytes);
+
 /* Fixed-size results: every rank contributes `bytes_per_rank` bytes (int32 start[n] / end[n] of
  * mrx_match_first_dev / mrx_search_dev, the span rows of mrx_captures_dev, uint8 flags ...);
  * d_recv[r * bytes_per_rank ...] = rank r's bytes, i.e. global text order for contiguous shards of
@@ -49,7 +66,7 @@ int mrx_allgather_fixed(mrx_comm* c, const void* d_send, void* d_recv, size_t by
  * row counts are all-gathered (8 bytes each) and read back once (the only host synchronisation),
  * then every rank's rows travel by one grouped ncclBroadcast straight into their final place.
  * d_out receives all rows in rank order; *rows_total (host, may be NULL) their number;
- * MRX_E_CAPACITY when out_cap_rows is too small (nothing is written then). */
+ * MRX_E_CAPACITY on every rank when out_cap_rows is too small on ANY rank (nothing is written then). */
 int mrx_allgatherv_rows(mrx_comm* c, const void* d_send, int64_t rows_local, size_t row_bytes,
                         void* d_out, int64_t out_cap_rows, int64_t* rows_total, void* stream);
 
@@ -62,15 +79,15 @@ int mrx_allgatherv_rows(mrx_comm* c, const void* d_send, int64_t rows_local, siz
  * of the shifted prefix segments and of the spans into their offsets.
  * cap_spans_per_rank == 0: EXACT form -- the 16 x nranks bytes of sizes are read back once so that
  *   the broadcasts carry exactly the bytes that exist (one host synchronisation per call).
- * cap_spans_per_rank  > 0: PADDED form -- no host synchronisation at all: the sizes stay on the
+ * cap_spans_per_rank  > 0: PADDED form -- no host synchronisation (given reserved staging, see above): the sizes stay on the
  *   device, every rank ships cap_spans_per_rank span slots and ceil(N / nranks) + 1 prefix slots
  *   (ncclAllGather into staging owned by the communicator), and a kernel compacts the staged rows
  *   into the global CSR.  n_local may differ between ranks by what a contiguous split leaves
  *   (rank r owns texts [r N / G, (r + 1) N / G)); a rank with more than cap_spans_per_rank spans
  *   sets the error word: *d_status (int32 on the device, may be NULL) becomes MRX_E_CAPACITY.
  * N_total / T_total (host, may be NULL): filled in the exact form only.
- * gprefix_cap / gspans_cap: capacities in entries / spans; exact form returns MRX_E_CAPACITY
- * without writing when they do not hold the result. */
+ * gprefix_cap / gspans_cap: capacities in entries / spans; when they do not hold the result on ANY rank, every rank
+ * reports MRX_E_CAPACITY and nothing is written (exact form: the return value; padded form: *d_status). */
 int mrx_allgatherv_spans(mrx_comm* c, const int64_t* d_prefix, int64_t n_local, const int32_t* d_spans,
                          int64_t cap_spans_per_rank, int64_t n_global,
                          int64_t* d_gprefix, int64_t gprefix_cap, int32_t* d_gspans, int64_t gspans_cap,

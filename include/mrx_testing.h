@@ -72,11 +72,14 @@ void mrx_debug_multiwalk(int mode);
 void mrx_debug_rec_skew(int64_t bytes);
 /* include/mrx_comm.h, padded form of mrx_allgatherv_spans: its two device steps on buffers the caller fills as
  * ncclAllGather would have, so that the multi-rank arithmetic can be checked on one GPU.
+ * meta_all: meta_stride int64 words per rank -- 2: {texts, spans}; 4: {texts (-1: that rank's arguments were invalid),
+ * spans, capacity of that rank's global offsets buffer, of its global spans buffer}, the words the library gathers.
  * shift: out[i] = prefix[i + 1] + (spans of the ranks before `rank`) for i < n_local, 0 up to pad_to.
- * compact: meta_all[r] = {texts, spans} of rank r; stage_prefix[r][P], stage_spans[r][cap][2] -> global CSR. */
-int mrx_testing_comm_shift(const int64_t* d_prefix, int64_t n_local, const int64_t* d_meta_all, int rank,
+ * compact: stage_prefix[r][P], stage_spans[r][cap][2] -> global CSR; *d_status = MRX_OK, MRX_E_CAPACITY (some rank's
+ * capacities, or these, do not hold the result: nothing is written) or MRX_E_ARGUMENT (some rank was invalid). */
+int mrx_testing_comm_shift(const int64_t* d_prefix, int64_t n_local, const int64_t* d_meta_all, int meta_stride, int rank,
                            int64_t* d_out, int64_t pad_to, void* stream);
-int mrx_testing_comm_compact(const int64_t* d_meta_all, int nranks, const int64_t* d_stage_prefix, int64_t P,
+int mrx_testing_comm_compact(const int64_t* d_meta_all, int meta_stride, int nranks, const int64_t* d_stage_prefix, int64_t P,
                              const int32_t* d_stage_spans, int64_t cap, int64_t* d_gprefix, int64_t gprefix_cap,
                              int32_t* d_gspans, int64_t gspans_cap, int32_t* d_status, void* stream);
 /* Bytes of device memory the calling thread's scratch arenas hold (see mrx_release_scratch). */

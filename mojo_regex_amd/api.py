@@ -128,13 +128,15 @@ def load_library():
         "mrx_comm_free": (None, [H]),
         "mrx_comm_rank": (C.c_int, [H]),
         "mrx_comm_size": (C.c_int, [H]),
+        "mrx_comm_spans_staging_bytes": (C.c_size_t, [H, C.c_int64, C.c_int64]),
+        "mrx_comm_reserve": (C.c_int, [H, C.c_size_t]),
         "mrx_allgather_fixed": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
         "mrx_allgatherv_rows": (C.c_int, [H, C.c_void_p, C.c_int64, C.c_size_t, C.c_void_p, C.c_int64,
                                           C.POINTER(C.c_int64), C.c_void_p]),
         "mrx_allgatherv_spans": (C.c_int, [H, i64p, C.c_int64, i32p, C.c_int64, C.c_int64, i64p, C.c_int64, i32p,
                                            C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), i32p, C.c_void_p]),
-        "mrx_testing_comm_shift": (C.c_int, [i64p, C.c_int64, i64p, C.c_int, i64p, C.c_int64, C.c_void_p]),
-        "mrx_testing_comm_compact": (C.c_int, [i64p, C.c_int, i64p, C.c_int64, i32p, C.c_int64, i64p, C.c_int64,
+        "mrx_testing_comm_shift": (C.c_int, [i64p, C.c_int64, i64p, C.c_int, C.c_int, i64p, C.c_int64, C.c_void_p]),
+        "mrx_testing_comm_compact": (C.c_int, [i64p, C.c_int, C.c_int, i64p, C.c_int64, i32p, C.c_int64, i64p, C.c_int64,
                                                i32p, C.c_int64, i32p, C.c_void_p]),
     }
     for name, (res, args) in sigs.items():
@@ -165,6 +167,7 @@ TESTING_SYMBOLS = [
 ]
 COMM_SYMBOLS = [
     "mrx_comm_unique_id", "mrx_comm_init", "mrx_comm_free", "mrx_comm_rank", "mrx_comm_size",
+    "mrx_comm_spans_staging_bytes", "mrx_comm_reserve",
     "mrx_allgather_fixed", "mrx_allgatherv_rows", "mrx_allgatherv_spans",
 ]
 

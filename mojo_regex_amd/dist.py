@@ -107,6 +107,13 @@ class Comm:
         except Exception:
             pass
 
+    def reserve_spans(self, n_global: int, cap_spans_per_rank: int):
+        """Allocates the staging of the padded gather_spans now (mrx_comm_reserve), so that no call allocates or
+        synchronises the device later."""
+        from .api import load_library, _check
+        lib = load_library()
+        _check(lib.mrx_comm_reserve(self._h, lib.mrx_comm_spans_staging_bytes(self._h, n_global, cap_spans_per_rank)))
+
     def gather_fixed(self, local):
         """Equal shards: [world * n_local, ...] in rank order (one ncclAllGather, no host synchronisation)."""
         import torch
