@@ -585,6 +585,14 @@ def main():
             same_counts = bool((gpu_counts == counts).all()) and bool((ocnt == counts).all())
             cb["parity_on_sample"] = same_counts and bool(np.array_equal(spans[:int(pre[-1])].cpu().numpy(), ospans))
             cb["parity_checks"] = "counts, offsets and all %d spans of the sample's texts" % int(pre[-1])
+            # match_first in SURVEY.md 8(d)'s units: its algorithmic bytes are data dependent -- the sum over the texts of
+            # min(len, bytes consumed before the dead transition + 1) -- so the fraction comes from the oracle (same sample)
+            frac = CDfa(PATTERN).match_first_bytes(host.reshape(-1), np.arange(0, (m + 1) * L, L, dtype=np.int64)) / float(m * L)
+            if other is not None:
+                line["other_ops"]["match_first_alg_GBps"] = round(frac * other["match_first_GBps_whole_batch"], 1)
+                line["other_ops"]["match_first_algorithmic_fraction"] = round(frac, 4)
+                line["other_ops"]["note"] += ("; match_first_alg_GBps = the whole-batch rate x the fraction of the bytes the reference's "
+                                              "match_first examines (sum of min(len, consumed + 1), oracle, the cpu_baseline sample)")
             line["cpu_baseline"] = cb
         if _claim_print():
             print(json.dumps(line), flush=True)

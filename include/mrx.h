@@ -223,6 +223,20 @@ int mrx_sub_strided_dev(const mrx_handle* h, const char* repl, size_t repl_len, 
                         int64_t* d_out_offsets, uint8_t* d_out_data, int64_t out_cap,
                         int64_t* total_bytes, void* stream);
 
+/* regex.split (matcher.mojo:1357-1393): the text between successive non-overlapping matches, the matches themselves
+ * removed; a separator at the very start or end, or two adjacent ones, yields an empty piece.  maxsplit == 0: no limit;
+ * > 0: at most that many splits per text, the rest of the text is the last piece; < 0: no split at all (the whole text
+ * is the only piece) -- the reference's loop `if maxsplit != 0 and splits_done >= maxsplit: break`.
+ *   d_piece_prefix[n + 1]  CSR offsets of the texts' pieces (text i has min(matches, maxsplit) + 1 of them)
+ *   d_pieces[piece_cap][2] byte ranges [start, end) within the piece's own text, text order then position
+ * *total (host, may be NULL) = number of pieces; MRX_E_CAPACITY when piece_cap does not hold them (what fits is not
+ * written then; *total holds the need when the limit is off, a lower bound otherwise).  One stream synchronisation. */
+int mrx_split_dev(const mrx_handle* h, const uint8_t* d_data, const int64_t* d_offsets, int64_t n, int64_t maxsplit,
+                  int64_t* d_piece_prefix, int32_t* d_pieces, int64_t piece_cap, int64_t* total, void* stream);
+int mrx_split_strided_dev(const mrx_handle* h, const uint8_t* d_data, int64_t stride, const int32_t* d_lens, int32_t len,
+                          int64_t n, int64_t maxsplit, int64_t* d_piece_prefix, int32_t* d_pieces, int64_t piece_cap,
+                          int64_t* total, void* stream);
+
 /* ---- host-buffer convenience wrappers (copy in, run, copy out) -------------- */
 int mrx_match_first_batch(const mrx_handle* h, const uint8_t* data,
                           const int64_t* offsets, int64_t n, int32_t* start,
@@ -231,6 +245,8 @@ int mrx_search_batch(const mrx_handle* h, const uint8_t* data, const int64_t* of
                      int64_t n, int32_t* start, int32_t* end);
 int mrx_is_match_batch(const mrx_handle* h, const uint8_t* data, const int64_t* offsets,
                        int64_t n, uint8_t* flag);
+int mrx_split_batch(const mrx_handle* h, const uint8_t* data, const int64_t* offsets, int64_t n, int64_t maxsplit,
+                    int64_t* piece_prefix, int32_t* pieces, int64_t piece_cap, int64_t* total);
 int mrx_findall_batch(const mrx_handle* h, const uint8_t* data, const int64_t* offsets,
                       int64_t n, int64_t* counts_prefix, int32_t* spans,
                       int64_t span_cap, int64_t* total);

@@ -99,6 +99,11 @@ def load_library():
         "mrx_match_first_batch": (C.c_int, [H, u8p, i64p, C.c_int64, i32p, i32p]),
         "mrx_search_batch": (C.c_int, [H, u8p, i64p, C.c_int64, i32p, i32p]),
         "mrx_is_match_batch": (C.c_int, [H, u8p, i64p, C.c_int64, u8p]),
+        "mrx_split_batch": (C.c_int, [H, u8p, i64p, C.c_int64, C.c_int64, i64p, i32p, C.c_int64, C.POINTER(C.c_int64)]),
+        "mrx_split_dev": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
+                                    C.POINTER(C.c_int64), C.c_void_p]),
+        "mrx_split_strided_dev": (C.c_int, [H, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_void_p,
+                                            C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.c_void_p]),
         "mrx_findall_batch": (C.c_int, [H, u8p, i64p, C.c_int64, i64p, i32p, C.c_int64,
                                         C.POINTER(C.c_int64)]),
         "mrx_captures_batch": (C.c_int, [H, u8p, i64p, C.c_int64, i32p]),
@@ -156,7 +161,7 @@ EXPORTED_SYMBOLS = [
     "mrx_captures_strided_dev", "mrx_captures_dev",
     "mrx_match_first_at_dev", "mrx_search_at_dev", "mrx_is_match_at_dev", "mrx_match_first_at_strided_dev",
     "mrx_search_at_strided_dev", "mrx_is_match_at_strided_dev",
-    "mrx_sub_dev", "mrx_sub_strided_dev", "mrx_match_first_batch", "mrx_search_batch", "mrx_is_match_batch",
+    "mrx_sub_dev", "mrx_sub_strided_dev", "mrx_split_dev", "mrx_split_strided_dev", "mrx_split_batch", "mrx_match_first_batch", "mrx_search_batch", "mrx_is_match_batch",
     "mrx_findall_batch", "mrx_captures_batch", "mrx_sub_batch", "mrx_version", "mrx_release_scratch",
 ]
 TESTING_SYMBOLS = [
@@ -212,9 +217,11 @@ class DeviceBatch:
             raise MrxError("batch data must be a contiguous uint8 tensor")
         self.data, self.offsets, self.stride, self.length, self.lens = data, offsets, stride, length, lens
         # CSR batches whose offsets were built on the host: offsets[n] and the longest text, so that findall does not
-        # have to read them back from the device (mrx_findall_known_dev); None = not known
-        self.end_offset: Optional[int] = None
-        self.max_len: Optional[int] = None
+        # have to read them back from the device (mrx_findall_known_dev); None = not known.  Private: set by
+        # from_texts / from_arrow only, from the very offsets they upload -- the C side sizes its record scratch from
+        # them ("neither may be too small"), so a stale or hand-set value would be an out-of-bounds write, not an error
+        self._end_offset: Optional[int] = None
+        self._max_len: Optional[int] = None
         if offsets is not None:
             if offsets.dtype != torch.int64 or not offsets.is_contiguous() or offsets.device != data.device:
                 raise MrxError("offsets must be a contiguous int64 tensor on the data's device")
@@ -250,8 +257,8 @@ class DeviceBatch:
         data, offsets = pack_texts(texts)
         d = torch.from_numpy(data).to(device) if data.size else torch.zeros(0, dtype=torch.uint8, device=device)
         b = cls(d, torch.from_numpy(offsets).to(device))
-        b.end_offset = int(offsets[-1])
-        b.max_len = int(np.diff(offsets).max()) if len(offsets) > 1 else 0
+        b._end_offset = int(offsets[-1])
+        b._max_len = int(np.diff(offsets).max()) if len(offsets) > 1 else 0
         return b
 
     @classmethod
@@ -279,8 +286,8 @@ class DeviceBatch:
         offs -= lo
         d = torch.from_numpy(data.copy()).to(device) if data.size else torch.zeros(0, dtype=torch.uint8, device=device)
         b = cls(d, torch.from_numpy(offs).to(device))
-        b.end_offset = int(offs[-1])
-        b.max_len = int(np.diff(offs).max()) if n > 0 else 0
+        b._end_offset = int(offs[-1])
+        b._max_len = int(np.diff(offs).max()) if n > 0 else 0
         return b
 
     def csr_offsets(self):
@@ -467,6 +474,51 @@ class CompiledRegex:
             out.append([(int(a), int(b)) for a, b in spans[prefix[i]:prefix[i + 1]]])
         return out
 
+    def split(self, texts, maxsplit: int = 0) -> List[List[bytes]]:
+        """regex.split per text: the pieces between successive matches (mrx_split_batch)."""
+        bs = [_b(t) for t in texts]
+        data, offsets = pack_texts(bs)
+        n = len(bs)
+        prefix = np.zeros(n + 1, dtype=np.int64)
+        cap = max(16, 2 * n + len(data) // 8)
+        total = C.c_int64(0)
+        while True:
+            pieces = np.empty((cap, 2), dtype=np.int32)
+            rc = self._lib.mrx_split_batch(self._h, data.ctypes.data, offsets.ctypes.data, n, int(maxsplit), prefix.ctypes.data,
+                                           pieces.ctypes.data, cap, C.byref(total))
+            if rc == MRX_E_CAPACITY and int(total.value) > cap:
+                cap = int(total.value)
+                continue
+            _check(rc)
+            break
+        out = []
+        for i, t in enumerate(bs):
+            out.append([t[int(a):int(b)] for a, b in pieces[prefix[i]:prefix[i + 1]]])
+        return out
+
+    def split_dev(self, batch: "DeviceBatch", maxsplit: int = 0, piece_cap: Optional[int] = None):
+        """regex.split of a device-resident batch: (piece_prefix int64[n + 1], pieces int32[total, 2], total)."""
+        import torch
+        dev = batch.data.device
+        n = batch.n
+        prefix = torch.empty(n + 1, dtype=torch.int64, device=dev)
+        cap = piece_cap if piece_cap is not None else max(16, 2 * n + batch.data.numel() // 8)
+        total = C.c_int64(0)
+        while True:
+            pieces = torch.empty((cap, 2), dtype=torch.int32, device=dev)
+            if batch.offsets is not None:
+                rc = self._lib.mrx_split_dev(self._h, _ptr(batch.data), _ptr(batch.offsets), n, int(maxsplit), _ptr(prefix),
+                                             _ptr(pieces), cap, C.byref(total), self._stream_ptr())
+            else:
+                rc = self._lib.mrx_split_strided_dev(self._h, _ptr(batch.data), batch.stride, _ptr(batch.lens), batch.length, n,
+                                                     int(maxsplit), _ptr(prefix), _ptr(pieces), cap, C.byref(total), self._stream_ptr())
+            if rc == MRX_E_CAPACITY and piece_cap is None and int(total.value) > cap:
+                cap = int(total.value)
+                continue
+            _check(rc)
+            break
+        return prefix, pieces, int(total.value)
+
     def captures(self, texts) -> np.ndarray:
         """search + capture groups, int32[n, g+1, 2] in the order the reference's
         NFAEngine._match_group appends them: groups 1..g, then group 0."""
@@ -557,9 +609,9 @@ class CompiledRegex:
         out = (counts_prefix int64[n+1], spans int32[cap, 2]) device tensors; the total
         is counts_prefix[n] once the stream has drained (check it against cap)."""
         prefix, spans = out
-        if batch.offsets is not None and batch.end_offset is not None:
+        if batch.offsets is not None and batch._end_offset is not None:
             rc = self._lib.mrx_findall_known_dev(self._h, _ptr(batch.data), _ptr(batch.offsets), batch.n,
-                                                 batch.end_offset, batch.max_len, _ptr(prefix), _ptr(spans),
+                                                 batch._end_offset, batch._max_len, _ptr(prefix), _ptr(spans),
                                                  spans.shape[0], None, self._stream_ptr())
         elif batch.offsets is not None:
             rc = self._lib.mrx_findall_dev(self._h, _ptr(batch.data), _ptr(batch.offsets), batch.n,
@@ -586,9 +638,9 @@ class CompiledRegex:
             span_cap = spans.shape[0]
         total = C.c_int64(0)
         while True:
-            if batch.offsets is not None and batch.end_offset is not None:
+            if batch.offsets is not None and batch._end_offset is not None:
                 rc = self._lib.mrx_findall_known_dev(self._h, _ptr(batch.data), _ptr(batch.offsets), batch.n,
-                                                     batch.end_offset, batch.max_len, _ptr(prefix), _ptr(spans),
+                                                     batch._end_offset, batch._max_len, _ptr(prefix), _ptr(spans),
                                                      span_cap, C.byref(total), self._stream_ptr())
             elif batch.offsets is not None:
                 rc = self._lib.mrx_findall_dev(self._h, _ptr(batch.data), _ptr(batch.offsets), batch.n,
@@ -655,18 +707,5 @@ def sub(pattern, repl, texts, count: int = 0) -> List[bytes]:
 
 
 def split(pattern, texts, maxsplit: int = 0) -> List[List[bytes]]:
-    """regex.split (matcher.mojo:1357-1393): derived from findall, per text."""
-    bs = [_b(t) for t in texts]
-    lists = compile_regex(pattern).findall_lists(bs)
-    out = []
-    for text, spans in zip(bs, lists):
-        parts, prev, done = [], 0, 0
-        for (s, e) in spans:
-            if maxsplit != 0 and done >= maxsplit:
-                break
-            parts.append(text[prev:s])
-            prev = e
-            done += 1
-        parts.append(text[prev:])
-        out.append(parts)
-    return out
+    """regex.split (matcher.mojo:1357-1393) through the C ABI (mrx_split_batch): pieces as byte ranges per text."""
+    return compile_regex(pattern).split(texts, maxsplit)

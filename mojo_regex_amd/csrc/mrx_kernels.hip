@@ -4745,6 +4745,31 @@ void launch_stream_dyn(const mrx_handle* h, const Layout& lay, int64_t n, int32_
 #undef MRX_DYN_R
 }
 
+// (a named function, not a lambda: hipcc gave two namespace-scope lambdas of this shape ONE body -- the second
+// variable was initialised by the first one's getenv -- see env_int's other user, g_subs_group)
+static int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+// Measurement knobs of the call path, read from the environment ONCE (at the first call that looks): no getenv per call.
+struct EnvKnobs {
+  int decode_grid, decode_reverse, piece_c, fused_skew, fused_debug;
+  bool piece_c_set;
+};
+static const EnvKnobs& env_knobs() {
+  static const EnvKnobs k = [] {
+    EnvKnobs e;
+    e.decode_grid = env_int("MRX_DECODE_GRID", 0);
+    e.decode_reverse = env_int("MRX_DECODE_REVERSE", 0);
+    e.piece_c_set = getenv("MRX_PIECE_C") != nullptr;
+    e.piece_c = env_int("MRX_PIECE_C", 0);
+    e.fused_skew = env_int("MRX_FUSED_SKEW", 0);
+    e.fused_debug = env_int("MRX_FUSED_DEBUG", 0);
+    return e;
+  }();
+  return k;
+}
+
 // Long texts on the streaming kernels: cut into pieces at synchronising bytes when one lane per text
 // would leave most of the device idle.
 struct Pieces {
@@ -4781,7 +4806,7 @@ int pieces_prepare(const mrx_handle* h, const Layout& lay, int64_t n, hipStream_
   if (p.st_nsync <= 0 || g_long_text_mode == 2 || (g_long_text_mode == 3 && disjoint) || n <= 0) return MRX_OK;
   // pays when one lane per text leaves the device mostly idle, or for outliers of a ragged batch; a
   // fixed-length batch of many texts is decided before anything is launched
-  const bool env_pieces = getenv("MRX_PIECE_C") != nullptr;   // measurement
+  const bool env_pieces = env_knobs().piece_c_set;   // measurement
   if (g_long_text_mode == 0 && n > 131072 && !lay.offsets && !lay.lens && !env_pieces) return MRX_OK;
   // count / search of a large CSR batch stay free of any host synchronisation: its outliers are only
   // looked for where the caller has the batch's statistics anyway (findall)
@@ -4796,7 +4821,7 @@ int pieces_prepare(const mrx_handle* h, const Layout& lay, int64_t n, hipStream_
     total = n * lay.stride;
   }
   int C;
-  static const int env_c = getenv("MRX_PIECE_C") ? atoi(getenv("MRX_PIECE_C")) : 0;   // measurement: piece size
+  const int env_c = env_knobs().piece_c;   // measurement: piece size
   if (env_c > 0 && g_long_text_mode == 0) {
     C = env_c;
     if (max_len <= C) return MRX_OK;
@@ -4929,12 +4954,6 @@ int findall_pieces(const mrx_handle* h, const Pieces& pc, int64_t n, int64_t* d_
 // per launch: the ramp-up and the tail of a launch weigh twice), which is more than the overlap returns.  What
 // does pay is overlapping WHOLE calls on two caller streams (bench.py --streams 2: 0.287 ms on the same box).
 // MRX_FINDALL_SPLIT=1 / mrx_debug_split_findall(1): on.
-// (a named function, not a lambda: hipcc gave two namespace-scope lambdas of this shape ONE body -- the second
-// variable was initialised by the first one's getenv -- see env_int's other user, g_subs_group)
-static int env_int(const char* name, int dflt) {
-  const char* e = getenv(name);
-  return e ? atoi(e) : dflt;
-}
 std::atomic<int> g_split_findall{env_int("MRX_FINDALL_SPLIT", 0)};
 constexpr int64_t kSplitMinTexts = 1 << 18;
 struct SideStream {
@@ -5208,8 +5227,8 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
         HIP_TRY(scratch_alloc((void**)&d_fz, sizeof(FusedArgs), s));
         FusedArgs fz;
         fz.ctrl = d_ctrl; fz.prefix = d_prefix; fz.spans = d_spans; fz.span_cap = span_cap; fz.total_out = d_total;
-        fz.rec_cap = 64 * fz_per_text + (getenv("MRX_FUSED_SKEW") ? atoi(getenv("MRX_FUSED_SKEW")) : 0);
-        fz.debug = getenv("MRX_FUSED_DEBUG") ? atoi(getenv("MRX_FUSED_DEBUG")) : 0;
+        fz.rec_cap = 64 * fz_per_text + env_knobs().fused_skew;
+        fz.debug = env_knobs().fused_debug;
         hipLaunchKernelGGL(k_fused_init, dim3((unsigned)((ctrl_words + kBlock * 8 - 1) / (kBlock * 8))), dim3(kBlock), 0, s,
                            d_ctrl, (int64_t)ctrl_words, d_fz, fz);
         ScanTimer tm(s);
@@ -5407,9 +5426,9 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
                            d_wbase, d_tsum, d_prefix, d_spans, span_cap, p.st_fixed_len, d_total);
     } else
     if (pack16 && rec32 && max_text >= 768)
-      hipLaunchKernelGGL((k_decode<true, false, true, false, 3072>), dim3(env_int("MRX_DECODE_GRID", 0) > 0 ? env_int("MRX_DECODE_GRID", 0) : grid_for(n, kBlock) * 2), dim3(kBlock), 0, s, n, d_nrecs, d_recs,
+      hipLaunchKernelGGL((k_decode<true, false, true, false, 3072>), dim3(env_knobs().decode_grid > 0 ? env_knobs().decode_grid : grid_for(n, kBlock) * 2), dim3(kBlock), 0, s, n, d_nrecs, d_recs,
                          rec_row, lay.offsets, d_counts, d_wbase, d_tsum, d_prefix, d_spans, span_cap, p.st_fixed_len,
-                         d_total, (const int32_t*)nullptr, (const int64_t*)nullptr, env_int("MRX_DECODE_REVERSE", 0));
+                         d_total, (const int32_t*)nullptr, (const int64_t*)nullptr, env_knobs().decode_reverse);
     else if (pack16 && rec32)
       hipLaunchKernelGGL((k_decode<true, false, true>), dim3(grid_for(n, kBlock) * 2), dim3(kBlock), 0, s, n, d_nrecs, d_recs,
                          rec_row, lay.offsets, d_counts, d_wbase, d_tsum, d_prefix, d_spans, span_cap, p.st_fixed_len,
@@ -6086,6 +6105,110 @@ int mrx_findall_strided_dev(const mrx_handle* h, const uint8_t* d, int64_t strid
   return run_findall(h, Layout{d, nullptr, stride, lens, len}, n, prefix, spans, cap, total, st);
 }
 
+}  // extern "C"
+namespace {
+// ---- regex.split (matcher.mojo:1357-1393): the text between successive findall matches ------------------------
+// kept[i] = min(matches of text i, maxsplit) (all of them for maxsplit == 0, none for a negative maxsplit)
+__global__ __launch_bounds__(kBlock) void k_split_kept(int64_t n, const int64_t* __restrict__ prefix, int64_t maxsplit,
+                                                       int32_t* __restrict__ kept) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t c = prefix[i + 1] - prefix[i];
+    kept[i] = (int32_t)(maxsplit == 0 ? c : maxsplit < 0 ? 0 : (c < maxsplit ? c : maxsplit));
+  }
+}
+// piece_prefix[i] = (kept matches of the texts before i) + i: text i yields kept[i] + 1 pieces
+__global__ __launch_bounds__(kBlock) void k_split_prefix(int64_t n, const int64_t* __restrict__ kept_prefix,
+                                                         int64_t* __restrict__ piece_prefix, int64_t* __restrict__ total) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += (int64_t)gridDim.x * blockDim.x) {
+    piece_prefix[i] = kept_prefix[i] + i;
+    if (i == n && total) *total = kept_prefix[n] + n;
+  }
+}
+// one lane per PIECE: piece q of text i is [end of match q - 1 (0 for q = 0), start of match q (the text's end behind the
+// last kept match)); its text is found by bisection of the piece offsets (coalesced stores whatever the texts hold)
+__global__ __launch_bounds__(kBlock) void k_split_pieces(Layout lay, int64_t n, const int64_t* __restrict__ prefix,
+                                                         const int32_t* __restrict__ spans, const int64_t* __restrict__ piece_prefix,
+                                                         int32_t* __restrict__ pieces, int64_t piece_cap) {
+  const int64_t total = piece_prefix[n] < piece_cap ? piece_prefix[n] : piece_cap;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += (int64_t)gridDim.x * blockDim.x) {
+    int64_t lo = 0, hi = n;   // the last i with piece_prefix[i] <= j
+    while (hi - lo > 1) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (piece_prefix[mid] <= j) lo = mid; else hi = mid;
+    }
+    const int64_t i = lo, q = j - piece_prefix[i];
+    const int64_t kept = piece_prefix[i + 1] - piece_prefix[i] - 1;
+    const int32_t* sp = spans + 2 * prefix[i];
+    const int a = q == 0 ? 0 : sp[2 * (q - 1) + 1];
+    const int b = q < kept ? sp[2 * q] : lay.text(i).len;
+    *(int2*)(pieces + 2 * j) = make_int2(a, b);
+  }
+}
+
+int run_split(const mrx_handle* h, const Layout& lay, int64_t n, int64_t maxsplit, int64_t* d_piece_prefix, int32_t* d_pieces,
+              int64_t piece_cap, int64_t* total, void* st) {
+  hipStream_t s = (hipStream_t)st;
+  ScratchScope scratch_scope_(s);
+  if (!h) return fail(MRX_E_ARGUMENT, "null handle");
+  if (n < 0 || piece_cap < 0 || !d_piece_prefix || (!d_pieces && piece_cap > 0)) return fail(MRX_E_ARGUMENT, "bad arguments");
+  if ((uintptr_t)d_pieces & 7) return fail(MRX_E_ARGUMENT, "d_pieces must be 8-byte aligned");
+  // findall into scratch: every piece but a text's last ends at a match, so piece_cap holds the spans of any result
+  // that fits (maxsplit == 0: pieces = spans + n)
+  int64_t* d_prefix = nullptr;
+  int32_t* d_spans = nullptr;
+  int32_t* d_kept = nullptr;
+  int64_t* d_kprefix = nullptr;
+  int64_t* d_tot = nullptr;
+  const int64_t span_cap = piece_cap > n ? piece_cap : n + 1;
+  HIP_TRY(scratch_alloc((void**)&d_prefix, sizeof(int64_t) * (n + 1), s));
+  HIP_TRY(scratch_alloc((void**)&d_spans, sizeof(int32_t) * 2 * (size_t)span_cap, s));
+  HIP_TRY(scratch_alloc((void**)&d_kept, sizeof(int32_t) * (n > 0 ? n : 1), s));
+  HIP_TRY(scratch_alloc((void**)&d_kprefix, sizeof(int64_t) * (n + 1), s));
+  HIP_TRY(scratch_alloc((void**)&d_tot, sizeof(int64_t) * 2, s));
+  int64_t nspans = 0;
+  int rc_f = run_findall(h, lay, n, d_prefix, d_spans, span_cap, &nspans, s);
+  if (rc_f == MRX_E_CAPACITY && maxsplit == 0) {   // pieces = matches + n: the need is known
+    if (total) *total = nspans + n;
+    return fail(MRX_E_CAPACITY, "piece buffer too small: need " + std::to_string(nspans + n));
+  }
+  if (rc_f == MRX_E_CAPACITY) {   // a limit is on: the pieces may well fit although the matches did not -- once more, all of them
+    HIP_TRY(scratch_alloc((void**)&d_spans, sizeof(int32_t) * 2 * (size_t)nspans, s));
+    rc_f = run_findall(h, lay, n, d_prefix, d_spans, nspans, &nspans, s);
+  }
+  if (rc_f != MRX_OK) return rc_f;
+  const char* scanned = g_last_kernel;
+  if (n > 0) {
+    hipLaunchKernelGGL(k_split_kept, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, n, d_prefix, maxsplit, d_kept);
+    if (int rc = device_scan<int32_t>(d_kept, n, d_kprefix, d_tot, s)) return rc;
+  } else {
+    HIP_TRY(hipMemsetAsync(d_kprefix, 0, sizeof(int64_t), s));
+  }
+  hipLaunchKernelGGL(k_split_prefix, dim3(grid_for(n + 1, kBlock)), dim3(kBlock), 0, s, n, d_kprefix, d_piece_prefix, d_tot + 1);
+  int64_t pieces_total = 0;
+  HIP_TRY(hipMemcpyAsync(&pieces_total, d_tot + 1, sizeof pieces_total, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (total) *total = pieces_total;
+  if (piece_cap > 0 && n > 0)
+    hipLaunchKernelGGL(k_split_pieces, dim3(grid_for(pieces_total < piece_cap ? pieces_total : piece_cap, kBlock)), dim3(kBlock), 0, s,
+                       lay, n, d_prefix, d_spans, d_piece_prefix, d_pieces, piece_cap);
+  HIP_TRY(hipGetLastError());
+  g_last_kernel = scanned;   // (the scan that found the separators)
+  if (pieces_total > piece_cap) return fail(MRX_E_CAPACITY, "piece buffer too small: need " + std::to_string(pieces_total));
+  return MRX_OK;
+}
+}  // namespace
+extern "C" {
+int mrx_split_dev(const mrx_handle* h, const uint8_t* d, const int64_t* off, int64_t n, int64_t maxsplit,
+                  int64_t* d_piece_prefix, int32_t* d_pieces, int64_t piece_cap, int64_t* total, void* st) {
+  return run_split(h, Layout{d, off, 0, nullptr, 0}, n, maxsplit, d_piece_prefix, d_pieces, piece_cap, total, st);
+}
+int mrx_split_strided_dev(const mrx_handle* h, const uint8_t* d, int64_t stride, const int32_t* lens, int32_t len, int64_t n,
+                          int64_t maxsplit, int64_t* d_piece_prefix, int32_t* d_pieces, int64_t piece_cap, int64_t* total, void* st) {
+  if (stride <= 0) return fail(MRX_E_ARGUMENT, "stride must be positive");
+  if (!lens && (len < 0 || len > stride)) return fail(MRX_E_ARGUMENT, "len must be in [0, stride]");
+  return run_split(h, Layout{d, nullptr, stride, lens, len}, n, maxsplit, d_piece_prefix, d_pieces, piece_cap, total, st);
+}
+
 static int run_count_any(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* counts, void* st) {
   ScratchScope scratch_scope_((hipStream_t)st);
   if (!h) return fail(MRX_E_ARGUMENT, "null handle");
@@ -6241,7 +6364,8 @@ int mrx_sub_dev(const mrx_handle* h, const char* repl, size_t repl_len, int64_t 
 int mrx_sub_strided_dev(const mrx_handle* h, const char* repl, size_t repl_len, int64_t count,
                         const uint8_t* d, int64_t stride, const int32_t* d_lens, int32_t len, int64_t n,
                         int64_t* out_off, uint8_t* out, int64_t out_cap, int64_t* total_bytes, void* st) {
-  if (stride <= 0 || len < 0 || len > stride) return fail(MRX_E_ARGUMENT, "bad pitch / length");
+  // (`len` is ignored when d_lens is given, as in every other strided entry point)
+  if (stride <= 0 || (!d_lens && (len < 0 || len > stride))) return fail(MRX_E_ARGUMENT, "bad pitch / length");
   if (!d_lens && (int64_t)len == stride && n > 0) {
     ScratchScope scope_((hipStream_t)st);
     int64_t* d_off = nullptr;
@@ -6413,6 +6537,20 @@ int mrx_findall_batch(const mrx_handle* h, const uint8_t* data, const int64_t* o
   if (rc == MRX_OK && tot > 0)
     HIP_TRY(hipMemcpy(spans, sp.p, sizeof(int32_t) * 2 * tot, hipMemcpyDeviceToHost));
   return rc;
+}
+int mrx_split_batch(const mrx_handle* h, const uint8_t* data, const int64_t* off, int64_t n, int64_t maxsplit,
+                    int64_t* piece_prefix, int32_t* pieces, int64_t piece_cap, int64_t* total) {
+  DevBatch b; DevBuf<int64_t> pre; DevBuf<int32_t> pc;
+  if (int rc = b.upload(data, off, n)) return rc;
+  if (int rc = pre.alloc(n + 1)) return rc;
+  if (int rc = pc.alloc(2 * (size_t)(piece_cap > 0 ? piece_cap : 1))) return rc;
+  int64_t tot = 0;
+  const int rc = mrx_split_dev(h, b.data, b.offsets, n, maxsplit, pre.p, pc.p, piece_cap, &tot, nullptr);
+  if (total) *total = tot;
+  if (rc != MRX_OK) return rc;
+  HIP_TRY(hipMemcpy(piece_prefix, pre.p, sizeof(int64_t) * (n + 1), hipMemcpyDeviceToHost));
+  if (tot > 0) HIP_TRY(hipMemcpy(pieces, pc.p, sizeof(int32_t) * 2 * tot, hipMemcpyDeviceToHost));
+  return MRX_OK;
 }
 int mrx_captures_batch(const mrx_handle* h, const uint8_t* data, const int64_t* off, int64_t n,
                        int32_t* spans) {

@@ -712,13 +712,13 @@ def test_findall_with_offsets_known_on_the_host(pat):
     texts = _random_texts(rng, 3000, 300, al) + _random_texts(rng, 8, 9000, al) + [b"", b"ab12"]
     rx = M.compile_regex(pat)
     plain = M.DeviceBatch.from_texts(texts)
-    exact_end, exact_max = plain.end_offset, plain.max_len
+    exact_end, exact_max = plain._end_offset, plain._max_len
     assert exact_end == sum(len(t) for t in texts) and exact_max == max(len(t) for t in texts)
-    plain.end_offset = plain.max_len = None            # mrx_findall_dev: reads both from the device
+    plain._end_offset = plain._max_len = None            # mrx_findall_dev: reads both from the device
     want = rx._dev_findall(plain)
     for end, mx in ((exact_end, exact_max), (exact_end + 12345, exact_max * 3 + 7)):
         b = M.DeviceBatch(plain.data, plain.offsets)
-        b.end_offset, b.max_len = end, mx
+        b._end_offset, b._max_len = end, mx
         got = rx._dev_findall(b)
         assert got[2] == want[2] and torch.equal(got[0], want[0]) and torch.equal(got[1][:got[2]], want[1][:want[2]]), (pat, end, mx)
         pre = torch.empty_like(want[0]); sp = torch.empty_like(want[1])
@@ -2555,3 +2555,41 @@ def test_dense_matches_decode_in_row_windows(pat):
     for i in (0, 3, 5, 64, 191):
         t = arr[i, : lens[i]].tobytes()
         assert [tuple(int(x) for x in r) for r in sp_h[pre_h[i]:pre_h[i + 1]]] == O.findall(pat, t), (pat, i)
+
+
+@pytest.mark.parametrize("pat", [b"[, ]+", b"\\d+", b"ab", b"[a-z]+\\d+", b"x*", b"(\\d{3})(\\d{3})(\\d{4})", b"hello.*world"])
+@pytest.mark.parametrize("maxsplit", [0, 1, 3, -1])
+def test_split_behind_the_c_abi_equals_the_oracle(pat, maxsplit):
+    """regex.split (matcher.mojo:1357-1393) through mrx_split_batch / mrx_split_dev / mrx_split_strided_dev: pieces as
+    byte ranges per text, against the oracle's split text by text -- separators at the very start and end, adjacent
+    separators (empty pieces), texts without a separator, empty texts, every maxsplit rule (0 no limit, n at most n
+    splits, negative: none)."""
+    _need_gpu()
+    rng = np.random.default_rng(zlib.crc32(pat) + maxsplit + 7)
+    al = b"ab12, xhelloworld" + bytes(c for c in pat if chr(c).isalnum())
+    texts = _random_texts(rng, 400, 90, al) + [b"", b",", b",,a,,", b"a,b", b"12ab34", b"hello big world, hello world"]
+    rx = M.compile_regex(pat)
+    try:
+        want = [O.split(pat, t, maxsplit) for t in texts]
+    except UnsupportedByOracle:
+        pytest.skip("oracle does not cover this pattern")
+    assert rx.split(texts, maxsplit) == want
+    batch = M.DeviceBatch.from_texts(texts)
+    prefix, pieces, total = rx.split_dev(batch, maxsplit)
+    pre, pc = prefix.cpu().numpy(), pieces.cpu().numpy()
+    assert total == int(pre[-1]) == sum(len(w) for w in want)
+    for i, t in enumerate(texts):
+        assert [t[int(a):int(b)] for a, b in pc[pre[i]:pre[i + 1]]] == want[i], (pat, maxsplit, i, t)
+    # fixed pitch with per-text lengths
+    pitch = 96
+    arr = np.zeros((len(texts), pitch), dtype=np.uint8)
+    lens = np.array([len(t) for t in texts], dtype=np.int32)
+    for i, t in enumerate(texts):
+        arr[i, : len(t)] = np.frombuffer(t, dtype=np.uint8)
+    sb = M.DeviceBatch.strided(torch.from_numpy(arr).cuda().reshape(-1), pitch, lens=torch.from_numpy(lens).cuda())
+    p2, c2, t2 = rx.split_dev(sb, maxsplit)
+    assert t2 == total and torch.equal(p2, prefix) and torch.equal(c2[:t2], pieces[:total])
+    # a piece buffer that is too small is reported, with the need when no limit is on
+    if total > 4:
+        with pytest.raises(M.MrxError):
+            rx.split_dev(batch, maxsplit, piece_cap=total - 1)

@@ -123,10 +123,10 @@ def ragged():
         lib.mrx_debug_force_generic(0)
         # the same with offsets[n] and the longest text known to the caller (mrx_findall_known_dev: no read-back
         # before the scan)
-        batch.end_offset, batch.max_len = nbytes, 1024
+        batch._end_offset, batch._max_len = nbytes, 1024
         row["findall_GBps_known_totals"] = round(nbytes / timeit(lambda: rx._dev_findall(batch, out=(prefix, spans))) / 1e9, 1)
         row["findall_async_GBps_known_totals"] = round(nbytes / timeit(lambda: rx.findall_async(batch, (prefix, spans))) / 1e9, 1)
-        batch.end_offset = batch.max_len = None
+        batch._end_offset = batch._max_len = None
         print(json.dumps(row), flush=True)
 
 
