@@ -377,6 +377,9 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_wstep(DevPlan p, const uint8_
     bool fin = !live || t.len == 0 || skipped;
     uint64_t lz_mid = 0, lz_end = 0;     // LZ: (state, last byte value) pairs first computed inside the text / on its last byte
     const int lz_byte = (LZ && live && t.len > 0) ? (int)t.ptr[t.len - 1] : -1;
+    // LZ: the last FAILED walk, walked again one byte per step beside whatever the lane does now (see the step below):
+    // its state at `pos` (-1: none), and the state the current walk had behind its first byte
+    int lz_sh = -1, lz_s1 = 0;
     const uint32_t* mybm = nullptr;      // BM: my text's marks (frame coordinates)
     int bm_idx = -1;
     uint32_t bm_word = 0;
@@ -405,6 +408,8 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_wstep(DevPlan p, const uint8_
     if (BM && __all(fin)) max_end = 0;
     const uint8_t* myrow = tile + lane * kRowPitch;
     const uint8_t* frame = (const uint8_t*)rb;   // frame position f is frame[f] in global memory
+    uint4 back_w = make_uint4(0, 0, 0, 0);        // the 16-byte block of the frame a lane behind the window reads from
+    int back_idx = -1;
     uint4 v[NL];
 #define MRX_WS_LOAD(CB)                                                                   \
     do {                                                                                  \
@@ -500,6 +505,20 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_wstep(DevPlan p, const uint8_
           if (at_end) row = state == idle ? idle + 1 : (ns >> 1) + state;
         }
         const uint32_t e = CLSIDX ? trc[state * p.ncls + clsT[byte]] : tab[(row << 8) + byte];
+        // LZ.  Upstream restarts a failed walk one byte on and walks again: quadratic where walks are long and fail (a
+        // kilobyte of letters in front of a byte that is no digit: 0.6 GB/s on bench.py's mix in round 3).  A walk's
+        // future depends on (position, state) only -- the cache is monotone, and every pair a walk met is decided for
+        // good -- so the last failed walk R is stepped AGAIN beside the lane (its pairs are all decided: it reads the
+        // masks, never writes them), and the moment the current walk W stands in R's state at R's position, W's
+        // future is R's: no accepting state any more.  W then ends here -- failed, or matched up to its last accepting
+        // position -- instead of at the byte that killed R.  In a run of letters that is the restart's first step.
+        int sh_next = -1;
+        if (LZ && act && inside && lz_sh >= 0) {
+          int row2 = lz_sh;
+          if ((int)byte == lz_byte && ((lz_end >> lz_sh) & 1ull)) row2 = (ns >> 1) + lz_sh;
+          const uint32_t e2 = tab[(row2 << 8) + byte];
+          sh_next = e2 == kWsDead ? -1 : (int)(e2 & 0x3FFFu);
+        }
         if (ROUTE == 1) {
           const bool scanning = state == idle;
           // SCAN
@@ -567,6 +586,31 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_wstep(DevPlan p, const uint8_
         last = (alive && (e & kWsAcc)) ? nxt : last;
         pos = alive ? nxt : (ends ? after : pos);
         state = alive ? (int)(e & 0x3FFFu) : (stop ? idle : state);
+        if (LZ) {
+          if (begins) lz_s1 = state;
+          const bool merged = alive && state != idle && sh_next == state;   // W stands where R stood
+          if (merged) {
+            const bool m = last >= 0;   // W has accepted: [start, last) is its match, nothing behind this byte adds to it
+            if (m) {
+              if (MODE == STEP_EMIT) {
+                if (wo < span_cap) *(int2*)(spans + 2 * wo) = make_int2(start - mis, last - mis);
+                ++wo;
+              }
+              if (MODE == STEP_SLOTS) {
+                if (wo < slot_cap) *(int2*)(spans + 2 * (slot0 + wo)) = make_int2(start - mis, last - mis);
+                ++wo;
+              }
+              if (MODE == STEP_SEARCH) { rs = start - mis; re = last - mis; fin = true; }
+              ++k;
+            }
+            pos = m ? last : start + 1;
+            state = idle;
+            lz_sh = m ? -1 : lz_s1;   // a failed W is the next R: at start + 1 it stood in lz_s1
+          } else if (act) {
+            // W failed by itself: it is the next R.  A match: nothing to walk beside.  Otherwise R moves on with the lane.
+            lz_sh = (ends && !matched) ? lz_s1 : matched ? -1 : sh_next;
+          }
+        }
       };
       while (true) {
         // fast phase: 32 steps on the tile without any cross-lane vote; lanes that are ahead of the
@@ -582,10 +626,19 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_wstep(DevPlan p, const uint8_
           // (marks: a lane without a mark in the window leaves it in one step -- do not idle through the other steps)
           if (BM && !__any(!fin && pos >= wb && (pos < wb + CH || pos >= end))) break;
         }
-        // a restart moved some lane behind the window: it reads those bytes from memory
+        // a restart moved some lane behind the window: it reads those bytes from memory -- 16 at a time into
+        // registers (round 4; a dependent byte load per step before: a lane that came back from a long failed walk
+        // paid a memory round trip for every byte up to the window)
         while (__any(!fin && pos < wb)) {
           const bool act = !fin && pos < wb;
-          step(act, act && pos >= mis ? (uint32_t)frame[pos] : 0u);
+          uint32_t byte = 0u;
+          if (act && pos >= mis) {
+            if ((pos >> 4) != back_idx) { back_idx = pos >> 4; back_w = *(const uint4*)(frame + ((uint32_t)pos & ~15u)); }
+            const int j = (pos >> 2) & 3;
+            const uint32_t wv = j == 0 ? back_w.x : j == 1 ? back_w.y : j == 2 ? back_w.z : back_w.w;
+            byte = (wv >> (8 * (pos & 3))) & 0xFFu;
+          }
+          step(act, byte);
         }
         if (!__any(!fin && (pos < wb + CH || pos >= end))) break;
       }

@@ -2593,3 +2593,66 @@ def test_split_behind_the_c_abi_equals_the_oracle(pat, maxsplit):
     if total > 4:
         with pytest.raises(M.MrxError):
             rx.split_dev(batch, maxsplit, piece_cap=total - 1)
+
+
+@pytest.mark.parametrize("pat", [b"[a-z]+[0-9]+$", b"(foo|[0-9]+)$", b"[a-c]+[0-9]*$", b"(a|b)+c$", b"x*y$|z[0-9]", b"(ab|a)c*$",
+                                 b"[a-z]+[0-9]+x?$", b"(\\d+|[a-f]+)$", b"[a-z]+$"])
+def test_lazy_end_stepper_ends_a_walk_where_it_meets_the_last_failed_one(pat):
+    """Round 4: the LZ stepper walks the last failed walk again beside the lane and ends the current walk the moment it
+    stands in that walk's state at that walk's position (same future: no accepting state any more) -- upstream's
+    restart-per-position loop (pikevm.mojo:754-867) without its quadratic cost on long failing walks.  Same answers
+    as the literal restatement (generic kernels: every restart walks to its death, walk_lazy_end) on texts made of
+    long runs, with the text's last byte value also inside the text / only at its end / in every state's reach, and as
+    the oracle on a sample."""
+    _need_gpu()
+    from mrx_ref import hybrid as H
+    lib = M.load_library()
+    rx = M.compile_regex(pat)
+    d = rx.describe()
+    if "device.lazy_end_cache=yes" not in d:
+        pytest.skip("not a '$' program on the LazyDFA search")
+    rng = np.random.default_rng(zlib.crc32(pat) + 4)
+    al = b"abcf019xyz " + bytes(c for c in pat if chr(c).isalnum())
+    texts = []
+    for L in (40, 200, 1024):
+        for _ in range(120):
+            kind = rng.integers(0, 6)
+            if kind == 0:     # one long run of one class, then a byte that kills / ends it
+                t = bytes(rng.choice(np.frombuffer(b"abc", dtype=np.uint8), size=L - 1).tolist()) + bytes([rng.choice(list(b"!1c9 "))])
+            elif kind == 1:   # letters then digits to the end (a match that runs to the end), last digit also inside
+                k = int(rng.integers(1, L - 1))
+                t = bytes(rng.choice(np.frombuffer(b"abc", dtype=np.uint8), size=k).tolist()) + bytes(rng.choice(np.frombuffer(b"019", dtype=np.uint8), size=L - k).tolist())
+            elif kind == 2:   # tokens
+                t = b" ".join(bytes(rng.choice(np.frombuffer(b"abcf", dtype=np.uint8), size=int(rng.integers(1, 9))).tolist()) +
+                              bytes(rng.choice(np.frombuffer(b"019", dtype=np.uint8), size=int(rng.integers(0, 4))).tolist())
+                              for _ in range(L // 6))[:L]
+            elif kind == 3:   # runs of runs: abab...c, xxxy
+                t = (bytes(rng.choice(np.frombuffer(b"ab", dtype=np.uint8), size=L // 2).tolist()) + b"c" +
+                     b"x" * (L // 4) + b"y" + bytes(rng.choice(np.frombuffer(b"z0f", dtype=np.uint8), size=L // 8).tolist()))[:L]
+            else:
+                t = bytes(rng.choice(np.frombuffer(al, dtype=np.uint8), size=L).tolist())
+            texts.append(t)
+    texts += [b"", b"a", b"a1", b"aa1a1", b"abcabc", b"foofoo", b"xxyxxy", b"a" * 700 + b"1", b"a" * 700 + b"!", b"ab" * 300 + b"c"]
+    batch = M.DeviceBatch.from_texts(texts)
+
+    def run():
+        prefix, spans, total = rx._dev_findall(batch)
+        k1 = lib.mrx_last_kernel_name()
+        cnt = rx.count(batch)
+        s, e = rx.match_next(batch)
+        return (prefix.cpu().numpy(), spans[:total].cpu().numpy(), cnt.cpu().numpy(), s.cpu().numpy(), e.cpu().numpy()), k1
+
+    got, k1 = run()
+    with generic_kernels():
+        want, k2 = run()
+    assert k2 in (b"k_findall_count", b"k_findall"), k2
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b), (pat, k1)
+    o = H.CompiledRegex(pat)
+    for i, t in enumerate(texts):
+        if len(t) > 220 and i % 9:
+            continue   # (the Python oracle is quadratic on these too)
+        have = [tuple(int(x) for x in r) for r in got[1][got[0][i]:got[0][i + 1]]]
+        assert have == o.match_all(t), (pat, i, t[:60])
+        w = o.match_next(t, 0)
+        assert (int(got[3][i]), int(got[4][i])) == (w if w else (-1, -1)), (pat, i)
