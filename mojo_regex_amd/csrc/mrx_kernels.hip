@@ -1731,9 +1731,14 @@ constexpr int kFusedBatch = MRX_FUSED_BATCH;   // ST_FUSED: independent record l
 // odd group, start | (pos_base + 16) << 16, meta}, start / pos_base / matches-before taken at the even
 // group.  Fewer records for the same events: 13 instead of 19 per KiB on the bench workload.
 #ifndef MRX_REC32_MAX_LEN
-#define MRX_REC32_MAX_LEN 65500
+#define MRX_REC32_MAX_LEN 65300
 #endif
 constexpr int kRec32MaxLen = MRX_REC32_MAX_LEN;
+// position field of a REC32 record: text position of the even group + kRecPosBias.  The even group of a pair may lie in
+// front of its text -- by up to 15 bytes in a 16-byte frame, up to 127 in the 128-byte frames of ragged batches
+// (round 4) -- so the bias keeps the field positive: 16 (the pair's odd group holds text) + 128.
+constexpr int kRecPosBias = 144;
+static_assert(MRX_REC32_MAX_LEN + 16 + kRecPosBias < 65536, "position field is 16 bits");
 
 __host__ __device__ inline int64_t rec_row_len(int64_t max_len) { return max_len / 16 + 2; }
 // CSR batches: wavefront w's record region.  A text yields at most len/16 + 3 records (its frame
@@ -1797,7 +1802,7 @@ __device__ __forceinline__ void fused_fill_tile(const EvRec* __restrict__ wave_r
       const int rel_t = __shfl(my_rel, (int)(r.w >> 26));
       int dst = rel_t + (int)(r.w & kRecBeforeMask) - tb;
       uint32_t Fw = r.x;
-      int pb = REC32 ? (int)(r.z >> 16) - 16 : (int)r.z;
+      int pb = REC32 ? (int)(r.z >> 16) - kRecPosBias : (int)r.z;
       int rstart = REC32 ? (int)(r.z & 0xFFFFu) : (int)r.y;
 #pragma unroll
       for (int half = 0; half < (REC32 ? 2 : 1); ++half) {
@@ -2055,8 +2060,15 @@ __global__ __launch_bounds__(64 * kStreamWaves, (MODE == ST_FUSED ? MRX_FUSED_WA
       }
       // an empty text owns no block: park its row on the plan blob (valid memory, never read as text)
       const uintptr_t addr = my_len > 0 ? (uintptr_t)(data + o0) : (uintptr_t)blob;
-      mis = my_len > 0 ? (int)(addr & 15) : 0;
-      const uintptr_t rb = addr & ~(uintptr_t)15;
+      // The frame begins at the 128-byte LINE that holds the text's first byte (round 4; the 16-byte block before):
+      // a chunk of a row is then one whole line, where a row at an arbitrary offset had every line of its text loaded
+      // by two consecutive chunks -- the non-temporal loads keep nothing, so the kernel moved twice the batch (ragged
+      // count: FETCH_SIZE 601 MB raw for 570 MB of text against 537 MB raw for 1074 MB at a fixed pitch; profiles/
+      // r04_ragged.md).  Up to 112 more masked bytes per text; never leaves the page of the text's first byte.
+      // (match_first keeps the 16-byte frame: its probe reads the text's first block only.)
+      constexpr uintptr_t kFrameMask = MODE == ST_FIRST ? 15 : 127;
+      mis = my_len > 0 ? (int)(addr & kFrameMask) : 0;
+      const uintptr_t rb = addr & ~kFrameMask;
       *(uint4*)(tile + lane * kRowPitch + CH) =
           make_uint4((uint32_t)rb, (uint32_t)((uint64_t)rb >> 32), (uint32_t)(mis + my_len), 0u);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -2292,7 +2304,7 @@ __global__ __launch_bounds__(64 * kStreamWaves, (MODE == ST_FUSED ? MRX_FUSED_WA
         if (RECS && REC32) {
           if ((g & 1) == 0) {
             F_even = F;
-            sp_even = (uint32_t)start | ((uint32_t)(gbase + 16) << 16);
+            sp_even = (uint32_t)start | ((uint32_t)(gbase + kRecPosBias) << 16);
             meta_even = ((uint32_t)lane << 26) | ((uint32_t)cnt & kRecBeforeMask);
           } else {
             const bool any = ((F_even | F) & 0xAAAAAAAAu) != 0u;
@@ -2360,7 +2372,7 @@ __global__ __launch_bounds__(64 * kStreamWaves, (MODE == ST_FUSED ? MRX_FUSED_WA
           EvRec r;
           r.F = 2u; r.start = start; r.pos_base = my_len;  // EMIT at byte 0 of a group placed at len
           r.meta = ((uint32_t)lane << 26) | ((uint32_t)cnt & kRecBeforeMask);
-          if (REC32) *(uint4*)(wave_recs + wrec + rank) = make_uint4(2u, 0u, (uint32_t)start | ((uint32_t)(my_len + 16) << 16), r.meta);
+          if (REC32) *(uint4*)(wave_recs + wrec + rank) = make_uint4(2u, 0u, (uint32_t)start | ((uint32_t)(my_len + kRecPosBias) << 16), r.meta);
           else
           wave_recs[wrec + rank] = r;
         }
@@ -2502,8 +2514,9 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_dyn(
       uintptr_t addr = (uintptr_t)blob;
       if (t < 0) len = 0;
       if (len > 0) addr = (uintptr_t)(data + o0);
-      const int m0 = len > 0 ? (int)(addr & 15) : 0;
-      const uintptr_t rb = (addr & ~(uintptr_t)15) - (uintptr_t)shift;
+      // (the frame begins at the 128-byte line of the text's first byte: see k_stream_findall)
+      const int m0 = len > 0 ? (int)(addr & 127) : 0;
+      const uintptr_t rb = (addr & ~(uintptr_t)127) - (uintptr_t)shift;
       len_o = len; mis_o = shift + m0; flen_o = shift + m0 + len;
       // (no text, or an empty one: frame end 0 -- every load of the row falls back to the row's first block)
       *(uint4*)(tile + lane * kRowPitch + CH) =
@@ -2713,7 +2726,7 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_dyn(
         if (MODE == ST_RECORDS && REC32) {
           if ((g & 1) == 0) {
             F_even = F;
-            sp_even = (uint32_t)start | ((uint32_t)(gbase + 16) << 16);
+            sp_even = (uint32_t)start | ((uint32_t)(gbase + kRecPosBias) << 16);
             meta_even = tix | ((uint32_t)cnt & kDynBeforeMask);
           } else {
             const bool any = ((F_even | F) & 0xAAAAAAAAu) != 0u;
@@ -2760,7 +2773,7 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_dyn(
             if (tail) {
               const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(has >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)has, 0));
               const uint32_t meta = ((uint32_t)(my_text - T0) << kDynShift) | ((uint32_t)cnt & kDynBeforeMask);
-              if (REC32) *(uint4*)(wave_recs + wrec + rank) = make_uint4(2u, 0u, (uint32_t)start | ((uint32_t)(my_len + 16) << 16), meta);
+              if (REC32) *(uint4*)(wave_recs + wrec + rank) = make_uint4(2u, 0u, (uint32_t)start | ((uint32_t)(my_len + kRecPosBias) << 16), meta);
               else *(uint4*)(wave_recs + wrec + rank) = make_uint4(2u, (uint32_t)start, (uint32_t)my_len, meta);
             }
             wrec += __builtin_popcountll(has);
@@ -2959,7 +2972,7 @@ __global__ __launch_bounds__(kBlock) void k_decode(int64_t n, const int32_t* __r
           int within = (int)(r.meta & kBefore);                       // index of my record's first span within its text
           int64_t dst = pre0 + rel_t + within;
           uint32_t Fw = r.F;
-          int pb = REC32 ? (int)((uint32_t)r.pos_base >> 16) - 16 : r.pos_base;
+          int pb = REC32 ? (int)((uint32_t)r.pos_base >> 16) - kRecPosBias : r.pos_base;
           int rstart = REC32 ? (int)((uint32_t)r.pos_base & 0xFFFFu) : r.start;
 #pragma unroll
           for (int half = 0; half < (REC32 ? 2 : 1); ++half) {
@@ -3033,7 +3046,7 @@ __global__ __launch_bounds__(kBlock) void k_decode(int64_t n, const int32_t* __r
           int dst = rel_t + (int)(r.meta & kBefore) - tb;
           // REC32: {F even, F odd, start | (pos + 16) << 16, meta} -- two event words per record
           uint32_t Fw = r.F;
-          int pb = REC32 ? (int)((uint32_t)r.pos_base >> 16) - 16 : r.pos_base;
+          int pb = REC32 ? (int)((uint32_t)r.pos_base >> 16) - kRecPosBias : r.pos_base;
           int rstart = REC32 ? (int)((uint32_t)r.pos_base & 0xFFFFu) : r.start;
 #pragma unroll
           for (int half = 0; half < (REC32 ? 2 : 1); ++half) {
@@ -5125,24 +5138,96 @@ static int dense_candidates(const mrx_handle* h, const Layout& lay, int64_t n, h
   *dense = (double)hits >= 0.08 * (double)bytes;
   return MRX_OK;
 }
-int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_prefix,
-                int32_t* d_spans, int64_t span_cap, int64_t* total, void* stream, bool match_next_sequence = false,
-                int64_t known_total = -1, int64_t known_max = -1) {
-  ScratchScope scratch_scope_((hipStream_t)stream);
-  if (!h) return fail(MRX_E_ARGUMENT, "null handle");
-  if (n < 0 || span_cap < 0) return fail(MRX_E_ARGUMENT, "negative size");
-  if ((uintptr_t)d_spans & 7) return fail(MRX_E_ARGUMENT, "d_spans must be 8-byte aligned");
-  if (int rc = check_search_supported(h)) return rc;
-  if (int rc = check_lds(h)) return rc;
-  if (int rc = ensure_device(h)) return rc;
-  hipStream_t s = (hipStream_t)stream;
+int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_prefix, int32_t* d_spans, int64_t span_cap,
+                int64_t* total, void* stream, bool match_next_sequence = false, int64_t known_total = -1, int64_t known_max = -1);
+
+// One findall call.  The members are the state the routes share (the launch macros of this file read the route flags by
+// name); one member function per route -- round 3's run_findall was a single 420-line function steering ~25 flags.
+struct FindallJob {
+  const mrx_handle* h;
+  const Layout& lay;
+  int64_t n;
+  int64_t* d_prefix;
+  int32_t* d_spans;
+  int64_t span_cap;
+  int64_t* total;
+  hipStream_t s;
+  bool match_next_sequence;
+  int64_t known_total, known_max;
+  const DevPlan& p;
   int32_t* d_counts = nullptr;
   int64_t* d_total = nullptr;
-  HIP_TRY(scratch_alloc((void**)&d_counts, sizeof(int32_t) * (n > 0 ? n : 1), s));
-  HIP_TRY(scratch_alloc((void**)&d_total, sizeof(int64_t), s));
-  const DevPlan& p = h->hp.dev;
-  if (n > 0 && anchored_at_zero(h) && stream_layout_ok(lay, n)) {
-    int32_t* d_se = nullptr;
+  // ---- route (chosen by choose_route(); the launch macros of this file read these by name) ----
+  bool stream_ok = false, use_req_route = false, wstep_bits = false, wstep_lz = false, wstep_empty = false;
+  bool mwalk_req = false, wstep_mwalk = false;
+  DevPlan pk;                      // what the lane kernels are launched with
+  int wstep_mwalk_k = 0;
+  bool wstep_mwalk_pk = false;     // k_mwalk's packed-start form (every text below 64 KiB)
+  bool step_ok = false;
+  bool bits_fixed = false;         // bitset program whose matches all have one length: the union pass counts and emits by itself
+  bool bits_fixed_slots = false;   // ... with the spans in slot rows (one pass)
+  bool fused = false;              // streaming path: scan, CSR offsets and spans in one launch (ST_FUSED / k_stream_bits)
+  bool split_done = false;         // streaming path: two halves on two streams (findall_split)
+  bool dyn = false;                // streaming path: ragged CSR batch on k_stream_dyn (256-text tasks)
+  unsigned long long* d_ctrl = nullptr;   // its ticket word, error word and descriptors
+  int32_t* d_blimit = nullptr;            // bitset NFA: per-text limits of the first pass
+  bool rec32 = false;              // streaming path: one record per two groups (positions fit 16 bits)
+  int64_t max_text = int64_t(1) << 40;    // longest text of the batch, where known
+  bool req_wave = false;           // the stepper's route on the wavefront-per-text kernel
+  bool mwalk_two_pass = false;     // multi-walk plan: count pass + emit pass instead of slot rows
+  bool wstep_bm = false;           // stepper behind the right-to-left pass that marks where matches begin (PF_BACKSET)
+  bool wstep_bm_big = false;       // ... with its table class indexed (more than 96 states)
+  int step_split = 0;              // > 0: lane kernel for texts below this length AND wavefront kernel for the rest
+  Layout lay2;                     // lay + that split
+  EvRec* d_recs = nullptr;
+  EvRec* d_recs_alloc = nullptr;   // what d_recs was cut from when it is skewed (mrx_debug_rec_skew)
+  int32_t* d_nrecs = nullptr;
+  int64_t* d_wbase = nullptr;
+  int32_t* d_slots = nullptr;
+  int64_t rec_row = 0;
+  Pieces pc;
+  Layout lay_pre;                  // literal restatement of a backtracker-routed plan: lay + bt_prepass()
+  int64_t csr_total = -1, csr_max = -1;   // CSR batches on the streaming path: byte count and longest text
+  bool by_pieces = false;
+  bool finished = false;           // a route that answered the whole call by itself (the stepper's pieces)
+
+  FindallJob(const mrx_handle* h_, const Layout& lay_, int64_t n_, int64_t* d_prefix_, int32_t* d_spans_, int64_t span_cap_,
+             int64_t* total_, hipStream_t s_, bool mns, int64_t kt, int64_t km)
+      : h(h_), lay(lay_), n(n_), d_prefix(d_prefix_), d_spans(d_spans_), span_cap(span_cap_), total(total_), s(s_),
+        match_next_sequence(mns), known_total(kt), known_max(km), p(h_->hp.dev), pk(h_->hp.dev), lay2(lay_), lay_pre(lay_) {}
+
+  // Which kernels serve this call.  Streamable plans: the streaming scan (records -> prefix sums -> decode, or one of
+  // its one-launch forms); everything else: the stepper family (multi-walk table, backward marks, bitset union pass,
+  // wavefront per text, required-byte route) or the literal restatement.
+  void choose_route() {
+    stream_ok = !g_force_generic && (p.flags & PF_STREAMABLE) && stream_layout_ok(lay, n);
+    // match_next_sequence: the caller (sub) wants the matches that iterating match_next from each
+    // match end visits -- the plain walk even on plans whose findall takes the required-byte route
+    use_req_route = (p.flags & PF_STEP_REQ) && !match_next_sequence;
+    wstep_bits = (p.flags & PF_BSTEP) != 0;   // bitset NFA on the lane-per-text stepper
+    wstep_lz = (p.flags & PF_LAZY_END) != 0;  // '$' on the LazyDFA search: lane per text only (the cache is the text's)
+    // plans with empty matches: count, then emit (nearly every text has more matches than a slot row holds)
+    wstep_empty = (p.flags & PF_STEP_EMPTY) != 0 && !match_next_sequence && g_force_generic < 2;
+    // several walks in one pass instead of the restart-per-position loop (plain route; sub's match_next sequence is
+    // the same list of matches, but a memchr-prefiltered match_next is not the plain search)
+    mwalk_req = use_req_route && (p.flags & PF_MWALK_REQ) && mwalk_enabled();
+    wstep_mwalk = (mwalk_req || (mwalk_on(p) && !use_req_route)) && !wstep_bits && !wstep_empty &&
+                  !(match_next_sequence && (p.flags & PF_PREFILTER));
+    pk = mwalk_req ? mwalk_req_plan(p) : p;
+    wstep_mwalk_k = pk.mw_k;
+    step_ok = g_force_generic < 2 &&
+              (wstep_mwalk ||
+               (match_next_sequence ? ((p.flags & PF_STEP_SEARCH) && !(p.flags & PF_PREFILTER))
+                                    : (p.flags & (PF_STEPPABLE | PF_STEP_REQ | PF_STEP_EMPTY)) != 0));
+    // bitset program whose matches all have one length: the union pass counts and emits by itself (k_bscan modes 2, 3)
+    bits_fixed = step_ok && wstep_bits && bits_fixed_on(p) && !(match_next_sequence && (p.flags & PF_PREFILTER));
+    lay2 = lay;
+    lay_pre = lay;
+  }
+
+  // '^'-anchored DFA plan: the anchored automaton's run from byte 0 is the whole answer
+  int anchored() {
+  int32_t* d_se = nullptr;
     HIP_TRY(scratch_alloc((void**)&d_se, sizeof(int32_t) * 2 * n, s));
     {
       ScanTimer tm(s);
@@ -5167,296 +5252,101 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
     }
     return rc;
   }
-  bool stream_ok = !g_force_generic && (p.flags & PF_STREAMABLE) && stream_layout_ok(lay, n);
-  // match_next_sequence: the caller (sub) wants the matches that iterating match_next from each
-  // match end visits -- the plain walk even on plans whose findall takes the required-byte route
-  const bool use_req_route = (p.flags & PF_STEP_REQ) && !match_next_sequence;
-  const bool wstep_bits = (p.flags & PF_BSTEP) != 0;   // bitset NFA on the lane-per-text stepper
-  const bool wstep_lz = (p.flags & PF_LAZY_END) != 0;  // '$' on the LazyDFA search: lane per text only (the cache is the text's)
-  // plans with empty matches: count, then emit (nearly every text has more matches than a slot row holds)
-  const bool wstep_empty = (p.flags & PF_STEP_EMPTY) != 0 && !match_next_sequence && g_force_generic < 2;
-  // several walks in one pass instead of the restart-per-position loop (plain route; sub's match_next sequence is
-  // the same list of matches, but a memchr-prefiltered match_next is not the plain search)
-  const bool mwalk_req = use_req_route && (p.flags & PF_MWALK_REQ) && mwalk_enabled();
-  const bool wstep_mwalk = (mwalk_req || (mwalk_on(p) && !use_req_route)) && !wstep_bits && !wstep_empty &&
-                           !(match_next_sequence && (p.flags & PF_PREFILTER));
-  const DevPlan pk = mwalk_req ? mwalk_req_plan(p) : p;   // what the lane kernels are launched with
-  const int wstep_mwalk_k = pk.mw_k;
-  bool wstep_mwalk_pk = false;   // k_mwalk's packed-start form (every text below 64 KiB)
-  bool step_ok = g_force_generic < 2 &&
-                 (wstep_mwalk ||
-                  (match_next_sequence ? ((p.flags & PF_STEP_SEARCH) && !(p.flags & PF_PREFILTER))
-                                       : (p.flags & (PF_STEPPABLE | PF_STEP_REQ | PF_STEP_EMPTY)) != 0));
-  // bitset program whose matches all have one length: the union pass counts and emits by itself (k_bscan modes 2, 3)
-  const bool bits_fixed = step_ok && wstep_bits && bits_fixed_on(p) && !(match_next_sequence && (p.flags & PF_PREFILTER));
-  bool bits_fixed_slots = false;   // ... with the spans in slot rows (one pass)
-  bool fused = false;      // streaming path: scan, CSR offsets and spans in one launch (ST_FUSED)
-  bool split_done = false; // streaming path: two halves on two streams (findall_split)
-  bool dyn = false;        // streaming path: ragged CSR batch on k_stream_dyn (256-text tasks)
-  unsigned long long* d_ctrl = nullptr;   // its ticket word, error word and descriptors
-  int32_t* d_blimit = nullptr;            // bitset NFA: per-text limits of the first pass
-  bool rec32 = false;      // streaming path: one record per two groups (positions fit 16 bits)
-  int64_t max_text = int64_t(1) << 40;   // longest text of the batch, where known
-  bool req_wave = false;   // the stepper's route on the wavefront-per-text kernel
-  bool mwalk_two_pass = false;   // multi-walk plan: count pass + emit pass instead of slot rows
-  bool wstep_bm = false;         // stepper behind the right-to-left pass that marks where matches begin (PF_BACKSET)
-  bool wstep_bm_big = false;     // ... with its table class indexed (more than 96 states)
-  int step_split = 0;      // > 0: lane kernel for texts below this length AND wavefront kernel for the rest
-  Layout lay2 = lay;       // lay + that split
-  EvRec* d_recs = nullptr;
-  EvRec* d_recs_alloc = nullptr;   // what d_recs was cut from when it is skewed (mrx_debug_rec_skew)
-  int32_t* d_nrecs = nullptr;
-  int64_t* d_wbase = nullptr;
-  int32_t* d_slots = nullptr;
-  int64_t rec_row = 0;
-  Pieces pc;
-  Layout lay_pre = lay;                   // literal restatement of a backtracker-routed plan: lay + bt_prepass()
-  int64_t csr_total = -1, csr_max = -1;   // CSR batches on the streaming path: byte count and longest text
-  if (n > 0 && stream_ok && lay.offsets) {
-    if (known_total >= 0) { csr_total = known_total; csr_max = known_max; }   // the caller (sub) has read them
-    else if (int rc = csr_stats(lay, n, s, &csr_total, &csr_max)) return rc;
-    if (csr_total < 0) return fail(MRX_E_ARGUMENT, "offsets[n] is negative");
-  }
-  // An event record counts the matches of its text in front of it in 26 bits (kRecBeforeMask), and a
-  // text of 2^26 bytes can hold that many (one-byte matches, no synchronising byte to cut at): such
-  // texts take the lane-per-text kernels, whose span cursor is 64 bits wide.
-  if (stream_ok && stream_text_too_long(lay.offsets ? csr_max : (lay.lens ? lay.stride : (int64_t)lay.len)))
-    stream_ok = false;
-  if (n > 0 && stream_ok)
-    if (int rc = pieces_prepare(h, lay, n, s, &pc, csr_total, csr_max)) return rc;
-  const bool by_pieces = pc.on;
-  if (pc.on) {
-    if (int rc = findall_pieces(h, pc, n, d_prefix, d_spans, span_cap, d_total, s)) return rc;
-    if (int rc = pieces_release(&pc, s)) return rc;
-  } else if (n > 0) {
-    if (stream_ok) {
-      const int64_t nw = (n + 63) / 64;
-      size_t nrec;
-      if (lay.offsets) {
-        // the record buffer is sized by the batch's byte count, which only the device knows
-        // (csr_stats above: the only host synchronisation the CSR path adds)
-        nrec = (size_t)(csr_total / 16 + 256 * nw + 256);
-      } else {
-        // one 16-byte record per 16-byte group at most (+1 for the match that ends at len)
-        rec_row = rec_row_len(lay.lens ? lay.stride : lay.len) + (strided_fast(lay) ? 0 : 1);  // frame: one more group
-        nrec = (size_t)rec_row * n;
-      }
-      max_text = lay.offsets ? csr_max : (lay.lens ? lay.stride : (int64_t)lay.len);
-      rec32 = max_text <= kRec32MaxLen;
-      // (a CSR batch of equal-length texts leaves no lane idle: the 64-text wavefronts and their decode are faster)
-      dyn = dyn_ok(h, lay, n) && max_text < (int64_t(1) << kDynShift) &&
-            (g_dyn_mode == 1 || csr_total < max_text * n - max_text * n / 8);
-      // One launch (ST_FUSED) when a record region per resident wavefront -- sized for the most one
-      // 64-text task can produce -- stays within twice the record stream of the three-launch form
-      // (ragged batches whose longest text is far above the average do not: they are cut into pieces
-      // above, or keep the stream that is sized by the batch's byte count).
-      const int64_t fz_per_text = (rec32 ? max_text / 32 : max_text / 16) + 4;
-      int64_t fz_grid = (nw + kStreamWaves - 1) / kStreamWaves;
-      if (fz_grid > fused_grid_cap()) fz_grid = fused_grid_cap();
-      const size_t fz_nrec = (size_t)(64 * fz_per_text + 64) * (size_t)(fz_grid * kStreamWaves) * 2;   // two regions per wavefront
-      const int64_t batch_bytes = lay.offsets ? csr_total : n * (lay.lens ? lay.stride : (int64_t)lay.len);
-      fused = !dyn && g_fused && span_cap > 0 && fz_nrec <= 2 * nrec + (size_t(8) << 20) && (g_fused == 2 || batch_bytes >= nw * kFusedMinTaskBytes);
-      // texts of at most 1 KiB at a 16-byte aligned pitch, automaton in registers: one launch, no records at all
-      // (mrx_stream_bits.hip)
-      const bool bits = !dyn && !fused && !lay.offsets && span_cap > 0 && !g_split_findall &&
-                        stream_bits_eligible(p, lay.data, lay.stride, max_text, n);
-      if (bits) {
-        void* d_args = nullptr;
-        HIP_TRY(scratch_alloc((void**)&d_ctrl, sizeof(unsigned long long) * stream_bits_ctrl_words(n), s));
-        HIP_TRY(scratch_alloc(&d_args, stream_bits_args_bytes(), s));
-        if (int rc = stream_bits_init(n, max_text, d_prefix, d_spans, span_cap, d_total, d_ctrl, d_args, s)) return rc;
-        ScanTimer tm(s);
-        if (int rc = stream_bits_scan(p, H_BLOB(h), lay.data, lay.stride, lay.lens, lay.len, max_text, n, d_args, s)) return rc;
-        g_last_kernel = "k_stream_bits";
-        tm.stop();
-        fused = true;   // (offsets and spans are complete: nothing is left for the launches below)
-      } else
-      if (fused) {
-        // ticket | error | one descriptor per task | two words per group of 64 tasks; a 16-byte multiple
-        const size_t ctrl_words = (size_t)((2 + nw + 2 * ((nw + 63) / 64) + 1) & ~int64_t(1));
-        HIP_TRY(scratch_alloc((void**)&d_ctrl, sizeof(unsigned long long) * ctrl_words, s));   // first: starts its own 256-byte block
-        HIP_TRY(scratch_alloc((void**)&d_recs, sizeof(EvRec) * fz_nrec, s));
-        FusedArgs* d_fz = nullptr;
-        HIP_TRY(scratch_alloc((void**)&d_fz, sizeof(FusedArgs), s));
-        FusedArgs fz;
-        fz.ctrl = d_ctrl; fz.prefix = d_prefix; fz.spans = d_spans; fz.span_cap = span_cap; fz.total_out = d_total;
-        fz.rec_cap = 64 * fz_per_text + env_knobs().fused_skew;
-        fz.debug = env_knobs().fused_debug;
-        hipLaunchKernelGGL(k_fused_init, dim3((unsigned)((ctrl_words + kBlock * 8 - 1) / (kBlock * 8))), dim3(kBlock), 0, s,
-                           d_ctrl, (int64_t)ctrl_words, d_fz, fz);
-        ScanTimer tm(s);
-        launch_stream<ST_FUSED>(h, lay, n, nullptr, nullptr, d_recs, 0, nullptr, nullptr, s, nullptr, nullptr, rec32, d_fz,
-                                (int)fz_grid);
-        g_last_kernel = "k_stream_findall_fused";
-        HIP_TRY(hipGetLastError());
-        tm.stop();
-      } else if (dyn) {
-        const int64_t nt = (n + kDynTexts - 1) / kDynTexts;
-        HIP_TRY(scratch_alloc((void**)&d_recs, sizeof(EvRec) * (size_t)(csr_total / 16 + 4 * kDynTexts * (nt + 1)), s));
-        HIP_TRY(scratch_alloc((void**)&d_nrecs, sizeof(int32_t) * 2 * nt, s));   // records | matches per task
-        HIP_TRY(scratch_alloc((void**)&d_wbase, sizeof(int64_t) * (nt + 1), s));
-        ScanTimer tm(s);
-        launch_stream_dyn<ST_RECORDS>(h, lay, n, d_counts, d_nrecs, d_recs, nullptr, nullptr, s, rec32);
-        g_last_kernel = "k_stream_findall_dyn";
-        HIP_TRY(hipGetLastError());
-        tm.stop();
-      } else if (g_split_findall && !lay.offsets && strided_fast(lay) && span_cap > 0 && n >= kSplitMinTexts) {
-        split_done = true;
-        if (int rc = findall_split(h, lay, n, d_counts, d_prefix, d_spans, span_cap, d_total, rec_row, rec32, max_text <= 65535, s))
-          return rc;
-      } else {
-      const int64_t skew = g_rec_skew.load(std::memory_order_relaxed);   // (mrx_debug_rec_skew: placement experiments)
-      HIP_TRY(scratch_alloc((void**)&d_recs_alloc, sizeof(EvRec) * nrec + (size_t)skew, s));
-      d_recs = (EvRec*)((uint8_t*)d_recs_alloc + skew);
-      HIP_TRY(scratch_alloc((void**)&d_nrecs, sizeof(int32_t) * 2 * nw, s));  // records | matches per wavefront
-      HIP_TRY(scratch_alloc((void**)&d_wbase, sizeof(int64_t) * (nw + 1), s));
-      ScanTimer tm(s);
-      launch_stream<ST_RECORDS>(h, lay, n, d_counts, d_nrecs, d_recs, rec_row, nullptr, nullptr, s, nullptr, nullptr, rec32);
-      g_last_kernel = "k_stream_findall";
-      HIP_TRY(hipGetLastError());
-      tm.stop();
-      }
+
+  // streamable plan: the scan (records, or one of the one-launch forms)
+  int stream_scan() {
+  const int64_t nw = (n + 63) / 64;
+    size_t nrec;
+    if (lay.offsets) {
+      // the record buffer is sized by the batch's byte count, which only the device knows
+      // (csr_stats above: the only host synchronisation the CSR path adds)
+      nrec = (size_t)(csr_total / 16 + 256 * nw + 256);
     } else {
-      if (step_ok && !wstep_bits && !wstep_empty && !t_in_pieces && !(p.flags & PF_STEP_BIG) && p.st_nsync > 0 &&
-          !(p.flags & PF_STREAMABLE) && span_cap > 0 && (!use_req_route || g_long_text_mode == 1)) {
-        Pieces spc;
-        if (int rc = pieces_prepare(h, lay, n, s, &spc, -1, -1, /*disjoint=*/true, wstep_mwalk)) return rc;
-        if (spc.on && !wstep_mwalk) {   // (a multi-walk plan scans every piece once, dense candidates or not)
-          bool dense = true;
-          if (int rc = dense_candidates(h, lay, n, s, &dense)) return rc;
-          if (!dense)
-            if (int rc = pieces_release(&spc, s)) return rc;
-        }
-        if (spc.on) {
-          int64_t* d_vprefix = nullptr;
-          HIP_TRY(scratch_alloc((void**)&d_vprefix, sizeof(int64_t) * (spc.nv + 1), s));
-          t_in_pieces = true;
-          const int rc = run_findall(h, spc.lay, spc.nv, d_vprefix, d_spans, span_cap, nullptr, s, match_next_sequence);
-          t_in_pieces = false;
-          if (rc != MRX_OK) return rc;
-          const std::string inner = g_last_kernel;
-          hipLaunchKernelGGL(k_virt_prefix, dim3(grid_for(n + 1, kBlock)), dim3(kBlock), 0, s, n, spc.vfirst, d_vprefix, d_prefix);
-          hipLaunchKernelGGL(k_virt_add_base, dim3(grid_for(spc.nv * 64, kBlock)), dim3(kBlock), 0, s, spc.nv, d_vprefix, spc.vbase,
-                             d_spans, span_cap);
-          HIP_TRY(hipGetLastError());
-          static thread_local std::string piece_name;
-          piece_name = inner + "_pieces";
-          g_last_kernel = piece_name.c_str();
-          int rc2 = MRX_OK;
-          if (total) {
-            int64_t tot = 0;
-            HIP_TRY(hipMemcpyAsync(&tot, d_vprefix + spc.nv, sizeof tot, hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipStreamSynchronize(s));
-            *total = tot;
-            if (tot > span_cap) rc2 = fail(MRX_E_CAPACITY, "span buffer too small: need " + std::to_string(tot));
-          }
-          HIP_TRY(scratch_free(d_vprefix, s));
-          if (int rc3 = pieces_release(&spc, s)) return rc3;
-          HIP_TRY(scratch_free(d_counts, s));
-          HIP_TRY(scratch_free(d_total, s));
-          return rc2;
-        }
-      }
-      if (step_ok && !wstep_bits && !wstep_empty && !t_in_pieces && !wstep_lz) {
-        if (int rc = req_wave_pays(lay, n, use_req_route, s, &req_wave, (p.flags & PF_STEP_BIG) ? nullptr : &step_split,
-                                   (p.flags & PF_STEP_BIG) != 0, wstep_mwalk, backset_on(p) && !wstep_mwalk))
-          return rc;
-        wstep_mwalk_pk = wstep_mwalk && mwalk_pk_ok(lay, t_csr_max_len);
-      }
-      lay2.split = step_split;
-      wstep_bm = step_ok && backset_on(p) && !wstep_mwalk && !wstep_bits && !wstep_empty && !use_req_route && !req_wave &&
-                 step_split == 0;
-      wstep_bm_big = wstep_bm && (p.flags & PF_STEP_BIG) != 0;
-      if (wstep_bm) {
-        const int32_t split_keep = lay2.split;
-        if (int rc = backscan_marks(h, lay, n, s, &lay2)) return rc;
-        lay2.split = split_keep;
-      }
-      if (step_ok && !bits_fixed && !wstep_empty && !wstep_mwalk && !wstep_bm && (wstep_bits || (!req_wave && step_split == 0 && !use_req_route && union_pass_for_table_plan(p, false)))) {
-        // union automaton first: texts in which no walk from any start reaches MATCH are not walked at all
-        // (mode 0: a wavefront stops as soon as each of its texts has shown one match end, so on texts full
-        // of matches the pass costs next to nothing; cutting tails -- mode 1 -- would scan everything)
-        if (int rc = bscan_limits(h, lay, n, 0, s, &lay2, &d_blimit)) return rc;
-      }
-      // big tables: only the wavefront kernel has their form; many short texts stay on the literal restatement
-      if ((p.flags & PF_STEP_BIG) && !req_wave && !wstep_mwalk && !wstep_bm) step_ok = false;
+      // one 16-byte record per 16-byte group at most (+1 for the match that ends at len)
+      rec_row = rec_row_len(lay.lens ? lay.stride : lay.len) + (strided_fast(lay) ? 0 : 1);  // frame: one more group
+      nrec = (size_t)rec_row * n;
+    }
+    max_text = lay.offsets ? csr_max : (lay.lens ? lay.stride : (int64_t)lay.len);
+    rec32 = max_text <= kRec32MaxLen;
+    // (a CSR batch of equal-length texts leaves no lane idle: the 64-text wavefronts and their decode are faster)
+    dyn = dyn_ok(h, lay, n) && max_text < (int64_t(1) << kDynShift) &&
+          (g_dyn_mode == 1 || csr_total < max_text * n - max_text * n / 8);
+    // One launch (ST_FUSED) when a record region per resident wavefront -- sized for the most one
+    // 64-text task can produce -- stays within twice the record stream of the three-launch form
+    // (ragged batches whose longest text is far above the average do not: they are cut into pieces
+    // above, or keep the stream that is sized by the batch's byte count).
+    const int64_t fz_per_text = (rec32 ? max_text / 32 : max_text / 16) + 4;
+    int64_t fz_grid = (nw + kStreamWaves - 1) / kStreamWaves;
+    if (fz_grid > fused_grid_cap()) fz_grid = fused_grid_cap();
+    const size_t fz_nrec = (size_t)(64 * fz_per_text + 64) * (size_t)(fz_grid * kStreamWaves) * 2;   // two regions per wavefront
+    const int64_t batch_bytes = lay.offsets ? csr_total : n * (lay.lens ? lay.stride : (int64_t)lay.len);
+    fused = !dyn && g_fused && span_cap > 0 && fz_nrec <= 2 * nrec + (size_t(8) << 20) && (g_fused == 2 || batch_bytes >= nw * kFusedMinTaskBytes);
+    // texts of at most 1 KiB at a 16-byte aligned pitch, automaton in registers: one launch, no records at all
+    // (mrx_stream_bits.hip)
+    const bool bits = !dyn && !fused && !lay.offsets && span_cap > 0 && !g_split_findall &&
+                      stream_bits_eligible(p, lay.data, lay.stride, max_text, n);
+    if (bits) {
+      void* d_args = nullptr;
+      HIP_TRY(scratch_alloc((void**)&d_ctrl, sizeof(unsigned long long) * stream_bits_ctrl_words(n), s));
+      HIP_TRY(scratch_alloc(&d_args, stream_bits_args_bytes(), s));
+      if (int rc = stream_bits_init(n, max_text, d_prefix, d_spans, span_cap, d_total, d_ctrl, d_args, s)) return rc;
       ScanTimer tm(s);
-      // multi-walk plans: count, prefix sums, emit -- two one-pass scans whatever the match density (the count pass
-      // keeps no start registers and runs at 3 TB/s; slot rows + a second walk for overflowing texts would be three)
-      mwalk_two_pass = wstep_mwalk && !req_wave && step_split == 0;
-      if (bits_fixed) {
-        // matches of at least four bytes: one pass, spans into slot rows of len / 4 + 32 (they cannot overflow),
-        // gathered behind the prefix sums; shorter ones: count, prefix sums, the pass once more to emit
-        bits_fixed_slots = p.bs_fixed_len >= 4 && span_cap > 0 && !lay.vlen;
-        if (bits_fixed_slots) {
-          int64_t bytes = 0;
-          if (lay.offsets) {
-            HIP_TRY(hipMemcpyAsync(&bytes, lay.offsets + n, sizeof bytes, hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipStreamSynchronize(s));
-          } else {
-            bytes = n * (lay.lens ? lay.stride : (int64_t)lay.len);
-          }
-          lay2.wide_slots = 1;
-          HIP_TRY(scratch_alloc((void**)&d_slots, sizeof(int32_t) * 2 * (size_t)(bytes / 4 + 32 * n + 64), s));
-        }
-        if (int rc = bscan_fixed(h, lay, n, bits_fixed_slots ? 5 : 2, s, d_counts, d_slots, nullptr, 0)) return rc;
-      } else if (step_ok && span_cap > 0 && !wstep_empty && !mwalk_two_pass) {
-        if (req_wave) {
-          // long texts: rows of len / 4 + 32 slots (twice the bytes of the batch) -- the second walk
-          // is then only for texts with a match every 4 bytes
-          int64_t bytes = 0;
-          if (lay.offsets) {
-            HIP_TRY(hipMemcpyAsync(&bytes, lay.offsets + n, sizeof bytes, hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipStreamSynchronize(s));
-          } else {
-            bytes = n * (lay.lens ? lay.stride : (int64_t)lay.len);
-          }
-          lay2.wide_slots = 1;
-          HIP_TRY(scratch_alloc((void**)&d_slots, sizeof(int32_t) * 2 * (size_t)(bytes / 4 + 32 * n + 64), s));
-        } else if (!lay.offsets && step_split == 0 && (lay.lens ? lay.stride : (int64_t)lay.len) >= 2048) {
-          // one lane per text, but texts long enough to hold more than kStepSlots matches as a rule
-          // (rows sized as Layout::slot_row sizes them for lay2 -- the bitset first pass gives it per-text lengths)
-          lay2.wide_slots = 1;
-          HIP_TRY(scratch_alloc((void**)&d_slots,
-                                sizeof(int32_t) * 2 * (size_t)(n * ((lay2.lens ? lay2.stride : (int64_t)lay2.len) / 4 + 32) + 64), s));
-        } else
-        HIP_TRY(scratch_alloc((void**)&d_slots, sizeof(int32_t) * 2 * kStepSlots * (size_t)n, s));
-        if (req_wave)
-          MRX_REQWAVE_LAUNCH(STEP_SLOTS, h, lay2, n, d_counts, (const int64_t*)nullptr, d_slots, (int64_t)0, s);
-        else
-        {
-        MRX_WSTEP_LAUNCH(STEP_SLOTS, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_lds(pk, wstep_mwalk, wstep_bm_big), s, pk,
-                           H_BLOB(h), lay2, n, d_counts, (const int64_t*)nullptr, d_slots, (int64_t)0,
-                           (int32_t*)nullptr, (int32_t*)nullptr);
-        if (step_split > 0)
-          MRX_REQWAVE_LAUNCH(STEP_SLOTS, h, lay2, n, d_counts, (const int64_t*)nullptr, d_slots, (int64_t)0, s);
-        }
-      } else if (step_ok && req_wave)
-        MRX_REQWAVE_LAUNCH(STEP_COUNT, h, lay, n, d_counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0, s);
-      else if (step_ok) {
-        MRX_WSTEP_LAUNCH(STEP_COUNT, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_lds(pk, wstep_mwalk, wstep_bm_big), s, pk,
-                           H_BLOB(h), lay2, n, d_counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0,
-                           (int32_t*)nullptr, (int32_t*)nullptr);
-        if (step_split > 0)
-          MRX_REQWAVE_LAUNCH(STEP_COUNT, h, lay2, n, d_counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0, s);
-      } else {
-        if (p.flags & PF_BT_SEARCH)
-          if (int rc = bt_prepass(h, lay, n, s, &lay_pre)) return rc;
-#define MRX_L(B) hipLaunchKernelGGL((k_findall<FA_COUNT, B>), dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s, \
-                                   p, H_BLOB(h), lay_pre, n, d_counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0)
-        MRX_BT_DISPATCH(bt_kernel_kind(h, plan_uses_backtracker(h)), MRX_L);
-#undef MRX_L
-      }
-      g_last_kernel = bits_fixed ? "k_bscan_fixed" : req_wave ? "k_req_wave" : step_ok ? (wstep_mwalk ? (step_split > 0 ? "k_mwalk+k_req_wave" : "k_mwalk") : wstep_bm ? "k_backscan+k_step_count" : wstep_bits ? "k_bstep_count" : wstep_empty ? "k_estep_count" : step_split > 0 ? "k_step_count+k_req_wave" : "k_step_count")
-                                                        : "k_findall_count";
+      if (int rc = stream_bits_scan(p, H_BLOB(h), lay.data, lay.stride, lay.lens, lay.len, max_text, n, d_args, s)) return rc;
+      g_last_kernel = "k_stream_bits";
+      tm.stop();
+      fused = true;   // (offsets and spans are complete: nothing is left for the launches below)
+    } else
+    if (fused) {
+      // ticket | error | one descriptor per task | two words per group of 64 tasks; a 16-byte multiple
+      const size_t ctrl_words = (size_t)((2 + nw + 2 * ((nw + 63) / 64) + 1) & ~int64_t(1));
+      HIP_TRY(scratch_alloc((void**)&d_ctrl, sizeof(unsigned long long) * ctrl_words, s));   // first: starts its own 256-byte block
+      HIP_TRY(scratch_alloc((void**)&d_recs, sizeof(EvRec) * fz_nrec, s));
+      FusedArgs* d_fz = nullptr;
+      HIP_TRY(scratch_alloc((void**)&d_fz, sizeof(FusedArgs), s));
+      FusedArgs fz;
+      fz.ctrl = d_ctrl; fz.prefix = d_prefix; fz.spans = d_spans; fz.span_cap = span_cap; fz.total_out = d_total;
+      fz.rec_cap = 64 * fz_per_text + env_knobs().fused_skew;
+      fz.debug = env_knobs().fused_debug;
+      hipLaunchKernelGGL(k_fused_init, dim3((unsigned)((ctrl_words + kBlock * 8 - 1) / (kBlock * 8))), dim3(kBlock), 0, s,
+                         d_ctrl, (int64_t)ctrl_words, d_fz, fz);
+      ScanTimer tm(s);
+      launch_stream<ST_FUSED>(h, lay, n, nullptr, nullptr, d_recs, 0, nullptr, nullptr, s, nullptr, nullptr, rec32, d_fz,
+                              (int)fz_grid);
+      g_last_kernel = "k_stream_findall_fused";
       HIP_TRY(hipGetLastError());
       tm.stop();
+    } else if (dyn) {
+      const int64_t nt = (n + kDynTexts - 1) / kDynTexts;
+      HIP_TRY(scratch_alloc((void**)&d_recs, sizeof(EvRec) * (size_t)(csr_total / 16 + 4 * kDynTexts * (nt + 1)), s));
+      HIP_TRY(scratch_alloc((void**)&d_nrecs, sizeof(int32_t) * 2 * nt, s));   // records | matches per task
+      HIP_TRY(scratch_alloc((void**)&d_wbase, sizeof(int64_t) * (nt + 1), s));
+      ScanTimer tm(s);
+      launch_stream_dyn<ST_RECORDS>(h, lay, n, d_counts, d_nrecs, d_recs, nullptr, nullptr, s, rec32);
+      g_last_kernel = "k_stream_findall_dyn";
+      HIP_TRY(hipGetLastError());
+      tm.stop();
+    } else if (g_split_findall && !lay.offsets && strided_fast(lay) && span_cap > 0 && n >= kSplitMinTexts) {
+      split_done = true;
+      if (int rc = findall_split(h, lay, n, d_counts, d_prefix, d_spans, span_cap, d_total, rec_row, rec32, max_text <= 65535, s))
+        return rc;
+    } else {
+    const int64_t skew = g_rec_skew.load(std::memory_order_relaxed);   // (mrx_debug_rec_skew: placement experiments)
+    HIP_TRY(scratch_alloc((void**)&d_recs_alloc, sizeof(EvRec) * nrec + (size_t)skew, s));
+    d_recs = (EvRec*)((uint8_t*)d_recs_alloc + skew);
+    HIP_TRY(scratch_alloc((void**)&d_nrecs, sizeof(int32_t) * 2 * nw, s));  // records | matches per wavefront
+    HIP_TRY(scratch_alloc((void**)&d_wbase, sizeof(int64_t) * (nw + 1), s));
+    ScanTimer tm(s);
+    launch_stream<ST_RECORDS>(h, lay, n, d_counts, d_nrecs, d_recs, rec_row, nullptr, nullptr, s, nullptr, nullptr, rec32);
+    g_last_kernel = "k_stream_findall";
+    HIP_TRY(hipGetLastError());
+    tm.stop();
     }
+    return MRX_OK;
   }
-  if (by_pieces || fused || split_done) {
-    // done over the pieces above / by the one launch / in two halves (findall_split)
-  } else if (stream_ok) {
-    // prefix sums over the wavefronts' totals only (n/64 values); k_decode derives the per-text
+
+  // ... and what turns its records into the CSR: prefix sums over the wavefronts' totals, k_decode
+  int stream_finish() {
+  // prefix sums over the wavefronts' totals only (n/64 values); k_decode derives the per-text
     // offsets from its 64 counts and writes them along with the spans
     const int64_t nw = dyn ? (n + kDynTexts - 1) / kDynTexts : (n + 63) / 64;
     // one launch: tile-local exclusive sums of the wavefront totals + one sum per tile
@@ -5496,72 +5386,264 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
                          d_total);
     HIP_TRY(hipGetLastError());
     HIP_TRY(scratch_free(d_tsum, s));
-  } else if (int rc = device_scan<int32_t>(d_counts, n, d_prefix, d_total, s)) return rc;
-  // Second stage is enqueued before the total is known on the host: both kernels clip
-  // at span_cap, so a too-small buffer is reported (MRX_E_CAPACITY) without overrun and
-  // the whole call needs a single stream synchronisation.
-  if (n > 0 && span_cap > 0) {
-    if (stream_ok) {
-      // spans were written by k_decode above
+    return MRX_OK;
+  }
+
+  // every other plan, first stage: counts (+ slot rows) on the stepper family / the literal restatement
+  int step_scan() {
+  if (step_ok && !wstep_bits && !wstep_empty && !t_in_pieces && !(p.flags & PF_STEP_BIG) && p.st_nsync > 0 &&
+        !(p.flags & PF_STREAMABLE) && span_cap > 0 && (!use_req_route || g_long_text_mode == 1)) {
+      Pieces spc;
+      if (int rc = pieces_prepare(h, lay, n, s, &spc, -1, -1, /*disjoint=*/true, wstep_mwalk)) return rc;
+      if (spc.on && !wstep_mwalk) {   // (a multi-walk plan scans every piece once, dense candidates or not)
+        bool dense = true;
+        if (int rc = dense_candidates(h, lay, n, s, &dense)) return rc;
+        if (!dense)
+          if (int rc = pieces_release(&spc, s)) return rc;
+      }
+      if (spc.on) {
+        int64_t* d_vprefix = nullptr;
+        HIP_TRY(scratch_alloc((void**)&d_vprefix, sizeof(int64_t) * (spc.nv + 1), s));
+        t_in_pieces = true;
+        const int rc = run_findall(h, spc.lay, spc.nv, d_vprefix, d_spans, span_cap, nullptr, s, match_next_sequence);
+        t_in_pieces = false;
+        if (rc != MRX_OK) return rc;
+        const std::string inner = g_last_kernel;
+        hipLaunchKernelGGL(k_virt_prefix, dim3(grid_for(n + 1, kBlock)), dim3(kBlock), 0, s, n, spc.vfirst, d_vprefix, d_prefix);
+        hipLaunchKernelGGL(k_virt_add_base, dim3(grid_for(spc.nv * 64, kBlock)), dim3(kBlock), 0, s, spc.nv, d_vprefix, spc.vbase,
+                           d_spans, span_cap);
+        HIP_TRY(hipGetLastError());
+        static thread_local std::string piece_name;
+        piece_name = inner + "_pieces";
+        g_last_kernel = piece_name.c_str();
+        int rc2 = MRX_OK;
+        if (total) {
+          int64_t tot = 0;
+          HIP_TRY(hipMemcpyAsync(&tot, d_vprefix + spc.nv, sizeof tot, hipMemcpyDeviceToHost, s));
+          HIP_TRY(hipStreamSynchronize(s));
+          *total = tot;
+          if (tot > span_cap) rc2 = fail(MRX_E_CAPACITY, "span buffer too small: need " + std::to_string(tot));
+        }
+        HIP_TRY(scratch_free(d_vprefix, s));
+        if (int rc3 = pieces_release(&spc, s)) return rc3;
+        finished = true;   // the pieces answered the whole call
+        finished_rc = rc2;
+        return MRX_OK;
+      }
+    }
+    if (step_ok && !wstep_bits && !wstep_empty && !t_in_pieces && !wstep_lz) {
+      if (int rc = req_wave_pays(lay, n, use_req_route, s, &req_wave, (p.flags & PF_STEP_BIG) ? nullptr : &step_split,
+                                 (p.flags & PF_STEP_BIG) != 0, wstep_mwalk, backset_on(p) && !wstep_mwalk))
+        return rc;
+      wstep_mwalk_pk = wstep_mwalk && mwalk_pk_ok(lay, t_csr_max_len);
+    }
+    lay2.split = step_split;
+    wstep_bm = step_ok && backset_on(p) && !wstep_mwalk && !wstep_bits && !wstep_empty && !use_req_route && !req_wave &&
+               step_split == 0;
+    wstep_bm_big = wstep_bm && (p.flags & PF_STEP_BIG) != 0;
+    if (wstep_bm) {
+      const int32_t split_keep = lay2.split;
+      if (int rc = backscan_marks(h, lay, n, s, &lay2)) return rc;
+      lay2.split = split_keep;
+    }
+    if (step_ok && !bits_fixed && !wstep_empty && !wstep_mwalk && !wstep_bm && (wstep_bits || (!req_wave && step_split == 0 && !use_req_route && union_pass_for_table_plan(p, false)))) {
+      // union automaton first: texts in which no walk from any start reaches MATCH are not walked at all
+      // (mode 0: a wavefront stops as soon as each of its texts has shown one match end, so on texts full
+      // of matches the pass costs next to nothing; cutting tails -- mode 1 -- would scan everything)
+      if (int rc = bscan_limits(h, lay, n, 0, s, &lay2, &d_blimit)) return rc;
+    }
+    // big tables: only the wavefront kernel has their form; many short texts stay on the literal restatement
+    if ((p.flags & PF_STEP_BIG) && !req_wave && !wstep_mwalk && !wstep_bm) step_ok = false;
+    ScanTimer tm(s);
+    // multi-walk plans: count, prefix sums, emit -- two one-pass scans whatever the match density (the count pass
+    // keeps no start registers and runs at 3 TB/s; slot rows + a second walk for overflowing texts would be three)
+    mwalk_two_pass = wstep_mwalk && !req_wave && step_split == 0;
+    if (bits_fixed) {
+      // matches of at least four bytes: one pass, spans into slot rows of len / 4 + 32 (they cannot overflow),
+      // gathered behind the prefix sums; shorter ones: count, prefix sums, the pass once more to emit
+      bits_fixed_slots = p.bs_fixed_len >= 4 && span_cap > 0 && !lay.vlen;
+      if (bits_fixed_slots) {
+        int64_t bytes = 0;
+        if (lay.offsets) {
+          HIP_TRY(hipMemcpyAsync(&bytes, lay.offsets + n, sizeof bytes, hipMemcpyDeviceToHost, s));
+          HIP_TRY(hipStreamSynchronize(s));
+        } else {
+          bytes = n * (lay.lens ? lay.stride : (int64_t)lay.len);
+        }
+        lay2.wide_slots = 1;
+        HIP_TRY(scratch_alloc((void**)&d_slots, sizeof(int32_t) * 2 * (size_t)(bytes / 4 + 32 * n + 64), s));
+      }
+      if (int rc = bscan_fixed(h, lay, n, bits_fixed_slots ? 5 : 2, s, d_counts, d_slots, nullptr, 0)) return rc;
+    } else if (step_ok && span_cap > 0 && !wstep_empty && !mwalk_two_pass) {
+      if (req_wave) {
+        // long texts: rows of len / 4 + 32 slots (twice the bytes of the batch) -- the second walk
+        // is then only for texts with a match every 4 bytes
+        int64_t bytes = 0;
+        if (lay.offsets) {
+          HIP_TRY(hipMemcpyAsync(&bytes, lay.offsets + n, sizeof bytes, hipMemcpyDeviceToHost, s));
+          HIP_TRY(hipStreamSynchronize(s));
+        } else {
+          bytes = n * (lay.lens ? lay.stride : (int64_t)lay.len);
+        }
+        lay2.wide_slots = 1;
+        HIP_TRY(scratch_alloc((void**)&d_slots, sizeof(int32_t) * 2 * (size_t)(bytes / 4 + 32 * n + 64), s));
+      } else if (!lay.offsets && step_split == 0 && (lay.lens ? lay.stride : (int64_t)lay.len) >= 2048) {
+        // one lane per text, but texts long enough to hold more than kStepSlots matches as a rule
+        // (rows sized as Layout::slot_row sizes them for lay2 -- the bitset first pass gives it per-text lengths)
+        lay2.wide_slots = 1;
+        HIP_TRY(scratch_alloc((void**)&d_slots,
+                              sizeof(int32_t) * 2 * (size_t)(n * ((lay2.lens ? lay2.stride : (int64_t)lay2.len) / 4 + 32) + 64), s));
+      } else
+      HIP_TRY(scratch_alloc((void**)&d_slots, sizeof(int32_t) * 2 * kStepSlots * (size_t)n, s));
+      if (req_wave)
+        MRX_REQWAVE_LAUNCH(STEP_SLOTS, h, lay2, n, d_counts, (const int64_t*)nullptr, d_slots, (int64_t)0, s);
+      else
+      {
+      MRX_WSTEP_LAUNCH(STEP_SLOTS, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_lds(pk, wstep_mwalk, wstep_bm_big), s, pk,
+                         H_BLOB(h), lay2, n, d_counts, (const int64_t*)nullptr, d_slots, (int64_t)0,
+                         (int32_t*)nullptr, (int32_t*)nullptr);
+      if (step_split > 0)
+        MRX_REQWAVE_LAUNCH(STEP_SLOTS, h, lay2, n, d_counts, (const int64_t*)nullptr, d_slots, (int64_t)0, s);
+      }
+    } else if (step_ok && req_wave)
+      MRX_REQWAVE_LAUNCH(STEP_COUNT, h, lay, n, d_counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0, s);
+    else if (step_ok) {
+      MRX_WSTEP_LAUNCH(STEP_COUNT, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_lds(pk, wstep_mwalk, wstep_bm_big), s, pk,
+                         H_BLOB(h), lay2, n, d_counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0,
+                         (int32_t*)nullptr, (int32_t*)nullptr);
+      if (step_split > 0)
+        MRX_REQWAVE_LAUNCH(STEP_COUNT, h, lay2, n, d_counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0, s);
     } else {
-      if (bits_fixed && bits_fixed_slots) {
+      if (p.flags & PF_BT_SEARCH)
+        if (int rc = bt_prepass(h, lay, n, s, &lay_pre)) return rc;
+  #define MRX_L(B) hipLaunchKernelGGL((k_findall<FA_COUNT, B>), dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s, \
+                                 p, H_BLOB(h), lay_pre, n, d_counts, (const int64_t*)nullptr, (int32_t*)nullptr, (int64_t)0)
+      MRX_BT_DISPATCH(bt_kernel_kind(h, plan_uses_backtracker(h)), MRX_L);
+  #undef MRX_L
+    }
+    g_last_kernel = bits_fixed ? "k_bscan_fixed" : req_wave ? "k_req_wave" : step_ok ? (wstep_mwalk ? (step_split > 0 ? "k_mwalk+k_req_wave" : "k_mwalk") : wstep_bm ? "k_backscan+k_step_count" : wstep_bits ? "k_bstep_count" : wstep_empty ? "k_estep_count" : step_split > 0 ? "k_step_count+k_req_wave" : "k_step_count")
+                                                      : "k_findall_count";
+    HIP_TRY(hipGetLastError());
+    tm.stop();
+    return MRX_OK;
+  }
+
+  // ... second stage, behind the prefix sums: spans to their CSR place
+  int step_finish() {
+  if (bits_fixed && bits_fixed_slots) {
+      hipLaunchKernelGGL(k_slots_gather_wide, dim3(grid_for(n * 64, kBlock)), dim3(kBlock), 0, s, lay2, n, d_counts,
+                         d_prefix, d_slots, d_spans, span_cap);
+    } else if (bits_fixed) {   // the union pass once more, texts that hold a match: spans straight to their CSR place
+      if (int rc = bscan_fixed(h, lay, n, 3, s, d_counts, d_spans, d_prefix, span_cap)) return rc;
+    } else if (step_ok && mwalk_two_pass) {   // second scan, texts that hold a match: spans straight to their CSR place
+      Layout lay_e = lay2;
+      lay_e.wide_slots = 2;
+      MRX_WSTEP_LAUNCH(STEP_EMIT, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_lds(pk, wstep_mwalk, wstep_bm_big), s, pk, H_BLOB(h),
+                       lay_e, n, d_counts, d_prefix, d_spans, span_cap, (int32_t*)nullptr, (int32_t*)nullptr);
+    } else if (step_ok && wstep_empty) {   // second walk, every text: spans straight to their CSR place
+      MRX_WSTEP_LAUNCH(STEP_EMIT, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_lds(pk, wstep_mwalk, wstep_bm_big), s, pk, H_BLOB(h),
+                       lay2, n, (int32_t*)nullptr, d_prefix, d_spans, span_cap, (int32_t*)nullptr, (int32_t*)nullptr);
+    } else if (step_ok) {
+      if (lay2.wide_slots)
         hipLaunchKernelGGL(k_slots_gather_wide, dim3(grid_for(n * 64, kBlock)), dim3(kBlock), 0, s, lay2, n, d_counts,
                            d_prefix, d_slots, d_spans, span_cap);
-      } else if (bits_fixed) {   // the union pass once more, texts that hold a match: spans straight to their CSR place
-        if (int rc = bscan_fixed(h, lay, n, 3, s, d_counts, d_spans, d_prefix, span_cap)) return rc;
-      } else if (step_ok && mwalk_two_pass) {   // second scan, texts that hold a match: spans straight to their CSR place
-        Layout lay_e = lay2;
-        lay_e.wide_slots = 2;
-        MRX_WSTEP_LAUNCH(STEP_EMIT, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_lds(pk, wstep_mwalk, wstep_bm_big), s, pk, H_BLOB(h),
-                         lay_e, n, d_counts, d_prefix, d_spans, span_cap, (int32_t*)nullptr, (int32_t*)nullptr);
-      } else if (step_ok && wstep_empty) {   // second walk, every text: spans straight to their CSR place
-        MRX_WSTEP_LAUNCH(STEP_EMIT, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_lds(pk, wstep_mwalk, wstep_bm_big), s, pk, H_BLOB(h),
-                         lay2, n, (int32_t*)nullptr, d_prefix, d_spans, span_cap, (int32_t*)nullptr, (int32_t*)nullptr);
-      } else if (step_ok) {
-        if (lay2.wide_slots)
-          hipLaunchKernelGGL(k_slots_gather_wide, dim3(grid_for(n * 64, kBlock)), dim3(kBlock), 0, s, lay2, n, d_counts,
-                             d_prefix, d_slots, d_spans, span_cap);
-        else
-        hipLaunchKernelGGL(k_slots_gather, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, n, d_counts, d_prefix,
-                           d_slots, d_spans, span_cap);
-        // wavefronts without an overflowing text leave at once
-        if (req_wave)
-          MRX_REQWAVE_LAUNCH(STEP_EMIT, h, lay2, n, d_counts, d_prefix, d_spans, span_cap, s);
-        else {
-        MRX_WSTEP_LAUNCH(STEP_EMIT, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_lds(pk, wstep_mwalk, wstep_bm_big), s, pk, H_BLOB(h),
-                           lay2, n, d_counts, d_prefix, d_spans, span_cap, (int32_t*)nullptr,
-                           (int32_t*)nullptr);
-        if (step_split > 0) MRX_REQWAVE_LAUNCH(STEP_EMIT, h, lay2, n, d_counts, d_prefix, d_spans, span_cap, s);
-        }
-      } else
-#define MRX_L(B) hipLaunchKernelGGL((k_findall<FA_EMIT, B>), dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s, p, \
-                                   H_BLOB(h), lay_pre, n, (int32_t*)nullptr, d_prefix, d_spans, span_cap)
-        MRX_BT_DISPATCH(bt_kernel_kind(h, plan_uses_backtracker(h)), MRX_L);
-#undef MRX_L
-    }
+      else
+      hipLaunchKernelGGL(k_slots_gather, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, n, d_counts, d_prefix,
+                         d_slots, d_spans, span_cap);
+      // wavefronts without an overflowing text leave at once
+      if (req_wave)
+        MRX_REQWAVE_LAUNCH(STEP_EMIT, h, lay2, n, d_counts, d_prefix, d_spans, span_cap, s);
+      else {
+      MRX_WSTEP_LAUNCH(STEP_EMIT, dim3(wstep_grid(n)), dim3(64 * kWsWaves), wstep_lds(pk, wstep_mwalk, wstep_bm_big), s, pk, H_BLOB(h),
+                         lay2, n, d_counts, d_prefix, d_spans, span_cap, (int32_t*)nullptr,
+                         (int32_t*)nullptr);
+      if (step_split > 0) MRX_REQWAVE_LAUNCH(STEP_EMIT, h, lay2, n, d_counts, d_prefix, d_spans, span_cap, s);
+      }
+    } else
+  #define MRX_L(B) hipLaunchKernelGGL((k_findall<FA_EMIT, B>), dim3(grid_for(n, kBlock)), dim3(kBlock), lds_for(h), s, p, \
+                                 H_BLOB(h), lay_pre, n, (int32_t*)nullptr, d_prefix, d_spans, span_cap)
+      MRX_BT_DISPATCH(bt_kernel_kind(h, plan_uses_backtracker(h)), MRX_L);
+  #undef MRX_L
     HIP_TRY(hipGetLastError());
+    return MRX_OK;
   }
+
+  // the total (one stream synchronisation when the caller asked for it)
+  int read_total() {
   int rc = MRX_OK;
-  if (total) {
-    int64_t tot = 0;
-    unsigned long long fused_err = 0;
-    HIP_TRY(hipMemcpyAsync(&tot, d_total, sizeof tot, hipMemcpyDeviceToHost, s));
-    if (d_ctrl) HIP_TRY(hipMemcpyAsync(&fused_err, d_ctrl + 1, sizeof fused_err, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    *total = tot;
-    if (fused_err) return fail(MRX_E_NO_DEVICE, "internal: a wavefront gave up waiting for its predecessors' span counts");
-    if (tot > span_cap) rc = fail(MRX_E_CAPACITY, "span buffer too small: need " + std::to_string(tot));
-  }  // total == NULL: fully asynchronous; d_counts_prefix[n] holds the total when the stream drains
-  HIP_TRY(scratch_free(d_counts, s));
-  HIP_TRY(scratch_free(d_total, s));
-  if (d_ctrl) { HIP_TRY(scratch_free(d_ctrl, s)); HIP_TRY(scratch_free(d_ctrl, s)); }   // ctrl block and the argument copy
-  if (d_recs_alloc) HIP_TRY(scratch_free(d_recs_alloc, s));
-  else if (d_recs) HIP_TRY(scratch_free(d_recs, s));
-  if (d_nrecs) HIP_TRY(scratch_free(d_nrecs, s));
-  if (d_wbase) HIP_TRY(scratch_free(d_wbase, s));
-  if (d_slots) HIP_TRY(scratch_free(d_slots, s));
-  if (d_blimit) HIP_TRY(scratch_free(d_blimit, s));
-  return rc;
+    if (total) {
+      int64_t tot = 0;
+      unsigned long long fused_err = 0;
+      HIP_TRY(hipMemcpyAsync(&tot, d_total, sizeof tot, hipMemcpyDeviceToHost, s));
+      if (d_ctrl) HIP_TRY(hipMemcpyAsync(&fused_err, d_ctrl + 1, sizeof fused_err, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      *total = tot;
+      if (fused_err) return fail(MRX_E_NO_DEVICE, "internal: a wavefront gave up waiting for its predecessors' span counts");
+      if (tot > span_cap) rc = fail(MRX_E_CAPACITY, "span buffer too small: need " + std::to_string(tot));
+    }  // total == NULL: fully asynchronous; d_counts_prefix[n] holds the total when the stream drains
+    HIP_TRY(scratch_free(d_counts, s));
+    HIP_TRY(scratch_free(d_total, s));
+    if (d_ctrl) { HIP_TRY(scratch_free(d_ctrl, s)); HIP_TRY(scratch_free(d_ctrl, s)); }   // ctrl block and the argument copy
+    if (d_recs_alloc) HIP_TRY(scratch_free(d_recs_alloc, s));
+    else if (d_recs) HIP_TRY(scratch_free(d_recs, s));
+    if (d_nrecs) HIP_TRY(scratch_free(d_nrecs, s));
+    if (d_wbase) HIP_TRY(scratch_free(d_wbase, s));
+    if (d_slots) HIP_TRY(scratch_free(d_slots, s));
+    if (d_blimit) HIP_TRY(scratch_free(d_blimit, s));
+    return rc;
+  }
+
+  int run() {
+    HIP_TRY(scratch_alloc((void**)&d_counts, sizeof(int32_t) * (n > 0 ? n : 1), s));
+    HIP_TRY(scratch_alloc((void**)&d_total, sizeof(int64_t), s));
+    if (n > 0 && anchored_at_zero(h) && stream_layout_ok(lay, n)) return anchored();
+    choose_route();
+  if (n > 0 && stream_ok && lay.offsets) {
+      if (known_total >= 0) { csr_total = known_total; csr_max = known_max; }   // the caller (sub) has read them
+      else if (int rc = csr_stats(lay, n, s, &csr_total, &csr_max)) return rc;
+      if (csr_total < 0) return fail(MRX_E_ARGUMENT, "offsets[n] is negative");
+    }
+    // An event record counts the matches of its text in front of it in 26 bits (kRecBeforeMask), and a
+    // text of 2^26 bytes can hold that many (one-byte matches, no synchronising byte to cut at): such
+    // texts take the lane-per-text kernels, whose span cursor is 64 bits wide.
+    if (stream_ok && stream_text_too_long(lay.offsets ? csr_max : (lay.lens ? lay.stride : (int64_t)lay.len)))
+      stream_ok = false;
+    if (n > 0 && stream_ok)
+      if (int rc = pieces_prepare(h, lay, n, s, &pc, csr_total, csr_max)) return rc;
+    by_pieces = pc.on;
+    if (pc.on) {
+      if (int rc = findall_pieces(h, pc, n, d_prefix, d_spans, span_cap, d_total, s)) return rc;
+      if (int rc = pieces_release(&pc, s)) return rc;
+    } else if (n > 0) {
+      if (int rc = stream_ok ? stream_scan() : step_scan()) return rc;
+      if (finished) return finished_rc;
+    }
+    if (by_pieces || fused || split_done) {
+      // done over the pieces above / by the one launch / in two halves (findall_split)
+    } else if (stream_ok) {
+      if (int rc = stream_finish()) return rc;
+    } else if (int rc = device_scan<int32_t>(d_counts, n, d_prefix, d_total, s)) return rc;
+    // Second stage is enqueued before the total is known on the host: both kernels clip
+    // at span_cap, so a too-small buffer is reported (MRX_E_CAPACITY) without overrun and
+    // the whole call needs a single stream synchronisation.
+    if (n > 0 && span_cap > 0 && !stream_ok)
+      if (int rc = step_finish()) return rc;
+    return read_total();
+  }
+  int finished_rc = MRX_OK;
+};
+
+int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_prefix, int32_t* d_spans, int64_t span_cap,
+                int64_t* total, void* stream, bool match_next_sequence, int64_t known_total, int64_t known_max) {
+  ScratchScope scratch_scope_((hipStream_t)stream);
+  if (!h) return fail(MRX_E_ARGUMENT, "null handle");
+  if (n < 0 || span_cap < 0) return fail(MRX_E_ARGUMENT, "negative size");
+  if ((uintptr_t)d_spans & 7) return fail(MRX_E_ARGUMENT, "d_spans must be 8-byte aligned");
+  if (int rc = check_search_supported(h)) return rc;
+  if (int rc = check_lds(h)) return rc;
+  if (int rc = ensure_device(h)) return rc;
+  FindallJob job(h, lay, n, d_prefix, d_spans, span_cap, total, (hipStream_t)stream, match_next_sequence, known_total, known_max);
+  return job.run();
 }
 
 }  // namespace

@@ -58,5 +58,16 @@ traffic = {
     "correction": "FETCH_SIZE x2 (gfx950 wide coalesced streaming read), WRITE_SIZE exact; "
                   "separate --pmc passes (tools/pmc_pass.sh)",
 }
+# round 4: the whole findall STEP, not only its dominant kernel -- scan + decode, same correction
+d = summary.get("k_decode", {})
+if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+    d_fetch, d_write = d["FETCH_SIZE"] * 1024.0, d["WRITE_SIZE"] * 1024.0
+    traffic["step"] = {
+        "k_stream_findall_bytes": 2.0 * fetch_raw + write,
+        "k_decode_fetch_size_raw_bytes": d_fetch, "k_decode_write_size_bytes": d_write,
+        "k_decode_bytes": 2.0 * d_fetch + d_write,
+        "step_bytes": 2.0 * fetch_raw + write + 2.0 * d_fetch + d_write,
+        "note": "scan + decode (the prefix-sum launch between them moves 0.2 MB); FETCH_SIZE x2 + WRITE_SIZE per kernel",
+    }
 json.dump(traffic, open(os.path.join(out, "%s_traffic.json" % rnd), "w"), indent=1, sort_keys=True)
 print(json.dumps(traffic))
