@@ -3229,18 +3229,56 @@ __global__ __launch_bounds__(kBlock) void k_candidate_density(DevPlan p, const u
   for (int off = 32; off > 0; off >>= 1) k += __shfl_xor(k, off);
   if ((threadIdx.x & 63) == 0 && k) atomicAdd(hits, k);
 }
-// spans of piece v are piece-relative: make them text-relative (stepper plans, whose kernels know nothing of pieces)
+// spans of piece v are piece-relative: make them text-relative (stepper plans, whose kernels know nothing of pieces).
+// One lane per SPAN (round 4; a wavefront per piece before: 131 K pieces of a few spans each took 167 us for 7 M spans
+// on the reference's phone texts -- a quarter of the call): a workgroup takes 1024 consecutive spans, finds the pieces
+// that hold the first and the last of them by bisection of the piece offsets (once, wavefront 0), and every lane bisects
+// within that short range (the lines are the workgroup's own: L1 / L2 hits).
 __global__ __launch_bounds__(kBlock) void k_virt_add_base(int64_t nv, const int64_t* __restrict__ vprefix,
                                                           const int32_t* __restrict__ vbase, int32_t* __restrict__ spans,
                                                           int64_t span_cap) {
-  // one wavefront per piece: its spans are contiguous
-  const int lane = threadIdx.x & 63;
-  for (int64_t v = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; v < nv; v += ((int64_t)gridDim.x * blockDim.x) >> 6) {
-    const int b = vbase[v];
-    if (b == 0) continue;
-    int64_t a = vprefix[v], e = vprefix[v + 1];
-    if (e > span_cap) e = span_cap;
-    for (int64_t k = a + lane; k < e; k += 64) { spans[2 * k] += b; spans[2 * k + 1] += b; }
+  __shared__ int64_t range[2];
+  const int64_t total = vprefix[nv] < span_cap ? vprefix[nv] : span_cap;
+  constexpr int kPer = 4;
+  for (int64_t k0 = (int64_t)blockIdx.x * kBlock * kPer; k0 < total; k0 += (int64_t)gridDim.x * kBlock * kPer) {
+    const int64_t k1 = k0 + kBlock * kPer - 1 < total - 1 ? k0 + kBlock * kPer - 1 : total - 1;
+    __syncthreads();
+    if (threadIdx.x < 128) {   // the last piece v with vprefix[v] <= k: wavefront 0 for k0, wavefront 1 for k1,
+      // 64 probes per round trip (a plain bisection is 17 dependent loads: the latency of this kernel)
+      const int lane = threadIdx.x & 63;
+      const int64_t k = threadIdx.x < 64 ? k0 : k1;
+      int64_t lo = 0, hi = nv;   // invariant: vprefix[lo] <= k < vprefix[hi] (vprefix[nv] = all spans > k)
+      while (hi - lo > 1) {
+        const int64_t step = (hi - lo + 63) >> 6;
+        const int64_t probe = lo + (int64_t)(lane + 1) * step;   // lane's probe; beyond hi: "greater"
+        const bool le = probe < hi && vprefix[probe] <= k;
+        const uint64_t m = __ballot(le);
+        const int cnt = __builtin_popcountll(m);   // probes are increasing, so the lanes that answer "<=" are a prefix
+        const int64_t nlo = lo + (int64_t)cnt * step;
+        const int64_t nhi = lo + (int64_t)(cnt + 1) * step;
+        lo = nlo < hi ? nlo : lo;
+        hi = nhi < hi ? nhi : hi;
+      }
+      if (lane == 0) range[threadIdx.x >> 6] = lo;
+    }
+    __syncthreads();
+    const int64_t v_lo = range[0], v_hi = range[1];
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+      const int64_t k = k0 + (int64_t)j * kBlock + threadIdx.x;
+      if (k > k1) break;
+      int64_t lo = v_lo, hi = v_hi + 1;
+      while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (vprefix[mid] <= k) lo = mid; else hi = mid;
+      }
+      const int b = vbase[lo];
+      if (b != 0) {
+        int2 sp = *(int2*)(spans + 2 * k);
+        sp.x += b; sp.y += b;
+        *(int2*)(spans + 2 * k) = sp;
+      }
+    }
   }
 }
 // per-text entries of the per-piece prefix sums / counts
@@ -4011,6 +4049,21 @@ struct mrx_handle {
   // sub: matches per KiB of input the last batch held (0 = nothing seen yet): sizes the span buffer of the next
   // call so that a dense batch (more than one match per eight bytes) does not scan twice every time
   mutable std::atomic<int64_t> sub_matches_per_kib{0};
+  // findall of a required-byte plan on long texts: the wavefront-per-text kernel or pieces on the multi-walk kernel?
+  // Neither candidate density nor batch shape predicts it (profiles/r04_suite_routes.md), so the first two calls of a
+  // batch shape try each route (see ReqTune) and the faster one is kept.
+  // Four measured calls per batch shape: each route once untimed (its scratch gets allocated), then each route timed --
+  // two HIP events on the caller's stream around the call's work, read by a LATER call of the shape once the last pair
+  // has completed: no call ever waits for the tuner, and callers that enqueue back to back are served as well.
+  struct ReqTune {
+    int issued = 0, choice = 0;   // calls measured so far (0..4); choice: 1 wavefront kernel, 2 pieces
+    bool probed = false;
+    float ms_wave = 0, ms_pieces = 0;
+    hipEvent_t ev[4][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
+    int dev = 0;                  // device the events belong to (part of the key)
+  };
+  mutable std::mutex tune_mu;
+  mutable std::map<uint32_t, ReqTune> req_tune;
   mrx_handle() { for (auto& b : d_blobs) b.store(nullptr, std::memory_order_relaxed); }
 };
 
@@ -5138,6 +5191,43 @@ static int dense_candidates(const mrx_handle* h, const Layout& lay, int64_t n, h
   *dense = (double)hits >= 0.08 * (double)bytes;
   return MRX_OK;
 }
+// share of the bytes of the batch's first MiB that are synchronising bytes of the plan (DevPlan::off_st_sync): pieces are
+// cut at those, and a text without them (timestamps for a timestamp pattern) is cut nowhere -- every piece then reaches
+// back to the text's start (measured: datetime_quantifiers 1.1 ms on the wavefront kernel, 17 ms in "pieces")
+__global__ __launch_bounds__(kBlock) void k_sync_density(const uint8_t* __restrict__ sync, const uint8_t* __restrict__ data,
+                                                         int64_t nbytes, unsigned int* __restrict__ hits) {
+  __shared__ uint8_t tab[256];
+  for (int b = threadIdx.x; b < 256; b += blockDim.x) tab[b] = sync[b] ? 1 : 0;
+  __syncthreads();
+  unsigned int k = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nbytes; i += (int64_t)gridDim.x * blockDim.x) k += tab[data[i]];
+  for (int off = 32; off > 0; off >>= 1) k += __shfl_xor(k, off);
+  if ((threadIdx.x & 63) == 0 && k) atomicAdd(hits, k);
+}
+static int sync_bytes_frequent(const mrx_handle* h, const Layout& lay, int64_t n, hipStream_t s, bool* frequent) {
+  *frequent = false;
+  const DevPlan& p = h->hp.dev;
+  if (p.st_nsync <= 0 || p.off_st_sync < 0) return MRX_OK;
+  int64_t bytes = 0;
+  if (lay.offsets) {
+    HIP_TRY(hipMemcpyAsync(&bytes, lay.offsets + n, sizeof bytes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+  } else {
+    bytes = n * lay.stride;
+  }
+  if (bytes > (1 << 20)) bytes = 1 << 20;
+  if (bytes <= 0) return MRX_OK;
+  unsigned int* d_hits = nullptr;
+  unsigned int hits = 0;
+  HIP_TRY(scratch_alloc((void**)&d_hits, sizeof(unsigned int), s));
+  HIP_TRY(hipMemsetAsync(d_hits, 0, sizeof(unsigned int), s));
+  hipLaunchKernelGGL(k_sync_density, dim3(256), dim3(kBlock), 0, s, H_BLOB(h) + p.off_st_sync, lay.data, bytes, d_hits);
+  HIP_TRY(hipMemcpyAsync(&hits, d_hits, sizeof hits, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  *frequent = (double)hits >= 0.015 * (double)bytes;   // one at least every 64 bytes or so
+  return MRX_OK;
+}
+
 int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_prefix, int32_t* d_spans, int64_t span_cap,
                 int64_t* total, void* stream, bool match_next_sequence = false, int64_t known_total = -1, int64_t known_max = -1);
 
@@ -5190,6 +5280,9 @@ struct FindallJob {
   int64_t csr_total = -1, csr_max = -1;   // CSR batches on the streaming path: byte count and longest text
   bool by_pieces = false;
   bool finished = false;           // a route that answered the whole call by itself (the stepper's pieces)
+  // required-byte plan on long texts: the route being timed for the handle's tuner (0: none), and when the call began
+  int tune_route = 0, tune_slot = 0;
+  uint32_t tune_key = 0;
 
   FindallJob(const mrx_handle* h_, const Layout& lay_, int64_t n_, int64_t* d_prefix_, int32_t* d_spans_, int64_t span_cap_,
              int64_t* total_, hipStream_t s_, bool mns, int64_t kt, int64_t km)
@@ -5389,12 +5482,80 @@ struct FindallJob {
     return MRX_OK;
   }
 
+  // ---- required-byte plan on long texts: which route?  (mrx_handle::req_tune) ----
+  // First call of a batch shape: are the plan's synchronising bytes frequent in the text at all (one small kernel, one
+  // 4-byte read-back; else: the wavefront kernel, for good).  Then four measured calls (mrx_handle::ReqTune), and the
+  // faster route from the first call that finds the last measurement complete.
+  int req_route_tuner(bool* pieces) {
+    *pieces = false;
+    const int64_t bytes_per_text = lay.offsets ? 0 : (lay.lens ? lay.stride : (int64_t)lay.len);
+    uint32_t lb = 0, nb = 0;
+    for (int64_t v = bytes_per_text; v > 1; v >>= 1) ++lb;
+    for (int64_t v = n; v > 1; v >>= 1) ++nb;
+    tune_key = (lay.offsets ? 1u << 31 : 0u) | ((uint32_t)(t_dev & 63) << 16) | (lb << 8) | nb;
+    bool probe = false;
+    {
+      std::lock_guard<std::mutex> lk(h->tune_mu);
+      mrx_handle::ReqTune& t = h->req_tune[tune_key];
+      if (t.choice) { *pieces = t.choice == 2; return MRX_OK; }
+      if (t.issued == 4) {   // all four are enqueued: through?
+        if (hipEventQuery(t.ev[3][1]) != hipSuccess) return MRX_OK;   // not yet: the default route, unmeasured
+        if (hipEventElapsedTime(&t.ms_wave, t.ev[2][0], t.ev[2][1]) != hipSuccess ||
+            hipEventElapsedTime(&t.ms_pieces, t.ev[3][0], t.ev[3][1]) != hipSuccess) { t.choice = 1; return MRX_OK; }
+        t.choice = t.ms_pieces < t.ms_wave ? 2 : 1;
+        static const bool verbose = getenv("MRX_TUNE_VERBOSE") != nullptr;
+        if (verbose) fprintf(stderr, "mrx: required-byte route of '%s' (key %08x): wavefront %.3f ms, pieces %.3f ms -> %s\n",
+                             h->hp.pattern.c_str(), tune_key, t.ms_wave, t.ms_pieces, t.choice == 2 ? "pieces" : "wavefront");
+        *pieces = t.choice == 2;
+        return MRX_OK;
+      }
+      probe = !t.probed;
+      t.probed = true;
+    }
+    if (probe) {
+      bool freq = false;
+      if (int rc = sync_bytes_frequent(h, lay, n, s, &freq)) return rc;
+      std::lock_guard<std::mutex> lk(h->tune_mu);
+      mrx_handle::ReqTune& t = h->req_tune[tune_key];
+      if (!freq) { t.choice = 1; return MRX_OK; }
+      t.dev = t_dev;
+      for (auto& pr : t.ev)
+        for (auto& e : pr)
+          if (hipEventCreate(&e) != hipSuccess) { t.choice = 1; return MRX_OK; }
+    }
+    std::lock_guard<std::mutex> lk(h->tune_mu);
+    mrx_handle::ReqTune& t = h->req_tune[tune_key];
+    if (t.choice || t.issued >= 4 || !t.ev[3][1]) return MRX_OK;   // (another thread got here first, or is still probing)
+    tune_slot = t.issued++;
+    tune_route = (tune_slot & 1) ? 2 : 1;
+    *pieces = tune_route == 2;
+    HIP_TRY(hipEventRecord(t.ev[tune_slot][0], s));
+    return MRX_OK;
+  }
+  void req_tuner_unavailable() {   // nothing to cut: the wavefront kernel it is
+    std::lock_guard<std::mutex> lk(h->tune_mu);
+    h->req_tune[tune_key].choice = 1;
+    tune_route = 0;
+  }
+  void req_tuner_report() {   // the call's work is enqueued: close the measurement
+    if (!tune_route) return;
+    std::lock_guard<std::mutex> lk(h->tune_mu);
+    mrx_handle::ReqTune& t = h->req_tune[tune_key];
+    if (t.ev[tune_slot][1]) (void)hipEventRecord(t.ev[tune_slot][1], s);
+    tune_route = 0;
+  }
+
   // every other plan, first stage: counts (+ slot rows) on the stepper family / the literal restatement
   int step_scan() {
-  if (step_ok && !wstep_bits && !wstep_empty && !t_in_pieces && !(p.flags & PF_STEP_BIG) && p.st_nsync > 0 &&
-        !(p.flags & PF_STREAMABLE) && span_cap > 0 && (!use_req_route || g_long_text_mode == 1)) {
+  bool req_pieces = false;   // required-byte plan: pieces on the multi-walk kernel instead of the wavefront-per-text kernel
+    if (use_req_route && mwalk_req && g_long_text_mode == 0 && !t_in_pieces && p.st_nsync > 0 && span_cap > 0 &&
+        !(p.flags & (PF_STEP_BIG | PF_STREAMABLE)))
+      if (int rc = req_route_tuner(&req_pieces)) return rc;
+    if (step_ok && !wstep_bits && !wstep_empty && !t_in_pieces && !(p.flags & PF_STEP_BIG) && p.st_nsync > 0 &&
+        !(p.flags & PF_STREAMABLE) && span_cap > 0 && (!use_req_route || g_long_text_mode == 1 || req_pieces)) {
       Pieces spc;
       if (int rc = pieces_prepare(h, lay, n, s, &spc, -1, -1, /*disjoint=*/true, wstep_mwalk)) return rc;
+      if (req_pieces && !spc.on) req_tuner_unavailable();   // nothing to cut (texts too short, too many of them): the wavefront kernel it is
       if (spc.on && !wstep_mwalk) {   // (a multi-walk plan scans every piece once, dense candidates or not)
         bool dense = true;
         if (int rc = dense_candidates(h, lay, n, s, &dense)) return rc;
@@ -5410,12 +5571,13 @@ struct FindallJob {
         if (rc != MRX_OK) return rc;
         const std::string inner = g_last_kernel;
         hipLaunchKernelGGL(k_virt_prefix, dim3(grid_for(n + 1, kBlock)), dim3(kBlock), 0, s, n, spc.vfirst, d_vprefix, d_prefix);
-        hipLaunchKernelGGL(k_virt_add_base, dim3(grid_for(spc.nv * 64, kBlock)), dim3(kBlock), 0, s, spc.nv, d_vprefix, spc.vbase,
+        hipLaunchKernelGGL(k_virt_add_base, dim3(grid_cap()), dim3(kBlock), 0, s, spc.nv, d_vprefix, spc.vbase,
                            d_spans, span_cap);
         HIP_TRY(hipGetLastError());
         static thread_local std::string piece_name;
         piece_name = inner + "_pieces";
         g_last_kernel = piece_name.c_str();
+        req_tuner_report();
         int rc2 = MRX_OK;
         if (total) {
           int64_t tot = 0;
@@ -5570,6 +5732,7 @@ struct FindallJob {
 
   // the total (one stream synchronisation when the caller asked for it)
   int read_total() {
+    req_tuner_report();
   int rc = MRX_OK;
     if (total) {
       int64_t tot = 0;
@@ -5873,6 +6036,12 @@ void mrx_free(mrx_handle* h) {
   (void)hipGetDevice(&cur);
   for (int d = 0; d < kMaxDevices; ++d)
     if (uint8_t* p = h->d_blobs[d].load()) { (void)hipSetDevice(d); (void)hipFree(p); }
+  for (auto& kv : h->req_tune) {   // the route tuner's events
+    (void)hipSetDevice(kv.second.dev);
+    for (auto& pr : kv.second.ev)
+      for (auto& e : pr)
+        if (e) (void)hipEventDestroy(e);
+  }
   (void)hipSetDevice(cur);
   delete h;
 }

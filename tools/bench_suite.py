@@ -23,6 +23,7 @@ from mojo_regex_amd.api import UnsupportedPattern  # noqa: E402
 
 TARGET_BYTES = 256 << 20
 REPS = 5
+WARM = 6   # untimed calls (round 4: the required-byte route tuner has settled by then: two routes untimed, two timed, one to read the events)
 
 
 def make_batch(text: bytes, csr: bool):
@@ -46,8 +47,9 @@ def main():
     lib = M.load_library()
     lib.mrx_debug_long_text_kernels(int(os.environ.get("MRX_LONG_TEXT_MODE", "0")))   # 1 always, 2 never (A/B runs)
     only = sys.argv[1] if len(sys.argv) > 1 else ""
+    ops = os.environ.get("MRX_SUITE_OPS", "")   # e.g. "findall": only the cases of these operations
     for case in B.CASES:
-        if not case.name.startswith(only):
+        if not case.name.startswith(only) or (ops and case.op not in ops.split(",")):
             continue
         row = {"case": case.name, "op": case.op, "pattern": case.pattern.decode()[:60], "text_bytes": len(case.text)}
         rx = M.compile_regex(case.pattern)
@@ -70,7 +72,7 @@ def main():
             else:
                 cap = n * (2 * L + 64)
                 fn = lambda: rx.sub_dev(case.repl, batch, case.count, out_cap=cap)  # noqa: E731
-            for _ in range(3):   # the per-stream scratch arena settles within two calls of a new shape
+            for _ in range(WARM):   # the per-stream scratch arena settles within two calls of a new shape, the route tuner within five
                 fn()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
