@@ -57,6 +57,9 @@ struct Layout {  // where text i lives
   // data + offsets[i] (offsets need not be contiguous); nullptr = plain CSR
   const int32_t* vlen = nullptr;
   const uint32_t* vskip = nullptr;   // with vlen: the per-text word k_stream_findall's VIRT form expects
+  // k_mwalk<STEP_SLOTS / STEP_EMIT> only: text i is a piece of a longer text and its spans are reported as positions
+  // of that text, vbase[i] + position in the piece (FindallJob::step_scan's pieces); nullptr = as found
+  const int32_t* vbase = nullptr;
   // per text: first occurrence of the backtracking matcher's literal, last occurrence << 1 | has-newline
   // (k_litscan in front of the lane-per-text kernels, see bt_prepass()); nullptr = not computed
   const int2* pre = nullptr;
@@ -775,9 +778,10 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_mwalk(DevPlan p, const uint8_
     int2* const orow = (int2*)spans + (MODE == STEP_SLOTS ? slot0 : wo);
     const int64_t room64 = MODE == STEP_SLOTS ? (int64_t)slot_cap : span_cap - wo;
     const int oroom = room64 < 0 ? 0 : room64 > 0x7FFFFFFF ? 0x7FFFFFFF : (int)room64;
+    const int vb = ((MODE == STEP_EMIT || MODE == STEP_SLOTS) && lay.vbase && live) ? lay.vbase[i] : 0;
     auto report = [&](int a, int b) {
       if (MODE == STEP_EMIT || MODE == STEP_SLOTS) {
-        if (k < oroom) orow[k] = make_int2(a, b);
+        if (k < oroom) orow[k] = make_int2(a + vb, b + vb);
       }
       if (MODE == STEP_SEARCH) { rs = a; re = b; fin = true; }
       if (MODE == STEP_ANY) fin = true;
@@ -5164,6 +5168,10 @@ static int findall_split(const mrx_handle* h, const Layout& lay, int64_t n, int3
 // texts of their own with one lane each -- where the wavefront-per-text kernel pays for its busiest lane and for the
 // walks it repeats.  The recursion runs with t_in_pieces set: the batch of pieces is a view, not a CSR batch.
 thread_local bool t_in_pieces = false;
+// findall by pieces: the pieces' bases, for an inner route whose emit kernel can add them itself (k_mwalk), and whether
+// it did -- otherwise k_virt_add_base goes over the spans once more
+thread_local const int32_t* t_piece_vbase = nullptr;
+thread_local bool t_piece_base_applied = false;
 // plain-route stepper plan on long texts: pieces (true) or the wavefront kernel (false)?  Decided by the share of
 // bytes that can begin a walk in the first MiB of the batch (one small kernel, one 4-byte read-back): measured on the
 // reference's list, dense candidates (phone numbers everywhere: 30 %) are where one lane per piece wins (1.57 -> 0.84
@@ -5566,13 +5574,17 @@ struct FindallJob {
         int64_t* d_vprefix = nullptr;
         HIP_TRY(scratch_alloc((void**)&d_vprefix, sizeof(int64_t) * (spc.nv + 1), s));
         t_in_pieces = true;
+        t_piece_vbase = spc.vbase;
+        t_piece_base_applied = false;
         const int rc = run_findall(h, spc.lay, spc.nv, d_vprefix, d_spans, span_cap, nullptr, s, match_next_sequence);
         t_in_pieces = false;
+        t_piece_vbase = nullptr;
         if (rc != MRX_OK) return rc;
         const std::string inner = g_last_kernel;
         hipLaunchKernelGGL(k_virt_prefix, dim3(grid_for(n + 1, kBlock)), dim3(kBlock), 0, s, n, spc.vfirst, d_vprefix, d_prefix);
-        hipLaunchKernelGGL(k_virt_add_base, dim3(grid_cap()), dim3(kBlock), 0, s, spc.nv, d_vprefix, spc.vbase,
-                           d_spans, span_cap);
+        if (!t_piece_base_applied)
+          hipLaunchKernelGGL(k_virt_add_base, dim3(grid_cap()), dim3(kBlock), 0, s, spc.nv, d_vprefix, spc.vbase,
+                             d_spans, span_cap);
         HIP_TRY(hipGetLastError());
         static thread_local std::string piece_name;
         piece_name = inner + "_pieces";
@@ -5620,6 +5632,10 @@ struct FindallJob {
     // multi-walk plans: count, prefix sums, emit -- two one-pass scans whatever the match density (the count pass
     // keeps no start registers and runs at 3 TB/s; slot rows + a second walk for overflowing texts would be three)
     mwalk_two_pass = wstep_mwalk && !req_wave && step_split == 0;
+    if (mwalk_two_pass && t_in_pieces && t_piece_vbase) {   // every span of this call leaves k_mwalk<STEP_EMIT>
+      lay2.vbase = t_piece_vbase;
+      t_piece_base_applied = true;
+    }
     if (bits_fixed) {
       // matches of at least four bytes: one pass, spans into slot rows of len / 4 + 32 (they cannot overflow),
       // gathered behind the prefix sums; shorter ones: count, prefix sums, the pass once more to emit
