@@ -3566,7 +3566,9 @@ __global__ __launch_bounds__(kBlock) void k_subs_emit(int64_t n, const uint8_t* 
                                                       const int64_t* __restrict__ out_off,
                                                       uint8_t* __restrict__ out, int skip_g,
                                                       const int32_t* __restrict__ left) {
-  if (skip_g && *left == 0) return;   // k_subs_wave<skip_g> took every text
+  // `left`: k_subs_wave<skip_g> in front took every text (skip_g != 0), or the host's go-ahead behind the totals
+  // (k_subs_gate: the kernel is enqueued before the host has seen them) says no
+  if (left && *left == 0) return;
   // kSubsLanes lanes share one text (4 texts per wavefront): a 1 KiB text has ~70 output blocks,
   // which 64 lanes cover in two half-empty rounds; 16 lanes cover them in five full ones, and the
   // four texts' dependent round trips (offsets -> spans -> bytes) overlap.
@@ -3719,7 +3721,9 @@ __global__ __launch_bounds__(kBlock) void k_subs_wave(int64_t n, const uint8_t* 
                                                       const int32_t* __restrict__ spans, long long count,
                                                       int R, const uint16_t* __restrict__ rmap,
                                                       const int64_t* __restrict__ out_off,
-                                                      uint8_t* __restrict__ out, int32_t* __restrict__ left) {
+                                                      uint8_t* __restrict__ out, int32_t* __restrict__ left,
+                                                      const int32_t* __restrict__ go, int dbg) {
+  if (*go == 0) return;   // k_subs_gate: the spans or the output do not fit (the host finds out behind this launch)
   constexpr int NG = kBlock / G, F = 32 * G + 16, O = 64 * G, BW = F / 32 + 1;
   static_assert(G == 256 || G == 64 || G == 32 || G == 16, "group = workgroup, wavefront, half or quarter of one");
   constexpr bool BLK = G > 64;   // the workgroup shares one text: barriers instead of wavefront order, prefix
@@ -3732,7 +3736,7 @@ __global__ __launch_bounds__(kBlock) void k_subs_wave(int64_t n, const uint8_t* 
   __shared__ int xw_all[3][BLK ? kBlock / 64 : 1];   // BLK: per-wavefront totals of the three prefix sums
   extern __shared__ __align__(16) uint8_t subs_dyn[];   // the replacement map (R u16 entries)
   uint16_t* rmap_lds = (uint16_t*)subs_dyn;
-  for (int r = threadIdx.x; r < R; r += blockDim.x) rmap_lds[r] = rmap[r];
+  for (int r = threadIdx.x; r < R + 8; r += blockDim.x) rmap_lds[r] = r < R ? rmap[r] : (uint16_t)0;
   __syncthreads();
   auto group_sync = [&]() {
     if (BLK) { __syncthreads(); return; }
@@ -3842,7 +3846,7 @@ __global__ __launch_bounds__(kBlock) void k_subs_wave(int64_t n, const uint8_t* 
     group_sync();
     // ---- matches: boundary bits, replacement bytes
     int carry = 0;
-    for (int m0 = 0; m0 < k; m0 += G) {
+    for (int m0 = 0; m0 < ((dbg & 16) ? 0 : k); m0 += G) {
       const int m = m0 + lane;
       int ms = 0, me = 0;
       if (m < k) {
@@ -3859,16 +3863,24 @@ __global__ __launch_bounds__(kBlock) void k_subs_wave(int64_t n, const uint8_t* 
         atomicOr(&ebits[(mis + me) >> 5], 1u << ((mis + me) & 31));
         uint8_t* dst = otile + (head + ms - before + m * R);
         const uint8_t* msrc = text + mis + ms;
-        for (int t = 0; t < R; ++t) {
-          const uint32_t r = rmap_lds[t];
-          dst[t] = (r & 0x8000u) ? msrc[r & 0x7FFFu] : (uint8_t)r;
+        // four bytes a round: the map entries (one address for every lane) and the match bytes they name are read
+        // together -- a byte at a time the loop waits for two dependent LDS reads per replacement byte
+        for (int t = 0; t < ((dbg & 1) ? 0 : R); t += 4) {
+          uint32_t r[4], v[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) r[q] = rmap_lds[t + q];   // (the map is padded with eight zero entries)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = msrc[(r[q] & 0x8000u) ? (r[q] & 0x7FFFu) : 0u];
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (t + q < R) dst[t + q] = (r[q] & 0x8000u) ? (uint8_t)v[q] : (uint8_t)r[q];
         }
       }
     }
     group_sync();
     // ---- frame blocks: kept bytes
     int kept_carry = 0, starts_carry = 0, inside_carry = 0;
-    for (int b0 = 0; b0 < nfb; b0 += G) {
+    for (int b0 = 0; b0 < ((dbg & 8) ? 0 : nfb); b0 += G) {
       const int b = b0 + lane;
       uint32_t S = 0, T = 0, valid = 0;
       uint4 bx = make_uint4(0, 0, 0, 0);
@@ -3902,7 +3914,7 @@ __global__ __launch_bounds__(kBlock) void k_subs_wave(int64_t n, const uint8_t* 
       starts_carry += tot >> 16;
       // 16 unconditional byte writes: a byte that is not kept goes to the lane's own spare word (a select costs
       // less than an execution-mask round trip per byte); a wavefront without any kept byte skips them
-      if (__builtin_amdgcn_ballot_w64(keep != 0) == 0) continue;
+      if (__builtin_amdgcn_ballot_w64(keep != 0) == 0 || (dbg & 2)) continue;
       const uint32_t wv[4] = {bx.x, bx.y, bx.z, bx.w};
       uint8_t* const spare = (uint8_t*)&spare_all[threadIdx.x];
       const int Rs = S ? R : 0;
@@ -3918,7 +3930,7 @@ __global__ __launch_bounds__(kBlock) void k_subs_wave(int64_t n, const uint8_t* 
     group_sync();
     // ---- output blocks
     uint8_t* dst0 = out + obase - head;
-    const int nob = (head + olen + 15) >> 4;
+    const int nob = (dbg & 4) ? 0 : (head + olen + 15) >> 4;
     for (int b = lane; b < nob; b += G) {
       if (16 * b >= head && 16 * b + 16 <= head + olen) {
         *(uint4*)(dst0 + 16 * b) = *(const uint4*)(otile + 16 * b);
@@ -4877,6 +4889,7 @@ static int env_int(const char* name, int dflt) {
 // Measurement knobs of the call path, read from the environment ONCE (at the first call that looks): no getenv per call.
 struct EnvKnobs {
   int decode_grid, decode_reverse, piece_c, fused_skew, fused_debug;
+  int subs_debug;   // k_subs_wave with phases left out (timing only, the output is wrong): 1 replacement bytes, 2 kept bytes, 4 stores, 8 frame phase, 16 match phase
   bool piece_c_set;
 };
 static const EnvKnobs& env_knobs() {
@@ -4888,6 +4901,7 @@ static const EnvKnobs& env_knobs() {
     e.piece_c = env_int("MRX_PIECE_C", 0);
     e.fused_skew = env_int("MRX_FUSED_SKEW", 0);
     e.fused_debug = env_int("MRX_FUSED_DEBUG", 0);
+    e.subs_debug = env_int("MRX_SUBS_DEBUG", 0);
     return e;
   }();
   return k;
@@ -5848,14 +5862,20 @@ __global__ __launch_bounds__(kBlock) void k_subs_reach(int64_t n, const int64_t*
     if (b > a && (int64_t)spans[2 * (b - 1)] + reach > offsets[i + 1] - offsets[i]) *over = 1;
   }
 }
+// go = 1 when the assembly may run: every span had room, the output fits, there is output, no group reaches behind its text
+__global__ void k_subs_gate(const int64_t* __restrict__ matches, int64_t span_cap, const int64_t* __restrict__ out_bytes,
+                            int64_t out_cap, const int32_t* __restrict__ over, int32_t* __restrict__ go) {
+  *go = (*matches <= span_cap && *out_bytes <= out_cap && *out_bytes > 0 && !(over && *over)) ? 1 : 0;
+}
 int sub_from_spans(const mrx_handle* h, const Layout& lay, int64_t n, const std::vector<uint16_t>& rmap,
                    int64_t count, int64_t* out_off, uint8_t* out, int64_t out_cap, int64_t* total_bytes,
-                   hipStream_t s, int group_reach = 0) {
+                   hipStream_t s, int group_reach = 0, int64_t known_bytes = -1, int64_t known_max = -1) {
   // Two host synchronisations per call: the batch's byte count and longest text (sizes the span buffer
-  // and, handed on, spares findall its own look), and the two totals -- matches and output bytes -- behind
-  // findall, sizes and prefix sums, all enqueued without waiting.
-  int64_t in_bytes = 0, max_len = 0;
-  if (int rc0 = csr_stats(lay, n, s, &in_bytes, &max_len)) return rc0;
+  // and, handed on, spares findall its own look; none when the caller knows them: rows at a fixed pitch), and the
+  // two totals -- matches and output bytes -- behind findall, sizes and prefix sums, all enqueued without waiting.
+  int64_t in_bytes = known_bytes, max_len = known_max;
+  if (known_bytes < 0 || known_max < 0)
+    if (int rc0 = csr_stats(lay, n, s, &in_bytes, &max_len)) return rc0;
   if (in_bytes < 0) return fail(MRX_E_ARGUMENT, "offsets[n] is negative");
   const int R = (int)rmap.size();
   int64_t* d_prefix = nullptr;
@@ -5864,6 +5884,7 @@ int sub_from_spans(const mrx_handle* h, const Layout& lay, int64_t n, const std:
   int32_t* d_cum = nullptr;
   int64_t *d_sizes = nullptr, *d_total = nullptr;
   int32_t* d_left = nullptr;
+  int32_t* d_go = nullptr;
   int32_t* d_over = nullptr;
   int32_t over = 0;
   HIP_TRY(scratch_alloc((void**)&d_over, sizeof(int32_t), s));
@@ -5873,6 +5894,7 @@ int sub_from_spans(const mrx_handle* h, const Layout& lay, int64_t n, const std:
   HIP_TRY(scratch_alloc((void**)&d_sizes, sizeof(int64_t) * n, s));
   HIP_TRY(scratch_alloc((void**)&d_total, sizeof(int64_t), s));
   HIP_TRY(scratch_alloc((void**)&d_left, sizeof(int32_t), s));
+  HIP_TRY(scratch_alloc((void**)&d_go, sizeof(int32_t), s));
   if (R) HIP_TRY(hipMemcpyAsync(d_rmap, rmap.data(), sizeof(uint16_t) * R, hipMemcpyHostToDevice, s));
   int64_t cap = in_bytes / 8 + n + 64, nm = 0, tot = 0;
   if (const int64_t seen = h->sub_matches_per_kib.load(std::memory_order_relaxed); seen > 128) {
@@ -5910,11 +5932,49 @@ int sub_from_spans(const mrx_handle* h, const Layout& lay, int64_t n, const std:
     HIP_TRY(hipGetLastError());
     rc = device_scan<int64_t>(d_sizes, n, out_off, d_total, s);
     if (rc != MRX_OK) return rc;
-    if (group_reach > 0) {
+    if (group_reach > 0)
       hipLaunchKernelGGL(k_subs_reach, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, n, lay.offsets, d_prefix, d_spans, cap,
                          group_reach, d_over);
-      HIP_TRY(hipMemcpyAsync(&over, d_over, sizeof over, hipMemcpyDeviceToHost, s));
+    // The assembly is enqueued BEHIND a device-side go-ahead and BEFORE the host has seen the totals: the stream does
+    // not run dry while they travel (63 us of 1.7 ms on config 4).  When the go-ahead says no, the kernels return at
+    // once and the host, which reads the same numbers below, retries or reports.
+    hipLaunchKernelGGL(k_subs_gate, dim3(1), dim3(1), 0, s, d_prefix + n, cap, d_total, out_cap,
+                       group_reach > 0 ? (const int32_t*)d_over : (const int32_t*)nullptr, d_go);
+    if (G == 0 && (g_long_text_mode == 1 || g_long_text_mode == 3 || in_bytes / n >= 4096) && g_long_text_mode != 2) {   // long texts: a workgroup per text
+      hipLaunchKernelGGL(k_subs_emit<kBlock>, dim3((unsigned)(n < 4096 ? n : 4096)), dim3(kBlock),
+                         (size_t)(2 * R + 16), s, n, lay.data, lay.offsets, d_prefix, d_spans, d_cum, (long long)count, R,
+                         d_rmap, out_off, out, 0, (const int32_t*)d_go);
+      g_last_kernel = "k_subs_emit_long";
+    } else {
+      // short texts: G lanes assemble a text in LDS (k_subs_wave); what does not fit its tiles is left to
+      // k_subs_emit, which returns at once when nothing was left
+      HIP_TRY(hipMemsetAsync(d_left, 0, sizeof(int32_t), s));
+#define MRX_SUBS_WAVE(GG)                                                                                        \
+  do {                                                                                                           \
+    const int64_t blocks = (n + (kBlock / GG) - 1) / (kBlock / GG);                                              \
+    hipLaunchKernelGGL(k_subs_wave<GG>, dim3((unsigned)(blocks < grid_cap() ? blocks : grid_cap())), dim3(kBlock), \
+                       (size_t)(2 * R + 16), s, n, lay.data, lay.offsets, d_prefix, d_spans, (long long)count, R,   \
+                       d_rmap, out_off, out, d_left, (const int32_t*)d_go, env_knobs().subs_debug);              \
+  } while (0)
+      if (G == 256) MRX_SUBS_WAVE(256);
+      else if (G == 64) MRX_SUBS_WAVE(64);
+      else if (G == 32) MRX_SUBS_WAVE(32);
+      else if (G == 16) MRX_SUBS_WAVE(16);
+#undef MRX_SUBS_WAVE
+      HIP_TRY(hipGetLastError());
+      const int64_t blocks = (n + (kBlock / kSubsLanes) - 1) / (kBlock / kSubsLanes);
+      if (cum_later)
+        hipLaunchKernelGGL(k_subs_sizes, dim3((unsigned)(blocks < grid_cap() ? blocks : grid_cap())), dim3(kBlock), 0, s,
+                           n, lay.offsets, d_prefix, d_spans, (long long)count, R, (int64_t*)nullptr, d_cum, cap,
+                           (const int32_t*)d_left);
+      // (behind k_subs_wave: the texts it left over -- none when the go-ahead stopped it; alone: the go-ahead itself)
+      hipLaunchKernelGGL(k_subs_emit<kSubsLanes>, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(kBlock),
+                         (size_t)(2 * R + 16), s, n, lay.data, lay.offsets, d_prefix, d_spans, d_cum, (long long)count, R,
+                         d_rmap, out_off, out, G, G ? (const int32_t*)d_left : (const int32_t*)d_go);
+      g_last_kernel = G ? "k_subs_wave" : "k_subs_emit";
     }
+    HIP_TRY(hipGetLastError());   // the output bytes are complete when `s` reaches this point, as with every _dev call
+    if (group_reach > 0) HIP_TRY(hipMemcpyAsync(&over, d_over, sizeof over, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(&nm, d_prefix + n, sizeof nm, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(&tot, d_total, sizeof tot, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -5929,43 +5989,7 @@ int sub_from_spans(const mrx_handle* h, const Layout& lay, int64_t n, const std:
     rc = kSubsRetryGeneric;
   } else {
     if (total_bytes) *total_bytes = tot;
-    if (tot > out_cap) {
-      rc = fail(MRX_E_CAPACITY, "output buffer too small: need " + std::to_string(tot));
-    } else if (tot > 0) {
-      if (G == 0 && (g_long_text_mode == 1 || g_long_text_mode == 3 || in_bytes / n >= 4096) && g_long_text_mode != 2) {   // long texts: a workgroup per text
-        hipLaunchKernelGGL(k_subs_emit<kBlock>, dim3((unsigned)(n < 4096 ? n : 4096)), dim3(kBlock),
-                           (size_t)(2 * R + 16), s, n, lay.data, lay.offsets, d_prefix, d_spans, d_cum, (long long)count, R,
-                           d_rmap, out_off, out, 0, (const int32_t*)nullptr);
-        g_last_kernel = "k_subs_emit_long";
-      } else {
-        // short texts: G lanes assemble a text in LDS (k_subs_wave); what does not fit its tiles is left to
-        // k_subs_emit, which returns at once when nothing was left
-        HIP_TRY(hipMemsetAsync(d_left, 0, sizeof(int32_t), s));
-#define MRX_SUBS_WAVE(GG)                                                                                        \
-  do {                                                                                                           \
-    const int64_t blocks = (n + (kBlock / GG) - 1) / (kBlock / GG);                                              \
-    hipLaunchKernelGGL(k_subs_wave<GG>, dim3((unsigned)(blocks < grid_cap() ? blocks : grid_cap())), dim3(kBlock), \
-                       (size_t)(2 * R + 16), s, n, lay.data, lay.offsets, d_prefix, d_spans, (long long)count, R,   \
-                       d_rmap, out_off, out, d_left);                                                            \
-  } while (0)
-        if (G == 256) MRX_SUBS_WAVE(256);
-        else if (G == 64) MRX_SUBS_WAVE(64);
-        else if (G == 32) MRX_SUBS_WAVE(32);
-        else if (G == 16) MRX_SUBS_WAVE(16);
-#undef MRX_SUBS_WAVE
-        HIP_TRY(hipGetLastError());
-        const int64_t blocks = (n + (kBlock / kSubsLanes) - 1) / (kBlock / kSubsLanes);
-        if (cum_later)
-          hipLaunchKernelGGL(k_subs_sizes, dim3((unsigned)(blocks < grid_cap() ? blocks : grid_cap())), dim3(kBlock), 0, s,
-                             n, lay.offsets, d_prefix, d_spans, (long long)count, R, (int64_t*)nullptr, d_cum, cap,
-                             (const int32_t*)d_left);
-        hipLaunchKernelGGL(k_subs_emit<kSubsLanes>, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(kBlock),
-                           (size_t)(2 * R + 16), s, n, lay.data, lay.offsets, d_prefix, d_spans, d_cum, (long long)count, R,
-                           d_rmap, out_off, out, G, (const int32_t*)d_left);
-        g_last_kernel = G ? "k_subs_wave" : "k_subs_emit";
-      }
-      HIP_TRY(hipGetLastError());   // the output bytes are complete when `s` reaches this point, as with every _dev call
-    }
+    if (tot > out_cap) rc = fail(MRX_E_CAPACITY, "output buffer too small: need " + std::to_string(tot));
   }
   HIP_TRY(scratch_free(d_prefix, s));
   HIP_TRY(scratch_free(d_spans, s));
@@ -5974,6 +5998,7 @@ int sub_from_spans(const mrx_handle* h, const Layout& lay, int64_t n, const std:
   HIP_TRY(scratch_free(d_sizes, s));
   HIP_TRY(scratch_free(d_total, s));
   HIP_TRY(scratch_free(d_left, s));
+  HIP_TRY(scratch_free(d_go, s));
   HIP_TRY(scratch_free(d_over, s));
   return rc;
 }
@@ -6671,7 +6696,8 @@ __global__ __launch_bounds__(kBlock) void k_pitch_offsets(int64_t n, int64_t str
 }
 }  // namespace
 static int sub_any(const mrx_handle* h, const char* repl, size_t repl_len, int64_t count, const Layout& lay_in,
-                   int64_t n, int64_t* out_off, uint8_t* out, int64_t out_cap, int64_t* total_bytes, void* st);
+                   int64_t n, int64_t* out_off, uint8_t* out, int64_t out_cap, int64_t* total_bytes, void* st,
+                   int64_t known_bytes = -1, int64_t known_max = -1);   // (byte count and longest text, when the caller has them)
 extern "C" {
 int mrx_sub_dev(const mrx_handle* h, const char* repl, size_t repl_len, int64_t count,
                 const uint8_t* d, const int64_t* off, int64_t n, int64_t* out_off, uint8_t* out,
@@ -6692,13 +6718,15 @@ int mrx_sub_strided_dev(const mrx_handle* h, const char* repl, size_t repl_len, 
     HIP_TRY(scratch_alloc((void**)&d_off, sizeof(int64_t) * (n + 1), (hipStream_t)st));
     hipLaunchKernelGGL(k_pitch_offsets, dim3(grid_for(n + 1, kBlock)), dim3(kBlock), 0, (hipStream_t)st, n, stride, d_off);
     HIP_TRY(hipGetLastError());
-    return sub_any(h, repl, repl_len, count, Layout{d, d_off, 0, nullptr, 0}, n, out_off, out, out_cap, total_bytes, st);
+    return sub_any(h, repl, repl_len, count, Layout{d, d_off, 0, nullptr, 0}, n, out_off, out, out_cap, total_bytes, st,
+                   n * stride, stride);
   }
   return sub_any(h, repl, repl_len, count, Layout{d, nullptr, stride, d_lens, len}, n, out_off, out, out_cap, total_bytes, st);
 }
 }  // extern "C"
 static int sub_any(const mrx_handle* h, const char* repl, size_t repl_len, int64_t count, const Layout& lay_in,
-                   int64_t n, int64_t* out_off, uint8_t* out, int64_t out_cap, int64_t* total_bytes, void* st) {
+                   int64_t n, int64_t* out_off, uint8_t* out, int64_t out_cap, int64_t* total_bytes, void* st,
+                   int64_t known_bytes, int64_t known_max) {
   const uint8_t* d = lay_in.data;
   const int64_t* off = lay_in.offsets;
   ScratchScope scratch_scope_((hipStream_t)st);
@@ -6755,7 +6783,7 @@ static int sub_any(const mrx_handle* h, const char* repl, size_t repl_len, int64
     if (h->hp.fixed_pure) group_reach = 0;
     if (rmap.size() <= 4096 && h->hp.fixed_total < 0x7FFF) {
       const int rc = sub_from_spans(h, Layout{d, off, 0, nullptr, 0}, n, rmap, count, out_off, out, out_cap,
-                                    total_bytes, s, group_reach);
+                                    total_bytes, s, group_reach, known_bytes, known_max);
       if (rc != kSubsRetryGeneric) return rc;   // else: a group reaches behind its text, the lane-per-text form cuts it
     }
   }
