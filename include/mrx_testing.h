@@ -53,6 +53,10 @@ void mrx_debug_dynamic_texts(int mode);
  * first under the scan of the second); 0 (default: the split measured slower) = one batch, three launches on the
  * caller's stream.  Results are the same. */
 void mrx_debug_split_findall(int on);
+/* findall of a batch full of matches by event rows (k_stream_findall<ST_ROWS> + k_decode_rows; texts of 2 KiB and more at
+ * an aligned fixed pitch, common length a multiple of 128): 0 = when the handle's previous call found one match per 20
+ * bytes or more (default), 1 = whenever the batch has the shape, 2 = never */
+void mrx_debug_dense_rows(int mode);
 /* sub assembled from findall spans: lanes that share one text in k_subs_wave (16, 32 or 64; texts whose
  * frame or output exceed the group's LDS tiles go to k_subs_emit); 0 = k_subs_emit for every text,
  * anything else = chosen from the average text length. */

@@ -1765,7 +1765,11 @@ __host__ __device__ inline int64_t rec_region_start(int64_t first_off, int64_t w
 // no record stream through HBM, no second and third launch.  64-text tasks are handed out in text
 // order through a ticket counter: a wavefront only ever waits for tasks with lower numbers, and those
 // are held by wavefronts that are already running.
-enum { ST_RECORDS = 0, ST_COUNT = 1, ST_SEARCH = 2, ST_FIRST = 3, ST_FUSED = 4 };
+// ST_ROWS: findall of batches full of matches (round 4).  The event words of every 32 bytes of a text go to a row of
+// fixed pitch -- 8 bytes per 32 text bytes, position implied, nothing else -- instead of a 16-byte record per 32 bytes
+// that hold a match end; k_decode_rows derives the rest.  Texts at a fixed 16-byte aligned pitch whose common length is
+// a multiple of the chunk only (`recs` = the rows, `rec_row` = pairs per row).
+enum { ST_RECORDS = 0, ST_COUNT = 1, ST_SEARCH = 2, ST_FIRST = 3, ST_FUSED = 4, ST_ROWS = 5 };
 
 struct FusedArgs {
   // [0] ticket counter, [1] error word, [2 ..] one descriptor per 64-text task, then two words per
@@ -1936,7 +1940,9 @@ __global__ __launch_bounds__(64 * kStreamWaves, (MODE == ST_FUSED ? MRX_FUSED_WA
   // they would be live in scalar registers across the scan loop, which has none to spare)
 #define fz (*fzp)
   constexpr bool RECS = MODE == ST_RECORDS || MODE == ST_FUSED;   // event records are produced
+  constexpr bool ROWS = MODE == ST_ROWS;
   static_assert(!(MODE == ST_FUSED && VIRT), "pieces of long texts keep the three-launch form");
+  static_assert(!ROWS || (!CSR && !VIRT && !REC32), "event rows: texts at a fixed aligned pitch");
   constexpr int kChunk = CH;
   constexpr int kRowPitch = CH + 16;      // +16: the per-lane 16-byte read-back is bank-conflict free
   constexpr int LPR = CH / 16;            // lanes that cover one text row in a load instruction
@@ -2176,6 +2182,7 @@ __global__ __launch_bounds__(64 * kStreamWaves, (MODE == ST_FUSED ? MRX_FUSED_WA
     for (int j = 0; j < NL; ++j) v[j] = make_uint4(0, 0, 0, 0);
     if (max_len > 0) MRX_LOAD_CHUNK(0);
     uint8_t* wr = tile + rsub * kRowPitch + seg * 16;
+    uint4 rowacc[ROWS ? 8 : 1];   // ST_ROWS: the event words of the last four chunks
     for (int cbase = 0; cbase < max_len; cbase += kChunk) {
 #pragma unroll
       for (int j = 0; j < NL; ++j) *(uint4*)(wr + j * RPI * kRowPitch) = v[j];
@@ -2201,6 +2208,7 @@ __global__ __launch_bounds__(64 * kStreamWaves, (MODE == ST_FUSED ? MRX_FUSED_WA
       const bool all_inside = __all(lim >= kChunk && lo <= 0);
       const bool full = all_inside || use_fill;   // branch-free steps: no byte needs a predicate
       uint32_t F_even = 0, meta_even = 0, sp_even = 0;   // REC32: the even group of the current pair
+      uint2 rowbuf[ROWS ? kChunk / 32 : 1];               // ST_ROWS: the chunk's event words
 #pragma unroll
       for (int g = 0; g < kChunk / 16; ++g) {
         const uint4 wv = *(const uint4*)(tile + lane * kRowPitch + g * 16);
@@ -2305,6 +2313,10 @@ __global__ __launch_bounds__(64 * kStreamWaves, (MODE == ST_FUSED ? MRX_FUSED_WA
           }
         }
         if (MRX_ABLATE & 16) { cnt += (F == 0x12345u); continue; }
+        if (ROWS) {
+          if ((g & 1) == 0) F_even = F;
+          else rowbuf[g >> 1] = make_uint2(F_even, F);
+        } else
         if (RECS && REC32) {
           if ((g & 1) == 0) {
             F_even = F;
@@ -2353,6 +2365,26 @@ __global__ __launch_bounds__(64 * kStreamWaves, (MODE == ST_FUSED ? MRX_FUSED_WA
         }
         cnt += __builtin_popcount(em);
         if (ns) start = gbase + ((31 - __builtin_clz(ns)) >> 1);
+      }
+      if constexpr (ROWS) {
+        // 32 bytes of event words per lane and chunk.  Written chunk by chunk, a row's 128-byte line is touched four times
+        // some microseconds apart and the lines in flight (64 per wavefront) are as many as L2 holds: WRITE_SIZE read
+        // 7.2 GB for 4.3 GB of rows.  So four chunks are kept in registers and a lane writes a whole line at a time.
+        static_assert(kChunk == 128, "event rows: four pairs per chunk");
+#pragma unroll
+        for (int q = 0; q < 6; ++q) rowacc[q] = rowacc[q + 2];
+        rowacc[6] = make_uint4(rowbuf[0].x, rowbuf[0].y, rowbuf[1].x, rowbuf[1].y);
+        rowacc[7] = make_uint4(rowbuf[2].x, rowbuf[2].y, rowbuf[3].x, rowbuf[3].y);
+        const int ci = cbase >> 7;
+        if ((ci & 3) == 3 || cbase + kChunk >= max_len) {   // (wave uniform: one common length)
+          const int nc = (ci & 3) + 1;   // the accumulator's last nc chunks are new
+          if (live) {
+            uint4* const dst = (uint4*)((uint2*)recs + my_text * rec_row) + 2 * (ci - (nc - 1));
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+              if (q >= 8 - 2 * nc) dst[q - (8 - 2 * nc)] = rowacc[q];
+          }
+        }
       }
       __builtin_amdgcn_wave_barrier();
     }
@@ -3088,6 +3120,113 @@ __global__ __launch_bounds__(kBlock) void k_decode(int64_t n, const int32_t* __r
         }
       }
       __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+// event rows -> CSR spans (behind k_stream_findall<ST_ROWS>).  A wavefront per text; a round is 128 pairs of event words
+// = 4 KiB of text, two pairs (one 16-byte load) per lane.  What a record carried is derived here: the index of a lane's
+// first span within its text is a prefix sum over the lanes' match-end counts, the walk alive at a lane's first byte began
+// at the last NEWSTART of the lanes in front (a running maximum) -- both carried from round to round.  The spans of a round
+// are contiguous in the output: they are laid out in an LDS tile (16-bit positions, 4 bytes a span) and leave as
+// coalesced 8-byte stores.  The match that ends with the text has no event (the scan counts it): the text's count says
+// whether there is one.  prefix[] is complete before this launch (device_scan over the scan's counts).
+constexpr int kRowsTile = 1024;   // spans per wavefront and pass
+__global__ __launch_bounds__(kBlock) void k_decode_rows(int64_t n, const uint2* __restrict__ rows, int64_t row_pairs, int npairs,
+                                                        int text_len, const int32_t* __restrict__ counts,
+                                                        const int64_t* __restrict__ prefix, int32_t* __restrict__ spans,
+                                                        int64_t span_cap, int fixed_len) {
+  __shared__ uint32_t tile_all[kBlock / 64][kRowsTile];
+  const int lane = threadIdx.x & 63;
+  uint32_t* tile = tile_all[threadIdx.x >> 6];
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  auto load_pairs = [&](int64_t i, int p0) {   // pairs p0 + 2 lane, p0 + 2 lane + 1 of text i (zero beyond the text)
+    const int a = p0 + 2 * lane;
+    uint4 q = make_uint4(0, 0, 0, 0);
+    if (i < n && a < npairs) {
+      q = mrx_ldg((const uint4*)(rows + i * row_pairs + a));   // (row_pairs is even: 16-byte aligned; last use of the words)
+      if (a + 1 >= npairs) { q.z = 0; q.w = 0; }
+    }
+    return q;
+  };
+  int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  uint4 q_next = load_pairs(i, 0);
+  int64_t base_next = i < n ? prefix[i] : 0;
+  int total_next = i < n ? counts[i] : 0;
+  for (; i < n; i += nwaves) {
+    uint4 q = q_next;
+    const int64_t base = base_next;
+    const int total_i = total_next;
+    if (npairs <= 128) {   // the next text's first round travels while this one is expanded
+      q_next = load_pairs(i + nwaves, 0);
+      base_next = i + nwaves < n ? prefix[i + nwaves] : 0;
+      total_next = i + nwaves < n ? counts[i + nwaves] : 0;
+    }
+    int carry_cnt = 0, carry_start = 0;
+    for (int p0 = 0; p0 < npairs; p0 += 128) {
+      if (p0 > 0) q = load_pairs(i, p0);
+      const uint32_t W[4] = {q.x, q.y, q.z, q.w};
+      const int pb0 = 32 * (p0 + 2 * lane);
+      int c = 0, ln = -1;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        c += __builtin_popcount(W[k] & 0xAAAAAAAAu);
+        const uint32_t ns = W[k] & 0x55555555u;
+        if (ns) ln = pb0 + 16 * k + ((31 - __builtin_clz(ns)) >> 1);
+      }
+      int incl = c, mx = ln;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int v = __shfl_up(incl, d), m = __shfl_up(mx, d);
+        if (lane >= d) { incl += v; mx = max(mx, m); }
+      }
+      const int round_total = __shfl(incl, 63);
+      int ex_start = __shfl_up(mx, 1);
+      if (lane == 0) ex_start = -1;
+      const int rstart0 = ex_start >= 0 ? ex_start : carry_start;
+      const int before = incl - c;   // spans of this round in front of my first
+      for (int tb = 0; tb < round_total; tb += kRowsTile) {
+        int dst = before - tb;
+        int rs = rstart0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          uint32_t em = W[k] & 0xAAAAAAAAu;
+          const uint32_t ns = W[k] & 0x55555555u;
+          const int pb = pb0 + 16 * k;
+          while (em) {
+            const int kk = __builtin_ctz(em) >> 1;
+            const uint32_t nsb = ns & ((1u << (2 * kk)) - 1u);   // NEWSTARTs strictly before this EMIT
+            int st = nsb ? pb + ((31 - __builtin_clz(nsb)) >> 1) : rs;
+            if (fixed_len > 0) st = pb + kk - fixed_len;
+            if (dst >= 0 && dst < kRowsTile) tile[dst] = ((uint32_t)st << 16) | (uint32_t)(pb + kk);
+            ++dst;
+            em &= em - 1;
+          }
+          if (ns) rs = pb + ((31 - __builtin_clz(ns)) >> 1);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int cntp = round_total - tb < kRowsTile ? round_total - tb : kRowsTile;
+        const int64_t d0 = base + carry_cnt + tb;
+        for (int k = lane; k < cntp; k += 64) {
+          const uint32_t v = tile[k];
+          if (d0 + k < span_cap) mrx_stg_span(spans + 2 * (d0 + k), (int)(v >> 16), (int)(v & 0xFFFFu));
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      carry_cnt += round_total;
+      const int last = __shfl(mx, 63);
+      if (last >= 0) carry_start = last;
+    }
+    if (carry_cnt < total_i && lane == 0) {   // the match that runs to the end of the text
+      const int64_t d = base + carry_cnt;
+      if (d < span_cap) mrx_stg_span(spans + 2 * d, fixed_len > 0 ? text_len - fixed_len : carry_start, text_len);
+    }
+    if (npairs > 128) {
+      q_next = load_pairs(i + nwaves, 0);
+      base_next = i + nwaves < n ? prefix[i + nwaves] : 0;
+      total_next = i + nwaves < n ? counts[i + nwaves] : 0;
     }
   }
 }
@@ -4080,6 +4219,17 @@ struct mrx_handle {
   };
   mutable std::mutex tune_mu;
   mutable std::map<uint32_t, ReqTune> req_tune;
+  // findall on texts FULL of matches (config 5: a match every six bytes): event rows instead of records (ST_ROWS,
+  // k_decode_rows).  How full a batch is, the handle's previous eligible call tells: its total travels to pinned host
+  // memory behind the call's work and is looked at by the next call if it has arrived -- no call waits for it.
+  struct DenseProbe {
+    int64_t* host_total = nullptr;   // pinned
+    hipEvent_t ev = nullptr;
+    bool pending = false;
+    int64_t bytes = 0;               // of the batch the pending total belongs to
+    int dev = 0, dense = 0;          // dense: 1 = the last batch seen held at least one match per kDenseBytesPerSpan bytes
+  };
+  mutable DenseProbe dense_probe;    // (under tune_mu)
   mrx_handle() { for (auto& b : d_blobs) b.store(nullptr, std::memory_order_relaxed); }
 };
 
@@ -4825,10 +4975,12 @@ void launch_stream(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d
 #undef MRX_LAUNCH_V
     }
   } else if (!strided_fast(lay)) {
+    if constexpr (MODE != ST_ROWS) {   // (event rows: the aligned fixed pitch only, the caller has checked)
     if (pairs) { if constexpr (MODE != ST_FIRST) MRX_LAUNCH(4, 1); }
     else if (table) MRX_LAUNCH(2, 1);
     else if (wide) MRX_LAUNCH(3, 1);
     else MRX_LAUNCH(1, 1);
+    }
   } else {
     if (pairs) { if constexpr (MODE != ST_FIRST) MRX_LAUNCH(4, 0); }
     else if (table) MRX_LAUNCH(2, 0);
@@ -5092,6 +5244,9 @@ int findall_pieces(const mrx_handle* h, const Pieces& pc, int64_t n, int64_t* d_
 // does pay is overlapping WHOLE calls on two caller streams (bench.py --streams 2: 0.287 ms on the same box).
 // MRX_FINDALL_SPLIT=1 / mrx_debug_split_findall(1): on.
 std::atomic<int> g_split_findall{env_int("MRX_FINDALL_SPLIT", 0)};
+// findall by event rows (ST_ROWS, k_decode_rows): 0 = when the handle's last batch was full of matches, 1 = whenever the
+// batch has the shape, 2 = never (MRX_DENSE_ROWS / mrx_debug_dense_rows)
+std::atomic<int> g_dense_rows{env_int("MRX_DENSE_ROWS", 0)};
 constexpr int64_t kSplitMinTexts = 1 << 18;
 struct SideStream {
   hipStream_t side = nullptr;
@@ -5302,6 +5457,10 @@ struct FindallJob {
   int64_t csr_total = -1, csr_max = -1;   // CSR batches on the streaming path: byte count and longest text
   bool by_pieces = false;
   bool finished = false;           // a route that answered the whole call by itself (the stepper's pieces)
+  // event rows (ST_ROWS) instead of records: a batch the handle's last call found full of matches
+  bool rows = false, rows_shape = false;
+  uint2* d_rows = nullptr;
+  int64_t row_pairs = 0;
   // required-byte plan on long texts: the route being timed for the handle's tuner (0: none), and when the call began
   int tune_route = 0, tune_slot = 0;
   uint32_t tune_key = 0;
@@ -5386,6 +5545,11 @@ struct FindallJob {
     // (a CSR batch of equal-length texts leaves no lane idle: the 64-text wavefronts and their decode are faster)
     dyn = dyn_ok(h, lay, n) && max_text < (int64_t(1) << kDynShift) &&
           (g_dyn_mode == 1 || csr_total < max_text * n - max_text * n / 8);
+    // Event rows: texts of 2 KiB and more at an aligned fixed pitch, one common length that is a multiple of the chunk
+    // (no byte behind a text is ever walked: the match that ends with the text is the count's business), 16-bit positions.
+    rows_shape = !dyn && !lay.offsets && !lay.lens && strided_fast(lay) && span_cap > 0 && !g_split_findall && rec32 &&
+                 max_text >= 2048 && max_text <= 65024 && max_text % MRX_STREAM_CHUNK == 0 && g_dense_rows != 2;
+    rows = rows_shape && (g_dense_rows == 1 || dense_probe_read());
     // One launch (ST_FUSED) when a record region per resident wavefront -- sized for the most one
     // 64-text task can produce -- stays within twice the record stream of the three-launch form
     // (ragged batches whose longest text is far above the average do not: they are cut into pieces
@@ -5395,11 +5559,20 @@ struct FindallJob {
     if (fz_grid > fused_grid_cap()) fz_grid = fused_grid_cap();
     const size_t fz_nrec = (size_t)(64 * fz_per_text + 64) * (size_t)(fz_grid * kStreamWaves) * 2;   // two regions per wavefront
     const int64_t batch_bytes = lay.offsets ? csr_total : n * (lay.lens ? lay.stride : (int64_t)lay.len);
-    fused = !dyn && g_fused && span_cap > 0 && fz_nrec <= 2 * nrec + (size_t(8) << 20) && (g_fused == 2 || batch_bytes >= nw * kFusedMinTaskBytes);
+    fused = !dyn && !rows && g_fused && span_cap > 0 && fz_nrec <= 2 * nrec + (size_t(8) << 20) && (g_fused == 2 || batch_bytes >= nw * kFusedMinTaskBytes);
     // texts of at most 1 KiB at a 16-byte aligned pitch, automaton in registers: one launch, no records at all
     // (mrx_stream_bits.hip)
-    const bool bits = !dyn && !fused && !lay.offsets && span_cap > 0 && !g_split_findall &&
+    const bool bits = !dyn && !fused && !rows && !lay.offsets && span_cap > 0 && !g_split_findall &&
                       stream_bits_eligible(p, lay.data, lay.stride, max_text, n);
+    if (rows) {
+      row_pairs = ((max_text / 32) + 1) & ~int64_t(1);
+      HIP_TRY(scratch_alloc((void**)&d_rows, sizeof(uint2) * (size_t)row_pairs * (size_t)n, s));
+      ScanTimer tm(s);
+      launch_stream<ST_ROWS>(h, lay, n, d_counts, nullptr, (EvRec*)d_rows, row_pairs, nullptr, nullptr, s);
+      g_last_kernel = "k_stream_findall_rows";
+      HIP_TRY(hipGetLastError());
+      tm.stop();
+    } else
     if (bits) {
       void* d_args = nullptr;
       HIP_TRY(scratch_alloc((void**)&d_ctrl, sizeof(unsigned long long) * stream_bits_ctrl_words(n), s));
@@ -5461,6 +5634,15 @@ struct FindallJob {
 
   // ... and what turns its records into the CSR: prefix sums over the wavefronts' totals, k_decode
   int stream_finish() {
+    if (rows) {   // offsets from the scan's counts, then a wavefront per text (k_decode_rows)
+      if (int rc = device_scan<int32_t>(d_counts, n, d_prefix, d_total, s)) return rc;
+      const int64_t blocks = (n + (kBlock / 64) - 1) / (kBlock / 64);
+      hipLaunchKernelGGL(k_decode_rows, dim3((unsigned)(blocks < 8 * grid_cap() ? blocks : 8 * grid_cap())), dim3(kBlock), 0, s,
+                         n, (const uint2*)d_rows, row_pairs, (int)(max_text / 32), (int)max_text, (const int32_t*)d_counts,
+                         (const int64_t*)d_prefix, d_spans, span_cap, p.st_fixed_len);
+      HIP_TRY(hipGetLastError());
+      return MRX_OK;
+    }
   // prefix sums over the wavefronts' totals only (n/64 values); k_decode derives the per-text
     // offsets from its 64 counts and writes them along with the spans
     const int64_t nw = dyn ? (n + kDynTexts - 1) / kDynTexts : (n + 63) / 64;
@@ -5761,8 +5943,38 @@ struct FindallJob {
   }
 
   // the total (one stream synchronisation when the caller asked for it)
+  // mrx_handle::dense_probe: was the handle's last eligible batch full of matches?  (Takes a total that has arrived.)
+  static constexpr int64_t kDenseBytesPerSpan = 20;
+  bool dense_probe_read() {
+    std::lock_guard<std::mutex> lk(h->tune_mu);
+    mrx_handle::DenseProbe& d = h->dense_probe;
+    if (d.pending && d.dev == t_dev && hipEventQuery(d.ev) == hipSuccess) {
+      d.dense = (*d.host_total > 0 && *d.host_total * kDenseBytesPerSpan >= d.bytes) ? 1 : 0;
+      d.pending = false;
+    }
+    return d.dense == 1;
+  }
+  // ... and this call's total on its way (nothing in flight and the shape eligible: else the older answer stands)
+  void dense_probe_send() {
+    if (!rows_shape || g_dense_rows != 0) return;
+    std::lock_guard<std::mutex> lk(h->tune_mu);
+    mrx_handle::DenseProbe& d = h->dense_probe;
+    if (d.pending) return;
+    if (!d.host_total) {
+      if (hipHostMalloc((void**)&d.host_total, sizeof(int64_t)) != hipSuccess) { d.host_total = nullptr; return; }
+      if (hipEventCreateWithFlags(&d.ev, hipEventDisableTiming) != hipSuccess) { d.ev = nullptr; return; }
+      d.dev = t_dev;
+    }
+    if (!d.ev || d.dev != t_dev) return;   // (a handle used on several devices keeps the first one's answer)
+    if (hipMemcpyAsync(d.host_total, d_total, sizeof(int64_t), hipMemcpyDeviceToHost, s) != hipSuccess) return;
+    if (hipEventRecord(d.ev, s) != hipSuccess) return;
+    d.bytes = n * max_text;
+    d.pending = true;
+  }
+
   int read_total() {
     req_tuner_report();
+    dense_probe_send();
   int rc = MRX_OK;
     if (total) {
       int64_t tot = 0;
@@ -5783,6 +5995,7 @@ struct FindallJob {
     if (d_wbase) HIP_TRY(scratch_free(d_wbase, s));
     if (d_slots) HIP_TRY(scratch_free(d_slots, s));
     if (d_blimit) HIP_TRY(scratch_free(d_blimit, s));
+    if (d_rows) HIP_TRY(scratch_free(d_rows, s));
     return rc;
   }
 
@@ -6082,6 +6295,11 @@ void mrx_free(mrx_handle* h) {
     for (auto& pr : kv.second.ev)
       for (auto& e : pr)
         if (e) (void)hipEventDestroy(e);
+  }
+  if (h->dense_probe.ev || h->dense_probe.host_total) {
+    (void)hipSetDevice(h->dense_probe.dev);
+    if (h->dense_probe.ev) { (void)hipEventSynchronize(h->dense_probe.ev); (void)hipEventDestroy(h->dense_probe.ev); }
+    if (h->dense_probe.host_total) (void)hipHostFree(h->dense_probe.host_total);
   }
   (void)hipSetDevice(cur);
   delete h;
@@ -6942,6 +7160,7 @@ void mrx_debug_stream_bits(int on) { mrx::stream_bits_set_mode(on); }
 void mrx_debug_stream_bits_trace(int64_t* d_trace) { mrx::stream_bits_set_trace(d_trace); }
 void mrx_debug_dynamic_texts(int mode) { g_dyn_mode = mode < 0 ? 0 : mode > 2 ? 0 : mode; }
 void mrx_debug_split_findall(int on) { g_split_findall = on ? 1 : 0; }
+void mrx_debug_dense_rows(int mode) { g_dense_rows = mode; }
 void mrx_debug_subs_group(int g) { g_subs_group = (g == 0 || g == 16 || g == 32 || g == 64 || g == 256) ? g : -1; }
 void mrx_debug_litscan_pieces(int mode) { g_litscan_pieces = (mode == 0 || mode == 1) ? mode : 2; }
 void mrx_debug_multiwalk(int mode) { g_mwalk_mode = mode == 2 ? 2 : 0; g_mwalk_pk = mode == 3 ? 0 : 1; }

@@ -2656,3 +2656,89 @@ def test_lazy_end_stepper_ends_a_walk_where_it_meets_the_last_failed_one(pat):
         assert have == o.match_all(t), (pat, i, t[:60])
         w = o.match_next(t, 0)
         assert (int(got[3][i]), int(got[4][i])) == (w if w else (-1, -1)), (pat, i)
+
+
+@pytest.mark.parametrize("pat", [b"(x|y|foo|bar)+", b"[a-z]+\\d+", b"\\d+", b"hello", b"[0-9a-f]", b"(\\d{3})(\\d{3})(\\d{4})", b"a+b"])
+@pytest.mark.parametrize("L", [2048, 4096, 8192 + 4096])
+def test_findall_by_event_rows_equals_records_and_oracle(pat, L):
+    """mrx_debug_dense_rows(1): the scan writes 8 bytes of event words per 32 text bytes at a fixed pitch and
+    k_decode_rows (a wavefront per text) derives starts, indices and the match that ends with the text -- against the
+    record form (mrx_debug_dense_rows(2)) span by span, and against the oracle on a sample.  Texts of one, one and three
+    rounds of 128 pairs; matches across lane, round and text ends; texts without a match; a match every byte; a batch
+    that is not a multiple of 64 texts."""
+    _need_gpu()
+    lib = M.load_library()
+    rng = np.random.default_rng(zlib.crc32(pat) + L)
+    n = 64 * 5 + 37
+    kinds = [b"xyfoobar ", b"abcdefgh0123456789 ", b"0123456789abcdef", b"hello wrd", b"ab"]
+    data = np.empty((n, L), dtype=np.uint8)
+    for i in range(n):
+        al = np.frombuffer(kinds[i % len(kinds)], dtype=np.uint8)
+        data[i] = al[rng.integers(0, len(al), L)]
+    data[3] = ord("x")                      # one match over the whole text: ends with it, no event
+    data[4] = ord("7")
+    data[5] = ord(" ")                      # no match at all
+    data[6, :] = np.frombuffer((b"ab12 " * (L // 5 + 1))[:L], dtype=np.uint8)
+    data[7, -3:] = np.frombuffer(b"a12", dtype=np.uint8)   # a match that ends with the text behind others
+    data[8, :] = np.frombuffer((b"1234567890" * (L // 10 + 1))[:L], dtype=np.uint8)
+    d = torch.from_numpy(data).cuda()
+    rx = M.compile_regex(pat)
+    if "device.streamable=yes" not in rx.describe():
+        pytest.skip("does not stream")
+    batch = M.DeviceBatch.strided(d.reshape(-1), L, length=L)
+    lib.mrx_debug_dense_rows(2)
+    lib.mrx_debug_long_text_kernels(2)   # (a few hundred texts of some KiB would go by pieces)
+    try:
+        pre0, sp0, tot0 = rx._dev_findall(batch)
+        k0 = lib.mrx_last_kernel_name()
+        lib.mrx_debug_dense_rows(1)
+        pre1, sp1, tot1 = rx._dev_findall(batch)
+        k1 = lib.mrx_last_kernel_name()
+        # a span buffer that is too small: clipped, the total still reported
+        small = torch.empty((max(tot0 // 2, 1), 2), dtype=torch.int32, device="cuda")
+        prefix = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+        rx.findall_async(batch, (prefix, small))
+        torch.cuda.synchronize()
+    finally:
+        lib.mrx_debug_dense_rows(0)
+        lib.mrx_debug_long_text_kernels(0)
+    assert k1 == b"k_stream_findall_rows" and k0 != k1, (k0, k1)
+    assert tot0 == tot1 and torch.equal(pre0, pre1) and torch.equal(sp0[:tot0], sp1[:tot0])
+    assert torch.equal(prefix, pre0) and torch.equal(small, sp0[:small.shape[0]])
+    pre, sp = pre1.cpu().numpy(), sp1.cpu().numpy()
+    for i in list(range(0, 12)) + list(range(n - 5, n)):
+        want = O.findall(pat, data[i].tobytes())
+        got = [tuple(x) for x in sp[pre[i]:pre[i + 1]].tolist()]
+        assert got == want, (pat, L, i, got[:3], want[:3])
+
+
+def test_event_rows_are_chosen_after_a_dense_batch_and_dropped_after_a_sparse_one():
+    """Default mode: the handle's previous eligible call decides (its total travels to pinned memory behind the call's work;
+    nobody waits for it).  First call: records; after a batch with a match every few bytes: rows; after a batch with few
+    matches: records again."""
+    _need_gpu()
+    lib = M.load_library()
+    rx = M.compile_regex(b"(x|y|foo|bar)+")
+    n, L = 4096, 4096
+    g = torch.Generator(device="cuda")
+    g.manual_seed(11)
+    al = torch.tensor(list(b"xyfoobar "), dtype=torch.uint8, device="cuda")
+    dense = al[torch.randint(0, al.numel(), (n, L), generator=g, device="cuda")]
+    sparse = torch.full((n, L), ord("."), dtype=torch.uint8, device="cuda")
+    sparse[:, 100] = ord("x")
+    bd = M.DeviceBatch.strided(dense.reshape(-1), L, length=L)
+    bs = M.DeviceBatch.strided(sparse.reshape(-1), L, length=L)
+    names = []
+    want = None
+    for batch in (bd, bd, bd, bs, bs, bd):
+        pre, sp, tot = rx._dev_findall(batch)
+        names.append(lib.mrx_last_kernel_name())
+        torch.cuda.synchronize()
+        if batch is bd:
+            if want is None:
+                want = (pre.clone(), sp[:tot].clone())
+            assert torch.equal(pre, want[0]) and torch.equal(sp[:tot], want[1])
+    assert names[0] != b"k_stream_findall_rows"
+    assert names[2] == b"k_stream_findall_rows", names      # the first call's total has arrived by the third at the latest
+    assert names[3] == b"k_stream_findall_rows"             # the sparse batch: the last answer still says dense
+    assert names[5] != b"k_stream_findall_rows", names      # ... and its own total says otherwise
