@@ -215,6 +215,13 @@ int mrx_sub_dev(const mrx_handle* h, const char* repl, size_t repl_len, int64_t 
                 const uint8_t* d_data, const int64_t* d_offsets, int64_t n,
                 int64_t* d_out_offsets, uint8_t* d_out_data, int64_t out_cap,
                 int64_t* total_bytes, void* stream);
+/* Same for a caller that knows its offsets (see mrx_findall_known_dev: end_offset = d_offsets[n], max_text_len = the
+ * longest text; upper bounds are fine, neither may be too small): spares the small kernel and the stream
+ * synchronisation with which mrx_sub_dev reads the two from the device before anything else can be enqueued. */
+int mrx_sub_known_dev(const mrx_handle* h, const char* repl, size_t repl_len, int64_t count,
+                      const uint8_t* d_data, const int64_t* d_offsets, int64_t n, int64_t end_offset,
+                      int64_t max_text_len, int64_t* d_out_offsets, uint8_t* d_out_data, int64_t out_cap,
+                      int64_t* total_bytes, void* stream);
 
 /* Same, texts at a fixed pitch (round 3; every other operation already had this form).  Rows without padding
  * (len == stride, d_lens == NULL) take every fast path of mrx_sub_dev; padded rows run on the lane-per-text kernels. */

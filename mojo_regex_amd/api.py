@@ -94,6 +94,8 @@ def load_library():
         "mrx_captures_dev": (C.c_int, [H, u8p, i64p, C.c_int64, i32p, C.c_void_p]),
         "mrx_sub_dev": (C.c_int, [H, C.c_char_p, C.c_size_t, C.c_int64, u8p, i64p, C.c_int64, i64p,
                                   u8p, C.c_int64, C.POINTER(C.c_int64), C.c_void_p]),
+        "mrx_sub_known_dev": (C.c_int, [H, C.c_char_p, C.c_size_t, C.c_int64, u8p, i64p, C.c_int64, C.c_int64, C.c_int64,
+                                        i64p, u8p, C.c_int64, C.POINTER(C.c_int64), C.c_void_p]),
         "mrx_sub_strided_dev": (C.c_int, [H, C.c_char_p, C.c_size_t, C.c_int64, u8p, C.c_int64, i32p, C.c_int32,
                                           C.c_int64, i64p, u8p, C.c_int64, C.POINTER(C.c_int64), C.c_void_p]),
         "mrx_match_first_batch": (C.c_int, [H, u8p, i64p, C.c_int64, i32p, i32p]),
@@ -162,7 +164,7 @@ EXPORTED_SYMBOLS = [
     "mrx_captures_strided_dev", "mrx_captures_dev",
     "mrx_match_first_at_dev", "mrx_search_at_dev", "mrx_is_match_at_dev", "mrx_match_first_at_strided_dev",
     "mrx_search_at_strided_dev", "mrx_is_match_at_strided_dev",
-    "mrx_sub_dev", "mrx_sub_strided_dev", "mrx_split_dev", "mrx_split_strided_dev", "mrx_split_batch", "mrx_match_first_batch", "mrx_search_batch", "mrx_is_match_batch",
+    "mrx_sub_dev", "mrx_sub_known_dev", "mrx_sub_strided_dev", "mrx_split_dev", "mrx_split_strided_dev", "mrx_split_batch", "mrx_match_first_batch", "mrx_search_batch", "mrx_is_match_batch",
     "mrx_findall_batch", "mrx_captures_batch", "mrx_sub_batch", "mrx_version", "mrx_release_scratch",
 ]
 TESTING_SYMBOLS = [
@@ -231,6 +233,18 @@ class DeviceBatch:
             self.n = int(offsets.numel()) - 1
         else:
             self.n = int(n)
+
+    @classmethod
+    def csr_known(cls, data, offsets, end_offset: int, max_len: int):
+        """A CSR batch whose builder knows offsets[n] and the longest text (it produced the offsets, or holds an Arrow
+        array's): findall and sub then need no look at the device before their first kernel (mrx_findall_known_dev,
+        mrx_sub_known_dev).  Upper bounds are fine; neither may be too small -- the C side sizes scratch from them that
+        its kernels index with the real offsets."""
+        b = cls(data, offsets)
+        if int(end_offset) < 0 or int(max_len) < 0:
+            raise MrxError("end_offset and max_len must not be negative")
+        b._end_offset, b._max_len = int(end_offset), int(max_len)
+        return b
 
     @classmethod
     def strided(cls, data, stride: int, length: Optional[int] = None, lens=None):
@@ -579,6 +593,10 @@ class CompiledRegex:
                 rc = self._lib.mrx_sub_strided_dev(self._h, repl, len(repl), count, _ptr(batch.data), batch.stride,
                                                    _ptr(batch.lens), batch.length, batch.n, _ptr(out_off), _ptr(out),
                                                    cap, C.byref(total), self._stream_ptr())
+            elif batch.offsets is not None and batch._end_offset is not None:
+                rc = self._lib.mrx_sub_known_dev(self._h, repl, len(repl), count, _ptr(batch.data), _ptr(off), batch.n,
+                                                 batch._end_offset, batch._max_len, _ptr(out_off), _ptr(out), cap,
+                                                 C.byref(total), self._stream_ptr())
             else:
                 rc = self._lib.mrx_sub_dev(self._h, repl, len(repl), count, _ptr(batch.data), _ptr(off), batch.n,
                                            _ptr(out_off), _ptr(out), cap, C.byref(total), self._stream_ptr())

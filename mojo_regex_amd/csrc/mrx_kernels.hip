@@ -5549,7 +5549,7 @@ struct FindallJob {
     // (no byte behind a text is ever walked: the match that ends with the text is the count's business), 16-bit positions.
     rows_shape = !dyn && !lay.offsets && !lay.lens && strided_fast(lay) && span_cap > 0 && !g_split_findall && rec32 &&
                  max_text >= 2048 && max_text <= 65024 && max_text % MRX_STREAM_CHUNK == 0 && g_dense_rows != 2;
-    rows = rows_shape && (g_dense_rows == 1 || dense_probe_read());
+    rows = rows_shape && (g_dense_rows == 1 || (g_fused != 2 && dense_probe_read()));   // (a forced one-launch form stays forced)
     // One launch (ST_FUSED) when a record region per resident wavefront -- sized for the most one
     // 64-text task can produce -- stays within twice the record stream of the three-launch form
     // (ragged batches whose longest text is far above the average do not: they are cut into pieces
@@ -6921,6 +6921,13 @@ int mrx_sub_dev(const mrx_handle* h, const char* repl, size_t repl_len, int64_t 
                 const uint8_t* d, const int64_t* off, int64_t n, int64_t* out_off, uint8_t* out,
                 int64_t out_cap, int64_t* total_bytes, void* st) {
   return sub_any(h, repl, repl_len, count, Layout{d, off, 0, nullptr, 0}, n, out_off, out, out_cap, total_bytes, st);
+}
+int mrx_sub_known_dev(const mrx_handle* h, const char* repl, size_t repl_len, int64_t count,
+                      const uint8_t* d, const int64_t* off, int64_t n, int64_t end_offset, int64_t max_text_len,
+                      int64_t* out_off, uint8_t* out, int64_t out_cap, int64_t* total_bytes, void* st) {
+  if (end_offset < 0 || max_text_len < 0) return fail(MRX_E_ARGUMENT, "negative end offset / text length");
+  return sub_any(h, repl, repl_len, count, Layout{d, off, 0, nullptr, 0}, n, out_off, out, out_cap, total_bytes, st,
+                 end_offset, max_text_len);
 }
 // Texts at a fixed pitch.  Rows without padding (len == stride, no per-text lengths) are a CSR batch whose offsets
 // are i * stride: they are written once on the device and the call takes every fast path of mrx_sub_dev; padded

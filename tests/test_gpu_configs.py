@@ -14,7 +14,7 @@ from mojo_regex_amd.workloads import make_digits_batch, make_phone_batch, make_a
 from mrx_ref.cfast import CDfa  # noqa: E402  (oracle: checker only)
 
 
-STREAM_FINDALL = (b"k_stream_findall_fused", b"k_stream_findall", b"k_stream_bits")
+STREAM_FINDALL = (b"k_stream_findall_fused", b"k_stream_findall", b"k_stream_bits", b"k_stream_findall_rows")
 
 
 def _need_gpu():

@@ -207,7 +207,7 @@ ALPHABETS = {
 import contextlib
 
 # findall of a streamable plan: one launch (scan + CSR offsets + spans fused), or scan -> sums -> decode
-STREAM_FINDALL = (b"k_stream_findall_fused", b"k_stream_findall", b"k_stream_bits")
+STREAM_FINDALL = (b"k_stream_findall_fused", b"k_stream_findall", b"k_stream_bits", b"k_stream_findall_rows")
 
 
 @contextlib.contextmanager
@@ -1910,8 +1910,12 @@ def test_fused_findall_equals_three_launch_form(pat, shape):
             with fused_findall(), stream_bits(0):
                 p1, s1, t1 = rx._dev_findall(batch)
                 assert lib.mrx_last_kernel_name() == b"k_stream_findall_fused"
-            with stream_bits(0):
-                p3, s3, t3 = rx._dev_findall(batch)
+            lib.mrx_debug_dense_rows(2)   # (records: a handle that has seen a batch full of matches would take event rows)
+            try:
+                with stream_bits(0):
+                    p3, s3, t3 = rx._dev_findall(batch)
+            finally:
+                lib.mrx_debug_dense_rows(0)
             assert lib.mrx_last_kernel_name() == b"k_stream_findall"
         assert t1 == t3 and torch.equal(p1, p3) and torch.equal(s1[:t1], s3[:t3]), (pat, shape, n, pitch)
         # a span buffer that is too small: what fits is written in order, the need is reported
@@ -2719,7 +2723,7 @@ def test_event_rows_are_chosen_after_a_dense_batch_and_dropped_after_a_sparse_on
     _need_gpu()
     lib = M.load_library()
     rx = M.compile_regex(b"(x|y|foo|bar)+")
-    n, L = 4096, 4096
+    n, L = (1 << 17) + 64, 4096   # (more than 2^17 texts: fewer go by pieces)
     g = torch.Generator(device="cuda")
     g.manual_seed(11)
     al = torch.tensor(list(b"xyfoobar "), dtype=torch.uint8, device="cuda")
@@ -2742,3 +2746,24 @@ def test_event_rows_are_chosen_after_a_dense_batch_and_dropped_after_a_sparse_on
     assert names[2] == b"k_stream_findall_rows", names      # the first call's total has arrived by the third at the latest
     assert names[3] == b"k_stream_findall_rows"             # the sparse batch: the last answer still says dense
     assert names[5] != b"k_stream_findall_rows", names      # ... and its own total says otherwise
+
+
+@pytest.mark.parametrize("pat,repl", [(b"[a-z]+\\d+", b"#"), (b"(\\d{3})(\\d{3})(\\d{4})", b"\\1-\\2-\\3"), (b"hello", b"<bye>"), (b"\\d+", b"")])
+def test_sub_with_known_totals_equals_sub(pat, repl):
+    """mrx_sub_known_dev (DeviceBatch.csr_known / from_texts): the same bytes as mrx_sub_dev, which reads offsets[n] and
+    the longest text from the device first; upper bounds instead of the exact values change nothing either."""
+    _need_gpu()
+    rng = np.random.default_rng(zlib.crc32(pat) + 3)
+    texts = _random_texts(rng, 700, 900, b"abchelo 0123456789-") + [b"", b"hello", b"5551234567", b"ab12" * 500, b"x" * 3000]
+    data, offsets = M.api.pack_texts(texts)
+    d = torch.from_numpy(data).cuda()
+    o = torch.from_numpy(offsets).cuda()
+    rx = M.compile_regex(pat)
+    off0, out0 = rx.sub_dev(repl, M.DeviceBatch(d, o))
+    for end, mx in ((int(offsets[-1]), 3000), (int(offsets[-1]) + 4096, 5000)):
+        off1, out1 = rx.sub_dev(repl, M.DeviceBatch.csr_known(d, o, end, mx))
+        assert torch.equal(off0, off1) and torch.equal(out0, out1)
+    got = out0.cpu().numpy().tobytes()
+    oo = off0.cpu().numpy()
+    for i in (0, 1, 350, 699, 700, 701, 702, 703, 704):
+        assert got[oo[i]:oo[i + 1]] == O.sub(pat, repl, texts[i]), (pat, i)

@@ -39,7 +39,9 @@ def make_batch(text: bytes, csr: bool):
         rot = (torch.arange(lo, hi, device="cuda") * 37) % L
         data[lo:hi, :L] = t2[rot[:, None] + col[None, :]]
     if csr:
-        return M.DeviceBatch(data.reshape(-1), torch.arange(0, (n + 1) * L, L, dtype=torch.int64, device="cuda")), n, L
+        # (the builder of these offsets knows offsets[n] and the longest text: the known-totals entry points)
+        return M.DeviceBatch.csr_known(data.reshape(-1), torch.arange(0, (n + 1) * L, L, dtype=torch.int64, device="cuda"),
+                                       n * L, L), n, L
     return M.DeviceBatch.strided(data.reshape(-1), pitch, length=L), n, L
 
 
