@@ -157,8 +157,21 @@ def test_config5_alternation_at_full_size():
     d = make_alt_batch(n, L, device="cuda")
     rx = M.compile_regex(pat)
     batch = M.DeviceBatch.strided(d.reshape(-1), L, length=L)
-    prefix, spans, total = rx._dev_findall(batch, span_cap=n * 720)
-    assert M.load_library().mrx_last_kernel_name() in STREAM_FINDALL
+    lib = M.load_library()
+    # both forms of the streaming findall at full size: event rows (what a handle takes once it has seen how full of
+    # matches these batches are; checked against the oracle below) and records (round 3's form; must be the same CSR)
+    try:
+        lib.mrx_debug_dense_rows(2)
+        prefix_r, spans_r, total_r = rx._dev_findall(batch, span_cap=n * 720)
+        assert lib.mrx_last_kernel_name() in STREAM_FINDALL and lib.mrx_last_kernel_name() != b"k_stream_findall_rows"
+        lib.mrx_debug_dense_rows(1)
+        prefix, spans, total = rx._dev_findall(batch, span_cap=n * 720)
+        assert lib.mrx_last_kernel_name() == b"k_stream_findall_rows"
+    finally:
+        lib.mrx_debug_dense_rows(0)
+    assert total_r == total and torch.equal(prefix, prefix_r) and torch.equal(spans[:total], spans_r[:total])
+    del prefix_r, spans_r
+    torch.cuda.empty_cache()
     assert total == int(prefix[n].item()) > n * 600
     blk = 1 << 19
     for a in range(0, n, blk):
