@@ -66,6 +66,16 @@ enum {
 };
 
 /* ---- compile (replaces CompiledRegex(pattern), matcher.mojo:964-978) ---------- */
+/* A CONTRACT OF THIS LIBRARY'S OWN -- `$` on the LazyDFA search (search / findall / count / sub of a pattern with `$`
+ * that the reference routes to NFAMatcher: matcher.mojo:401-431).  Upstream's LazyDFA decides whether `$` holds when a
+ * (state, byte) transition is FIRST computed -- it holds iff that byte is the last of the text in hand -- and caches the
+ * answer for every later use, in that call and in every later call on the same CompiledRegex (pikevm.mojo:869-942):
+ * `^[a-z]+$` finds "abc" in a fresh process, nothing in "abcabc", and after that nothing in "abc" either.  A batch
+ * has no call order, so every text of every call is answered AS A FRESHLY COMPILED PATTERN WOULD answer it: the
+ * cache is empty when a text begins and is carried through that text's walks (findall, the match_next calls of one
+ * sub) exactly as upstream carries it.  The oracle restates this (oracle/mrx_ref), tests/test_oracle_golden.py holds
+ * hand traces; no reference test pins it ("parity-unpinned").  match_first / is_match of `$` patterns run on
+ * the reference's OnePass automaton and have no such history. */
 int mrx_compile(const char* pattern, size_t pattern_len, mrx_handle** out);
 /* Options.  MRX_COMPILE_LAZYDFA_SEMANTICS routes the pattern as the reference does when
  * DFAEngine compilation fails (matcher.mojo:666-672): NFAMatcher / LazyDFA, leftmost-longest

@@ -5957,6 +5957,8 @@ struct FindallJob {
   // ... and this call's total on its way (nothing in flight and the shape eligible: else the older answer stands)
   void dense_probe_send() {
     if (!rows_shape || g_dense_rows != 0) return;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;   // (a stream under graph capture: no event of ours in the graph)
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return;
     std::lock_guard<std::mutex> lk(h->tune_mu);
     mrx_handle::DenseProbe& d = h->dense_probe;
     if (d.pending) return;

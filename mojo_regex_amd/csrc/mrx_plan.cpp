@@ -1348,8 +1348,24 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
   if ((d.kind == PLAN_DFA || d.kind == PLAN_LAZY) && hp.why_no_search.empty() && (d.flags & PF_START_ACCEPTING) &&
       !(d.flags & (PF_START_ANCHOR | PF_END_ANCHOR | PF_PURE_LITERAL | PF_EXACT_LITERAL | PF_PREFILTER | PF_HAS_MATCHER |
                    PF_START_DEAD | PF_BITSET | PF_SCAN_ELIGIBLE | PF_BT_SEARCH)) &&
-      d.required_byte < 0 && d.nstates <= 96)
+      d.required_byte < 0 && d.nstates <= 96) {
     d.flags |= PF_STEP_EMPTY;
+    // census for the one-pass form: does a walk ever read beyond its last accepting position?  (Never, when every
+    // state a walk can reach accepts: it dies ON the byte behind its match.)
+    std::vector<uint8_t> seen(d.nstates, 0);
+    std::vector<int> st{0};
+    seen[0] = 1;
+    bool all_acc = true;
+    while (!st.empty()) {
+      const int q = st.back(); st.pop_back();
+      if (!acc[q]) all_acc = false;
+      for (int c = 0; c < 256; ++c) {
+        const int t = T[q][c];
+        if (t >= 0 && !seen[t]) { seen[t] = 1; st.push_back(t); }
+      }
+    }
+    hp.empty_all_accepting = all_acc;
+  }
 
   // The same plain route for a LazyDFA that is walked as a bitset NFA (pikevm.mojo:754-817 over the state
   // sets of pikevm.mojo:497-648): one 64-bit word of live positions per lane, no determinised table.
@@ -1606,7 +1622,7 @@ std::string describe_plan(const HostPlan& hp) {
     << (d.off_stg_pair >= 0 ? " pair_table=1" : "") << "\n";
   o << "device.steppable=" << ((d.flags & PF_STEPPABLE) ? "yes" : (d.flags & PF_STEP_REQ) ? "required-byte route" : "no")
     << " step_search=" << ((d.flags & PF_STEP_SEARCH) ? 1 : 0) << ((d.flags & PF_STEP_BIG) ? " big_table=1" : "")
-    << ((d.flags & PF_BSTEP) ? " bitset=1" : "") << ((d.flags & PF_STEP_EMPTY) ? " empty_matches=1" : "") << "\n";
+    << ((d.flags & PF_BSTEP) ? " bitset=1" : "") << ((d.flags & PF_STEP_EMPTY) ? (hp.empty_all_accepting ? " empty_matches=1 every_state_accepts=1" : " empty_matches=1") : "") << "\n";
   o << "device.first_stream=" << (d.fa_bytes ? "yes" : ("no: " + hp.first_stream_why_not))
     << " fa_nstates=" << d.fa_nstates << " fa_kind=" << d.fa_kind << (hp.first_onepass ? " onepass=yes" : "")
     << (d.off_fa_run >= 0 ? " class_run=1" : "") << "\n";

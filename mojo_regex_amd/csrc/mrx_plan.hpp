@@ -149,6 +149,7 @@ struct DevPlan {
 };
 
 struct HostPlan {
+  bool empty_all_accepting = false;   // PF_STEP_EMPTY plans: every state a walk can reach accepts (a walk never overshoots)
   std::string pattern;
   // routing facts (for mrx_engine_type / mrx_stats / mrx_describe)
   Complexity complexity = CX_SIMPLE;
