@@ -2767,3 +2767,45 @@ def test_sub_with_known_totals_equals_sub(pat, repl):
     oo = off0.cpu().numpy()
     for i in (0, 1, 350, 699, 700, 701, 702, 703, 704):
         assert got[oo[i]:oo[i + 1]] == O.sub(pat, repl, texts[i]), (pat, i)
+
+
+@pytest.mark.parametrize("seed", [20260701, 20260702])
+def test_generated_patterns_event_rows_equal_records(seed):
+    """Every generated pattern whose plan streams: findall by event rows (mrx_debug_dense_rows(1)) against the record form
+    on texts of 2 KiB and 5 KiB built from the pattern's own alphabet -- long single-byte runs, texts that end in a
+    match, a batch that is not a multiple of 64 texts; every automaton form the generator reaches (byte columns, code
+    columns, class tables, pair tables)."""
+    _need_gpu()
+    from pattern_gen import patterns
+    lib = M.load_library()
+    rng = np.random.default_rng(seed)
+    base = np.frombuffer(b"abcxyz019 -@.fobrhelcatdg", dtype=np.uint8)
+    nstream = 0
+    lib.mrx_debug_long_text_kernels(2)
+    try:
+        for p in patterns(seed, 300):
+            pb = p.encode()
+            try:
+                rx = M.compile_regex(pb)
+            except M.RegexSyntaxError:
+                continue
+            if "device.streamable=yes" not in rx.describe():
+                continue
+            nstream += 1
+            lit = np.frombuffer(bytes(c for c in pb if chr(c).isalnum() or c in b" -@."), dtype=np.uint8)
+            al = np.concatenate([base, lit, lit]) if lit.size else base
+            for n, L in ((64 + 9, 2048), (70, 5 * 1024)):
+                arr = rng.choice(al, size=(n, L)).astype(np.uint8)
+                for i in range(0, n, 4):
+                    arr[i, : int(rng.integers(0, L))] = al[int(rng.integers(0, al.size))]
+                batch = M.DeviceBatch.strided(torch.from_numpy(arr).cuda().reshape(-1), L, length=L)
+                lib.mrx_debug_dense_rows(2)
+                pre0, sp0, tot0 = rx._dev_findall(batch)
+                lib.mrx_debug_dense_rows(1)
+                pre1, sp1, tot1 = rx._dev_findall(batch)
+                assert lib.mrx_last_kernel_name() == b"k_stream_findall_rows", p
+                assert tot0 == tot1 and torch.equal(pre0, pre1) and torch.equal(sp0[:tot0], sp1[:tot0]), (p, n, L)
+    finally:
+        lib.mrx_debug_dense_rows(0)
+        lib.mrx_debug_long_text_kernels(0)
+    assert nstream > 40, nstream
