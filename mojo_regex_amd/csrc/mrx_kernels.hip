@@ -2489,7 +2489,10 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_dyn(
     const int32_t* __restrict__ vlen, int64_t n, int32_t* __restrict__ counts, int32_t* __restrict__ wave_nrecs,
     EvRec* __restrict__ recs, int32_t* __restrict__ out_s, int32_t* __restrict__ out_e) {
   static_assert(MODE == ST_RECORDS || MODE == ST_COUNT || MODE == ST_SEARCH, "search modes only");
-  constexpr int CH = 128, kRowPitch = CH + 16, LPR = CH / 16, RPI = 64 / LPR, NL = 64 / RPI;
+#ifndef MRX_DYN_CH
+#define MRX_DYN_CH 128
+#endif
+  constexpr int CH = MRX_DYN_CH, kRowPitch = CH + 16, LPR = CH / 16, RPI = 64 / LPR, NL = 64 / RPI;
   __shared__ __align__(16) uint8_t tiles[kStreamWaves][64 * kRowPitch];
   __shared__ __align__(16) uint16_t col_lds[256];
   __shared__ __align__(16) uint4 pmask[17];   // pmask[x]: the first x bytes of a 16-byte group set
@@ -2551,8 +2554,8 @@ __global__ __launch_bounds__(64 * kStreamWaves) void k_stream_dyn(
       if (t < 0) len = 0;
       if (len > 0) addr = (uintptr_t)(data + o0);
       // (the frame begins at the 128-byte line of the text's first byte: see k_stream_findall)
-      const int m0 = len > 0 ? (int)(addr & 127) : 0;
-      const uintptr_t rb = (addr & ~(uintptr_t)127) - (uintptr_t)shift;
+      const int m0 = len > 0 ? (int)(addr & (CH - 1)) : 0;
+      const uintptr_t rb = (addr & ~(uintptr_t)(CH - 1)) - (uintptr_t)shift;
       len_o = len; mis_o = shift + m0; flen_o = shift + m0 + len;
       // (no text, or an empty one: frame end 0 -- every load of the row falls back to the row's first block)
       *(uint4*)(tile + lane * kRowPitch + CH) =
