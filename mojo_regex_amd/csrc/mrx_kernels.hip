@@ -3127,24 +3127,28 @@ __global__ __launch_bounds__(kBlock) void k_decode(int64_t n, const int32_t* __r
   }
 }
 
-// event rows -> CSR spans (behind k_stream_findall<ST_ROWS>).  A wavefront per text; a round is 128 pairs of event words
-// = 4 KiB of text, two pairs (one 16-byte load) per lane.  What a record carried is derived here: the index of a lane's
-// first span within its text is a prefix sum over the lanes' match-end counts, the walk alive at a lane's first byte began
-// at the last NEWSTART of the lanes in front (a running maximum) -- both carried from round to round.  The spans of a round
-// are contiguous in the output: they are laid out in an LDS tile (16-bit positions, 4 bytes a span) and leave as
-// coalesced 8-byte stores.  The match that ends with the text has no event (the scan counts it): the text's count says
-// whether there is one.  prefix[] is complete before this launch (device_scan over the scan's counts).
+// event rows -> CSR spans (behind k_stream_findall<ST_ROWS>).  G lanes per text (a wavefront, half or quarter of one: 64 / G
+// texts per wavefront); a round is 2 G pairs of event words = 64 G bytes of text, two pairs (one 16-byte load) per lane.
+// What a record carried is derived here: the index of a lane's first span within its text is a prefix sum over the
+// lanes' match-end counts, the walk alive at a lane's first byte began at the last NEWSTART of the lanes in front (a
+// running maximum) -- both carried from round to round.  The spans of a round are contiguous in the output: they are
+// laid out in the text's part of an LDS tile (16-bit positions, 4 bytes a span) and leave as coalesced 8-byte stores.
+// The match that ends with the text has no event (the scan counts it): the text's count says whether there is one.
+// prefix[] is complete before this launch (device_scan over the scan's counts).
 constexpr int kRowsTile = 1024;   // spans per wavefront and pass
+template <int G>
 __global__ __launch_bounds__(kBlock) void k_decode_rows(int64_t n, const uint2* __restrict__ rows, int64_t row_pairs, int npairs,
                                                         int text_len, const int32_t* __restrict__ counts,
                                                         const int64_t* __restrict__ prefix, int32_t* __restrict__ spans,
                                                         int64_t span_cap, int fixed_len) {
+  static_assert(G == 16 || G == 32 || G == 64, "lanes per text");
+  constexpr int TPW = 64 / G, kTile = kRowsTile / TPW;   // texts per wavefront; spans per text and pass
   __shared__ uint32_t tile_all[kBlock / 64][kRowsTile];
-  const int lane = threadIdx.x & 63;
-  uint32_t* tile = tile_all[threadIdx.x >> 6];
-  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
-  auto load_pairs = [&](int64_t i, int p0) {   // pairs p0 + 2 lane, p0 + 2 lane + 1 of text i (zero beyond the text)
-    const int a = p0 + 2 * lane;
+  const int lane = threadIdx.x & 63, gl = lane & (G - 1), grp = lane / G;
+  uint32_t* tile = tile_all[threadIdx.x >> 6] + grp * kTile;
+  const int64_t ngroups = (int64_t)gridDim.x * (blockDim.x >> 6) * TPW;
+  auto load_pairs = [&](int64_t i, int p0) {   // pairs p0 + 2 gl, p0 + 2 gl + 1 of text i (zero beyond the text)
+    const int a = p0 + 2 * gl;
     uint4 q = make_uint4(0, 0, 0, 0);
     if (i < n && a < npairs) {
       q = mrx_ldg((const uint4*)(rows + i * row_pairs + a));   // (row_pairs is even: 16-byte aligned; last use of the words)
@@ -3152,24 +3156,25 @@ __global__ __launch_bounds__(kBlock) void k_decode_rows(int64_t n, const uint2* 
     }
     return q;
   };
-  int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  int64_t i = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * TPW + grp;
   uint4 q_next = load_pairs(i, 0);
   int64_t base_next = i < n ? prefix[i] : 0;
   int total_next = i < n ? counts[i] : 0;
-  for (; i < n; i += nwaves) {
+  // (the trip count is the wavefront's: a group beyond the batch rides along with nothing to do)
+  for (; __any(i < n); i += ngroups) {
     uint4 q = q_next;
     const int64_t base = base_next;
     const int total_i = total_next;
-    if (npairs <= 128) {   // the next text's first round travels while this one is expanded
-      q_next = load_pairs(i + nwaves, 0);
-      base_next = i + nwaves < n ? prefix[i + nwaves] : 0;
-      total_next = i + nwaves < n ? counts[i + nwaves] : 0;
+    if (npairs <= 2 * G) {   // the next text's first round travels while this one is expanded
+      q_next = load_pairs(i + ngroups, 0);
+      base_next = i + ngroups < n ? prefix[i + ngroups] : 0;
+      total_next = i + ngroups < n ? counts[i + ngroups] : 0;
     }
     int carry_cnt = 0, carry_start = 0;
-    for (int p0 = 0; p0 < npairs; p0 += 128) {
+    for (int p0 = 0; p0 < npairs; p0 += 2 * G) {
       if (p0 > 0) q = load_pairs(i, p0);
       const uint32_t W[4] = {q.x, q.y, q.z, q.w};
-      const int pb0 = 32 * (p0 + 2 * lane);
+      const int pb0 = 32 * (p0 + 2 * gl);
       int c = 0, ln = -1;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -3179,16 +3184,16 @@ __global__ __launch_bounds__(kBlock) void k_decode_rows(int64_t n, const uint2* 
       }
       int incl = c, mx = ln;
 #pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const int v = __shfl_up(incl, d), m = __shfl_up(mx, d);
-        if (lane >= d) { incl += v; mx = max(mx, m); }
+      for (int d = 1; d < G; d <<= 1) {
+        const int v = __shfl_up(incl, d, G), m = __shfl_up(mx, d, G);
+        if (gl >= d) { incl += v; mx = max(mx, m); }
       }
-      const int round_total = __shfl(incl, 63);
-      int ex_start = __shfl_up(mx, 1);
-      if (lane == 0) ex_start = -1;
+      const int round_total = __shfl(incl, G - 1, G);
+      int ex_start = __shfl_up(mx, 1, G);
+      if (gl == 0) ex_start = -1;
       const int rstart0 = ex_start >= 0 ? ex_start : carry_start;
       const int before = incl - c;   // spans of this round in front of my first
-      for (int tb = 0; tb < round_total; tb += kRowsTile) {
+      for (int tb = 0; __any(tb < round_total); tb += kTile) {
         int dst = before - tb;
         int rs = rstart0;
 #pragma unroll
@@ -3201,7 +3206,7 @@ __global__ __launch_bounds__(kBlock) void k_decode_rows(int64_t n, const uint2* 
             const uint32_t nsb = ns & ((1u << (2 * kk)) - 1u);   // NEWSTARTs strictly before this EMIT
             int st = nsb ? pb + ((31 - __builtin_clz(nsb)) >> 1) : rs;
             if (fixed_len > 0) st = pb + kk - fixed_len;
-            if (dst >= 0 && dst < kRowsTile) tile[dst] = ((uint32_t)st << 16) | (uint32_t)(pb + kk);
+            if (dst >= 0 && dst < kTile) tile[dst] = ((uint32_t)st << 16) | (uint32_t)(pb + kk);
             ++dst;
             em &= em - 1;
           }
@@ -3210,26 +3215,27 @@ __global__ __launch_bounds__(kBlock) void k_decode_rows(int64_t n, const uint2* 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const int cntp = round_total - tb < kRowsTile ? round_total - tb : kRowsTile;
+        const int left = round_total - tb;
+        const int cntp = left < 0 ? 0 : left < kTile ? left : kTile;
         const int64_t d0 = base + carry_cnt + tb;
-        for (int k = lane; k < cntp; k += 64) {
+        for (int k = gl; k < cntp; k += G) {
           const uint32_t v = tile[k];
           if (d0 + k < span_cap) mrx_stg_span(spans + 2 * (d0 + k), (int)(v >> 16), (int)(v & 0xFFFFu));
         }
         __builtin_amdgcn_wave_barrier();
       }
       carry_cnt += round_total;
-      const int last = __shfl(mx, 63);
+      const int last = __shfl(mx, G - 1, G);
       if (last >= 0) carry_start = last;
     }
-    if (carry_cnt < total_i && lane == 0) {   // the match that runs to the end of the text
+    if (i < n && carry_cnt < total_i && gl == 0) {   // the match that runs to the end of the text
       const int64_t d = base + carry_cnt;
       if (d < span_cap) mrx_stg_span(spans + 2 * d, fixed_len > 0 ? text_len - fixed_len : carry_start, text_len);
     }
-    if (npairs > 128) {
-      q_next = load_pairs(i + nwaves, 0);
-      base_next = i + nwaves < n ? prefix[i + nwaves] : 0;
-      total_next = i + nwaves < n ? counts[i + nwaves] : 0;
+    if (npairs > 2 * G) {
+      q_next = load_pairs(i + ngroups, 0);
+      base_next = i + ngroups < n ? prefix[i + ngroups] : 0;
+      total_next = i + ngroups < n ? counts[i + ngroups] : 0;
     }
   }
 }
@@ -5549,6 +5555,8 @@ struct FindallJob {
     dyn = dyn_ok(h, lay, n) && max_text < (int64_t(1) << kDynShift) &&
           (g_dyn_mode == 1 || csr_total < max_text * n - max_text * n / 8);
     // Event rows: texts of 2 KiB and more at an aligned fixed pitch, one common length that is a multiple of the chunk
+    // (1 KiB texts were measured with sixteen lanes per text: config 4 0.462 -> 0.502 ms, config 2 0.363 -> 0.471 -- per
+    // text the prefix sums and the decode's fixed work outweigh the smaller intermediate; profiles/r04_config5_rows.md)
     // (no byte behind a text is ever walked: the match that ends with the text is the count's business), 16-bit positions.
     rows_shape = !dyn && !lay.offsets && !lay.lens && strided_fast(lay) && span_cap > 0 && !g_split_findall && rec32 &&
                  max_text >= 2048 && max_text <= 65024 && max_text % MRX_STREAM_CHUNK == 0 && g_dense_rows != 2;
@@ -5639,10 +5647,16 @@ struct FindallJob {
   int stream_finish() {
     if (rows) {   // offsets from the scan's counts, then a wavefront per text (k_decode_rows)
       if (int rc = device_scan<int32_t>(d_counts, n, d_prefix, d_total, s)) return rc;
-      const int64_t blocks = (n + (kBlock / 64) - 1) / (kBlock / 64);
-      hipLaunchKernelGGL(k_decode_rows, dim3((unsigned)(blocks < 8 * grid_cap() ? blocks : 8 * grid_cap())), dim3(kBlock), 0, s,
-                         n, (const uint2*)d_rows, row_pairs, (int)(max_text / 32), (int)max_text, (const int32_t*)d_counts,
-                         (const int64_t*)d_prefix, d_spans, span_cap, p.st_fixed_len);
+      // lanes per text by length: a round of 2 G pairs covers 64 G bytes
+      const int G = max_text <= 1024 ? 16 : max_text <= 2048 ? 32 : 64;
+      const int64_t per_block = (kBlock / 64) * (64 / G);
+      const int64_t blocks = (n + per_block - 1) / per_block;
+      const dim3 dg((unsigned)(blocks < 8 * grid_cap() ? blocks : 8 * grid_cap())), db(kBlock);
+#define MRX_DR(GG) hipLaunchKernelGGL(k_decode_rows<GG>, dg, db, 0, s, n, (const uint2*)d_rows, row_pairs, (int)(max_text / 32), \
+                                      (int)max_text, (const int32_t*)d_counts, (const int64_t*)d_prefix, d_spans, span_cap,      \
+                                      p.st_fixed_len)
+      if (G == 16) MRX_DR(16); else if (G == 32) MRX_DR(32); else MRX_DR(64);
+#undef MRX_DR
       HIP_TRY(hipGetLastError());
       return MRX_OK;
     }

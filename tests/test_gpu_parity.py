@@ -2663,13 +2663,13 @@ def test_lazy_end_stepper_ends_a_walk_where_it_meets_the_last_failed_one(pat):
 
 
 @pytest.mark.parametrize("pat", [b"(x|y|foo|bar)+", b"[a-z]+\\d+", b"\\d+", b"hello", b"[0-9a-f]", b"(\\d{3})(\\d{3})(\\d{4})", b"a+b"])
-@pytest.mark.parametrize("L", [2048, 4096, 8192 + 4096])
+@pytest.mark.parametrize("L", [2048, 2048 + 128, 4096, 8192 + 4096])
 def test_findall_by_event_rows_equals_records_and_oracle(pat, L):
     """mrx_debug_dense_rows(1): the scan writes 8 bytes of event words per 32 text bytes at a fixed pitch and
-    k_decode_rows (a wavefront per text) derives starts, indices and the match that ends with the text -- against the
-    record form (mrx_debug_dense_rows(2)) span by span, and against the oracle on a sample.  Texts of one, one and three
-    rounds of 128 pairs; matches across lane, round and text ends; texts without a match; a match every byte; a batch
-    that is not a multiple of 64 texts."""
+    k_decode_rows (32 or 64 lanes per text) derives starts, indices and the match that ends with the text -- against
+    the record form (mrx_debug_dense_rows(2)) span by span, and against the oracle on a sample.  Texts of exactly one round,
+    a round and a bit, and three rounds; matches across lane, round and text ends; texts without a match; a match every
+    byte; a batch that is not a multiple of 64 texts (nor of the texts a wavefront takes)."""
     _need_gpu()
     lib = M.load_library()
     rng = np.random.default_rng(zlib.crc32(pat) + L)
@@ -2794,7 +2794,7 @@ def test_generated_patterns_event_rows_equal_records(seed):
             nstream += 1
             lit = np.frombuffer(bytes(c for c in pb if chr(c).isalnum() or c in b" -@."), dtype=np.uint8)
             al = np.concatenate([base, lit, lit]) if lit.size else base
-            for n, L in ((64 + 9, 2048), (70, 5 * 1024)):
+            for n, L in ((64 + 9, 2048), (70, 5 * 1024), (67, 2048 + 256)):
                 arr = rng.choice(al, size=(n, L)).astype(np.uint8)
                 for i in range(0, n, 4):
                     arr[i, : int(rng.integers(0, L))] = al[int(rng.integers(0, al.size))]
