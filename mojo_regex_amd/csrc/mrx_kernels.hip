@@ -685,7 +685,9 @@ __host__ __device__ inline size_t mwalk_table_bytes(const DevPlan& p) { return (
 //   KW = 4:  R01 = perm(prpr, perm(R23, R01, selA), selB),  R23 = perm(prpr, R23, selC)
 //   both:    L   = perm(prpr + 0x10001, L, selL)                               (low half = last)
 // perm(a, b, sel): result byte k = byte sel[k] of the eight bytes b (0-3) | a (4-7).
-template <int MODE, int KW = 4, int PK = 0>
+// EMP = 1 (PF_MW_EMPTY plans, build_emptywalk(): one walk, every state accepts): entry bit 11 = the empty match at this
+// byte (reported behind the match the byte ends, if it ends one), and every text ends with the empty match at its length.
+template <int MODE, int KW = 4, int PK = 0, int EMP = 0>
 __global__ __launch_bounds__(64 * kWsWaves) void k_mwalk(DevPlan p, const uint8_t* __restrict__ blob, Layout lay,
                                                          int64_t n, int32_t* __restrict__ counts,
                                                          const int64_t* __restrict__ prefix,
@@ -693,6 +695,7 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_mwalk(DevPlan p, const uint8_
                                                          int32_t* __restrict__ out_s, int32_t* __restrict__ out_e) {
   constexpr int CH = 128, kRowPitch = CH + 16, LPR = CH / 16, RPI = 64 / LPR, NL = 64 / RPI;
   static_assert(!PK || ((KW == 2 || KW == 4) && MODE != STEP_COUNT && MODE != STEP_ANY), "packed starts: two or four slots, modes with registers");
+  static_assert(!EMP || (KW == 2 && !PK && (MODE == STEP_COUNT || MODE == STEP_EMIT)), "empty-match walk: count and emit passes");
   __shared__ __align__(16) uint8_t tiles[kWsWaves][64 * kRowPitch];
   __shared__ __align__(16) uint32_t plut[PK ? 512 * (KW == 2 ? 2 : 4) : 4];   // PK: the permute selectors per code
   if (PK) {
@@ -764,7 +767,7 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_mwalk(DevPlan p, const uint8_
       // EMIT after STEP_SLOTS: only texts that overflowed their slots.  wide_slots == 2 (the two-pass findall of these
       // plans; search behind a STEP_ANY pass): counts come from a first pass -- texts without a match are not scanned again
       if (live && (lay.wide_slots == 2 ? counts[i] == 0 : counts[i] <= slot_cap)) fin = true;
-      if (__all(fin)) {
+      if (!EMP && __all(fin)) {   // (EMP: an empty text still has its empty match)
         if (MODE == STEP_SEARCH && live && !skipped) { out_s[i] = -1; out_e[i] = -1; }
         continue;
       }
@@ -821,6 +824,7 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_mwalk(DevPlan p, const uint8_
         if (PK) { if (act && (en & 1u)) report((int)(R01 & 0xFFFFu), (int)(Lr & 0xFFFFu)); }                         \
         else                                                                                                         \
         if (act && (en & 1u)) report(s0, last);      /* the oldest walk ended behind its last accepting position (rare branch) */ \
+        if (EMP) { if (act && (en & 0x800u)) report(pr, pr); }   /* ... and no walk begins on this byte: the empty match here */ \
         /* the start registers move as the entry says; plain selects, no branches (code 0 = stays; a lane that is    \
            not stepping takes code 0 everywhere) */                                                                  \
         const uint32_t ea = ((FULL_) == 2 || act) ? en : 0u;                                                         \
@@ -892,6 +896,7 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_mwalk(DevPlan p, const uint8_
           if ((e >> 10) & 1u) {
             if (PK) report((int)(R01 & 0xFFFFu), (int)(Lr & 0xFFFFu)); else report(s0, last);
           }
+          if (EMP) report(t.len, t.len);   // the last try, at pos == len: the empty match
           fin = true;
         }
       }
@@ -903,6 +908,9 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_mwalk(DevPlan p, const uint8_
     if (PK) { if (!fin && ((e >> 10) & 1u)) report((int)(R01 & 0xFFFFu), (int)(Lr & 0xFFFFu)); }
     else
     if (!fin && ((e >> 10) & 1u)) report(s0, last);   // end of the text: the oldest walk has accepted
+    if (EMP) {   // the last try, at pos == len (the empty text: its only one)
+      if (!fin || (live && !skipped && t.len == 0)) report(t.len, t.len);
+    }
     if (live && !skipped) {
       if (MODE == STEP_COUNT || MODE == STEP_SLOTS || MODE == STEP_ANY) counts[i] = k;
       if (MODE == STEP_SEARCH) { out_s[i] = rs; out_e[i] = re; }
@@ -4424,6 +4432,12 @@ bool mwalk_pk_ok(const Layout& lay, int64_t known_max) {
 }
 template <int MODE, class... Args>
 void mwalk_launch(int kw, bool pk, dim3 g, dim3 b, size_t lds_bytes, hipStream_t s, Args... args) {
+  if constexpr (MODE == STEP_COUNT || MODE == STEP_EMIT) {
+    if (kw == 0) {   // (DevPlan::mw_k == 0: the empty-match walk of a PF_MW_EMPTY plan)
+      hipLaunchKernelGGL((k_mwalk<MODE, 2, 0, 1>), g, b, lds_bytes, s, args...);
+      return;
+    }
+  }
   if constexpr (MODE == STEP_COUNT || MODE == STEP_ANY) {
     if (kw <= 2) hipLaunchKernelGGL((k_mwalk<MODE, 2>), g, b, lds_bytes, s, args...);
     else if (kw == 3) hipLaunchKernelGGL((k_mwalk<MODE, 3>), g, b, lds_bytes, s, args...);
@@ -5434,7 +5448,7 @@ struct FindallJob {
   int32_t* d_counts = nullptr;
   int64_t* d_total = nullptr;
   // ---- route (chosen by choose_route(); the launch macros of this file read these by name) ----
-  bool stream_ok = false, use_req_route = false, wstep_bits = false, wstep_lz = false, wstep_empty = false;
+  bool stream_ok = false, use_req_route = false, wstep_bits = false, wstep_lz = false, wstep_empty = false, mw_empty = false;
   bool mwalk_req = false, wstep_mwalk = false;
   DevPlan pk;                      // what the lane kernels are launched with
   int wstep_mwalk_k = 0;
@@ -5490,11 +5504,13 @@ struct FindallJob {
     wstep_bits = (p.flags & PF_BSTEP) != 0;   // bitset NFA on the lane-per-text stepper
     wstep_lz = (p.flags & PF_LAZY_END) != 0;  // '$' on the LazyDFA search: lane per text only (the cache is the text's)
     // plans with empty matches: count, then emit (nearly every text has more matches than a slot row holds)
-    wstep_empty = (p.flags & PF_STEP_EMPTY) != 0 && !match_next_sequence && g_force_generic < 2;
+    // ... in one pass on k_mwalk when no walk of the plan ever reads beyond its match (PF_MW_EMPTY)
+    mw_empty = (p.flags & PF_MW_EMPTY) != 0 && mwalk_enabled() && !match_next_sequence && g_force_generic < 2;
+    wstep_empty = (p.flags & PF_STEP_EMPTY) != 0 && !match_next_sequence && g_force_generic < 2 && !mw_empty;
     // several walks in one pass instead of the restart-per-position loop (plain route; sub's match_next sequence is
     // the same list of matches, but a memchr-prefiltered match_next is not the plain search)
     mwalk_req = use_req_route && (p.flags & PF_MWALK_REQ) && mwalk_enabled();
-    wstep_mwalk = (mwalk_req || (mwalk_on(p) && !use_req_route)) && !wstep_bits && !wstep_empty &&
+    wstep_mwalk = (mwalk_req || (mwalk_on(p) && !use_req_route) || mw_empty) && !wstep_bits && !wstep_empty &&
                   !(match_next_sequence && (p.flags & PF_PREFILTER));
     pk = mwalk_req ? mwalk_req_plan(p) : p;
     wstep_mwalk_k = pk.mw_k;
@@ -5818,7 +5834,7 @@ struct FindallJob {
         return MRX_OK;
       }
     }
-    if (step_ok && !wstep_bits && !wstep_empty && !t_in_pieces && !wstep_lz) {
+    if (step_ok && !wstep_bits && !wstep_empty && !mw_empty && !t_in_pieces && !wstep_lz) {
       if (int rc = req_wave_pays(lay, n, use_req_route, s, &req_wave, (p.flags & PF_STEP_BIG) ? nullptr : &step_split,
                                  (p.flags & PF_STEP_BIG) != 0, wstep_mwalk, backset_on(p) && !wstep_mwalk))
         return rc;
@@ -6835,9 +6851,10 @@ static int run_count_any(const mrx_handle* h, const Layout& lay, int64_t n, int3
     const bool use_req_route = (h->hp.dev.flags & PF_STEP_REQ) != 0;
     const bool wstep_bits = (h->hp.dev.flags & PF_BSTEP) != 0;
     const bool wstep_lz = (h->hp.dev.flags & PF_LAZY_END) != 0;
-    const bool wstep_empty = (h->hp.dev.flags & PF_STEP_EMPTY) != 0 && g_force_generic < 2;
+    const bool mw_empty = (h->hp.dev.flags & PF_MW_EMPTY) != 0 && mwalk_enabled() && g_force_generic < 2;
+    const bool wstep_empty = (h->hp.dev.flags & PF_STEP_EMPTY) != 0 && g_force_generic < 2 && !mw_empty;
     const bool mwalk_req = use_req_route && (h->hp.dev.flags & PF_MWALK_REQ) && mwalk_enabled();
-    const bool wstep_mwalk = (mwalk_req || (mwalk_on(h->hp.dev) && !use_req_route)) && !wstep_bits && !wstep_empty;
+    const bool wstep_mwalk = (mwalk_req || (mwalk_on(h->hp.dev) && !use_req_route) || mw_empty) && !wstep_bits && !wstep_empty;
     const DevPlan pk = mwalk_req ? mwalk_req_plan(h->hp.dev) : h->hp.dev;
     const int wstep_mwalk_k = pk.mw_k;
     const bool wstep_mwalk_pk = false;   // (count keeps no start registers)

@@ -303,6 +303,80 @@ bool build_multiwalk(const SearchAutomaton& s, MultiWalk& mw, std::string& why) 
   return true;
 }
 
+// Empty matches in one pass (PF_MW_EMPTY).  The reference's loop (dfa.mojo:2118-2130 / pikevm.mojo:805-817): try at pos --
+// the start state accepts, so every try matches --, report (pos, end), resume at end, or one byte on after an empty
+// match; the last try is at pos == len.  When EVERY state a walk can reach accepts, a walk dies ON the byte behind its
+// match: nothing is read twice, one walk at a time is the whole search, and a byte sees at most two reports -- the match
+// it ends (start, pos) and, when no walk can begin on it either, the empty match (pos, pos).  In k_mwalk's entry format:
+// configuration = the walk's state (0: nothing consumed yet); bit 0 = the oldest walk ends behind its last accepting
+// position (report (start, last): every step accepts, so last is this byte's position), bit 1 = accepts now, bits 2-4 =
+// 4: the start register takes this byte's position, bit 10 = the walk has consumed something (reported at the text's
+// end), bit 11 = an empty match at this byte.  The empty match at len is the kernel's (PF_MW_EMPTY).
+bool build_emptywalk(const SearchAutomaton& s, MultiWalk& mw, std::string& why) {
+  std::vector<int> rep;
+  {
+    std::map<std::vector<int>, int> seen;
+    for (int c = 0; c < 256; ++c) {
+      std::vector<int> col(s.n);
+      for (int q = 0; q < s.n; ++q) col[q] = s.next[q][c];
+      auto it = seen.find(col);
+      if (it == seen.end()) { it = seen.emplace(col, (int)rep.size()).first; rep.push_back(c); }
+      mw.cls[c] = (uint8_t)it->second;
+    }
+  }
+  mw.ncls = (int)rep.size();
+  if (mw.ncls > 64) { why = "empty-match walk: more than 64 byte classes"; return false; }
+  mw.cshift = 0;
+  while ((1 << mw.cshift) < mw.ncls) ++mw.cshift;
+  const int ncp = 1 << mw.cshift;
+  // configurations: 0 = nothing consumed yet (the walk stands in the start state at the search position), then the
+  // states a walk can be in after a byte (the start state among them when the table loops back into it)
+  std::vector<int> id(s.n, -1), order;
+  auto cfg_of = [&](int t) {
+    if (id[t] < 0) { id[t] = 1 + (int)order.size(); order.push_back(t); }
+    return id[t];
+  };
+  for (int k = 0; k < mw.ncls; ++k)
+    if (s.next[0][rep[k]] >= 0) cfg_of(s.next[0][rep[k]]);
+  for (size_t i = 0; i < order.size(); ++i)
+    for (int k = 0; k < mw.ncls; ++k) {
+      const int t = s.next[order[i]][rep[k]];
+      if (t >= 0) cfg_of(t);
+    }
+  mw.ncfg = 1 + (int)order.size();
+  if ((int64_t)mw.ncfg * ncp > 8192 || ((((uint64_t)mw.ncfg) << mw.cshift) >> 16) != 0) {
+    why = "empty-match walk: table beyond the LDS budget";
+    return false;
+  }
+  mw.kmax = 1;
+  mw.tab.assign((size_t)mw.ncfg * ncp, 0);
+  for (int ci = 0; ci < mw.ncfg; ++ci) {
+    const bool fresh = ci == 0;
+    const int q = fresh ? 0 : order[ci - 1];
+    for (int k = 0; k < mw.ncls; ++k) {
+      const int c = rep[k];
+      uint32_t e = 0;
+      int t = s.next[q][c];
+      if (t < 0) {               // the walk dies on this byte
+        if (!fresh) {            // ... behind a match: reported, and the search resumes ON this byte
+          e |= 1u;
+          t = s.next[0][c];
+        }
+        if (t < 0) e |= 1u << 11;   // no walk begins on it either: the empty match here, the search resumes one byte on
+      }
+      int nid = 0;
+      if (t >= 0) {
+        nid = id[t];
+        e |= 2u | (1u << 10);                    // consumed and accepting
+        if (fresh || (e & 1u)) e |= 4u << 2;     // a walk began on this byte
+      }
+      e |= ((uint32_t)nid << mw.cshift) << 16;
+      mw.tab[(size_t)ci * ncp + k] = e;
+    }
+  }
+  return true;
+}
+
 // ---- where do matches begin?  (backward table, DevPlan::off_bk_*) -----------------------------------------------------
 // The restart-per-position search spends its time on walks that fail.  Whether the walk from position s succeeds
 // does not depend on the search's history -- only on the text from s on -- so it can be known for EVERY s before the
@@ -1365,6 +1439,30 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
       }
     }
     hp.empty_all_accepting = all_acc;
+    if (all_acc) {
+      SearchAutomaton sa;
+      sa.n = d.nstates;
+      sa.next = T;
+      sa.acc = acc;
+      sa.allowed.fill(1);
+      MultiWalk mw;
+      std::string why;
+      if (build_emptywalk(sa, mw, why)) {
+        align(hp.blob, 16);
+        d.off_mw_cls = (int)hp.blob.size();
+        put(hp.blob, mw.cls.data(), 256);
+        d.off_mw_tab = (int)hp.blob.size();
+        put(hp.blob, mw.tab.data(), mw.tab.size() * 4);
+        d.mw_ncfg = mw.ncfg;
+        d.mw_cshift = mw.cshift;
+        d.mw_k = 0;   // (0 = the empty-match walk: k_mwalk<., 2, 0, EMP>)
+        d.mw_bytes = 256 + (int)mw.tab.size() * 4;
+        d.flags |= PF_MW_EMPTY;
+        align(hp.blob, 16);
+      } else {
+        hp.mwalk_why_not = why;
+      }
+    }
   }
 
   // The same plain route for a LazyDFA that is walked as a bitset NFA (pikevm.mojo:754-817 over the state
@@ -1622,7 +1720,8 @@ std::string describe_plan(const HostPlan& hp) {
     << (d.off_stg_pair >= 0 ? " pair_table=1" : "") << "\n";
   o << "device.steppable=" << ((d.flags & PF_STEPPABLE) ? "yes" : (d.flags & PF_STEP_REQ) ? "required-byte route" : "no")
     << " step_search=" << ((d.flags & PF_STEP_SEARCH) ? 1 : 0) << ((d.flags & PF_STEP_BIG) ? " big_table=1" : "")
-    << ((d.flags & PF_BSTEP) ? " bitset=1" : "") << ((d.flags & PF_STEP_EMPTY) ? (hp.empty_all_accepting ? " empty_matches=1 every_state_accepts=1" : " empty_matches=1") : "") << "\n";
+    << ((d.flags & PF_BSTEP) ? " bitset=1" : "") << ((d.flags & PF_STEP_EMPTY) ? (hp.empty_all_accepting ? " empty_matches=1 every_state_accepts=1" : " empty_matches=1") : "")
+    << ((d.flags & PF_MW_EMPTY) ? " empty_walk=1" : "") << "\n";
   o << "device.first_stream=" << (d.fa_bytes ? "yes" : ("no: " + hp.first_stream_why_not))
     << " fa_nstates=" << d.fa_nstates << " fa_kind=" << d.fa_kind << (hp.first_onepass ? " onepass=yes" : "")
     << (d.off_fa_run >= 0 ? " class_run=1" : "") << "\n";

@@ -58,6 +58,10 @@ enum PlanFlags : uint32_t {
                                 // that succeed (k_backscan + k_wstep<., 0, 0, 0, 1>)
   PF_LAZY_END = 1u << 23,       // '$' program on the LazyDFA search: transition rows nstates/2.. are the "computed at the
                                 // text's end" variants, chosen per text as the lazy cache would have them (generic kernels only)
+  PF_MW_EMPTY = 1u << 24,       // PF_STEP_EMPTY plan whose walks never read beyond their last accepting position (every
+                                // reachable state accepts): findall / count in one pass on k_mwalk, one walk, up to two
+                                // reports per byte -- the match that a byte ends, and the empty match at that byte when
+                                // no walk can begin on it (DevPlan::off_mw_*; build_emptywalk())
   PF_STREAM_SEARCH = 1u << 11   // search / sub / captures may use the streaming kernel too (findall and
                                 // count may whenever PF_STREAMABLE is set): not with a memchr prefilter,
                                 // which only match_next consults (matcher.mojo:784-796)

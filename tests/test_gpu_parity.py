@@ -1756,11 +1756,14 @@ def test_stepper_on_fixed_pitch_batches(pat, n, pitch, var, mw):
 
 
 @pytest.mark.parametrize("pat", [b"z*", b"x*", b"(abc)*", b"a+b*", b"", b"a**", b"http?", b"ca*t", b"(?:abc)?", b"cat|(dog){0,2}\\d?",
-                                 b"1{2}.{3}|hello|xy|(?:abc)?", b"(ab|cd)*", b"(?:a|b)*c?", b"x?y?", b"(foo)?(bar)?"])
+                                 b"1{2}.{3}|hello|xy|(?:abc)?", b"(ab|cd)*", b"(?:a|b)*c?", b"x?y?", b"(foo)?(bar)?",
+                                 b"\\d*", b"[a-c]*x?", b"\\s?", b"a{0,2}", b"[abc]*[xyz]*", b"b{0,2}c?"])
 def test_empty_match_plans_on_the_stepper(pat):
     """Plans whose start state accepts and that have no first-byte matcher (dfa.mojo:2118-2130,
     pikevm.mojo:805-817): every position yields a match, possibly empty; findall / count run the windowed
-    stepper's EMPTY form (count, then emit) -- against the literal restatement on every text and the oracle."""
+    stepper's EMPTY form (count, then emit) -- or, when no walk of the plan ever reads beyond its match (every state
+    accepts: `empty_walk=1`), ONE pass on k_mwalk with up to two reports per byte (round 4) -- against the literal
+    restatement on every text, the stepper, and the oracle."""
     _need_gpu()
     rx = M.compile_regex(pat)
     d = rx.describe()
@@ -1786,7 +1789,16 @@ def test_empty_match_plans_on_the_stepper(pat):
         assert lists[i] == O.findall(pat, texts[i]), (pat, texts[i])
     for t, got in zip(texts[-22:], lists[-22:]):
         assert got == O.findall(pat, t), (pat, t)
-    if "empty_matches=1" in d:
+    if "empty_walk=1" in d:
+        assert used == b"k_mwalk" and used_cnt == b"k_mwalk", (used, used_cnt)
+        lib.mrx_debug_multiwalk(2)   # the stepper's EMPTY form on the same batch
+        try:
+            assert rx.findall_lists(texts) == lists, pat
+            assert lib.mrx_last_kernel_name() == b"k_estep_count"
+            assert (rx.count(batch).cpu().numpy() == cnt).all(), pat
+        finally:
+            lib.mrx_debug_multiwalk(0)
+    elif "empty_matches=1" in d:
         assert used == b"k_estep_count" and used_cnt == b"k_estep_count", (used, used_cnt)
     # fixed pitch, and the C ABI's capacity protocol on a batch where nearly every byte is a match
     if "empty_matches=1" in d:
