@@ -4433,7 +4433,7 @@ bool mwalk_pk_ok(const Layout& lay, int64_t known_max) {
 template <int MODE, class... Args>
 void mwalk_launch(int kw, bool pk, dim3 g, dim3 b, size_t lds_bytes, hipStream_t s, Args... args) {
   if constexpr (MODE == STEP_COUNT || MODE == STEP_EMIT) {
-    if (kw == 0) {   // (DevPlan::mw_k == 0: the empty-match walk of a PF_MW_EMPTY plan)
+    if (kw < 0) {   // (DevPlan::mw_k == -1: the empty-match walk of a PF_MW_EMPTY plan; 0 is a table no walk ever enters)
       hipLaunchKernelGGL((k_mwalk<MODE, 2, 0, 1>), g, b, lds_bytes, s, args...);
       return;
     }

@@ -1455,7 +1455,7 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
         put(hp.blob, mw.tab.data(), mw.tab.size() * 4);
         d.mw_ncfg = mw.ncfg;
         d.mw_cshift = mw.cshift;
-        d.mw_k = 0;   // (0 = the empty-match walk: k_mwalk<., 2, 0, EMP>)
+        d.mw_k = -1;   // (-1 = the empty-match walk: k_mwalk<., 2, 0, EMP>)
         d.mw_bytes = 256 + (int)mw.tab.size() * 4;
         d.flags |= PF_MW_EMPTY;
         align(hp.blob, 16);

@@ -2821,3 +2821,19 @@ def test_generated_patterns_event_rows_equal_records(seed):
         lib.mrx_debug_dense_rows(0)
         lib.mrx_debug_long_text_kernels(0)
     assert nstream > 40, nstream
+
+
+def test_multiwalk_table_that_no_walk_ever_enters():
+    """`[^0-9]id\\s+baz`: the first-byte filter (digits: A.6's "later transition overwrites" quirk) allows no byte the
+    start row has a transition on, so the multi-walk table has one configuration and zero walks (mw_walks=0).  Found by
+    the round-4 fuzz when 0 was briefly the marker of the empty-match walk: sub appended a replacement to every text."""
+    _need_gpu()
+    pat = b"[^0-9]id\\s+baz"
+    rx = M.compile_regex(pat)
+    assert "mw_walks=0" in rx.describe()
+    rng = np.random.default_rng(5)
+    texts = _random_texts(rng, 200, 60, b"abcidz 0129-baz.") + [b"", b"xid baz", b"0id  baz", b".id\tbaz 1id baz"]
+    assert rx.findall_lists(texts) == [O.findall(pat, t) for t in texts]
+    assert rx.sub(b"#", texts) == [O.sub(pat, b"#", t) for t in texts]
+    batch = M.DeviceBatch.from_texts(texts)
+    assert rx.count(batch).cpu().tolist() == [len(O.findall(pat, t)) for t in texts]
