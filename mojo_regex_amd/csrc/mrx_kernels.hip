@@ -687,6 +687,10 @@ __host__ __device__ inline size_t mwalk_table_bytes(const DevPlan& p) { return (
 // perm(a, b, sel): result byte k = byte sel[k] of the eight bytes b (0-3) | a (4-7).
 // EMP = 1 (PF_MW_EMPTY plans, build_emptywalk(): one walk, every state accepts): entry bit 11 = the empty match at this
 // byte (reported behind the match the byte ends, if it ends one), and every text ends with the empty match at its length.
+// EMP = 2 (DevPlan::mw_k == -2, build_emptywalk2()): walks that read up to three bytes beyond their match.  64-bit
+// entries: low word bit 0 report (start, last) registers, bit 1 last = pos + 1, bits 2-4 / 5-7 the entry that takes over as
+// the oldest walk (start = pos - a, last = start + len), bits 8-10 how many dead tries are reported, bits 16.. next row;
+// high word: their (a, len), six bits each.  end[config] behind the table: the same at the end of the text.
 template <int MODE, int KW = 4, int PK = 0, int EMP = 0>
 __global__ __launch_bounds__(64 * kWsWaves) void k_mwalk(DevPlan p, const uint8_t* __restrict__ blob, Layout lay,
                                                          int64_t n, int32_t* __restrict__ counts,
@@ -696,6 +700,7 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_mwalk(DevPlan p, const uint8_
   constexpr int CH = 128, kRowPitch = CH + 16, LPR = CH / 16, RPI = 64 / LPR, NL = 64 / RPI;
   static_assert(!PK || ((KW == 2 || KW == 4) && MODE != STEP_COUNT && MODE != STEP_ANY), "packed starts: two or four slots, modes with registers");
   static_assert(!EMP || (KW == 2 && !PK && (MODE == STEP_COUNT || MODE == STEP_EMIT)), "empty-match walk: count and emit passes");
+  static_assert(EMP >= 0 && EMP <= 2, "0: multi-walk table, 1: one walk that never overshoots, 2: walks with pending tries behind them");
   __shared__ __align__(16) uint8_t tiles[kWsWaves][64 * kRowPitch];
   __shared__ __align__(16) uint32_t plut[PK ? 512 * (KW == 2 ? 2 : 4) : 4];   // PK: the permute selectors per code
   if (PK) {
@@ -724,7 +729,7 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_mwalk(DevPlan p, const uint8_
   typedef __attribute__((address_space(3))) const uint8_t lds_cu8;
   typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
   const uint32_t lds_base = (uint32_t)(uintptr_t)lds;   // (the low half of a flat LDS address is the LDS offset)
-  const bool pre = p.mw_cshift <= 6 && lds_base + (uint32_t)p.mw_bytes <= 65536u;
+  const bool pre = EMP != 2 && p.mw_cshift <= 6 && lds_base + (uint32_t)p.mw_bytes <= 65536u;   // (EMP == 2: 64-bit entries, as stored)
   {
     const uint32_t* src = (const uint32_t*)(blob + p.off_mw_cls);   // cls[256] | tab[...], contiguous and 16-byte aligned
     uint32_t* dst = (uint32_t*)lds;
@@ -737,6 +742,8 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_mwalk(DevPlan p, const uint8_
   __syncthreads();
   const uint8_t* clsT = lds;
   const uint32_t* tab = (const uint32_t*)(lds + 256);
+  const uint2* tab64 = (const uint2*)(lds + 256);                                        // EMP == 2
+  const uint2* end64 = tab64 + ((size_t)p.mw_ncfg << p.mw_cshift);                       // ... one entry per configuration
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint8_t* tile = tiles[wave];
   const int seg = lane % LPR, rsub = lane / LPR;
@@ -790,6 +797,24 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_mwalk(DevPlan p, const uint8_
       if (MODE == STEP_ANY) fin = true;
       ++k;
     };
+    // EMP == 2: one entry -- W0's match, the dead tries the chase passes, the try that takes over, the next row
+    auto ew2_apply = [&](const uint2 en2, const int base, const bool step) {
+      if (MODE == STEP_COUNT) {
+        k += (int)(en2.x & 1u) + (int)((en2.x >> 8) & 7u);
+      } else {
+        if (en2.x & 1u) report(s0, last);
+        uint32_t rf = en2.y;
+        for (int nrep = (int)((en2.x >> 8) & 7u); nrep > 0; --nrep) {
+          const int st = base - (int)(rf & 7u);
+          report(st, st + (int)((rf >> 3) & 7u));
+          rf >>= 6;
+        }
+        const int ta = (int)((en2.x >> 2) & 7u);
+        if (ta) { s0 = base - (ta - 1); last = s0 + (int)((en2.x >> 5) & 7u); }
+        else if (en2.x & 2u) last = base + 1;
+      }
+      if (step) e = en2.x;
+    };
     const uint8_t* myrow = tile + lane * kRowPitch;
     uint4 v[NL];
 #define MRX_MW_LOAD(CB)                                                                   \
@@ -814,6 +839,10 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_mwalk(DevPlan p, const uint8_
 #define MRX_MW_BYTE(BYTE_, F_, FULL_, PRE_)                                                                          \
       do {                                                                                                           \
         const int f = (F_);                           /* frame position, the same for every lane */                  \
+        if constexpr (EMP == 2) {                                                                                    \
+          if (!fin && f >= mis && f < end) ew2_apply(tab64[(e >> 16) + clsT[(BYTE_)]], f - mis, true);               \
+          break;                                                                                                     \
+        }                                                                                                            \
         /* FULL_ = 2 (search): a lane that has its answer keeps stepping on whatever its row holds -- its registers   \
            are dead, only the report is guarded */                                                                   \
         const bool act = (FULL_) == 2 ? !fin : ((FULL_) || (!fin && f >= mis && f < end));                           \
@@ -893,6 +922,9 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_mwalk(DevPlan p, const uint8_
         }
         if (MODE != STEP_COUNT && !all_full && !fin && f0 + 16 >= end) {
           // the text ended in this group: its last report now (the oldest walk has accepted), then the lane rides along
+          if constexpr (EMP == 2) {
+            ew2_apply(end64[(e >> 16) >> p.mw_cshift], t.len, false);   // every walk dies behind the last byte
+          } else
           if ((e >> 10) & 1u) {
             if (PK) report((int)(R01 & 0xFFFFu), (int)(Lr & 0xFFFFu)); else report(s0, last);
           }
@@ -905,6 +937,9 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_mwalk(DevPlan p, const uint8_
       if (__all(fin || wb + CH >= end)) break;
     }
 #undef MRX_MW_LOAD
+    if constexpr (EMP == 2) {
+      if (!fin) ew2_apply(end64[(e >> 16) >> p.mw_cshift], t.len, false);
+    } else
     if (PK) { if (!fin && ((e >> 10) & 1u)) report((int)(R01 & 0xFFFFu), (int)(Lr & 0xFFFFu)); }
     else
     if (!fin && ((e >> 10) & 1u)) report(s0, last);   // end of the text: the oldest walk has accepted
@@ -4433,6 +4468,10 @@ bool mwalk_pk_ok(const Layout& lay, int64_t known_max) {
 template <int MODE, class... Args>
 void mwalk_launch(int kw, bool pk, dim3 g, dim3 b, size_t lds_bytes, hipStream_t s, Args... args) {
   if constexpr (MODE == STEP_COUNT || MODE == STEP_EMIT) {
+    if (kw == -2) {   // (PF_MW_EMPTY, walks that read beyond their match: build_emptywalk2())
+      hipLaunchKernelGGL((k_mwalk<MODE, 2, 0, 2>), g, b, lds_bytes, s, args...);
+      return;
+    }
     if (kw < 0) {   // (DevPlan::mw_k == -1: the empty-match walk of a PF_MW_EMPTY plan; 0 is a table no walk ever enters)
       hipLaunchKernelGGL((k_mwalk<MODE, 2, 0, 1>), g, b, lds_bytes, s, args...);
       return;
@@ -7204,6 +7243,12 @@ void mrx_debug_stream_bits_trace(int64_t* d_trace) { mrx::stream_bits_set_trace(
 void mrx_debug_dynamic_texts(int mode) { g_dyn_mode = mode < 0 ? 0 : mode > 2 ? 0 : mode; }
 void mrx_debug_split_findall(int on) { g_split_findall = on ? 1 : 0; }
 void mrx_debug_dense_rows(int mode) { g_dense_rows = mode; }
+int mrx_testing_emptywalk2_findall(const mrx_handle* h, const uint8_t* text, int len, int32_t* spans, int cap) {
+  if (!h || !h->hp.ew2_ok || len < 0) return -1;
+  const std::vector<std::pair<int, int>> v = emptywalk2_run(h->hp.ew2, text, len);
+  for (size_t k = 0; k < v.size() && (int)k < cap; ++k) { spans[2 * k] = v[k].first; spans[2 * k + 1] = v[k].second; }
+  return (int)v.size();
+}
 void mrx_debug_subs_group(int g) { g_subs_group = (g == 0 || g == 16 || g == 32 || g == 64 || g == 256) ? g : -1; }
 void mrx_debug_litscan_pieces(int mode) { g_litscan_pieces = (mode == 0 || mode == 1) ? mode : 2; }
 void mrx_debug_multiwalk(int mode) { g_mwalk_mode = mode == 2 ? 2 : 0; g_mwalk_pk = mode == 3 ? 0 : 1; }

@@ -377,6 +377,144 @@ bool build_emptywalk(const SearchAutomaton& s, MultiWalk& mw, std::string& why) 
   return true;
 }
 
+// The general form (PF_MW_EMPTY with DevPlan::mw_k == -2): walks that read up to three bytes beyond their last accepting
+// position (`(ab)*`, `(foo)?x*`).  When such a walk dies at byte p the reference resumes at its match's end (or one byte
+// behind its start after an empty match) and tries again from there -- over bytes this pass has already seen.  So the
+// tries that MAY be asked for run beside the oldest walk W0: one per position from W0's resume point R up to p, each
+// alive (its state, how far its match reaches) or dead (how far its match reached).  A configuration is W0's state and
+// that list (at most three entries); W0's start and match end are the lane's registers.  Per byte: every walk steps, a
+// walk begins on the byte; when W0 accepts, the list is dropped (every entry began inside its match); when W0 dies, its
+// match is reported and the list is chased as the reference's loop would: a dead entry is reported and skipped past, the
+// first live entry reached takes over as W0 (the entries in front of ITS resume point are dropped), and when the chase
+// runs off the list the next byte starts afresh.  Entry, 64 bits: bit 0 report W0 (start, last registers), bit 1 W0
+// accepts here, bits 2-4 a + 1 / bits 5-7 len of the entry that takes over (start = pos - a, last = start + len; 0: none),
+// bits 8-10 how many dead entries are reported, bits 16-31 the next configuration; high word: their (a, len) pairs, six
+// bits each, in report order.  end[config]: the same for the end of the text (every walk dies; a relative to len); the
+// empty match at len is the kernel's.
+bool build_emptywalk2(const SearchAutomaton& s, EmptyWalk2& ew, std::string& why) {
+  constexpr int kSlots = 3;
+  std::vector<int> rep;
+  {
+    std::map<std::vector<int>, int> seen;
+    for (int c = 0; c < 256; ++c) {
+      std::vector<int> col(s.n);
+      for (int q = 0; q < s.n; ++q) col[q] = s.next[q][c];
+      auto it = seen.find(col);
+      if (it == seen.end()) { it = seen.emplace(col, (int)rep.size()).first; rep.push_back(c); }
+      ew.cls[c] = (uint8_t)it->second;
+    }
+  }
+  ew.ncls = (int)rep.size();
+  if (ew.ncls > 64) { why = "empty-match walk: more than 64 byte classes"; return false; }
+  ew.cshift = 0;
+  while ((1 << ew.cshift) < ew.ncls) ++ew.cshift;
+  const int ncp = 1 << ew.cshift;
+  struct Slot { int state; int rel; };   // state < 0: dead; rel: match length so far
+  using Key = std::vector<int>;          // {q0, state, rel, state, rel, ...}; {-1}: nothing consumed yet (fresh)
+  std::map<Key, int> ids;
+  std::vector<Key> cfgs;
+  auto id_of = [&](const Key& k) {
+    auto it = ids.find(k);
+    if (it == ids.end()) { it = ids.emplace(k, (int)cfgs.size()).first; cfgs.push_back(k); }
+    return it->second;
+  };
+  id_of(Key{-1});
+  // the chase behind W0's death: list[idx] is the try at position R + idx; reports go to `out` as (a, len) with a = base - position
+  auto chase = [&](const std::vector<Slot>& list, int base_minus_R, std::vector<std::pair<int, int>>& out, int* take_idx) {
+    *take_idx = -1;
+    int idx = 0;
+    while (idx < (int)list.size()) {
+      if (list[idx].state >= 0) { *take_idx = idx; return; }
+      out.push_back({base_minus_R - idx, list[idx].rel});
+      idx += list[idx].rel > 0 ? list[idx].rel : 1;
+    }
+  };
+  std::vector<std::vector<uint64_t>> rows;
+  for (size_t ci = 0; ci < cfgs.size(); ++ci) {
+    if ((int64_t)cfgs.size() * (ncp + 1) > 8000) { why = "empty-match walk: configuration table beyond the LDS budget"; return false; }
+    const Key cur = cfgs[ci];
+    const bool fresh = cur[0] < 0;
+    const int q0 = fresh ? 0 : cur[0];
+    std::vector<Slot> slots;
+    for (size_t j = 1; j + 1 < cur.size(); j += 2) slots.push_back({cur[j], cur[j + 1]});
+    const int m = (int)slots.size();   // tries at positions R .. p - 1, R = p - m
+    std::vector<uint64_t> row(ncp + 1, 0);
+    for (int k = 0; k <= ew.ncls; ++k) {
+      const bool at_end = k == ew.ncls;   // the virtual step behind the last byte: every walk dies, none begins
+      const int c = at_end ? 0 : rep[k];
+      uint64_t e = 0;
+      std::vector<Slot> list;
+      for (int j = 0; j < m; ++j) {
+        Slot sl = slots[j];
+        if (sl.state >= 0) {
+          const int t = at_end ? -1 : s.next[sl.state][c];
+          if (t < 0) sl.state = -1;
+          else { sl.state = t; if (s.acc[t]) sl.rel = (m - j) + 1; }   // its start is p - (m - j): the match now ends behind p
+        }
+        list.push_back(sl);
+      }
+      if (!at_end) {
+        const int tn = s.next[0][c];
+        list.push_back(tn < 0 ? Slot{-1, 0} : Slot{tn, s.acc[tn] ? 1 : 0});
+      }
+      const int t0 = at_end ? -1 : s.next[q0][c];
+      Key nk;
+      if (fresh) {
+        // the try at p is the newest list entry itself
+        const Slot me = list.back();
+        if (at_end) { nk = Key{-1}; }
+        else if (me.state < 0) { e |= (uint64_t)1 << 8; e |= (uint64_t)(0 | (0 << 3)) << 32; nk = Key{-1}; }   // the empty match at p
+        else {
+          e |= 2u * (s.acc[me.state] ? 1 : 0);
+          e |= (uint64_t)(0 + 1) << 2;                       // takes over: start = p ...
+          e |= (uint64_t)(s.acc[me.state] ? 1 : 0) << 5;     // ... last = start + rel
+          nk = Key{me.state};   // (no entries: its resume point is p + 1 either way)
+        }
+      } else if (t0 >= 0 && s.acc[t0]) {
+        e |= 2u;
+        nk = Key{t0};
+      } else if (t0 >= 0) {
+        if ((int)list.size() > kSlots) { why = "empty-match walk: a walk reads more than three bytes beyond its last accepting position"; return false; }
+        nk = Key{t0};
+        for (const Slot& sl : list) { nk.push_back(sl.state); nk.push_back(sl.rel); }
+      } else {
+        e |= 1u;   // W0's match
+        std::vector<std::pair<int, int>> out;
+        int take = -1;
+        // positions: list[idx] is at R + idx with R = p - m; relative to base (p, or len = p at the end): a = base - R - idx = m - idx
+        chase(list, m, out, &take);
+        if (out.size() > 4) { why = "empty-match walk: more than four reports on one byte"; return false; }
+        e |= (uint64_t)out.size() << 8;
+        for (size_t r = 0; r < out.size(); ++r) e |= (uint64_t)((out[r].first & 7) | ((out[r].second & 7) << 3)) << (32 + 6 * r);
+        if (take >= 0) {
+          const Slot w = list[take];
+          const int a = m - take;
+          e |= (uint64_t)(a + 1) << 2;
+          e |= (uint64_t)w.rel << 5;
+          nk = Key{w.state};
+          // its resume point: behind its match, or one byte behind its start; the entries from there on stay
+          const int keep_from = take + (w.rel > 0 ? w.rel : 1);
+          for (int j = keep_from; j < (int)list.size(); ++j) { nk.push_back(list[j].state); nk.push_back(list[j].rel); }
+          if ((int)(nk.size() - 1) / 2 > kSlots) { why = "empty-match walk: a walk reads more than three bytes beyond its last accepting position"; return false; }
+        } else nk = Key{-1};
+      }
+      if (at_end) { row[ncp] = e; continue; }
+      const int nid = id_of(nk);
+      if ((((uint64_t)nid << ew.cshift) >> 16) != 0) { why = "empty-match walk: configuration table beyond the LDS budget"; return false; }
+      e |= (((uint64_t)nid << ew.cshift) & 0xFFFFu) << 16;
+      row[k] = e;
+    }
+    rows.push_back(row);
+  }
+  ew.ncfg = (int)cfgs.size();
+  ew.tab.assign((size_t)ew.ncfg * ncp, 0);
+  ew.end.assign(ew.ncfg, 0);
+  for (int ci = 0; ci < ew.ncfg; ++ci) {
+    for (int k = 0; k < ew.ncls; ++k) ew.tab[(size_t)ci * ncp + k] = rows[ci][k];
+    ew.end[ci] = rows[ci][ncp];
+  }
+  return true;
+}
 // ---- where do matches begin?  (backward table, DevPlan::off_bk_*) -----------------------------------------------------
 // The restart-per-position search spends its time on walks that fail.  Whether the walk from position s succeeds
 // does not depend on the search's history -- only on the text from s on -- so it can be known for EVERY s before the
@@ -577,6 +715,36 @@ void align(std::vector<uint8_t>& blob, size_t a) {
 }
 
 }  // namespace
+
+// The table run on the host (tests: against the oracle, before any kernel sees it): findall of one text.
+std::vector<std::pair<int, int>> emptywalk2_run(const EmptyWalk2& ew, const uint8_t* text, int len) {
+  std::vector<std::pair<int, int>> out;
+  const int ncp = 1 << ew.cshift;
+  uint32_t row = 0;
+  int s0 = 0, last = 0;
+  auto apply = [&](uint64_t e, int base) {
+    if (e & 1u) out.push_back({s0, last});
+    const int nrep = (int)((e >> 8) & 7);
+    for (int r = 0; r < nrep; ++r) {
+      const int f = (int)((e >> (32 + 6 * r)) & 63);
+      const int st = base - (f & 7);
+      out.push_back({st, st + (f >> 3)});
+    }
+    const int ta = (int)((e >> 2) & 7);
+    if (ta) { s0 = base - (ta - 1); last = s0 + (int)((e >> 5) & 7); }
+    else if (e & 2u) last = base + 1;
+  };
+  for (int p = 0; p < len; ++p) {
+    const uint64_t e = ew.tab[(size_t)row + ew.cls[text[p]]];
+    apply(e, p);
+    row = (uint32_t)((e >> 16) & 0xFFFFu);
+  }
+  apply(ew.end[row >> ew.cshift], len);
+  out.push_back({len, len});
+  (void)ncp;
+  return out;
+}
+
 
 bool repl_has_group_refs(const std::string& r) {  // matcher.mojo:1472-1482
   for (size_t i = 0; i + 1 < r.size(); ++i)
@@ -1439,6 +1607,28 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
       }
     }
     hp.empty_all_accepting = all_acc;
+    if (!all_acc) {   // walks that read beyond their match: the general table (host copy for the tests' table run as well)
+      SearchAutomaton sa;
+      sa.n = d.nstates;
+      sa.next = T;
+      sa.acc = acc;
+      sa.allowed.fill(1);
+      hp.ew2_ok = build_emptywalk2(sa, hp.ew2, hp.ew2_why);
+      if (hp.ew2_ok) {
+        align(hp.blob, 16);
+        d.off_mw_cls = (int)hp.blob.size();
+        put(hp.blob, hp.ew2.cls.data(), 256);
+        d.off_mw_tab = (int)hp.blob.size();
+        put(hp.blob, hp.ew2.tab.data(), hp.ew2.tab.size() * 8);
+        put(hp.blob, hp.ew2.end.data(), hp.ew2.end.size() * 8);
+        d.mw_ncfg = hp.ew2.ncfg;
+        d.mw_cshift = hp.ew2.cshift;
+        d.mw_k = -2;   // (-2: k_mwalk<., 2, 0, 2>, 64-bit entries)
+        d.mw_bytes = 256 + (int)(hp.ew2.tab.size() + hp.ew2.end.size()) * 8;
+        d.flags |= PF_MW_EMPTY;
+        align(hp.blob, 16);
+      }
+    }
     if (all_acc) {
       SearchAutomaton sa;
       sa.n = d.nstates;
@@ -1721,7 +1911,8 @@ std::string describe_plan(const HostPlan& hp) {
   o << "device.steppable=" << ((d.flags & PF_STEPPABLE) ? "yes" : (d.flags & PF_STEP_REQ) ? "required-byte route" : "no")
     << " step_search=" << ((d.flags & PF_STEP_SEARCH) ? 1 : 0) << ((d.flags & PF_STEP_BIG) ? " big_table=1" : "")
     << ((d.flags & PF_BSTEP) ? " bitset=1" : "") << ((d.flags & PF_STEP_EMPTY) ? (hp.empty_all_accepting ? " empty_matches=1 every_state_accepts=1" : " empty_matches=1") : "")
-    << ((d.flags & PF_MW_EMPTY) ? " empty_walk=1" : "") << "\n";
+    << ((d.flags & PF_MW_EMPTY) ? " empty_walk=1" : "")
+    << (((d.flags & PF_STEP_EMPTY) && !hp.empty_all_accepting) ? (hp.ew2_ok ? " empty_walk2=yes configs=" + std::to_string(hp.ew2.ncfg) : " empty_walk2=no: " + hp.ew2_why) : std::string()) << "\n";
   o << "device.first_stream=" << (d.fa_bytes ? "yes" : ("no: " + hp.first_stream_why_not))
     << " fa_nstates=" << d.fa_nstates << " fa_kind=" << d.fa_kind << (hp.first_onepass ? " onepass=yes" : "")
     << (d.off_fa_run >= 0 ? " class_run=1" : "") << "\n";

@@ -4,8 +4,10 @@
 // CompiledRegex fixed-width groups, matcher.mojo:1002-1035) plus the flat,
 // byte-class-compressed table blob the kernels stage into LDS.
 #pragma once
+#include <array>
 #include <cstdint>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "mrx_analysis.hpp"
@@ -152,7 +154,19 @@ struct DevPlan {
   int32_t off_bt_items, bt_nitems, off_bt_tbl, bt_ngroups, off_bt_lit, bt_lit_len, bt_flags, bt_pattern_len;
 };
 
+// empty-match plans whose walks read beyond their match: the one-pass table (build_emptywalk2(), mrx_plan.cpp)
+struct EmptyWalk2 {
+  std::array<uint8_t, 256> cls{};
+  int ncls = 0, cshift = 0, ncfg = 0;
+  std::vector<uint64_t> tab;   // [ncfg][1 << cshift]
+  std::vector<uint64_t> end;   // [ncfg]
+};
+std::vector<std::pair<int, int>> emptywalk2_run(const EmptyWalk2& ew, const uint8_t* text, int len);
+
 struct HostPlan {
+  EmptyWalk2 ew2;   // PF_STEP_EMPTY plans that are not every_state_accepts: the general one-pass table, when it exists
+  bool ew2_ok = false;
+  std::string ew2_why;
   bool empty_all_accepting = false;   // PF_STEP_EMPTY plans: every state a walk can reach accepts (a walk never overshoots)
   std::string pattern;
   // routing facts (for mrx_engine_type / mrx_stats / mrx_describe)

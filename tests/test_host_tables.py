@@ -200,3 +200,52 @@ def test_fixed_width_group_patterns_that_are_nothing_but_groups():
         assert pure(p) is False, p
     for p in ("(\\w+) (\\w+)", "[a-z]+(\\d)*", "hello"):
         assert pure(p) is None, p
+
+
+def test_emptywalk2_table_run_on_the_host_equals_the_oracle():
+    """The one-pass table of empty-match plans whose walks read beyond their match (build_emptywalk2(): pending tries
+    behind the oldest walk, chased when it dies), run on the HOST through mrx_testing_emptywalk2_findall: findall of
+    hand-picked and generated patterns against the oracle, before any kernel sees the table."""
+    import ctypes as C
+    import numpy as np
+    import mojo_regex_amd as M
+    from mrx_ref import hybrid as O
+    from pattern_gen import patterns, patterns2
+    lib = M.load_library()
+
+    def run(rx, t):
+        buf = (C.c_int32 * (4 * (len(t) + 2)))()
+        k = lib.mrx_testing_emptywalk2_findall(rx._h, t, len(t), buf, len(buf) // 2)
+        return None if k < 0 else [(buf[2 * i], buf[2 * i + 1]) for i in range(k)]
+
+    rng = np.random.default_rng(7)
+    texts = [b"", b"a", b"ab", b"aba", b"abab", b"abcabcab", b"abx", b"xyxy", b"foobar", b"fooba", b"barfoo", b"http", b"htt",
+             b"catdogdog1", b"aabbb", b"abcab"]
+    texts += [bytes(rng.choice(list(b"abcdxyfotrh p1g"), size=int(rng.integers(1, 40))).tolist()) for _ in range(60)]
+    tables = 0
+    for p in (b"(abc)*", b"a+b*", b"http?", b"ca*t", b"x?y?", b"(foo)?(bar)?", b"cat|(dog){0,2}\\d?"):
+        rx = M.compile_regex(p)
+        assert "empty_walk2=yes" in rx.describe(), p
+        tables += 1
+        for t in texts:
+            assert run(rx, t) == O.findall(p, t), (p, t)
+    seen = set()
+    for gen, seeds in ((patterns, (20260503, 20260504)), (patterns2, (20260601,))):
+        for sd in seeds:
+            for ps in gen(sd, 300):
+                if ps in seen:
+                    continue
+                seen.add(ps)
+                p = ps.encode()
+                try:
+                    rx = M.compile_regex(p)
+                except Exception:
+                    continue
+                if "empty_walk2=yes" not in rx.describe():
+                    continue
+                tables += 1
+                al = b"abcxyz019 -@.fobrhelcatdg" + bytes(c for c in p if chr(c).isalnum()) * 2
+                for _ in range(25):
+                    t = bytes(rng.choice(list(al), size=int(rng.integers(0, 60))).tolist())
+                    assert run(rx, t) == O.findall(p, t), (p, t)
+    assert tables > 15, tables

@@ -28,7 +28,7 @@ lib = M.load_library()
 d = W.make_c2_batch(1 << 18, 1024)
 n, L = d.shape
 batch = M.DeviceBatch.strided(d.reshape(-1), L, length=L)
-for pat in (b"[a-z]*", b"a{0,2}", b"\\s?", b"z*"):
+for pat in (b"a{0,2}", b"\\s?", b"z*", b"(abc)*", b"http?", b"x?y?", b"(foo)?(bar)?"):
     rx = M.compile_regex(pat)
     if "empty_walk=1" not in rx.describe():
         print(json.dumps({"pattern": pat.decode(), "skipped": "no empty_walk form"}))
