@@ -60,7 +60,7 @@ void mrx_debug_dense_rows(int mode);
 /* Host-side run of the one-pass table of an empty-match plan whose walks read beyond their match (build_emptywalk2(),
  * mrx_plan.cpp): findall of ONE text on the CPU, for tests that pin the table to the oracle without a GPU.  Returns the
  * number of spans (spans[2 k], spans[2 k + 1] for k < min(count, cap)), -1 when the handle has no such table. */
-int mrx_testing_emptywalk2_findall(const mrx_handle* h, const uint8_t* text, int len, int32_t* spans, int cap);
+int mrx_testing_emptywalk_findall(const mrx_handle* h, const uint8_t* text, int len, int32_t* spans, int cap);
 /* sub assembled from findall spans: lanes that share one text in k_subs_wave (16, 32 or 64; texts whose
  * frame or output exceed the group's LDS tiles go to k_subs_emit); 0 = k_subs_emit for every text,
  * anything else = chosen from the average text length. */

@@ -687,10 +687,10 @@ __host__ __device__ inline size_t mwalk_table_bytes(const DevPlan& p) { return (
 // perm(a, b, sel): result byte k = byte sel[k] of the eight bytes b (0-3) | a (4-7).
 // EMP = 1 (PF_MW_EMPTY plans, build_emptywalk(): one walk, every state accepts): entry bit 11 = the empty match at this
 // byte (reported behind the match the byte ends, if it ends one), and every text ends with the empty match at its length.
-// EMP = 2 (DevPlan::mw_k == -2, build_emptywalk2()): walks that read up to three bytes beyond their match.  64-bit
-// entries: low word bit 0 report (start, last) registers, bit 1 last = pos + 1, bits 2-4 / 5-7 the entry that takes over as
-// the oldest walk (start = pos - a, last = start + len), bits 8-10 how many dead tries are reported, bits 16.. next row;
-// high word: their (a, len), six bits each.  end[config] behind the table: the same at the end of the text.
+// EMP = 2 (DevPlan::mw_k == -2, build_emptywalk2()): walks that read up to seven bytes beyond their match.  128-bit
+// entries (EwEntry): x bit 0 report (start, last) registers, bit 1 last = pos + 1, bits 2-5 / 6-9 the try that takes over as
+// the oldest walk (start = pos - a, last = start + len), bits 10-13 how many dead tries are reported, bits 16.. next row;
+// y, z, w: their (a, len), eight bits each.  end[config] behind the table: the same at the end of the text.
 template <int MODE, int KW = 4, int PK = 0, int EMP = 0>
 __global__ __launch_bounds__(64 * kWsWaves) void k_mwalk(DevPlan p, const uint8_t* __restrict__ blob, Layout lay,
                                                          int64_t n, int32_t* __restrict__ counts,
@@ -742,8 +742,8 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_mwalk(DevPlan p, const uint8_
   __syncthreads();
   const uint8_t* clsT = lds;
   const uint32_t* tab = (const uint32_t*)(lds + 256);
-  const uint2* tab64 = (const uint2*)(lds + 256);                                        // EMP == 2
-  const uint2* end64 = tab64 + ((size_t)p.mw_ncfg << p.mw_cshift);                       // ... one entry per configuration
+  const uint4* tab64 = (const uint4*)(lds + 256);                                        // EMP == 2: 128-bit entries (EwEntry)
+  const uint4* end64 = tab64 + ((size_t)p.mw_ncfg << p.mw_cshift);                       // ... one per configuration behind them
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint8_t* tile = tiles[wave];
   const int seg = lane % LPR, rsub = lane / LPR;
@@ -798,19 +798,26 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_mwalk(DevPlan p, const uint8_
       ++k;
     };
     // EMP == 2: one entry -- W0's match, the dead tries the chase passes, the try that takes over, the next row
-    auto ew2_apply = [&](const uint2 en2, const int base, const bool step) {
+    auto ew2_apply = [&](const uint4 en2, const int base, const bool step) {
       if (MODE == STEP_COUNT) {
-        k += (int)(en2.x & 1u) + (int)((en2.x >> 8) & 7u);
+        k += (int)(en2.x & 1u) + (int)((en2.x >> 10) & 15u);
       } else {
         if (en2.x & 1u) report(s0, last);
-        uint32_t rf = en2.y;
-        for (int nrep = (int)((en2.x >> 8) & 7u); nrep > 0; --nrep) {
-          const int st = base - (int)(rf & 7u);
-          report(st, st + (int)((rf >> 3) & 7u));
-          rf >>= 6;
+        const int nrep = (int)((en2.x >> 10) & 15u);
+        if (nrep) {   // (rare: the oldest walk died with tries behind it, or no walk begins on this byte)
+          uint32_t rw[3] = {en2.y, en2.z, en2.w};
+#pragma unroll
+          for (int w3 = 0; w3 < 3; ++w3) {
+            uint32_t rf = rw[w3];
+            for (int r = 4 * w3; r < nrep && r < 4 * w3 + 4; ++r) {
+              const int st = base - (int)(rf & 15u);
+              report(st, st + (int)((rf >> 4) & 15u));
+              rf >>= 8;
+            }
+          }
         }
-        const int ta = (int)((en2.x >> 2) & 7u);
-        if (ta) { s0 = base - (ta - 1); last = s0 + (int)((en2.x >> 5) & 7u); }
+        const int ta = (int)((en2.x >> 2) & 15u);
+        if (ta) { s0 = base - (ta - 1); last = s0 + (int)((en2.x >> 6) & 15u); }
         else if (en2.x & 2u) last = base + 1;
       }
       if (step) e = en2.x;
@@ -7243,7 +7250,7 @@ void mrx_debug_stream_bits_trace(int64_t* d_trace) { mrx::stream_bits_set_trace(
 void mrx_debug_dynamic_texts(int mode) { g_dyn_mode = mode < 0 ? 0 : mode > 2 ? 0 : mode; }
 void mrx_debug_split_findall(int on) { g_split_findall = on ? 1 : 0; }
 void mrx_debug_dense_rows(int mode) { g_dense_rows = mode; }
-int mrx_testing_emptywalk2_findall(const mrx_handle* h, const uint8_t* text, int len, int32_t* spans, int cap) {
+int mrx_testing_emptywalk_findall(const mrx_handle* h, const uint8_t* text, int len, int32_t* spans, int cap) {
   if (!h || !h->hp.ew2_ok || len < 0) return -1;
   const std::vector<std::pair<int, int>> v = emptywalk2_run(h->hp.ew2, text, len);
   for (size_t k = 0; k < v.size() && (int)k < cap; ++k) { spans[2 * k] = v[k].first; spans[2 * k + 1] = v[k].second; }

@@ -377,22 +377,22 @@ bool build_emptywalk(const SearchAutomaton& s, MultiWalk& mw, std::string& why) 
   return true;
 }
 
-// The general form (PF_MW_EMPTY with DevPlan::mw_k == -2): walks that read up to three bytes beyond their last accepting
+// The general form (PF_MW_EMPTY with DevPlan::mw_k == -2): walks that read up to seven bytes beyond their last accepting
 // position (`(ab)*`, `(foo)?x*`).  When such a walk dies at byte p the reference resumes at its match's end (or one byte
 // behind its start after an empty match) and tries again from there -- over bytes this pass has already seen.  So the
 // tries that MAY be asked for run beside the oldest walk W0: one per position from W0's resume point R up to p, each
 // alive (its state, how far its match reaches) or dead (how far its match reached).  A configuration is W0's state and
-// that list (at most three entries); W0's start and match end are the lane's registers.  Per byte: every walk steps, a
+// that list (at most seven entries); W0's start and match end are the lane's registers.  Per byte: every walk steps, a
 // walk begins on the byte; when W0 accepts, the list is dropped (every entry began inside its match); when W0 dies, its
 // match is reported and the list is chased as the reference's loop would: a dead entry is reported and skipped past, the
 // first live entry reached takes over as W0 (the entries in front of ITS resume point are dropped), and when the chase
-// runs off the list the next byte starts afresh.  Entry, 64 bits: bit 0 report W0 (start, last registers), bit 1 W0
-// accepts here, bits 2-4 a + 1 / bits 5-7 len of the entry that takes over (start = pos - a, last = start + len; 0: none),
-// bits 8-10 how many dead entries are reported, bits 16-31 the next configuration; high word: their (a, len) pairs, six
-// bits each, in report order.  end[config]: the same for the end of the text (every walk dies; a relative to len); the
-// empty match at len is the kernel's.
+// runs off the list the next byte starts afresh.  Entry, 128 bits (EwEntry): x bit 0 report W0 (start, last registers),
+// bit 1 W0 accepts here, bits 2-5 a + 1 / bits 6-9 len of the entry that takes over (start = pos - a, last = start +
+// len; 0: none), bits 10-13 how many dead entries are reported, bits 16-31 the next configuration; r[0..2]: their (a, len)
+// pairs, eight bits each, in report order.  end[config]: the same for the end of the text (every walk dies; a relative
+// to len); the empty match at len is the kernel's.  Up to seven entries behind W0 and twelve reports on a byte.
 bool build_emptywalk2(const SearchAutomaton& s, EmptyWalk2& ew, std::string& why) {
-  constexpr int kSlots = 3;
+  constexpr int kSlots = 7, kReports = 12;
   std::vector<int> rep;
   {
     std::map<std::vector<int>, int> seen;
@@ -429,20 +429,20 @@ bool build_emptywalk2(const SearchAutomaton& s, EmptyWalk2& ew, std::string& why
       idx += list[idx].rel > 0 ? list[idx].rel : 1;
     }
   };
-  std::vector<std::vector<uint64_t>> rows;
+  std::vector<std::vector<EwEntry>> rows;
   for (size_t ci = 0; ci < cfgs.size(); ++ci) {
-    if ((int64_t)cfgs.size() * (ncp + 1) > 8000) { why = "empty-match walk: configuration table beyond the LDS budget"; return false; }
+    if ((int64_t)cfgs.size() * (ncp + 1) > 3900) { why = "empty-match walk: configuration table beyond the LDS budget"; return false; }
     const Key cur = cfgs[ci];
     const bool fresh = cur[0] < 0;
     const int q0 = fresh ? 0 : cur[0];
     std::vector<Slot> slots;
     for (size_t j = 1; j + 1 < cur.size(); j += 2) slots.push_back({cur[j], cur[j + 1]});
     const int m = (int)slots.size();   // tries at positions R .. p - 1, R = p - m
-    std::vector<uint64_t> row(ncp + 1, 0);
+    std::vector<EwEntry> row(ncp + 1);
     for (int k = 0; k <= ew.ncls; ++k) {
       const bool at_end = k == ew.ncls;   // the virtual step behind the last byte: every walk dies, none begins
       const int c = at_end ? 0 : rep[k];
-      uint64_t e = 0;
+      EwEntry e;
       std::vector<Slot> list;
       for (int j = 0; j < m; ++j) {
         Slot sl = slots[j];
@@ -463,52 +463,53 @@ bool build_emptywalk2(const SearchAutomaton& s, EmptyWalk2& ew, std::string& why
         // the try at p is the newest list entry itself
         const Slot me = list.back();
         if (at_end) { nk = Key{-1}; }
-        else if (me.state < 0) { e |= (uint64_t)1 << 8; e |= (uint64_t)(0 | (0 << 3)) << 32; nk = Key{-1}; }   // the empty match at p
+        else if (me.state < 0) { e.x |= 1u << 10; nk = Key{-1}; }   // the empty match at p: one report, (a, len) = (0, 0)
         else {
-          e |= 2u * (s.acc[me.state] ? 1 : 0);
-          e |= (uint64_t)(0 + 1) << 2;                       // takes over: start = p ...
-          e |= (uint64_t)(s.acc[me.state] ? 1 : 0) << 5;     // ... last = start + rel
+          e.x |= 2u * (s.acc[me.state] ? 1 : 0);
+          e.x |= (uint32_t)(0 + 1) << 2;                       // takes over: start = p ...
+          e.x |= (uint32_t)(s.acc[me.state] ? 1 : 0) << 6;     // ... last = start + rel
           nk = Key{me.state};   // (no entries: its resume point is p + 1 either way)
         }
       } else if (t0 >= 0 && s.acc[t0]) {
-        e |= 2u;
+        e.x |= 2u;
         nk = Key{t0};
       } else if (t0 >= 0) {
-        if ((int)list.size() > kSlots) { why = "empty-match walk: a walk reads more than three bytes beyond its last accepting position"; return false; }
+        if ((int)list.size() > kSlots) { why = "empty-match walk: a walk reads more than seven bytes beyond its last accepting position"; return false; }
         nk = Key{t0};
         for (const Slot& sl : list) { nk.push_back(sl.state); nk.push_back(sl.rel); }
       } else {
-        e |= 1u;   // W0's match
+        e.x |= 1u;   // W0's match
         std::vector<std::pair<int, int>> out;
         int take = -1;
         // positions: list[idx] is at R + idx with R = p - m; relative to base (p, or len = p at the end): a = base - R - idx = m - idx
         chase(list, m, out, &take);
-        if (out.size() > 4) { why = "empty-match walk: more than four reports on one byte"; return false; }
-        e |= (uint64_t)out.size() << 8;
-        for (size_t r = 0; r < out.size(); ++r) e |= (uint64_t)((out[r].first & 7) | ((out[r].second & 7) << 3)) << (32 + 6 * r);
+        if ((int)out.size() > kReports) { why = "empty-match walk: more than twelve reports on one byte"; return false; }
+        e.x |= (uint32_t)out.size() << 10;
+        for (size_t r = 0; r < out.size(); ++r)
+          e.r[r / 4] |= (uint32_t)((out[r].first & 15) | ((out[r].second & 15) << 4)) << (8 * (r % 4));
         if (take >= 0) {
           const Slot w = list[take];
           const int a = m - take;
-          e |= (uint64_t)(a + 1) << 2;
-          e |= (uint64_t)w.rel << 5;
+          e.x |= (uint32_t)(a + 1) << 2;
+          e.x |= (uint32_t)w.rel << 6;
           nk = Key{w.state};
           // its resume point: behind its match, or one byte behind its start; the entries from there on stay
           const int keep_from = take + (w.rel > 0 ? w.rel : 1);
           for (int j = keep_from; j < (int)list.size(); ++j) { nk.push_back(list[j].state); nk.push_back(list[j].rel); }
-          if ((int)(nk.size() - 1) / 2 > kSlots) { why = "empty-match walk: a walk reads more than three bytes beyond its last accepting position"; return false; }
+          if ((int)(nk.size() - 1) / 2 > kSlots) { why = "empty-match walk: a walk reads more than seven bytes beyond its last accepting position"; return false; }
         } else nk = Key{-1};
       }
       if (at_end) { row[ncp] = e; continue; }
       const int nid = id_of(nk);
       if ((((uint64_t)nid << ew.cshift) >> 16) != 0) { why = "empty-match walk: configuration table beyond the LDS budget"; return false; }
-      e |= (((uint64_t)nid << ew.cshift) & 0xFFFFu) << 16;
+      e.x |= (((uint32_t)nid << ew.cshift) & 0xFFFFu) << 16;
       row[k] = e;
     }
     rows.push_back(row);
   }
   ew.ncfg = (int)cfgs.size();
-  ew.tab.assign((size_t)ew.ncfg * ncp, 0);
-  ew.end.assign(ew.ncfg, 0);
+  ew.tab.assign((size_t)ew.ncfg * ncp, EwEntry{});
+  ew.end.assign(ew.ncfg, EwEntry{});
   for (int ci = 0; ci < ew.ncfg; ++ci) {
     for (int k = 0; k < ew.ncls; ++k) ew.tab[(size_t)ci * ncp + k] = rows[ci][k];
     ew.end[ci] = rows[ci][ncp];
@@ -719,29 +720,27 @@ void align(std::vector<uint8_t>& blob, size_t a) {
 // The table run on the host (tests: against the oracle, before any kernel sees it): findall of one text.
 std::vector<std::pair<int, int>> emptywalk2_run(const EmptyWalk2& ew, const uint8_t* text, int len) {
   std::vector<std::pair<int, int>> out;
-  const int ncp = 1 << ew.cshift;
   uint32_t row = 0;
   int s0 = 0, last = 0;
-  auto apply = [&](uint64_t e, int base) {
-    if (e & 1u) out.push_back({s0, last});
-    const int nrep = (int)((e >> 8) & 7);
+  auto apply = [&](const EwEntry& e, int base) {
+    if (e.x & 1u) out.push_back({s0, last});
+    const int nrep = (int)((e.x >> 10) & 15);
     for (int r = 0; r < nrep; ++r) {
-      const int f = (int)((e >> (32 + 6 * r)) & 63);
-      const int st = base - (f & 7);
-      out.push_back({st, st + (f >> 3)});
+      const int f = (int)((e.r[r / 4] >> (8 * (r % 4))) & 255);
+      const int st = base - (f & 15);
+      out.push_back({st, st + (f >> 4)});
     }
-    const int ta = (int)((e >> 2) & 7);
-    if (ta) { s0 = base - (ta - 1); last = s0 + (int)((e >> 5) & 7); }
-    else if (e & 2u) last = base + 1;
+    const int ta = (int)((e.x >> 2) & 15);
+    if (ta) { s0 = base - (ta - 1); last = s0 + (int)((e.x >> 6) & 15); }
+    else if (e.x & 2u) last = base + 1;
   };
   for (int p = 0; p < len; ++p) {
-    const uint64_t e = ew.tab[(size_t)row + ew.cls[text[p]]];
+    const EwEntry& e = ew.tab[(size_t)row + ew.cls[text[p]]];
     apply(e, p);
-    row = (uint32_t)((e >> 16) & 0xFFFFu);
+    row = e.x >> 16;
   }
   apply(ew.end[row >> ew.cshift], len);
   out.push_back({len, len});
-  (void)ncp;
   return out;
 }
 
@@ -1619,12 +1618,12 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
         d.off_mw_cls = (int)hp.blob.size();
         put(hp.blob, hp.ew2.cls.data(), 256);
         d.off_mw_tab = (int)hp.blob.size();
-        put(hp.blob, hp.ew2.tab.data(), hp.ew2.tab.size() * 8);
-        put(hp.blob, hp.ew2.end.data(), hp.ew2.end.size() * 8);
+        put(hp.blob, hp.ew2.tab.data(), hp.ew2.tab.size() * sizeof(EwEntry));
+        put(hp.blob, hp.ew2.end.data(), hp.ew2.end.size() * sizeof(EwEntry));
         d.mw_ncfg = hp.ew2.ncfg;
         d.mw_cshift = hp.ew2.cshift;
-        d.mw_k = -2;   // (-2: k_mwalk<., 2, 0, 2>, 64-bit entries)
-        d.mw_bytes = 256 + (int)(hp.ew2.tab.size() + hp.ew2.end.size()) * 8;
+        d.mw_k = -2;   // (-2: k_mwalk<., 2, 0, 2>, 128-bit entries)
+        d.mw_bytes = 256 + (int)((hp.ew2.tab.size() + hp.ew2.end.size()) * sizeof(EwEntry));
         d.flags |= PF_MW_EMPTY;
         align(hp.blob, 16);
       }

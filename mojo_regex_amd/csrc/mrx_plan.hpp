@@ -155,11 +155,12 @@ struct DevPlan {
 };
 
 // empty-match plans whose walks read beyond their match: the one-pass table (build_emptywalk2(), mrx_plan.cpp)
+struct EwEntry { uint32_t x = 0; uint32_t r[3] = {0, 0, 0}; };   // control word | up to twelve (a, len) reports (mrx_plan.cpp)
 struct EmptyWalk2 {
   std::array<uint8_t, 256> cls{};
   int ncls = 0, cshift = 0, ncfg = 0;
-  std::vector<uint64_t> tab;   // [ncfg][1 << cshift]
-  std::vector<uint64_t> end;   // [ncfg]
+  std::vector<EwEntry> tab;   // [ncfg][1 << cshift]
+  std::vector<EwEntry> end;   // [ncfg]
 };
 std::vector<std::pair<int, int>> emptywalk2_run(const EmptyWalk2& ew, const uint8_t* text, int len);
 

@@ -204,7 +204,7 @@ def test_fixed_width_group_patterns_that_are_nothing_but_groups():
 
 def test_emptywalk2_table_run_on_the_host_equals_the_oracle():
     """The one-pass table of empty-match plans whose walks read beyond their match (build_emptywalk2(): pending tries
-    behind the oldest walk, chased when it dies), run on the HOST through mrx_testing_emptywalk2_findall: findall of
+    behind the oldest walk, chased when it dies), run on the HOST through mrx_testing_emptywalk_findall: findall of
     hand-picked and generated patterns against the oracle, before any kernel sees the table."""
     import ctypes as C
     import numpy as np
@@ -215,7 +215,7 @@ def test_emptywalk2_table_run_on_the_host_equals_the_oracle():
 
     def run(rx, t):
         buf = (C.c_int32 * (4 * (len(t) + 2)))()
-        k = lib.mrx_testing_emptywalk2_findall(rx._h, t, len(t), buf, len(buf) // 2)
+        k = lib.mrx_testing_emptywalk_findall(rx._h, t, len(t), buf, len(buf) // 2)
         return None if k < 0 else [(buf[2 * i], buf[2 * i + 1]) for i in range(k)]
 
     rng = np.random.default_rng(7)
