@@ -700,7 +700,9 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_mwalk(DevPlan p, const uint8_
   constexpr int CH = 128, kRowPitch = CH + 16, LPR = CH / 16, RPI = 64 / LPR, NL = 64 / RPI;
   static_assert(!PK || ((KW == 2 || KW == 4) && MODE != STEP_COUNT && MODE != STEP_ANY), "packed starts: two or four slots, modes with registers");
   static_assert(!EMP || (KW == 2 && !PK && (MODE == STEP_COUNT || MODE == STEP_EMIT)), "empty-match walk: count and emit passes");
-  static_assert(EMP >= 0 && EMP <= 2, "0: multi-walk table, 1: one walk that never overshoots, 2: walks with pending tries behind them");
+  static_assert(EMP >= 0 && EMP <= 3, "0: multi-walk table, 1: one walk that never overshoots, 2: walks with pending tries behind them, 3: the same for plans without empty matches");
+  constexpr bool TRIES = EMP == 2 || EMP == 3;     // 128-bit entries (EwEntry)
+  constexpr bool LAST_TRY = EMP == 1 || EMP == 2;  // empty matches: the last try is at pos == len
   __shared__ __align__(16) uint8_t tiles[kWsWaves][64 * kRowPitch];
   __shared__ __align__(16) uint32_t plut[PK ? 512 * (KW == 2 ? 2 : 4) : 4];   // PK: the permute selectors per code
   if (PK) {
@@ -729,7 +731,7 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_mwalk(DevPlan p, const uint8_
   typedef __attribute__((address_space(3))) const uint8_t lds_cu8;
   typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
   const uint32_t lds_base = (uint32_t)(uintptr_t)lds;   // (the low half of a flat LDS address is the LDS offset)
-  const bool pre = EMP != 2 && p.mw_cshift <= 6 && lds_base + (uint32_t)p.mw_bytes <= 65536u;   // (EMP == 2: 64-bit entries, as stored)
+  const bool pre = !TRIES && p.mw_cshift <= 6 && lds_base + (uint32_t)p.mw_bytes <= 65536u;   // (TRIES: 128-bit entries, as stored)
   {
     const uint32_t* src = (const uint32_t*)(blob + p.off_mw_cls);   // cls[256] | tab[...], contiguous and 16-byte aligned
     uint32_t* dst = (uint32_t*)lds;
@@ -774,7 +776,7 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_mwalk(DevPlan p, const uint8_
       // EMIT after STEP_SLOTS: only texts that overflowed their slots.  wide_slots == 2 (the two-pass findall of these
       // plans; search behind a STEP_ANY pass): counts come from a first pass -- texts without a match are not scanned again
       if (live && (lay.wide_slots == 2 ? counts[i] == 0 : counts[i] <= slot_cap)) fin = true;
-      if (!EMP && __all(fin)) {   // (EMP: an empty text still has its empty match)
+      if (!LAST_TRY && __all(fin)) {   // (empty-match plans: an empty text still has its empty match)
         if (MODE == STEP_SEARCH && live && !skipped) { out_s[i] = -1; out_e[i] = -1; }
         continue;
       }
@@ -846,7 +848,7 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_mwalk(DevPlan p, const uint8_
 #define MRX_MW_BYTE(BYTE_, F_, FULL_, PRE_)                                                                          \
       do {                                                                                                           \
         const int f = (F_);                           /* frame position, the same for every lane */                  \
-        if constexpr (EMP == 2) {                                                                                    \
+        if constexpr (TRIES) {                                                                                       \
           if (!fin && f >= mis && f < end) ew2_apply(tab64[(e >> 16) + clsT[(BYTE_)]], f - mis, true);               \
           break;                                                                                                     \
         }                                                                                                            \
@@ -860,7 +862,7 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_mwalk(DevPlan p, const uint8_
         if (PK) { if (act && (en & 1u)) report((int)(R01 & 0xFFFFu), (int)(Lr & 0xFFFFu)); }                         \
         else                                                                                                         \
         if (act && (en & 1u)) report(s0, last);      /* the oldest walk ended behind its last accepting position (rare branch) */ \
-        if (EMP) { if (act && (en & 0x800u)) report(pr, pr); }   /* ... and no walk begins on this byte: the empty match here */ \
+        if (EMP == 1) { if (act && (en & 0x800u)) report(pr, pr); }   /* ... and no walk begins on this byte: the empty match here */ \
         /* the start registers move as the entry says; plain selects, no branches (code 0 = stays; a lane that is    \
            not stepping takes code 0 everywhere) */                                                                  \
         const uint32_t ea = ((FULL_) == 2 || act) ? en : 0u;                                                         \
@@ -929,13 +931,13 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_mwalk(DevPlan p, const uint8_
         }
         if (MODE != STEP_COUNT && !all_full && !fin && f0 + 16 >= end) {
           // the text ended in this group: its last report now (the oldest walk has accepted), then the lane rides along
-          if constexpr (EMP == 2) {
+          if constexpr (TRIES) {
             ew2_apply(end64[(e >> 16) >> p.mw_cshift], t.len, false);   // every walk dies behind the last byte
           } else
           if ((e >> 10) & 1u) {
             if (PK) report((int)(R01 & 0xFFFFu), (int)(Lr & 0xFFFFu)); else report(s0, last);
           }
-          if (EMP) report(t.len, t.len);   // the last try, at pos == len: the empty match
+          if (LAST_TRY) report(t.len, t.len);   // the last try, at pos == len: the empty match
           fin = true;
         }
       }
@@ -944,13 +946,13 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_mwalk(DevPlan p, const uint8_
       if (__all(fin || wb + CH >= end)) break;
     }
 #undef MRX_MW_LOAD
-    if constexpr (EMP == 2) {
+    if constexpr (TRIES) {
       if (!fin) ew2_apply(end64[(e >> 16) >> p.mw_cshift], t.len, false);
     } else
     if (PK) { if (!fin && ((e >> 10) & 1u)) report((int)(R01 & 0xFFFFu), (int)(Lr & 0xFFFFu)); }
     else
     if (!fin && ((e >> 10) & 1u)) report(s0, last);   // end of the text: the oldest walk has accepted
-    if (EMP) {   // the last try, at pos == len (the empty text: its only one)
+    if (LAST_TRY) {   // the last try, at pos == len (the empty text: its only one)
       if (!fin || (live && !skipped && t.len == 0)) report(t.len, t.len);
     }
     if (live && !skipped) {
@@ -4479,6 +4481,10 @@ void mwalk_launch(int kw, bool pk, dim3 g, dim3 b, size_t lds_bytes, hipStream_t
       hipLaunchKernelGGL((k_mwalk<MODE, 2, 0, 2>), g, b, lds_bytes, s, args...);
       return;
     }
+    if (kw == -3) {   // (PF_MW_TRIES: the same table form for a plan without empty matches)
+      hipLaunchKernelGGL((k_mwalk<MODE, 2, 0, 3>), g, b, lds_bytes, s, args...);
+      return;
+    }
     if (kw < 0) {   // (DevPlan::mw_k == -1: the empty-match walk of a PF_MW_EMPTY plan; 0 is a table no walk ever enters)
       hipLaunchKernelGGL((k_mwalk<MODE, 2, 0, 1>), g, b, lds_bytes, s, args...);
       return;
@@ -4522,6 +4528,11 @@ bool mwalk_enabled() {
   return !off && g_mwalk_mode != 2 && g_force_generic == 0;   // (level 1 = the stepper and nothing newer)
 }
 bool mwalk_on(const DevPlan& p) { return (p.flags & PF_MWALK) && mwalk_enabled(); }
+// PF_MW_TRIES plans on k_mwalk (MRX_NO_TRIES=1: their marks / stepper route instead -- A/B runs)
+bool mw_tries_on(const DevPlan& p) {
+  static const bool off = getenv("MRX_NO_TRIES") && getenv("MRX_NO_TRIES")[0] == '1';
+  return (p.flags & PF_MW_TRIES) && !off && mwalk_enabled();
+}
 // PF_BACKSET plans: mark where matches begin (k_backscan), then the stepper only starts walks that succeed.
 // MRX_NO_BACKSET=1 / mrx_debug_multiwalk(2): off.
 bool backset_on(const DevPlan& p) {
@@ -5494,7 +5505,7 @@ struct FindallJob {
   int32_t* d_counts = nullptr;
   int64_t* d_total = nullptr;
   // ---- route (chosen by choose_route(); the launch macros of this file read these by name) ----
-  bool stream_ok = false, use_req_route = false, wstep_bits = false, wstep_lz = false, wstep_empty = false, mw_empty = false;
+  bool stream_ok = false, use_req_route = false, wstep_bits = false, wstep_lz = false, wstep_empty = false, mw_empty = false, mw_tries = false;
   bool mwalk_req = false, wstep_mwalk = false;
   DevPlan pk;                      // what the lane kernels are launched with
   int wstep_mwalk_k = 0;
@@ -5556,7 +5567,9 @@ struct FindallJob {
     // several walks in one pass instead of the restart-per-position loop (plain route; sub's match_next sequence is
     // the same list of matches, but a memchr-prefiltered match_next is not the plain search)
     mwalk_req = use_req_route && (p.flags & PF_MWALK_REQ) && mwalk_enabled();
-    wstep_mwalk = (mwalk_req || (mwalk_on(p) && !use_req_route) || mw_empty) && !wstep_bits && !wstep_empty &&
+    // ... and plain-route plans outside the multi-walk proofs whose walks stay within seven bytes of their match (PF_MW_TRIES)
+    mw_tries = mw_tries_on(p) && !use_req_route && g_force_generic < 2;
+    wstep_mwalk = (mwalk_req || (mwalk_on(p) && !use_req_route) || mw_empty || mw_tries) && !wstep_bits && !wstep_empty &&
                   !(match_next_sequence && (p.flags & PF_PREFILTER));
     pk = mwalk_req ? mwalk_req_plan(p) : p;
     wstep_mwalk_k = pk.mw_k;
@@ -5880,7 +5893,7 @@ struct FindallJob {
         return MRX_OK;
       }
     }
-    if (step_ok && !wstep_bits && !wstep_empty && !mw_empty && !t_in_pieces && !wstep_lz) {
+    if (step_ok && !wstep_bits && !wstep_empty && !mw_empty && !mw_tries && !t_in_pieces && !wstep_lz) {
       if (int rc = req_wave_pays(lay, n, use_req_route, s, &req_wave, (p.flags & PF_STEP_BIG) ? nullptr : &step_split,
                                  (p.flags & PF_STEP_BIG) != 0, wstep_mwalk, backset_on(p) && !wstep_mwalk))
         return rc;
@@ -6900,7 +6913,8 @@ static int run_count_any(const mrx_handle* h, const Layout& lay, int64_t n, int3
     const bool mw_empty = (h->hp.dev.flags & PF_MW_EMPTY) != 0 && mwalk_enabled() && g_force_generic < 2;
     const bool wstep_empty = (h->hp.dev.flags & PF_STEP_EMPTY) != 0 && g_force_generic < 2 && !mw_empty;
     const bool mwalk_req = use_req_route && (h->hp.dev.flags & PF_MWALK_REQ) && mwalk_enabled();
-    const bool wstep_mwalk = (mwalk_req || (mwalk_on(h->hp.dev) && !use_req_route) || mw_empty) && !wstep_bits && !wstep_empty;
+    const bool mw_tries = mw_tries_on(h->hp.dev) && !use_req_route && g_force_generic < 2;
+    const bool wstep_mwalk = (mwalk_req || (mwalk_on(h->hp.dev) && !use_req_route) || mw_empty || mw_tries) && !wstep_bits && !wstep_empty;
     const DevPlan pk = mwalk_req ? mwalk_req_plan(h->hp.dev) : h->hp.dev;
     const int wstep_mwalk_k = pk.mw_k;
     const bool wstep_mwalk_pk = false;   // (count keeps no start registers)
@@ -6931,7 +6945,7 @@ static int run_count_any(const mrx_handle* h, const Layout& lay, int64_t n, int3
         return pieces_release(&spc, s);
       }
     }
-    if (g_force_generic < 2 && !wstep_bits && !wstep_lz && !t_in_pieces && (h->hp.dev.flags & (PF_STEPPABLE | PF_STEP_REQ)))
+    if (g_force_generic < 2 && !wstep_bits && !wstep_lz && !mw_tries && !t_in_pieces && (h->hp.dev.flags & (PF_STEPPABLE | PF_STEP_REQ)))
       if (int rc = req_wave_pays(lay, n, use_req_route, s, &req_wave, (h->hp.dev.flags & PF_STEP_BIG) ? nullptr : &split,
                                  (h->hp.dev.flags & PF_STEP_BIG) != 0, wstep_mwalk, backset_on(h->hp.dev) && !wstep_mwalk))
         return rc;

@@ -391,14 +391,21 @@ bool build_emptywalk(const SearchAutomaton& s, MultiWalk& mw, std::string& why) 
 // len; 0: none), bits 10-13 how many dead entries are reported, bits 16-31 the next configuration; r[0..2]: their (a, len)
 // pairs, eight bits each, in report order.  end[config]: the same for the end of the text (every walk dies; a relative
 // to len); the empty match at len is the kernel's.  Up to seven entries behind W0 and twelve reports on a byte.
-bool build_emptywalk2(const SearchAutomaton& s, EmptyWalk2& ew, std::string& why) {
+// empty = false: the same search for plans WITHOUT empty matches (the plain restart-per-position route of a table plan
+// that fails the multi-walk proofs, e.g. `foo|[a-z]{3}\d|[ab]`: a later start accepts while the earlier walk is still
+// undecided -- here that later try simply waits in the list with its match).  A try that leaves no match (it dies before
+// it accepts, or its byte may not start a walk) is a dead entry of length 0 that is skipped WITHOUT a report, W0 is
+// reported only once it has accepted (part of the configuration), and there is no try at len.
+bool build_emptywalk2(const SearchAutomaton& s, EmptyWalk2& ew, std::string& why, bool empty = true) {
   constexpr int kSlots = 7, kReports = 12;
+  ew.empty = empty;
   std::vector<int> rep;
   {
     std::map<std::vector<int>, int> seen;
     for (int c = 0; c < 256; ++c) {
-      std::vector<int> col(s.n);
+      std::vector<int> col(s.n + 1);
       for (int q = 0; q < s.n; ++q) col[q] = s.next[q][c];
+      col[s.n] = empty ? 1 : s.allowed[c];
       auto it = seen.find(col);
       if (it == seen.end()) { it = seen.emplace(col, (int)rep.size()).first; rep.push_back(c); }
       ew.cls[c] = (uint8_t)it->second;
@@ -410,7 +417,7 @@ bool build_emptywalk2(const SearchAutomaton& s, EmptyWalk2& ew, std::string& why
   while ((1 << ew.cshift) < ew.ncls) ++ew.cshift;
   const int ncp = 1 << ew.cshift;
   struct Slot { int state; int rel; };   // state < 0: dead; rel: match length so far
-  using Key = std::vector<int>;          // {q0, state, rel, state, rel, ...}; {-1}: nothing consumed yet (fresh)
+  using Key = std::vector<int>;          // {q0, W0 has a match to report, state, rel, state, rel, ...}; {-1}: nothing consumed yet (fresh)
   std::map<Key, int> ids;
   std::vector<Key> cfgs;
   auto id_of = [&](const Key& k) {
@@ -425,7 +432,7 @@ bool build_emptywalk2(const SearchAutomaton& s, EmptyWalk2& ew, std::string& why
     int idx = 0;
     while (idx < (int)list.size()) {
       if (list[idx].state >= 0) { *take_idx = idx; return; }
-      out.push_back({base_minus_R - idx, list[idx].rel});
+      if (empty || list[idx].rel > 0) out.push_back({base_minus_R - idx, list[idx].rel});   // (a try without a match: skipped silently)
       idx += list[idx].rel > 0 ? list[idx].rel : 1;
     }
   };
@@ -435,8 +442,9 @@ bool build_emptywalk2(const SearchAutomaton& s, EmptyWalk2& ew, std::string& why
     const Key cur = cfgs[ci];
     const bool fresh = cur[0] < 0;
     const int q0 = fresh ? 0 : cur[0];
+    const bool w0acc = !fresh && cur[1] != 0;
     std::vector<Slot> slots;
-    for (size_t j = 1; j + 1 < cur.size(); j += 2) slots.push_back({cur[j], cur[j + 1]});
+    for (size_t j = 2; j + 1 < cur.size(); j += 2) slots.push_back({cur[j], cur[j + 1]});
     const int m = (int)slots.size();   // tries at positions R .. p - 1, R = p - m
     std::vector<EwEntry> row(ncp + 1);
     for (int k = 0; k <= ew.ncls; ++k) {
@@ -454,7 +462,7 @@ bool build_emptywalk2(const SearchAutomaton& s, EmptyWalk2& ew, std::string& why
         list.push_back(sl);
       }
       if (!at_end) {
-        const int tn = s.next[0][c];
+        const int tn = (empty || s.allowed[c]) ? s.next[0][c] : -1;
         list.push_back(tn < 0 ? Slot{-1, 0} : Slot{tn, s.acc[tn] ? 1 : 0});
       }
       const int t0 = at_end ? -1 : s.next[q0][c];
@@ -463,22 +471,22 @@ bool build_emptywalk2(const SearchAutomaton& s, EmptyWalk2& ew, std::string& why
         // the try at p is the newest list entry itself
         const Slot me = list.back();
         if (at_end) { nk = Key{-1}; }
-        else if (me.state < 0) { e.x |= 1u << 10; nk = Key{-1}; }   // the empty match at p: one report, (a, len) = (0, 0)
+        else if (me.state < 0) { if (empty) e.x |= 1u << 10; nk = Key{-1}; }   // the empty match at p: one report, (a, len) = (0, 0)
         else {
           e.x |= 2u * (s.acc[me.state] ? 1 : 0);
           e.x |= (uint32_t)(0 + 1) << 2;                       // takes over: start = p ...
           e.x |= (uint32_t)(s.acc[me.state] ? 1 : 0) << 6;     // ... last = start + rel
-          nk = Key{me.state};   // (no entries: its resume point is p + 1 either way)
+          nk = Key{me.state, (empty || s.acc[me.state]) ? 1 : 0};   // (no entries: its resume point is p + 1 either way)
         }
       } else if (t0 >= 0 && s.acc[t0]) {
         e.x |= 2u;
-        nk = Key{t0};
+        nk = Key{t0, 1};
       } else if (t0 >= 0) {
         if ((int)list.size() > kSlots) { why = "empty-match walk: a walk reads more than seven bytes beyond its last accepting position"; return false; }
-        nk = Key{t0};
+        nk = Key{t0, w0acc ? 1 : 0};
         for (const Slot& sl : list) { nk.push_back(sl.state); nk.push_back(sl.rel); }
       } else {
-        e.x |= 1u;   // W0's match
+        if (w0acc) e.x |= 1u;   // W0's match
         std::vector<std::pair<int, int>> out;
         int take = -1;
         // positions: list[idx] is at R + idx with R = p - m; relative to base (p, or len = p at the end): a = base - R - idx = m - idx
@@ -492,11 +500,11 @@ bool build_emptywalk2(const SearchAutomaton& s, EmptyWalk2& ew, std::string& why
           const int a = m - take;
           e.x |= (uint32_t)(a + 1) << 2;
           e.x |= (uint32_t)w.rel << 6;
-          nk = Key{w.state};
+          nk = Key{w.state, (empty || w.rel > 0) ? 1 : 0};
           // its resume point: behind its match, or one byte behind its start; the entries from there on stay
           const int keep_from = take + (w.rel > 0 ? w.rel : 1);
           for (int j = keep_from; j < (int)list.size(); ++j) { nk.push_back(list[j].state); nk.push_back(list[j].rel); }
-          if ((int)(nk.size() - 1) / 2 > kSlots) { why = "empty-match walk: a walk reads more than seven bytes beyond its last accepting position"; return false; }
+          if ((int)(nk.size() - 2) / 2 > kSlots) { why = "empty-match walk: a walk reads more than seven bytes beyond its last accepting position"; return false; }
         } else nk = Key{-1};
       }
       if (at_end) { row[ncp] = e; continue; }
@@ -740,7 +748,7 @@ std::vector<std::pair<int, int>> emptywalk2_run(const EmptyWalk2& ew, const uint
     row = e.x >> 16;
   }
   apply(ew.end[row >> ew.cshift], len);
-  out.push_back({len, len});
+  if (ew.empty) out.push_back({len, len});
   return out;
 }
 
@@ -1518,6 +1526,25 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
           align(hp.blob, 16);
         } else {
           hp.mwalk_why_not = mwhy;
+          // ... then the tries that may be asked for beside the oldest walk (build_emptywalk2, empty = false): host copy
+          if (!sa.acc[0]) {
+            hp.ew2_ok = build_emptywalk2(sa, hp.ew2, hp.ew2_why, false);
+            hp.ew2_tries = true;
+            if (hp.ew2_ok) {
+              align(hp.blob, 16);
+              d.off_mw_cls = (int)hp.blob.size();
+              put(hp.blob, hp.ew2.cls.data(), 256);
+              d.off_mw_tab = (int)hp.blob.size();
+              put(hp.blob, hp.ew2.tab.data(), hp.ew2.tab.size() * sizeof(EwEntry));
+              put(hp.blob, hp.ew2.end.data(), hp.ew2.end.size() * sizeof(EwEntry));
+              d.mw_ncfg = hp.ew2.ncfg;
+              d.mw_cshift = hp.ew2.cshift;
+              d.mw_k = -3;   // (-3: k_mwalk<., 2, 0, 3>)
+              d.mw_bytes = 256 + (int)((hp.ew2.tab.size() + hp.ew2.end.size()) * sizeof(EwEntry));
+              d.flags |= PF_MW_TRIES;
+              align(hp.blob, 16);
+            }
+          }
         }
       }
     } else {
@@ -1911,7 +1938,8 @@ std::string describe_plan(const HostPlan& hp) {
     << " step_search=" << ((d.flags & PF_STEP_SEARCH) ? 1 : 0) << ((d.flags & PF_STEP_BIG) ? " big_table=1" : "")
     << ((d.flags & PF_BSTEP) ? " bitset=1" : "") << ((d.flags & PF_STEP_EMPTY) ? (hp.empty_all_accepting ? " empty_matches=1 every_state_accepts=1" : " empty_matches=1") : "")
     << ((d.flags & PF_MW_EMPTY) ? " empty_walk=1" : "")
-    << (((d.flags & PF_STEP_EMPTY) && !hp.empty_all_accepting) ? (hp.ew2_ok ? " empty_walk2=yes configs=" + std::to_string(hp.ew2.ncfg) : " empty_walk2=no: " + hp.ew2_why) : std::string()) << "\n";
+    << (((d.flags & PF_STEP_EMPTY) && !hp.empty_all_accepting) ? (hp.ew2_ok ? " empty_walk2=yes configs=" + std::to_string(hp.ew2.ncfg) : " empty_walk2=no: " + hp.ew2_why) : std::string())
+    << (hp.ew2_tries ? (hp.ew2_ok ? " tries_walk=yes configs=" + std::to_string(hp.ew2.ncfg) : " tries_walk=no: " + hp.ew2_why) : std::string()) << "\n";
   o << "device.first_stream=" << (d.fa_bytes ? "yes" : ("no: " + hp.first_stream_why_not))
     << " fa_nstates=" << d.fa_nstates << " fa_kind=" << d.fa_kind << (hp.first_onepass ? " onepass=yes" : "")
     << (d.off_fa_run >= 0 ? " class_run=1" : "") << "\n";

@@ -64,6 +64,10 @@ enum PlanFlags : uint32_t {
                                 // reachable state accepts): findall / count in one pass on k_mwalk, one walk, up to two
                                 // reports per byte -- the match that a byte ends, and the empty match at that byte when
                                 // no walk can begin on it (DevPlan::off_mw_*; build_emptywalk())
+  PF_MW_TRIES = 1u << 25,       // plain-route table plan that fails the multi-walk proofs but whose walks read at most seven
+                                // bytes beyond their last accepting position: findall / count in one pass with the tries the
+                                // reference may come back to kept beside the oldest walk (build_emptywalk2(., empty = false);
+                                // DevPlan::off_mw_* with mw_k == -3; k_mwalk<., 2, 0, 3>).  search keeps its own route.
   PF_STREAM_SEARCH = 1u << 11   // search / sub / captures may use the streaming kernel too (findall and
                                 // count may whenever PF_STREAMABLE is set): not with a memchr prefilter,
                                 // which only match_next consults (matcher.mojo:784-796)
@@ -159,6 +163,7 @@ struct EwEntry { uint32_t x = 0; uint32_t r[3] = {0, 0, 0}; };   // control word
 struct EmptyWalk2 {
   std::array<uint8_t, 256> cls{};
   int ncls = 0, cshift = 0, ncfg = 0;
+  bool empty = true;          // the plan has empty matches (a try at every position, the last one at len)
   std::vector<EwEntry> tab;   // [ncfg][1 << cshift]
   std::vector<EwEntry> end;   // [ncfg]
 };
@@ -167,6 +172,7 @@ std::vector<std::pair<int, int>> emptywalk2_run(const EmptyWalk2& ew, const uint
 struct HostPlan {
   EmptyWalk2 ew2;   // PF_STEP_EMPTY plans that are not every_state_accepts: the general one-pass table, when it exists
   bool ew2_ok = false;
+  bool ew2_tries = false;   // ew2 is the table of a plan WITHOUT empty matches (multi-walk proofs failed)
   std::string ew2_why;
   bool empty_all_accepting = false;   // PF_STEP_EMPTY plans: every state a walk can reach accepts (a walk never overshoots)
   std::string pattern;

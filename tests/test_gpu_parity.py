@@ -1396,7 +1396,10 @@ def test_generated_patterns_multiwalk_equals_stepper_and_oracle(seed):
             texts[j] = (bytes([al[int(rng.integers(0, len(al)))]]) * (k // 2) + texts[j])[:k]
         with long_text_kernels(2):
             got = rx.findall_lists(texts)
-            if "multiwalk=yes" not in dsc and "multiwalk_req=yes" not in dsc:   # marks of the match starts + the stepper
+            if "tries_walk=yes" in dsc and "multiwalk_req=yes" not in dsc and "required-byte route" not in dsc:
+                # (round 4: walks that stay within seven bytes of their match -- one pass with the pending tries)
+                assert lib.mrx_last_kernel_name() == b"k_mwalk", (p, lib.mrx_last_kernel_name())
+            elif "multiwalk=yes" not in dsc and "multiwalk_req=yes" not in dsc:   # marks of the match starts + the stepper
                 # (tables of more than 96 states: the marked stepper in its class-indexed form)
                 assert lib.mrx_last_kernel_name() in (b"k_backscan+k_step_count", b"k_req_wave"), (p, lib.mrx_last_kernel_name())
             elif "multiwalk_req=yes" in dsc or "required-byte route" not in dsc:
@@ -1735,10 +1738,11 @@ def test_stepper_on_fixed_pitch_batches(pat, n, pitch, var, mw):
     batch = M.DeviceBatch.strided(d, pitch, length=pitch, lens=torch.from_numpy(lens).cuda() if var else None)
     lib = M.load_library()
     has_mw = mw != 2 and "multiwalk=yes" in rx.describe()
+    has_tries = mw != 2 and "tries_walk=yes" in rx.describe() and "required-byte route" not in rx.describe()   # (findall / count only)
     with long_text_kernels(2), multiwalk(mw):   # this test is about the lane-per-text kernels
         pre, sp, tot = rx._dev_findall(batch)
         has_bk = mw != 2 and not has_mw and "backset=yes" in rx.describe() and "required-byte route" not in rx.describe()
-        assert lib.mrx_last_kernel_name() == (b"k_mwalk" if has_mw else b"k_backscan+k_step_count" if has_bk else b"k_step_count")
+        assert lib.mrx_last_kernel_name() == (b"k_mwalk" if has_mw or has_tries else b"k_backscan+k_step_count" if has_bk else b"k_step_count")
         ss, se = rx.match_next(batch)
         if has_mw and b"@" not in pat:
             assert lib.mrx_last_kernel_name() == b"k_mwalk_search"

@@ -28,6 +28,8 @@ def route(d):
         return "required-byte route on k_mwalk / k_req_wave" if "multiwalk_req=yes" in d else "required-byte route: stepper / k_req_wave"
     if " multiwalk=yes" in d:
         return "multi-walk table (k_mwalk)"
+    if "tries_walk=yes" in d:
+        return "pending tries beside the oldest walk (k_mwalk, round 4)"
     if "backset=yes" in d and "device.steppable=yes" in d:
         return "backward marks + stepper (k_backscan + k_wstep)"
     if "bitset=1" in d:
