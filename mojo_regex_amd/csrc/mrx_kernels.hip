@@ -687,10 +687,11 @@ __host__ __device__ inline size_t mwalk_table_bytes(const DevPlan& p) { return (
 // perm(a, b, sel): result byte k = byte sel[k] of the eight bytes b (0-3) | a (4-7).
 // EMP = 1 (PF_MW_EMPTY plans, build_emptywalk(): one walk, every state accepts): entry bit 11 = the empty match at this
 // byte (reported behind the match the byte ends, if it ends one), and every text ends with the empty match at its length.
-// EMP = 2 (DevPlan::mw_k == -2, build_emptywalk2()): walks that read up to seven bytes beyond their match.  128-bit
-// entries (EwEntry): x bit 0 report (start, last) registers, bit 1 last = pos + 1, bits 2-5 / 6-9 the try that takes over as
-// the oldest walk (start = pos - a, last = start + len), bits 10-13 how many dead tries are reported, bits 16.. next row;
-// y, z, w: their (a, len), eight bits each.  end[config] behind the table: the same at the end of the text.
+// EMP = 2 (DevPlan::mw_k == -2, build_emptywalk2()): walks that read up to fourteen bytes beyond their match.  32-byte
+// entries (EwEntry): word 0 bit 0 report (start, last) registers, bit 1 last = pos + 1, bits 2-5 / 6-9 the try that takes
+// over as the oldest walk (start = pos - a, last = start + len), bits 10-14 how many dead tries are reported, bits 16..
+// next row; words 1-7: their (a, len), eight bits each.  end[config] behind the table: the same at the end of the text.
+// EMP = 3 (mw_k == -3, PF_MW_TRIES): the same table form for a plan without empty matches (no try at len).
 template <int MODE, int KW = 4, int PK = 0, int EMP = 0>
 __global__ __launch_bounds__(64 * kWsWaves) void k_mwalk(DevPlan p, const uint8_t* __restrict__ blob, Layout lay,
                                                          int64_t n, int32_t* __restrict__ counts,
@@ -744,8 +745,8 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_mwalk(DevPlan p, const uint8_
   __syncthreads();
   const uint8_t* clsT = lds;
   const uint32_t* tab = (const uint32_t*)(lds + 256);
-  const uint4* tab64 = (const uint4*)(lds + 256);                                        // EMP == 2: 128-bit entries (EwEntry)
-  const uint4* end64 = tab64 + ((size_t)p.mw_ncfg << p.mw_cshift);                       // ... one per configuration behind them
+  const uint32_t* tab64 = (const uint32_t*)(lds + 256);                                  // TRIES: 32-byte entries (EwEntry), eight words each
+  const uint32_t* end64 = tab64 + (((size_t)p.mw_ncfg << p.mw_cshift) << 3);             // ... one per configuration behind them
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint8_t* tile = tiles[wave];
   const int seg = lane % LPR, rsub = lane / LPR;
@@ -800,29 +801,23 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_mwalk(DevPlan p, const uint8_
       ++k;
     };
     // EMP == 2: one entry -- W0's match, the dead tries the chase passes, the try that takes over, the next row
-    auto ew2_apply = [&](const uint4 en2, const int base, const bool step) {
+    auto ew2_apply = [&](const uint32_t* ent, const int base, const bool step) {
+      const uint32_t x = ent[0];
       if (MODE == STEP_COUNT) {
-        k += (int)(en2.x & 1u) + (int)((en2.x >> 10) & 15u);
+        k += (int)(x & 1u) + (int)((x >> 10) & 31u);
       } else {
-        if (en2.x & 1u) report(s0, last);
-        const int nrep = (int)((en2.x >> 10) & 15u);
-        if (nrep) {   // (rare: the oldest walk died with tries behind it, or no walk begins on this byte)
-          uint32_t rw[3] = {en2.y, en2.z, en2.w};
-#pragma unroll
-          for (int w3 = 0; w3 < 3; ++w3) {
-            uint32_t rf = rw[w3];
-            for (int r = 4 * w3; r < nrep && r < 4 * w3 + 4; ++r) {
-              const int st = base - (int)(rf & 15u);
-              report(st, st + (int)((rf >> 4) & 15u));
-              rf >>= 8;
-            }
-          }
+        if (x & 1u) report(s0, last);
+        const int nrep = (int)((x >> 10) & 31u);
+        for (int r = 0; r < nrep; ++r) {   // (rare: the oldest walk died with tries behind it, or no walk begins on this byte)
+          const uint32_t rf = ent[1 + (r >> 2)] >> (8 * (r & 3));
+          const int st = base - (int)(rf & 15u);
+          report(st, st + (int)((rf >> 4) & 15u));
         }
-        const int ta = (int)((en2.x >> 2) & 15u);
-        if (ta) { s0 = base - (ta - 1); last = s0 + (int)((en2.x >> 6) & 15u); }
-        else if (en2.x & 2u) last = base + 1;
+        const int ta = (int)((x >> 2) & 15u);
+        if (ta) { s0 = base - (ta - 1); last = s0 + (int)((x >> 6) & 15u); }
+        else if (x & 2u) last = base + 1;
       }
-      if (step) e = en2.x;
+      if (step) e = x;
     };
     const uint8_t* myrow = tile + lane * kRowPitch;
     uint4 v[NL];
@@ -849,7 +844,7 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_mwalk(DevPlan p, const uint8_
       do {                                                                                                           \
         const int f = (F_);                           /* frame position, the same for every lane */                  \
         if constexpr (TRIES) {                                                                                       \
-          if (!fin && f >= mis && f < end) ew2_apply(tab64[(e >> 16) + clsT[(BYTE_)]], f - mis, true);               \
+          if (!fin && f >= mis && f < end) ew2_apply(tab64 + (((e >> 16) + clsT[(BYTE_)]) << 3), f - mis, true);     \
           break;                                                                                                     \
         }                                                                                                            \
         /* FULL_ = 2 (search): a lane that has its answer keeps stepping on whatever its row holds -- its registers   \
@@ -932,7 +927,7 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_mwalk(DevPlan p, const uint8_
         if (MODE != STEP_COUNT && !all_full && !fin && f0 + 16 >= end) {
           // the text ended in this group: its last report now (the oldest walk has accepted), then the lane rides along
           if constexpr (TRIES) {
-            ew2_apply(end64[(e >> 16) >> p.mw_cshift], t.len, false);   // every walk dies behind the last byte
+            ew2_apply(end64 + (((e >> 16) >> p.mw_cshift) << 3), t.len, false);   // every walk dies behind the last byte
           } else
           if ((e >> 10) & 1u) {
             if (PK) report((int)(R01 & 0xFFFFu), (int)(Lr & 0xFFFFu)); else report(s0, last);
@@ -947,7 +942,7 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_mwalk(DevPlan p, const uint8_
     }
 #undef MRX_MW_LOAD
     if constexpr (TRIES) {
-      if (!fin) ew2_apply(end64[(e >> 16) >> p.mw_cshift], t.len, false);
+      if (!fin) ew2_apply(end64 + (((e >> 16) >> p.mw_cshift) << 3), t.len, false);
     } else
     if (PK) { if (!fin && ((e >> 10) & 1u)) report((int)(R01 & 0xFFFFu), (int)(Lr & 0xFFFFu)); }
     else

@@ -377,27 +377,27 @@ bool build_emptywalk(const SearchAutomaton& s, MultiWalk& mw, std::string& why) 
   return true;
 }
 
-// The general form (PF_MW_EMPTY with DevPlan::mw_k == -2): walks that read up to seven bytes beyond their last accepting
+// The general form (PF_MW_EMPTY with DevPlan::mw_k == -2): walks that read up to fourteen bytes beyond their last accepting
 // position (`(ab)*`, `(foo)?x*`).  When such a walk dies at byte p the reference resumes at its match's end (or one byte
 // behind its start after an empty match) and tries again from there -- over bytes this pass has already seen.  So the
 // tries that MAY be asked for run beside the oldest walk W0: one per position from W0's resume point R up to p, each
 // alive (its state, how far its match reaches) or dead (how far its match reached).  A configuration is W0's state and
-// that list (at most seven entries); W0's start and match end are the lane's registers.  Per byte: every walk steps, a
+// that list (at most fourteen entries); W0's start and match end are the lane's registers.  Per byte: every walk steps, a
 // walk begins on the byte; when W0 accepts, the list is dropped (every entry began inside its match); when W0 dies, its
 // match is reported and the list is chased as the reference's loop would: a dead entry is reported and skipped past, the
 // first live entry reached takes over as W0 (the entries in front of ITS resume point are dropped), and when the chase
-// runs off the list the next byte starts afresh.  Entry, 128 bits (EwEntry): x bit 0 report W0 (start, last registers),
+// runs off the list the next byte starts afresh.  Entry, 32 bytes (EwEntry): x bit 0 report W0 (start, last registers),
 // bit 1 W0 accepts here, bits 2-5 a + 1 / bits 6-9 len of the entry that takes over (start = pos - a, last = start +
-// len; 0: none), bits 10-13 how many dead entries are reported, bits 16-31 the next configuration; r[0..2]: their (a, len)
-// pairs, eight bits each, in report order.  end[config]: the same for the end of the text (every walk dies; a relative
-// to len); the empty match at len is the kernel's.  Up to seven entries behind W0 and twelve reports on a byte.
+// len; 0: none), bits 10-14 how many dead entries are reported, bits 16-31 the next configuration; r[0..6]: their (a, len)
+// pairs, eight bits each, in report order (read only when there are any).  end[config]: the same for the end of the text
+// (every walk dies; a relative to len); the empty match at len is the kernel's.  Up to fourteen entries behind W0.
 // empty = false: the same search for plans WITHOUT empty matches (the plain restart-per-position route of a table plan
 // that fails the multi-walk proofs, e.g. `foo|[a-z]{3}\d|[ab]`: a later start accepts while the earlier walk is still
 // undecided -- here that later try simply waits in the list with its match).  A try that leaves no match (it dies before
 // it accepts, or its byte may not start a walk) is a dead entry of length 0 that is skipped WITHOUT a report, W0 is
 // reported only once it has accepted (part of the configuration), and there is no try at len.
 bool build_emptywalk2(const SearchAutomaton& s, EmptyWalk2& ew, std::string& why, bool empty = true) {
-  constexpr int kSlots = 7, kReports = 12;
+  constexpr int kSlots = 14, kReports = 28;
   ew.empty = empty;
   std::vector<int> rep;
   {
@@ -438,7 +438,11 @@ bool build_emptywalk2(const SearchAutomaton& s, EmptyWalk2& ew, std::string& why
   };
   std::vector<std::vector<EwEntry>> rows;
   for (size_t ci = 0; ci < cfgs.size(); ++ci) {
-    if ((int64_t)cfgs.size() * (ncp + 1) > 3900) { why = "empty-match walk: configuration table beyond the LDS budget"; return false; }
+    // 32-byte entries, 16 KB at most: the table shares the plan's blob (60 KiB for everything the generic kernels stage),
+    // and measured on the reference's phone patterns (75-83 configurations, 38-42 KB: two workgroups per CU, a chase on most
+    // bytes) the form is SLOWER than marks + stepper (flexible_phone 269 -> 195 GB/s), while the small tables of the
+    // generated patterns gain 3-10 x
+    if ((int64_t)cfgs.size() * (ncp + 1) > 512) { why = "pending-tries walk: configuration table beyond 16 KB"; return false; }
     const Key cur = cfgs[ci];
     const bool fresh = cur[0] < 0;
     const int q0 = fresh ? 0 : cur[0];
@@ -482,7 +486,7 @@ bool build_emptywalk2(const SearchAutomaton& s, EmptyWalk2& ew, std::string& why
         e.x |= 2u;
         nk = Key{t0, 1};
       } else if (t0 >= 0) {
-        if ((int)list.size() > kSlots) { why = "empty-match walk: a walk reads more than seven bytes beyond its last accepting position"; return false; }
+        if ((int)list.size() > kSlots) { why = "pending-tries walk: a walk reads more than fourteen bytes beyond its last accepting position"; return false; }
         nk = Key{t0, w0acc ? 1 : 0};
         for (const Slot& sl : list) { nk.push_back(sl.state); nk.push_back(sl.rel); }
       } else {
@@ -491,8 +495,8 @@ bool build_emptywalk2(const SearchAutomaton& s, EmptyWalk2& ew, std::string& why
         int take = -1;
         // positions: list[idx] is at R + idx with R = p - m; relative to base (p, or len = p at the end): a = base - R - idx = m - idx
         chase(list, m, out, &take);
-        if ((int)out.size() > kReports) { why = "empty-match walk: more than twelve reports on one byte"; return false; }
-        e.x |= (uint32_t)out.size() << 10;
+        if ((int)out.size() > kReports) { why = "pending-tries walk: more than 28 reports on one byte"; return false; }
+        e.x |= (uint32_t)out.size() << 10;   // (five bits)
         for (size_t r = 0; r < out.size(); ++r)
           e.r[r / 4] |= (uint32_t)((out[r].first & 15) | ((out[r].second & 15) << 4)) << (8 * (r % 4));
         if (take >= 0) {
@@ -504,7 +508,7 @@ bool build_emptywalk2(const SearchAutomaton& s, EmptyWalk2& ew, std::string& why
           // its resume point: behind its match, or one byte behind its start; the entries from there on stay
           const int keep_from = take + (w.rel > 0 ? w.rel : 1);
           for (int j = keep_from; j < (int)list.size(); ++j) { nk.push_back(list[j].state); nk.push_back(list[j].rel); }
-          if ((int)(nk.size() - 2) / 2 > kSlots) { why = "empty-match walk: a walk reads more than seven bytes beyond its last accepting position"; return false; }
+          if ((int)(nk.size() - 2) / 2 > kSlots) { why = "pending-tries walk: a walk reads more than fourteen bytes beyond its last accepting position"; return false; }
         } else nk = Key{-1};
       }
       if (at_end) { row[ncp] = e; continue; }
@@ -732,7 +736,7 @@ std::vector<std::pair<int, int>> emptywalk2_run(const EmptyWalk2& ew, const uint
   int s0 = 0, last = 0;
   auto apply = [&](const EwEntry& e, int base) {
     if (e.x & 1u) out.push_back({s0, last});
-    const int nrep = (int)((e.x >> 10) & 15);
+    const int nrep = (int)((e.x >> 10) & 31);
     for (int r = 0; r < nrep; ++r) {
       const int f = (int)((e.r[r / 4] >> (8 * (r % 4))) & 255);
       const int st = base - (f & 15);

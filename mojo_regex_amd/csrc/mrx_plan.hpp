@@ -159,7 +159,7 @@ struct DevPlan {
 };
 
 // empty-match plans whose walks read beyond their match: the one-pass table (build_emptywalk2(), mrx_plan.cpp)
-struct EwEntry { uint32_t x = 0; uint32_t r[3] = {0, 0, 0}; };   // control word | up to twelve (a, len) reports (mrx_plan.cpp)
+struct EwEntry { uint32_t x = 0; uint32_t r[7] = {0, 0, 0, 0, 0, 0, 0}; };   // control word | up to 28 (a, len) reports (mrx_plan.cpp)
 struct EmptyWalk2 {
   std::array<uint8_t, 256> cls{};
   int ncls = 0, cshift = 0, ncfg = 0;
