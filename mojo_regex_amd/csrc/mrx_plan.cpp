@@ -436,6 +436,18 @@ bool build_emptywalk2(const SearchAutomaton& s, EmptyWalk2& ew, std::string& why
       idx += list[idx].rel > 0 ? list[idx].rel : 1;
     }
   };
+  // Entries the chase can never reach are all alike: the first entry is where the chase begins; behind a dead entry it goes on
+  // at its match's end (one byte on when it left none); an entry inside a match that can only grow (a dead one's, or a
+  // live one's so far) is never asked for.  They become "dead, no match" -- fewer configurations, same reports.
+  auto canon = [&](std::vector<Slot>& list, size_t from) {
+    size_t idx = from;
+    while (idx < list.size()) {
+      const Slot e = list[idx];
+      for (size_t j = idx + 1; j < idx + (size_t)e.rel && j < list.size(); ++j) list[j] = Slot{-1, 0};
+      if (e.state >= 0) break;   // (how far a live entry's match will reach is not known yet)
+      idx += e.rel > 0 ? (size_t)e.rel : 1;
+    }
+  };
   std::vector<std::vector<EwEntry>> rows;
   for (size_t ci = 0; ci < cfgs.size(); ++ci) {
     // 32-byte entries, 16 KB at most: the table shares the plan's blob (60 KiB for everything the generic kernels stage),
@@ -488,6 +500,7 @@ bool build_emptywalk2(const SearchAutomaton& s, EmptyWalk2& ew, std::string& why
       } else if (t0 >= 0) {
         if ((int)list.size() > kSlots) { why = "pending-tries walk: a walk reads more than fourteen bytes beyond its last accepting position"; return false; }
         nk = Key{t0, w0acc ? 1 : 0};
+        canon(list, 0);
         for (const Slot& sl : list) { nk.push_back(sl.state); nk.push_back(sl.rel); }
       } else {
         if (w0acc) e.x |= 1u;   // W0's match
@@ -507,6 +520,7 @@ bool build_emptywalk2(const SearchAutomaton& s, EmptyWalk2& ew, std::string& why
           nk = Key{w.state, (empty || w.rel > 0) ? 1 : 0};
           // its resume point: behind its match, or one byte behind its start; the entries from there on stay
           const int keep_from = take + (w.rel > 0 ? w.rel : 1);
+          canon(list, (size_t)keep_from);
           for (int j = keep_from; j < (int)list.size(); ++j) { nk.push_back(list[j].state); nk.push_back(list[j].rel); }
           if ((int)(nk.size() - 2) / 2 > kSlots) { why = "pending-tries walk: a walk reads more than fourteen bytes beyond its last accepting position"; return false; }
         } else nk = Key{-1};
