@@ -57,6 +57,9 @@ void mrx_debug_split_findall(int on);
  * an aligned fixed pitch, common length a multiple of 128): 0 = when the handle's previous call found one match per 20
  * bytes or more (default), 1 = whenever the batch has the shape, 2 = never */
 void mrx_debug_dense_rows(int mode);
+/* PF_MW_TRIES plans: 1 = always the pending-tries walk; 0 (default) = the handle times it against
+ * marks + stepper on the first calls of a batch shape (4096 texts and more) and keeps the faster route. */
+void mrx_debug_tries_always(int on);
 /* Host-side run of the one-pass table of an empty-match plan whose walks read beyond their match (build_emptywalk2(),
  * mrx_plan.cpp): findall of ONE text on the CPU, for tests that pin the table to the oracle without a GPU.  Returns the
  * number of spans (spans[2 k], spans[2 k + 1] for k < min(count, cap)), -1 when the handle has no such table. */

@@ -4523,6 +4523,9 @@ bool mwalk_enabled() {
   return !off && g_mwalk_mode != 2 && g_force_generic == 0;   // (level 1 = the stepper and nothing newer)
 }
 bool mwalk_on(const DevPlan& p) { return (p.flags & PF_MWALK) && mwalk_enabled(); }
+// MRX_TRIES_ALWAYS=1 / mrx_debug_tries_always(1): PF_MW_TRIES plans take the pending-tries walk without the route
+// tuner's measurement (tests, A/B runs)
+std::atomic<int> g_tries_always{(getenv("MRX_TRIES_ALWAYS") && getenv("MRX_TRIES_ALWAYS")[0] == '1') ? 1 : 0};
 // PF_MW_TRIES plans on k_mwalk (MRX_NO_TRIES=1: their marks / stepper route instead -- A/B runs)
 bool mw_tries_on(const DevPlan& p) {
   static const bool off = getenv("MRX_NO_TRIES") && getenv("MRX_NO_TRIES")[0] == '1';
@@ -5564,6 +5567,11 @@ struct FindallJob {
     mwalk_req = use_req_route && (p.flags & PF_MWALK_REQ) && mwalk_enabled();
     // ... and plain-route plans outside the multi-walk proofs whose walks stay within seven bytes of their match (PF_MW_TRIES)
     mw_tries = mw_tries_on(p) && !use_req_route && g_force_generic < 2;
+    if (mw_tries && !t_in_pieces && n >= 4096 && backset_on(p) && !g_tries_always) {   // (marks + stepper is the other candidate)
+      bool use_tries = true;
+      tries_route_tuner(&use_tries);
+      mw_tries = use_tries;
+    }
     wstep_mwalk = (mwalk_req || (mwalk_on(p) && !use_req_route) || mw_empty || mw_tries) && !wstep_bits && !wstep_empty &&
                   !(match_next_sequence && (p.flags & PF_PREFILTER));
     pk = mwalk_req ? mwalk_req_plan(p) : p;
@@ -5771,6 +5779,50 @@ struct FindallJob {
     HIP_TRY(hipGetLastError());
     HIP_TRY(scratch_free(d_tsum, s));
     return MRX_OK;
+  }
+
+  // ---- PF_MW_TRIES plan: the pending-tries walk or round 3's marks + stepper?  (mrx_handle::req_tune, kind bit 30) ----
+  // The one-pass walk wins where matches are found (3-10 x), marks alone are faster where nothing matches, and bigger
+  // tables sit in between (tools/r04_tries_cap.py): as for the required-byte routes the handle measures -- the first four
+  // eligible calls of a batch shape take the routes alternately, the last two timed; no call waits.
+  static uint32_t tries_tune_key(const Layout& lay, int64_t n) {
+    const int64_t bytes_per_text = lay.offsets ? 0 : (lay.lens ? lay.stride : (int64_t)lay.len);
+    uint32_t lb = 0, nb = 0;
+    for (int64_t v = bytes_per_text; v > 1; v >>= 1) ++lb;
+    for (int64_t v = n; v > 1; v >>= 1) ++nb;
+    return (1u << 30) | (lay.offsets ? 1u << 31 : 0u) | ((uint32_t)(t_dev & 63) << 16) | (lb << 8) | nb;
+  }
+  void tries_route_tuner(bool* use_tries) {
+    *use_tries = true;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return;
+    const uint32_t key = tries_tune_key(lay, n);
+    std::lock_guard<std::mutex> lk(h->tune_mu);
+    mrx_handle::ReqTune& t = h->req_tune[key];
+    if (t.choice) { *use_tries = t.choice == 1; return; }
+    if (t.issued == 4) {
+      if (hipEventQuery(t.ev[3][1]) != hipSuccess) return;   // not through yet: the default route, unmeasured
+      if (hipEventElapsedTime(&t.ms_wave, t.ev[2][0], t.ev[2][1]) != hipSuccess ||
+          hipEventElapsedTime(&t.ms_pieces, t.ev[3][0], t.ev[3][1]) != hipSuccess) { t.choice = 1; return; }
+      t.choice = t.ms_pieces < t.ms_wave ? 2 : 1;
+      static const bool verbose = getenv("MRX_TUNE_VERBOSE") != nullptr;
+      if (verbose) fprintf(stderr, "mrx: plain route of '%s' (key %08x): pending tries %.3f ms, marks + stepper %.3f ms -> %s\n",
+                           h->hp.pattern.c_str(), key, t.ms_wave, t.ms_pieces, t.choice == 2 ? "marks" : "tries");
+      *use_tries = t.choice == 1;
+      return;
+    }
+    if (!t.ev[3][1]) {
+      t.dev = t_dev;
+      for (auto& pr : t.ev)
+        for (auto& e : pr)
+          if (hipEventCreate(&e) != hipSuccess) { t.choice = 1; return; }
+    }
+    if (t.dev != t_dev) return;
+    tune_key = key;
+    tune_slot = t.issued++;
+    tune_route = (tune_slot & 1) ? 2 : 1;
+    *use_tries = tune_route == 1;
+    if (hipEventRecord(t.ev[tune_slot][0], s) != hipSuccess) { t.choice = 1; tune_route = 0; *use_tries = true; }
   }
 
   // ---- required-byte plan on long texts: which route?  (mrx_handle::req_tune) ----
@@ -6908,7 +6960,12 @@ static int run_count_any(const mrx_handle* h, const Layout& lay, int64_t n, int3
     const bool mw_empty = (h->hp.dev.flags & PF_MW_EMPTY) != 0 && mwalk_enabled() && g_force_generic < 2;
     const bool wstep_empty = (h->hp.dev.flags & PF_STEP_EMPTY) != 0 && g_force_generic < 2 && !mw_empty;
     const bool mwalk_req = use_req_route && (h->hp.dev.flags & PF_MWALK_REQ) && mwalk_enabled();
-    const bool mw_tries = mw_tries_on(h->hp.dev) && !use_req_route && g_force_generic < 2;
+    bool mw_tries = mw_tries_on(h->hp.dev) && !use_req_route && g_force_generic < 2;
+    if (mw_tries && !t_in_pieces && n >= 4096 && !g_tries_always) {   // (findall's measurement for this batch shape, if there is one)
+      std::lock_guard<std::mutex> lk(h->tune_mu);
+      const auto it = h->req_tune.find(FindallJob::tries_tune_key(lay, n));
+      if (it != h->req_tune.end() && it->second.choice == 2) mw_tries = false;
+    }
     const bool wstep_mwalk = (mwalk_req || (mwalk_on(h->hp.dev) && !use_req_route) || mw_empty || mw_tries) && !wstep_bits && !wstep_empty;
     const DevPlan pk = mwalk_req ? mwalk_req_plan(h->hp.dev) : h->hp.dev;
     const int wstep_mwalk_k = pk.mw_k;
@@ -7259,6 +7316,7 @@ void mrx_debug_stream_bits_trace(int64_t* d_trace) { mrx::stream_bits_set_trace(
 void mrx_debug_dynamic_texts(int mode) { g_dyn_mode = mode < 0 ? 0 : mode > 2 ? 0 : mode; }
 void mrx_debug_split_findall(int on) { g_split_findall = on ? 1 : 0; }
 void mrx_debug_dense_rows(int mode) { g_dense_rows = mode; }
+void mrx_debug_tries_always(int on) { g_tries_always = on ? 1 : 0; }
 int mrx_testing_emptywalk_findall(const mrx_handle* h, const uint8_t* text, int len, int32_t* spans, int cap) {
   if (!h || !h->hp.ew2_ok || len < 0) return -1;
   const std::vector<std::pair<int, int>> v = emptywalk2_run(h->hp.ew2, text, len);

@@ -450,11 +450,13 @@ bool build_emptywalk2(const SearchAutomaton& s, EmptyWalk2& ew, std::string& why
   };
   std::vector<std::vector<EwEntry>> rows;
   for (size_t ci = 0; ci < cfgs.size(); ++ci) {
-    // 32-byte entries, 16 KB at most: the table shares the plan's blob (60 KiB for everything the generic kernels stage),
-    // and measured on the reference's phone patterns (75-83 configurations, 38-42 KB: two workgroups per CU, a chase on most
-    // bytes) the form is SLOWER than marks + stepper (flexible_phone 269 -> 195 GB/s), while the small tables of the
-    // generated patterns gain 3-10 x
-    if ((int64_t)cfgs.size() * (ncp + 1) > 512) { why = "pending-tries walk: configuration table beyond 16 KB"; return false; }
+    // 32-byte entries, 41 KB at most, and no more than the plan's blob has room for (60 KiB for everything the generic kernels
+    // stage: checked where the table is stored).  Small tables gain 3-10 x over marks + stepper; tables of 16-41 KB run at
+    // about half their speed (two workgroups per CU) and win two times out of three (tools/r04_tries_cap.py); on the
+    // reference's phone patterns by pieces the form is slower (flexible_phone 269 -> 195 GB/s).  Plans without empty matches
+    // are therefore MEASURED per handle against marks + stepper (FindallJob::tries_route_tuner).
+    static const int64_t cap_entries = getenv("MRX_TRIES_CAP_ENTRIES") ? atoll(getenv("MRX_TRIES_CAP_ENTRIES")) : 1300;   // (A/B runs)
+    if ((int64_t)cfgs.size() * (ncp + 1) > cap_entries) { why = "pending-tries walk: configuration table beyond 41 KB"; return false; }
     const Key cur = cfgs[ci];
     const bool fresh = cur[0] < 0;
     const int q0 = fresh ? 0 : cur[0];
@@ -1548,6 +1550,10 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
           if (!sa.acc[0]) {
             hp.ew2_ok = build_emptywalk2(sa, hp.ew2, hp.ew2_why, false);
             hp.ew2_tries = true;
+            if (hp.ew2_ok && hp.blob.size() + 8192 + (hp.ew2.tab.size() + hp.ew2.end.size()) * sizeof(EwEntry) > 60 * 1024) {
+              hp.ew2_ok = false;   // (8 KiB kept for what is appended behind this point: stepper table, sync bytes)
+              hp.ew2_why = "pending-tries walk: no room left in the plan's 60 KiB";
+            }
             if (hp.ew2_ok) {
               align(hp.blob, 16);
               d.off_mw_cls = (int)hp.blob.size();
@@ -1658,6 +1664,10 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
       sa.acc = acc;
       sa.allowed.fill(1);
       hp.ew2_ok = build_emptywalk2(sa, hp.ew2, hp.ew2_why);
+      if (hp.ew2_ok && hp.blob.size() + 512 + (hp.ew2.tab.size() + hp.ew2.end.size()) * sizeof(EwEntry) > 60 * 1024) {
+        hp.ew2_ok = false;
+        hp.ew2_why = "pending-tries walk: no room left in the plan's 60 KiB";
+      }
       if (hp.ew2_ok) {
         align(hp.blob, 16);
         d.off_mw_cls = (int)hp.blob.size();

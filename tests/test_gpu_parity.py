@@ -2841,3 +2841,33 @@ def test_multiwalk_table_that_no_walk_ever_enters():
     assert rx.sub(b"#", texts) == [O.sub(pat, b"#", t) for t in texts]
     batch = M.DeviceBatch.from_texts(texts)
     assert rx.count(batch).cpu().tolist() == [len(O.findall(pat, t)) for t in texts]
+
+
+def test_pending_tries_walk_is_timed_against_marks_and_the_answers_stay_the_same():
+    """PF_MW_TRIES plan on a batch of 4096 texts and more: the handle takes the pending-tries walk and marks + stepper
+    alternately on its first four calls (two of them timed) and keeps the faster route; every call returns the same CSR."""
+    _need_gpu()
+    lib = M.load_library()
+    pat = b"foo|[a-z]{3}\\d|[ab]"
+    rx = M.CompiledRegex(pat)   # (a handle of its own: the tuner's state is the handle's)
+    assert "tries_walk=yes" in rx.describe()
+    rng = np.random.default_rng(12)
+    al = np.frombuffer(b"abcfoxyz0123 -", dtype=np.uint8)
+    n, L = 8192, 208
+    arr = al[rng.integers(0, len(al), (n, L))]
+    batch = M.DeviceBatch.strided(torch.from_numpy(arr).cuda().reshape(-1), L, length=L)
+    names, first = [], None
+    for _ in range(7):
+        pre, sp, tot = rx._dev_findall(batch, span_cap=n * L)   # (room for every span: a retry would be a call of its own)
+        names.append(lib.mrx_last_kernel_name())
+        torch.cuda.synchronize()
+        if first is None:
+            first = (pre.clone(), sp[:tot].clone())
+        assert torch.equal(pre, first[0]) and torch.equal(sp[:tot], first[1])
+    assert names[0] == b"k_mwalk" and names[1] == b"k_backscan+k_step_count", names     # the two candidates in turn
+    assert names[5] == names[6] and names[6] in (b"k_mwalk", b"k_backscan+k_step_count"), names
+    cnt = rx.count(batch).cpu()
+    assert torch.equal(cnt.to(torch.int64), (first[0][1:] - first[0][:-1]).cpu())
+    pre_h, sp_h = first[0].cpu().numpy(), first[1].cpu().numpy()
+    for i in range(0, n, 997):
+        assert [tuple(x) for x in sp_h[pre_h[i]:pre_h[i + 1]].tolist()] == O.findall(pat, arr[i].tobytes())
