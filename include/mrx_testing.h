@@ -58,7 +58,7 @@ void mrx_debug_split_findall(int on);
  * bytes or more (default), 1 = whenever the batch has the shape, 2 = never */
 void mrx_debug_dense_rows(int mode);
 /* PF_MW_TRIES plans: 1 = always the pending-tries walk; 0 (default) = the handle times it against
- * marks + stepper on the first calls of a batch shape (4096 texts and more) and keeps the faster route. */
+ * marks + stepper on the first calls of a batch shape (256 texts and more) and keeps the faster route. */
 void mrx_debug_tries_always(int on);
 /* Host-side run of the one-pass table of an empty-match plan whose walks read beyond their match (build_emptywalk2(),
  * mrx_plan.cpp): findall of ONE text on the CPU, for tests that pin the table to the oracle without a GPU.  Returns the

@@ -5417,6 +5417,7 @@ static int findall_split(const mrx_handle* h, const Layout& lay, int64_t n, int3
 thread_local bool t_in_pieces = false;
 // findall by pieces: the pieces' bases, for an inner route whose emit kernel can add them itself (k_mwalk), and whether
 // it did -- otherwise k_virt_add_base goes over the spans once more
+thread_local int t_piece_tries = -1;   // findall by pieces: the outer call's choice for a PF_MW_TRIES plan (-1: none, 0 marks + stepper, 1 tries)
 thread_local const int32_t* t_piece_vbase = nullptr;
 thread_local bool t_piece_base_applied = false;
 // plain-route stepper plan on long texts: pieces (true) or the wavefront kernel (false)?  Decided by the share of
@@ -5567,7 +5568,8 @@ struct FindallJob {
     mwalk_req = use_req_route && (p.flags & PF_MWALK_REQ) && mwalk_enabled();
     // ... and plain-route plans outside the multi-walk proofs whose walks stay within seven bytes of their match (PF_MW_TRIES)
     mw_tries = mw_tries_on(p) && !use_req_route && g_force_generic < 2;
-    if (mw_tries && !t_in_pieces && n >= 4096 && backset_on(p) && !g_tries_always) {   // (marks + stepper is the other candidate)
+    if (t_in_pieces && t_piece_tries >= 0) mw_tries = mw_tries && t_piece_tries == 1;   // (the pieces follow the call they belong to)
+    if (mw_tries && !t_in_pieces && n >= 256 && backset_on(p) && !g_tries_always) {   // (marks + stepper is the other candidate)
       bool use_tries = true;
       tries_route_tuner(&use_tries);
       mw_tries = use_tries;
@@ -5911,9 +5913,11 @@ struct FindallJob {
         t_in_pieces = true;
         t_piece_vbase = spc.vbase;
         t_piece_base_applied = false;
+        t_piece_tries = (p.flags & PF_MW_TRIES) ? (mw_tries ? 1 : 0) : -1;
         const int rc = run_findall(h, spc.lay, spc.nv, d_vprefix, d_spans, span_cap, nullptr, s, match_next_sequence);
         t_in_pieces = false;
         t_piece_vbase = nullptr;
+        t_piece_tries = -1;
         if (rc != MRX_OK) return rc;
         const std::string inner = g_last_kernel;
         hipLaunchKernelGGL(k_virt_prefix, dim3(grid_for(n + 1, kBlock)), dim3(kBlock), 0, s, n, spc.vfirst, d_vprefix, d_prefix);
@@ -6961,7 +6965,8 @@ static int run_count_any(const mrx_handle* h, const Layout& lay, int64_t n, int3
     const bool wstep_empty = (h->hp.dev.flags & PF_STEP_EMPTY) != 0 && g_force_generic < 2 && !mw_empty;
     const bool mwalk_req = use_req_route && (h->hp.dev.flags & PF_MWALK_REQ) && mwalk_enabled();
     bool mw_tries = mw_tries_on(h->hp.dev) && !use_req_route && g_force_generic < 2;
-    if (mw_tries && !t_in_pieces && n >= 4096 && !g_tries_always) {   // (findall's measurement for this batch shape, if there is one)
+    if (t_in_pieces && t_piece_tries >= 0) mw_tries = mw_tries && t_piece_tries == 1;
+    if (mw_tries && !t_in_pieces && n >= 256 && !g_tries_always) {   // (findall's measurement for this batch shape, if there is one)
       std::lock_guard<std::mutex> lk(h->tune_mu);
       const auto it = h->req_tune.find(FindallJob::tries_tune_key(lay, n));
       if (it != h->req_tune.end() && it->second.choice == 2) mw_tries = false;
@@ -6988,8 +6993,10 @@ static int run_count_any(const mrx_handle* h, const Layout& lay, int64_t n, int3
         int32_t* d_vcounts = nullptr;
         HIP_TRY(scratch_alloc((void**)&d_vcounts, sizeof(int32_t) * spc.nv, s));
         t_in_pieces = true;
+        t_piece_tries = (h->hp.dev.flags & PF_MW_TRIES) ? (mw_tries ? 1 : 0) : -1;
         const int rc = run_count_any(h, spc.lay, spc.nv, d_vcounts, st);
         t_in_pieces = false;
+        t_piece_tries = -1;
         if (rc != MRX_OK) return rc;
         hipLaunchKernelGGL(k_virt_sum, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, n, spc.vfirst, d_vcounts, counts);
         HIP_TRY(hipGetLastError());

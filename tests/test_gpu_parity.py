@@ -2844,7 +2844,7 @@ def test_multiwalk_table_that_no_walk_ever_enters():
 
 
 def test_pending_tries_walk_is_timed_against_marks_and_the_answers_stay_the_same():
-    """PF_MW_TRIES plan on a batch of 4096 texts and more: the handle takes the pending-tries walk and marks + stepper
+    """PF_MW_TRIES plan on a batch of 256 texts and more: the handle takes the pending-tries walk and marks + stepper
     alternately on its first four calls (two of them timed) and keeps the faster route; every call returns the same CSR."""
     _need_gpu()
     lib = M.load_library()
