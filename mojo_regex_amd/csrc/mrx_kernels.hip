@@ -5489,6 +5489,47 @@ int run_findall(const mrx_handle* h, const Layout& lay, int64_t n, int64_t* d_pr
 
 // One findall call.  The members are the state the routes share (the launch macros of this file read the route flags by
 // name); one member function per route -- round 3's run_findall was a single 420-line function steering ~25 flags.
+// Two routes for one plan and batch shape, measured by the handle (mrx_handle::req_tune[key]): the first four eligible calls
+// take route 1, 2, 1, 2, the last two between HIP events on the caller's stream; a later call that finds the last event
+// complete keeps the faster route.  Returns the route this call takes (1 or 2); *slot >= 0 when the call is one of the
+// four (ab_tuner_end records its closing event once the call's work is enqueued).  No call waits; a stream under graph
+// capture is left alone (route 1).
+static int ab_tuner_begin(const mrx_handle* h, uint32_t key, hipStream_t s, const char* what, int* slot) {
+  *slot = -1;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return 1;
+  std::lock_guard<std::mutex> lk(h->tune_mu);
+  mrx_handle::ReqTune& t = h->req_tune[key];
+  if (t.choice) return t.choice;
+  if (t.issued == 4) {
+    if (hipEventQuery(t.ev[3][1]) != hipSuccess) return 1;   // not through yet: the default route, unmeasured
+    if (hipEventElapsedTime(&t.ms_wave, t.ev[2][0], t.ev[2][1]) != hipSuccess ||
+        hipEventElapsedTime(&t.ms_pieces, t.ev[3][0], t.ev[3][1]) != hipSuccess) { t.choice = 1; return 1; }
+    t.choice = t.ms_pieces < t.ms_wave ? 2 : 1;
+    static const bool verbose = getenv("MRX_TUNE_VERBOSE") != nullptr;
+    if (verbose) fprintf(stderr, "mrx: %s of '%s' (key %08x): pending tries %.3f ms, marks + stepper %.3f ms -> %s\n", what,
+                         h->hp.pattern.c_str(), key, t.ms_wave, t.ms_pieces, t.choice == 2 ? "marks" : "tries");
+    return t.choice;
+  }
+  if (!t.ev[3][1]) {
+    t.dev = t_dev;
+    for (auto& pr : t.ev)
+      for (auto& e : pr)
+        if (hipEventCreate(&e) != hipSuccess) { t.choice = 1; return 1; }
+  }
+  if (t.dev != t_dev) return 1;
+  const int sl = t.issued++;
+  if (hipEventRecord(t.ev[sl][0], s) != hipSuccess) { t.choice = 1; return 1; }
+  *slot = sl;
+  return (sl & 1) ? 2 : 1;
+}
+static void ab_tuner_end(const mrx_handle* h, uint32_t key, int slot, hipStream_t s) {
+  if (slot < 0) return;
+  std::lock_guard<std::mutex> lk(h->tune_mu);
+  mrx_handle::ReqTune& t = h->req_tune[key];
+  if (t.ev[slot][1]) (void)hipEventRecord(t.ev[slot][1], s);
+}
+
 struct FindallJob {
   const mrx_handle* h;
   const Layout& lay;
@@ -5795,36 +5836,10 @@ struct FindallJob {
     return (1u << 30) | (lay.offsets ? 1u << 31 : 0u) | ((uint32_t)(t_dev & 63) << 16) | (lb << 8) | nb;
   }
   void tries_route_tuner(bool* use_tries) {
-    *use_tries = true;
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return;
+    int slot = -1;
     const uint32_t key = tries_tune_key(lay, n);
-    std::lock_guard<std::mutex> lk(h->tune_mu);
-    mrx_handle::ReqTune& t = h->req_tune[key];
-    if (t.choice) { *use_tries = t.choice == 1; return; }
-    if (t.issued == 4) {
-      if (hipEventQuery(t.ev[3][1]) != hipSuccess) return;   // not through yet: the default route, unmeasured
-      if (hipEventElapsedTime(&t.ms_wave, t.ev[2][0], t.ev[2][1]) != hipSuccess ||
-          hipEventElapsedTime(&t.ms_pieces, t.ev[3][0], t.ev[3][1]) != hipSuccess) { t.choice = 1; return; }
-      t.choice = t.ms_pieces < t.ms_wave ? 2 : 1;
-      static const bool verbose = getenv("MRX_TUNE_VERBOSE") != nullptr;
-      if (verbose) fprintf(stderr, "mrx: plain route of '%s' (key %08x): pending tries %.3f ms, marks + stepper %.3f ms -> %s\n",
-                           h->hp.pattern.c_str(), key, t.ms_wave, t.ms_pieces, t.choice == 2 ? "marks" : "tries");
-      *use_tries = t.choice == 1;
-      return;
-    }
-    if (!t.ev[3][1]) {
-      t.dev = t_dev;
-      for (auto& pr : t.ev)
-        for (auto& e : pr)
-          if (hipEventCreate(&e) != hipSuccess) { t.choice = 1; return; }
-    }
-    if (t.dev != t_dev) return;
-    tune_key = key;
-    tune_slot = t.issued++;
-    tune_route = (tune_slot & 1) ? 2 : 1;
-    *use_tries = tune_route == 1;
-    if (hipEventRecord(t.ev[tune_slot][0], s) != hipSuccess) { t.choice = 1; tune_route = 0; *use_tries = true; }
+    *use_tries = ab_tuner_begin(h, key, s, "findall", &slot) == 1;
+    if (slot >= 0) { tune_key = key; tune_slot = slot; tune_route = *use_tries ? 1 : 2; }
   }
 
   // ---- required-byte plan on long texts: which route?  (mrx_handle::req_tune) ----
@@ -6966,11 +6981,14 @@ static int run_count_any(const mrx_handle* h, const Layout& lay, int64_t n, int3
     const bool mwalk_req = use_req_route && (h->hp.dev.flags & PF_MWALK_REQ) && mwalk_enabled();
     bool mw_tries = mw_tries_on(h->hp.dev) && !use_req_route && g_force_generic < 2;
     if (t_in_pieces && t_piece_tries >= 0) mw_tries = mw_tries && t_piece_tries == 1;
-    if (mw_tries && !t_in_pieces && n >= 256 && !g_tries_always) {   // (findall's measurement for this batch shape, if there is one)
-      std::lock_guard<std::mutex> lk(h->tune_mu);
-      const auto it = h->req_tune.find(FindallJob::tries_tune_key(lay, n));
-      if (it != h->req_tune.end() && it->second.choice == 2) mw_tries = false;
-    }
+    int cnt_slot = -1;
+    const uint32_t cnt_key = FindallJob::tries_tune_key(lay, n) | (1u << 29);   // (count's own measurement)
+    if (mw_tries && !t_in_pieces && n >= 256 && backset_on(h->hp.dev) && !g_tries_always)
+      mw_tries = ab_tuner_begin(h, cnt_key, s, "count", &cnt_slot) == 1;
+    struct CountTuneEnd {   // (closes the measurement on every way out of this call)
+      const mrx_handle* h; uint32_t key; int slot; hipStream_t s;
+      ~CountTuneEnd() { ab_tuner_end(h, key, slot, s); }
+    } cnt_tune_end{h, cnt_key, cnt_slot, s};
     const bool wstep_mwalk = (mwalk_req || (mwalk_on(h->hp.dev) && !use_req_route) || mw_empty || mw_tries) && !wstep_bits && !wstep_empty;
     const DevPlan pk = mwalk_req ? mwalk_req_plan(h->hp.dev) : h->hp.dev;
     const int wstep_mwalk_k = pk.mw_k;
