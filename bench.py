@@ -559,6 +559,8 @@ def main():
                     "error": "the extra legs did not finish within %.0f s (watchdog); %s; headline unaffected" % (limit, where)}
                 print(json.dumps(line), flush=True)
             os._exit(3)
+        # (the first leg is named before the timer starts: a timer that fires at once must not report leg 'none')
+        progress["leg"], progress["call"] = "scan_plus_gather", "starting"
         watchdog = threading.Timer(limit, _bail)
         watchdog.daemon = True
         watchdog.start()
