@@ -700,7 +700,8 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_mwalk(DevPlan p, const uint8_
                                                          int32_t* __restrict__ out_s, int32_t* __restrict__ out_e) {
   constexpr int CH = 128, kRowPitch = CH + 16, LPR = CH / 16, RPI = 64 / LPR, NL = 64 / RPI;
   static_assert(!PK || ((KW == 2 || KW == 4) && MODE != STEP_COUNT && MODE != STEP_ANY), "packed starts: two or four slots, modes with registers");
-  static_assert(!EMP || (KW == 2 && !PK && (MODE == STEP_COUNT || MODE == STEP_EMIT)), "empty-match walk: count and emit passes");
+  static_assert(!EMP || (KW == 2 && !PK && (MODE == STEP_COUNT || MODE == STEP_EMIT || (MODE == STEP_SEARCH && EMP == 3))),
+                "empty-match / pending-tries walk: count and emit passes; search for plans without empty matches");
   static_assert(EMP >= 0 && EMP <= 3, "0: multi-walk table, 1: one walk that never overshoots, 2: walks with pending tries behind them, 3: the same for plans without empty matches");
   constexpr bool TRIES = EMP == 2 || EMP == 3;     // 128-bit entries (EwEntry)
   constexpr bool LAST_TRY = EMP == 1 || EMP == 2;  // empty matches: the last try is at pos == len
@@ -807,11 +808,12 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_mwalk(DevPlan p, const uint8_
         k += (int)(x & 1u) + (int)((x >> 10) & 31u);
       } else {
         if (x & 1u) report(s0, last);
-        const int nrep = (int)((x >> 10) & 31u);
+        const int nrep = (MODE == STEP_SEARCH && fin) ? 0 : (int)((x >> 10) & 31u);   // (search: the first report is the answer)
         for (int r = 0; r < nrep; ++r) {   // (rare: the oldest walk died with tries behind it, or no walk begins on this byte)
           const uint32_t rf = ent[1 + (r >> 2)] >> (8 * (r & 3));
           const int st = base - (int)(rf & 15u);
           report(st, st + (int)((rf >> 4) & 15u));
+          if (MODE == STEP_SEARCH) break;
         }
         const int ta = (int)((x >> 2) & 15u);
         if (ta) { s0 = base - (ta - 1); last = s0 + (int)((x >> 6) & 15u); }
@@ -4471,6 +4473,12 @@ bool mwalk_pk_ok(const Layout& lay, int64_t known_max) {
 }
 template <int MODE, class... Args>
 void mwalk_launch(int kw, bool pk, dim3 g, dim3 b, size_t lds_bytes, hipStream_t s, Args... args) {
+  if constexpr (MODE == STEP_SEARCH) {
+    if (kw == -3) {   // (PF_MW_TRIES: match_next is the first report of the same walk)
+      hipLaunchKernelGGL((k_mwalk<MODE, 2, 0, 3>), g, b, lds_bytes, s, args...);
+      return;
+    }
+  }
   if constexpr (MODE == STEP_COUNT || MODE == STEP_EMIT) {
     if (kw == -2) {   // (PF_MW_EMPTY, walks that read beyond their match: build_emptywalk2())
       hipLaunchKernelGGL((k_mwalk<MODE, 2, 0, 2>), g, b, lds_bytes, s, args...);
@@ -4885,7 +4893,7 @@ int run_match(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d_s, i
     int split = 0;
     const bool lz = (h->hp.dev.flags & PF_LAZY_END) != 0;   // '$' on the LazyDFA search: one lane per text (the cache is the text's)
     if (!bits && !lz)
-      if (int rc = req_wave_pays(lay, n, false, s, &wave, big ? nullptr : &split, false, mwalk_on(h->hp.dev))) return rc;   // (not the `big` rule: search stops at the first match)
+      if (int rc = req_wave_pays(lay, n, false, s, &wave, big ? nullptr : &split, false, mwalk_on(h->hp.dev) || mw_tries_on(h->hp.dev))) return rc;   // (not the `big` rule: search stops at the first match)
     Layout lay2 = lay;
     lay2.split = split;
     if (bits && bits_fixed_on(h->hp.dev)) {   // one match length: the first match end of the union pass is the answer
@@ -4901,7 +4909,7 @@ int run_match(const mrx_handle* h, const Layout& lay, int64_t n, int32_t* d_s, i
       HIP_TRY(scratch_free(d_limit, s));
       g_last_kernel = "k_bstep_search";
     } else
-    if (!wave && !big && mwalk_on(h->hp.dev)) {   // several walks in one pass; the few very long texts keep their kernel
+    if (!wave && !big && (mwalk_on(h->hp.dev) || mw_tries_on(h->hp.dev))) {   // several walks in one pass; the few very long texts keep their kernel
       // (measured, profiles/r03_multiwalk.md: an "is there a match" pass in front -- STEP_ANY, no start registers,
       // 3 TB/s -- doubles the rate on texts without a match and halves it where the first match lies deep in
       // the text; one pass at 0.9-1.3 TB/s whatever the text holds is the default)

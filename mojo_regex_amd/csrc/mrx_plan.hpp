@@ -67,7 +67,7 @@ enum PlanFlags : uint32_t {
   PF_MW_TRIES = 1u << 25,       // plain-route table plan that fails the multi-walk proofs but whose walks read at most seven
                                 // bytes beyond their last accepting position: findall / count in one pass with the tries the
                                 // reference may come back to kept beside the oldest walk (build_emptywalk2(., empty = false);
-                                // DevPlan::off_mw_* with mw_k == -3; k_mwalk<., 2, 0, 3>).  search keeps its own route.
+                                // DevPlan::off_mw_* with mw_k == -3; k_mwalk<., 2, 0, 3>); search = the first report of the same walk.
   PF_STREAM_SEARCH = 1u << 11   // search / sub / captures may use the streaming kernel too (findall and
                                 // count may whenever PF_STREAMABLE is set): not with a memchr prefilter,
                                 // which only match_next consults (matcher.mojo:784-796)
