@@ -449,14 +449,15 @@ bool build_emptywalk2(const SearchAutomaton& s, EmptyWalk2& ew, std::string& why
     }
   };
   std::vector<std::vector<EwEntry>> rows;
+  std::vector<std::vector<int>> nexts;   // [configuration][class]: the next configuration
   for (size_t ci = 0; ci < cfgs.size(); ++ci) {
     // 32-byte entries, 41 KB at most, and no more than the plan's blob has room for (60 KiB for everything the generic kernels
     // stage: checked where the table is stored).  Small tables gain 3-10 x over marks + stepper; tables of 16-41 KB run at
     // about half their speed (two workgroups per CU) and win two times out of three (tools/r04_tries_cap.py); on the
     // reference's phone patterns by pieces the form is slower (flexible_phone 269 -> 195 GB/s).  Plans without empty matches
     // are therefore MEASURED per handle against marks + stepper (FindallJob::tries_route_tuner).
-    static const int64_t cap_entries = getenv("MRX_TRIES_CAP_ENTRIES") ? atoll(getenv("MRX_TRIES_CAP_ENTRIES")) : 1300;   // (A/B runs)
-    if ((int64_t)cfgs.size() * (ncp + 1) > cap_entries) { why = "pending-tries walk: configuration table beyond 41 KB"; return false; }
+    // (the configurations are explored first and MERGED afterwards -- below -- so the limit here is on the exploration)
+    if (cfgs.size() > 20000) { why = "pending-tries walk: more than 20000 configurations explored"; return false; }
     const Key cur = cfgs[ci];
     const bool fresh = cur[0] < 0;
     const int q0 = fresh ? 0 : cur[0];
@@ -465,6 +466,7 @@ bool build_emptywalk2(const SearchAutomaton& s, EmptyWalk2& ew, std::string& why
     for (size_t j = 2; j + 1 < cur.size(); j += 2) slots.push_back({cur[j], cur[j + 1]});
     const int m = (int)slots.size();   // tries at positions R .. p - 1, R = p - m
     std::vector<EwEntry> row(ncp + 1);
+    std::vector<int> nrow(ew.ncls, 0);
     for (int k = 0; k <= ew.ncls; ++k) {
       const bool at_end = k == ew.ncls;   // the virtual step behind the last byte: every walk dies, none begins
       const int c = at_end ? 0 : rep[k];
@@ -528,19 +530,66 @@ bool build_emptywalk2(const SearchAutomaton& s, EmptyWalk2& ew, std::string& why
         } else nk = Key{-1};
       }
       if (at_end) { row[ncp] = e; continue; }
-      const int nid = id_of(nk);
-      if ((((uint64_t)nid << ew.cshift) >> 16) != 0) { why = "empty-match walk: configuration table beyond the LDS budget"; return false; }
-      e.x |= (((uint32_t)nid << ew.cshift) & 0xFFFFu) << 16;
+      nrow[k] = id_of(nk);   // (the next configuration is packed into the entry once the configurations are merged)
       row[k] = e;
     }
     rows.push_back(row);
+    nexts.push_back(nrow);
   }
-  ew.ncfg = (int)cfgs.size();
+  // Merge configurations that behave alike (the table is a Mealy machine: partition refinement on what an entry does
+  // and which block it leads to).  Lists that differ only in tries that never matter again -- the usual case once a list
+  // holds a dozen entries -- collapse; the reports are unchanged by construction.
+  const int nc = (int)cfgs.size();
+  std::vector<int> block(nc, 0);
+  int nblocks = 1;
+  for (;;) {
+    std::map<std::vector<uint32_t>, int> sig_ids;
+    std::vector<int> nb(nc);
+    for (int ci = 0; ci < nc; ++ci) {
+      std::vector<uint32_t> sig;
+      sig.reserve((size_t)(ew.ncls + 1) * 9);
+      for (int k = 0; k <= ew.ncls; ++k) {
+        const EwEntry& e = rows[ci][k == ew.ncls ? ncp : k];
+        sig.push_back(e.x);
+        for (int w = 0; w < 7; ++w) sig.push_back(e.r[w]);
+        sig.push_back(k == ew.ncls ? 0u : (uint32_t)block[nexts[ci][k]]);
+      }
+      auto it = sig_ids.find(sig);
+      if (it == sig_ids.end()) it = sig_ids.emplace(std::move(sig), (int)sig_ids.size()).first;
+      nb[ci] = it->second;
+    }
+    const int n2 = (int)sig_ids.size();
+    block.swap(nb);
+    if (n2 == nblocks) break;
+    nblocks = n2;
+  }
+  // block of the fresh configuration first (row 0 is where a text begins)
+  std::vector<int> order(nblocks, -1), repr(nblocks, -1);
+  int next_id = 0;
+  order[block[0]] = next_id++;
+  for (int ci = 0; ci < nc; ++ci) {
+    if (order[block[ci]] < 0) order[block[ci]] = next_id++;
+    if (repr[order[block[ci]]] < 0) repr[order[block[ci]]] = ci;
+  }
+  static const int64_t cap_entries = getenv("MRX_TRIES_CAP_ENTRIES") ? atoll(getenv("MRX_TRIES_CAP_ENTRIES")) : 1300;   // (A/B runs)
+  // 32-byte entries, 41 KB at most, and no more than the plan's blob has room for (60 KiB for everything the generic kernels
+  // stage: checked where the table is stored).  Small tables gain 3-10 x over marks + stepper; tables of 16-41 KB run at
+  // about half their speed (two workgroups per CU) and win two times out of three (tools/r04_tries_cap.py); on the
+  // reference's phone patterns by pieces the form is slower (flexible_phone 269 -> 195 GB/s).  Plans without empty matches
+  // are therefore MEASURED per handle against marks + stepper (ab_tuner_begin).
+  if ((int64_t)nblocks * (ncp + 1) > cap_entries) { why = "pending-tries walk: configuration table beyond 41 KB"; return false; }
+  if ((((uint64_t)nblocks << ew.cshift) >> 16) != 0) { why = "pending-tries walk: configuration table beyond the LDS budget"; return false; }
+  ew.ncfg = nblocks;
   ew.tab.assign((size_t)ew.ncfg * ncp, EwEntry{});
   ew.end.assign(ew.ncfg, EwEntry{});
-  for (int ci = 0; ci < ew.ncfg; ++ci) {
-    for (int k = 0; k < ew.ncls; ++k) ew.tab[(size_t)ci * ncp + k] = rows[ci][k];
-    ew.end[ci] = rows[ci][ncp];
+  for (int b = 0; b < nblocks; ++b) {
+    const int ci = repr[b];
+    for (int k = 0; k < ew.ncls; ++k) {
+      EwEntry e = rows[ci][k];
+      e.x |= (((uint32_t)order[block[nexts[ci][k]]] << ew.cshift) & 0xFFFFu) << 16;
+      ew.tab[(size_t)b * ncp + k] = e;
+    }
+    ew.end[b] = rows[ci][ncp];
   }
   return true;
 }
