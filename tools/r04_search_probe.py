@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""search (match_next) of plans with a pending-tries table against other plan families: whole-batch rate on bench.py's
+mix (2^20 x 1 KiB).  usage: python tools/r04_search_probe.py"""
 import os, sys, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
