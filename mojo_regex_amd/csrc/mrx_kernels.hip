@@ -845,8 +845,8 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_mwalk(DevPlan p, const uint8_
 #define MRX_MW_BYTE(BYTE_, F_, FULL_, PRE_)                                                                          \
       do {                                                                                                           \
         const int f = (F_);                           /* frame position, the same for every lane */                  \
-        if constexpr (TRIES) {                                                                                       \
-          if (!fin && f >= mis && f < end) ew2_apply(tab64 + (((e >> 16) + clsT[(BYTE_)]) << 3), f - mis, true);     \
+        if constexpr (TRIES) {   /* FULL_: every lane's text covers the group (or the lane is finished) */        \
+          if (!fin && ((FULL_) || (f >= mis && f < end))) ew2_apply(tab64 + (((e >> 16) + clsT[(BYTE_)]) << 3), f - mis, true); \
           break;                                                                                                     \
         }                                                                                                            \
         /* FULL_ = 2 (search): a lane that has its answer keeps stepping on whatever its row holds -- its registers   \
@@ -913,6 +913,10 @@ __global__ __launch_bounds__(64 * kWsWaves) void k_mwalk(DevPlan p, const uint8_
         const bool covers = f0 >= mis && f0 + 16 <= end;
         // (the count pass keeps its loop lean: one fast form, no finished lanes in it)
         const bool all_full = pre && MODE != STEP_ANY && __all(MODE == STEP_COUNT ? (!fin && covers) : (fin || covers));
+        if (TRIES && __all(fin || covers)) {   // (the pending-tries walk: no frame test per byte where no text begins or ends)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) MRX_MW_BYTE((words[q >> 2] >> ((q & 3) * 8)) & 0xFFu, f0 + q, 1, false);
+        } else
         if (all_full && MODE != STEP_COUNT && (MODE == STEP_SEARCH || __any(fin))) {
 #pragma unroll
           for (int q = 0; q < 16; ++q) MRX_MW_BYTE((words[q >> 2] >> ((q & 3) * 8)) & 0xFFu, f0 + q, 2, true);
