@@ -6389,6 +6389,291 @@ int sub_from_spans(const mrx_handle* h, const Layout& lay, int64_t n, const std:
 }
 }  // namespace
 
+// ---- sub() with \1..\9 on a deterministic chain (HostPlan::chain) -----------------------------------------
+// The matches are the plain search's spans (run_findall, match_next_sequence); a wavefront takes a text: the text in an
+// LDS tile, a lane per match finds the leaves' boundaries as runs of their classes (mask[byte] bit l), from them the
+// groups and the replacement's length.  k_subc_sizes: output length per text and, per match, the bytes the output has
+// gained in front of it; k_subc_emit: gaps and replacements into an output tile, the tile out in 16-byte stores.
+// Texts or outputs beyond the tiles raise *over: the call is then the lane-per-text interpreter's (k_sub).
+namespace {
+constexpr int kSubcTile = 4096;
+struct ChainDev {
+  int nleaf, ntpl;
+  int lmin[kChainLeaves], lmax[kChainLeaves];
+  int8_t gopen[10], gclose[10];
+};
+struct SubcLds {
+  uint8_t text[kBlock / 64][kSubcTile + 32];
+  uint16_t bnd[kBlock / 64][64 * (kChainLeaves + 1)];
+  uint16_t mask[256];
+};
+// the text's 16-byte blocks into the tile (frame of the blocks: the text begins at tile[mis])
+__device__ __forceinline__ void subc_load_text(uint8_t* tile, const uint8_t* tptr, int tlen, int lane) {
+  const int mis = (int)((uintptr_t)tptr & 15);
+  const uint8_t* fptr = tptr - mis;
+  const int nfb = (mis + tlen + 15) >> 4;
+  for (int b = lane; b < nfb; b += 64) *(uint4*)(tile + 16 * b) = *(const uint4*)(fptr + 16 * b);
+}
+// boundaries of the leaves of the match [ms, me) -> bnd[0 .. nleaf] (lane's row); positions relative to the text
+__device__ __forceinline__ void subc_walk(const ChainDev& cd, const uint8_t* txt, const uint16_t* mask, uint16_t* bnd,
+                                          int ms, int me) {
+  int pos = ms;
+  for (int l = 0; l < cd.nleaf; ++l) {
+    bnd[l] = (uint16_t)pos;
+    const int stop = cd.lmax[l] < 0 || pos + cd.lmax[l] > me ? me : pos + cd.lmax[l];
+    while (pos < stop && ((mask[txt[pos]] >> l) & 1)) ++pos;
+  }
+  bnd[cd.nleaf] = (uint16_t)pos;
+}
+__device__ __forceinline__ int subc_repl_len(const ChainDev& cd, const ReplSeg* tpl, const uint16_t* bnd) {
+  int rl = 0;
+  for (int k = 0; k < cd.ntpl; ++k) {
+    const ReplSeg sg = tpl[k];
+    if (sg.group_ref > 0) {
+      const int o = sg.group_ref <= 9 ? cd.gopen[sg.group_ref] : -1;
+      if (o >= 0) rl += (int)bnd[cd.gclose[sg.group_ref]] - (int)bnd[o];
+    } else {
+      rl += sg.length;
+    }
+  }
+  return rl;
+}
+__global__ __launch_bounds__(kBlock) void k_subc_sizes(ChainDev cd, int64_t n, const uint8_t* __restrict__ data,
+                                                       const int64_t* __restrict__ offsets,
+                                                       const int64_t* __restrict__ prefix, const int32_t* __restrict__ spans,
+                                                       long long count, const uint16_t* __restrict__ g_mask,
+                                                       const ReplSeg* __restrict__ tpl, int64_t* __restrict__ sizes,
+                                                       int32_t* __restrict__ dcum, int32_t* __restrict__ over) {
+  __shared__ __align__(16) SubcLds L;
+  for (int c = threadIdx.x; c < 256; c += blockDim.x) L.mask[c] = g_mask[c];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  uint8_t* tile = L.text[wv];
+  uint16_t* bnd = L.bnd[wv] + lane * (kChainLeaves + 1);
+  const int64_t nw = (int64_t)gridDim.x * (kBlock / 64);
+  for (int64_t i = (int64_t)blockIdx.x * (kBlock / 64) + wv; i < n; i += nw) {
+    const int64_t ibase = offsets[i];
+    const int tlen = (int)(offsets[i + 1] - ibase);
+    const int64_t a = prefix[i];
+    int64_t k64 = prefix[i + 1] - a;
+    if (count > 0 && k64 > count) k64 = count;
+    const int k = (int)k64;
+    if (tlen > kSubcTile) {
+      if (lane == 0) { *over = 1; sizes[i] = 0; }
+      continue;
+    }
+    const uint8_t* tptr = data + ibase;
+    const int mis = (int)((uintptr_t)tptr & 15);
+    __builtin_amdgcn_wave_barrier();
+    if (k > 0) subc_load_text(tile, tptr, tlen, lane);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    int carry = 0;
+    for (int m0 = 0; m0 < k; m0 += 64) {
+      const int m = m0 + lane;
+      int delta = 0;
+      if (m < k) {
+        const int2 sp = *(const int2*)(spans + 2 * (a + m));
+        subc_walk(cd, tile + mis, L.mask, bnd, sp.x, sp.y);
+        delta = subc_repl_len(cd, tpl, bnd) - (sp.y - sp.x);
+      }
+      const int incl = group_scan<64, false>(delta);
+      if (m < k) dcum[a + m] = carry + incl - delta;
+      carry += __shfl(incl, 63, 64);
+    }
+    if (lane == 0) {
+      sizes[i] = (int64_t)tlen + carry;
+      if (tlen + carry > kSubcTile) *over = 1;
+    }
+  }
+}
+__global__ __launch_bounds__(kBlock) void k_subc_emit(ChainDev cd, int64_t n, const uint8_t* __restrict__ data,
+                                                      const int64_t* __restrict__ offsets,
+                                                      const int64_t* __restrict__ prefix, const int32_t* __restrict__ spans,
+                                                      long long count, const uint16_t* __restrict__ g_mask,
+                                                      const ReplSeg* __restrict__ tpl, const uint8_t* __restrict__ repl,
+                                                      const int32_t* __restrict__ dcum, const int64_t* __restrict__ out_off,
+                                                      uint8_t* __restrict__ out) {
+  __shared__ __align__(16) SubcLds L;
+  __shared__ __align__(16) uint8_t otile_all[kBlock / 64][kSubcTile + 32];
+  for (int c = threadIdx.x; c < 256; c += blockDim.x) L.mask[c] = g_mask[c];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  uint8_t* tile = L.text[wv];
+  uint8_t* otile = otile_all[wv];
+  uint16_t* bnd = L.bnd[wv] + lane * (kChainLeaves + 1);
+  auto wave_sync = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  const int64_t nw = (int64_t)gridDim.x * (kBlock / 64);
+  for (int64_t i = (int64_t)blockIdx.x * (kBlock / 64) + wv; i < n; i += nw) {
+    const int64_t ibase = offsets[i];
+    const int tlen = (int)(offsets[i + 1] - ibase);
+    const int64_t a = prefix[i];
+    int64_t k64 = prefix[i + 1] - a;
+    if (count > 0 && k64 > count) k64 = count;
+    const int k = (int)k64;
+    const int64_t obase = out_off[i];
+    const int olen = (int)(out_off[i + 1] - obase);
+    if (olen <= 0) continue;
+    const uint8_t* tptr = data + ibase;
+    const int mis = (int)((uintptr_t)tptr & 15), head = (int)((uintptr_t)(out + obase) & 15);
+    wave_sync();   // the previous text's tiles are free
+    subc_load_text(tile, tptr, tlen, lane);
+    wave_sync();
+    const uint8_t* txt = tile + mis;
+    uint8_t* o = otile + head;
+    // the whole wavefront copies text[src, src + len) to o[dst ..]
+    auto copy_all = [&](int src, int len, int dst) {
+      for (int j = lane; j < len; j += 64) o[dst + j] = txt[src + j];
+    };
+    int prev_end = 0;   // end of the match in front of this round's first
+    for (int m0 = 0; m0 < k; m0 += 64) {
+      const int m = m0 + lane;
+      const bool live = m < k;
+      int ms = 0, me = 0, before = 0;
+      if (live) {
+        const int2 sp = *(const int2*)(spans + 2 * (a + m));
+        ms = sp.x; me = sp.y;
+        before = dcum[a + m];
+      }
+      int pe = __shfl_up(me, 1, 64);
+      if (lane == 0) pe = prev_end;
+      const int nlive = k - m0 < 64 ? k - m0 : 64;
+      prev_end = __shfl(me, nlive - 1, 64);
+      // the kept bytes in front of the match: short gaps by the lane, long ones by the wavefront
+      const int gap = live ? ms - pe : 0;
+      if (gap <= 24)
+        for (int j = 0; j < gap; ++j) o[pe + before + j] = txt[pe + j];
+      uint64_t wide = __ballot(gap > 24);
+      while (wide) {
+        const int src_lane = __ffsll((unsigned long long)wide) - 1;
+        wide &= wide - 1;
+        copy_all(__shfl(pe, src_lane, 64), __shfl(gap, src_lane, 64), __shfl(pe + before, src_lane, 64));
+      }
+      if (live) {
+        subc_walk(cd, txt, L.mask, bnd, ms, me);
+        uint8_t* dst = o + ms + before;
+        for (int q = 0; q < cd.ntpl; ++q) {
+          const ReplSeg sg = tpl[q];
+          if (sg.group_ref > 0) {
+            const int og = sg.group_ref <= 9 ? cd.gopen[sg.group_ref] : -1;
+            if (og >= 0) {
+              const int gs = bnd[og], ge = bnd[cd.gclose[sg.group_ref]];
+              for (int j = gs; j < ge; ++j) *dst++ = txt[j];
+            }
+          } else {
+            for (int j = 0; j < sg.length; ++j) *dst++ = repl[sg.start + j];
+          }
+        }
+      }
+    }
+    copy_all(prev_end, tlen - prev_end, prev_end + (olen - tlen));   // behind the last replaced match
+    wave_sync();
+    // the tile out: whole 16-byte blocks where the block is the text's alone, bytes at the two ends
+    uint8_t* oframe = out + obase - head;
+    const int nob = (head + olen + 15) >> 4;
+    for (int b = lane; b < nob; b += 64) {
+      const int lo = 16 * b, hi = lo + 16;
+      if (lo >= head && hi <= head + olen) {
+        *(uint4*)(oframe + lo) = *(const uint4*)(otile + lo);
+      } else {
+        const int from = lo > head ? lo : head, to = hi < head + olen ? hi : head + olen;
+        for (int j = from; j < to; ++j) oframe[j] = otile[j];
+      }
+    }
+  }
+}
+
+int sub_chain_from_spans(const mrx_handle* h, const Layout& lay, int64_t n, const std::string& r,
+                         const std::vector<ReplSeg>& tpl, int64_t count, int64_t* out_off, uint8_t* out, int64_t out_cap,
+                         int64_t* total_bytes, hipStream_t s, int64_t known_bytes, int64_t known_max) {
+  const ChainGroups& cg = h->hp.chain;
+  int64_t in_bytes = known_bytes, max_len = known_max;
+  if (known_bytes < 0 || known_max < 0)
+    if (int rc0 = csr_stats(lay, n, s, &in_bytes, &max_len)) return rc0;
+  if (in_bytes < 0) return fail(MRX_E_ARGUMENT, "offsets[n] is negative");
+  if (max_len > kSubcTile) return kSubsRetryGeneric;
+  ChainDev cd{};
+  cd.nleaf = cg.nleaf; cd.ntpl = (int)tpl.size();
+  for (int l = 0; l < kChainLeaves; ++l) { cd.lmin[l] = cg.lmin[l]; cd.lmax[l] = cg.lmax[l]; }
+  for (int g = 0; g < 10; ++g) { cd.gopen[g] = (int8_t)cg.gopen[g]; cd.gclose[g] = (int8_t)cg.gclose[g]; }
+  int64_t *d_prefix = nullptr, *d_sizes = nullptr, *d_total = nullptr;
+  int32_t *d_spans = nullptr, *d_dcum = nullptr, *d_over = nullptr;
+  uint16_t* d_mask = nullptr;
+  ReplSeg* d_tpl = nullptr;
+  uint8_t* d_repl = nullptr;
+  HIP_TRY(scratch_alloc((void**)&d_prefix, sizeof(int64_t) * (n + 1), s));
+  HIP_TRY(scratch_alloc((void**)&d_sizes, sizeof(int64_t) * n, s));
+  HIP_TRY(scratch_alloc((void**)&d_total, sizeof(int64_t), s));
+  HIP_TRY(scratch_alloc((void**)&d_over, sizeof(int32_t), s));
+  HIP_TRY(scratch_alloc((void**)&d_mask, sizeof(uint16_t) * 256, s));
+  HIP_TRY(scratch_alloc((void**)&d_tpl, sizeof(ReplSeg) * (tpl.size() + 1), s));
+  HIP_TRY(scratch_alloc((void**)&d_repl, r.size() + 16, s));
+  HIP_TRY(hipMemcpyAsync(d_mask, cg.mask.data(), sizeof(uint16_t) * 256, hipMemcpyHostToDevice, s));
+  if (!tpl.empty()) HIP_TRY(hipMemcpyAsync(d_tpl, tpl.data(), sizeof(ReplSeg) * tpl.size(), hipMemcpyHostToDevice, s));
+  if (!r.empty()) HIP_TRY(hipMemcpyAsync(d_repl, r.data(), r.size(), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemsetAsync(d_over, 0, sizeof(int32_t), s));
+  int64_t cap = in_bytes / 8 + n + 64, nm = 0, tot = 0;
+  if (const int64_t seen = h->sub_matches_per_kib.load(std::memory_order_relaxed); seen > 128) {
+    const int64_t by_hint = (in_bytes >> 10) * (seen + seen / 8 + 1) + n + 64;
+    if (by_hint > cap) cap = by_hint < in_bytes + n + 64 ? by_hint : in_bytes + n + 64;
+  }
+  int32_t over = 0;
+  const int64_t blocks = (n + (kBlock / 64) - 1) / (kBlock / 64);
+  const unsigned grid = (unsigned)(blocks < grid_cap() ? blocks : grid_cap());
+  int rc = MRX_OK;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    HIP_TRY(scratch_alloc((void**)&d_spans, sizeof(int32_t) * 2 * (size_t)cap, s));
+    HIP_TRY(scratch_alloc((void**)&d_dcum, sizeof(int32_t) * (size_t)(cap + 1), s));
+    rc = run_findall(h, lay, n, d_prefix, d_spans, cap, nullptr, s, /*match_next_sequence=*/true, in_bytes, max_len);
+    if (rc != MRX_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(&nm, d_prefix + n, sizeof nm, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    h->sub_matches_per_kib.store(in_bytes >= 1024 ? nm / (in_bytes >> 10) : 0, std::memory_order_relaxed);
+    if (nm <= cap) break;
+    if (attempt == 1) return fail(MRX_E_NO_DEVICE, "sub: match count changed between two passes");
+    HIP_TRY(scratch_free(d_spans, s));
+    HIP_TRY(scratch_free(d_dcum, s));
+    cap = nm;
+  }
+  hipLaunchKernelGGL(k_subc_sizes, dim3(grid), dim3(kBlock), 0, s, cd, n, lay.data, lay.offsets, d_prefix, d_spans,
+                     (long long)count, d_mask, d_tpl, d_sizes, d_dcum, d_over);
+  HIP_TRY(hipGetLastError());
+  rc = device_scan<int64_t>(d_sizes, n, out_off, d_total, s);
+  if (rc != MRX_OK) return rc;
+  HIP_TRY(hipMemcpyAsync(&tot, d_total, sizeof tot, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(&over, d_over, sizeof over, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (over) {
+    rc = kSubsRetryGeneric;
+  } else {
+    if (total_bytes) *total_bytes = tot;
+    if (tot > out_cap) {
+      rc = fail(MRX_E_CAPACITY, "output buffer too small: need " + std::to_string(tot));
+    } else if (tot > 0) {
+      hipLaunchKernelGGL(k_subc_emit, dim3(grid), dim3(kBlock), 0, s, cd, n, lay.data, lay.offsets, d_prefix, d_spans,
+                         (long long)count, d_mask, d_tpl, d_repl, d_dcum, out_off, out);
+      HIP_TRY(hipGetLastError());
+      g_last_kernel = "k_subc_emit";
+    }
+  }
+  HIP_TRY(scratch_free(d_prefix, s));
+  HIP_TRY(scratch_free(d_sizes, s));
+  HIP_TRY(scratch_free(d_total, s));
+  HIP_TRY(scratch_free(d_over, s));
+  HIP_TRY(scratch_free(d_mask, s));
+  HIP_TRY(scratch_free(d_tpl, s));
+  HIP_TRY(scratch_free(d_repl, s));
+  HIP_TRY(scratch_free(d_spans, s));
+  HIP_TRY(scratch_free(d_dcum, s));
+  return rc;
+}
+}  // namespace
+
 namespace {
 struct DevBatch {
   uint8_t* data = nullptr;
@@ -7161,6 +7446,14 @@ static int sub_any(const mrx_handle* h, const char* repl, size_t repl_len, int64
   if (int rc = check_lds(h)) return rc;
   if (int rc = ensure_device(h)) return rc;
   hipStream_t s = (hipStream_t)st;
+  // \1..\9 on a deterministic chain whose matches are the table walk's: spans of the plain search, groups from the
+  // leaves' runs (k_subc_sizes / k_subc_emit); batches with a text or an output beyond the tiles stay the interpreter's
+  if (general_groups && h->hp.chain.ok && !g_force_generic && n > 0 && off && count >= 0 &&
+      (h->hp.dev.flags & (PF_STREAM_SEARCH | PF_STEP_SEARCH)) && h->hp.why_no_search.empty()) {
+    const int rc = sub_chain_from_spans(h, Layout{d, off, 0, nullptr, 0}, n, r, tpl, count, out_off, out, out_cap,
+                                        total_bytes, s, known_bytes, known_max);
+    if (rc != kSubsRetryGeneric) return rc;
+  }
   // sub() iterates match_next from the previous match end; on the plain route that is exactly the
   // findall sequence, so the spans of the streaming kernel or of the windowed stepper serve it.
   // (Not with a memchr prefilter, which only match_next consults; not for exact literals, whose

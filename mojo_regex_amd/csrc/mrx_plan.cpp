@@ -1251,6 +1251,85 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
       }
       if (chain) d.bt_flags |= 32;
     }
+    // "chain groups": are NFAEngine.match_next_with_groups' matches (nfa.mojo:500-574: every start in turn, the greedy
+    // count of every leaf, the first failure final) the matches of the plain table walk?  Decided on the tables: the
+    // chain's own automaton -- state (leaf, bytes it has taken) -- against the engine's, pair by pair.
+    {
+      ChainGroups& cg = hp.chain;
+      cg = ChainGroups();
+      for (int g = 0; g < 10; ++g) cg.gopen[g] = cg.gclose[g] = -1;
+      const auto& items = hp.bt.items;
+      const auto& tbls = hp.bt.tables;
+      std::string why;
+      if (!(d.bt_flags & 32)) why = "not a deterministic chain";
+      else if (d.bt_flags & 1) why = "NFAEngine literal prefilter";
+      else if (d.kind != PLAN_DFA || (d.flags & (PF_START_ANCHOR | PF_END_ANCHOR | PF_PREFILTER | PF_EXACT_LITERAL | PF_PURE_LITERAL | PF_SCAN_ELIGIBLE)))
+        why = "the search is not a plain DFAEngine table walk";
+      std::vector<int> ltbl;
+      for (size_t i = 0; i < items.size() && why.empty(); ++i) {
+        const BtItem& it = items[i];
+        if (it.kind == BT_OPEN || it.kind == BT_CLOSE) {
+          if ((it.flags & BTF_CAPTURING) && it.gid >= 1 && it.gid <= 9)
+            (it.kind == BT_OPEN ? cg.gopen : cg.gclose)[it.gid] = cg.nleaf;
+          continue;
+        }
+        if (it.kind != BT_LEAF) { why = "anchor in the chain"; break; }
+        if (cg.nleaf >= kChainLeaves) { why = "more than 16 leaves"; break; }
+        if (it.min < 1 || (it.max != -1 && it.max < it.min) || it.max > 4000 || it.min > 4000) { why = "leaf that may take no byte"; break; }
+        if (tbls[it.tbl * 3] != tbls[it.tbl * 3 + 1] || tbls[it.tbl * 3] != tbls[it.tbl * 3 + 2]) { why = "a leaf's three membership tests differ"; break; }
+        cg.lmin[cg.nleaf] = it.min; cg.lmax[cg.nleaf] = it.max;
+        ltbl.push_back(it.tbl * 3);
+        ++cg.nleaf;
+      }
+      auto in = [&](int leaf, int c) { return (tbls[ltbl[leaf]][c >> 3] >> (c & 7)) & 1; };
+      if (why.empty() && cg.nleaf == 0) why = "no leaf";
+      for (int l = 0; l + 1 < cg.nleaf && why.empty(); ++l)
+        if (cg.lmin[l] != cg.lmax[l])
+          for (int c = 0; c < 256; ++c)
+            if (in(l, c) && in(l + 1, c)) { why = "a leaf with a variable count shares a byte with the leaf behind it"; break; }
+      for (int g = 1; g <= 9 && why.empty(); ++g)
+        if ((cg.gopen[g] < 0) != (cg.gclose[g] < 0)) why = "group without both ends";
+      if (why.empty()) {
+        // states of the chain: base[l] + c, c = bytes leaf l has taken (capped at min for an unbounded leaf); -1 dead
+        std::vector<int> base(cg.nleaf + 1, 0);
+        for (int l = 0; l < cg.nleaf; ++l) base[l + 1] = base[l] + (cg.lmax[l] == -1 ? cg.lmin[l] : cg.lmax[l]) + 1;
+        if (base[cg.nleaf] > 20000) why = "counted leaves: more than 20000 chain states";
+        auto step = [&](int st, int c) {
+          int l = 0;
+          while (base[l + 1] <= st) ++l;
+          const int k = st - base[l];
+          const bool stay = cg.lmax[l] == -1 || k < cg.lmax[l];
+          if (in(l, c) && stay) return base[l] + (cg.lmax[l] == -1 ? std::min(k + 1, cg.lmin[l]) : k + 1);
+          if (k >= cg.lmin[l] && l + 1 < cg.nleaf && in(l + 1, c)) return base[l + 1] + 1;
+          return -1;
+        };
+        auto accepts = [&](int st) { return st >= base[cg.nleaf - 1] + cg.lmin[cg.nleaf - 1]; };
+        std::set<std::pair<int, int>> seen;
+        std::vector<std::pair<int, int>> todo{{0, 0}};
+        seen.insert({0, 0});
+        while (!todo.empty() && why.empty()) {
+          const auto [a, q] = todo.back(); todo.pop_back();
+          const bool acc_a = a >= 0 && accepts(a), acc_q = q >= 0 && acc[q];
+          if (acc_a != acc_q) { why = "the chain and the engine's table accept different texts"; break; }
+          if (a < 0 && q < 0) continue;
+          if (seen.size() > 200000) { why = "chain against table: too many pairs"; break; }
+          for (int c = 0; c < 256; ++c) {
+            const std::pair<int, int> nx{a < 0 ? -1 : step(a, c), q < 0 ? -1 : T[q][c]};
+            if (nx.first < 0 && nx.second < 0) continue;
+            if (seen.insert(nx).second) todo.push_back(nx);
+          }
+        }
+      }
+      if (why.empty()) {
+        for (int c = 0; c < 256; ++c) {
+          uint16_t m = 0;
+          for (int l = 0; l < cg.nleaf; ++l) if (in(l, c)) m |= (uint16_t)(1u << l);
+          cg.mask[c] = m;
+        }
+        cg.ok = true;
+      }
+      cg.why = why;
+    }
     align(hp.blob, 8);
   }
 
@@ -2023,6 +2102,7 @@ std::string describe_plan(const HostPlan& hp) {
   o << "device.backtrack=" << (hp.bt.ok ? "yes" : ("no: " + (hp.bt.why_not.empty() ? std::string("'.*' shortcut") : hp.bt.why_not)));
   if (hp.bt.ok) o << " items=" << d.bt_nitems << " groups=" << d.bt_ngroups << " literal_opt=" << (d.bt_flags & 1)
                   << " prefix_literal=" << ((d.bt_flags >> 1) & 1) << " chain=" << ((d.bt_flags >> 5) & 1);
+    o << " chain_groups=" << (hp.chain.ok ? "yes leaves=" + std::to_string(hp.chain.nleaf) : "no: " + hp.chain.why);
   o << "\n";
   if (hp.fixed_total >= 0)   // group templates of regex.sub: see HostPlan::fixed_pure
     o << "device.sub_groups=fixed pure=" << (hp.fixed_pure ? 1 : 0) << "\n";

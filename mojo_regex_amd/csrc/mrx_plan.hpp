@@ -169,6 +169,18 @@ struct EmptyWalk2 {
 };
 std::vector<std::pair<int, int>> emptywalk2_run(const EmptyWalk2& ew, const uint8_t* text, int len);
 
+// Leaves of a chain program in order (BtProg without ALT / LOOP / anchors), every leaf's three membership tables equal,
+// min >= 1; a leaf with a variable count is followed by a leaf whose set is disjoint from its own.  gopen / gclose: the
+// number of leaves in front of a capturing group's OPEN / CLOSE (-1: no such group).  mask[byte] bit i: leaf i takes it.
+constexpr int kChainLeaves = 16;
+struct ChainGroups {
+  bool ok = false;
+  std::string why;
+  int nleaf = 0;
+  int lmin[kChainLeaves] = {0}, lmax[kChainLeaves] = {0};
+  int gopen[10], gclose[10];
+  std::array<uint16_t, 256> mask{};
+};
 struct HostPlan {
   EmptyWalk2 ew2;   // PF_STEP_EMPTY plans that are not every_state_accepts: the general one-pass table, when it exists
   bool ew2_ok = false;
@@ -207,6 +219,9 @@ struct HostPlan {
   bool fixed_concat = false;
   bool fixed_pure = false;   // the pattern is nothing but (\d{N}) groups (see build_plan)
   int fixed_off[10] = {0}, fixed_w[10] = {0};
+  // general capture groups of a deterministic chain whose matches are the table walk's (build_plan: "chain groups"):
+  // regex.sub with \1..\9 takes the spans of the plain search and finds the group boundaries as runs of the leaves' classes
+  ChainGroups chain;
   // device payload
   DevPlan dev{};
   std::vector<uint8_t> blob;

@@ -863,6 +863,56 @@ def test_onepass_match_first_matches_oracle(pat):
         assert (int(ss[i]), int(se[i])) == (w if w else (-1, -1)), (pat, t)
 
 
+CHAIN_SUBS = [(b"(\\w+) (\\w+)", b"\\2 \\1"), (b"(\\w+) (\\w+)", b"<\\2|\\1|\\2>"), (b"(\\w+) (\\w+)", b"\\3x\\1"),
+              (b"([a-z]+)(\\d+)", b"\\2\\1"), (b"([a-z]+)-(\\d{2,4})", b"[\\2:\\1]"), (b"(\\d+)\\.(\\d+)", b"\\2,\\1"),
+              (b"([a-c]{2,3})(x+)(\\d)", b"\\3\\2\\1"), (b"((\\d+)-([a-z]+))", b"\\3=\\2 (\\1)"), (b"(?:([a-z])(\\d+)) ", b"\\1"),
+              (b"(\\d+)", b"<\\1>"), (b"([a-z]+)@([a-z]+)\\.(com|org)", b"\\2")]
+
+
+@pytest.mark.parametrize("pat,repl", CHAIN_SUBS)
+@pytest.mark.parametrize("count", [0, 2])
+def test_sub_with_groups_of_a_chain_from_spans_equals_the_interpreter_and_oracle(pat, repl, count):
+    """regex.sub with \\1..\\9 on a deterministic chain (describe(): chain_groups=yes): the matches are the plain search's
+    spans, the groups the runs of the leaves' classes (k_subc_sizes / k_subc_emit), against the flat-program interpreter
+    (k_sub: NFAEngine.match_next_with_groups, matcher.mojo:1781-1822) on every text and the oracle on a sample.  Patterns
+    outside the form (an alternation, here) keep the interpreter; so does a batch with a text beyond the 4 KiB tile."""
+    _need_gpu()
+    rng = np.random.default_rng(zlib.crc32(pat + repl) + count)
+    al = b"abcxyz0123456789 -.@" + bytes(c for c in pat if chr(c).isalnum()) * 2
+    texts = _random_texts(rng, 300, 90, al) + _random_texts(rng, 60, 1500, al) + _random_texts(rng, 8, 4000, al) + [
+        b"", b"a", b"hello world", b"hello world foo bar baz", b" hello  world ", b"ab12cd345", b"ab-123 cd-12345 e-1",
+        b"3.14 2.718.1", b"abxx1 abcx9 abcdx1", b"12-ab 7-q", b"a1 b22 c333 ", b"joe@example.com ann@site.org x@y.net",
+        b"word " * 800, b"w " * 2000, b"x" * 4096, b"ab 12 " * 600, b"q" * 3000 + b" zz yy"]
+    rx = M.compile_regex(pat)
+    lib = M.load_library()
+    form = "chain_groups=yes" in rx.describe()
+    with generic_kernels():
+        want = rx.sub(repl, texts, count)
+        assert lib.mrx_last_kernel_name() == b"k_sub_size"
+    got = rx.sub(repl, texts, count)
+    fits = max(len(w) for w in want) <= 4096   # (an output beyond the tile also hands the call to the interpreter)
+    assert lib.mrx_last_kernel_name() == (b"k_subc_emit" if form and fits else b"k_sub_size"), rx.describe()
+    if form and not fits:
+        short = [t for t, w in zip(texts, want) if len(w) <= 4096]
+        assert rx.sub(repl, short, count) == [w for w in want if len(w) <= 4096]
+        assert lib.mrx_last_kernel_name() == b"k_subc_emit"
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert a == b, (pat, repl, count, i, texts[i][:80], len(texts[i]), a[:80], b[:80])
+    for i in list(range(0, len(texts), 5)) + list(range(len(texts) - 17, len(texts))):
+        assert got[i] == O.sub(pat, repl, texts[i], count), (pat, repl, texts[i][:80], count)
+    # texts at every alignment of the input and of the output
+    shifted = [texts[(i * 7) % 300][: 30 + i] for i in range(80)]
+    with generic_kernels():
+        want = rx.sub(repl, shifted, count)
+    assert rx.sub(repl, shifted, count) == want
+    # one text beyond the tile: the whole call is the interpreter's
+    long_batch = texts[:20] + [b"ab 12 " * 900]
+    with generic_kernels():
+        want = rx.sub(repl, long_batch, count)
+    assert rx.sub(repl, long_batch, count) == want
+    assert lib.mrx_last_kernel_name() == b"k_sub_size"
+
+
 @pytest.mark.parametrize("pat,repl", [(b"[a-z]+\\d+", b"#"), (b"[a-z]+\\d+", b""), (b"\\d", b""), (b"\\d+", b"<NUM>"),
                                       (b"(\\d{3})(\\d{3})(\\d{4})", b"\\1-\\2-\\3"),
                                       (b"(\\d{3})(\\d{3})(\\d{4})", b"(\\1) \\2-\\3 ext \\7"),
