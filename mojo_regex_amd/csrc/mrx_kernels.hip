@@ -6390,140 +6390,250 @@ int sub_from_spans(const mrx_handle* h, const Layout& lay, int64_t n, const std:
 }  // namespace
 
 // ---- sub() with \1..\9 on a deterministic chain (HostPlan::chain) -----------------------------------------
-// The matches are the plain search's spans (run_findall, match_next_sequence); a wavefront takes a text: the text in an
-// LDS tile, a lane per match finds the leaves' boundaries as runs of their classes (mask[byte] bit l), from them the
-// groups and the replacement's length.  k_subc_sizes: output length per text and, per match, the bytes the output has
-// gained in front of it; k_subc_emit: gaps and replacements into an output tile, the tile out in 16-byte stores.
-// Texts or outputs beyond the tiles raise *over: the call is then the lane-per-text interpreter's (k_sub).
+// The matches are the plain search's spans (run_findall, match_next_sequence); a wavefront takes a text: every byte's
+// leaf mask (bit l: leaf l takes the byte) in an LDS tile, a lane per match finds the leaves' boundaries as runs of
+// mask bits, four bytes a step; from them the groups and the replacement's length.  k_subc_sizes: output length per
+// text and, per match, the bytes the output has gained in front of it; k_subc_emit<TILE>: gaps and replacements into
+// an output tile, the tile out in 16-byte stores.  A text or an output beyond 4 KiB: the call is the lane-per-text
+// interpreter's (k_sub).
 namespace {
-constexpr int kSubcTile = 4096;
+constexpr int kSubcLeaves = 8, kSubcTpl = 16, kSubcRepl = 256;
 struct ChainDev {
   int nleaf, ntpl;
-  int lmin[kChainLeaves], lmax[kChainLeaves];
-  int8_t gopen[10], gclose[10];
+  int lmax[kSubcLeaves];
+  ReplSeg tpl[kSubcTpl];   // (as sub_chain_from_spans rewrites them: a group's segment names its two boundaries)
 };
-struct SubcLds {
-  uint8_t text[kBlock / 64][kSubcTile + 32];
-  uint16_t bnd[kBlock / 64][64 * (kChainLeaves + 1)];
-  uint16_t mask[256];
-};
-// the text's 16-byte blocks into the tile (frame of the blocks: the text begins at tile[mis])
-__device__ __forceinline__ void subc_load_text(uint8_t* tile, const uint8_t* tptr, int tlen, int lane) {
-  const int mis = (int)((uintptr_t)tptr & 15);
-  const uint8_t* fptr = tptr - mis;
-  const int nfb = (mis + tlen + 15) >> 4;
-  for (int b = lane; b < nfb; b += 64) *(uint4*)(tile + 16 * b) = *(const uint4*)(fptr + 16 * b);
+// One text's descriptor, loaded two texts ahead; its blocks, first spans and first gains one text ahead: the global
+// round trips of text i + 1 run under the LDS phases of text i (as in k_subs_wave).
+struct SubcDesc { int64_t ibase, a, obase; int tlen, k, olen; };
+template <bool EMIT>
+__device__ __forceinline__ SubcDesc subc_desc(int64_t i, int64_t n, const int64_t* offsets, const int64_t* prefix,
+                                              const int64_t* out_off, long long count) {
+  SubcDesc d{0, 0, 0, 0, 0, 0};
+  if (i < n) {
+    d.ibase = offsets[i];
+    d.tlen = (int)(offsets[i + 1] - d.ibase);
+    d.a = prefix[i];
+    int64_t k64 = prefix[i + 1] - d.a;
+    if (count > 0 && k64 > count) k64 = count;
+    d.k = (int)k64;
+    if constexpr (EMIT) {
+      d.obase = out_off[i];
+      d.olen = (int)(out_off[i + 1] - d.obase);
+    }
+  }
+  return d;
 }
-// boundaries of the leaves of the match [ms, me) -> bnd[0 .. nleaf] (lane's row); positions relative to the text
-__device__ __forceinline__ void subc_walk(const ChainDev& cd, const uint8_t* txt, const uint16_t* mask, uint16_t* bnd,
-                                          int ms, int me) {
+// blocks in registers -> per-leaf bitmaps (bm[l * ROW + b] bit j: leaf l takes byte 16 b + j of the frame) and, when wanted,
+// the text tile; frame of the blocks: the text begins at [address & 15]
+template <int NB, int ROW, bool TEXT>
+__device__ __forceinline__ void subc_store(const uint4 (&tx)[NB], uint16_t* bm, uint8_t* tile, const uint8_t* mask, int nleaf,
+                                           int nfb, int lane) {
+#pragma unroll
+  for (int r = 0; r < NB; ++r) {
+    const int b = lane + 64 * r;
+    if (b < nfb) {
+      const uint4 v = tx[r];
+      if constexpr (TEXT) *(uint4*)(tile + 16 * b) = v;
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+      uint32_t o[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        o[q] = (uint32_t)mask[w[q] & 255] | ((uint32_t)mask[(w[q] >> 8) & 255] << 8) |
+               ((uint32_t)mask[(w[q] >> 16) & 255] << 16) | ((uint32_t)mask[w[q] >> 24] << 24);
+      for (int l = 0; l < nleaf; ++l) {
+        uint32_t bits = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)   // bit l of four bytes -> four adjacent bits (the products' other terms stay below bit 24)
+          bits |= (((((o[q] >> l) & 0x01010101u) * 0x01020408u) >> 24) & 15u) << (4 * q);
+        bm[l * ROW + b] = (uint16_t)bits;
+      }
+    }
+  }
+}
+// boundaries of the leaves of the match [ms, me) -> bnd[0 .. nleaf] (the lane's row); positions relative to the text, which
+// begins at frame position mis; a leaf's run: trailing ones of its bitmap from the position on, 32 positions a step
+template <int ROW>
+__device__ __forceinline__ void subc_walk(const ChainDev& cd, const uint16_t* bm, int mis, uint16_t* bnd, int ms, int me) {
   int pos = ms;
   for (int l = 0; l < cd.nleaf; ++l) {
     bnd[l] = (uint16_t)pos;
-    const int stop = cd.lmax[l] < 0 || pos + cd.lmax[l] > me ? me : pos + cd.lmax[l];
-    while (pos < stop && ((mask[txt[pos]] >> l) & 1)) ++pos;
+    const int lm = cd.lmax[l];
+    const int stop = lm < 0 || pos + lm > me ? me : pos + lm;
+    const uint16_t* row = bm + l * ROW;
+    while (pos < stop) {
+      const int f = mis + pos;
+      const uint16_t* w = row + (f >> 4);
+      const uint32_t lo = (uint32_t)w[0] | ((uint32_t)w[1] << 16), hi = w[2];
+      const uint32_t miss = ~__funnelshift_r(lo, hi, f & 15);
+      int k = miss ? __ffs((int)miss) - 1 : 32;
+      if (k > stop - pos) k = stop - pos;
+      pos += k;
+      if (k < 32) break;
+    }
   }
   bnd[cd.nleaf] = (uint16_t)pos;
 }
-__device__ __forceinline__ int subc_repl_len(const ChainDev& cd, const ReplSeg* tpl, const uint16_t* bnd) {
+// (ChainDev::tpl as the host rewrote it: group_ref != 0: bytes between the boundaries `start` and `length`; else literal)
+__device__ __forceinline__ int subc_repl_len(const ChainDev& cd, const uint16_t* bnd) {
   int rl = 0;
   for (int k = 0; k < cd.ntpl; ++k) {
-    const ReplSeg sg = tpl[k];
-    if (sg.group_ref > 0) {
-      const int o = sg.group_ref <= 9 ? cd.gopen[sg.group_ref] : -1;
-      if (o >= 0) rl += (int)bnd[cd.gclose[sg.group_ref]] - (int)bnd[o];
-    } else {
-      rl += sg.length;
-    }
+    const ReplSeg sg = cd.tpl[k];
+    rl += sg.group_ref ? (int)bnd[sg.length] - (int)bnd[sg.start] : sg.length;
   }
   return rl;
 }
+// n bytes src -> dst (LDS, one lane), four reads in flight
+__device__ __forceinline__ void subc_copy(uint8_t* dst, const uint8_t* src, int n) {
+  for (int j = 0; j < n; j += 4) {
+    const uint8_t b0 = src[j], b1 = src[j + 1], b2 = src[j + 2], b3 = src[j + 3];   // (the tiles are padded)
+    dst[j] = b0;
+    if (j + 1 < n) dst[j + 1] = b1;
+    if (j + 2 < n) dst[j + 2] = b2;
+    if (j + 3 < n) dst[j + 3] = b3;
+  }
+}
+#define MRX_SUBC_WAVE_SYNC()                                      \
+  do {                                                            \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");        \
+    __builtin_amdgcn_wave_barrier();                              \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");        \
+  } while (0)
+template <int TILE>
 __global__ __launch_bounds__(kBlock) void k_subc_sizes(ChainDev cd, int64_t n, const uint8_t* __restrict__ data,
                                                        const int64_t* __restrict__ offsets,
                                                        const int64_t* __restrict__ prefix, const int32_t* __restrict__ spans,
-                                                       long long count, const uint16_t* __restrict__ g_mask,
-                                                       const ReplSeg* __restrict__ tpl, int64_t* __restrict__ sizes,
-                                                       int32_t* __restrict__ dcum, int32_t* __restrict__ over) {
-  __shared__ __align__(16) SubcLds L;
-  for (int c = threadIdx.x; c < 256; c += blockDim.x) L.mask[c] = g_mask[c];
+                                                       long long count, const uint8_t* __restrict__ g_mask,
+                                                       int64_t* __restrict__ sizes, int32_t* __restrict__ dcum,
+                                                       int32_t* __restrict__ longest, int64_t span_cap, int dbg) {
+  if (prefix[n] > span_cap) return;   // the findall in front did not have room for its spans: the host retries
+  constexpr int NB = TILE / 1024 + 1;
+  constexpr int ROW = TILE / 16 + 4;
+  __shared__ uint16_t bm_all[kBlock / 64][kSubcLeaves * ROW];
+  __shared__ uint16_t bnd_all[kBlock / 64][64 * (kSubcLeaves + 1)];
+  __shared__ uint8_t mask[256];
+  for (int c = threadIdx.x; c < 256; c += blockDim.x) mask[c] = g_mask[c];
   __syncthreads();
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  uint8_t* tile = L.text[wv];
-  uint16_t* bnd = L.bnd[wv] + lane * (kChainLeaves + 1);
+  uint16_t* bm = bm_all[wv];
+  uint16_t* bnd = bnd_all[wv] + lane * (kSubcLeaves + 1);
+  int worst = 0;
   const int64_t nw = (int64_t)gridDim.x * (kBlock / 64);
-  for (int64_t i = (int64_t)blockIdx.x * (kBlock / 64) + wv; i < n; i += nw) {
-    const int64_t ibase = offsets[i];
-    const int tlen = (int)(offsets[i + 1] - ibase);
-    const int64_t a = prefix[i];
-    int64_t k64 = prefix[i + 1] - a;
-    if (count > 0 && k64 > count) k64 = count;
-    const int k = (int)k64;
-    if (tlen > kSubcTile) {
-      if (lane == 0) { *over = 1; sizes[i] = 0; }
+  uint4 tx[NB];
+  int2 sp_first;
+  auto issue = [&](const SubcDesc& d) {
+    const uint8_t* tptr = data + d.ibase;
+    const int mis = (int)((uintptr_t)tptr & 15);
+    const uint8_t* fptr = tptr - mis;
+    const int nfb = d.k > 0 && d.tlen <= TILE ? (mis + d.tlen + 15) >> 4 : 0;
+#pragma unroll
+    for (int r = 0; r < NB; ++r) {
+      const int b = lane + 64 * r;
+      tx[r] = b < nfb ? *(const uint4*)(fptr + 16 * b) : make_uint4(0, 0, 0, 0);
+    }
+    sp_first = lane < d.k ? *(const int2*)(spans + 2 * (d.a + lane)) : make_int2(0, 0);
+  };
+  int64_t i = (int64_t)blockIdx.x * (kBlock / 64) + wv;
+  SubcDesc d0 = subc_desc<false>(i, n, offsets, prefix, nullptr, count), d1 = subc_desc<false>(i + nw, n, offsets, prefix, nullptr, count);
+  issue(d0);
+  for (; i < n; i += nw) {
+    const SubcDesc d = d0;
+    d0 = d1;
+    d1 = subc_desc<false>(i + 2 * nw, n, offsets, prefix, nullptr, count);
+    const int tlen = d.tlen, k = d.k;
+    const int64_t a = d.a;
+    if (tlen > TILE) {   // (the host has looked at the longest text already: not reached)
+      if (lane == 0) sizes[i] = 0;
+      worst = 0x7FFFFFFF;
+      issue(d0);
       continue;
     }
-    const uint8_t* tptr = data + ibase;
-    const int mis = (int)((uintptr_t)tptr & 15);
-    __builtin_amdgcn_wave_barrier();
-    if (k > 0) subc_load_text(tile, tptr, tlen, lane);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int mis = (int)((uintptr_t)(data + d.ibase) & 15);
+    MRX_SUBC_WAVE_SYNC();
+    if (k > 0 && !(dbg & 2)) subc_store<NB, ROW, false>(tx, bm, nullptr, mask, cd.nleaf, (mis + tlen + 15) >> 4, lane);
+    const int2 sp_cur = sp_first;
+    issue(d0);
+    MRX_SUBC_WAVE_SYNC();
     int carry = 0;
     for (int m0 = 0; m0 < k; m0 += 64) {
       const int m = m0 + lane;
       int delta = 0;
       if (m < k) {
-        const int2 sp = *(const int2*)(spans + 2 * (a + m));
-        subc_walk(cd, tile + mis, L.mask, bnd, sp.x, sp.y);
-        delta = subc_repl_len(cd, tpl, bnd) - (sp.y - sp.x);
+        const int2 sp = m0 == 0 ? sp_cur : *(const int2*)(spans + 2 * (a + m));
+        if (!(dbg & 1)) {
+          subc_walk<ROW>(cd, bm, mis, bnd, sp.x, sp.y);
+          delta = subc_repl_len(cd, bnd) - (sp.y - sp.x);
+        }
       }
       const int incl = group_scan<64, false>(delta);
-      if (m < k) dcum[a + m] = carry + incl - delta;
+      if (m < k && !(dbg & 4)) dcum[a + m] = carry + incl - delta;
       carry += __shfl(incl, 63, 64);
     }
-    if (lane == 0) {
-      sizes[i] = (int64_t)tlen + carry;
-      if (tlen + carry > kSubcTile) *over = 1;
-    }
+    if (lane == 0) sizes[i] = (int64_t)tlen + carry;
+    if (tlen + carry > worst) worst = tlen + carry;
   }
+  if (lane == 0 && worst > 0) atomicMax(longest, worst);
 }
+template <int TILE>
 __global__ __launch_bounds__(kBlock) void k_subc_emit(ChainDev cd, int64_t n, const uint8_t* __restrict__ data,
                                                       const int64_t* __restrict__ offsets,
                                                       const int64_t* __restrict__ prefix, const int32_t* __restrict__ spans,
-                                                      long long count, const uint16_t* __restrict__ g_mask,
-                                                      const ReplSeg* __restrict__ tpl, const uint8_t* __restrict__ repl,
+                                                      long long count, const uint8_t* __restrict__ g_mask,
+                                                      const uint8_t* __restrict__ g_repl, int repl_len,
                                                       const int32_t* __restrict__ dcum, const int64_t* __restrict__ out_off,
                                                       uint8_t* __restrict__ out) {
-  __shared__ __align__(16) SubcLds L;
-  __shared__ __align__(16) uint8_t otile_all[kBlock / 64][kSubcTile + 32];
-  for (int c = threadIdx.x; c < 256; c += blockDim.x) L.mask[c] = g_mask[c];
+  constexpr int NB = TILE / 1024 + 1;
+  constexpr int ROW = TILE / 16 + 4;
+  __shared__ uint16_t bm_all[kBlock / 64][kSubcLeaves * ROW];
+  __shared__ __align__(16) uint8_t text_all[kBlock / 64][TILE + 32];
+  __shared__ __align__(16) uint8_t otile_all[kBlock / 64][TILE + 32];
+  __shared__ uint16_t bnd_all[kBlock / 64][64 * (kSubcLeaves + 1)];
+  __shared__ uint8_t mask[256];
+  __shared__ uint8_t repl[kSubcRepl + 8];
+  for (int c = threadIdx.x; c < 256; c += blockDim.x) mask[c] = g_mask[c];
+  for (int c = threadIdx.x; c < repl_len; c += blockDim.x) repl[c] = g_repl[c];
   __syncthreads();
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  uint8_t* tile = L.text[wv];
+  uint16_t* bm = bm_all[wv];
+  uint8_t* tile = text_all[wv];
   uint8_t* otile = otile_all[wv];
-  uint16_t* bnd = L.bnd[wv] + lane * (kChainLeaves + 1);
-  auto wave_sync = [&]() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  };
+  uint16_t* bnd = bnd_all[wv] + lane * (kSubcLeaves + 1);
   const int64_t nw = (int64_t)gridDim.x * (kBlock / 64);
-  for (int64_t i = (int64_t)blockIdx.x * (kBlock / 64) + wv; i < n; i += nw) {
-    const int64_t ibase = offsets[i];
-    const int tlen = (int)(offsets[i + 1] - ibase);
-    const int64_t a = prefix[i];
-    int64_t k64 = prefix[i + 1] - a;
-    if (count > 0 && k64 > count) k64 = count;
-    const int k = (int)k64;
-    const int64_t obase = out_off[i];
-    const int olen = (int)(out_off[i + 1] - obase);
-    if (olen <= 0) continue;
-    const uint8_t* tptr = data + ibase;
-    const int mis = (int)((uintptr_t)tptr & 15), head = (int)((uintptr_t)(out + obase) & 15);
-    wave_sync();   // the previous text's tiles are free
-    subc_load_text(tile, tptr, tlen, lane);
-    wave_sync();
+  uint4 tx[NB];
+  int2 sp_first;
+  int dc_first;
+  auto takes = [&](const SubcDesc& d) { return d.olen > 0 && d.olen <= TILE && d.tlen <= TILE; };   // (else: not launched)
+  auto issue = [&](const SubcDesc& d) {
+    const uint8_t* tptr = data + d.ibase;
+    const int mis = (int)((uintptr_t)tptr & 15);
+    const uint8_t* fptr = tptr - mis;
+    const int nfb = takes(d) ? (mis + d.tlen + 15) >> 4 : 0;
+#pragma unroll
+    for (int r = 0; r < NB; ++r) {
+      const int b = lane + 64 * r;
+      tx[r] = b < nfb ? *(const uint4*)(fptr + 16 * b) : make_uint4(0, 0, 0, 0);
+    }
+    const bool have = takes(d) && lane < d.k;
+    sp_first = have ? *(const int2*)(spans + 2 * (d.a + lane)) : make_int2(0, 0);
+    dc_first = have ? dcum[d.a + lane] : 0;
+  };
+  int64_t i = (int64_t)blockIdx.x * (kBlock / 64) + wv;
+  SubcDesc d0 = subc_desc<true>(i, n, offsets, prefix, out_off, count), d1 = subc_desc<true>(i + nw, n, offsets, prefix, out_off, count);
+  issue(d0);
+  for (; i < n; i += nw) {
+    const SubcDesc d = d0;
+    d0 = d1;
+    d1 = subc_desc<true>(i + 2 * nw, n, offsets, prefix, out_off, count);
+    const int tlen = d.tlen, k = d.k, olen = d.olen;
+    const int64_t a = d.a, obase = d.obase;
+    if (!takes(d)) { issue(d0); continue; }
+    const int mis = (int)((uintptr_t)(data + d.ibase) & 15), head = (int)((uintptr_t)(out + obase) & 15);
+    MRX_SUBC_WAVE_SYNC();   // the previous text's tiles are free
+    subc_store<NB, ROW, true>(tx, bm, tile, mask, cd.nleaf, (mis + tlen + 15) >> 4, lane);
+    const int2 sp_cur = sp_first;
+    const int dc_cur = dc_first;
+    issue(d0);
+    MRX_SUBC_WAVE_SYNC();
     const uint8_t* txt = tile + mis;
     uint8_t* o = otile + head;
     // the whole wavefront copies text[src, src + len) to o[dst ..]
@@ -6536,9 +6646,9 @@ __global__ __launch_bounds__(kBlock) void k_subc_emit(ChainDev cd, int64_t n, co
       const bool live = m < k;
       int ms = 0, me = 0, before = 0;
       if (live) {
-        const int2 sp = *(const int2*)(spans + 2 * (a + m));
+        const int2 sp = m0 == 0 ? sp_cur : *(const int2*)(spans + 2 * (a + m));
         ms = sp.x; me = sp.y;
-        before = dcum[a + m];
+        before = m0 == 0 ? dc_cur : dcum[a + m];
       }
       int pe = __shfl_up(me, 1, 64);
       if (lane == 0) pe = prev_end;
@@ -6546,8 +6656,7 @@ __global__ __launch_bounds__(kBlock) void k_subc_emit(ChainDev cd, int64_t n, co
       prev_end = __shfl(me, nlive - 1, 64);
       // the kept bytes in front of the match: short gaps by the lane, long ones by the wavefront
       const int gap = live ? ms - pe : 0;
-      if (gap <= 24)
-        for (int j = 0; j < gap; ++j) o[pe + before + j] = txt[pe + j];
+      if (gap <= 24) subc_copy(o + pe + before, txt + pe, gap);
       uint64_t wide = __ballot(gap > 24);
       while (wide) {
         const int src_lane = __ffsll((unsigned long long)wide) - 1;
@@ -6555,24 +6664,23 @@ __global__ __launch_bounds__(kBlock) void k_subc_emit(ChainDev cd, int64_t n, co
         copy_all(__shfl(pe, src_lane, 64), __shfl(gap, src_lane, 64), __shfl(pe + before, src_lane, 64));
       }
       if (live) {
-        subc_walk(cd, txt, L.mask, bnd, ms, me);
+        subc_walk<ROW>(cd, bm, mis, bnd, ms, me);
         uint8_t* dst = o + ms + before;
         for (int q = 0; q < cd.ntpl; ++q) {
-          const ReplSeg sg = tpl[q];
-          if (sg.group_ref > 0) {
-            const int og = sg.group_ref <= 9 ? cd.gopen[sg.group_ref] : -1;
-            if (og >= 0) {
-              const int gs = bnd[og], ge = bnd[cd.gclose[sg.group_ref]];
-              for (int j = gs; j < ge; ++j) *dst++ = txt[j];
-            }
+          const ReplSeg sg = cd.tpl[q];
+          if (sg.group_ref) {
+            const int gs = bnd[sg.start], gl = (int)bnd[sg.length] - gs;
+            subc_copy(dst, txt + gs, gl);
+            dst += gl;
           } else {
-            for (int j = 0; j < sg.length; ++j) *dst++ = repl[sg.start + j];
+            subc_copy(dst, repl + sg.start, sg.length);
+            dst += sg.length;
           }
         }
       }
     }
     copy_all(prev_end, tlen - prev_end, prev_end + (olen - tlen));   // behind the last replaced match
-    wave_sync();
+    MRX_SUBC_WAVE_SYNC();
     // the tile out: whole 16-byte blocks where the block is the text's alone, bytes at the two ends
     uint8_t* oframe = out + obase - head;
     const int nob = (head + olen + 15) >> 4;
@@ -6587,51 +6695,73 @@ __global__ __launch_bounds__(kBlock) void k_subc_emit(ChainDev cd, int64_t n, co
     }
   }
 }
+#undef MRX_SUBC_WAVE_SYNC
 
 int sub_chain_from_spans(const mrx_handle* h, const Layout& lay, int64_t n, const std::string& r,
                          const std::vector<ReplSeg>& tpl, int64_t count, int64_t* out_off, uint8_t* out, int64_t out_cap,
                          int64_t* total_bytes, hipStream_t s, int64_t known_bytes, int64_t known_max) {
   const ChainGroups& cg = h->hp.chain;
+  if (cg.nleaf > kSubcLeaves || (int)tpl.size() > kSubcTpl || (int)r.size() > kSubcRepl) return kSubsRetryGeneric;
   int64_t in_bytes = known_bytes, max_len = known_max;
   if (known_bytes < 0 || known_max < 0)
     if (int rc0 = csr_stats(lay, n, s, &in_bytes, &max_len)) return rc0;
   if (in_bytes < 0) return fail(MRX_E_ARGUMENT, "offsets[n] is negative");
-  if (max_len > kSubcTile) return kSubsRetryGeneric;
+  if (max_len > 4096) return kSubsRetryGeneric;
   ChainDev cd{};
   cd.nleaf = cg.nleaf; cd.ntpl = (int)tpl.size();
-  for (int l = 0; l < kChainLeaves; ++l) { cd.lmin[l] = cg.lmin[l]; cd.lmax[l] = cg.lmax[l]; }
-  for (int g = 0; g < 10; ++g) { cd.gopen[g] = (int8_t)cg.gopen[g]; cd.gclose[g] = (int8_t)cg.gclose[g]; }
+  for (int l = 0; l < kSubcLeaves; ++l) cd.lmax[l] = cg.lmax[l];
+  cd.ntpl = 0;
+  for (const ReplSeg& sg : tpl) {   // a group's segment: the two boundaries it lies between (a group the pattern lacks: nothing)
+    if (sg.group_ref > 0) {
+      if (sg.group_ref <= 9 && cg.gopen[sg.group_ref] >= 0) cd.tpl[cd.ntpl++] = ReplSeg{1, cg.gopen[sg.group_ref], cg.gclose[sg.group_ref]};
+    } else if (sg.length > 0) {
+      cd.tpl[cd.ntpl++] = sg;
+    }
+  }
+  uint8_t mask8[256];
+  for (int c = 0; c < 256; ++c) mask8[c] = (uint8_t)cg.mask[c];
   int64_t *d_prefix = nullptr, *d_sizes = nullptr, *d_total = nullptr;
-  int32_t *d_spans = nullptr, *d_dcum = nullptr, *d_over = nullptr;
-  uint16_t* d_mask = nullptr;
-  ReplSeg* d_tpl = nullptr;
-  uint8_t* d_repl = nullptr;
+  int32_t *d_spans = nullptr, *d_dcum = nullptr, *d_longest = nullptr;
+  uint8_t *d_mask = nullptr, *d_repl = nullptr;
   HIP_TRY(scratch_alloc((void**)&d_prefix, sizeof(int64_t) * (n + 1), s));
   HIP_TRY(scratch_alloc((void**)&d_sizes, sizeof(int64_t) * n, s));
   HIP_TRY(scratch_alloc((void**)&d_total, sizeof(int64_t), s));
-  HIP_TRY(scratch_alloc((void**)&d_over, sizeof(int32_t), s));
-  HIP_TRY(scratch_alloc((void**)&d_mask, sizeof(uint16_t) * 256, s));
-  HIP_TRY(scratch_alloc((void**)&d_tpl, sizeof(ReplSeg) * (tpl.size() + 1), s));
+  HIP_TRY(scratch_alloc((void**)&d_longest, sizeof(int32_t), s));
+  HIP_TRY(scratch_alloc((void**)&d_mask, 256, s));
   HIP_TRY(scratch_alloc((void**)&d_repl, r.size() + 16, s));
-  HIP_TRY(hipMemcpyAsync(d_mask, cg.mask.data(), sizeof(uint16_t) * 256, hipMemcpyHostToDevice, s));
-  if (!tpl.empty()) HIP_TRY(hipMemcpyAsync(d_tpl, tpl.data(), sizeof(ReplSeg) * tpl.size(), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(d_mask, mask8, 256, hipMemcpyHostToDevice, s));   // (pageable source: copied before the call returns)
   if (!r.empty()) HIP_TRY(hipMemcpyAsync(d_repl, r.data(), r.size(), hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemsetAsync(d_over, 0, sizeof(int32_t), s));
+  HIP_TRY(hipMemsetAsync(d_longest, 0, sizeof(int32_t), s));
   int64_t cap = in_bytes / 8 + n + 64, nm = 0, tot = 0;
   if (const int64_t seen = h->sub_matches_per_kib.load(std::memory_order_relaxed); seen > 128) {
     const int64_t by_hint = (in_bytes >> 10) * (seen + seen / 8 + 1) + n + 64;
     if (by_hint > cap) cap = by_hint < in_bytes + n + 64 ? by_hint : in_bytes + n + 64;
   }
-  int32_t over = 0;
+  int32_t longest = 0;
+  const int subc_dbg = getenv("MRX_SUBC_DEBUG") ? atoi(getenv("MRX_SUBC_DEBUG")) : 0;   // (ablation runs: wrong results)
   const int64_t blocks = (n + (kBlock / 64) - 1) / (kBlock / 64);
   const unsigned grid = (unsigned)(blocks < grid_cap() ? blocks : grid_cap());
   int rc = MRX_OK;
+  // (three host synchronisations: the match total, which sizes the spans; the output total and the longest output, which
+  // pick the emit kernel's tile)
   for (int attempt = 0; attempt < 2; ++attempt) {
     HIP_TRY(scratch_alloc((void**)&d_spans, sizeof(int32_t) * 2 * (size_t)cap, s));
     HIP_TRY(scratch_alloc((void**)&d_dcum, sizeof(int32_t) * (size_t)(cap + 1), s));
     rc = run_findall(h, lay, n, d_prefix, d_spans, cap, nullptr, s, /*match_next_sequence=*/true, in_bytes, max_len);
     if (rc != MRX_OK) return rc;
+    // (sizes behind the spans without waiting: when the spans did not fit it returns at once)
+    if (max_len <= 2048)
+      hipLaunchKernelGGL(k_subc_sizes<2048>, dim3(grid), dim3(kBlock), 0, s, cd, n, lay.data, lay.offsets, d_prefix, d_spans,
+                         (long long)count, d_mask, d_sizes, d_dcum, d_longest, cap, subc_dbg);
+    else
+      hipLaunchKernelGGL(k_subc_sizes<4096>, dim3(grid), dim3(kBlock), 0, s, cd, n, lay.data, lay.offsets, d_prefix, d_spans,
+                         (long long)count, d_mask, d_sizes, d_dcum, d_longest, cap, subc_dbg);
+    HIP_TRY(hipGetLastError());
+    rc = device_scan<int64_t>(d_sizes, n, out_off, d_total, s);
+    if (rc != MRX_OK) return rc;
     HIP_TRY(hipMemcpyAsync(&nm, d_prefix + n, sizeof nm, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&tot, d_total, sizeof tot, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&longest, d_longest, sizeof longest, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     h->sub_matches_per_kib.store(in_bytes >= 1024 ? nm / (in_bytes >> 10) : 0, std::memory_order_relaxed);
     if (nm <= cap) break;
@@ -6640,23 +6770,19 @@ int sub_chain_from_spans(const mrx_handle* h, const Layout& lay, int64_t n, cons
     HIP_TRY(scratch_free(d_dcum, s));
     cap = nm;
   }
-  hipLaunchKernelGGL(k_subc_sizes, dim3(grid), dim3(kBlock), 0, s, cd, n, lay.data, lay.offsets, d_prefix, d_spans,
-                     (long long)count, d_mask, d_tpl, d_sizes, d_dcum, d_over);
-  HIP_TRY(hipGetLastError());
-  rc = device_scan<int64_t>(d_sizes, n, out_off, d_total, s);
-  if (rc != MRX_OK) return rc;
-  HIP_TRY(hipMemcpyAsync(&tot, d_total, sizeof tot, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(&over, d_over, sizeof over, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
-  if (over) {
+  if (longest > 4096) {
     rc = kSubsRetryGeneric;
   } else {
     if (total_bytes) *total_bytes = tot;
     if (tot > out_cap) {
       rc = fail(MRX_E_CAPACITY, "output buffer too small: need " + std::to_string(tot));
     } else if (tot > 0) {
-      hipLaunchKernelGGL(k_subc_emit, dim3(grid), dim3(kBlock), 0, s, cd, n, lay.data, lay.offsets, d_prefix, d_spans,
-                         (long long)count, d_mask, d_tpl, d_repl, d_dcum, out_off, out);
+#define MRX_SUBC_EMIT(TT)                                                                                              \
+  hipLaunchKernelGGL(k_subc_emit<TT>, dim3(grid), dim3(kBlock), 0, s, cd, n, lay.data, lay.offsets, d_prefix, d_spans, \
+                     (long long)count, d_mask, d_repl, (int)r.size(), d_dcum, out_off, out)
+      if (longest <= 2048 && max_len <= 2048) MRX_SUBC_EMIT(2048);
+      else MRX_SUBC_EMIT(4096);
+#undef MRX_SUBC_EMIT
       HIP_TRY(hipGetLastError());
       g_last_kernel = "k_subc_emit";
     }
@@ -6664,9 +6790,8 @@ int sub_chain_from_spans(const mrx_handle* h, const Layout& lay, int64_t n, cons
   HIP_TRY(scratch_free(d_prefix, s));
   HIP_TRY(scratch_free(d_sizes, s));
   HIP_TRY(scratch_free(d_total, s));
-  HIP_TRY(scratch_free(d_over, s));
+  HIP_TRY(scratch_free(d_longest, s));
   HIP_TRY(scratch_free(d_mask, s));
-  HIP_TRY(scratch_free(d_tpl, s));
   HIP_TRY(scratch_free(d_repl, s));
   HIP_TRY(scratch_free(d_spans, s));
   HIP_TRY(scratch_free(d_dcum, s));
