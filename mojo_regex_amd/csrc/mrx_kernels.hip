@@ -6397,7 +6397,8 @@ int sub_from_spans(const mrx_handle* h, const Layout& lay, int64_t n, const std:
 // an output tile, the tile out in 16-byte stores.  A text or an output beyond 4 KiB: the call is the lane-per-text
 // interpreter's (k_sub).
 namespace {
-constexpr int kSubcLeaves = 8, kSubcTpl = 16, kSubcRepl = 256;
+constexpr int kSubcLeaves = 8, kSubcTpl = 8, kSubcRepl = 256;   // (loops over leaves and segments are unrolled: the kernel
+                                                                   // arguments they index stay in scalar registers)
 struct ChainDev {
   int nleaf, ntpl;
   int lmax[kSubcLeaves];
@@ -6441,7 +6442,9 @@ __device__ __forceinline__ void subc_store(const uint4 (&tx)[NB], uint16_t* bm, 
       for (int q = 0; q < 4; ++q)
         o[q] = (uint32_t)mask[w[q] & 255] | ((uint32_t)mask[(w[q] >> 8) & 255] << 8) |
                ((uint32_t)mask[(w[q] >> 16) & 255] << 16) | ((uint32_t)mask[w[q] >> 24] << 24);
-      for (int l = 0; l < nleaf; ++l) {
+#pragma unroll
+      for (int l = 0; l < kSubcLeaves; ++l) {
+        if (l >= nleaf) break;
         uint32_t bits = 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q)   // bit l of four bytes -> four adjacent bits (the products' other terms stay below bit 24)
@@ -6456,7 +6459,9 @@ __device__ __forceinline__ void subc_store(const uint4 (&tx)[NB], uint16_t* bm, 
 template <int ROW>
 __device__ __forceinline__ void subc_walk(const ChainDev& cd, const uint16_t* bm, int mis, uint16_t* bnd, int ms, int me) {
   int pos = ms;
-  for (int l = 0; l < cd.nleaf; ++l) {
+#pragma unroll
+  for (int l = 0; l < kSubcLeaves; ++l) {
+    if (l >= cd.nleaf) break;
     bnd[l] = (uint16_t)pos;
     const int lm = cd.lmax[l];
     const int stop = lm < 0 || pos + lm > me ? me : pos + lm;
@@ -6477,7 +6482,9 @@ __device__ __forceinline__ void subc_walk(const ChainDev& cd, const uint16_t* bm
 // (ChainDev::tpl as the host rewrote it: group_ref != 0: bytes between the boundaries `start` and `length`; else literal)
 __device__ __forceinline__ int subc_repl_len(const ChainDev& cd, const uint16_t* bnd) {
   int rl = 0;
-  for (int k = 0; k < cd.ntpl; ++k) {
+#pragma unroll
+  for (int k = 0; k < kSubcTpl; ++k) {
+    if (k >= cd.ntpl) break;
     const ReplSeg sg = cd.tpl[k];
     rl += sg.group_ref ? (int)bnd[sg.length] - (int)bnd[sg.start] : sg.length;
   }
@@ -6666,7 +6673,9 @@ __global__ __launch_bounds__(kBlock) void k_subc_emit(ChainDev cd, int64_t n, co
       if (live) {
         subc_walk<ROW>(cd, bm, mis, bnd, ms, me);
         uint8_t* dst = o + ms + before;
-        for (int q = 0; q < cd.ntpl; ++q) {
+#pragma unroll
+        for (int q = 0; q < kSubcTpl; ++q) {
+          if (q >= cd.ntpl) break;
           const ReplSeg sg = cd.tpl[q];
           if (sg.group_ref) {
             const int gs = bnd[sg.start], gl = (int)bnd[sg.length] - gs;

@@ -1263,8 +1263,10 @@ void build_plan(const std::string& pattern, HostPlan& hp, bool force_nfa, bool f
       std::string why;
       if (!(d.bt_flags & 32)) why = "not a deterministic chain";
       else if (d.bt_flags & 1) why = "NFAEngine literal prefilter";
-      else if (d.kind != PLAN_DFA || (d.flags & (PF_START_ANCHOR | PF_END_ANCHOR | PF_PREFILTER | PF_EXACT_LITERAL | PF_PURE_LITERAL | PF_SCAN_ELIGIBLE)))
-        why = "the search is not a plain DFAEngine table walk";
+      else if ((d.kind != PLAN_DFA && d.kind != PLAN_LAZY) ||
+               (d.flags & (PF_START_ANCHOR | PF_END_ANCHOR | PF_PREFILTER | PF_EXACT_LITERAL | PF_PURE_LITERAL | PF_SCAN_ELIGIBLE |
+                           PF_BITSET | PF_LAZY_END | PF_START_DEAD)))
+        why = "the search is not a plain walk of a DFAEngine / LazyDFA table";
       std::vector<int> ltbl;
       for (size_t i = 0; i < items.size() && why.empty(); ++i) {
         const BtItem& it = items[i];

@@ -913,6 +913,81 @@ def test_sub_with_groups_of_a_chain_from_spans_equals_the_interpreter_and_oracle
     assert lib.mrx_last_kernel_name() == b"k_sub_size"
 
 
+def _random_chain_with_groups(rng):
+    """A random chain of classes and literals with quantifiers, capture groups around runs of its elements (nested now
+    and then), and a replacement template over the groups."""
+    atoms = ["\\w", "\\d", "\\s", "[a-z]", "[a-c]", "[0-9a-f]", "[^ ]", " ", "-", "\\.", "@", "x", "a", ":"]
+    quants = ["", "", "+", "+", "{2}", "{1,3}", "{2,}", "{3,5}"]
+    n = int(rng.integers(1, 7))
+    elems = [atoms[int(rng.integers(len(atoms)))] + quants[int(rng.integers(len(quants)))] for _ in range(n)]
+    opens, closes = [0] * (n + 1), [0] * (n + 1)
+    ngroups = int(rng.integers(1, 4))
+    for _ in range(ngroups):
+        a = int(rng.integers(0, n))
+        b = int(rng.integers(a + 1, n + 1))
+        opens[a] += 1
+        closes[b] += 1
+    # (groups opened at a and closed at b in any order nest or overlap: close the inner ones first by emitting every
+    # close in front of the opens of the same position -- overlapping pairs are then simply another nesting)
+    pat = ""
+    depth = 0
+    for i in range(n):
+        c = min(closes[i], depth)
+        pat += ")" * c
+        depth -= c
+        pat += "(" * opens[i]
+        depth += opens[i]
+        pat += elems[i]
+    pat += ")" * depth
+    refs = [b"\\1", b"\\2", b"\\3", b"\\4", b"<", b">", b"-", b"", b"::", b"x"]
+    repl = b"".join(refs[int(rng.integers(len(refs)))] for _ in range(int(rng.integers(1, 6))))
+    if b"\\" not in repl:
+        repl += b"\\1"
+    return pat.encode(), repl
+
+
+def test_sub_with_groups_on_generated_chains_equals_the_oracle():
+    """Generated chains with groups (the fuzz campaign's generators almost never produce one): regex.sub with a group
+    template against the oracle on every text, whichever kernel the plan takes -- k_subc_emit where build_plan proves
+    the chain's matches to be the table walk's (chain_groups=yes), the interpreter elsewhere -- and, for the proven ones,
+    against the interpreter as well."""
+    _need_gpu()
+    rng = np.random.default_rng(int(os.environ.get("MRX_CHAIN_FUZZ_SEED", "20261005")))   # (other seeds: the round's soak runs)
+    lib = M.load_library()
+    al = b"abcxyz0123456789 -.@:af"
+    texts = _random_texts(rng, 100, 60, al) + _random_texts(rng, 12, 700, al) + [
+        b"", b"a", b" ", b"ab 12", b"hello world foo", b"aa-bb.cc@dd:ee", b"abc 123 abc 123 " * 40, b"x" * 300, b"a1 " * 500]
+    proven = checked = 0
+    for _ in range(260):
+        pat, repl = _random_chain_with_groups(rng)
+        try:
+            rx = M.compile_regex(pat)
+        except M.RegexSyntaxError:
+            continue
+        for count in (0, 2):
+            try:
+                got = rx.sub(repl, texts, count)
+            except M.UnsupportedPattern:
+                break
+            kernel = lib.mrx_last_kernel_name()
+            form = "chain_groups=yes" in rx.describe() and "fixed_total=-1" in rx.describe()   # (fixed-width groups: k_subs_wave)
+            if form:
+                assert kernel == b"k_subc_emit", (pat, repl, kernel)
+                with generic_kernels():
+                    assert rx.sub(repl, texts, count) == got, (pat, repl, count)
+            else:
+                assert kernel != b"k_subc_emit", (pat, repl)
+            for t, g in list(zip(texts, got))[:: 1 if form else 4]:   # (the interpreter has its own tests)
+                try:
+                    w = O.sub(pat, repl, t, count)
+                except (O.UnsupportedByOracle, O.ReferenceDoesNotTerminate):
+                    continue
+                assert g == w, (pat, repl, count, t[:80], g[:80], w[:80], form)
+                checked += 1
+            proven += form
+    assert proven >= 60 and checked > 12000, (proven, checked)
+
+
 @pytest.mark.parametrize("pat,repl", [(b"[a-z]+\\d+", b"#"), (b"[a-z]+\\d+", b""), (b"\\d", b""), (b"\\d+", b"<NUM>"),
                                       (b"(\\d{3})(\\d{3})(\\d{4})", b"\\1-\\2-\\3"),
                                       (b"(\\d{3})(\\d{3})(\\d{4})", b"(\\1) \\2-\\3 ext \\7"),
