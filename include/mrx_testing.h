@@ -60,6 +60,9 @@ void mrx_debug_dense_rows(int mode);
 /* PF_MW_TRIES plans: 1 = always the pending-tries walk; 0 (default) = the handle times it against
  * marks + stepper on the first calls of a batch shape (256 texts and more) and keeps the faster route. */
 void mrx_debug_tries_always(int on);
+/* regex.sub with \\1..\\9 on a deterministic chain: 1 = always measure every match's replacement
+ * (k_subc_sizes), 0 (default) = templates under which every match gains the same number of bytes skip that pass. */
+void mrx_debug_chain_sub_general(int on);
 /* Host-side run of the one-pass table of an empty-match plan whose walks read beyond their match (build_emptywalk2(),
  * mrx_plan.cpp): findall of ONE text on the CPU, for tests that pin the table to the oracle without a GPU.  Returns the
  * number of spans (spans[2 k], spans[2 k + 1] for k < min(count, cap)), -1 when the handle has no such table. */

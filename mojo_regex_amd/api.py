@@ -125,6 +125,7 @@ def load_library():
         "mrx_debug_split_findall": (None, [C.c_int]),
         "mrx_debug_dense_rows": (None, [C.c_int]),
         "mrx_debug_tries_always": (None, [C.c_int]),
+        "mrx_debug_chain_sub_general": (None, [C.c_int]),
         "mrx_testing_emptywalk_findall": (C.c_int, [H, C.c_char_p, C.c_int, i32p, C.c_int]),
         "mrx_debug_litscan_pieces": (None, [C.c_int]),
         "mrx_debug_multiwalk": (None, [C.c_int]),
@@ -173,7 +174,7 @@ TESTING_SYMBOLS = [
     "mrx_timing_reset", "mrx_timing_enable", "mrx_timing_scan_ms", "mrx_last_kernel_name",
     "mrx_debug_force_generic", "mrx_debug_long_text_kernels", "mrx_debug_scratch_bytes",
     "mrx_debug_fused_findall", "mrx_debug_stream_bits", "mrx_debug_stream_bits_trace", "mrx_debug_dynamic_texts", "mrx_debug_subs_group",
-    "mrx_debug_split_findall", "mrx_debug_dense_rows", "mrx_debug_tries_always", "mrx_testing_emptywalk_findall", "mrx_debug_litscan_pieces", "mrx_debug_multiwalk", "mrx_debug_rec_skew", "mrx_testing_comm_shift", "mrx_testing_comm_compact",
+    "mrx_debug_split_findall", "mrx_debug_dense_rows", "mrx_debug_tries_always", "mrx_debug_chain_sub_general", "mrx_testing_emptywalk_findall", "mrx_debug_litscan_pieces", "mrx_debug_multiwalk", "mrx_debug_rec_skew", "mrx_testing_comm_shift", "mrx_testing_comm_compact",
 ]
 COMM_SYMBOLS = [
     "mrx_comm_unique_id", "mrx_comm_init", "mrx_comm_free", "mrx_comm_rank", "mrx_comm_size",

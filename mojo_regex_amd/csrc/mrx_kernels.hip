@@ -6389,6 +6389,7 @@ int sub_from_spans(const mrx_handle* h, const Layout& lay, int64_t n, const std:
 }
 }  // namespace
 
+static int g_chain_sub_general = 0;   // mrx_debug_chain_sub_general
 // ---- sub() with \1..\9 on a deterministic chain (HostPlan::chain) -----------------------------------------
 // The matches are the plain search's spans (run_findall, match_next_sequence); a wavefront takes a text: every byte's
 // leaf mask (bit l: leaf l takes the byte) in an LDS tile, a lane per match finds the leaves' boundaries as runs of
@@ -6581,6 +6582,27 @@ __global__ __launch_bounds__(kBlock) void k_subc_sizes(ChainDev cd, int64_t n, c
   }
   if (lane == 0 && worst > 0) atomicMax(longest, worst);
 }
+// Every match's replacement differs from the match by the same number of bytes (each leaf of variable width lies in
+// exactly one referenced group -- a template that reorders the groups): no walk for the sizes, a lane per text.
+__global__ __launch_bounds__(kBlock) void k_subc_sizes_const(int64_t n, const int64_t* __restrict__ offsets,
+                                                             const int64_t* __restrict__ prefix, long long count, int delta,
+                                                             int64_t* __restrict__ sizes, int32_t* __restrict__ longest,
+                                                             int64_t span_cap) {
+  if (prefix[n] > span_cap) return;
+  int worst = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t tlen = offsets[i + 1] - offsets[i];
+    int64_t k = prefix[i + 1] - prefix[i];
+    if (count > 0 && k > count) k = count;
+    const int64_t olen = tlen + k * delta;
+    sizes[i] = olen;
+    const int w = tlen > 0x7FFFFFFF || olen > 0x7FFFFFFF ? 0x7FFFFFFF : (int)(tlen > olen ? tlen : olen);
+    if (w > worst) worst = w;
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(worst, d, 64); if (o > worst) worst = o; }
+  if ((threadIdx.x & 63) == 0 && worst > 0) atomicMax(longest, worst);
+}
 template <int TILE>
 __global__ __launch_bounds__(kBlock) void k_subc_emit(ChainDev cd, int64_t n, const uint8_t* __restrict__ data,
                                                       const int64_t* __restrict__ offsets,
@@ -6588,7 +6610,8 @@ __global__ __launch_bounds__(kBlock) void k_subc_emit(ChainDev cd, int64_t n, co
                                                       long long count, const uint8_t* __restrict__ g_mask,
                                                       const uint8_t* __restrict__ g_repl, int repl_len,
                                                       const int32_t* __restrict__ dcum, const int64_t* __restrict__ out_off,
-                                                      uint8_t* __restrict__ out) {
+                                                      uint8_t* __restrict__ out, int cdelta) {
+  // dcum == nullptr: every match gains cdelta bytes (k_subc_sizes_const)
   constexpr int NB = TILE / 1024 + 1;
   constexpr int ROW = TILE / 16 + 4;
   __shared__ uint16_t bm_all[kBlock / 64][kSubcLeaves * ROW];
@@ -6622,7 +6645,7 @@ __global__ __launch_bounds__(kBlock) void k_subc_emit(ChainDev cd, int64_t n, co
     }
     const bool have = takes(d) && lane < d.k;
     sp_first = have ? *(const int2*)(spans + 2 * (d.a + lane)) : make_int2(0, 0);
-    dc_first = have ? dcum[d.a + lane] : 0;
+    dc_first = have && dcum ? dcum[d.a + lane] : lane * cdelta;
   };
   int64_t i = (int64_t)blockIdx.x * (kBlock / 64) + wv;
   SubcDesc d0 = subc_desc<true>(i, n, offsets, prefix, out_off, count), d1 = subc_desc<true>(i + nw, n, offsets, prefix, out_off, count);
@@ -6655,7 +6678,7 @@ __global__ __launch_bounds__(kBlock) void k_subc_emit(ChainDev cd, int64_t n, co
       if (live) {
         const int2 sp = m0 == 0 ? sp_cur : *(const int2*)(spans + 2 * (a + m));
         ms = sp.x; me = sp.y;
-        before = m0 == 0 ? dc_cur : dcum[a + m];
+        before = m0 == 0 ? dc_cur : dcum ? dcum[a + m] : m * cdelta;
       }
       int pe = __shfl_up(me, 1, 64);
       if (lane == 0) pe = prev_end;
@@ -6729,6 +6752,22 @@ int sub_chain_from_spans(const mrx_handle* h, const Layout& lay, int64_t n, cons
   }
   uint8_t mask8[256];
   for (int c = 0; c < 256; ++c) mask8[c] = (uint8_t)cg.mask[c];
+  // does every match gain the same number of bytes?  (literal bytes + fixed-width leaves counted by the groups that hold
+  // them - their own width; a leaf of variable width must lie in exactly one referenced group)
+  bool const_delta = true;
+  int cdelta = 0;
+  {
+    int covers[kSubcLeaves] = {0};
+    for (int k = 0; k < cd.ntpl; ++k) {
+      if (cd.tpl[k].group_ref) for (int l = cd.tpl[k].start; l < cd.tpl[k].length; ++l) ++covers[l];
+      else cdelta += cd.tpl[k].length;
+    }
+    for (int l = 0; l < cg.nleaf; ++l) {
+      if (cg.lmin[l] == cg.lmax[l]) cdelta += (covers[l] - 1) * cg.lmin[l];
+      else if (covers[l] != 1) const_delta = false;
+    }
+    if (g_chain_sub_general) const_delta = false;   // (mrx_debug_chain_sub_general: the general form, for A/B runs and tests)
+  }
   int64_t *d_prefix = nullptr, *d_sizes = nullptr, *d_total = nullptr;
   int32_t *d_spans = nullptr, *d_dcum = nullptr, *d_longest = nullptr;
   uint8_t *d_mask = nullptr, *d_repl = nullptr;
@@ -6759,7 +6798,10 @@ int sub_chain_from_spans(const mrx_handle* h, const Layout& lay, int64_t n, cons
     rc = run_findall(h, lay, n, d_prefix, d_spans, cap, nullptr, s, /*match_next_sequence=*/true, in_bytes, max_len);
     if (rc != MRX_OK) return rc;
     // (sizes behind the spans without waiting: when the spans did not fit it returns at once)
-    if (max_len <= 2048)
+    if (const_delta)
+      hipLaunchKernelGGL(k_subc_sizes_const, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, n, lay.offsets, d_prefix,
+                         (long long)count, cdelta, d_sizes, d_longest, cap);
+    else if (max_len <= 2048)
       hipLaunchKernelGGL(k_subc_sizes<2048>, dim3(grid), dim3(kBlock), 0, s, cd, n, lay.data, lay.offsets, d_prefix, d_spans,
                          (long long)count, d_mask, d_sizes, d_dcum, d_longest, cap, subc_dbg);
     else
@@ -6788,7 +6830,7 @@ int sub_chain_from_spans(const mrx_handle* h, const Layout& lay, int64_t n, cons
     } else if (tot > 0) {
 #define MRX_SUBC_EMIT(TT)                                                                                              \
   hipLaunchKernelGGL(k_subc_emit<TT>, dim3(grid), dim3(kBlock), 0, s, cd, n, lay.data, lay.offsets, d_prefix, d_spans, \
-                     (long long)count, d_mask, d_repl, (int)r.size(), d_dcum, out_off, out)
+                     (long long)count, d_mask, d_repl, (int)r.size(), const_delta ? (const int32_t*)nullptr : d_dcum, out_off, out, cdelta)
       if (longest <= 2048 && max_len <= 2048) MRX_SUBC_EMIT(2048);
       else MRX_SUBC_EMIT(4096);
 #undef MRX_SUBC_EMIT
@@ -7781,6 +7823,7 @@ void mrx_debug_dynamic_texts(int mode) { g_dyn_mode = mode < 0 ? 0 : mode > 2 ? 
 void mrx_debug_split_findall(int on) { g_split_findall = on ? 1 : 0; }
 void mrx_debug_dense_rows(int mode) { g_dense_rows = mode; }
 void mrx_debug_tries_always(int on) { g_tries_always = on ? 1 : 0; }
+void mrx_debug_chain_sub_general(int on) { g_chain_sub_general = on ? 1 : 0; }
 int mrx_testing_emptywalk_findall(const mrx_handle* h, const uint8_t* text, int len, int32_t* spans, int cap) {
   if (!h || !h->hp.ew2_ok || len < 0) return -1;
   const std::vector<std::pair<int, int>> v = emptywalk2_run(h->hp.ew2, text, len);

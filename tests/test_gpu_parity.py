@@ -890,6 +890,12 @@ def test_sub_with_groups_of_a_chain_from_spans_equals_the_interpreter_and_oracle
         want = rx.sub(repl, texts, count)
         assert lib.mrx_last_kernel_name() == b"k_sub_size"
     got = rx.sub(repl, texts, count)
+    if form:   # (templates under which every match gains the same number of bytes skip the measuring pass: both forms)
+        lib.mrx_debug_chain_sub_general(1)
+        try:
+            assert rx.sub(repl, texts, count) == got
+        finally:
+            lib.mrx_debug_chain_sub_general(0)
     fits = max(len(w) for w in want) <= 4096   # (an output beyond the tile also hands the call to the interpreter)
     assert lib.mrx_last_kernel_name() == (b"k_subc_emit" if form and fits else b"k_sub_size"), rx.describe()
     if form and not fits:
@@ -975,6 +981,11 @@ def test_sub_with_groups_on_generated_chains_equals_the_oracle():
                 assert kernel == b"k_subc_emit", (pat, repl, kernel)
                 with generic_kernels():
                     assert rx.sub(repl, texts, count) == got, (pat, repl, count)
+                lib.mrx_debug_chain_sub_general(1)
+                try:
+                    assert rx.sub(repl, texts, count) == got, (pat, repl, count)
+                finally:
+                    lib.mrx_debug_chain_sub_general(0)
             else:
                 assert kernel != b"k_subc_emit", (pat, repl)
             for t, g in list(zip(texts, got))[:: 1 if form else 4]:   # (the interpreter has its own tests)
