@@ -6403,6 +6403,8 @@ constexpr int kSubcLeaves = 8, kSubcTpl = 8, kSubcRepl = 256;   // (loops over l
 struct ChainDev {
   int nleaf, ntpl;
   int lmax[kSubcLeaves];
+  int lfix[kSubcLeaves];   // width of a leaf with a fixed count, else 0
+  int need;                // bit l: leaf l's runs are looked at (variable count, not the last leaf): its bitmap is built
   ReplSeg tpl[kSubcTpl];   // (as sub_chain_from_spans rewrites them: a group's segment names its two boundaries)
 };
 // One text's descriptor, loaded two texts ahead; its blocks, first spans and first gains one text ahead: the global
@@ -6429,7 +6431,7 @@ __device__ __forceinline__ SubcDesc subc_desc(int64_t i, int64_t n, const int64_
 // blocks in registers -> per-leaf bitmaps (bm[l * ROW + b] bit j: leaf l takes byte 16 b + j of the frame) and, when wanted,
 // the text tile; frame of the blocks: the text begins at [address & 15]
 template <int NB, int ROW, bool TEXT>
-__device__ __forceinline__ void subc_store(const uint4 (&tx)[NB], uint16_t* bm, uint8_t* tile, const uint8_t* mask, int nleaf,
+__device__ __forceinline__ void subc_store(const uint4 (&tx)[NB], uint16_t* bm, uint8_t* tile, const uint8_t* mask, int need,
                                            int nfb, int lane) {
 #pragma unroll
   for (int r = 0; r < NB; ++r) {
@@ -6445,7 +6447,7 @@ __device__ __forceinline__ void subc_store(const uint4 (&tx)[NB], uint16_t* bm, 
                ((uint32_t)mask[(w[q] >> 16) & 255] << 16) | ((uint32_t)mask[w[q] >> 24] << 24);
 #pragma unroll
       for (int l = 0; l < kSubcLeaves; ++l) {
-        if (l >= nleaf) break;
+        if (!((need >> l) & 1)) continue;
         uint32_t bits = 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q)   // bit l of four bytes -> four adjacent bits (the products' other terms stay below bit 24)
@@ -6464,6 +6466,8 @@ __device__ __forceinline__ void subc_walk(const ChainDev& cd, const uint16_t* bm
   for (int l = 0; l < kSubcLeaves; ++l) {
     if (l >= cd.nleaf) break;
     bnd[l] = (uint16_t)pos;
+    if (l == cd.nleaf - 1) { pos = me; break; }          // the last leaf ends with the match
+    if (cd.lfix[l]) { pos += cd.lfix[l]; continue; }     // a fixed count: nothing to look at (the match is the table walk's)
     const int lm = cd.lmax[l];
     const int stop = lm < 0 || pos + lm > me ? me : pos + lm;
     const uint16_t* row = bm + l * ROW;
@@ -6558,7 +6562,7 @@ __global__ __launch_bounds__(kBlock) void k_subc_sizes(ChainDev cd, int64_t n, c
     }
     const int mis = (int)((uintptr_t)(data + d.ibase) & 15);
     MRX_SUBC_WAVE_SYNC();
-    if (k > 0 && !(dbg & 2)) subc_store<NB, ROW, false>(tx, bm, nullptr, mask, cd.nleaf, (mis + tlen + 15) >> 4, lane);
+    if (k > 0 && !(dbg & 2)) subc_store<NB, ROW, false>(tx, bm, nullptr, mask, cd.need, (mis + tlen + 15) >> 4, lane);
     const int2 sp_cur = sp_first;
     issue(d0);
     MRX_SUBC_WAVE_SYNC();
@@ -6659,7 +6663,7 @@ __global__ __launch_bounds__(kBlock) void k_subc_emit(ChainDev cd, int64_t n, co
     if (!takes(d)) { issue(d0); continue; }
     const int mis = (int)((uintptr_t)(data + d.ibase) & 15), head = (int)((uintptr_t)(out + obase) & 15);
     MRX_SUBC_WAVE_SYNC();   // the previous text's tiles are free
-    subc_store<NB, ROW, true>(tx, bm, tile, mask, cd.nleaf, (mis + tlen + 15) >> 4, lane);
+    subc_store<NB, ROW, true>(tx, bm, tile, mask, cd.need, (mis + tlen + 15) >> 4, lane);
     const int2 sp_cur = sp_first;
     const int dc_cur = dc_first;
     issue(d0);
@@ -6741,7 +6745,8 @@ int sub_chain_from_spans(const mrx_handle* h, const Layout& lay, int64_t n, cons
   if (max_len > 4096) return kSubsRetryGeneric;
   ChainDev cd{};
   cd.nleaf = cg.nleaf; cd.ntpl = (int)tpl.size();
-  for (int l = 0; l < kSubcLeaves; ++l) cd.lmax[l] = cg.lmax[l];
+  for (int l = 0; l < kSubcLeaves; ++l) { cd.lmax[l] = cg.lmax[l]; cd.lfix[l] = l < cg.nleaf && cg.lmin[l] == cg.lmax[l] ? cg.lmin[l] : 0; }
+  for (int l = 0; l + 1 < cg.nleaf; ++l) if (!cd.lfix[l]) cd.need |= 1 << l;
   cd.ntpl = 0;
   for (const ReplSeg& sg : tpl) {   // a group's segment: the two boundaries it lies between (a group the pattern lacks: nothing)
     if (sg.group_ref > 0) {
