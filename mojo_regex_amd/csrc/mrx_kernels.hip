@@ -5131,6 +5131,7 @@ static int env_int(const char* name, int dflt) {
 // Measurement knobs of the call path, read from the environment ONCE (at the first call that looks): no getenv per call.
 struct EnvKnobs {
   int decode_grid, decode_reverse, piece_c, fused_skew, fused_debug;
+  int subc_debug;   // k_subc_sizes / k_subc_emit with phases left out (timing only): 1 no walk, 2 no bitmaps, 4 no per-match store; 8 no gap copies, 32 no replacement bytes, 64 no stores
   int subs_debug;   // k_subs_wave with phases left out (timing only, the output is wrong): 1 replacement bytes, 2 kept bytes, 4 stores, 8 frame phase, 16 match phase
   bool piece_c_set;
 };
@@ -5144,6 +5145,7 @@ static const EnvKnobs& env_knobs() {
     e.fused_skew = env_int("MRX_FUSED_SKEW", 0);
     e.fused_debug = env_int("MRX_FUSED_DEBUG", 0);
     e.subs_debug = env_int("MRX_SUBS_DEBUG", 0);
+    e.subc_debug = env_int("MRX_SUBC_DEBUG", 0);
     return e;
   }();
   return k;
@@ -6614,7 +6616,8 @@ __global__ __launch_bounds__(kBlock) void k_subc_emit(ChainDev cd, int64_t n, co
                                                       long long count, const uint8_t* __restrict__ g_mask,
                                                       const uint8_t* __restrict__ g_repl, int repl_len,
                                                       const int32_t* __restrict__ dcum, const int64_t* __restrict__ out_off,
-                                                      uint8_t* __restrict__ out, int cdelta) {
+                                                      uint8_t* __restrict__ out, int cdelta, int dbg) {
+  // dbg (MRX_SUBC_DEBUG, timing only): 8 no gap copies, 32 no replacement bytes, 64 no stores
   // dcum == nullptr: every match gains cdelta bytes (k_subc_sizes_const)
   constexpr int NB = TILE / 1024 + 1;
   constexpr int ROW = TILE / 16 + 4;
@@ -6690,7 +6693,7 @@ __global__ __launch_bounds__(kBlock) void k_subc_emit(ChainDev cd, int64_t n, co
       prev_end = __shfl(me, nlive - 1, 64);
       // the kept bytes in front of the match: short gaps by the lane, long ones by the wavefront
       const int gap = live ? ms - pe : 0;
-      if (gap <= 24) subc_copy(o + pe + before, txt + pe, gap);
+      if (gap <= 24 && !(dbg & 8)) subc_copy(o + pe + before, txt + pe, gap);
       uint64_t wide = __ballot(gap > 24);
       while (wide) {
         const int src_lane = __ffsll((unsigned long long)wide) - 1;
@@ -6700,6 +6703,7 @@ __global__ __launch_bounds__(kBlock) void k_subc_emit(ChainDev cd, int64_t n, co
       if (live) {
         subc_walk<ROW>(cd, bm, mis, bnd, ms, me);
         uint8_t* dst = o + ms + before;
+        if (!(dbg & 32))
 #pragma unroll
         for (int q = 0; q < kSubcTpl; ++q) {
           if (q >= cd.ntpl) break;
@@ -6720,7 +6724,7 @@ __global__ __launch_bounds__(kBlock) void k_subc_emit(ChainDev cd, int64_t n, co
     // the tile out: whole 16-byte blocks where the block is the text's alone, bytes at the two ends
     uint8_t* oframe = out + obase - head;
     const int nob = (head + olen + 15) >> 4;
-    for (int b = lane; b < nob; b += 64) {
+    for (int b = lane; b < ((dbg & 64) ? 0 : nob); b += 64) {
       const int lo = 16 * b, hi = lo + 16;
       if (lo >= head && hi <= head + olen) {
         *(uint4*)(oframe + lo) = *(const uint4*)(otile + lo);
@@ -6791,7 +6795,7 @@ int sub_chain_from_spans(const mrx_handle* h, const Layout& lay, int64_t n, cons
     if (by_hint > cap) cap = by_hint < in_bytes + n + 64 ? by_hint : in_bytes + n + 64;
   }
   int32_t longest = 0;
-  const int subc_dbg = getenv("MRX_SUBC_DEBUG") ? atoi(getenv("MRX_SUBC_DEBUG")) : 0;   // (ablation runs: wrong results)
+  const int subc_dbg = env_knobs().subc_debug;   // (ablation runs: wrong results)
   const int64_t blocks = (n + (kBlock / 64) - 1) / (kBlock / 64);
   const unsigned grid = (unsigned)(blocks < grid_cap() ? blocks : grid_cap());
   int rc = MRX_OK;
@@ -6835,7 +6839,7 @@ int sub_chain_from_spans(const mrx_handle* h, const Layout& lay, int64_t n, cons
     } else if (tot > 0) {
 #define MRX_SUBC_EMIT(TT)                                                                                              \
   hipLaunchKernelGGL(k_subc_emit<TT>, dim3(grid), dim3(kBlock), 0, s, cd, n, lay.data, lay.offsets, d_prefix, d_spans, \
-                     (long long)count, d_mask, d_repl, (int)r.size(), const_delta ? (const int32_t*)nullptr : d_dcum, out_off, out, cdelta)
+                     (long long)count, d_mask, d_repl, (int)r.size(), const_delta ? (const int32_t*)nullptr : d_dcum, out_off, out, cdelta, subc_dbg)
       if (longest <= 2048 && max_len <= 2048) MRX_SUBC_EMIT(2048);
       else MRX_SUBC_EMIT(4096);
 #undef MRX_SUBC_EMIT

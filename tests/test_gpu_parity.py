@@ -964,7 +964,7 @@ def test_sub_with_groups_on_generated_chains_equals_the_oracle():
     texts = _random_texts(rng, 100, 60, al) + _random_texts(rng, 12, 700, al) + [
         b"", b"a", b" ", b"ab 12", b"hello world foo", b"aa-bb.cc@dd:ee", b"abc 123 abc 123 " * 40, b"x" * 300, b"a1 " * 500]
     proven = checked = 0
-    for _ in range(260):
+    for _ in range(int(os.environ.get("MRX_CHAIN_FUZZ_N", "170"))):
         pat, repl = _random_chain_with_groups(rng)
         try:
             rx = M.compile_regex(pat)
@@ -996,7 +996,7 @@ def test_sub_with_groups_on_generated_chains_equals_the_oracle():
                 assert g == w, (pat, repl, count, t[:80], g[:80], w[:80], form)
                 checked += 1
             proven += form
-    assert proven >= 60 and checked > 12000, (proven, checked)
+    assert proven >= 40 and checked > 8000, (proven, checked)
 
 
 @pytest.mark.parametrize("pat,repl", [(b"[a-z]+\\d+", b"#"), (b"[a-z]+\\d+", b""), (b"\\d", b""), (b"\\d+", b"<NUM>"),

@@ -187,6 +187,27 @@ def test_backtracker_chain_classification():
         assert not chain(p), p
 
 
+def test_chain_groups_form_is_proven_on_the_tables():
+    """HostPlan::chain (`chain_groups=yes|no: why` in mrx_describe): regex.sub with \\1..\\9 may take the plain search's
+    spans only where the chain's matches are provably the table walk's -- a deterministic chain without anchors or a
+    literal prefilter, every leaf's three membership tests equal, a leaf of variable count disjoint from the leaf behind
+    it (also the last leaf of a group, which the matcher never backs off), and the chain's automaton equal to the
+    engine's table pair by pair."""
+    def verdict(p):
+        d = M.CompiledRegex(p).describe()
+        line = [x for x in d.split("\n") if x.startswith("device.backtrack=yes")]
+        assert line, (p, d)
+        return line[0].split("chain_groups=")[1]
+    for p, leaves in (("(\\w+) (\\w+)", 3), ("([a-z]+)(\\d+)", 2), ("([a-z]+)-(\\d{2,4})", 3), ("(\\d+)\\.(\\d+)", 3),
+                      ("((\\d+)-([a-z]+))", 3), ("\\w(a{2,})", 2), ("(@+(([a-z]{2,})))", 2)):
+        assert verdict(p) == "yes leaves=%d" % leaves, (p, verdict(p))
+    # the group's last leaf would have to give a byte back, which the matcher never does: its matches are not the walk's
+    assert verdict("(\\w+)x").startswith("no: a leaf with a variable count shares a byte"), verdict("(\\w+)x")
+    assert verdict("(a|b)(c)").startswith("no: not a deterministic chain")
+    assert verdict("(\\s+)(x)").startswith("no: a leaf's three membership tests differ"), verdict("(\\s+)(x)")
+    assert verdict("^(\\w+) (\\w+)").startswith("no: "), verdict("^(\\w+) (\\w+)")
+
+
 def test_fixed_width_group_patterns_that_are_nothing_but_groups():
     """HostPlan::fixed_pure (`device.sub_groups=fixed pure=1`): the pattern is (\\d{N}) / (\\d) groups end to end -- only
     then does every match hold all its group windows and equal the whole-text shortcut of regex.sub
