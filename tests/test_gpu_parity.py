@@ -964,12 +964,28 @@ def test_sub_with_groups_on_generated_chains_equals_the_oracle():
     texts = _random_texts(rng, 100, 60, al) + _random_texts(rng, 12, 700, al) + [
         b"", b"a", b" ", b"ab 12", b"hello world foo", b"aa-bb.cc@dd:ee", b"abc 123 abc 123 " * 40, b"x" * 300, b"a1 " * 500]
     proven = checked = 0
+    # (the oracle's Python backtracker needs minutes on chains like \\w+\\w{2,}...; its C twin, equal to it on every reference
+    # vector and on generated patterns -- tests/test_oracle_c.py --, takes over for this test, as in tests/big_fuzz.py)
+    import mrx_ref.hybrid as _H
+    monkey = _H.USE_C_BACKTRACK
+    _H.USE_C_BACKTRACK = True
+    try:
+        proven, checked = _generated_chains_body(rng, lib, texts)
+    finally:
+        _H.USE_C_BACKTRACK = monkey
+    assert proven >= 40 and checked > 8000, (proven, checked)
+
+
+def _generated_chains_body(rng, lib, texts):
+    proven = checked = 0
     for _ in range(int(os.environ.get("MRX_CHAIN_FUZZ_N", "170"))):
         pat, repl = _random_chain_with_groups(rng)
         try:
             rx = M.compile_regex(pat)
         except M.RegexSyntaxError:
             continue
+        if " chain=1" not in rx.describe():   # (programs that backtrack are the interpreter's, with its own tests -- and
+            continue                          # quadratic and worse on texts like these, upstream as here)
         for count in (0, 2):
             try:
                 got = rx.sub(repl, texts, count)
@@ -977,7 +993,10 @@ def test_sub_with_groups_on_generated_chains_equals_the_oracle():
                 break
             kernel = lib.mrx_last_kernel_name()
             form = "chain_groups=yes" in rx.describe() and "fixed_total=-1" in rx.describe()   # (fixed-width groups: k_subs_wave)
-            if form:
+            fits = max(len(g) for g in got) <= 4096   # (an output beyond the tile hands the call to the interpreter)
+            if form and not fits:
+                assert kernel == b"k_sub_size", (pat, repl, kernel)
+            elif form:
                 assert kernel == b"k_subc_emit", (pat, repl, kernel)
                 with generic_kernels():
                     assert rx.sub(repl, texts, count) == got, (pat, repl, count)
@@ -995,8 +1014,8 @@ def test_sub_with_groups_on_generated_chains_equals_the_oracle():
                     continue
                 assert g == w, (pat, repl, count, t[:80], g[:80], w[:80], form)
                 checked += 1
-            proven += form
-    assert proven >= 40 and checked > 8000, (proven, checked)
+            proven += form and fits
+    return proven, checked
 
 
 @pytest.mark.parametrize("pat,repl", [(b"[a-z]+\\d+", b"#"), (b"[a-z]+\\d+", b""), (b"\\d", b""), (b"\\d+", b"<NUM>"),

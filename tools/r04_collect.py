@@ -25,7 +25,8 @@ out = ["# The reference's benchmark list on one MI355X (round 4, final build)", 
        "route tuner has settled by then) and timed as a whole.  Boxes differ by 1.3-2x on these short calls, so the `r03`",
        "columns (round 3's table, another box) are a guide, not an A/B; rows whose KERNEL changed are the round-4 work",
        "(`k_mwalk_pieces` where round 3 had `k_req_wave`: the route tuner of `profiles/r04_suite_routes.md`; `sub` rows: no",
-       "host synchronisation in front of the scan or the assembly, `profiles/r04_sub.md`).  All %d cases run; median %.0f GB/s"
+       "host synchronisation in front of the scan or the assembly, `profiles/r04_sub.md`; `sub_group_word_swap`: the chain sub,",
+       "`profiles/r04_sub_chain.md`; `single_quantifier_alpha` re-measured alone).  All %d cases run; median %.0f GB/s"
        % (len(g), statistics.median(g)),
        "(round 3: %.0f), %d above 1 TB/s (%d), %d below 300 GB/s (%d), slowest %.0f GB/s.  findall rows: median %.0f (%.0f),"
        % (statistics.median(g3), sum(1 for x in g if x > 1000), sum(1 for x in g3 if x > 1000), sum(1 for x in g if x < 300),
