@@ -6782,13 +6782,14 @@ int sub_chain_from_spans(const mrx_handle* h, const Layout& lay, int64_t n, cons
   uint8_t *d_mask = nullptr, *d_repl = nullptr;
   HIP_TRY(scratch_alloc((void**)&d_prefix, sizeof(int64_t) * (n + 1), s));
   HIP_TRY(scratch_alloc((void**)&d_sizes, sizeof(int64_t) * n, s));
-  HIP_TRY(scratch_alloc((void**)&d_total, sizeof(int64_t), s));
-  HIP_TRY(scratch_alloc((void**)&d_longest, sizeof(int32_t), s));
+  // (output total, longest output, match total: three words side by side, one copy to the host)
+  HIP_TRY(scratch_alloc((void**)&d_total, 3 * sizeof(int64_t), s));
+  d_longest = (int32_t*)(d_total + 1);
   HIP_TRY(scratch_alloc((void**)&d_mask, 256, s));
   HIP_TRY(scratch_alloc((void**)&d_repl, r.size() + 16, s));
   HIP_TRY(hipMemcpyAsync(d_mask, mask8, 256, hipMemcpyHostToDevice, s));   // (pageable source: copied before the call returns)
   if (!r.empty()) HIP_TRY(hipMemcpyAsync(d_repl, r.data(), r.size(), hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemsetAsync(d_longest, 0, sizeof(int32_t), s));
+  HIP_TRY(hipMemsetAsync(d_total, 0, 3 * sizeof(int64_t), s));
   int64_t cap = in_bytes / 8 + n + 64, nm = 0, tot = 0;
   if (const int64_t seen = h->sub_matches_per_kib.load(std::memory_order_relaxed); seen > 128) {
     const int64_t by_hint = (in_bytes >> 10) * (seen + seen / 8 + 1) + n + 64;
@@ -6799,8 +6800,8 @@ int sub_chain_from_spans(const mrx_handle* h, const Layout& lay, int64_t n, cons
   const int64_t blocks = (n + (kBlock / 64) - 1) / (kBlock / 64);
   const unsigned grid = (unsigned)(blocks < grid_cap() ? blocks : grid_cap());
   int rc = MRX_OK;
-  // (three host synchronisations: the match total, which sizes the spans; the output total and the longest output, which
-  // pick the emit kernel's tile)
+  // (one host synchronisation: the match total, which sizes the spans; the output total and the longest output, which
+  // picks the emit kernel's tile)
   for (int attempt = 0; attempt < 2; ++attempt) {
     HIP_TRY(scratch_alloc((void**)&d_spans, sizeof(int32_t) * 2 * (size_t)cap, s));
     HIP_TRY(scratch_alloc((void**)&d_dcum, sizeof(int32_t) * (size_t)(cap + 1), s));
@@ -6819,10 +6820,11 @@ int sub_chain_from_spans(const mrx_handle* h, const Layout& lay, int64_t n, cons
     HIP_TRY(hipGetLastError());
     rc = device_scan<int64_t>(d_sizes, n, out_off, d_total, s);
     if (rc != MRX_OK) return rc;
-    HIP_TRY(hipMemcpyAsync(&nm, d_prefix + n, sizeof nm, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(&tot, d_total, sizeof tot, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(&longest, d_longest, sizeof longest, hipMemcpyDeviceToHost, s));
+    int64_t h3[3] = {0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(d_total + 2, d_prefix + n, sizeof(int64_t), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(h3, d_total, sizeof h3, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    tot = h3[0]; longest = (int32_t)(h3[1] & 0xFFFFFFFF); nm = h3[2];
     h->sub_matches_per_kib.store(in_bytes >= 1024 ? nm / (in_bytes >> 10) : 0, std::memory_order_relaxed);
     if (nm <= cap) break;
     if (attempt == 1) return fail(MRX_E_NO_DEVICE, "sub: match count changed between two passes");
@@ -6850,7 +6852,6 @@ int sub_chain_from_spans(const mrx_handle* h, const Layout& lay, int64_t n, cons
   HIP_TRY(scratch_free(d_prefix, s));
   HIP_TRY(scratch_free(d_sizes, s));
   HIP_TRY(scratch_free(d_total, s));
-  HIP_TRY(scratch_free(d_longest, s));
   HIP_TRY(scratch_free(d_mask, s));
   HIP_TRY(scratch_free(d_repl, s));
   HIP_TRY(scratch_free(d_spans, s));

@@ -978,7 +978,7 @@ def test_sub_with_groups_on_generated_chains_equals_the_oracle():
 
 def _generated_chains_body(rng, lib, texts):
     proven = checked = 0
-    for _ in range(int(os.environ.get("MRX_CHAIN_FUZZ_N", "170"))):
+    for _ in range(int(os.environ.get("MRX_CHAIN_FUZZ_N", "400"))):
         pat, repl = _random_chain_with_groups(rng)
         try:
             rx = M.compile_regex(pat)
