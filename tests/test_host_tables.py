@@ -208,6 +208,44 @@ def test_chain_groups_form_is_proven_on_the_tables():
     assert verdict("^(\\w+) (\\w+)").startswith("no: "), verdict("^(\\w+) (\\w+)")
 
 
+def test_chain_groups_verdict_implies_the_greedy_leftmost_parse():
+    """Where build_plan says chain_groups=yes, the reference's sub with group templates (the oracle's restatement of
+    NFAEngine.match_next_with_groups, C twin of its backtracker) must be what a leftmost search with ONE greedy parse per
+    start gives -- that is what the spans of the table walk plus runs of the leaves' classes compute on the GPU.  Python's
+    `re` has exactly those semantics on such chains (ASCII classes on bytes patterns), so it stands in for them here:
+    the verdict is checked without a GPU, on generated chains with random groups and templates."""
+    import numpy as np
+    import mrx_ref as O
+    import mrx_ref.hybrid as H
+    from test_gpu_parity import _random_chain_with_groups, _random_texts
+    rng = np.random.default_rng(4242)
+    al = b"abcxyz0123456789 -.@:af"
+    texts = _random_texts(rng, 60, 60, al) + _random_texts(rng, 6, 400, al) + [b"", b"a", b"ab 12", b"hello world foo",
+                                                                              b"aa-bb.cc@dd:ee", b"abc 123 abc 123 " * 20]
+    before = H.USE_C_BACKTRACK
+    H.USE_C_BACKTRACK = True
+    proven = 0
+    try:
+        for _ in range(300):
+            pat, repl = _random_chain_with_groups(rng)
+            try:
+                rx = M.CompiledRegex(pat.decode())
+            except M.RegexSyntaxError:
+                continue
+            if "chain_groups=yes" not in rx.describe() or "fixed_total=-1" not in rx.describe():
+                continue   # (patterns of the fixed-width (\\d{N}) form never take general groups: matcher.mojo:1726-1744)
+            cre = re.compile(pat)
+            # (a reference to a group the pattern lacks is empty upstream, an error in `re`)
+            repl_py = re.sub(rb"\\([1-9])", lambda m: m.group(0) if int(m.group(1)) <= cre.groups else b"", repl)
+            proven += 1
+            for count in (0, 2):
+                for t in texts:
+                    assert O.sub(pat, repl, t, count) == cre.sub(repl_py, t, count), (pat, repl, count, t)
+    finally:
+        H.USE_C_BACKTRACK = before
+    assert proven >= 60, proven
+
+
 def test_fixed_width_group_patterns_that_are_nothing_but_groups():
     """HostPlan::fixed_pure (`device.sub_groups=fixed pure=1`): the pattern is (\\d{N}) / (\\d) groups end to end -- only
     then does every match hold all its group windows and equal the whole-text shortcut of regex.sub
